@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the upstream reference's own modules (lib/modules.py, models/vunets.py and -- behind
+throw-away stub modules for the absent third-party packages -- lib/losses.py,
+models/synth_discriminator.py, models/imagenet_pretrained.py), drives them on seeded synthetic
+inputs / parameters (tests/golden/synth.py) and writes small ``.npz`` fixtures with the expected
+outputs.  The fixtures hold data only (shapes, seeds, inputs' recipe, expected outputs).
+
+    python tests/golden/make_golden.py            # regenerate tests/golden/*.npz
+
+The tests never import the reference; they rebuild inputs from the recipe and compare the oracle
+(oracle/vunet_oracle.py) against the stored outputs.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+REF = os.environ.get("VUNET_REFERENCE", "/root/reference")
+
+from synth import seeded_randn, synth_image, synth_state_dict  # noqa: E402
+
+
+def _install_stubs():
+    """Absent third-party packages that the reference imports at module import time only."""
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return type(k, (), {"__init__": lambda self, *a, **kw: None})
+
+    for name in ["cv2", "kornia", "ignite", "ignite.engine", "ignite.handlers", "ignite.metrics",
+                 "ignite.contrib", "ignite.contrib.handlers", "torch.utils.tensorboard", "torchvision",
+                 "torchvision.utils", "torchvision.models", "torchvision.transforms", "wandb",
+                 "tqdm.autonotebook", "matplotlib.backends.backend_agg"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = _Any(name)
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+from lib import modules as rm  # noqa: E402
+from models import vunets as rv  # noqa: E402
+from lib import losses as rl  # noqa: E402
+from models import synth_discriminator as rd  # noqa: E402
+from models import imagenet_pretrained as rp  # noqa: E402
+
+
+def shapes_of(mod):
+    return {k: list(v.shape) for k, v in mod.state_dict().items()}
+
+
+def load_synth(mod, seed):
+    sh = shapes_of(mod)
+    mod.load_state_dict(synth_state_dict(sh, seed))
+    return sh
+
+
+def npify(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def save(name, meta, arrays):
+    arrays = dict(arrays)
+    arrays["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+class FixedNoise:
+    """Replace torch.randn_like by a recorded, seeded sequence (SURVEY 8c determinism recipe)."""
+
+    def __init__(self, tag, seed):
+        self.tag, self.seed, self.i, self.shapes = tag, seed, 0, []
+
+    def __enter__(self):
+        self._orig = torch.randn_like
+
+        def fake(t, **kw):
+            e = seeded_randn(f"{self.tag}.eps{self.i}", tuple(t.shape), self.seed)
+            self.shapes.append(list(t.shape))
+            self.i += 1
+            return e
+        torch.randn_like = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self._orig
+
+
+# ---------------------------------------------------------------- G1 primitives
+def g1_primitives():
+    seed = 11
+    arrays, meta = {}, {"seed": seed, "cases": {}}
+
+    def run(case, mod, inputs, call):
+        sh = load_synth(mod, seed) if len(list(mod.parameters())) else {}
+        mod.train()
+        ins = [t.clone().requires_grad_(True) for t in inputs]
+        y = call(mod, *ins)
+        wgt = seeded_randn(case + ".wgt", tuple(y.shape), seed)
+        (y * wgt).sum().backward()
+        arrays[case + ".y"] = y.detach().numpy()
+        for i, t in enumerate(ins):
+            arrays[f"{case}.gin{i}"] = t.grad.numpy()
+        for k, p in mod.named_parameters():
+            arrays[f"{case}.gp.{k}"] = p.grad.numpy()
+        meta["cases"][case] = {"shapes": sh, "inputs": [list(t.shape) for t in inputs], "out": list(y.shape)}
+
+    x = lambda case, *s: synth_image(case + ".x", s, seed)  # noqa: E731
+    a = lambda case, *s: synth_image(case + ".a", s, seed)  # noqa: E731
+    run("nc_k3s1", rm.NormConv2d(6, 10, 3, 1, 1), [x("nc_k3s1", 2, 6, 12, 12)], lambda m, t: m(t))
+    run("nc_k1", rm.NormConv2d(3, 8, 1), [x("nc_k1", 2, 3, 16, 16)], lambda m, t: m(t))
+    run("nc_k3valid", rm.NormConv2d(3, 16, 3), [x("nc_k3valid", 2, 3, 10, 10)], lambda m, t: m(t))
+    run("down", rm.Downsample(8, 16), [x("down", 2, 8, 16, 16)], lambda m, t: m(t))
+    run("up", rm.Upsample(8, 4), [x("up", 2, 8, 8, 8)], lambda m, t: m(t))
+    run("rnb_plain", rm.VunetRNB(8), [x("rnb_plain", 2, 8, 12, 12)], lambda m, t: m(t))
+    run("rnb_res", rm.VunetRNB(8, a_channels=8, residual=True),
+        [x("rnb_res", 2, 8, 8, 8), a("rnb_res", 2, 8, 8, 8)], lambda m, t, u: m(t, u))
+    run("rnb_res2", rm.VunetRNB(8, a_channels=16, residual=True),
+        [x("rnb_res2", 2, 8, 4, 4), a("rnb_res2", 2, 16, 4, 4)], lambda m, t, u: m(t, u))
+    run("s2d", rm.SpaceToDepth(2), [x("s2d", 2, 3, 8, 12)], lambda m, t: m(t))
+    run("d2s", rm.DepthToSpace(2), [x("d2s", 2, 12, 4, 6)], lambda m, t: m(t))
+    run("l2nc", rm.L2NormConv2d(6, 8, 3, 1, 1, bias=False), [x("l2nc", 2, 6, 8, 8)], lambda m, t: m(t))
+    run("lnc", rm.LayerNormConv2d(6, 8, 3, 1, 1), [x("lnc", 2, 6, 8, 8)], lambda m, t: m(t))
+    save("g1_primitives", meta, arrays)
+
+
+# ---------------------------------------------------------------- G2 whole models
+ALTER_CFG = dict(spatial_size=32, bottleneck_factor=2, box_factor=2, n_scales=0, n_latent_scales=2,
+                 conv_layer_type="l1", nf_start=8, nf_max=16, subpixel_upsampling=True, dropout_prob=0.0,
+                 # unrelated keys that the reference splats in and must be ignored
+                 dataset="Human3.6m", n_rnb=2, cvae=False, linear_width_factor=1)
+ALTER_BOX_CFG = dict(ALTER_CFG, bottleneck_factor=1, box_factor=1)
+ORG_CFG = dict(ALTER_CFG, nf_start=4, nf_max=8)
+
+
+def model_loss(outs, tag, seed):
+    tot = 0.0
+    flat = []
+    for o in outs:
+        if isinstance(o, (list, tuple)):
+            flat.extend(o)
+        else:
+            flat.append(o)
+    for i, o in enumerate(flat):
+        tot = tot + (o * seeded_randn(f"{tag}.lw{i}", tuple(o.shape), seed)).sum()
+    return tot, flat
+
+
+def g2_models():
+    seed = 21
+    # ---- VunetAlter, 3-channel appearance input
+    for tag, cfg, ncx, xshape in [("alter", ALTER_CFG, 3, (2, 3, 32, 32)),
+                                  ("alter_box", ALTER_BOX_CFG, 6, (2, 6, 16, 16))]:
+        arrays = {}
+        net = rv.VunetAlter(n_channels_x=ncx, **cfg)
+        sh = load_synth(net, seed)
+        net.train()
+        x = synth_image(tag + ".x", xshape, seed).requires_grad_(True)
+        c = synth_image(tag + ".c", (2, 3, 32, 32), seed).requires_grad_(True)
+        with FixedNoise(tag, seed) as fn:
+            img, means, logstds, acts = net(x, c)
+        loss, flat = model_loss([img, means, logstds], tag, seed)
+        loss.backward()
+        arrays["img"] = img.detach().numpy()
+        for i, (m, l) in enumerate(zip(means, logstds)):
+            arrays[f"mean{i}"] = m.detach().numpy()
+            arrays[f"logstd{i}"] = l.detach().numpy()
+        arrays["gx"] = x.grad.numpy()
+        arrays["gc"] = c.grad.numpy()
+        gsum = {}
+        for k, p in net.named_parameters():
+            # parameters behind the discarded ``es`` output of ``ed`` get no gradient (None)
+            gsum[k] = None if p.grad is None else [float(p.grad.double().sum()), float(p.grad.double().abs().sum())]
+        for k in ["eu.nin.conv.weight_v", "eu.blocks.0.conv.gamma", "ed.make_logstds.1.conv.weight_g",
+                  "ed.blocks.1.nin.conv.weight_v", "du.downs.0.down.conv.bias", "dd.ups.0.up.conv.weight_v",
+                  "dd.auto_blocks.1.conv.beta", "dd.out_conv.conv.weight_v"]:
+            arrays["gp." + k] = dict(net.named_parameters())[k].grad.numpy()
+        with FixedNoise(tag + ".tr", seed):
+            net.eval()
+            with torch.no_grad():
+                arrays["transfer"] = net.transfer(x.detach(), c.detach()).numpy()
+        with FixedNoise(tag + ".tf", seed) as fn2:
+            with torch.no_grad():
+                arrays["test_forward"] = net.test_forward(c.detach()).numpy()
+        meta = {"seed": seed, "cfg": cfg, "n_channels_x": ncx, "shapes": sh, "x": list(xshape),
+                "c": [2, 3, 32, 32], "eps_shapes": fn.shapes, "tf_eps_shapes": fn2.shapes,
+                "grad_sums": gsum, "n_params": sum(p.numel() for p in net.parameters())}
+        save("g2_" + tag, meta, arrays)
+
+    # ---- VunetOrg
+    tag, arrays = "org", {}
+    net = rv.VunetOrg(n_channels_x=3, **ORG_CFG)
+    sh = load_synth(net, seed)
+    net.train()
+    x = synth_image(tag + ".x", (2, 3, 32, 32), seed).requires_grad_(True)
+    c = synth_image(tag + ".c", (2, 3, 32, 32), seed).requires_grad_(True)
+    with FixedNoise(tag, seed) as fn:
+        img, qs, ps, acts = net(x, c)
+    loss, flat = model_loss([img, qs, ps], tag, seed)
+    loss.backward()
+    arrays["img"] = img.detach().numpy()
+    for i, (q, p_) in enumerate(zip(qs, ps)):
+        arrays[f"q{i}"] = q.detach().numpy()
+        arrays[f"p{i}"] = p_.detach().numpy()
+    arrays["gx"] = x.grad.numpy()
+    arrays["gc"] = c.grad.numpy()
+    arrays["kl"] = rl.compute_kl_loss(ps, qs).detach().numpy()
+    gsum = {k: (None if p.grad is None else [float(p.grad.double().sum()), float(p.grad.double().abs().sum())])
+            for k, p in net.named_parameters()}
+    meta = {"seed": seed, "cfg": ORG_CFG, "n_channels_x": 3, "shapes": sh, "x": [2, 3, 32, 32],
+            "c": [2, 3, 32, 32], "eps_shapes": fn.shapes, "grad_sums": gsum}
+    save("g2_org", meta, arrays)
+
+    # ---- Regressor (models/vunets.py:786-824)
+    reg = rv.Regressor(n_out=34, n_latent_scales=2, nf_max=16, latent_widths=[8, 4], linear_width_factor=1)
+    sh = load_synth(reg, seed)
+    e0 = seeded_randn("reg.e0", (2, 16, 4, 4), seed)
+    e1 = seeded_randn("reg.e1", (2, 16, 8, 8), seed)
+    out = reg([e0, e1])
+    save("g2_regressor", {"seed": seed, "shapes": sh}, {"out": out.detach().numpy()})
+
+
+# ---------------------------------------------------------------- G3 losses / VGG
+def build_vgg_features(vgg_sd):
+    from torch import nn
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+    layers, cin, idx = [], 3, 0
+    for v in cfg:
+        if v == "M":
+            layers.append(nn.MaxPool2d(2, 2))
+            idx += 1
+        else:
+            cout = vgg_sd[f"features.{idx}.weight"].shape[0]
+            layers += [nn.Conv2d(cin, cout, 3, padding=1), nn.ReLU(inplace=True)]
+            cin = cout
+            idx += 2
+    feats = nn.Sequential(*layers)
+    feats.load_state_dict({k[len("features."):]: v for k, v in vgg_sd.items()})
+
+    class V(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = feats
+    return V()
+
+
+def g3_losses():
+    sys.path.insert(0, ROOT)
+    from oracle.vunet_oracle import make_synthetic_vgg19
+    seed = 31
+    arrays = {}
+    means = [seeded_randn("kl.m0", (3, 16, 4, 4), seed), seeded_randn("kl.m1", (3, 16, 8, 8), seed)]
+    logstds = [torch.sigmoid(seeded_randn("kl.l0", (3, 16, 4, 4), seed)),
+               torch.sigmoid(seeded_randn("kl.l1", (3, 16, 8, 8), seed))]
+    arrays["kl"] = rl.compute_kl_with_prior(means, logstds).numpy()
+    arrays["latent_kl"] = rl.compute_kl_loss([means[0]], [logstds[0]]).numpy()
+
+    # full-width synthetic VGG19 on a 32x32 input: taps of the reference's PerceptualVGG
+    vsd = make_synthetic_vgg19(seed=1234)
+    pv = rp.PerceptualVGG(build_vgg_features(vsd), [1.0, 0.5, 2.0, 1.5, 0.25, 3.0])
+    pv.eval()
+    t = synth_image("vgg.t", (2, 3, 32, 32), seed)
+    p = synth_image("vgg.p", (2, 3, 32, 32), seed).requires_grad_(True)
+    feats = pv(t)
+    for k, v in feats.items():
+        v = v.detach()
+        arrays["tap." + k + ".stats"] = np.array([v.double().mean(), v.double().abs().mean(), v.double().std()])
+        arrays["tap." + k + ".head"] = v.flatten()[:64].numpy()
+    ld = rl.vgg_loss(pv, t, p)
+    tot = torch.stack([ld[k] for k in ld], 0).sum()
+    tot.backward()
+    for k, v in ld.items():
+        arrays["vggloss." + k] = v.detach().numpy()
+    arrays["vggloss.gp"] = p.grad.numpy()
+    save("g3_losses", {"seed": seed, "vgg_seed": 1234, "loss_weights": [1.0, 0.5, 2.0, 1.5, 0.25, 3.0],
+                       "tap_order": list(feats.keys())}, arrays)
+
+
+# ---------------------------------------------------------------- G4 discriminators
+def g4_discriminators():
+    seed = 41
+    arrays, meta = {}, {"seed": seed}
+    pd = rd.PartDiscriminator(n_scales=2, part_size=16)
+    meta["part_shapes"] = load_synth(pd, seed)
+    x = synth_image("pd.x", (2, 3, 18, 18), seed).requires_grad_(True)
+    out = pd(x)
+    reg = rd.compute_grad2(out, x).mean()
+    (out.sum() + 10.0 * reg).backward()
+    arrays["pd.out"] = out.detach().numpy()
+    arrays["pd.reg"] = reg.detach().numpy()
+    arrays["pd.gx"] = x.grad.numpy()
+    meta["pd_grad_sums"] = {k: [float(p.grad.double().sum()), float(p.grad.double().abs().sum())]
+                            for k, p in pd.named_parameters()}
+
+    pg = rd.PatchGANDiscriminator(3, ndf=8, n_layers=3)
+    meta["patch_shapes"] = load_synth(pg, seed)
+    x = synth_image("pg.x", (2, 3, 32, 32), seed).requires_grad_(True)
+    out = pg(x)
+    w = seeded_randn("pg.w", tuple(out.shape), seed)
+    (out * w).sum().backward()
+    arrays["pg.out"] = out.detach().numpy()
+    arrays["pg.gx"] = x.grad.numpy()
+    meta["pg_grad_sums"] = {k: [float(p.grad.double().sum()), float(p.grad.double().abs().sum())]
+                            for k, p in pg.named_parameters()}
+
+    # DiscTrainer: one D step + generator loss (models/synth_discriminator.py:139-206)
+    class Gen(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.last = torch.nn.Conv2d(3, 3, 1)
+    gen = Gen()
+    load_synth(gen, seed)
+    tr = rd.DiscTrainer(gen, {"pd_scales": 2, "adam_beta": (0.5, 0.9), "save_intervall": 10},
+                        spatial_size=64, grad_pen=True, lambda_gp=10, grad_weighting=True)
+    load_synth(tr.disc, seed)
+    tr.init_training([torch.device("cpu")], lr=1e-3)
+    real = synth_image("dt.real", (2, 3, 18, 18), seed)
+    zin = synth_image("dt.z", (2, 3, 18, 18), seed)
+    fake = gen.last(zin)
+    dout = tr.train_disc(real, fake.detach())
+    meta["train_disc"] = dout
+    meta["disc_after"] = {k: [float(v.double().sum()), float(v.double().abs().sum())]
+                          for k, v in tr.disc.state_dict().items()}
+    fake = gen.last(zin)
+    pre = (fake - real).abs().mean()
+    gl, wgt = tr.get_genloss(fake, pre, gen.last.weight)
+    arrays["dt.gen_loss"] = gl.detach().numpy()
+    arrays["dt.loss_weight"] = wgt.detach().numpy()
+    save("g4_discriminators", meta, arrays)
+
+
+# ---------------------------------------------------------------- G5 K-step training trajectory
+def g5_trajectory():
+    from oracle.vunet_oracle import make_synthetic_vgg19
+    seed, K = 51, 3
+    cfg = dict(ALTER_CFG)
+    net = rv.VunetAlter(n_channels_x=3, **cfg)
+    sh = load_synth(net, seed)
+    vsd = make_synthetic_vgg19(seed=77, width_div=8)
+    pv = rp.PerceptualVGG(build_vgg_features(vsd), [1.0] * 6)
+    pv.eval()
+    lr0, betas, gamma_step, imax, n_init, total_steps = 5e-4, (0.5, 0.9), 1e-5, 1000.0, 1, 100
+    opt = torch.optim.Adam([{"params": getattr(net, n).parameters(), "name": n} for n in ["eu", "ed", "du", "dd"]],
+                           lr=lr0, betas=betas)
+    gamma, lr = 0.5, lr0
+    rec = []
+    net.train()
+    for it in range(1, K + 1):
+        x = synth_image(f"traj.x{it}", (2, 3, 32, 32), seed)
+        c = synth_image(f"traj.c{it}", (2, 3, 32, 32), seed)
+        with FixedNoise(f"traj.{it}", seed):
+            img, means, logstds, _ = net(x, c)
+        ld = rl.vgg_loss(pv, x, img)
+        ll = 1.0 * torch.sum(torch.stack([ld[k] for k in ld], dim=0))
+        kl = rl.compute_kl_with_prior(means, logstds)
+        loss = ll
+        if it > n_init:
+            loss = loss + torch.tensor(gamma) * kl
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        gamma = max(gamma - gamma_step * (imax - float(kl)), 0)
+        rec.append({"it": it, "loss": float(loss), "ll": float(ll), "kl": float(kl), "gamma_after": gamma, "lr": lr})
+        lr = float(np.clip(float(0 - lr0) / (total_steps - 0) * (it - 0) + lr0, 0, lr0))
+        for pg_ in opt.param_groups:
+            pg_["lr"] = lr
+    csum = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in net.state_dict().items()}
+    meta = {"seed": seed, "cfg": cfg, "shapes": sh, "vgg_seed": 77, "vgg_width_div": 8, "K": K, "lr0": lr0,
+            "betas": list(betas), "gamma0": 0.5, "gamma_step": gamma_step, "imax": imax, "n_init_batches": n_init,
+            "total_steps": total_steps, "steps": rec, "param_checksums": csum}
+    save("g5_trajectory", meta, {"final.dd.out_conv.conv.weight_v": net.state_dict()["dd.out_conv.conv.weight_v"].numpy()})
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    g1_primitives()
+    g2_models()
+    g3_losses()
+    g4_discriminators()
+    g5_trajectory()

@@ -1,0 +1,213 @@
+"""Pins the CPU oracle (oracle/vunet_oracle.py) to golden vectors produced by the reference itself
+(tests/golden/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from synth import seeded_randn, synth_image, synth_state_dict
+from oracle import vunet_oracle as O
+
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def close(a, b, **kw):
+    tol = dict(TOL)
+    tol.update(kw)
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, **tol)
+
+
+PRIM = {
+    "nc_k3s1": lambda sd, x: O.norm_conv(sd, "", x, 1, 1),
+    "nc_k1": lambda sd, x: O.norm_conv(sd, "", x),
+    "nc_k3valid": lambda sd, x: O.norm_conv(sd, "", x),
+    "down": lambda sd, x: O.downsample(sd, "", x),
+    "up": lambda sd, x: O.upsample(sd, "", x),
+    "rnb_plain": lambda sd, x: O.rnb(sd, "", x),
+    "rnb_res": lambda sd, x, a: O.rnb(sd, "", x, a),
+    "rnb_res2": lambda sd, x, a: O.rnb(sd, "", x, a),
+    "s2d": lambda sd, x: O.space_to_depth(x),
+    "d2s": lambda sd, x: O.depth_to_space(x),
+    "l2nc": lambda sd, x: O.l2norm_conv(sd, "", x, 1, 1),
+    "lnc": lambda sd, x: O.layernorm_conv(sd, "", x, 1, 1),
+}
+
+
+def _prefixed(sd):
+    # oracle functions address parameters as "<prefix>.<leaf>"; primitives use an empty prefix
+    return {"." + k: v for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("case", sorted(PRIM))
+def test_g1_primitives(case):
+    meta, arr = load_golden("g1_primitives")
+    seed, info = meta["seed"], meta["cases"][case]
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(info["shapes"], seed).items()}
+    names = [case + ".x", case + ".a"]
+    ins = [synth_image(names[i], tuple(s), seed).requires_grad_(True) for i, s in enumerate(info["inputs"])]
+    y = PRIM[case](_prefixed(sd), *ins)
+    close(y, arr[case + ".y"])
+    (y * seeded_randn(case + ".wgt", tuple(y.shape), seed)).sum().backward()
+    for i, t in enumerate(ins):
+        close(t.grad, arr[f"{case}.gin{i}"])
+    for k, p in sd.items():
+        close(p.grad, arr[f"{case}.gp.{k}"], rtol=1e-3, atol=1e-4)
+
+
+def _model_loss(outs, tag, seed):
+    flat = []
+    for o in outs:
+        flat.extend(o) if isinstance(o, (list, tuple)) else flat.append(o)
+    return sum((o * seeded_randn(f"{tag}.lw{i}", tuple(o.shape), seed)).sum() for i, o in enumerate(flat))
+
+
+@pytest.mark.parametrize("tag", ["alter", "alter_box"])
+def test_g2_vunet_alter(tag):
+    meta, arr = load_golden("g2_" + tag)
+    seed, cfg, ncx = meta["seed"], meta["cfg"], meta["n_channels_x"]
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(meta["shapes"], seed).items()}
+    assert sum(v.numel() for v in sd.values()) == meta["n_params"]
+    x = synth_image(tag + ".x", tuple(meta["x"]), seed).requires_grad_(True)
+    c = synth_image(tag + ".c", tuple(meta["c"]), seed).requires_grad_(True)
+    eps = [seeded_randn(f"{tag}.eps{i}", tuple(s), seed) for i, s in enumerate(meta["eps_shapes"])]
+    img, means, logstds, _ = O.vunet_alter_forward(sd, cfg, x, c, eps, ncx)
+    close(img, arr["img"], atol=1e-4)
+    for i in range(len(means)):
+        close(means[i], arr[f"mean{i}"], atol=1e-4)
+        close(logstds[i], arr[f"logstd{i}"], atol=1e-4)
+    _model_loss([img, means, logstds], tag, seed).backward()
+    close(x.grad, arr["gx"], rtol=1e-3, atol=1e-4)
+    close(c.grad, arr["gc"], rtol=1e-3, atol=1e-4)
+    for k, v in arr.items():
+        if k.startswith("gp."):
+            close(sd[k[3:]].grad, v, rtol=1e-3, atol=2e-4)
+    for k, s in meta["grad_sums"].items():
+        if s is None:
+            assert sd[k].grad is None or float(sd[k].grad.abs().sum()) == 0.0
+        else:
+            g = sd[k].grad.double()
+            assert abs(float(g.abs().sum()) - s[1]) <= 1e-3 * s[1] + 1e-4, k
+    with torch.no_grad():
+        eps_t = [seeded_randn(f"{tag}.tr.eps{i}", tuple(s), seed) for i, s in enumerate(meta["eps_shapes"])]
+        close(O.vunet_alter_transfer(sd, cfg, x, c, eps_t, ncx), arr["transfer"], atol=1e-4)
+        pe = [seeded_randn(f"{tag}.tf.eps{i}", tuple(s), seed) for i, s in enumerate(meta["tf_eps_shapes"])]
+        close(O.vunet_alter_test_forward(sd, cfg, c, pe), arr["test_forward"], atol=1e-4)
+
+
+def test_g2_vunet_org():
+    tag = "org"
+    meta, arr = load_golden("g2_org")
+    seed, cfg = meta["seed"], meta["cfg"]
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(meta["shapes"], seed).items()}
+    x = synth_image(tag + ".x", tuple(meta["x"]), seed).requires_grad_(True)
+    c = synth_image(tag + ".c", tuple(meta["c"]), seed).requires_grad_(True)
+    shapes = meta["eps_shapes"]
+    n_lat = cfg["n_latent_scales"]
+    eps = [seeded_randn(f"{tag}.eps{i}", tuple(shapes[i]), seed) for i in range(n_lat)]
+    prior = [[seeded_randn(f"{tag}.eps{n_lat + 4 * i + l}", tuple(shapes[n_lat + 4 * i + l]), seed)
+              for l in range(4)] for i in range(n_lat)]
+    img, qs, ps = O.vunet_org_forward(sd, cfg, x, c, eps, prior)
+    close(img, arr["img"], atol=1e-4)
+    for i in range(n_lat):
+        close(qs[i], arr[f"q{i}"], atol=1e-4)
+        close(ps[i], arr[f"p{i}"], atol=1e-4)
+    close(O.compute_kl_loss(ps, qs), arr["kl"], rtol=1e-4)
+    _model_loss([img, qs, ps], tag, seed).backward()
+    close(x.grad, arr["gx"], rtol=1e-3, atol=1e-4)
+    close(c.grad, arr["gc"], rtol=1e-3, atol=1e-4)
+    for k, s in meta["grad_sums"].items():
+        if s is not None:
+            g = sd[k].grad.double()
+            assert abs(float(g.abs().sum()) - s[1]) <= 1e-3 * s[1] + 1e-4, k
+
+
+def test_g2_regressor():
+    meta, arr = load_golden("g2_regressor")
+    sd = synth_state_dict(meta["shapes"], meta["seed"])
+    e0 = seeded_randn("reg.e0", (2, 16, 4, 4), meta["seed"])
+    e1 = seeded_randn("reg.e1", (2, 16, 8, 8), meta["seed"])
+    close(O.regressor(sd, [e0, e1]), arr["out"])
+
+
+def test_g3_losses():
+    meta, arr = load_golden("g3_losses")
+    seed = meta["seed"]
+    means = [seeded_randn("kl.m0", (3, 16, 4, 4), seed), seeded_randn("kl.m1", (3, 16, 8, 8), seed)]
+    logstds = [torch.sigmoid(seeded_randn("kl.l0", (3, 16, 4, 4), seed)),
+               torch.sigmoid(seeded_randn("kl.l1", (3, 16, 8, 8), seed))]
+    close(O.compute_kl_with_prior(means, logstds), arr["kl"], rtol=1e-5)
+    close(O.compute_kl_loss([means[0]], [logstds[0]]), arr["latent_kl"], rtol=1e-5)
+    vsd = O.make_synthetic_vgg19(seed=meta["vgg_seed"])
+    t = synth_image("vgg.t", (2, 3, 32, 32), seed)
+    p = synth_image("vgg.p", (2, 3, 32, 32), seed).requires_grad_(True)
+    feats = O.perceptual_vgg(vsd, t)
+    assert list(feats.keys()) == meta["tap_order"]
+    for k, v in feats.items():
+        v = v.double()
+        close(torch.stack([v.mean(), v.abs().mean(), v.std()]), arr[f"tap.{k}.stats"], rtol=1e-4)
+        close(feats[k].flatten()[:64], arr[f"tap.{k}.head"], rtol=1e-3, atol=1e-4)
+    ld = O.vgg_loss(vsd, meta["loss_weights"], t, p)
+    for k, v in ld.items():
+        close(v, arr["vggloss." + k], rtol=1e-4)
+    torch.stack(list(ld.values()), 0).sum().backward()
+    close(p.grad, arr["vggloss.gp"], rtol=1e-3, atol=1e-6)
+
+
+def test_g4_discriminators():
+    meta, arr = load_golden("g4_discriminators")
+    seed = meta["seed"]
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(meta["part_shapes"], seed).items()}
+    x = synth_image("pd.x", (2, 3, 18, 18), seed).requires_grad_(True)
+    out = O.part_discriminator(sd, x, 2)
+    close(out, arr["pd.out"], atol=1e-4)
+    g = torch.autograd.grad(out.sum(), x, create_graph=True)[0]
+    reg = g.pow(2).reshape(2, -1).sum(1).mean()  # compute_grad2, models/synth_discriminator.py:244-256
+    close(reg, arr["pd.reg"], rtol=1e-3)
+    (out.sum() + 10.0 * reg).backward()
+    close(x.grad, arr["pd.gx"], rtol=2e-3, atol=1e-4)
+    for k, s in meta["pd_grad_sums"].items():
+        assert abs(float(sd[k].grad.double().abs().sum()) - s[1]) <= 2e-3 * s[1] + 1e-4, k
+
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(meta["patch_shapes"], seed).items()}
+    x = synth_image("pg.x", (2, 3, 32, 32), seed).requires_grad_(True)
+    out = O.patchgan_discriminator(sd, x, 3)
+    close(out, arr["pg.out"], atol=1e-4)
+    (out * seeded_randn("pg.w", tuple(out.shape), seed)).sum().backward()
+    close(x.grad, arr["pg.gx"], rtol=2e-3, atol=1e-4)
+    for k, s in meta["pg_grad_sums"].items():
+        assert abs(float(sd[k].grad.double().abs().sum()) - s[1]) <= 2e-3 * s[1] + 1e-4, k
+
+
+def test_g5_trajectory():
+    """K Adam steps of the reference loop's loss assembly (experiments/shape_and_pose_net.py:382-442)."""
+    meta, arr = load_golden("g5_trajectory")
+    seed, cfg = meta["seed"], meta["cfg"]
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(meta["shapes"], seed).items()}
+    vsd = O.make_synthetic_vgg19(seed=meta["vgg_seed"], width_div=meta["vgg_width_div"])
+    groups = [{"params": [v for k, v in sd.items() if k.startswith(n + ".")], "name": n}
+              for n in ["eu", "ed", "du", "dd"]]
+    opt = torch.optim.Adam(groups, lr=meta["lr0"], betas=tuple(meta["betas"]))
+    gamma, lr = meta["gamma0"], meta["lr0"]
+    for rec in meta["steps"]:
+        it = rec["it"]
+        x = synth_image(f"traj.x{it}", (2, 3, 32, 32), seed)
+        c = synth_image(f"traj.c{it}", (2, 3, 32, 32), seed)
+        eps = [seeded_randn(f"traj.{it}.eps{i}", s, seed) for i, s in enumerate([(2, 16, 4, 4), (2, 16, 8, 8)])]
+        loss, ll, kl, _ = O.train_step_losses(sd, cfg, vsd, [1.0] * 6, x, c, x, eps, gamma, it,
+                                              meta["n_init_batches"])
+        assert abs(float(loss) - rec["loss"]) <= 2e-4 * abs(rec["loss"]) + 1e-5
+        assert abs(float(ll) - rec["ll"]) <= 2e-4 * abs(rec["ll"]) + 1e-5
+        assert abs(float(kl) - rec["kl"]) <= 2e-4 * abs(rec["kl"]) + 1e-5
+        assert abs(lr - rec["lr"]) < 1e-12
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        gamma = O.update_gamma(gamma, meta["gamma_step"], meta["imax"], float(kl))
+        assert abs(gamma - rec["gamma_after"]) < 1e-9
+        lr = O.linear_var(it, 0, meta["total_steps"], meta["lr0"], 0, 0, meta["lr0"])
+        for g in opt.param_groups:
+            g["lr"] = lr
+    close(sd["dd.out_conv.conv.weight_v"], arr["final.dd.out_conv.conv.weight_v"], rtol=1e-3, atol=1e-5)
+    for k, s in meta["param_checksums"].items():
+        assert abs(float(sd[k].detach().double().abs().sum()) - s[1]) <= 1e-4 * s[1] + 1e-5, k
