@@ -1,0 +1,201 @@
+// Weight-gradient of the fused convolution on fp32 MFMA (generic geometry).
+//
+//   dW[co][tap][ci] = sum_px dy[co][px] * f(x)[ci][px (+) tap]        (K = pixels)
+//
+// A workgroup owns a (WM*32 output channels) x (all taps x 32 input channels) block of dW and a
+// contiguous range of 32-pixel chunks (split-K over pixels).  Per chunk it stages
+//   dyL[co][33]      -- the dy rows of its output channels (coalesced along pixels)
+//   fxL[tap][ci][33] -- the im2col'ed, prologue-activated input (ELU / dropout applied here)
+// into LDS (row pitch 33 dwords: conflict-free transposed reads), then every wave runs
+// v_mfma_f32_32x32x2_f32 with A = dy (lane: co, k-half: pixel parity) and B = f(x) (lane: ci).
+// Partial results go to per-split slabs (deterministic; summed by vunet_weightnorm_bwd).
+// The per-channel sum of dy (gradient of the folded shift) falls out of the A fragments.
+#include "common.h"
+
+struct WgradArgs {
+  vunet_wgrad_desc d;
+  const float* x1;
+  const float* x2;
+  const float* dy;
+  float* slabs;
+  float* dshift;
+  int NP, HoWo, HsWs, T, Ctot, Coutp, nchunks, cps;
+  InAct in1, in2;
+};
+
+template <int WM, int WN, int NTW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MB = 32 * WM;
+  constexpr int PITCH = 33;
+  float* dyL = smem;                 // [MB][33]
+  float* fxL = smem + MB * PITCH;    // [T*32][33]
+
+  const vunet_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int q = tid & 31, rgrp = tid >> 5;
+
+  const int split = blockIdx.x;
+  const int ci0 = blockIdx.y * 32;
+  const int co0 = blockIdx.z * MB;
+  const int T = a.T;
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float dsum = 0.f;
+
+  const int c_begin = split * a.cps;
+  const int c_end = min(c_begin + a.cps, a.nchunks);
+
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    // ---- this thread's pixel
+    const int P = chunk * 32 + q;
+    const bool pv = P < a.NP;
+    const int Pc = pv ? P : 0;
+    const int n = Pc / a.HoWo;
+    const int rem = Pc - n * a.HoWo;
+    const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+    const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+
+    __syncthreads();  // previous chunk's MFMA reads are done
+    // ---- stage dy rows
+#pragma unroll 4
+    for (int i = 0; i < MB / 8; ++i) {
+      const int col = rgrp + 8 * i, co = co0 + col;
+      float v = 0.f;
+      if (pv && co < d.Cout) v = a.dy[(size_t)(n * d.Cout + co) * a.HoWo + rem];
+      dyL[col * PITCH + q] = v;
+    }
+    // ---- stage im2col'ed activated input rows
+    int kh = 0, kw = 0;
+    for (int tap = 0; tap < T; ++tap) {
+      const int ih = ih0 + kh, iw = iw0 + kw;
+      const bool tv = pv && (unsigned)ih < (unsigned)d.Hs && (unsigned)iw < (unsigned)d.Ws;
+      const int sp = ih * d.Ws + iw;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int cl = rgrp + 8 * ii, ci = ci0 + cl;
+        float v = 0.f;
+        if (tv && ci < a.Ctot) {
+          if (ci < d.C1) {
+            const int off = (n * d.C1 + ci) * a.HsWs + sp;
+            v = apply_in_act(a.in1, a.x1[off], (uint32_t)off);
+          } else {
+            const int off = (n * d.C2 + (ci - d.C1)) * a.HsWs + sp;
+            v = apply_in_act(a.in2, a.x2[off], (uint32_t)off);
+          }
+        }
+        fxL[(tap * 32 + cl) * PITCH + q] = v;
+      }
+      if (++kw == d.KW) { kw = 0; ++kh; }
+    }
+    __syncthreads();
+
+    // ---- MFMA over the 32 pixels of the chunk (16 k-steps of 2)
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const float av = dyL[(wm * 32 + j) * PITCH + 2 * ks + h];
+      dsum += av;
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int nt = wn + WN * i;
+        if (nt < T) {
+          const float bv = fxL[(nt * 32 + j) * PITCH + 2 * ks + h];
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- write the partial slab  [split][Coutp][T*Ctot]
+  const size_t KT = (size_t)T * a.Ctot;
+  float* slab = a.slabs + (size_t)split * a.Coutp * KT;
+  const int ci = ci0 + j;
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int nt = wn + WN * i;
+    if (nt >= T || ci >= a.Ctot) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < d.Cout) slab[(size_t)co * KT + (size_t)nt * a.Ctot + ci] = acc[i][r];
+    }
+  }
+  if (wn == 0 && blockIdx.y == 0) {
+    const float tot = dsum + __shfl_xor(dsum, 32, 64);
+    const int co = co0 + wm * 32 + j;
+    if (h == 0 && co < a.Coutp) a.dshift[(size_t)split * a.Coutp + co] = co < d.Cout ? tot : 0.f;
+  }
+}
+
+static void wgrad_geometry(const vunet_wgrad_desc* d, int& T, int& Ctot, int& Coutp, int& nchunks, int& WM) {
+  T = d->KH * d->KW;
+  Ctot = d->C1 + d->C2;
+  Coutp = (d->Cout + 31) / 32 * 32;
+  const int64_t NP = (int64_t)d->N * d->Ho * d->Wo;
+  nchunks = (int)((NP + 31) / 32);
+  WM = d->Cout > 64 ? 4 : (d->Cout > 32 ? 2 : 1);
+  if (T > 9 && WM == 4) WM = 2;
+}
+
+extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
+  if (!d) return VUNET_ERR_ARG;
+  int T, Ctot, Coutp, nchunks, WM;
+  wgrad_geometry(d, T, Ctot, Coutp, nchunks, WM);
+  const int ciblocks = (Ctot + 31) / 32, coblocks = (d->Cout + 32 * WM - 1) / (32 * WM);
+  int S = 768 / (ciblocks * coblocks);
+  if (S > nchunks / 4) S = nchunks / 4;
+  if (S < 1) S = 1;
+  if (S > 256) S = 256;
+  return S;
+}
+
+template <int WM, int WN, int NTW>
+static int launch_wgrad(const WgradArgs& wa, hipStream_t st) {
+  const int ciblocks = (wa.Ctot + 31) / 32, coblocks = (wa.d.Cout + 32 * WM - 1) / (32 * WM);
+  dim3 grid(wa.d.nsplit, ciblocks, coblocks), block(256);
+  const size_t lds = (size_t)(32 * WM + wa.T * 32) * 33 * sizeof(float);
+  hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, NTW>), grid, block, lds, st, wa);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
+                                  float* slabs, float* dshift, void* stream) {
+  if (!d || !x1 || !dy || !slabs || !dshift) return VUNET_ERR_ARG;
+  if (d->C2 > 0 && !x2) return VUNET_ERR_ARG;
+  if (d->nsplit < 1 || d->KH < 1 || d->KW < 1) return VUNET_ERR_ARG;
+  const int64_t in_elems = (int64_t)d->N * (d->C1 > d->C2 ? d->C1 : d->C2) * d->Hs * d->Ws;
+  const int64_t out_elems = (int64_t)d->N * d->Cout * d->Ho * d->Wo;
+  if (in_elems >= (1ll << 31) || out_elems >= (1ll << 31)) return VUNET_ERR_UNSUPPORTED;
+  WgradArgs wa;
+  wa.d = *d;
+  wa.x1 = x1; wa.x2 = x2; wa.dy = dy; wa.slabs = slabs; wa.dshift = dshift;
+  int WM;
+  wgrad_geometry(d, wa.T, wa.Ctot, wa.Coutp, wa.nchunks, WM);
+  wa.NP = d->N * d->Ho * d->Wo;
+  wa.HoWo = d->Ho * d->Wo;
+  wa.HsWs = d->Hs * d->Ws;
+  wa.cps = (wa.nchunks + d->nsplit - 1) / d->nsplit;
+  wa.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
+  wa.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
+  hipStream_t st = (hipStream_t)stream;
+  const int T = wa.T;
+  if (T > 16) return VUNET_ERR_UNSUPPORTED;
+  if (T == 1) {
+    if (WM == 4) return launch_wgrad<4, 1, 1>(wa, st);
+    if (WM == 2) return launch_wgrad<2, 2, 1>(wa, st);
+    return launch_wgrad<1, 4, 1>(wa, st);
+  }
+  if (T <= 9) {
+    if (WM == 4) return launch_wgrad<4, 1, 9>(wa, st);
+    if (WM == 2) return launch_wgrad<2, 2, 5>(wa, st);
+    return launch_wgrad<1, 4, 3>(wa, st);
+  }
+  if (WM == 2) return launch_wgrad<2, 2, 8>(wa, st);
+  return launch_wgrad<1, 4, 4>(wa, st);
+}

@@ -1,0 +1,414 @@
+// HBM-bound pointwise / index / reduction kernels of the VUnet hot path.
+// Grid-stride loops over <= 2048 blocks (256 CUs x 8), 16-B accesses where the layout allows,
+// wavefront-shuffle reductions (64 lanes) with deterministic two-stage sums.
+#include "common.h"
+
+static inline dim3 ew_grid(int64_t n, int per_thread = 1) {
+  int64_t b = (n + 256ll * per_thread - 1) / (256ll * per_thread);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+#define EW_LOOP(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------ depth/space shuffles
+// out[n,c,2h+i,2w+j] = in[n,(2i+j)*Cq+c,h,w]
+__global__ void d2s_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W) {
+  const int Cq = C >> 2, H2 = 2 * H, W2 = 2 * W;
+  const int64_t total = (int64_t)N * C * H * W;
+  EW_LOOP(o, total) {
+    const int ow = (int)(o % W2);
+    int64_t t = o / W2;
+    const int oh = (int)(t % H2);
+    t /= H2;
+    const int c = (int)(t % Cq), n = (int)(t / Cq);
+    const int blk = ((oh & 1) << 1) | (ow & 1);
+    y[o] = x[(((int64_t)n * C + blk * Cq + c) * H + (oh >> 1)) * W + (ow >> 1)];
+  }
+}
+// out[n,(2i+j)*C+c,h,w] = in[n,c,2h+i,2w+j]     (x: [N,C,H,W], H and W even)
+__global__ void s2d_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W) {
+  const int Hh = H >> 1, Wh = W >> 1, C4 = 4 * C;
+  const int64_t total = (int64_t)N * C * H * W;
+  EW_LOOP(o, total) {
+    const int w = (int)(o % Wh);
+    int64_t t = o / Wh;
+    const int hh = (int)(t % Hh);
+    t /= Hh;
+    const int cc = (int)(t % C4), n = (int)(t / C4);
+    const int blk = cc / C, c = cc - blk * C;
+    y[o] = x[(((int64_t)n * C + c) * H + 2 * hh + (blk >> 1)) * W + 2 * w + (blk & 1)];
+  }
+}
+extern "C" int vunet_depth_to_space(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* st) {
+  if (!x || !y || C % 4) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(d2s_kernel, ew_grid((int64_t)N * C * H * W), dim3(256), 0, (hipStream_t)st, x, y, N, C, H, W);
+  return vunet_check_launch();
+}
+extern "C" int vunet_space_to_depth(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* st) {
+  if (!x || !y || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(s2d_kernel, ew_grid((int64_t)N * C * H * W), dim3(256), 0, (hipStream_t)st, x, y, N, C, H, W);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ simple elementwise
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ yin, float* __restrict__ y,
+                             float a, float b, int64_t n) {
+  EW_LOOP(i, n) y[i] = a * x[i] + (yin ? b * yin[i] : 0.f);
+}
+extern "C" int vunet_axpby(const float* x, const float* y_in, float* y, float a, float b, int64_t n, void* st) {
+  if (!x || !y) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(axpby_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y_in, y, a, b, n);
+  return vunet_check_launch();
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int act, float slope, int64_t n) {
+  EW_LOOP(i, n) {
+    float v = x[i];
+    if (act == ACT_ELU) v = elu_f(v);
+    else if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+    else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+    y[i] = v;
+  }
+}
+extern "C" int vunet_act_fwd(const float* x, float* y, int32_t act, float slope, int64_t n, void* st) {
+  if (!x || !y) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(act_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, act, slope, n);
+  return vunet_check_launch();
+}
+__global__ void act_bwd_out_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                   int act, float slope, int64_t n) {
+  EW_LOOP(i, n) {
+    const float o = y[i];
+    float g = 1.f;
+    if (act == ACT_SIGMOID) g = o * (1.f - o);
+    else if (act == ACT_RELU) g = o > 0.f ? 1.f : 0.f;
+    else if (act == ACT_LRELU) g = o > 0.f ? 1.f : slope;
+    else if (act == ACT_ELU) g = o > 0.f ? 1.f : o + 1.f;
+    dx[i] = dy[i] * g;
+  }
+}
+extern "C" int vunet_act_bwd_from_out(const float* y, const float* dy, float* dx, int32_t act, float slope, int64_t n,
+                                      void* st) {
+  if (!y || !dy || !dx) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(act_bwd_out_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, y, dy, dx, act, slope, n);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ reparametrisation
+__global__ void reparam_fwd_kernel(const float* mu, const float* ls, const float* eps, float* z, int64_t n) {
+  EW_LOOP(i, n) z[i] = eps[i] * __expf(ls[i]) + mu[i];
+}
+__global__ void reparam_bwd_kernel(const float* dz, const float* ls, const float* eps, float* dmu, float* dls,
+                                   int64_t n) {
+  EW_LOOP(i, n) {
+    const float g = dz[i];
+    dmu[i] = g;
+    dls[i] = g * eps[i] * __expf(ls[i]);
+  }
+}
+extern "C" int vunet_reparam_fwd(const float* mu, const float* ls, const float* eps, float* z, int64_t n, void* st) {
+  if (!mu || !ls || !eps || !z) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(reparam_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, ls, eps, z, n);
+  return vunet_check_launch();
+}
+extern "C" int vunet_reparam_bwd(const float* dz, const float* ls, const float* eps, float* dmu, float* dls, int64_t n,
+                                 void* st) {
+  if (!dz || !ls || !eps || !dmu || !dls) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(reparam_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, dz, ls, eps, dmu, dls, n);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ L1 mean (perceptual loss taps)
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ partial, int64_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 u = a4[i], v = b4[i];
+    s += fabsf(u.x - v.x) + fabsf(u.y - v.y) + fabsf(u.z - v.z) + fabsf(u.w - v.w);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += fabsf(a[i] - b[i]);
+  const float t = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void finish_sum_kernel(const float* partial, int nb, float* out, float scale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  const float t = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] += scale * t;
+}
+extern "C" int vunet_l1_mean_fwd(const float* a, const float* b, float* partial, float* out, float weight, int64_t n,
+                                 void* st) {
+  if (!a || !b || !partial || !out || n <= 0) return VUNET_ERR_ARG;
+  if ((((uintptr_t)a) | ((uintptr_t)b)) & 15) return VUNET_ERR_ARG;
+  int64_t nb = (n / 4 + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)st, a, b, partial, n);
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, partial, (int)nb, out,
+                     weight / (float)n);
+  return vunet_check_launch();
+}
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ add,
+                              float* __restrict__ db, float gs, const float* __restrict__ gout, int64_t n) {
+  if (gout) gs *= gout[0];
+  EW_LOOP(i, n) {
+    const float d = b[i] - a[i];
+    const float g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    db[i] = (add ? add[i] : 0.f) + g;
+  }
+}
+extern "C" int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* db, float gscale,
+                                 const float* gout, int64_t n, void* st) {
+  if (!a || !b || !db) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(l1_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, add, db, gscale, gout, n);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ KL / squared-difference (latents: small)
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* mu, const float* ls, float* out, float scale,
+                                                     float offset, int64_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float l = ls[i], m = mu[i], e = __expf(l);
+    s += -l + 0.5f * (e * e + m * m);
+  }
+  const float t = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] += scale * t - offset;
+}
+extern "C" int vunet_kl_fwd(const float* mu, const float* ls, float* out, float weight, int32_t N, int64_t D, void* st) {
+  if (!mu || !ls || !out || N <= 0) return VUNET_ERR_ARG;
+  // weight * ( (1/N) sum_all(...) - 0.5 D )
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, mu, ls, out, weight / (float)N,
+                     weight * 0.5f * (float)D, (int64_t)N * D);
+  return vunet_check_launch();
+}
+__global__ void kl_bwd_kernel(const float* mu, const float* ls, float* dmu, float* dls, float gs, const float* gout,
+                              int64_t n) {
+  if (gout) gs *= gout[0];
+  EW_LOOP(i, n) {
+    const float e = __expf(ls[i]);
+    dmu[i] = gs * mu[i];
+    dls[i] = gs * (e * e - 1.f);
+  }
+}
+extern "C" int vunet_kl_bwd(const float* mu, const float* ls, float* dmu, float* dls, float gscale, const float* gout,
+                            int64_t n, void* st) {
+  if (!mu || !ls || !dmu || !dls) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(kl_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, ls, dmu, dls, gscale, gout, n);
+  return vunet_check_launch();
+}
+__global__ __launch_bounds__(256) void sqdiff_fwd_kernel(const float* p, const float* q, float* out, float scale,
+                                                         int64_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float d = p[i] - q[i];
+    s += 0.5f * d * d;
+  }
+  const float t = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] += scale * t;
+}
+extern "C" int vunet_sqdiff_fwd(const float* p, const float* q, float* out, float weight, int32_t N, int64_t D, void* st) {
+  if (!p || !q || !out || N <= 0) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(sqdiff_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, p, q, out, weight / (float)N,
+                     (int64_t)N * D);
+  return vunet_check_launch();
+}
+__global__ void sqdiff_bwd_kernel(const float* p, const float* q, float* dp, float* dq, float gs, const float* gout,
+                                  int64_t n) {
+  if (gout) gs *= gout[0];
+  EW_LOOP(i, n) {
+    const float d = gs * (p[i] - q[i]);
+    if (dp) dp[i] = d;
+    if (dq) dq[i] = -d;
+  }
+}
+extern "C" int vunet_sqdiff_bwd(const float* p, const float* q, float* dp, float* dq, float gscale, const float* gout,
+                                int64_t n, void* st) {
+  if (!p || !q) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(sqdiff_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, p, q, dp, dq, gscale, gout, n);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ VGG input affine, max-pool
+__global__ void vgg_pre_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int64_t n) {
+  EW_LOOP(i, n) {
+    const int c = (int)((i / HW) % 3);
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+    const float std = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    y[i] = ((x[i] + 1.0f) / 2.0f - mean) / std;
+  }
+}
+extern "C" int vunet_vgg_preprocess(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* st) {
+  if (!x || !y) return VUNET_ERR_ARG;
+  const int64_t n = (int64_t)N * 3 * H * W;
+  hipLaunchKernelGGL(vgg_pre_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H * W, n);
+  return vunet_check_launch();
+}
+__global__ void vgg_pre_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dx,
+                                   int HW, int64_t n) {
+  EW_LOOP(i, n) {
+    const int c = (int)((i / HW) % 3);
+    const float std = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    dx[i] = (add ? add[i] : 0.f) + dy[i] * (0.5f / std);
+  }
+}
+extern "C" int vunet_vgg_preprocess_bwd(const float* dy, const float* add, float* dx, int32_t N, int32_t H, int32_t W,
+                                        void* st) {
+  if (!dy || !dx) return VUNET_ERR_ARG;
+  const int64_t n = (int64_t)N * 3 * H * W;
+  hipLaunchKernelGGL(vgg_pre_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, dy, add, dx, H * W, n);
+  return vunet_check_launch();
+}
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int64_t n) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  EW_LOOP(o, n) {
+    const int ow = (int)(o % Wo);
+    const int64_t t = o / Wo;
+    const int oh = (int)(t % Ho);
+    const int64_t nc = t / Ho;
+    const float* r0 = x + (nc * H + 2 * oh) * W + 2 * ow;
+    const float2 a = *reinterpret_cast<const float2*>(r0);
+    const float2 b = *reinterpret_cast<const float2*>(r0 + W);
+    y[o] = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, b.y));
+  }
+}
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                    const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int64_t n) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  EW_LOOP(o, n) {
+    const int ow = (int)(o % Wo);
+    const int64_t t = o / Wo;
+    const int oh = (int)(t % Ho);
+    const int64_t nc = t / Ho;
+    const int64_t i0 = (nc * H + 2 * oh) * W + 2 * ow;
+    const float m = y[o], g = dy[o];
+    const float2 a = *reinterpret_cast<const float2*>(x + i0);
+    const float2 b = *reinterpret_cast<const float2*>(x + i0 + W);
+    // first maximum in window scan order gets the gradient (ATen max_pool2d semantics)
+    const int k = a.x == m ? 0 : (a.y == m ? 1 : (b.x == m ? 2 : 3));
+    *reinterpret_cast<float2*>(dx + i0) = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
+    *reinterpret_cast<float2*>(dx + i0 + W) = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+  }
+}
+extern "C" int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t H, int32_t W, void* st) {
+  if (!x || !y || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
+  const int64_t n = (int64_t)NC * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H, W, n);
+  return vunet_check_launch();
+}
+extern "C" int vunet_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H,
+                                  int32_t W, void* st) {
+  if (!x || !y || !dy || !dx || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
+  const int64_t n = (int64_t)NC * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, dy, dx, H, W, n);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ InstanceNorm2d (affine=False)
+// one workgroup per (n,c) plane; two passes over the plane (L2-resident), wavefront-shuffle sums
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           float* __restrict__ stats, int HW, float eps) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * HW;
+  float* yr = y + (size_t)blockIdx.x * HW;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) s += xr[i];
+  const float mean = block_sum_256(s, red) / (float)HW;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) { const float d = xr[i] - mean; v += d * d; }
+  const float var = block_sum_256(v, red) / (float)HW;
+  const float rstd = rsqrtf(var + eps);
+  for (int i = threadIdx.x; i < HW; i += 256) yr[i] = (xr[i] - mean) * rstd;
+  if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+}
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                           const float* __restrict__ stats, float* __restrict__ dx,
+                                                           int HW) {
+  __shared__ float red[4];
+  const size_t o = (size_t)blockIdx.x * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) { const float g = dy[o + i]; s1 += g; s2 += g * y[o + i]; }
+  const float m1 = block_sum_256(s1, red) / (float)HW;
+  const float m2 = block_sum_256(s2, red) / (float)HW;
+  const float rstd = stats[2 * blockIdx.x + 1];
+  for (int i = threadIdx.x; i < HW; i += 256) dx[o + i] = rstd * (dy[o + i] - m1 - y[o + i] * m2);
+}
+extern "C" int vunet_instnorm_fwd(const float* x, float* y, float* stats, int32_t NC, int32_t HW, float eps, void* st) {
+  if (!x || !y || !stats || NC <= 0 || HW <= 0) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)st, x, y, stats, HW, eps);
+  return vunet_check_launch();
+}
+extern "C" int vunet_instnorm_bwd(const float* y, const float* dy, const float* stats, float* dx, int32_t NC,
+                                  int32_t HW, void* st) {
+  if (!y || !dy || !stats || !dx) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)st, y, dy, stats, dx, HW);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ fused Adam over a flat buffer
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float step_size, float b1, float b2, float eps,
+                            float wd, float inv_sqrt_bc2, float gscale) {
+  EW_LOOP(i, n) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+extern "C" int vunet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                               float grad_scale, void* st) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return VUNET_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, param, grad, exp_avg, exp_avg_sq, n,
+                     (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ misc
+__global__ void dropout_mask_kernel(float* mask, int64_t n, uint32_t thresh, uint32_t seed) {
+  EW_LOOP(i, n) mask[i] = vunet_hash_u32((uint32_t)i + seed) >= thresh ? 1.f : 0.f;
+}
+extern "C" int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* st) {
+  if (!mask) return VUNET_ERR_ARG;
+  const InAct a = make_inact(ACT_NONE, 0.f, p, seed);
+  hipLaunchKernelGGL(dropout_mask_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mask, n, a.thresh, seed);
+  return vunet_check_launch();
+}
+__global__ void u8_to_unit_kernel(const uint8_t* in, float* out, int64_t n) {
+  EW_LOOP(i, n) out[i] = ((float)in[i] / 255.0f) * 2.0f - 1.0f;
+}
+extern "C" int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* st) {
+  if (!in || !out) return VUNET_ERR_ARG;
+  hipLaunchKernelGGL(u8_to_unit_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, in, out, n);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_abi_version(void) { return 1; }

@@ -1,0 +1,178 @@
+// Weight normalisation folded with NormConv2d's learned affine, and its backward.
+//
+//   scale[co] = gamma[co] * g[co] / ||v[co]||_2        shift[co] = gamma[co]*bias[co] + beta[co]
+//   w_eff[co][ci][tap] = scale[co] * v[co][ci][tap]
+//
+// vunet_weightnorm_fwd packs w_eff into the two K-major matrices the MFMA conv kernels read
+// (forward: rows (source, tap, ci) x cols co ; data-gradient: rows (tap, co) x cols ci).
+// vunet_weightnorm_bwd reduces the split-K slabs of vunet_conv2d_wgrad (deterministic order) and
+// turns dL/dw_eff, dL/dshift into the gradients of v, g, bias, gamma, beta.
+// Reductions are wavefront shuffles (64 lanes) + one LDS hop.
+#include "common.h"
+
+struct WnArgs {
+  vunet_wn_desc d;
+  const float *v, *g, *bias, *gamma, *beta;
+  float *wt_f, *wt_d, *scale, *shift, *invnorm;
+  int T, Ctot, C1p, C2p, Kf, Mpad_f, Coutp2, Kd, Mpad_d;
+};
+
+__global__ __launch_bounds__(64) void wn_scale_kernel(const WnArgs a) {
+  const int co = blockIdx.x, lane = threadIdx.x;
+  const int K = a.Ctot * a.T;
+  const float* vr = a.v + (size_t)co * K;
+  float invn = 1.f, scale = 1.f;
+  if (a.d.kind != 1) {
+    float ss = 0.f;
+    for (int k = lane; k < K; k += 64) { const float t = vr[k]; ss += t * t; }
+    ss = wave_sum(ss);
+    float nrm = sqrtf(ss);
+    if (a.d.kind == 2) nrm = fmaxf(nrm, 1e-12f);
+    invn = 1.f / nrm;
+    const float gm = a.gamma ? a.gamma[co] : 1.f;
+    scale = a.d.kind == 0 ? gm * a.g[co] * invn : gm * invn;
+  }
+  if (lane == 0) {
+    const float gm = (a.d.kind != 1 && a.gamma) ? a.gamma[co] : 1.f;
+    const float b = a.bias ? a.bias[co] : 0.f;
+    const float be = (a.d.kind != 1 && a.beta) ? a.beta[co] : 0.f;
+    a.scale[co] = scale;
+    a.invnorm[co] = invn;
+    a.shift[co] = gm * b + be;
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_pack_kernel(const WnArgs a) {
+  const size_t nf = (size_t)a.Kf * a.Mpad_f;
+  const size_t nd = a.wt_d ? (size_t)a.Kd * a.Mpad_d : 0;
+  const int T = a.T;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += (size_t)gridDim.x * 256) {
+    if (i < nf) {
+      const int krow = (int)(i / a.Mpad_f), m = (int)(i - (size_t)krow * a.Mpad_f);
+      int tap, c, cg;
+      bool ok;
+      const int k1 = T * a.C1p;
+      if (krow < k1) { tap = krow / a.C1p; c = krow - tap * a.C1p; ok = c < a.d.C1; cg = c; }
+      else { const int r = krow - k1; tap = r / a.C2p; c = r - tap * a.C2p; ok = c < a.d.C2; cg = a.d.C1 + c; }
+      float w = 0.f;
+      if (ok && m < a.d.Cout) w = a.scale[m] * a.v[((size_t)m * a.Ctot + cg) * T + tap];
+      a.wt_f[i] = w;
+    } else {
+      const size_t e = i - nf;
+      const int row = (int)(e / a.Mpad_d), ci = (int)(e - (size_t)row * a.Mpad_d);
+      const int tap = row / a.Coutp2, co = row - tap * a.Coutp2;
+      float w = 0.f;
+      if (co < a.d.Cout && ci < a.Ctot) w = a.scale[co] * a.v[((size_t)co * a.Ctot + ci) * T + tap];
+      a.wt_d[e] = w;
+    }
+  }
+}
+
+static void wn_geometry(const vunet_wn_desc* d, WnArgs& a) {
+  a.T = d->KH * d->KW;
+  a.Ctot = d->C1 + d->C2;
+  a.C1p = (d->C1 + 1) & ~1;
+  a.C2p = (d->C2 + 1) & ~1;
+  a.Kf = a.T * (a.C1p + a.C2p);
+  a.Mpad_f = (d->Cout + 31) / 32 * 32;
+  a.Coutp2 = (d->Cout + 1) & ~1;
+  a.Kd = a.T * a.Coutp2;
+  a.Mpad_d = (a.Ctot + 31) / 32 * 32;
+}
+
+extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g, const float* bias,
+                                    const float* gamma, const float* beta, float* wt_f, float* wt_d, float* scale,
+                                    float* shift, float* invnorm, void* stream) {
+  if (!d || !v || !wt_f || !scale || !shift || !invnorm) return VUNET_ERR_ARG;
+  if (d->kind == 0 && !g) return VUNET_ERR_ARG;
+  if (d->Cout < 1 || d->C1 < 1 || d->C2 < 0) return VUNET_ERR_ARG;
+  WnArgs a;
+  a.d = *d;
+  a.v = v; a.g = g; a.bias = bias; a.gamma = gamma; a.beta = beta;
+  a.wt_f = wt_f; a.wt_d = wt_d; a.scale = scale; a.shift = shift; a.invnorm = invnorm;
+  wn_geometry(d, a);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wn_scale_kernel, dim3(d->Cout), dim3(64), 0, st, a);
+  const size_t n = (size_t)a.Kf * a.Mpad_f + (wt_d ? (size_t)a.Kd * a.Mpad_d : 0);
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wn_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  return vunet_check_launch();
+}
+
+struct WnBwdArgs {
+  vunet_wn_desc d;
+  const float *slabs, *dshift, *v, *g, *bias, *gamma, *invnorm;
+  float *dv, *dg, *dbias, *dgamma, *dbeta;
+  int nsplit, T, Ctot, Coutp;
+};
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* dWs = sm;  // [K]
+  __shared__ float red[4];
+  const int co = blockIdx.x, tid = threadIdx.x;
+  const int T = a.T, Ctot = a.Ctot, K = T * Ctot;
+  const float* vr = a.v + (size_t)co * K;
+  float dot = 0.f;
+  for (int k = tid; k < K; k += 256) {
+    // slab k order is (tap, ci); v order is (ci, tap)
+    float dw = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) dw += a.slabs[((size_t)s * a.Coutp + co) * K + k];
+    const int tap = k / Ctot, ci = k - tap * Ctot;
+    dWs[k] = dw;
+    dot += dw * vr[ci * T + tap];
+  }
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  const float D = red[0] + red[1] + red[2] + red[3];
+  float dsh = 0.f;
+  for (int s = 0; s < a.nsplit; ++s) dsh += a.dshift[(size_t)s * a.Coutp + co];
+
+  const int kind = a.d.kind;
+  const float invn = kind == 1 ? 1.f : a.invnorm[co];
+  const float gm = (kind != 1 && a.gamma) ? a.gamma[co] : 1.f;
+  const float gg = kind == 0 ? a.g[co] : 1.f;
+  const float b = a.bias ? a.bias[co] : 0.f;
+  if (tid == 0) {
+    if (kind == 1) {
+      if (a.dbias) a.dbias[co] = dsh;
+    } else {
+      if (a.dgamma) a.dgamma[co] = gg * invn * D + b * dsh;
+      if (a.dbeta) a.dbeta[co] = dsh;
+      if (a.dbias) a.dbias[co] = gm * dsh;
+      if (a.dg && kind == 0) a.dg[co] = gm * invn * D;
+    }
+  }
+  if (a.dv) {
+    const float c0 = gm * gg * invn, c1 = invn * invn * D;
+    float* dvr = a.dv + (size_t)co * K;
+    for (int k = tid; k < K; k += 256) {
+      const int ci = k / T, tap = k - ci * T;  // v order
+      const float dw = dWs[tap * Ctot + ci];
+      dvr[k] = kind == 1 ? dw : c0 * (dw - c1 * vr[k]);
+    }
+  }
+}
+
+extern "C" int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float* dshift, int32_t nsplit,
+                                    const float* v, const float* g, const float* bias, const float* gamma,
+                                    const float* invnorm, float* dv, float* dg, float* dbias, float* dgamma,
+                                    float* dbeta, void* stream) {
+  if (!d || !slabs || !dshift || !v || nsplit < 1) return VUNET_ERR_ARG;
+  if (d->kind != 1 && !invnorm) return VUNET_ERR_ARG;
+  if (d->kind == 0 && !g) return VUNET_ERR_ARG;
+  WnBwdArgs a;
+  a.d = *d;
+  a.slabs = slabs; a.dshift = dshift; a.v = v; a.g = g; a.bias = bias; a.gamma = gamma; a.invnorm = invnorm;
+  a.dv = dv; a.dg = dg; a.dbias = dbias; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.nsplit = nsplit;
+  a.T = d->KH * d->KW;
+  a.Ctot = d->C1 + d->C2;
+  a.Coutp = (d->Cout + 31) / 32 * 32;
+  const size_t lds = (size_t)a.T * a.Ctot * sizeof(float);
+  if (lds > 60 * 1024) return VUNET_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(d->Cout), dim3(256), lds, (hipStream_t)stream, a);
+  return vunet_check_launch();
+}

@@ -1,0 +1,298 @@
+"""MI355X-native counterparts of the reference's ``lib/modules.py`` (lines 11-233).
+
+Same class names, constructor signatures, state-dict keys and forward semantics as the reference
+(citations are ``lib/modules.py:<line>`` of CompVis/behavior-driven-video-synthesis), but every
+forward/backward is a hand-written gfx950 kernel reached through the C-ABI library
+(``include/vunet_hip.h``).  What the reference issues as separate ATen ops -- weight-norm, conv,
+``gamma*y+beta``, ELU, dropout, ``torch.cat``, the residual add, DepthToSpace -- is one fused
+implicit-GEMM launch here (``ops.fused_conv``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Union
+
+import torch
+from torch import nn
+
+from .. import ops
+
+TensorOrPair = Union[torch.Tensor, Sequence[torch.Tensor]]
+
+
+def _act_code(act_fn) -> tuple:
+    """nn activation module -> (kernel activation code, slope)."""
+    if act_fn is None or isinstance(act_fn, IDAct):
+        return ops.ACT_NONE, 0.0
+    if isinstance(act_fn, nn.ELU):
+        if act_fn.alpha != 1.0:
+            raise NotImplementedError("only ELU(alpha=1) is implemented in the HIP prologue")
+        return ops.ACT_ELU, 0.0
+    if isinstance(act_fn, nn.ReLU):
+        return ops.ACT_RELU, 0.0
+    if isinstance(act_fn, nn.LeakyReLU):
+        return ops.ACT_LRELU, float(act_fn.negative_slope)
+    raise NotImplementedError(f"activation {type(act_fn).__name__} has no HIP prologue")
+
+
+def _split(x: TensorOrPair):
+    if isinstance(x, (tuple, list)):
+        assert len(x) == 2
+        return x[0], x[1]
+    return x, None
+
+
+class SpaceToDepth(nn.Module):
+    """lib/modules.py:11-21 (block-major channel order)."""
+
+    def __init__(self, block_size):
+        super().__init__()
+        assert block_size == 2
+        self.bs = block_size
+
+    def forward(self, x):
+        return ops.SpaceToDepth.apply(x)
+
+
+class DepthToSpace(nn.Module):
+    """lib/modules.py:24-34 (block-major channel order, not pixel_shuffle)."""
+
+    def __init__(self, block_size):
+        super().__init__()
+        assert block_size == 2
+        self.bs = block_size
+
+    def forward(self, x):
+        return ops.DepthToSpace.apply(x)
+
+
+class IDAct(nn.Module):
+    """lib/modules.py:37-39."""
+
+    def forward(self, input):
+        return input
+
+
+class _WeightNormConvParams(nn.Module):
+    """Parameter holder with the key names of ``weight_norm(nn.Conv2d)``: bias, weight_g, weight_v."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = (kernel_size, kernel_size), (stride, stride), (padding, padding)
+        w = torch.empty(out_channels, in_channels, kernel_size, kernel_size)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))  # nn.Conv2d.reset_parameters
+        bound = 1.0 / math.sqrt(in_channels * kernel_size * kernel_size)
+        self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, 1, 1, 1).clone())  # g = ||v|| at init
+        self.weight_v = nn.Parameter(w)
+
+
+class NormConv2d(nn.Module):
+    """lib/modules.py:120-145: ``gamma * conv(x; g v/||v||, b) + beta``.
+
+    ``forward(x)`` is the reference call.  ``fused`` exposes the prologue/epilogue hooks the
+    surrounding modules use (second source instead of torch.cat, pre-activation, dropout, residual,
+    sub-pixel store).
+    """
+
+    kind = 0
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.beta = nn.Parameter(torch.zeros([1, out_channels, 1, 1], dtype=torch.float32))
+        self.gamma = nn.Parameter(torch.ones([1, out_channels, 1, 1], dtype=torch.float32))
+        self.conv = _WeightNormConvParams(in_channels, out_channels, kernel_size, stride, padding)
+        self.k, self.stride, self.padding = kernel_size, stride, padding
+
+    def _params(self):
+        return self.conv.weight_v, self.conv.weight_g, self.conv.bias, self.gamma, self.beta
+
+    def fused(self, x: TensorOrPair, res: Optional[torch.Tensor] = None, in_act: int = ops.ACT_NONE,
+              in_slope: float = 0.0, drop_p: float = 0.0, out_act: int = ops.ACT_NONE, d2s: bool = False):
+        x1, x2 = _split(x)
+        cfg = ops.ConvCfg(kind=self.kind, k=self.k, stride=self.stride, pad=self.padding, in_act=in_act,
+                          in_slope=in_slope, drop_p=drop_p, drop_seed=ops.next_dropout_seed() if drop_p > 0 else 0,
+                          out_act=out_act, d2s=d2s)
+        v, g, b, gamma, beta = self._params()
+        return ops.fused_conv(x1, x2, res, v, g, b, gamma, beta, cfg)
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+class L2NormConv2d(nn.Module):
+    """lib/modules.py:42-101 (``conv_layer_type: l2``), including the data-dependent init (:95-99)."""
+
+    kind = 2
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, init=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.k = kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size).normal_(0.0, 0.05))
+        if bias:
+            bound = 1 / math.sqrt(in_channels * kernel_size * kernel_size)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.bias = None
+        self.beta = nn.Parameter(torch.zeros([1, out_channels, 1, 1], dtype=torch.float32))
+        self.gamma = nn.Parameter(torch.ones([1, out_channels, 1, 1], dtype=torch.float32))
+        self.init_fn = init if callable(init) else (lambda: False)
+
+    def _params(self):
+        return self.weight, None, self.bias, self.gamma, self.beta
+
+    def fused(self, x: TensorOrPair, res=None, in_act=ops.ACT_NONE, in_slope=0.0, drop_p=0.0, out_act=ops.ACT_NONE,
+              d2s=False):
+        x1, x2 = _split(x)
+        if self.init_fn() and self.training:
+            # lib/modules.py:95-99: set gamma/beta from the batch statistics of the normalised conv output
+            with torch.no_grad():
+                cfg0 = ops.ConvCfg(kind=2, k=self.k, stride=self.stride, pad=self.padding, in_act=in_act,
+                                   in_slope=in_slope)
+                ones, zeros = torch.ones_like(self.gamma), torch.zeros_like(self.beta)
+                y0 = ops.fused_conv(x1, x2, None, self.weight, None, self.bias, ones, zeros, cfg0)
+                mean = y0.mean(dim=[0, 2, 3], keepdim=True)
+                var = y0.var(dim=[0, 2, 3], keepdim=True)
+                self.gamma.data = 1.0 / torch.sqrt(var + 1e-10)
+                self.beta.data = -mean * self.gamma
+        cfg = ops.ConvCfg(kind=2, k=self.k, stride=self.stride, pad=self.padding, in_act=in_act, in_slope=in_slope,
+                          drop_p=drop_p, drop_seed=ops.next_dropout_seed() if drop_p > 0 else 0, out_act=out_act,
+                          d2s=d2s)
+        v, g, b, gamma, beta = self._params()
+        return ops.fused_conv(x1, x2, res, v, g, b, gamma, beta, cfg)
+
+    def forward(self, x, it=None):
+        return self.fused(x)
+
+
+class _PlainConvParams(nn.Module):
+    """Parameter holder with nn.Conv2d's key names (weight, bias)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.k, self.stride, self.padding = kernel_size, stride, padding
+        w = torch.empty(out_channels, in_channels, kernel_size, kernel_size)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w)
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels * kernel_size * kernel_size)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+    def fused(self, x: TensorOrPair, res=None, in_act=ops.ACT_NONE, in_slope=0.0, drop_p=0.0, out_act=ops.ACT_NONE,
+              d2s=False):
+        x1, x2 = _split(x)
+        cfg = ops.ConvCfg(kind=1, k=self.k, stride=self.stride, pad=self.padding, in_act=in_act, in_slope=in_slope,
+                          drop_p=drop_p, drop_seed=ops.next_dropout_seed() if drop_p > 0 else 0, out_act=out_act,
+                          d2s=d2s)
+        return ops.fused_conv(x1, x2, res, self.weight, None, self.bias, None, None, cfg)
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+class Conv2d(_PlainConvParams):
+    """Drop-in for the plain ``nn.Conv2d`` layers of the path (PatchGAN, VGG19, Regressor)."""
+
+
+class LayerNormConv2d(nn.Module):
+    """lib/modules.py:104-117: plain conv followed by InstanceNorm2d (affine=False, eps=1e-5)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.conv = _PlainConvParams(in_channels, out_channels, kernel_size, stride, padding)
+        self.norm = InstanceNorm2d(out_channels)
+
+    def fused(self, x: TensorOrPair, res=None, in_act=ops.ACT_NONE, in_slope=0.0, drop_p=0.0, out_act=ops.ACT_NONE,
+              d2s=False):
+        y = self.norm(self.conv.fused(x, None, in_act, in_slope, drop_p))
+        if out_act != ops.ACT_NONE:
+            y = ops.Activation.apply(y, out_act, in_slope)
+        if d2s:
+            y = ops.DepthToSpace.apply(y)
+        if res is not None:
+            y = y + res
+        return y
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(affine=False, track_running_stats=False) on the wavefront-shuffle kernel."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+
+    def forward(self, x):
+        return ops.InstanceNorm.apply(x, self.eps)
+
+
+class Downsample(nn.Module):
+    """lib/modules.py:148-161: 3x3 stride-2 conv."""
+
+    def __init__(self, channels, out_channels=None, conv_layer=NormConv2d):
+        super().__init__()
+        self.down = conv_layer(channels, channels if out_channels is None else out_channels, kernel_size=3,
+                               stride=2, padding=1)
+
+    def forward(self, x):
+        return self.down(x)
+
+
+class Upsample(nn.Module):
+    """lib/modules.py:164-182.  Sub-pixel branch: the DepthToSpace is the conv's store addressing."""
+
+    def __init__(self, in_channels, out_channels, subpixel=True, conv_layer=NormConv2d):
+        super().__init__()
+        self.subpixel = subpixel
+        if subpixel:
+            self.up = conv_layer(in_channels, 4 * out_channels, 3, padding=1)
+            self.op2 = DepthToSpace(block_size=2)
+        else:
+            # lib/modules.py:172-175 (unreachable with subpixel_upsampling: True, the only shipped setting)
+            raise NotImplementedError("bilinear Upsample branch is not part of the MI355X hot path")
+
+    def forward(self, x):
+        return self.up.fused(x, d2s=True)
+
+
+class VunetRNB(nn.Module):
+    """lib/modules.py:185-233.
+
+    ``out = x + conv3x3(dropout(act(cat(x, nin(act(a))))))`` as two fused launches: the 1x1 ``nin``
+    with the activation as prologue, and the 3x3 conv reading (x, nin-out) as two sources with
+    activation+dropout as prologue and ``+ x`` as epilogue.  ``a`` may be a pair of tensors, which
+    is read as their channel concatenation (models/vunets.py:583 builds that concat).
+    """
+
+    def __init__(self, channels, a_channels=None, residual=False, kernel_size=3, activate=True,
+                 conv_layer=NormConv2d, act_fn=None, dropout_prob=0.0):
+        super().__init__()
+        self.residual = residual
+        self.dout = nn.Dropout(p=dropout_prob)
+        if self.residual:
+            assert a_channels is not None
+            self.nin = conv_layer(a_channels, channels, kernel_size=1)
+        if activate:
+            self.act_fn = nn.ELU() if act_fn is None else act_fn
+        else:
+            self.act_fn = IDAct()
+        in_c = 2 * channels if self.residual else channels
+        self.conv = conv_layer(in_channels=in_c, out_channels=channels, kernel_size=kernel_size,
+                               padding=kernel_size // 2)
+
+    def forward(self, x, a: Optional[TensorOrPair] = None):
+        act, slope = _act_code(self.act_fn)
+        p = self.dout.p if self.training else 0.0
+        if a is not None:
+            assert self.residual
+            a = self.nin.fused(a, in_act=act, in_slope=slope)
+            return self.conv.fused((x, a), res=x, in_act=act, in_slope=slope, drop_p=p)
+        return self.conv.fused(x, res=x, in_act=act, in_slope=slope, drop_p=p)

@@ -1,0 +1,458 @@
+"""torch.autograd glue over the C-ABI HIP library (include/vunet_hip.h).
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd tape; every number on
+the hot path is produced by a kernel of libvunet_hip.so, called through ctypes with raw device
+pointers.  There is no CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_ELU, ACT_RELU, ACT_SIGMOID, ACT_LRELU = 0, 1, 2, 3, 4
+SEED2_OFFSET = 0x9E3779B9  # seed offset of the second source of a dual-source conv (csrc/conv_gather.hip)
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("Hs", ctypes.c_int32),
+                ("Ws", ctypes.c_int32), ("M", ctypes.c_int32), ("m_off", ctypes.c_int32), ("Mpad", ctypes.c_int32),
+                ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("KH", ctypes.c_int32), ("KW", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("mode", ctypes.c_int32),
+                ("in_act", ctypes.c_int32), ("in_slope", ctypes.c_float), ("drop_p", ctypes.c_float),
+                ("drop_seed", ctypes.c_uint32), ("out_act", ctypes.c_int32), ("d2s", ctypes.c_int32),
+                ("aux_act", ctypes.c_int32), ("aux_slope", ctypes.c_float), ("aux_drop_p", ctypes.c_float),
+                ("aux_drop_seed", ctypes.c_uint32)]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("Hs", ctypes.c_int32),
+                ("Ws", ctypes.c_int32), ("Cout", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
+                ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("in_act", ctypes.c_int32), ("in_slope", ctypes.c_float), ("drop_p", ctypes.c_float),
+                ("drop_seed", ctypes.c_uint32), ("nsplit", ctypes.c_int32)]
+
+
+class WnDesc(ctypes.Structure):
+    _fields_ = [("Cout", ctypes.c_int32), ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("KH", ctypes.c_int32),
+                ("KW", ctypes.c_int32), ("kind", ctypes.c_int32)]
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vunet HIP path needs device tensors (hand-written gfx950 kernels; no CPU fallback)")
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"vunet HIP path computes in fp32, got {t.dtype}")
+
+
+def _call(name: str, *args):
+    rc = getattr(_lib.lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else (t if t.is_contiguous() else t.contiguous())
+
+
+def _r2(x: int) -> int:
+    return (x + 1) // 2 * 2
+
+
+def _r32(x: int) -> int:
+    return (x + 31) // 32 * 32
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout seeds: one fresh 32-bit seed per fused conv call, derived from torch's seed
+# ------------------------------------------------------------------------------------------------
+_drop_state = {"base": None, "ctr": 0}
+
+
+def set_dropout_seed(seed: int):
+    _drop_state["base"] = int(seed) & 0xFFFFFFFF
+    _drop_state["ctr"] = 0
+
+
+def next_dropout_seed() -> int:
+    if _drop_state["base"] is None:
+        set_dropout_seed(torch.initial_seed())
+    _drop_state["ctr"] += 1
+    x = (_drop_state["base"] * 0x9E3779B1 + _drop_state["ctr"] * 0x85EBCA77) & 0xFFFFFFFF
+    x ^= x >> 15
+    return (x * 0x2C1B3C6D) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+# fused (weight-normalised) convolution
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ConvCfg:
+    kind: int = 0          # 0 NormConv2d, 1 plain conv, 2 L2NormConv2d
+    k: int = 3
+    stride: int = 1
+    pad: int = 0
+    in_act: int = ACT_NONE
+    in_slope: float = 0.0
+    drop_p: float = 0.0
+    drop_seed: int = 0
+    out_act: int = ACT_NONE
+    d2s: bool = False
+    res_is_x1: bool = False  # residual tensor is source 1 itself -> its gradient is fused into the dgrad epilogue
+
+
+def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
+    return (h + 2 * pad - k) // stride + 1
+
+
+def pack_weights(v, g, bias, gamma, beta, c1: int, c2: int, kind: int, need_dgrad: bool):
+    """vunet_weightnorm_fwd -> (wt_f, wt_d, scale, shift, invnorm)."""
+    cout, ctot, kh, kw = v.shape
+    assert ctot == c1 + c2
+    t = kh * kw
+    dev = v.device
+    wt_f = torch.empty(t * (_r2(c1) + _r2(c2)), _r32(cout), device=dev, dtype=torch.float32)
+    wt_d = torch.empty(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_dgrad else None
+    small = torch.empty(3, cout, device=dev, dtype=torch.float32)
+    d = WnDesc(cout, c1, c2, kh, kw, kind)
+    _call("vunet_weightnorm_fwd", ctypes.byref(d), _p(v), _p(g), _p(bias), _p(gamma), _p(beta), _p(wt_f), _p(wt_d),
+          _p(small[0]), _p(small[1]), _p(small[2]), _stream())
+    return wt_f, wt_d, small[0], small[1], small[2]
+
+
+def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
+    _call("vunet_conv2d_gather", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(shift), _p(res), _p(aux), _p(y),
+          _stream())
+
+
+class FusedConv(torch.autograd.Function):
+    """y = [d2s] act_out( conv( drop(act_in(cat(x1, x2))) ; w_eff ) + shift ) [+ res]."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, res, v, g, bias, gamma, beta, cfg: ConvCfg):
+        _dev(x1, x2, res, v, g, bias, gamma, beta)
+        x1, x2, res = _c(x1), _c(x2), _c(res)
+        v, g, bias, gamma, beta = _c(v), _c(g), _c(bias), _c(gamma), _c(beta)
+        n, c1, hs, ws = x1.shape
+        c2 = 0 if x2 is None else x2.shape[1]
+        cout = v.shape[0]
+        k = cfg.k
+        ho, wo = conv_out_size(hs, k, cfg.stride, cfg.pad), conv_out_size(ws, k, cfg.stride, cfg.pad)
+        need_x = (ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]))
+        need_w = any(ctx.needs_input_grad[3:8])
+        wt_f, wt_d, scale, shift, invnorm = pack_weights(v, g, bias, gamma, beta, c1, c2, cfg.kind, need_x)
+        if cfg.d2s:
+            y = torch.empty(n, cout // 4, 2 * ho, 2 * wo, device=x1.device, dtype=torch.float32)
+        else:
+            y = torch.empty(n, cout, ho, wo, device=x1.device, dtype=torch.float32)
+        d = ConvDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, M=cout, m_off=0, Mpad=wt_f.shape[1], Ho=ho, Wo=wo, KH=k, KW=k,
+                     stride=cfg.stride, pad=cfg.pad, mode=0, in_act=cfg.in_act, in_slope=cfg.in_slope,
+                     drop_p=cfg.drop_p, drop_seed=cfg.drop_seed, out_act=cfg.out_act, d2s=int(cfg.d2s))
+        _conv_gather(d, x1, x2, wt_f, shift, res, None, y)
+        ctx.cfg = cfg
+        ctx.dims = (n, c1, c2, hs, ws, cout, ho, wo)
+        ctx.need_w = need_w
+        ctx.save_for_backward(x1, x2, v, g, bias, gamma, invnorm, wt_d,
+                              y if cfg.out_act in (ACT_SIGMOID, ACT_RELU, ACT_LRELU, ACT_ELU) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, v, g, bias, gamma, invnorm, wt_d, y = ctx.saved_tensors
+        cfg: ConvCfg = ctx.cfg
+        n, c1, c2, hs, ws, cout, ho, wo = ctx.dims
+        dy = _c(dy)
+        dres = dy if (ctx.needs_input_grad[2] and not cfg.res_is_x1) else None
+        dconv = dy
+        if cfg.out_act != ACT_NONE:
+            dconv = torch.empty_like(dy)
+            _call("vunet_act_bwd_from_out", _p(y), _p(dy), _p(dconv), cfg.out_act, cfg.in_slope, dy.numel(), _stream())
+        if cfg.d2s:
+            t = torch.empty(n, cout, ho, wo, device=dy.device, dtype=torch.float32)
+            _call("vunet_space_to_depth", _p(dconv), _p(t), n, cout // 4, 2 * ho, 2 * wo, _stream())
+            dconv = t
+        k = cfg.k
+        dv = dg = dbias = dgamma = dbeta = None
+        if ctx.need_w:
+            wd = WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=cfg.stride,
+                           pad=cfg.pad, in_act=cfg.in_act, in_slope=cfg.in_slope, drop_p=cfg.drop_p,
+                           drop_seed=cfg.drop_seed, nsplit=1)
+            ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
+            if ns < 1:
+                raise RuntimeError(f"vunet_conv2d_wgrad_nsplit failed with code {ns}")
+            wd.nsplit = ns
+            ktot = k * k * (c1 + c2)
+            slabs = torch.empty(ns * _r32(cout) * ktot + ns * _r32(cout), device=dy.device, dtype=torch.float32)
+            dshift = slabs[ns * _r32(cout) * ktot:]
+            _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift), _stream())
+            ni = ctx.needs_input_grad
+            dv = torch.empty_like(v) if ni[3] else None
+            dg = torch.empty_like(g) if (g is not None and ni[4]) else None
+            dbias = torch.empty_like(bias) if (bias is not None and ni[5]) else None
+            dgamma = torch.empty_like(gamma) if (gamma is not None and ni[6]) else None
+            dbeta = torch.empty_like(gamma) if (gamma is not None and ni[7]) else None
+            wn = WnDesc(cout, c1, c2, k, k, cfg.kind)
+            _call("vunet_weightnorm_bwd", ctypes.byref(wn), _p(slabs), _p(dshift), ns, _p(v), _p(g), _p(bias),
+                  _p(gamma), _p(invnorm), _p(dv), _p(dg), _p(dbias), _p(dgamma), _p(dbeta), _stream())
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            def dgrad(x, cs, m_off, seed, add):
+                dx = torch.empty_like(x)
+                d = ConvDesc(N=n, C1=cout, C2=0, Hs=ho, Ws=wo, M=cs, m_off=m_off, Mpad=wt_d.shape[1], Ho=hs, Wo=ws,
+                             KH=k, KW=k, stride=cfg.stride, pad=cfg.pad, mode=1, in_act=ACT_NONE, in_slope=0.0,
+                             drop_p=0.0, drop_seed=0, out_act=ACT_NONE, d2s=0, aux_act=cfg.in_act,
+                             aux_slope=cfg.in_slope, aux_drop_p=cfg.drop_p, aux_drop_seed=seed)
+                has_aux = cfg.in_act != ACT_NONE or cfg.drop_p > 0
+                _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx)
+                return dx
+            if ctx.needs_input_grad[0]:
+                dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else None)
+            if x2 is not None and ctx.needs_input_grad[1]:
+                dx2 = dgrad(x2, c2, c1, (cfg.drop_seed + SEED2_OFFSET) & 0xFFFFFFFF, None)
+        return dx1, dx2, dres, dv, dg, dbias, dgamma, dbeta, None
+
+
+def fused_conv(x1, x2, res, v, g, bias, gamma, beta, cfg: ConvCfg):
+    if res is not None and res is x1 and not cfg.d2s and cfg.out_act == ACT_NONE:
+        cfg.res_is_x1 = True
+    return FusedConv.apply(x1, x2, res, v, g, bias, gamma, beta, cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# small differentiable ops
+# ------------------------------------------------------------------------------------------------
+class DepthToSpace(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty(n, c // 4, 2 * h, 2 * w, device=x.device, dtype=x.dtype)
+        _call("vunet_depth_to_space", _p(x), _p(y), n, c, h, w, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        n, c, h, w = dy.shape
+        dx = torch.empty(n, 4 * c, h // 2, w // 2, device=dy.device, dtype=dy.dtype)
+        _call("vunet_space_to_depth", _p(dy), _p(dx), n, c, h, w, _stream())
+        return dx
+
+
+class SpaceToDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty(n, 4 * c, h // 2, w // 2, device=x.device, dtype=x.dtype)
+        _call("vunet_space_to_depth", _p(x), _p(y), n, c, h, w, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        n, c, h, w = dy.shape
+        dx = torch.empty(n, c // 4, 2 * h, 2 * w, device=dy.device, dtype=dy.dtype)
+        _call("vunet_depth_to_space", _p(dy), _p(dx), n, c, h, w, _stream())
+        return dx
+
+
+class Reparam(torch.autograd.Function):
+    """z = eps * exp(logstd) + mu   (models/vunets.py:594-597)."""
+
+    @staticmethod
+    def forward(ctx, mu, logstd, eps):
+        _dev(mu, logstd, eps)
+        mu, logstd, eps = _c(mu), _c(logstd), _c(eps)
+        z = torch.empty_like(mu)
+        _call("vunet_reparam_fwd", _p(mu), _p(logstd), _p(eps), _p(z), mu.numel(), _stream())
+        ctx.save_for_backward(logstd, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logstd, eps = ctx.saved_tensors
+        dz = _c(dz)
+        dmu, dls = torch.empty_like(dz), torch.empty_like(dz)
+        _call("vunet_reparam_bwd", _p(dz), _p(logstd), _p(eps), _p(dmu), _p(dls), dz.numel(), _stream())
+        return dmu, dls, None
+
+
+class L1Mean(torch.autograd.Function):
+    """weight * mean|target - pred|, shape [1]; gradient flows to pred only (lib/losses.py:98-102)."""
+
+    @staticmethod
+    def forward(ctx, target, pred, weight: float):
+        _dev(target, pred)
+        target, pred = _c(target), _c(pred)
+        out = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        partial = torch.empty(1024, device=pred.device, dtype=torch.float32)
+        _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
+        ctx.save_for_backward(target, pred)
+        ctx.weight = float(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        target, pred = ctx.saved_tensors
+        db = torch.empty_like(pred)
+        # the upstream scalar gradient stays on the device (no host sync): the kernel reads gout[0]
+        _call("vunet_l1_mean_bwd", _p(target), _p(pred), None, _p(db), ctx.weight / pred.numel(), _p(_c(gout)),
+              pred.numel(), _stream())
+        return None, db, None
+
+
+class KLPrior(torch.autograd.Function):
+    """weight * kl_loss(mu, logstd) of lib/losses.py:283-291 (inputs [N, ...] flattened per sample)."""
+
+    @staticmethod
+    def forward(ctx, mu, logstd, weight: float):
+        _dev(mu, logstd)
+        mu, logstd = _c(mu), _c(logstd)
+        n = mu.shape[0]
+        d = mu.numel() // n
+        out = torch.zeros((), device=mu.device, dtype=torch.float32)
+        _call("vunet_kl_fwd", _p(mu), _p(logstd), _p(out), float(weight), n, d, _stream())
+        ctx.save_for_backward(mu, logstd)
+        ctx.scale = float(weight) / n
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        mu, logstd = ctx.saved_tensors
+        dmu, dls = torch.empty_like(mu), torch.empty_like(mu)
+        _call("vunet_kl_bwd", _p(mu), _p(logstd), _p(dmu), _p(dls), ctx.scale, _p(_c(gout)), mu.numel(), _stream())
+        return dmu, dls, None
+
+
+class SqDiff(torch.autograd.Function):
+    """weight * mean_n sum_chw 0.5 (p-q)^2   (lib/losses.py:26-37)."""
+
+    @staticmethod
+    def forward(ctx, p, q, weight: float):
+        _dev(p, q)
+        p, q = _c(p), _c(q)
+        n = p.shape[0]
+        out = torch.zeros((), device=p.device, dtype=torch.float32)
+        _call("vunet_sqdiff_fwd", _p(p), _p(q), _p(out), float(weight), n, p.numel() // n, _stream())
+        ctx.save_for_backward(p, q)
+        ctx.scale = float(weight) / n
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, q = ctx.saved_tensors
+        dp, dq = torch.empty_like(p), torch.empty_like(p)
+        _call("vunet_sqdiff_bwd", _p(p), _p(q), _p(dp), _p(dq), ctx.scale, _p(_c(gout)), p.numel(), _stream())
+        return dp, dq, None
+
+
+class VggPreprocess(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        assert c == 3
+        y = torch.empty_like(x)
+        _call("vunet_vgg_preprocess", _p(x), _p(y), n, h, w, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        n, _, h, w = dy.shape
+        dx = torch.empty_like(dy)
+        _call("vunet_vgg_preprocess_bwd", _p(dy), None, _p(dx), n, h, w, _stream())
+        return dx
+
+
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=x.dtype)
+        _call("vunet_maxpool2_fwd", _p(x), _p(y), n * c, h, w, _stream())
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        dy = _c(dy)
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        _call("vunet_maxpool2_bwd", _p(x), _p(y), _p(dy), _p(dx), n * c, h, w, _stream())
+        return dx
+
+
+class InstanceNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps: float):
+        _dev(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(n * c, 2, device=x.device, dtype=torch.float32)
+        _call("vunet_instnorm_fwd", _p(x), _p(y), _p(stats), n * c, h * w, float(eps), _stream())
+        ctx.save_for_backward(y, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, stats = ctx.saved_tensors
+        dy = _c(dy)
+        n, c, h, w = y.shape
+        dx = torch.empty_like(y)
+        _call("vunet_instnorm_bwd", _p(y), _p(dy), _p(stats), _p(dx), n * c, h * w, _stream())
+        return dx, None
+
+
+class Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act: int, slope: float):
+        _dev(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        _call("vunet_act_fwd", _p(x), _p(y), act, float(slope), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        ctx.act, ctx.slope = act, float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _call("vunet_act_bwd_from_out", _p(y), _p(dy), _p(dx), ctx.act, ctx.slope, dy.numel(), _stream())
+        return dx, None, None
+
+
+def dropout_keep_mask(shape, p: float, seed: int, device) -> torch.Tensor:
+    """The conv prologue's keep-mask, materialised (tests / debugging)."""
+    m = torch.empty(shape, device=device, dtype=torch.float32)
+    _call("vunet_dropout_mask", _p(m), m.numel(), float(p), int(seed) & 0xFFFFFFFF, _stream())
+    return m
+
+
+def adam_step_flat(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _dev(param, grad, exp_avg, exp_avg_sq)
+    _call("vunet_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(beta1),
+          float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())

@@ -1,0 +1,192 @@
+/*
+ * vunet_hip.h -- C ABI of libvunet_hip.so: MI355X (gfx950) kernels for the VUnet
+ * shape-and-posture synthesis hot path.
+ *
+ * The upstream reference (CompVis/behavior-driven-video-synthesis) has no native layer: the path
+ * sits between its Python nn.Module API and ATen/cuDNN.  Each entry point below therefore cites
+ * the reference *operation* (file:line, relative to the upstream root) that it replaces; the
+ * Python host side (behavior_driven_video_synthesis_amd/) binds these with ctypes -- see
+ * INTEGRATION.md for the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only, no torch types.  All tensors are contiguous fp32
+ * NCHW device buffers owned by the caller; the library allocates nothing persistent, is stateless
+ * and re-entrant per stream.  `stream` is a hipStream_t passed as void*.  Every function returns 0
+ * on success or a negative VUNET_ERR_* code (no exceptions cross the ABI).
+ */
+#ifndef VUNET_HIP_H
+#define VUNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VUNET_OK 0
+#define VUNET_ERR_ARG (-1)
+#define VUNET_ERR_LAUNCH (-2)
+#define VUNET_ERR_UNSUPPORTED (-3)
+
+/* activation codes */
+#define VUNET_ACT_NONE 0
+#define VUNET_ACT_ELU 1      /* nn.ELU(alpha=1), lib/modules.py:207 */
+#define VUNET_ACT_RELU 2     /* VGG19 features ReLU, models/imagenet_pretrained.py:53-59 */
+#define VUNET_ACT_SIGMOID 3  /* EncDownAlter.squash, models/vunets.py:556,575 */
+#define VUNET_ACT_LRELU 4    /* PatchGAN LeakyReLU(0.2), models/synth_discriminator.py:34 */
+
+int vunet_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *
+ * Replaces F.conv2d + the pointwise ops around it in NormConv2d / VunetRNB / Upsample /
+ * Downsample (lib/modules.py:140-145, 221-233, 160-161, 179-182) and the VGG19 conv+ReLU stack
+ * (models/imagenet_pretrained.py:53-59):
+ *   prologue  : activation (ELU ...) and dropout on the gathered input values (lib/modules.py:229-230)
+ *   sources   : two input tensors read as one channel-concatenated tensor (torch.cat, lib/modules.py:227)
+ *   epilogue  : + shift[c] (folded gamma*bias+beta), activation, + residual (lib/modules.py:233),
+ *               block-major depth-to-space store (lib/modules.py:29-34)
+ * mode 1 runs the transposed gather (data gradient) with epilogue  y = acc * act'(aux) + res.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vunet_conv_desc {
+  int32_t N;
+  int32_t C1, C2;       /* channels of source 1 / source 2 (C2 == 0: single source)            */
+  int32_t Hs, Ws;       /* spatial size of the gathered (source) tensors                        */
+  int32_t M;            /* output channels produced by this launch                              */
+  int32_t m_off;        /* first column of wt used                                              */
+  int32_t Mpad;         /* row pitch of wt in floats (multiple of 32)                           */
+  int32_t Ho, Wo;       /* spatial size of the produced tensor (before depth-to-space)          */
+  int32_t KH, KW, stride, pad;
+  int32_t mode;         /* 0: ih = oh*stride - pad + kh ; 1: ih = (oh + pad - kh)/stride        */
+  int32_t in_act;       /* prologue activation                                                  */
+  float in_slope;
+  float drop_p;         /* prologue dropout probability (0: off), keep-mask = hash(idx+seed)    */
+  uint32_t drop_seed;
+  int32_t out_act;      /* mode 0 epilogue activation                                           */
+  int32_t d2s;          /* mode 0: store through DepthToSpace(2)                                */
+  int32_t aux_act;      /* mode 1 epilogue: multiply by d act / d v evaluated at aux            */
+  float aux_slope;
+  float aux_drop_p;
+  uint32_t aux_drop_seed;
+} vunet_conv_desc;
+
+/* wt: [T*(C1p+C2p)][Mpad] K-major effective weights (rows: source, tap, channel; CXp = CX rounded up
+ * to 2), shift: [M] or NULL, res: tensor shaped like y or NULL, aux: tensor shaped like y or NULL. */
+int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
+                        const float* shift, const float* res, const float* aux, float* y, void* stream);
+
+/* Weight gradient  dW[co][tap][ci] = sum_px dy[co][px] * f(x)[ci][px (+) tap]  with the same
+ * prologue f as the forward; split over `nsplit` pixel ranges into partial slabs
+ *   slabs[nsplit][Coutp][T*(C1+C2)]  (Coutp = Cout rounded up to 32)  and  dshift[nsplit][Coutp].
+ * Replaces the weight-gradient half of autograd's conv backward for the layers above. */
+typedef struct vunet_wgrad_desc {
+  int32_t N, C1, C2, Hs, Ws;
+  int32_t Cout, Ho, Wo;
+  int32_t KH, KW, stride, pad;
+  int32_t in_act;
+  float in_slope;
+  float drop_p;
+  uint32_t drop_seed;
+  int32_t nsplit;
+} vunet_wgrad_desc;
+
+int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
+                       float* slabs, float* dshift, void* stream);
+/* number of pixel splits the library wants for this problem (caller sizes the slabs from it) */
+int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight normalisation  (torch._weight_norm, lib/modules.py:135-138) folded with the learned
+ * affine of NormConv2d (lib/modules.py:143-145):
+ *   scale[co] = gamma[co] * g[co] / ||v[co]||      shift[co] = gamma[co]*bias[co] + beta[co]
+ * and packed into the K-major layouts the conv kernels read.
+ *   kind 0: NormConv2d (v, g, bias, gamma, beta)      kind 1: plain conv (weight=v, bias)
+ *   kind 2: L2NormConv2d (weight=v normalised, gamma, beta; lib/modules.py:89-101)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vunet_wn_desc {
+  int32_t Cout, C1, C2, KH, KW;
+  int32_t kind;
+} vunet_wn_desc;
+
+/* outputs: wt_f [T*(C1p+C2p)][Coutp32]  (forward),  wt_d [T*Coutp2][Cinp32] (dgrad; NULL to skip),
+ * scale[Cout], shift[Cout], invnorm[Cout].  Any of g/bias/gamma/beta may be NULL per kind.
+ * (CXp = CX rounded up to 2, Coutp2 = Cout rounded up to 2, Coutp32/Cinp32 rounded up to 32.) */
+int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g, const float* bias,
+                         const float* gamma, const float* beta, float* wt_f, float* wt_d, float* scale,
+                         float* shift, float* invnorm, void* stream);
+
+/* backward: reduces the wgrad slabs and produces the parameter gradients.
+ * dv[Cout][Cin][KH][KW], dg[Cout], dbias[Cout], dgamma[Cout], dbeta[Cout] (NULL to skip). */
+int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float* dshift, int32_t nsplit,
+                         const float* v, const float* g, const float* bias, const float* gamma,
+                         const float* invnorm, float* dv, float* dg, float* dbias, float* dgamma,
+                         float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pointwise / index / reduction kernels (HBM-bound)
+ * ------------------------------------------------------------------------------------------ */
+/* DepthToSpace / SpaceToDepth, block-major channel order (lib/modules.py:11-34). x:[N,C,H,W] */
+int vunet_depth_to_space(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int vunet_space_to_depth(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+
+/* y = a*x + b*y_in style helpers used by the autograd glue */
+int vunet_axpby(const float* x, const float* y_in, float* y, float a, float b, int64_t n, void* stream);
+/* dx = dy * act'(.) given the activation OUTPUT (sigmoid: y(1-y); relu: y>0; lrelu) */
+int vunet_act_bwd_from_out(const float* y, const float* dy, float* dx, int32_t act, float slope, int64_t n,
+                           void* stream);
+int vunet_act_fwd(const float* x, float* y, int32_t act, float slope, int64_t n, void* stream);
+
+/* reparametrisation z = eps*exp(logstd) + mu  (models/vunets.py:594-597) and its gradients */
+int vunet_reparam_fwd(const float* mu, const float* logstd, const float* eps, float* z, int64_t n, void* stream);
+int vunet_reparam_bwd(const float* dz, const float* logstd, const float* eps, float* dmu, float* dlogstd,
+                      int64_t n, void* stream);
+
+/* mean |a-b| (lib/losses.py:98-102): out[0] += weight * mean|a-b| ; backward wrt b:
+ * db = (add ? add : 0) + gscale * gout[0] * sign(b-a)  with gscale = weight/n; gout: device scalar (upstream
+ * gradient, NULL = 1) so that no host sync is needed */
+int vunet_l1_mean_fwd(const float* a, const float* b, float* partial, float* out, float weight, int64_t n,
+                      void* stream);
+int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* db, float gscale,
+                      const float* gout, int64_t n, void* stream);
+
+/* KL(N(mu, exp(l)^2) || N(0,1)) per lib/losses.py:283-291: out[0] += weight * mean_n(sum_d(-l + .5(e^{2l}+mu^2)) - .5 D) */
+int vunet_kl_fwd(const float* mu, const float* logstd, float* out, float weight, int32_t N, int64_t D, void* stream);
+int vunet_kl_bwd(const float* mu, const float* logstd, float* dmu, float* dlogstd, float gscale,
+                 const float* gout, int64_t n, void* stream);
+/* 0.5*(p-q)^2 summed over CHW, batch mean (lib/losses.py:26-37) */
+int vunet_sqdiff_fwd(const float* p, const float* q, float* out, float weight, int32_t N, int64_t D, void* stream);
+int vunet_sqdiff_bwd(const float* p, const float* q, float* dp, float* dq, float gscale, const float* gout,
+                     int64_t n, void* stream);
+
+/* VGG input affine ((x+1)/2 - mean_c)/std_c  (models/imagenet_pretrained.py:43-44) */
+int vunet_vgg_preprocess(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* stream);
+/* dx = (add ? add : 0) + dy * 0.5/std_c */
+int vunet_vgg_preprocess_bwd(const float* dy, const float* add, float* dx, int32_t N, int32_t H, int32_t W,
+                             void* stream);
+/* MaxPool2d(2,2) forward / backward (recomputes the argmax from x) */
+int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t H, int32_t W, void* stream);
+int vunet_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H,
+                       int32_t W, void* stream);
+
+/* InstanceNorm2d(affine=False, eps) forward/backward (lib/modules.py:112; synth_discriminator.py:48,63)
+ * stats: [NC][2] (mean, rstd) written by fwd and read by bwd */
+int vunet_instnorm_fwd(const float* x, float* y, float* stats, int32_t NC, int32_t HW, float eps, void* stream);
+int vunet_instnorm_bwd(const float* y, const float* dy, const float* stats, float* dx, int32_t NC, int32_t HW,
+                       void* stream);
+
+/* Fused multi-tensor Adam over one flat fp32 buffer (torch.optim.Adam semantics, eps outside sqrt;
+ * experiments/shape_and_pose_net.py:237-246).  grad_scale multiplies the gradient first. */
+int vunet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                    void* stream);
+
+/* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */
+int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* stream);
+
+/* uint8 planes -> fp32 in [-1,1]  (ToTensor, *2-1; data/base_dataset.py:183-190) */
+int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VUNET_HIP_H */

@@ -1,0 +1,137 @@
+"""-m gpu: HIP primitives (through the C-ABI library) vs golden vectors from the reference and vs the oracle.
+
+Tolerance: fp32 MFMA is a k-ordered fmaf chain (exact fp32), the CPU reference sums in a different
+order -> atol/rtol 1e-4 on outputs, 1e-3 on weight gradients (long reductions)  (SURVEY 8c).
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from hip_parity_utils import assert_close, dropout_keep_mask
+from synth import seeded_randn, synth_image, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from behavior_driven_video_synthesis_amd.lib import modules as M
+    return M
+
+
+def _build(case):
+    M = _mods()
+    return {
+        "nc_k3s1": lambda: M.NormConv2d(6, 10, 3, 1, 1),
+        "nc_k1": lambda: M.NormConv2d(3, 8, 1),
+        "nc_k3valid": lambda: M.NormConv2d(3, 16, 3),
+        "down": lambda: M.Downsample(8, 16),
+        "up": lambda: M.Upsample(8, 4),
+        "rnb_plain": lambda: M.VunetRNB(8),
+        "rnb_res": lambda: M.VunetRNB(8, a_channels=8, residual=True),
+        "rnb_res2": lambda: M.VunetRNB(8, a_channels=16, residual=True),
+        "s2d": lambda: M.SpaceToDepth(2),
+        "d2s": lambda: M.DepthToSpace(2),
+        "l2nc": lambda: M.L2NormConv2d(6, 8, 3, 1, 1, bias=False),
+        "lnc": lambda: M.LayerNormConv2d(6, 8, 3, 1, 1),
+    }[case]()
+
+
+CASES = ["nc_k3s1", "nc_k1", "nc_k3valid", "down", "up", "rnb_plain", "rnb_res", "rnb_res2", "s2d", "d2s", "l2nc",
+         "lnc"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_primitive_vs_golden(case):
+    meta, arr = load_golden("g1_primitives")
+    seed, info = meta["seed"], meta["cases"][case]
+    mod = _build(case)
+    assert {k: list(v.shape) for k, v in mod.state_dict().items()} == info["shapes"]
+    mod.load_state_dict(synth_state_dict(info["shapes"], seed))
+    mod = mod.cuda().train()
+    names = [case + ".x", case + ".a"]
+    ins = [synth_image(names[i], tuple(s), seed).cuda().requires_grad_(True) for i, s in enumerate(info["inputs"])]
+    y = mod(*ins)
+    assert_close(y, arr[case + ".y"], name=case + ".y")
+    (y * seeded_randn(case + ".wgt", tuple(y.shape), seed).cuda()).sum().backward()
+    for i, t in enumerate(ins):
+        assert_close(t.grad, arr[f"{case}.gin{i}"], name=f"{case}.gin{i}")
+    for k, p in mod.named_parameters():
+        assert_close(p.grad, arr[f"{case}.gp.{k}"], rtol=1e-3, atol=1e-4, name=f"{case}.gp.{k}")
+
+
+@pytest.mark.parametrize("shape", [
+    # (N, Cin, Cout, H, W, k, stride, pad)
+    (2, 32, 32, 32, 32, 3, 1, 1),     # full 32-channel tile
+    (1, 64, 128, 16, 16, 3, 1, 1),    # multiple m-blocks
+    (3, 5, 70, 9, 11, 3, 1, 1),       # ragged channels, ragged map
+    (2, 16, 24, 17, 13, 3, 2, 1),     # stride 2, odd sizes
+    (2, 3, 8, 10, 10, 4, 2, 1),       # PatchGAN-style 4x4 stride 2
+    (2, 8, 4, 6, 6, 4, 1, 1),         # 4x4 stride 1
+    (4, 128, 128, 4, 4, 3, 1, 1),     # bottleneck 4x4 map: tiles span images
+    (2, 7, 9, 2, 2, 3, 1, 1),         # 2x2 map (Market config latents)
+    (1, 16, 3, 40, 40, 3, 1, 1),      # out_conv-like: 3 output channels
+])
+def test_normconv_vs_oracle(shape):
+    """Fused NormConv2d fwd + dgrad + wgrad on shapes the golden file does not hold (edge cases)."""
+    from oracle import vunet_oracle as O
+    M = _mods()
+    n, cin, cout, h, w, k, s, p = shape
+    torch.manual_seed(0)
+    mod = M.NormConv2d(cin, cout, k, s, p)
+    sd = synth_state_dict({kk: list(v.shape) for kk, v in mod.state_dict().items()}, 5)
+    mod.load_state_dict(sd)
+    x = synth_image("x", (n, cin, h, w), 5)
+    sdr = {"m." + kk: v.clone().requires_grad_(True) for kk, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.norm_conv(sdr, "m", xr, s, p)
+    wgt = seeded_randn("w", tuple(yr.shape), 5)
+    (yr * wgt).sum().backward()
+    mod = mod.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = mod(xg)
+    assert_close(y, yr, name="y")
+    (y * wgt.cuda()).sum().backward()
+    assert_close(xg.grad, xr.grad, name="dx")
+    for kk, pp in mod.named_parameters():
+        assert_close(pp.grad, sdr["m." + kk].grad, rtol=1e-3, atol=2e-4, name=kk)
+
+
+def test_rnb_dropout_matches_oracle_with_same_mask():
+    """Dropout is a stateless hash of (element index, seed): the oracle is fed the same keep-mask."""
+    from oracle import vunet_oracle as O
+    from behavior_driven_video_synthesis_amd import ops
+    M = _mods()
+    c, p = 16, 0.3
+    mod = M.VunetRNB(c, a_channels=c, residual=True, dropout_prob=p)
+    sd = synth_state_dict({k: list(v.shape) for k, v in mod.state_dict().items()}, 7)
+    mod.load_state_dict(sd)
+    mod = mod.cuda().train()
+    x, a = synth_image("x", (2, c, 12, 12), 7), synth_image("a", (2, c, 12, 12), 7)
+    ops.set_dropout_seed(123)
+    seed = ops.next_dropout_seed()
+    ops.set_dropout_seed(123)  # the module will draw the same seed
+    xg, ag = x.cuda().requires_grad_(True), a.cuda().requires_grad_(True)
+    y = mod(xg, ag)
+    m1 = dropout_keep_mask((2, c, 12, 12), p, seed)
+    m2 = dropout_keep_mask((2, c, 12, 12), p, (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF)
+    assert_close(ops.dropout_keep_mask((2, c, 12, 12), p, seed, "cuda"), m1, 0, 0, "mask")
+    mask = torch.cat([m1, m2], dim=1)
+    assert 0.5 < float(mask.mean()) < 0.9
+    sdr = {"m." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    yr = O.rnb(sdr, "m", xr, ar, drop_mask=mask, drop_p=p)
+    assert_close(y, yr, name="y")
+    wgt = seeded_randn("w", tuple(yr.shape), 7)
+    (yr * wgt).sum().backward()
+    (y * wgt.cuda()).sum().backward()
+    assert_close(xg.grad, xr.grad, name="dx")
+    assert_close(ag.grad, ar.grad, name="da")
+    for k, pp in mod.named_parameters():
+        assert_close(pp.grad, sdr["m." + k].grad, rtol=1e-3, atol=2e-4, name=k)
+
+
+def test_cpu_tensors_are_refused():
+    M = _mods()
+    mod = M.NormConv2d(4, 4, 3, 1, 1)
+    with pytest.raises(RuntimeError):
+        mod(torch.zeros(1, 4, 8, 8))
