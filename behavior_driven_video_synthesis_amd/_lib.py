@@ -100,6 +100,9 @@ def lib() -> ctypes.CDLL:
     """The loaded library.  Raises if it has not been built -- there is no fallback."""
     global _LIB
     if _LIB is None:
+        # PyTorch ships its own libamdhip64: it must be the HIP runtime this library binds to (same
+        # streams / allocations), so torch is imported -- and its runtime loaded -- before the dlopen.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -87,3 +87,11 @@ static inline int vunet_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VUNET_OK : VUNET_ERR_LAUNCH;
 }
+
+// hipGetLastError() also reports stale, unrelated errors left by other users of the runtime in this
+// process (PyTorch does not always clear them): clear before every launch, then check.
+#define VUNET_LAUNCH(...)          \
+  do {                             \
+    (void)hipGetLastError();       \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)

@@ -193,10 +193,10 @@ static int launch_gather(const GatherArgs& ga, int pro, hipStream_t st) {
   const int mblocks = (ga.d.M + 32 * MT - 1) / (32 * MT);
   dim3 grid((unsigned)(pblocks * mblocks)), block(256);
   switch (pro) {
-    case 0: hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 0>), grid, block, 0, st, ga); break;
-    case 1: hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 1>), grid, block, 0, st, ga); break;
-    case 2: hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 2>), grid, block, 0, st, ga); break;
-    default: hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 3>), grid, block, 0, st, ga); break;
+    case 0: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 0>), grid, block, 0, st, ga); break;
+    case 1: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 1>), grid, block, 0, st, ga); break;
+    case 2: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 2>), grid, block, 0, st, ga); break;
+    default: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 3>), grid, block, 0, st, ga); break;
   }
   return vunet_check_launch();
 }

@@ -160,7 +160,7 @@ static int launch_wgrad(const WgradArgs& wa, hipStream_t st) {
   const int ciblocks = (wa.Ctot + 31) / 32, coblocks = (wa.d.Cout + 32 * WM - 1) / (32 * WM);
   dim3 grid(wa.d.nsplit, ciblocks, coblocks), block(256);
   const size_t lds = (size_t)(32 * WM + wa.T * 32) * 33 * sizeof(float);
-  hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, NTW>), grid, block, lds, st, wa);
+  VUNET_LAUNCH((conv_wgrad_kernel<WM, WN, NTW>), grid, block, lds, st, wa);
   return vunet_check_launch();
 }
 

@@ -52,12 +52,12 @@ __global__ void s2d_kernel(const float* __restrict__ x, float* __restrict__ y, i
 }
 extern "C" int vunet_depth_to_space(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* st) {
   if (!x || !y || C % 4) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(d2s_kernel, ew_grid((int64_t)N * C * H * W), dim3(256), 0, (hipStream_t)st, x, y, N, C, H, W);
+  VUNET_LAUNCH(d2s_kernel, ew_grid((int64_t)N * C * H * W), dim3(256), 0, (hipStream_t)st, x, y, N, C, H, W);
   return vunet_check_launch();
 }
 extern "C" int vunet_space_to_depth(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* st) {
   if (!x || !y || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(s2d_kernel, ew_grid((int64_t)N * C * H * W), dim3(256), 0, (hipStream_t)st, x, y, N, C, H, W);
+  VUNET_LAUNCH(s2d_kernel, ew_grid((int64_t)N * C * H * W), dim3(256), 0, (hipStream_t)st, x, y, N, C, H, W);
   return vunet_check_launch();
 }
 
@@ -68,7 +68,7 @@ __global__ void axpby_kernel(const float* __restrict__ x, const float* __restric
 }
 extern "C" int vunet_axpby(const float* x, const float* y_in, float* y, float a, float b, int64_t n, void* st) {
   if (!x || !y) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(axpby_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y_in, y, a, b, n);
+  VUNET_LAUNCH(axpby_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y_in, y, a, b, n);
   return vunet_check_launch();
 }
 
@@ -84,7 +84,7 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 extern "C" int vunet_act_fwd(const float* x, float* y, int32_t act, float slope, int64_t n, void* st) {
   if (!x || !y) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(act_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, act, slope, n);
+  VUNET_LAUNCH(act_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, act, slope, n);
   return vunet_check_launch();
 }
 __global__ void act_bwd_out_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
@@ -102,7 +102,7 @@ __global__ void act_bwd_out_kernel(const float* __restrict__ y, const float* __r
 extern "C" int vunet_act_bwd_from_out(const float* y, const float* dy, float* dx, int32_t act, float slope, int64_t n,
                                       void* st) {
   if (!y || !dy || !dx) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(act_bwd_out_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, y, dy, dx, act, slope, n);
+  VUNET_LAUNCH(act_bwd_out_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, y, dy, dx, act, slope, n);
   return vunet_check_launch();
 }
 
@@ -120,13 +120,13 @@ __global__ void reparam_bwd_kernel(const float* dz, const float* ls, const float
 }
 extern "C" int vunet_reparam_fwd(const float* mu, const float* ls, const float* eps, float* z, int64_t n, void* st) {
   if (!mu || !ls || !eps || !z) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(reparam_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, ls, eps, z, n);
+  VUNET_LAUNCH(reparam_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, ls, eps, z, n);
   return vunet_check_launch();
 }
 extern "C" int vunet_reparam_bwd(const float* dz, const float* ls, const float* eps, float* dmu, float* dls, int64_t n,
                                  void* st) {
   if (!dz || !ls || !eps || !dmu || !dls) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(reparam_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, dz, ls, eps, dmu, dls, n);
+  VUNET_LAUNCH(reparam_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, dz, ls, eps, dmu, dls, n);
   return vunet_check_launch();
 }
 
@@ -161,8 +161,8 @@ extern "C" int vunet_l1_mean_fwd(const float* a, const float* b, float* partial,
   int64_t nb = (n / 4 + 255) / 256;
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)st, a, b, partial, n);
-  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, partial, (int)nb, out,
+  VUNET_LAUNCH(l1_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)st, a, b, partial, n);
+  VUNET_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, partial, (int)nb, out,
                      weight / (float)n);
   return vunet_check_launch();
 }
@@ -178,7 +178,7 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
 extern "C" int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* db, float gscale,
                                  const float* gout, int64_t n, void* st) {
   if (!a || !b || !db) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(l1_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, add, db, gscale, gout, n);
+  VUNET_LAUNCH(l1_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, add, db, gscale, gout, n);
   return vunet_check_launch();
 }
 
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* mu, const floa
 extern "C" int vunet_kl_fwd(const float* mu, const float* ls, float* out, float weight, int32_t N, int64_t D, void* st) {
   if (!mu || !ls || !out || N <= 0) return VUNET_ERR_ARG;
   // weight * ( (1/N) sum_all(...) - 0.5 D )
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, mu, ls, out, weight / (float)N,
+  VUNET_LAUNCH(kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, mu, ls, out, weight / (float)N,
                      weight * 0.5f * (float)D, (int64_t)N * D);
   return vunet_check_launch();
 }
@@ -213,7 +213,7 @@ __global__ void kl_bwd_kernel(const float* mu, const float* ls, float* dmu, floa
 extern "C" int vunet_kl_bwd(const float* mu, const float* ls, float* dmu, float* dls, float gscale, const float* gout,
                             int64_t n, void* st) {
   if (!mu || !ls || !dmu || !dls) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(kl_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, ls, dmu, dls, gscale, gout, n);
+  VUNET_LAUNCH(kl_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, ls, dmu, dls, gscale, gout, n);
   return vunet_check_launch();
 }
 __global__ __launch_bounds__(256) void sqdiff_fwd_kernel(const float* p, const float* q, float* out, float scale,
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void sqdiff_fwd_kernel(const float* p, const f
 }
 extern "C" int vunet_sqdiff_fwd(const float* p, const float* q, float* out, float weight, int32_t N, int64_t D, void* st) {
   if (!p || !q || !out || N <= 0) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(sqdiff_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, p, q, out, weight / (float)N,
+  VUNET_LAUNCH(sqdiff_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, p, q, out, weight / (float)N,
                      (int64_t)N * D);
   return vunet_check_launch();
 }
@@ -245,7 +245,7 @@ __global__ void sqdiff_bwd_kernel(const float* p, const float* q, float* dp, flo
 extern "C" int vunet_sqdiff_bwd(const float* p, const float* q, float* dp, float* dq, float gscale, const float* gout,
                                 int64_t n, void* st) {
   if (!p || !q) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(sqdiff_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, p, q, dp, dq, gscale, gout, n);
+  VUNET_LAUNCH(sqdiff_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, p, q, dp, dq, gscale, gout, n);
   return vunet_check_launch();
 }
 
@@ -261,7 +261,7 @@ __global__ void vgg_pre_kernel(const float* __restrict__ x, float* __restrict__ 
 extern "C" int vunet_vgg_preprocess(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* st) {
   if (!x || !y) return VUNET_ERR_ARG;
   const int64_t n = (int64_t)N * 3 * H * W;
-  hipLaunchKernelGGL(vgg_pre_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H * W, n);
+  VUNET_LAUNCH(vgg_pre_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H * W, n);
   return vunet_check_launch();
 }
 __global__ void vgg_pre_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dx,
@@ -276,7 +276,7 @@ extern "C" int vunet_vgg_preprocess_bwd(const float* dy, const float* add, float
                                         void* st) {
   if (!dy || !dx) return VUNET_ERR_ARG;
   const int64_t n = (int64_t)N * 3 * H * W;
-  hipLaunchKernelGGL(vgg_pre_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, dy, add, dx, H * W, n);
+  VUNET_LAUNCH(vgg_pre_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, dy, add, dx, H * W, n);
   return vunet_check_launch();
 }
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int64_t n) {
@@ -313,14 +313,14 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
 extern "C" int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t H, int32_t W, void* st) {
   if (!x || !y || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
   const int64_t n = (int64_t)NC * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H, W, n);
+  VUNET_LAUNCH(maxpool2_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H, W, n);
   return vunet_check_launch();
 }
 extern "C" int vunet_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H,
                                   int32_t W, void* st) {
   if (!x || !y || !dy || !dx || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
   const int64_t n = (int64_t)NC * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, dy, dx, H, W, n);
+  VUNET_LAUNCH(maxpool2_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, dy, dx, H, W, n);
   return vunet_check_launch();
 }
 
@@ -355,13 +355,13 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
 }
 extern "C" int vunet_instnorm_fwd(const float* x, float* y, float* stats, int32_t NC, int32_t HW, float eps, void* st) {
   if (!x || !y || !stats || NC <= 0 || HW <= 0) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)st, x, y, stats, HW, eps);
+  VUNET_LAUNCH(instnorm_fwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)st, x, y, stats, HW, eps);
   return vunet_check_launch();
 }
 extern "C" int vunet_instnorm_bwd(const float* y, const float* dy, const float* stats, float* dx, int32_t NC,
                                   int32_t HW, void* st) {
   if (!y || !dy || !stats || !dx) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)st, y, dy, stats, dx, HW);
+  VUNET_LAUNCH(instnorm_bwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)st, y, dy, stats, dx, HW);
   return vunet_check_launch();
 }
 
@@ -387,7 +387,7 @@ extern "C" int vunet_adam_step(float* param, const float* grad, float* exp_avg, 
   if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return VUNET_ERR_ARG;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, param, grad, exp_avg, exp_avg_sq, n,
+  VUNET_LAUNCH(adam_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, param, grad, exp_avg, exp_avg_sq, n,
                      (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale);
   return vunet_check_launch();
 }
@@ -399,7 +399,7 @@ __global__ void dropout_mask_kernel(float* mask, int64_t n, uint32_t thresh, uin
 extern "C" int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* st) {
   if (!mask) return VUNET_ERR_ARG;
   const InAct a = make_inact(ACT_NONE, 0.f, p, seed);
-  hipLaunchKernelGGL(dropout_mask_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mask, n, a.thresh, seed);
+  VUNET_LAUNCH(dropout_mask_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mask, n, a.thresh, seed);
   return vunet_check_launch();
 }
 __global__ void u8_to_unit_kernel(const uint8_t* in, float* out, int64_t n) {
@@ -407,7 +407,7 @@ __global__ void u8_to_unit_kernel(const uint8_t* in, float* out, int64_t n) {
 }
 extern "C" int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* st) {
   if (!in || !out) return VUNET_ERR_ARG;
-  hipLaunchKernelGGL(u8_to_unit_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, in, out, n);
+  VUNET_LAUNCH(u8_to_unit_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, in, out, n);
   return vunet_check_launch();
 }
 

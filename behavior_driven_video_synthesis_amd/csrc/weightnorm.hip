@@ -92,11 +92,11 @@ extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, cons
   a.wt_f = wt_f; a.wt_d = wt_d; a.scale = scale; a.shift = shift; a.invnorm = invnorm;
   wn_geometry(d, a);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wn_scale_kernel, dim3(d->Cout), dim3(64), 0, st, a);
+  VUNET_LAUNCH(wn_scale_kernel, dim3(d->Cout), dim3(64), 0, st, a);
   const size_t n = (size_t)a.Kf * a.Mpad_f + (wt_d ? (size_t)a.Kd * a.Mpad_d : 0);
   size_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wn_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  VUNET_LAUNCH(wn_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   return vunet_check_launch();
 }
 
@@ -173,6 +173,6 @@ extern "C" int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, 
   a.Coutp = (d->Cout + 31) / 32 * 32;
   const size_t lds = (size_t)a.T * a.Ctot * sizeof(float);
   if (lds > 60 * 1024) return VUNET_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(wn_bwd_kernel, dim3(d->Cout), dim3(256), lds, (hipStream_t)stream, a);
+  VUNET_LAUNCH(wn_bwd_kernel, dim3(d->Cout), dim3(256), lds, (hipStream_t)stream, a);
   return vunet_check_launch();
 }

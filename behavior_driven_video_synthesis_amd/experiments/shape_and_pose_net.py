@@ -1,0 +1,196 @@
+"""Training-loop surface of the reference's ``experiments/shape_and_pose_net.py`` for the MI355X path.
+
+Keeps what ``train_fn`` (:360-466), ``__update_gamma`` (:82-85), ``adjust_params`` (:500-512) and the
+model / optimiser construction (:196-272) do, on synthetic or user-supplied batches, without the
+ignite / wandb / dataset plumbing that is out of scope:
+
+* ``VunetAlter`` + frozen ``PerceptualVGG`` + Adam(4 param groups, betas (0.5,0.9), lr linearly decayed),
+* loss = ll_weight * sum_i vgg_loss_i + gamma * KL once ``iteration > n_init_batches``,
+* gamma controller ``gamma <- max(gamma - gamma_step * (imax - kl), 0)``,
+* optional regressor side loop (:407-425), which contributes no gradient to the VUnet.
+
+MI355X-first differences (results unchanged): the gamma controller and every logged scalar stay on
+the device (the reference forces >= 10 host syncs per step), Adam is one fused launch per param
+group, and under data parallelism the gradient buckets are all-reduced while backward still runs.
+The checkpoint is ``{"model": state_dict, "optimizer": adam_state_dict}`` as at :474-482.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..lib.losses import compute_kl_with_prior, vgg_loss
+from ..lib.utils import get_member, linear_var, n_parameters
+from ..models.imagenet_pretrained import PerceptualVGG, vgg19
+from ..models.vunets import Regressor, VunetAlter
+from ..optim import FusedAdam
+from ..parallel import BucketedGradAverager, broadcast_parameters
+
+DEFAULT_CONFIG = {
+    # config/shape_and_pose_net.yaml (Human3.6m)
+    "general": {"seed": 42, "debug": False},
+    "data": {"dataset": "Human3.6m", "spatial_size": 256, "box_factor": 2, "bottleneck_factor": 2,
+             "inplane_normalize": False},
+    "architecture": {"n_latent_scales": 2, "conv_layer_type": "l1", "nf_start": 32, "nf_max": 128,
+                     "subpixel_upsampling": True, "n_scales": 0, "n_rnb": 2, "linear_width_factor": 1,
+                     "n_linear": 2, "cvae": False},
+    "training": {"batch_size": 12, "vgg_weights": [1.0] * 6, "dropout_prob": 0.05, "lr": 0.0005,
+                 "gamma_step": 0.00001, "n_init_batches": 4, "adam_betas": (0.5, 0.9), "end_iteration": 150000,
+                 "imax_scaling": "none", "information_max": 1000, "ll_weight": 1.0, "train_regressor": True,
+                 "weight_regressor": 4.0, "reg_steps": 5},
+}
+
+
+class ShapePoseNet:
+    def __init__(self, config: Dict, device="cuda:0", n_channels_x: int = 3, n_keypoints: int = 17,
+                 vgg_weights_path: Optional[str] = None, vgg_width_div: int = 1, total_steps: Optional[int] = None,
+                 process_group=None):
+        self.config = config
+        self.device = torch.device(device)
+        arch, data, tr = config["architecture"], config["data"], config["training"]
+        torch.manual_seed(config["general"].get("seed", 42))
+        # ---- models (:196-235)
+        kw = dict(arch)
+        kw.update(data)
+        kw["dropout_prob"] = tr.get("dropout_prob", 0.0)
+        self.vunet = VunetAlter(n_channels_x=n_channels_x, **kw).to(self.device)
+        self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
+        self.vgg.eval()
+        self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)
+        # ---- optimiser (:237-246)
+        self.optimizer = FusedAdam(
+            [{"params": list(get_member(self.vunet, n).parameters()), "name": n} for n in ("eu", "ed", "du", "dd")],
+            lr=tr["lr"], betas=tuple(tr["adam_betas"]))
+        self.train_regressor = bool(tr.get("train_regressor", False))
+        if self.train_regressor:
+            latent_widths = [data["spatial_size"] // (2 ** (self.vunet.n_scales - i))
+                             for i in range(arch["n_latent_scales"], 0, -1)]
+            self.regressor = Regressor(n_keypoints * 2, latent_widths=latent_widths, **arch).to(self.device)
+            self.optimizer_regressor = FusedAdam(list(self.regressor.parameters()), lr=0.001)
+        # ---- data parallel (replaces nn.DataParallel, :213-214)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        broadcast_parameters(self.optimizer.buckets, 0, process_group)
+        # backward finishes dd first, then ed/du, then eu: launch in that order
+        self.averager = BucketedGradAverager(self.optimizer.buckets, process_group)
+        # ---- schedules (:296-347)
+        self.total_steps = total_steps if total_steps is not None else tr["end_iteration"]
+        imax = tr["information_max"]
+        if tr.get("imax_scaling", "none") == "ascend":
+            self._imax = (0, imax)
+        elif tr.get("imax_scaling") == "descend":
+            self._imax = (imax, 0)
+        else:
+            self._imax = (imax, imax)
+        self.lr = self._adjust_lr(0)
+        self.imax = self._adjust_imax(0)
+        for pg in self.optimizer.param_groups:
+            pg["lr"] = self.lr
+        self.gamma = torch.zeros((), device=self.device, dtype=torch.float32)  # device-resident controller state
+        self.iteration = 0
+        print(f"Number of trainable params is {n_parameters(self.vunet)}")
+
+    # ---- schedules
+    def _adjust_lr(self, it):
+        lr0 = self.config["training"]["lr"]
+        return float(linear_var(it, 0, self.total_steps, lr0, 0, 0, lr0))
+
+    def _adjust_imax(self, it):
+        a, b = self._imax
+        return float(linear_var(it, 0, self.total_steps, a, b, min(a, b), max(a, b)))
+
+    def adjust_params(self, it):
+        """:500-512: lr / imax schedules after every iteration; gamma rides in the param groups."""
+        self.lr = self._adjust_lr(it)
+        self.imax = self._adjust_imax(it)
+        for pg in self.optimizer.param_groups:
+            pg["lr"] = self.lr
+            pg["gamma"] = self.gamma
+
+    # ---- one training step (:360-466)
+    def train_fn(self, batch: Dict[str, torch.Tensor], eps=None) -> Dict[str, torch.Tensor]:
+        tr = self.config["training"]
+        self.vunet.train()
+        self.iteration += 1
+        it = self.iteration
+        target_img = batch["pose_img"]
+        shape_img = batch["stickman"]
+        pose_img = batch.get("pose_img_inplane", target_img)
+
+        self.averager.start_step()
+        self.optimizer.zero_grad()
+        out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
+        ld = vgg_loss(self.custom_vgg, target_img, out_img)
+        likelihoods = torch.stack([ld[k] for k in ld], dim=0)
+        likelihood_loss = tr["ll_weight"] * torch.sum(likelihoods)
+        kl = compute_kl_with_prior(means, logstds)
+        loss = likelihood_loss
+        if it > tr["n_init_batches"]:
+            tuning = 1.0 if self.config["architecture"].get("cvae", False) else self.gamma
+            loss = loss + tuning * kl
+        out = {}
+        if self.train_regressor and "reg_imgs" in batch:
+            loss_regressor = self._regressor_steps(batch)
+            # pure scalar offset: no gradient path to the VUnet (:413 runs under no_grad)
+            loss = loss - torch.clamp(loss_regressor.detach(), max=1.2) * tr["weight_regressor"]
+            out["loss_reg"] = loss_regressor.detach()
+        loss.backward()
+        kl_avg = self.averager.finish(kl.detach().clone().reshape(1))
+        self.optimizer.step()
+        # gamma controller on the device (:82-85,442); with DP every rank sees the averaged KL
+        self.gamma = torch.clamp(self.gamma - tr["gamma_step"] * (self.imax - kl_avg.reshape(())), min=0.0)
+        self.adjust_params(it)
+        out.update({"loss": loss.detach(), "likelihood_loss": likelihood_loss.detach(), "kl_loss": kl.detach(),
+                    "learning_rate": self.lr, "gamma": self.gamma, "imax": self.imax})
+        out.update({k: v.detach() for k, v in ld.items()})
+        return out
+
+    def _regressor_steps(self, batch):
+        reg_imgs, reg_targets = batch["reg_imgs"], batch["reg_targets"]
+        loss_regressor = None
+        for i in range(reg_imgs.shape[1]):
+            with torch.no_grad():
+                _, means, _, _ = self.vunet.ed(self.vunet.eu(reg_imgs[:, i].contiguous()))
+            preds = self.regressor(means)
+            tgts = reg_targets[:, i].reshape(reg_targets.shape[0], -1)
+            loss_regressor = torch.norm(preds - tgts, dim=1).mean()
+            self.optimizer_regressor.zero_grad()
+            loss_regressor.backward()
+            self.optimizer_regressor.step()
+        return loss_regressor
+
+    @torch.no_grad()
+    def transfer(self, app_img, stickman):
+        """Inference path used by the render loop (models/vunets.py:508-515)."""
+        self.vunet.eval()
+        return self.vunet.transfer(app_img, stickman)
+
+    # ---- checkpoint layout of :474-482
+    def state_dict(self):
+        return {"model": self.vunet.state_dict(), "optimizer": self.optimizer.state_dict()}
+
+    def load_state_dict(self, ckpt):
+        self.vunet.load_state_dict(ckpt["model"])
+        if "optimizer" in ckpt and ckpt["optimizer"] is not None:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+            states = list(ckpt["optimizer"]["state"].values())
+            if states:
+                self.iteration = int(states[-1]["step"])  # :248-255
+
+
+def synthetic_batch(batch_size: int, spatial_size: int, device, seed: int = 42, n_channels_x: int = 3,
+                    with_regressor: bool = False, reg_steps: int = 5, n_keypoints: int = 17, rank: int = 0):
+    """Synthetic pose+appearance batch of SURVEY 8(d): U(-1,1) image, sparse {-1,+1} stickman mask."""
+    g = torch.Generator().manual_seed(seed + 1000 * rank)
+    pose = torch.rand(batch_size, 3, spatial_size, spatial_size, generator=g) * 2 - 1
+    stick = (torch.rand(batch_size, 3, spatial_size, spatial_size, generator=g) < 0.05).float() * 2 - 1
+    batch = {"pose_img": pose.to(device), "stickman": stick.to(device)}
+    if n_channels_x != 3:
+        xs = spatial_size // 2
+        batch["pose_img_inplane"] = (torch.rand(batch_size, n_channels_x, xs, xs, generator=g) * 2 - 1).to(device)
+    if with_regressor:
+        batch["reg_imgs"] = (torch.rand(batch_size, reg_steps, 3, spatial_size, spatial_size, generator=g) * 2 - 1
+                             ).to(device)
+        batch["reg_targets"] = torch.rand(batch_size, reg_steps, n_keypoints, 2, generator=g).to(device)
+    return batch

@@ -1,0 +1,87 @@
+"""MI355X-native counterparts of the hot subset of the reference's ``lib/losses.py`` (:11-14, :26-37,
+:55-119, :129-149, :283-291): same function names, argument meaning and return types; the reductions
+run in the fused HIP kernels (``vunet_l1_mean_*``, ``vunet_kl_*``, ``vunet_sqdiff_*``).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import torch
+from torch import nn
+
+from .. import ops
+from .utils import get_member
+
+VGGOutput = namedtuple("VGGOutput", ["input", "relu1_2", "relu2_2", "relu3_2", "relu4_2", "relu5_2"])
+
+
+def latent_kl(prior_mean, posterior_mean):
+    """lib/losses.py:26-37: 0.5 (p-q)^2 summed over CHW, batch mean."""
+    return ops.SqDiff.apply(prior_mean, posterior_mean, 1.0)
+
+
+def compute_kl_loss(prior_means, posterior_means):
+    """lib/losses.py:55-65 (sum over latent scales)."""
+    tot = None
+    for p, q in zip(prior_means, posterior_means):
+        t = latent_kl(p, q)
+        tot = t if tot is None else tot + t
+    return tot
+
+
+def aggregate_kl_loss(prior_means, posterior_means):
+    """lib/losses.py:40-52 (dict-valued variant)."""
+    return compute_kl_loss(list(prior_means.values()), list(posterior_means.values()))
+
+
+def kl_loss(mu, logstd):
+    """lib/losses.py:283-291; mu/logstd are [N, D] (any trailing shape is flattened per sample)."""
+    return ops.KLPrior.apply(mu, logstd, 1.0)
+
+
+def compute_kl_with_prior(means, logstds):
+    """lib/losses.py:68-78: mean over the latent scales of the per-scale KL."""
+    n = len(means)
+    tot = None
+    for m, l in zip(means, logstds):
+        t = ops.KLPrior.apply(m, l, 1.0 / n)
+        tot = t if tot is None else tot + t
+    return tot
+
+
+def vgg_loss(custom_vgg, target, pred, weights=None):
+    """lib/losses.py:81-119: ``w_i * mean|t_i - p_i|`` per tap, dict of tensors shaped [1].
+
+    The target pass runs without an autograd graph and the VGG weights are frozen: the reference
+    builds both (it never disables ``requires_grad`` on VGG), which changes neither the loss nor the
+    gradient reaching the generator.
+    """
+    if weights is not None:
+        raise NotImplementedError("pixel-weighted vgg_loss branch (lib/losses.py:103-117) is unused upstream")
+    with torch.no_grad():
+        target_feats = VGGOutput(**custom_vgg(target))
+    pred_feats = VGGOutput(**custom_vgg(pred))
+    names = list(pred_feats._asdict().keys())
+    lw = get_member(custom_vgg, "loss_weights")
+    losses = {}
+    for i, (tf, pf) in enumerate(zip(target_feats, pred_feats)):
+        losses[names[i]] = ops.L1Mean.apply(tf, pf, float(lw[i]))
+    return losses
+
+
+class GANLoss(nn.Module):
+    """lib/losses.py:129-149.  The logits are [N,1]-sized; the scalar loss itself is host-side plumbing."""
+
+    def __init__(self, loss_type: str = "mse"):
+        super().__init__()
+        if loss_type == "vanilla":
+            self.loss = nn.BCEWithLogitsLoss()
+        elif loss_type == "mse":
+            self.loss = nn.MSELoss()
+        else:
+            raise ValueError(
+                f'The loss type for GANLoss must be either "vanilla" or "mse", but is actually {loss_type}.')
+        self.loss_type = loss_type
+
+    def forward(self, pred, target):
+        return self.loss(pred, target)

@@ -1,0 +1,111 @@
+"""MI355X-native counterpart of ``models/imagenet_pretrained.py:8-61`` (PerceptualVGG) plus the VGG19
+``features`` container it wraps (torchvision.models.vgg19 is a third-party dependency of the reference,
+absent here; its cfg-'E' topology is restated with torchvision's state-dict key names so a
+user-supplied ``vgg19`` checkpoint loads unchanged).
+
+Every conv + ReLU pair is one fused MFMA launch (ReLU epilogue); the input affine, the 2x2 max-pools
+and their backward are HIP kernels.  The stack stops after module 31 (relu5_2): modules 32-36 of the
+reference loop produce values that are discarded (models/imagenet_pretrained.py:53-61).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..lib.modules import Conv2d
+
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+class _Marker(nn.Module):
+    """Parameter-free placeholder keeping torchvision's module indices (ReLU / MaxPool2d slots)."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self.kind = kind
+
+
+class VGG19(nn.Module):
+    """``features`` of torchvision's vgg19 (keys ``features.<idx>.{weight,bias}``), width-scalable for tests."""
+
+    def __init__(self, width_div: int = 1):
+        super().__init__()
+        layers, cin = [], 3
+        for v in VGG19_CFG:
+            if v == "M":
+                layers.append(_Marker("pool"))
+            else:
+                cout = max(v // width_div, 4)
+                layers += [Conv2d(cin, cout, 3, padding=1), _Marker("relu")]
+                cin = cout
+        self.features = nn.Sequential(*layers)
+
+    def init_synthetic(self, seed: int = 1234):
+        """Seeded He-normal weights (no network access for the pretrained ones); mirrors the oracle's recipe."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for m in self.features:
+                if isinstance(m, Conv2d):
+                    cout, cin = m.weight.shape[:2]
+                    m.weight.copy_(torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cin * 9)))
+                    m.bias.copy_((torch.rand(cout, generator=g) - 0.5) * 0.1)
+        return self
+
+
+def vgg19(pretrained: bool = False, weights_path: str = None, width_div: int = 1, seed: int = 1234) -> VGG19:
+    """Stand-in for ``torchvision.models.vgg19(pretrained=True)`` (experiments/shape_and_pose_net.py:222).
+
+    ``weights_path``: a torchvision vgg19 state dict (``features.N.weight``...; classifier keys ignored).
+    Without it the weights are seeded-synthetic (stated as such by bench.py / DESIGN.md).
+    """
+    net = VGG19(width_div)
+    if weights_path is not None:
+        sd = torch.load(weights_path, map_location="cpu")
+        net.load_state_dict({k: v for k, v in sd.items() if k.startswith("features.")})
+    else:
+        net.init_synthetic(seed)
+    return net
+
+
+class PerceptualVGG(nn.Module):
+    """models/imagenet_pretrained.py:8-61: dict ``input, relu1_2, relu2_2, relu3_2, relu4_2, relu5_2``."""
+
+    def __init__(self, vgg, weights):
+        super().__init__()
+        self.vgg_layers = vgg.module.features if isinstance(vgg, nn.DataParallel) else vgg.features
+        self.loss_weights = weights
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406], dtype=torch.float).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225], dtype=torch.float).view(1, 3, 1, 1))
+        self.target_layers = {"3": "relu1_2", "8": "relu2_2", "13": "relu3_2", "22": "relu4_2", "31": "relu5_2"}
+        for p in self.vgg_layers.parameters():  # frozen feature extractor
+            p.requires_grad_(False)
+
+    def forward(self, x):
+        x = ops.VggPreprocess.apply(x)  # ((x+1)/2 - mean)/std, :43-44
+        out = {"input": x}
+        last = max(int(k) for k in self.target_layers)
+        mods = list(self.vgg_layers._modules.items())
+        i = 0
+        while i < len(mods):
+            name, m = mods[i]
+            if int(name) > last:
+                break
+            if isinstance(m, Conv2d):
+                nxt = mods[i + 1][1] if i + 1 < len(mods) else None
+                if isinstance(nxt, _Marker) and nxt.kind == "relu":
+                    x = m.fused(x, out_act=ops.ACT_RELU)  # conv + ReLU(inplace) as one launch
+                    i += 1
+                    name = mods[i][0]
+                else:
+                    x = m(x)
+            elif m.kind == "pool":
+                x = ops.MaxPool2.apply(x)
+            else:
+                x = ops.Activation.apply(x, ops.ACT_RELU, 0.0)
+            if name in self.target_layers:
+                out[self.target_layers[name]] = x
+            i += 1
+        return out

@@ -133,9 +133,54 @@ def pack_weights(v, g, bias, gamma, beta, c1: int, c2: int, kind: int, need_dgra
     return wt_f, wt_d, small[0], small[1], small[2]
 
 
+# ------------------------------------------------------------------------------------------------
+# optional per-launch timing of the conv kernel families (bench.py roofline): HIP events on the launch stream
+# ------------------------------------------------------------------------------------------------
+_prof = {"on": False, "recs": []}
+
+
+def profile_start():
+    _prof["on"], _prof["recs"] = True, []
+
+
+def profile_stop():
+    """-> {family: {"ms": total kernel time, "flop": algorithmic FLOPs, "n": launches}} (call after a device sync)."""
+    _prof["on"] = False
+    fam = {}
+    for name, flop, e0, e1 in _prof["recs"]:
+        f = fam.setdefault(name, {"ms": 0.0, "flop": 0.0, "n": 0})
+        f["ms"] += e0.elapsed_time(e1)
+        f["flop"] += flop
+        f["n"] += 1
+    _prof["recs"] = []
+    return fam
+
+
+class _Timed:
+    def __init__(self, name, flop):
+        self.name, self.flop = name, flop
+
+    def __enter__(self):
+        if _prof["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if _prof["on"]:
+            self.e1.record()
+            _prof["recs"].append((self.name, self.flop, self.e0, self.e1))
+
+
 def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
-    _call("vunet_conv2d_gather", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(shift), _p(res), _p(aux), _p(y),
-          _stream())
+    t = desc.KH * desc.KW
+    if desc.mode == 0:
+        name, flop = "conv_gather_fwd", 2.0 * desc.N * desc.Ho * desc.Wo * desc.M * (desc.C1 + desc.C2) * t
+    else:  # transposed gather: MACs of the forward conv restricted to this source
+        name, flop = "conv_gather_dgrad", 2.0 * desc.N * desc.Hs * desc.Ws * desc.C1 * desc.M * t
+    with _Timed(name, flop):
+        _call("vunet_conv2d_gather", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(shift), _p(res), _p(aux), _p(y),
+              _stream())
 
 
 class FusedConv(torch.autograd.Function):
@@ -197,7 +242,9 @@ class FusedConv(torch.autograd.Function):
             ktot = k * k * (c1 + c2)
             slabs = torch.empty(ns * _r32(cout) * ktot + ns * _r32(cout), device=dy.device, dtype=torch.float32)
             dshift = slabs[ns * _r32(cout) * ktot:]
-            _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift), _stream())
+            with _Timed("conv_wgrad", 2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
+                _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
+                      _stream())
             ni = ctx.needs_input_grad
             dv = torch.empty_like(v) if ni[3] else None
             dg = torch.empty_like(g) if (g is not None and ni[4]) else None

@@ -1,0 +1,230 @@
+"""-m gpu: whole-model parity of the HIP product path against golden vectors produced by the reference
+(tests/golden/make_golden.py) and against the CPU oracle at the real layer widths.
+
+Tolerances (fp32): outputs atol/rtol 1e-4 (the fp32-vs-fp64 noise floor of the reference
+itself is 5e-7 at 256^2), gradients rtol 1e-3 (long reductions), PSNR vs oracle >= 100 dB.
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from hip_parity_utils import assert_close, psnr
+from synth import seeded_randn, synth_image, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_loss(outs, tag, seed):
+    flat = []
+    for o in outs:
+        flat.extend(o) if isinstance(o, (list, tuple)) else flat.append(o)
+    return sum((o * seeded_randn(f"{tag}.lw{i}", tuple(o.shape), seed).to(o.device)).sum() for i, o in enumerate(flat))
+
+
+@pytest.mark.parametrize("tag", ["alter", "alter_box"])
+def test_vunet_alter_vs_golden(tag):
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    meta, arr = load_golden("g2_" + tag)
+    seed, cfg, ncx = meta["seed"], meta["cfg"], meta["n_channels_x"]
+    net = VunetAlter(n_channels_x=ncx, **cfg)
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == meta["shapes"]
+    net.load_state_dict(synth_state_dict(meta["shapes"], seed), strict=True)
+    net = net.cuda().train()
+    x = synth_image(tag + ".x", tuple(meta["x"]), seed).cuda().requires_grad_(True)
+    c = synth_image(tag + ".c", tuple(meta["c"]), seed).cuda().requires_grad_(True)
+    eps = [seeded_randn(f"{tag}.eps{i}", tuple(s), seed).cuda() for i, s in enumerate(meta["eps_shapes"])]
+    img, means, logstds, acts = net(x, c, eps)
+    assert_close(img, arr["img"], name="img")
+    for i in range(len(means)):
+        assert_close(means[i], arr[f"mean{i}"], name=f"mean{i}")
+        assert_close(logstds[i], arr[f"logstd{i}"], name=f"logstd{i}")
+    _model_loss([img, means, logstds], tag, seed).backward()
+    assert_close(x.grad, arr["gx"], rtol=1e-3, atol=1e-5, name="gx")
+    assert_close(c.grad, arr["gc"], rtol=1e-3, atol=1e-5, name="gc")
+    params = dict(net.named_parameters())
+    for k, v in arr.items():
+        if k.startswith("gp."):
+            assert_close(params[k[3:]].grad, v, rtol=1e-3, atol=2e-4, name=k)
+    for k, s in meta["grad_sums"].items():
+        g = params[k].grad
+        if s is None:
+            assert g is None or float(g.abs().sum()) == 0.0, k
+        else:
+            got = float(g.double().abs().sum())
+            assert abs(got - s[1]) <= 1e-3 * s[1] + 1e-4, (k, got, s[1])
+    net.eval()
+    with torch.no_grad():
+        eps_t = [seeded_randn(f"{tag}.tr.eps{i}", tuple(s), seed).cuda() for i, s in enumerate(meta["eps_shapes"])]
+        assert_close(net.transfer(x, c, eps_t), arr["transfer"], name="transfer")
+        pe = [seeded_randn(f"{tag}.tf.eps{i}", tuple(s), seed).cuda() for i, s in enumerate(meta["tf_eps_shapes"])]
+        assert_close(net.test_forward(c, pe), arr["test_forward"], name="test_forward")
+
+
+def test_vunet_org_vs_golden():
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetOrg
+    from behavior_driven_video_synthesis_amd.lib.losses import compute_kl_loss
+    tag = "org"
+    meta, arr = load_golden("g2_org")
+    seed, cfg = meta["seed"], meta["cfg"]
+    net = VunetOrg(n_channels_x=3, **cfg)
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == meta["shapes"]
+    net.load_state_dict(synth_state_dict(meta["shapes"], seed))
+    net = net.cuda().train()
+    x = synth_image(tag + ".x", tuple(meta["x"]), seed).cuda().requires_grad_(True)
+    c = synth_image(tag + ".c", tuple(meta["c"]), seed).cuda().requires_grad_(True)
+    shapes, n_lat = meta["eps_shapes"], cfg["n_latent_scales"]
+    eps = [seeded_randn(f"{tag}.eps{i}", tuple(shapes[i]), seed).cuda() for i in range(n_lat)]
+    prior = [[seeded_randn(f"{tag}.eps{n_lat + 4 * i + l}", tuple(shapes[n_lat + 4 * i + l]), seed).cuda()
+              for l in range(4)] for i in range(n_lat)]
+    img, qs, ps, _ = net(x, c, eps, prior)
+    assert_close(img, arr["img"], name="img")
+    for i in range(n_lat):
+        assert_close(qs[i], arr[f"q{i}"], name=f"q{i}")
+        assert_close(ps[i], arr[f"p{i}"], name=f"p{i}")
+    assert_close(compute_kl_loss(ps, qs), arr["kl"], rtol=1e-4, name="kl")
+    _model_loss([img, qs, ps], tag, seed).backward()
+    assert_close(x.grad, arr["gx"], rtol=1e-3, atol=1e-5, name="gx")
+    assert_close(c.grad, arr["gc"], rtol=1e-3, atol=1e-5, name="gc")
+    params = dict(net.named_parameters())
+    for k, s in meta["grad_sums"].items():
+        if s is not None:
+            got = float(params[k].grad.double().abs().sum())
+            assert abs(got - s[1]) <= 1e-3 * s[1] + 1e-4, (k, got, s[1])
+
+
+def test_regressor_vs_golden():
+    from behavior_driven_video_synthesis_amd.models.vunets import Regressor
+    meta, arr = load_golden("g2_regressor")
+    reg = Regressor(n_out=34, n_latent_scales=2, nf_max=16, latent_widths=[8, 4], linear_width_factor=1)
+    assert {k: list(v.shape) for k, v in reg.state_dict().items()} == meta["shapes"]
+    reg.load_state_dict(synth_state_dict(meta["shapes"], meta["seed"]))
+    reg = reg.cuda()
+    e0 = seeded_randn("reg.e0", (2, 16, 4, 4), meta["seed"]).cuda()
+    e1 = seeded_randn("reg.e1", (2, 16, 8, 8), meta["seed"]).cuda()
+    assert_close(reg([e0, e1]), arr["out"], name="regressor")
+
+
+def test_losses_and_vgg_vs_golden():
+    from behavior_driven_video_synthesis_amd.lib.losses import compute_kl_loss, compute_kl_with_prior, vgg_loss
+    from behavior_driven_video_synthesis_amd.models.imagenet_pretrained import PerceptualVGG, vgg19
+    meta, arr = load_golden("g3_losses")
+    seed = meta["seed"]
+    means = [seeded_randn("kl.m0", (3, 16, 4, 4), seed).cuda(), seeded_randn("kl.m1", (3, 16, 8, 8), seed).cuda()]
+    logstds = [torch.sigmoid(seeded_randn("kl.l0", (3, 16, 4, 4), seed)).cuda(),
+               torch.sigmoid(seeded_randn("kl.l1", (3, 16, 8, 8), seed)).cuda()]
+    assert_close(compute_kl_with_prior(means, logstds), arr["kl"], rtol=1e-5, atol=1e-3, name="kl")
+    assert_close(compute_kl_loss([means[0]], [logstds[0]]), arr["latent_kl"], rtol=1e-5, atol=1e-3, name="latent_kl")
+    pv = PerceptualVGG(vgg19(seed=meta["vgg_seed"]), meta["loss_weights"]).cuda()
+    t = synth_image("vgg.t", (2, 3, 32, 32), seed).cuda()
+    p = synth_image("vgg.p", (2, 3, 32, 32), seed).cuda().requires_grad_(True)
+    feats = pv(t)
+    assert list(feats.keys()) == meta["tap_order"]
+    for k, v in feats.items():
+        d = v.double()
+        assert_close(torch.stack([d.mean(), d.abs().mean(), d.std()]), arr[f"tap.{k}.stats"], rtol=1e-4, atol=1e-6,
+                     name=k + ".stats")
+        assert_close(v.flatten()[:64], arr[f"tap.{k}.head"], rtol=1e-3, atol=1e-4, name=k + ".head")
+    ld = vgg_loss(pv, t, p)
+    for k, v in ld.items():
+        assert_close(v, arr["vggloss." + k], rtol=1e-4, atol=1e-6, name="vggloss." + k)
+    torch.stack(list(ld.values()), 0).sum().backward()
+    assert_close(p.grad, arr["vggloss.gp"], rtol=2e-3, atol=2e-6, name="vggloss.gp")
+
+
+def test_discriminators_vs_golden():
+    from behavior_driven_video_synthesis_amd.models.synth_discriminator import PartDiscriminator, PatchGANDiscriminator
+    meta, arr = load_golden("g4_discriminators")
+    seed = meta["seed"]
+    pd = PartDiscriminator(n_scales=2, part_size=16)
+    assert {k: list(v.shape) for k, v in pd.state_dict().items()} == meta["part_shapes"]
+    pd.load_state_dict(synth_state_dict(meta["part_shapes"], seed))
+    pd = pd.cuda()
+    x = synth_image("pd.x", (2, 3, 18, 18), seed).cuda()
+    assert_close(pd(x), arr["pd.out"], name="pd.out")
+
+    pg = PatchGANDiscriminator(3, ndf=8, n_layers=3)
+    assert {k: list(v.shape) for k, v in pg.state_dict().items()} == meta["patch_shapes"]
+    pg.load_state_dict(synth_state_dict(meta["patch_shapes"], seed))
+    pg = pg.cuda()
+    x = synth_image("pg.x", (2, 3, 32, 32), seed).cuda().requires_grad_(True)
+    out = pg(x)
+    assert_close(out, arr["pg.out"], name="pg.out")
+    (out * seeded_randn("pg.w", tuple(out.shape), seed).cuda()).sum().backward()
+    assert_close(x.grad, arr["pg.gx"], rtol=2e-3, atol=1e-4, name="pg.gx")
+    params = dict(pg.named_parameters())
+    for k, s in meta["pg_grad_sums"].items():
+        got = float(params[k].grad.double().abs().sum())
+        assert abs(got - s[1]) <= 2e-3 * s[1] + 1e-4, (k, got, s[1])
+
+
+def test_training_trajectory_vs_golden():
+    """K fused-Adam steps of the train_fn loss assembly reproduce the reference's torch.optim.Adam trajectory."""
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    from behavior_driven_video_synthesis_amd.models.imagenet_pretrained import PerceptualVGG, vgg19
+    from behavior_driven_video_synthesis_amd.lib.losses import compute_kl_with_prior, vgg_loss
+    from behavior_driven_video_synthesis_amd.optim import FusedAdam
+    from oracle import vunet_oracle as O
+    meta, arr = load_golden("g5_trajectory")
+    seed, cfg = meta["seed"], meta["cfg"]
+    net = VunetAlter(n_channels_x=3, **cfg)
+    net.load_state_dict(synth_state_dict(meta["shapes"], seed))
+    net = net.cuda().train()
+    pv = PerceptualVGG(vgg19(seed=meta["vgg_seed"], width_div=meta["vgg_width_div"]), [1.0] * 6).cuda()
+    opt = FusedAdam([{"params": list(getattr(net, n).parameters()), "name": n} for n in ["eu", "ed", "du", "dd"]],
+                    lr=meta["lr0"], betas=tuple(meta["betas"]))
+    gamma, lr = meta["gamma0"], meta["lr0"]
+    for rec in meta["steps"]:
+        it = rec["it"]
+        x = synth_image(f"traj.x{it}", (2, 3, 32, 32), seed).cuda()
+        c = synth_image(f"traj.c{it}", (2, 3, 32, 32), seed).cuda()
+        eps = [seeded_randn(f"traj.{it}.eps{i}", s, seed).cuda() for i, s in enumerate([(2, 16, 4, 4), (2, 16, 8, 8)])]
+        img, means, logstds, _ = net(x, c, eps)
+        ld = vgg_loss(pv, x, img)
+        ll = 1.0 * torch.sum(torch.stack([ld[k] for k in ld], dim=0))
+        kl = compute_kl_with_prior(means, logstds)
+        loss = ll + gamma * kl if it > meta["n_init_batches"] else ll
+        for got, key in ((loss, "loss"), (ll, "ll"), (kl, "kl")):
+            assert abs(float(got) - rec[key]) <= 5e-4 * abs(rec[key]) + 1e-5, (it, key, float(got), rec[key])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        gamma = O.update_gamma(gamma, meta["gamma_step"], meta["imax"], float(kl))
+        lr = O.linear_var(it, 0, meta["total_steps"], meta["lr0"], 0, 0, meta["lr0"])
+        for g in opt.param_groups:
+            g["lr"] = lr
+    sd = net.state_dict()
+    assert_close(sd["dd.out_conv.conv.weight_v"], arr["final.dd.out_conv.conv.weight_v"], rtol=2e-3, atol=2e-5,
+                 name="final weight")
+    for k, s in meta["param_checksums"].items():
+        got = float(sd[k].double().abs().sum())
+        assert abs(got - s[1]) <= 5e-4 * s[1] + 1e-5, (k, got, s[1])
+
+
+def test_full_width_vunet_vs_oracle():
+    """The real Human3.6m layer widths (nf 32..128, 7 scales) at 128^2, bs 2: HIP vs the CPU oracle."""
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    from oracle import vunet_oracle as O
+    cfg = dict(spatial_size=128, bottleneck_factor=2, box_factor=2, n_scales=0, n_latent_scales=2,
+               conv_layer_type="l1", nf_start=32, nf_max=128, subpixel_upsampling=True, dropout_prob=0.0)
+    net = VunetAlter(n_channels_x=3, **cfg)
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    sd = synth_state_dict(shapes, 3)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    x, c = synth_image("fx", (2, 3, 128, 128), 3), synth_image("fc", (2, 3, 128, 128), 3)
+    eps = [seeded_randn("fe0", (2, 128, 4, 4), 3), seeded_randn("fe1", (2, 128, 8, 8), 3)]
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    img_r, means_r, logstds_r, _ = O.vunet_alter_forward(sdr, cfg, x, c, eps)
+    wgt = seeded_randn("fw", tuple(img_r.shape), 3)
+    (img_r * wgt).sum().backward()
+    img, means, logstds, _ = net(x.cuda(), c.cuda(), [e.cuda() for e in eps])
+    scale = float(img_r.abs().max())
+    assert_close(img, img_r, rtol=1e-4, atol=1e-4 * max(scale, 1.0), name="img")
+    assert psnr(img, img_r, peak=2 * scale) >= 100.0
+    (img * wgt.cuda()).sum().backward()
+    for k, p in net.named_parameters():
+        gr = sdr[k].grad
+        if gr is None:
+            continue
+        tol = 2e-3 * float(gr.abs().max()) + 1e-6
+        assert_close(p.grad, gr, rtol=2e-3, atol=tol, name=k)
