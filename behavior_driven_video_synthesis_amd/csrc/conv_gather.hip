@@ -1,15 +1,23 @@
 // Generic implicit-GEMM convolution on fp32 MFMA, operands gathered straight from L1/L2.
 //
-//   D[m][px] = sum_k  W[k][m] * f(X)[k][px]          k = (source, tap, channel)
+//   D[m][px] = sum_k  W[k][m] * f(X)[k][px]          k = (source, channel pair, tap)
 //
 // One wave owns an (MT*32 channels) x (NT*32 pixels) output tile and issues
 // v_mfma_f32_32x32x2_f32: A = weights (lane: channel l&31, k-half l>>5), B = activations
 // (lane: pixel l&31, k-half l>>5).  Pixels are the MFMA column so that every accumulator
 // register stores 32 consecutive NCHW pixels of one channel (128-B segments).
 //
-// This kernel makes no assumption on the geometry (any kernel size / stride / padding / map
-// size, single or dual source, forward or transposed gather), so it is the fallback for the
-// shapes the LDS-tiled kernel (conv_tiled.hip) does not cover, and the data-gradient kernel.
+// K order is channel-pair outer, tap inner: the taps of one channel pair re-read the same cache
+// lines (L1 hits) and form one software-pipelined group -- all (MT+NT)*G loads of a group are
+// issued before its MT*NT*G MFMAs, so a wave keeps tens of loads in flight instead of paying one
+// L2 round trip per MFMA.
+//
+// This kernel makes no assumption on the geometry (any kernel size / stride / padding / map size,
+// single or dual source, forward or transposed gather): it is the data-gradient kernel and the
+// fallback for shapes the LDS-tiled kernel (conv_tiled.hip) does not take.  Small maps (few output
+// tiles, long K) go to the split-K variant: 16 waves of one workgroup share one 32x32 output tile,
+// each sums a strided subset of the channel pairs, partial tiles are reduced through LDS in a fixed
+// order (deterministic).
 #include "common.h"
 
 struct GatherArgs {
@@ -53,7 +61,190 @@ __device__ __forceinline__ float prologue(const InAct& a, float v, uint32_t idx)
   return apply_in_act(a, v, idx);
 }
 
-template <int MT, int NT, int PRO>
+// per-lane geometry of one 32-pixel tile: source base offsets and the tap validity bits
+struct TileGeo {
+  int base1, base2;
+  uint32_t vmask;  // bits 0..7 rows (kh), 8..15 cols (kw); 0 if the pixel is out of range
+};
+
+__device__ __forceinline__ TileGeo tile_geometry(const GatherArgs& a, int P) {
+  const vunet_conv_desc& d = a.d;
+  const PixGeo g = decompose(P, a.NP, a.HoWo, d.Wo);
+  const int s = d.stride, p = d.pad;
+  uint32_t rb = 0, cb = 0;
+  int sp;
+  if (d.mode == 0) {
+    const int ih0 = g.oh * s - p, iw0 = g.ow * s - p;
+    for (int k = 0; k < d.KH; ++k) rb |= ((unsigned)(ih0 + k) < (unsigned)d.Hs) << k;
+    for (int k = 0; k < d.KW; ++k) cb |= ((unsigned)(iw0 + k) < (unsigned)d.Ws) << k;
+    sp = ih0 * d.Ws + iw0;
+  } else {
+    const int ah = (g.oh + p) / s, rh = (g.oh + p) - ah * s;
+    const int aw = (g.ow + p) / s, rw = (g.ow + p) - aw * s;
+    for (int k = 0; k < d.KH; ++k) rb |= ((k % s == rh) && (unsigned)(ah - k / s) < (unsigned)d.Hs) << k;
+    for (int k = 0; k < d.KW; ++k) cb |= ((k % s == rw) && (unsigned)(aw - k / s) < (unsigned)d.Ws) << k;
+    sp = ah * d.Ws + aw;
+  }
+  TileGeo t;
+  t.base1 = g.n * d.C1 * a.HsWs + sp;
+  t.base2 = g.n * d.C2 * a.HsWs + sp;
+  t.vmask = g.valid ? (rb | (cb << 8)) : 0u;
+  return t;
+}
+
+__device__ __forceinline__ int tap_offset(const vunet_conv_desc& d, int kh, int kw) {
+  return d.mode == 0 ? kh * d.Ws + kw : -((kh / d.stride) * d.Ws + kw / d.stride);
+}
+
+// One K sweep over [c2_begin, Cp) step c2_step of one source, all taps.
+// KS: 3 -> 3x3 taps unrolled as one 9-step group per channel pair; 1 -> 1x1, groups of 8 channel
+// pairs; 0 -> generic runtime KH x KW, one step at a time.
+template <int MT, int NT, int PRO, int KS>
+__device__ __forceinline__ void k_sweep(const GatherArgs& a, const float* __restrict__ xs, const InAct& ia, int C,
+                                        int krow0, const int* base, const uint32_t* vmask, const bool* mok, int m0,
+                                        int j, int h, int c2_begin, int c2_step, f32x16 (&acc)[MT][NT]) {
+  const vunet_conv_desc& d = a.d;
+  const int Cp = (C + 1) & ~1;
+  const int HW2 = a.HsWs;
+  const float* __restrict__ wbase = a.wt + (size_t)d.m_off + m0 + j;
+
+  if (KS == 3) {
+    int toff[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) toff[t9] = tap_offset(d, t9 / 3, t9 % 3);
+    for (int c2 = c2_begin; c2 < Cp; c2 += c2_step) {
+      const int ci = c2 + h;
+      const bool cok = ci < C;
+      float av[9][MT], bv[9][NT];
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const float* wp = wbase + (size_t)(krow0 + t9 * Cp + ci) * d.Mpad;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[t9][mt] = mok[mt] ? wp[mt * 32] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bool ok = cok && (((vmask[t] >> (t9 / 3)) & (vmask[t] >> (8 + t9 % 3)) & 1u) != 0);
+          const int off = base[t] + ci * HW2 + toff[t9];
+          float v = 0.f;
+          if (ok) v = xs[off];
+          bv[t9][t] = prologue<PRO>(ia, v, (uint32_t)off);
+        }
+      }
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t9][mt], bv[t9][t], acc[mt][t], 0, 0, 0);
+    }
+  } else if (KS == 1) {
+    constexpr int G = 8;
+    bool tv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tv[t] = (vmask[t] & (vmask[t] >> 8) & 1u) != 0;
+    const int toff = tap_offset(d, 0, 0);
+    for (int c2 = c2_begin; c2 < Cp; c2 += G * c2_step) {
+      float av[G][MT], bv[G][NT];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int ci = c2 + u * c2_step + h;
+        const bool cok = ci < C;
+        const float* wp = wbase + (size_t)(krow0 + ci) * d.Mpad;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[u][mt] = (mok[mt] && ci < Cp) ? wp[mt * 32] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int off = base[t] + ci * HW2 + toff;
+          float v = 0.f;
+          if (tv[t] && cok) v = xs[off];
+          bv[u][t] = prologue<PRO>(ia, v, (uint32_t)off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][t], acc[mt][t], 0, 0, 0);
+    }
+  } else {
+    for (int c2 = c2_begin; c2 < Cp; c2 += c2_step) {
+      const int ci = c2 + h;
+      const bool cok = ci < C;
+      int tap = 0;
+      for (int kh = 0; kh < d.KH; ++kh) {
+        for (int kw = 0; kw < d.KW; ++kw, ++tap) {
+          const int toff = tap_offset(d, kh, kw);
+          const float* wp = wbase + (size_t)(krow0 + tap * Cp + ci) * d.Mpad;
+          float av[MT], bv[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) av[mt] = mok[mt] ? wp[mt * 32] : 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const bool ok = cok && (((vmask[t] >> kh) & (vmask[t] >> (8 + kw)) & 1u) != 0);
+            const int off = base[t] + ci * HW2 + toff;
+            float v = 0.f;
+            if (ok) v = xs[off];
+            bv[t] = prologue<PRO>(ia, v, (uint32_t)off);
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[t], acc[mt][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int PRO, int KS>
+__device__ __forceinline__ void k_loop(const GatherArgs& a, const TileGeo* tg, const bool* mok, int m0, int j, int h,
+                                       int c2_begin, int c2_step, f32x16 (&acc)[MT][NT]) {
+  const vunet_conv_desc& d = a.d;
+  int base[NT];
+  uint32_t vmask[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { base[t] = tg[t].base1; vmask[t] = tg[t].vmask; }
+  k_sweep<MT, NT, PRO, KS>(a, a.x1, a.in1, d.C1, 0, base, vmask, mok, m0, j, h, c2_begin, c2_step, acc);
+  if (d.C2 > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) base[t] = tg[t].base2;
+    const int krow2 = d.KH * d.KW * ((d.C1 + 1) & ~1);
+    k_sweep<MT, NT, PRO, KS>(a, a.x2, a.in2, d.C2, krow2, base, vmask, mok, m0, j, h, c2_begin, c2_step, acc);
+  }
+}
+
+// epilogue of one accumulator element
+__device__ __forceinline__ void store_out(const GatherArgs& a, const PixGeo& g, int m, float v) {
+  const vunet_conv_desc& d = a.d;
+  const int pix = g.oh * d.Wo + g.ow;
+  if (d.mode == 0) {
+    if (a.shift) v += a.shift[m];
+    if (d.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (d.out_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+    else if (d.out_act == ACT_ELU) v = elu_f(v);
+    else if (d.out_act == ACT_LRELU) v = v > 0.f ? v : v * d.in_slope;
+    size_t o;
+    if (d.d2s) {
+      const int Cq = d.M >> 2, blk = m / Cq, c = m - blk * Cq;
+      o = ((size_t)(g.n * Cq + c) * (2 * d.Ho) + (2 * g.oh + (blk >> 1))) * (2 * d.Wo) + 2 * g.ow + (blk & 1);
+    } else {
+      o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
+    }
+    if (a.res) v += a.res[o];
+    a.y[o] = v;
+  } else {
+    const size_t o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
+    if (a.aux) v *= in_act_grad(a.auxa, a.aux[o], (uint32_t)o);
+    if (a.res) v += a.res[o];
+    a.y[o] = v;
+  }
+}
+
+template <int MT, int NT, int PRO, int KS>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -66,31 +257,9 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
   const int tile0 = (pb * 4 + wave) * NT;
   if (tile0 * 32 >= a.NP) return;  // whole wave out of range (no barriers in this kernel)
 
-  // ---- per-lane pixel geometry for each pixel tile
-  int base1[NT], base2[NT];
-  uint32_t vmask[NT];
-  const int s = d.stride, p = d.pad;
+  TileGeo tg[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const PixGeo g = decompose((tile0 + t) * 32 + j, a.NP, a.HoWo, d.Wo);
-    uint32_t rb = 0, cb = 0;
-    int sp;
-    if (d.mode == 0) {
-      const int ih0 = g.oh * s - p, iw0 = g.ow * s - p;
-      for (int k = 0; k < d.KH; ++k) rb |= ((unsigned)(ih0 + k) < (unsigned)d.Hs) << k;
-      for (int k = 0; k < d.KW; ++k) cb |= ((unsigned)(iw0 + k) < (unsigned)d.Ws) << k;
-      sp = ih0 * d.Ws + iw0;
-    } else {
-      const int ah = (g.oh + p) / s, rh = (g.oh + p) - ah * s;
-      const int aw = (g.ow + p) / s, rw = (g.ow + p) - aw * s;
-      for (int k = 0; k < d.KH; ++k) rb |= ((k % s == rh) && (unsigned)(ah - k / s) < (unsigned)d.Hs) << k;
-      for (int k = 0; k < d.KW; ++k) cb |= ((k % s == rw) && (unsigned)(aw - k / s) < (unsigned)d.Ws) << k;
-      sp = ah * d.Ws + aw;
-    }
-    base1[t] = g.n * d.C1 * a.HsWs + sp;
-    base2[t] = g.n * d.C2 * a.HsWs + sp;
-    vmask[t] = g.valid ? (rb | (cb << 8)) : 0u;
-  }
+  for (int t = 0; t < NT; ++t) tg[t] = tile_geometry(a, (tile0 + t) * 32 + j);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -99,106 +268,100 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.f;
-
   bool mok[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) mok[mt] = (m0 + mt * 32 + j) < d.M;
 
-  int krow = 0;
-  for (int src = 0; src < 2; ++src) {
-    const int C = src ? d.C2 : d.C1;
-    if (C == 0) continue;
-    const int Cp = (C + 1) & ~1;
-    const float* __restrict__ xs = src ? a.x2 : a.x1;
-    const InAct ia = src ? a.in2 : a.in1;
-    for (int kh = 0; kh < d.KH; ++kh) {
-      for (int kw = 0; kw < d.KW; ++kw) {
-        const int toff = d.mode == 0 ? kh * d.Ws + kw : -((kh / s) * d.Ws + kw / s);
-        int off[NT];
-        bool tv[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          tv[t] = ((vmask[t] >> kh) & (vmask[t] >> (8 + kw)) & 1u) != 0;
-          off[t] = (src ? base2[t] : base1[t]) + toff + h * a.HsWs;
-        }
-        const float* __restrict__ wp = a.wt + (size_t)(krow + h) * d.Mpad + d.m_off + m0 + j;
-        const bool odd_tail = (C & 1) && h;  // last k-step: the h=1 half has no channel
-        for (int c2 = 0; c2 < Cp; c2 += 2) {
-          float av[MT], bv[NT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[mt] = mok[mt] ? wp[mt * 32] : 0.f;
-          const bool cok = !(odd_tail && (c2 + 2 >= Cp));
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            float v = 0.f;
-            if (tv[t] && cok) v = xs[off[t]];
-            bv[t] = prologue<PRO>(ia, v, (uint32_t)off[t]);
-            off[t] += 2 * a.HsWs;
-          }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-              acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[t], acc[mt][t], 0, 0, 0);
-          wp += 2 * (size_t)d.Mpad;
-        }
-        krow += Cp;
-      }
-    }
-  }
+  k_loop<MT, NT, PRO, KS>(a, tg, mok, m0, j, h, 0, 2, acc);
 
-  // ---- epilogue
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const PixGeo g = decompose((tile0 + t) * 32 + j, a.NP, a.HoWo, d.Wo);
     if (!g.valid) continue;
-    const int pix = g.oh * d.Wo + g.ow;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= d.M) continue;
-        float v = acc[mt][t][r];
-        if (d.mode == 0) {
-          if (a.shift) v += a.shift[m];
-          if (d.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
-          else if (d.out_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-          else if (d.out_act == ACT_ELU) v = elu_f(v);
-          else if (d.out_act == ACT_LRELU) v = v > 0.f ? v : v * d.in_slope;
-          size_t o;
-          if (d.d2s) {
-            const int Cq = d.M >> 2, blk = m / Cq, c = m - blk * Cq;
-            o = ((size_t)(g.n * Cq + c) * (2 * d.Ho) + (2 * g.oh + (blk >> 1))) * (2 * d.Wo) + 2 * g.ow + (blk & 1);
-          } else {
-            o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
-          }
-          if (a.res) v += a.res[o];
-          a.y[o] = v;
-        } else {
-          const size_t o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
-          if (a.aux) v *= in_act_grad(a.auxa, a.aux[o], (uint32_t)o);
-          if (a.res) v += a.res[o];
-          a.y[o] = v;
-        }
+        if (m < d.M) store_out(a, g, m, acc[mt][t][r]);
       }
-    }
   }
 }
 
-template <int MT, int NT>
+// ---- split-K variant for small maps: one 32x32 output tile per workgroup, SW waves share K
+template <int SW, int PRO, int KS>
+__global__ __launch_bounds__(SW * 64) void conv_gather_splitk_kernel(const GatherArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [SW][16][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const vunet_conv_desc& d = a.d;
+  const int mblocks = (d.M + 31) / 32;
+  const int mb = blockIdx.x % mblocks, pb = blockIdx.x / mblocks;
+  const int m0 = mb * 32;
+
+  TileGeo tg[1];
+  tg[0] = tile_geometry(a, pb * 32 + j);
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  bool mok[1];
+  mok[0] = (m0 + j) < d.M;
+
+  k_loop<1, 1, PRO, KS>(a, tg, mok, m0, j, h, 2 * wave, 2 * SW, acc);
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+  __syncthreads();
+  // wave w finishes accumulator register r = w, w + SW, ... (fixed summation order over the waves)
+  const PixGeo g = decompose(pb * 32 + j, a.NP, a.HoWo, d.Wo);
+  for (int r = wave; r < 16; r += SW) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SW; ++w) v += red[(w * 16 + r) * 64 + lane];
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (g.valid && m < d.M) store_out(a, g, m, v);
+  }
+}
+
+template <int MT, int NT, int KS>
 static int launch_gather(const GatherArgs& ga, int pro, hipStream_t st) {
   const int ntiles = (ga.NP + 31) / 32;
   const int pblocks = (ntiles + 4 * NT - 1) / (4 * NT);
   const int mblocks = (ga.d.M + 32 * MT - 1) / (32 * MT);
   dim3 grid((unsigned)(pblocks * mblocks)), block(256);
   switch (pro) {
-    case 0: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 0>), grid, block, 0, st, ga); break;
-    case 1: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 1>), grid, block, 0, st, ga); break;
-    case 2: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 2>), grid, block, 0, st, ga); break;
-    default: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 3>), grid, block, 0, st, ga); break;
+    case 0: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 0, KS>), grid, block, 0, st, ga); break;
+    case 1: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 1, KS>), grid, block, 0, st, ga); break;
+    case 2: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 2, KS>), grid, block, 0, st, ga); break;
+    default: VUNET_LAUNCH((conv_gather_kernel<MT, NT, 3, KS>), grid, block, 0, st, ga); break;
   }
   return vunet_check_launch();
+}
+
+template <int KS>
+static int launch_splitk(const GatherArgs& ga, int pro, hipStream_t st) {
+  constexpr int SW = 16;
+  const int ntiles = (ga.NP + 31) / 32, mblocks = (ga.d.M + 31) / 32;
+  dim3 grid((unsigned)(ntiles * mblocks)), block(SW * 64);
+  const size_t lds = (size_t)SW * 16 * 64 * sizeof(float);
+  switch (pro) {
+    case 0: VUNET_LAUNCH((conv_gather_splitk_kernel<SW, 0, KS>), grid, block, lds, st, ga); break;
+    case 1: VUNET_LAUNCH((conv_gather_splitk_kernel<SW, 1, KS>), grid, block, lds, st, ga); break;
+    case 2: VUNET_LAUNCH((conv_gather_splitk_kernel<SW, 2, KS>), grid, block, lds, st, ga); break;
+    default: VUNET_LAUNCH((conv_gather_splitk_kernel<SW, 3, KS>), grid, block, lds, st, ga); break;
+  }
+  return vunet_check_launch();
+}
+
+template <int KS>
+static int dispatch_gather(const GatherArgs& ga, int pro, hipStream_t st) {
+  const vunet_conv_desc& d = ga.d;
+  const int ntiles = (ga.NP + 31) / 32, mtiles = (d.M + 31) / 32;
+  const int kpairs = (((d.C1 + 1) >> 1) + ((d.C2 + 1) >> 1));
+  // few output tiles and a long K: share each tile's K loop between 16 waves
+  if ((long)ntiles * mtiles <= 768 && kpairs >= 32) return launch_splitk<KS>(ga, pro, st);
+  if (d.M <= 32) return launch_gather<1, 4, KS>(ga, pro, st);
+  return launch_gather<2, 2, KS>(ga, pro, st);
 }
 
 extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
@@ -228,6 +391,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   else if (d->in_act == ACT_ELU && d->drop_p <= 0.f) pro = 1;
   else if (d->in_act == ACT_ELU) pro = 2;
   hipStream_t st = (hipStream_t)stream;
-  if (d->M <= 32) return launch_gather<1, 4>(ga, pro, st);
-  return launch_gather<2, 2>(ga, pro, st);
+  if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
+  if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);
+  return dispatch_gather<0>(ga, pro, st);
 }
