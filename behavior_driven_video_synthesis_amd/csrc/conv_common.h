@@ -1,0 +1,73 @@
+// Shared pieces of the convolution kernels (conv_gather.hip, conv_tiled.hip): launch arguments,
+// pixel decomposition, the prologue (input activation / dropout) and the fused epilogue.
+#pragma once
+#include "common.h"
+
+struct GatherArgs {
+  vunet_conv_desc d;
+  const float* x1;
+  const float* x2;
+  const float* wt;
+  const float* shift;
+  const float* res;
+  const float* aux;
+  float* y;
+  int NP, HoWo, HsWs;
+  InAct in1, in2, auxa;
+};
+
+struct PixGeo {
+  int n, oh, ow;
+  bool valid;
+};
+
+__device__ __forceinline__ PixGeo decompose(int P, int NP, int HoWo, int Wo) {
+  PixGeo g;
+  g.valid = P < NP;
+  const int Pc = g.valid ? P : 0;
+  g.n = Pc / HoWo;
+  const int rem = Pc - g.n * HoWo;
+  g.oh = rem / Wo;
+  g.ow = rem - g.oh * Wo;
+  return g;
+}
+
+// PRO: 0 = no prologue activation, 1 = ELU, 2 = ELU + dropout, 3 = generic (runtime InAct)
+template <int PRO>
+__device__ __forceinline__ float prologue(const InAct& a, float v, uint32_t idx) {
+  if (PRO == 0) return v;
+  if (PRO == 1) return elu_f(v);
+  if (PRO == 2) {
+    v = elu_f(v);
+    return (vunet_hash_u32(idx + a.seed) >= a.thresh) ? v * a.keep_scale : 0.f;
+  }
+  return apply_in_act(a, v, idx);
+}
+
+// epilogue of one accumulator element
+__device__ __forceinline__ void store_out(const GatherArgs& a, const PixGeo& g, int m, float v) {
+  const vunet_conv_desc& d = a.d;
+  const int pix = g.oh * d.Wo + g.ow;
+  if (d.mode == 0) {
+    if (a.shift) v += a.shift[m];
+    if (d.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (d.out_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+    else if (d.out_act == ACT_ELU) v = elu_f(v);
+    else if (d.out_act == ACT_LRELU) v = v > 0.f ? v : v * d.in_slope;
+    size_t o;
+    if (d.d2s) {
+      const int Cq = d.M >> 2, blk = m / Cq, c = m - blk * Cq;
+      o = ((size_t)(g.n * Cq + c) * (2 * d.Ho) + (2 * g.oh + (blk >> 1))) * (2 * d.Wo) + 2 * g.ow + (blk & 1);
+    } else {
+      o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
+    }
+    if (a.res) v += a.res[o];
+    a.y[o] = v;
+  } else {
+    const size_t o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
+    if (a.aux) v *= in_act_grad(a.auxa, a.aux[o], (uint32_t)o);
+    if (a.res) v += a.res[o];
+    a.y[o] = v;
+  }
+}
+

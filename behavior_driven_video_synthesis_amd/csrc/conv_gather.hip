@@ -18,48 +18,7 @@
 // tiles, long K) go to the split-K variant: 16 waves of one workgroup share one 32x32 output tile,
 // each sums a strided subset of the channel pairs, partial tiles are reduced through LDS in a fixed
 // order (deterministic).
-#include "common.h"
-
-struct GatherArgs {
-  vunet_conv_desc d;
-  const float* x1;
-  const float* x2;
-  const float* wt;
-  const float* shift;
-  const float* res;
-  const float* aux;
-  float* y;
-  int NP, HoWo, HsWs;
-  InAct in1, in2, auxa;
-};
-
-struct PixGeo {
-  int n, oh, ow;
-  bool valid;
-};
-
-__device__ __forceinline__ PixGeo decompose(int P, int NP, int HoWo, int Wo) {
-  PixGeo g;
-  g.valid = P < NP;
-  const int Pc = g.valid ? P : 0;
-  g.n = Pc / HoWo;
-  const int rem = Pc - g.n * HoWo;
-  g.oh = rem / Wo;
-  g.ow = rem - g.oh * Wo;
-  return g;
-}
-
-// PRO: 0 = no prologue activation, 1 = ELU, 2 = ELU + dropout, 3 = generic (runtime InAct)
-template <int PRO>
-__device__ __forceinline__ float prologue(const InAct& a, float v, uint32_t idx) {
-  if (PRO == 0) return v;
-  if (PRO == 1) return elu_f(v);
-  if (PRO == 2) {
-    v = elu_f(v);
-    return (vunet_hash_u32(idx + a.seed) >= a.thresh) ? v * a.keep_scale : 0.f;
-  }
-  return apply_in_act(a, v, idx);
-}
+#include "conv_common.h"
 
 // per-lane geometry of one 32-pixel tile: source base offsets and the tap validity bits
 struct TileGeo {
@@ -217,33 +176,6 @@ __device__ __forceinline__ void k_loop(const GatherArgs& a, const TileGeo* tg, c
   }
 }
 
-// epilogue of one accumulator element
-__device__ __forceinline__ void store_out(const GatherArgs& a, const PixGeo& g, int m, float v) {
-  const vunet_conv_desc& d = a.d;
-  const int pix = g.oh * d.Wo + g.ow;
-  if (d.mode == 0) {
-    if (a.shift) v += a.shift[m];
-    if (d.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
-    else if (d.out_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-    else if (d.out_act == ACT_ELU) v = elu_f(v);
-    else if (d.out_act == ACT_LRELU) v = v > 0.f ? v : v * d.in_slope;
-    size_t o;
-    if (d.d2s) {
-      const int Cq = d.M >> 2, blk = m / Cq, c = m - blk * Cq;
-      o = ((size_t)(g.n * Cq + c) * (2 * d.Ho) + (2 * g.oh + (blk >> 1))) * (2 * d.Wo) + 2 * g.ow + (blk & 1);
-    } else {
-      o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
-    }
-    if (a.res) v += a.res[o];
-    a.y[o] = v;
-  } else {
-    const size_t o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
-    if (a.aux) v *= in_act_grad(a.auxa, a.aux[o], (uint32_t)o);
-    if (a.res) v += a.res[o];
-    a.y[o] = v;
-  }
-}
-
 template <int MT, int NT, int PRO, int KS>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -364,6 +296,11 @@ static int dispatch_gather(const GatherArgs& ga, int pro, hipStream_t st) {
   return launch_gather<2, 2, KS>(ga, pro, st);
 }
 
+// conv_tiled.hip: LDS-tiled kernel for the 3x3 / stride-1 layers on maps at least 32 wide
+bool vunet_conv_tiled_applicable(const vunet_conv_desc* d);
+int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT);
+int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st);
+
 extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
                                    const float* shift, const float* res, const float* aux, float* y,
                                    void* stream) {
@@ -391,6 +328,10 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   else if (d->in_act == ACT_ELU && d->drop_p <= 0.f) pro = 1;
   else if (d->in_act == ACT_ELU) pro = 2;
   hipStream_t st = (hipStream_t)stream;
+  const bool no_tiled = getenv("VUNET_NO_TILED") != nullptr;
+  int mt_unused;
+  if (!no_tiled && vunet_conv_tiled_applicable(d) && (d->mode == 0 || pro == 0) && pro != 3 && vunet_conv_tiled_pick(d, &mt_unused) > 0)
+    return vunet_conv_tiled_launch(ga, pro, st);
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
   if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);
   return dispatch_gather<0>(ga, pro, st);

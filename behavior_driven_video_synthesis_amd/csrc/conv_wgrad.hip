@@ -143,8 +143,15 @@ static void wgrad_geometry(const vunet_wgrad_desc* d, int& T, int& Ctot, int& Co
   if (T > 9 && WM == 4) WM = 2;
 }
 
+// conv_wgrad_tiled.hip: LDS halo-tile kernel for the 3x3 / stride-1 layers that carry the FLOPs
+bool vunet_wgrad_tiled_applicable(const vunet_wgrad_desc* d);
+int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d);
+int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
+                             float* slabs, float* dshift, hipStream_t st);
+
 extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
   if (!d) return VUNET_ERR_ARG;
+  if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_nslabs(d);
   int T, Ctot, Coutp, nchunks, WM;
   wgrad_geometry(d, T, Ctot, Coutp, nchunks, WM);
   const int ciblocks = (Ctot + 31) / 32, coblocks = (d->Cout + 32 * WM - 1) / (32 * WM);
@@ -160,6 +167,9 @@ static int launch_wgrad(const WgradArgs& wa, hipStream_t st) {
   const int ciblocks = (wa.Ctot + 31) / 32, coblocks = (wa.d.Cout + 32 * WM - 1) / (32 * WM);
   dim3 grid(wa.d.nsplit, ciblocks, coblocks), block(256);
   const size_t lds = (size_t)(32 * WM + wa.T * 32) * 33 * sizeof(float);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute((const void*)conv_wgrad_kernel<WM, WN, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
   VUNET_LAUNCH((conv_wgrad_kernel<WM, WN, NTW>), grid, block, lds, st, wa);
   return vunet_check_launch();
 }
@@ -172,6 +182,7 @@ extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, co
   const int64_t in_elems = (int64_t)d->N * (d->C1 > d->C2 ? d->C1 : d->C2) * d->Hs * d->Ws;
   const int64_t out_elems = (int64_t)d->N * d->Cout * d->Ho * d->Wo;
   if (in_elems >= (1ll << 31) || out_elems >= (1ll << 31)) return VUNET_ERR_UNSUPPORTED;
+  if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
   WgradArgs wa;
   wa.d = *d;
   wa.x1 = x1; wa.x2 = x2; wa.dy = dy; wa.slabs = slabs; wa.dshift = dshift;

@@ -1,0 +1,209 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution on fp32 MFMA -- LDS halo-tile kernel.
+//
+//   dW[co][tap][ci] = sum_px dy[co][px] * f(x)[ci][px (+) tap]          (K = pixels)
+//
+// A workgroup owns MTW*32 output channels x 32 input channels x 9 taps and walks rectangular
+// TH x 32 pixel tiles (split-K over tiles).  Per tile it stages into LDS, once per element,
+//   fxL[32 ci][TH+2][34] (+1 dword per channel: odd pitch, conflict-free column reads)
+//       = prologue-activated input with halo (ELU / dropout hash applied here, not per tap)
+//   dyL[MTW*32 co][TH*32] (+1 dword per row)
+// and every wave runs v_mfma_f32_32x32x2_f32 with A = dy (lane: co, k-half: pixel parity) and
+// B = f(x) shifted by the tap (lane: ci) into 9 accumulator tiles.  The 4 waves split the
+// (m-tile, pixel-row) space; waves that share an m-tile write separate slabs, which
+// vunet_weightnorm_bwd sums in a fixed order (deterministic, no atomics).
+#include "common.h"
+
+struct WgradTiledArgs {
+  vunet_wgrad_desc d;
+  const float* x1;
+  const float* x2;
+  const float* dy;
+  float* slabs;
+  float* dshift;
+  int HW, Ctot, Coutp, tiles_per_img_w, tiles_per_img, ntiles, tps, S;
+  InAct in1, in2;
+};
+
+template <int MTW, int TH>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTiledArgs a) {
+  constexpr int WP = 4 / MTW;        // pixel parts (waves sharing one m-tile)
+  constexpr int RW = TH / WP;        // tile rows per wave
+  constexpr int IH = TH + 2, IW = 34;
+  constexpr int CS = IH * IW + 1;    // fx channel pitch (odd)
+  constexpr int PS = TH * 32 + 1;    // dy row pitch (odd)
+  constexpr int MB = 32 * MTW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* fxL = smem;                 // [32][CS]
+  float* dyL = smem + 32 * CS;       // [MB][PS]
+
+  const vunet_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int wm = wave / WP, pw = wave % WP;
+  const int split = blockIdx.x;
+  const int ci0 = blockIdx.y * 32;
+  const int co0 = blockIdx.z * MB;
+  const int H = d.Hs, W = d.Ws;
+
+  // source of this input-channel block (C1 % 32 == 0 is a precondition of this kernel)
+  const bool second = ci0 >= d.C1;
+  const float* __restrict__ xs = second ? a.x2 : a.x1;
+  const int Cs = second ? d.C2 : d.C1;
+  const int cbase = second ? ci0 - d.C1 : ci0;
+  const InAct ia = second ? a.in2 : a.in1;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float dsum = 0.f;
+
+  const int t_begin = split * a.tps;
+  const int t_end = min(t_begin + a.tps, a.ntiles);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int n = tile / a.tiles_per_img;
+    const int tr = tile - n * a.tiles_per_img;
+    const int ty = tr / a.tiles_per_img_w, tx = tr - ty * a.tiles_per_img_w;
+    const int row0 = ty * TH, col0 = tx * 32;
+
+    __syncthreads();  // previous tile's LDS reads are done
+    // ---- stage f(x) with halo: 32 x IH x 34 elements, in register batches of BF
+    {
+      constexpr int E = 32 * IH * IW;
+      constexpr int NI = (E + 255) / 256;
+      constexpr int BF = 9;
+#pragma unroll 1
+      for (int i0 = 0; i0 < NI; i0 += BF) {
+        float v[BF];
+        int go[BF];
+#pragma unroll
+        for (int u = 0; u < BF; ++u) {
+          const int e = tid + 256 * (i0 + u);
+          const int c = e / (IH * IW);
+          const int rem = e - c * (IH * IW);
+          const int r = rem / IW, col = rem - r * IW;
+          const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+          const bool ok = e < E && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+          go[u] = ok ? ((n * Cs + cbase + c) * H + ih) * W + iw : -1;
+          v[u] = ok ? xs[go[u]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < BF; ++u) {
+          const int e = tid + 256 * (i0 + u);
+          if (e < E) {
+            const int c = e / (IH * IW);
+            fxL[e + c] = go[u] >= 0 ? apply_in_act(ia, v[u], (uint32_t)go[u]) : 0.f;  // c*CS + rem == e + c
+          }
+        }
+      }
+    }
+    // ---- stage dy: MB x TH x 32 elements, in register batches of 8
+    {
+      constexpr int E = MB * TH * 32;
+      constexpr int NI = E / 256;
+#pragma unroll 1
+      for (int i0 = 0; i0 < NI; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = tid + 256 * (i0 + u);
+          const int co = e / (TH * 32), p = e % (TH * 32);
+          const int cog = co0 + co;
+          v[u] = cog < d.Cout ? a.dy[((size_t)(n * d.Cout + cog) * H + row0 + (p >> 5)) * W + col0 + (p & 31)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = tid + 256 * (i0 + u);
+          dyL[(e / (TH * 32)) * PS + e % (TH * 32)] = v[u];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA: this wave's RW rows x 32 columns = RW*16 k-steps, 9 taps each
+    const float* aP = dyL + (wm * 32 + j) * PS + pw * RW * 32 + h;
+    const float* bP = fxL + j * CS + pw * RW * IW + h;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const float av = aP[rr * 32 + 2 * s];
+        dsum += av;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float bv = bP[(rr + t / 3) * IW + 2 * s + t % 3];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- partial slab of this (split, pixel part):  [slab][Coutp][9*Ctot], k order (tap, ci)
+  const size_t KT = (size_t)9 * a.Ctot;
+  const int slab_id = split * WP + pw;
+  float* slab = a.slabs + (size_t)slab_id * a.Coutp * KT;
+  const int ci = ci0 + j;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < d.Cout) slab[(size_t)co * KT + (size_t)t * a.Ctot + ci] = acc[t][r];
+    }
+  }
+  if (blockIdx.y == 0) {
+    const float tot = dsum + __shfl_xor(dsum, 32, 64);
+    const int co = co0 + wm * 32 + j;
+    if (h == 0 && co < a.Coutp) a.dshift[(size_t)slab_id * a.Coutp + co] = co < d.Cout ? tot : 0.f;
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+bool vunet_wgrad_tiled_applicable(const vunet_wgrad_desc* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ws % 32 == 0 && d->Hs % 4 == 0 &&
+         d->Ho == d->Hs && d->Wo == d->Ws && d->C1 % 32 == 0 && d->C2 % 32 == 0 && d->Cout % 32 == 0;
+}
+
+static void tiled_geometry(const vunet_wgrad_desc* d, int& MTW, int& WP, int& ntiles, int& ciblocks, int& coblocks) {
+  MTW = d->Cout >= 64 ? 2 : 1;
+  WP = 4 / MTW;
+  ntiles = d->N * (d->Hs / 4) * (d->Ws / 32);
+  ciblocks = (d->C1 + d->C2) / 32;
+  coblocks = d->Cout / (32 * MTW);
+}
+
+int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d) {
+  int MTW, WP, ntiles, ciblocks, coblocks;
+  tiled_geometry(d, MTW, WP, ntiles, ciblocks, coblocks);
+  int S = 1024 / (ciblocks * coblocks);
+  if (S > ntiles / 2) S = ntiles / 2;
+  if (S < 1) S = 1;
+  if (S > 128) S = 128;
+  return S * WP;
+}
+
+int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
+                             float* slabs, float* dshift, hipStream_t st) {
+  WgradTiledArgs a;
+  a.d = *d;
+  a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift;
+  int MTW, WP, ciblocks, coblocks;
+  tiled_geometry(d, MTW, WP, a.ntiles, ciblocks, coblocks);
+  if (d->nsplit % WP != 0) return VUNET_ERR_ARG;
+  a.S = d->nsplit / WP;
+  a.HW = d->Hs * d->Ws;
+  a.Ctot = d->C1 + d->C2;
+  a.Coutp = (d->Cout + 31) / 32 * 32;
+  a.tiles_per_img_w = d->Ws / 32;
+  a.tiles_per_img = (d->Hs / 4) * a.tiles_per_img_w;
+  a.tps = (a.ntiles + a.S - 1) / a.S;
+  a.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
+  a.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
+  dim3 grid(a.S, ciblocks, coblocks), block(256);
+  constexpr int TH = 4;
+  const size_t lds = (size_t)(32 * ((TH + 2) * 34 + 1) + 32 * MTW * (TH * 32 + 1)) * sizeof(float);
+  if (MTW == 1) VUNET_LAUNCH((conv_wgrad_tiled_kernel<1, TH>), grid, block, lds, st, a);
+  else VUNET_LAUNCH((conv_wgrad_tiled_kernel<2, TH>), grid, block, lds, st, a);
+  return vunet_check_launch();
+}

@@ -70,6 +70,9 @@ def test_primitive_vs_golden(case):
     (4, 128, 128, 4, 4, 3, 1, 1),     # bottleneck 4x4 map: tiles span images
     (2, 7, 9, 2, 2, 3, 1, 1),         # 2x2 map (Market config latents)
     (1, 16, 3, 40, 40, 3, 1, 1),      # out_conv-like: 3 output channels
+    (2, 32, 32, 8, 32, 3, 1, 1),      # LDS halo-tile wgrad path, one m-tile per workgroup
+    (1, 64, 128, 12, 64, 3, 1, 1),    # LDS halo-tile wgrad path, two m-tiles, several column tiles
+    (3, 32, 64, 4, 96, 3, 1, 1),      # tiled wgrad, more tiles than splits
 ])
 def test_normconv_vs_oracle(shape):
     """Fused NormConv2d fwd + dgrad + wgrad on shapes the golden file does not hold (edge cases)."""
@@ -126,6 +129,82 @@ def test_rnb_dropout_matches_oracle_with_same_mask():
     (y * wgt.cuda()).sum().backward()
     assert_close(xg.grad, xr.grad, name="dx")
     assert_close(ag.grad, ar.grad, name="da")
+    for k, pp in mod.named_parameters():
+        assert_close(pp.grad, sdr["m." + k].grad, rtol=1e-3, atol=2e-4, name=k)
+
+
+def test_rnb_dual_source_tiled_wgrad_vs_oracle():
+    """Residual block at 32 channels / 32-wide maps: dual-source conv through the tiled wgrad kernel, dropout on."""
+    from oracle import vunet_oracle as O
+    from behavior_driven_video_synthesis_amd import ops
+    M = _mods()
+    c, p = 32, 0.1
+    mod = M.VunetRNB(c, a_channels=c, residual=True, dropout_prob=p)
+    sd = synth_state_dict({k: list(v.shape) for k, v in mod.state_dict().items()}, 9)
+    mod.load_state_dict(sd)
+    mod = mod.cuda().train()
+    x, a = synth_image("x", (2, c, 8, 64), 9), synth_image("a", (2, c, 8, 64), 9)
+    ops.set_dropout_seed(77)
+    seed = ops.next_dropout_seed()
+    ops.set_dropout_seed(77)
+    xg, ag = x.cuda().requires_grad_(True), a.cuda().requires_grad_(True)
+    y = mod(xg, ag)
+    mask = torch.cat([dropout_keep_mask((2, c, 8, 64), p, seed),
+                      dropout_keep_mask((2, c, 8, 64), p, (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF)], dim=1)
+    sdr = {"m." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    yr = O.rnb(sdr, "m", xr, ar, drop_mask=mask, drop_p=p)
+    assert_close(y, yr, name="y")
+    wgt = seeded_randn("w", tuple(yr.shape), 9)
+    (yr * wgt).sum().backward()
+    (y * wgt.cuda()).sum().backward()
+    assert_close(xg.grad, xr.grad, name="dx")
+    assert_close(ag.grad, ar.grad, name="da")
+    for k, pp in mod.named_parameters():
+        assert_close(pp.grad, sdr["m." + k].grad, rtol=1e-3, atol=2e-4, name=k)
+
+
+@pytest.mark.parametrize("nt", [1, 2, 4])
+@pytest.mark.parametrize("cin,cout,dual", [(32, 32, False), (16, 64, True), (64, 128, False), (8, 3, False)])
+def test_lds_tiled_conv_vs_oracle(nt, cin, cout, dual, monkeypatch):
+    """LDS-tiled 3x3 kernel (forward with ELU+dropout prologue, data gradient with mirrored taps), every tile
+    height, one and two m-tiles, single and dual source; forced on small tensors through VUNET_TILED_FORCE_NT."""
+    from oracle import vunet_oracle as O
+    from behavior_driven_video_synthesis_amd import ops
+    M = _mods()
+    monkeypatch.setenv("VUNET_TILED_FORCE_NT", str(nt))
+    n, h, w, p = 2, 16, 64, 0.1
+    if dual:
+        mod = M.VunetRNB(cout, a_channels=cin, residual=True, dropout_prob=p)
+    else:
+        mod = M.NormConv2d(cin, cout, 3, 1, 1)
+    sd = synth_state_dict({k: list(v.shape) for k, v in mod.state_dict().items()}, 13)
+    mod.load_state_dict(sd)
+    mod = mod.cuda().train()
+    sdr = {"m." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    if dual:
+        x, a = synth_image("x", (n, cout, h, w), 13), synth_image("a", (n, cin, h, w), 13)
+        ops.set_dropout_seed(5)
+        seed = ops.next_dropout_seed()
+        ops.set_dropout_seed(5)
+        xg, ag = x.cuda().requires_grad_(True), a.cuda().requires_grad_(True)
+        y = mod(xg, ag)
+        mask = torch.cat([dropout_keep_mask((n, cout, h, w), p, seed),
+                          dropout_keep_mask((n, cout, h, w), p, (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF)], dim=1)
+        xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        yr = O.rnb(sdr, "m", xr, ar, drop_mask=mask, drop_p=p)
+        pairs = [(xg, xr, "dx"), (ag, ar, "da")]
+    else:
+        x = synth_image("x", (n, cin, h, w), 13)
+        xg, xr = x.cuda().requires_grad_(True), x.clone().requires_grad_(True)
+        y, yr = mod(xg), O.norm_conv(sdr, "m", xr, 1, 1)
+        pairs = [(xg, xr, "dx")]
+    assert_close(y, yr, name="y")
+    wgt = seeded_randn("w", tuple(yr.shape), 13)
+    (yr * wgt).sum().backward()
+    (y * wgt.cuda()).sum().backward()
+    for g, r, name in pairs:
+        assert_close(g.grad, r.grad, name=name)
     for k, pp in mod.named_parameters():
         assert_close(pp.grad, sdr["m." + k].grad, rtol=1e-3, atol=2e-4, name=k)
 
