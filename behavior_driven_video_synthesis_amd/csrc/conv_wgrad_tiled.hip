@@ -139,23 +139,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
     }
   }
 
-  // ---- partial slab of this (split, pixel part):  [slab][Coutp][9*Ctot], k order (tap, ci)
-  const size_t KT = (size_t)9 * a.Ctot;
-  const int slab_id = split * WP + pw;
-  float* slab = a.slabs + (size_t)slab_id * a.Coutp * KT;
-  const int ci = ci0 + j;
+  // ---- fold the WP pixel-part waves of each m-tile into the pw == 0 wave through LDS (fixed order),
+  //      one tap at a time (16 KiB), so that one slab per split leaves the workgroup
+  if (WP > 1) {
+    float* red = smem;  // [4 waves][16][64]
+    float ds_other = 0.f;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < 9; ++t) {
+      __syncthreads();
+      if (pw != 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < d.Cout) slab[(size_t)co * KT + (size_t)t * a.Ctot + ci] = acc[t][r];
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (pw == 0) {
+#pragma unroll
+        for (int o = 1; o < WP; ++o)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += red[((wave + o) * 16 + r) * 64 + lane];
+      }
     }
+    __syncthreads();
+    if (pw != 0) red[wave * 64 + lane] = dsum;
+    __syncthreads();
+    if (pw == 0)
+      for (int o = 1; o < WP; ++o) ds_other += red[(wave + o) * 64 + lane];
+    dsum += ds_other;
   }
-  if (blockIdx.y == 0) {
-    const float tot = dsum + __shfl_xor(dsum, 32, 64);
-    const int co = co0 + wm * 32 + j;
-    if (h == 0 && co < a.Coutp) a.dshift[(size_t)slab_id * a.Coutp + co] = co < d.Cout ? tot : 0.f;
+
+  // ---- partial slab of this split:  [split][Coutp][9*Ctot], k order (tap, ci)
+  const size_t KT = (size_t)9 * a.Ctot;
+  float* slab = a.slabs + (size_t)split * a.Coutp * KT;
+  const int ci = ci0 + j;
+  if (pw == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < d.Cout) slab[(size_t)co * KT + (size_t)t * a.Ctot + ci] = acc[t][r];
+      }
+    }
+    if (blockIdx.y == 0) {
+      const float tot = dsum + __shfl_xor(dsum, 32, 64);
+      const int co = co0 + wm * 32 + j;
+      if (h == 0 && co < a.Coutp) a.dshift[(size_t)split * a.Coutp + co] = co < d.Cout ? tot : 0.f;
+    }
   }
 }
 
@@ -176,11 +205,11 @@ static void tiled_geometry(const vunet_wgrad_desc* d, int& MTW, int& WP, int& nt
 int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d) {
   int MTW, WP, ntiles, ciblocks, coblocks;
   tiled_geometry(d, MTW, WP, ntiles, ciblocks, coblocks);
-  int S = 1024 / (ciblocks * coblocks);
+  int S = 1024 / (ciblocks * coblocks);  // ~4 workgroups per CU over the whole grid
   if (S > ntiles / 2) S = ntiles / 2;
   if (S < 1) S = 1;
-  if (S > 128) S = 128;
-  return S * WP;
+  if (S > 512) S = 512;
+  return S;
 }
 
 int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
@@ -190,8 +219,7 @@ int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const f
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift;
   int MTW, WP, ciblocks, coblocks;
   tiled_geometry(d, MTW, WP, a.ntiles, ciblocks, coblocks);
-  if (d->nsplit % WP != 0) return VUNET_ERR_ARG;
-  a.S = d->nsplit / WP;
+  a.S = d->nsplit;
   a.HW = d->Hs * d->Ws;
   a.Ctot = d->C1 + d->C2;
   a.Coutp = (d->Cout + 31) / 32 * 32;

@@ -104,31 +104,56 @@ struct WnBwdArgs {
   vunet_wn_desc d;
   const float *slabs, *dshift, *v, *g, *bias, *gamma, *invnorm;
   float *dv, *dg, *dbias, *dgamma, *dbeta;
-  int nsplit, T, Ctot, Coutp;
+  float *dwred, *dsred;  // workspace: reduced dW in v's (ci, tap) order [Cout][K], reduced dshift [Cout]
+  int nsplit, T, Ctot, Coutp, accumulate;
 };
 
+// Stage 1: sum the split-K slabs.  One workgroup = 64 consecutive K entries of one output channel (coalesced
+// 256-B rows of every slab) x 4 waves that each take a quarter of the slabs; fixed summation order.
+__global__ __launch_bounds__(256) void wn_slab_reduce_kernel(const WnBwdArgs a) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = a.T * a.Ctot;
+  const int kchunks = (K + 63) / 64;
+  const int co = blockIdx.x / kchunks, kc = blockIdx.x - co * kchunks;
+  const int k = kc * 64 + lane;  // slab order (tap, ci)
+  float s = 0.f;
+  if (k < K) {
+    const float* p = a.slabs + (size_t)co * K + k;
+    const size_t stride = (size_t)a.Coutp * K;
+#pragma unroll 8
+    for (int sl = wave; sl < a.nsplit; sl += 4) s += p[(size_t)sl * stride];
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && k < K) {
+    const float tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int tap = k / a.Ctot, ci = k - tap * a.Ctot;
+    a.dwred[(size_t)co * K + ci * a.T + tap] = tot;
+  }
+  if (kc == 0 && wave == 1) {  // the per-channel sum of dy
+    float t = 0.f;
+    for (int sl = lane; sl < a.nsplit; sl += 64) t += a.dshift[(size_t)sl * a.Coutp + co];
+    t = wave_sum(t);
+    if (lane == 0) a.dsred[co] = t;
+  }
+}
+
+// Stage 2: per output channel, D = <dW, v> and the parameter gradients.
 __global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* dWs = sm;  // [K]
   __shared__ float red[4];
   const int co = blockIdx.x, tid = threadIdx.x;
-  const int T = a.T, Ctot = a.Ctot, K = T * Ctot;
+  const int K = a.T * a.Ctot;
   const float* vr = a.v + (size_t)co * K;
+  const float* dwr = a.dwred + (size_t)co * K;
   float dot = 0.f;
-  for (int k = tid; k < K; k += 256) {
-    // slab k order is (tap, ci); v order is (ci, tap)
-    float dw = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) dw += a.slabs[((size_t)s * a.Coutp + co) * K + k];
-    const int tap = k / Ctot, ci = k - tap * Ctot;
-    dWs[k] = dw;
-    dot += dw * vr[ci * T + tap];
-  }
+  for (int k = tid; k < K; k += 256) dot += dwr[k] * vr[k];
   dot = wave_sum(dot);
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
   const float D = red[0] + red[1] + red[2] + red[3];
-  float dsh = 0.f;
-  for (int s = 0; s < a.nsplit; ++s) dsh += a.dshift[(size_t)s * a.Coutp + co];
+  const float dsh = a.dsred[co];
+  const float acc = a.accumulate ? 1.f : 0.f;
 
   const int kind = a.d.kind;
   const float invn = kind == 1 ? 1.f : a.invnorm[co];
@@ -137,21 +162,21 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
   const float b = a.bias ? a.bias[co] : 0.f;
   if (tid == 0) {
     if (kind == 1) {
-      if (a.dbias) a.dbias[co] = dsh;
+      if (a.dbias) a.dbias[co] = acc * a.dbias[co] + dsh;
     } else {
-      if (a.dgamma) a.dgamma[co] = gg * invn * D + b * dsh;
-      if (a.dbeta) a.dbeta[co] = dsh;
-      if (a.dbias) a.dbias[co] = gm * dsh;
-      if (a.dg && kind == 0) a.dg[co] = gm * invn * D;
+      if (a.dgamma) a.dgamma[co] = acc * a.dgamma[co] + gg * invn * D + b * dsh;
+      if (a.dbeta) a.dbeta[co] = acc * a.dbeta[co] + dsh;
+      if (a.dbias) a.dbias[co] = acc * a.dbias[co] + gm * dsh;
+      if (a.dg && kind == 0) a.dg[co] = acc * a.dg[co] + gm * invn * D;
     }
   }
   if (a.dv) {
     const float c0 = gm * gg * invn, c1 = invn * invn * D;
     float* dvr = a.dv + (size_t)co * K;
     for (int k = tid; k < K; k += 256) {
-      const int ci = k / T, tap = k - ci * T;  // v order
-      const float dw = dWs[tap * Ctot + ci];
-      dvr[k] = kind == 1 ? dw : c0 * (dw - c1 * vr[k]);
+      const float dw = dwr[k];
+      const float val = kind == 1 ? dw : c0 * (dw - c1 * vr[k]);
+      dvr[k] = a.accumulate ? dvr[k] + val : val;
     }
   }
 }
@@ -159,8 +184,8 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
 extern "C" int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float* dshift, int32_t nsplit,
                                     const float* v, const float* g, const float* bias, const float* gamma,
                                     const float* invnorm, float* dv, float* dg, float* dbias, float* dgamma,
-                                    float* dbeta, void* stream) {
-  if (!d || !slabs || !dshift || !v || nsplit < 1) return VUNET_ERR_ARG;
+                                    float* dbeta, float* workspace, int32_t accumulate, void* stream) {
+  if (!d || !slabs || !dshift || !v || !workspace || nsplit < 1) return VUNET_ERR_ARG;
   if (d->kind != 1 && !invnorm) return VUNET_ERR_ARG;
   if (d->kind == 0 && !g) return VUNET_ERR_ARG;
   WnBwdArgs a;
@@ -171,8 +196,12 @@ extern "C" int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, 
   a.T = d->KH * d->KW;
   a.Ctot = d->C1 + d->C2;
   a.Coutp = (d->Cout + 31) / 32 * 32;
-  const size_t lds = (size_t)a.T * a.Ctot * sizeof(float);
-  if (lds > 60 * 1024) return VUNET_ERR_UNSUPPORTED;
-  VUNET_LAUNCH(wn_bwd_kernel, dim3(d->Cout), dim3(256), lds, (hipStream_t)stream, a);
+  a.accumulate = accumulate;
+  const int K = a.T * a.Ctot;
+  a.dwred = workspace;                       // [Cout][K]
+  a.dsred = workspace + (size_t)d->Cout * K; // [Cout]
+  const int kchunks = (K + 63) / 64;
+  VUNET_LAUNCH(wn_slab_reduce_kernel, dim3((unsigned)(d->Cout * kchunks)), dim3(256), 0, (hipStream_t)stream, a);
+  VUNET_LAUNCH(wn_bwd_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, a);
   return vunet_check_launch();
 }

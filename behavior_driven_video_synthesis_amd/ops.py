@@ -185,6 +185,28 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
               _stream())
 
 
+# Parameters whose .grad is a view of a flat bucket (optim.FlatBucket) are written in place by the
+# weight-norm backward kernel (accumulate mode); autograd then gets None for them.  Listeners (the
+# data-parallel averager) are told which parameter gradients have just been completed.
+_grad_hooks = []
+
+
+def _has_direct_grad(p) -> bool:
+    return getattr(p, "_vunet_direct_grad", False) and p.grad is not None and p.grad.is_contiguous()
+
+
+def add_grad_hook(fn):
+    _grad_hooks.append(fn)
+
+
+def remove_grad_hook(fn):
+    if fn in _grad_hooks:
+        _grad_hooks.remove(fn)
+
+
+_frozen_pack_cache = {}
+
+
 class FusedConv(torch.autograd.Function):
     """y = [d2s] act_out( conv( drop(act_in(cat(x1, x2))) ; w_eff ) + shift ) [+ res]."""
 
@@ -200,7 +222,14 @@ class FusedConv(torch.autograd.Function):
         ho, wo = conv_out_size(hs, k, cfg.stride, cfg.pad), conv_out_size(ws, k, cfg.stride, cfg.pad)
         need_x = (ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]))
         need_w = any(ctx.needs_input_grad[3:8])
-        wt_f, wt_d, scale, shift, invnorm = pack_weights(v, g, bias, gamma, beta, c1, c2, cfg.kind, need_x)
+        frozen = not any(t is not None and t.requires_grad for t in (v, g, bias, gamma, beta))
+        key = (v.data_ptr(), v._version, c1, c2, cfg.kind, need_x) if frozen else None
+        if frozen and key in _frozen_pack_cache:
+            wt_f, wt_d, scale, shift, invnorm = _frozen_pack_cache[key]
+        else:
+            wt_f, wt_d, scale, shift, invnorm = pack_weights(v, g, bias, gamma, beta, c1, c2, cfg.kind, need_x)
+            if frozen:  # frozen feature extractor (VGG19): pack once, reuse for every pass
+                _frozen_pack_cache[key] = (wt_f, wt_d, scale, shift, invnorm)
         if cfg.d2s:
             y = torch.empty(n, cout // 4, 2 * ho, 2 * wo, device=x1.device, dtype=torch.float32)
         else:
@@ -210,6 +239,7 @@ class FusedConv(torch.autograd.Function):
                      drop_p=cfg.drop_p, drop_seed=cfg.drop_seed, out_act=cfg.out_act, d2s=int(cfg.d2s))
         _conv_gather(d, x1, x2, wt_f, shift, res, None, y)
         ctx.cfg = cfg
+        ctx.param_refs = (v, g, bias, gamma, beta)  # the caller's tensors (Parameters): direct .grad writes
         ctx.dims = (n, c1, c2, hs, ws, cout, ho, wo)
         ctx.need_w = need_w
         ctx.save_for_backward(x1, x2, v, g, bias, gamma, invnorm, wt_d,
@@ -249,14 +279,37 @@ class FusedConv(torch.autograd.Function):
                 _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
                       _stream())
             ni = ctx.needs_input_grad
-            dv = torch.empty_like(v) if ni[3] else None
-            dg = torch.empty_like(g) if (g is not None and ni[4]) else None
-            dbias = torch.empty_like(bias) if (bias is not None and ni[5]) else None
-            dgamma = torch.empty_like(gamma) if (gamma is not None and ni[6]) else None
-            dbeta = torch.empty_like(gamma) if (gamma is not None and ni[7]) else None
+            params = (v, g, bias, gamma, gamma)  # beta has gamma's shape
+            outs, direct = [], []
+            for idx, (p_, need) in enumerate(zip(ctx.param_refs, ni[3:8])):
+                if p_ is None or not need:
+                    outs.append(None)
+                    direct.append(False)
+                elif _has_direct_grad(p_):
+                    outs.append(p_.grad)      # written in place (+=) by the kernel: no autograd accumulation pass
+                    direct.append(True)
+                else:
+                    outs.append(torch.empty_like(params[idx]))
+                    direct.append(False)
+            n_direct = sum(direct)
+            n_needed = sum(o is not None for o in outs)
             wn = WnDesc(cout, c1, c2, k, k, cfg.kind)
-            _call("vunet_weightnorm_bwd", ctypes.byref(wn), _p(slabs), _p(dshift), ns, _p(v), _p(g), _p(bias),
-                  _p(gamma), _p(invnorm), _p(dv), _p(dg), _p(dbias), _p(dgamma), _p(dbeta), _stream())
+            work = torch.empty(cout * (ktot + 1), device=dy.device, dtype=torch.float32)
+
+            def run(sel_direct: bool):
+                sel = [o if (o is not None and d_ == sel_direct) else None for o, d_ in zip(outs, direct)]
+                _call("vunet_weightnorm_bwd", ctypes.byref(wn), _p(slabs), _p(dshift), ns, _p(v), _p(g), _p(bias),
+                      _p(gamma), _p(invnorm), _p(sel[0]), _p(sel[1]), _p(sel[2]), _p(sel[3]), _p(sel[4]), _p(work),
+                      1 if sel_direct else 0, _stream())
+            if n_direct:
+                run(True)
+            if n_needed > n_direct:
+                run(False)
+            dv, dg, dbias, dgamma, dbeta = [None if d_ else o for o, d_ in zip(outs, direct)]
+            for p_, d_ in zip(ctx.param_refs, direct):
+                if d_:
+                    for hook in _grad_hooks:
+                        hook(p_)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             def dgrad(x, cs, m_off, seed, add):

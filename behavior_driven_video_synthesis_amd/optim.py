@@ -36,6 +36,7 @@ class FlatBucket:
                 self.flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
+                p._vunet_direct_grad = True  # ops.FusedConv writes this view in place (no autograd add pass)
                 self.offsets.append(off)
                 off += n
 

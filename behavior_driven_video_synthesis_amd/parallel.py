@@ -28,9 +28,15 @@ class BucketedGradAverager:
         self._fired: List[int] = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         if self.world > 1:
+            from . import ops
+            self._bucket_of = {}
             for bi, b in enumerate(self.buckets):
                 for p in b.params:
+                    self._bucket_of[id(p)] = bi
+                    # gradients that autograd accumulates itself ...
                     p.register_post_accumulate_grad_hook(self._make_hook(bi))
+            # ... and those the HIP weight-norm backward writes straight into the flat bucket
+            ops.add_grad_hook(self._direct_hook)
 
     def _make_hook(self, bi):
         def hook(param):
@@ -38,6 +44,11 @@ class BucketedGradAverager:
             if self.overlap and self._expected[bi] is not None and self._fired[bi] == self._expected[bi]:
                 self._launch(bi)
         return hook
+
+    def _direct_hook(self, param):
+        bi = self._bucket_of.get(id(param))
+        if bi is not None:
+            self._make_hook(bi)(param)
 
     def _launch(self, bi):
         if self._launched[bi]:

@@ -115,12 +115,14 @@ int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g,
                          const float* gamma, const float* beta, float* wt_f, float* wt_d, float* scale,
                          float* shift, float* invnorm, void* stream);
 
-/* backward: reduces the wgrad slabs and produces the parameter gradients.
- * dv[Cout][Cin][KH][KW], dg[Cout], dbias[Cout], dgamma[Cout], dbeta[Cout] (NULL to skip). */
+/* backward: reduces the wgrad slabs (fixed order) and produces the parameter gradients
+ * dv[Cout][Cin][KH][KW], dg[Cout], dbias[Cout], dgamma[Cout], dbeta[Cout] (NULL to skip).
+ * workspace: Cout*(KH*KW*(C1+C2) + 1) floats.  accumulate != 0: add into the outputs (they are then the
+ * parameters' .grad buffers, written without an autograd accumulation pass). */
 int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float* dshift, int32_t nsplit,
                          const float* v, const float* g, const float* bias, const float* gamma,
                          const float* invnorm, float* dv, float* dg, float* dbias, float* dgamma,
-                         float* dbeta, void* stream);
+                         float* dbeta, float* workspace, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pointwise / index / reduction kernels (HBM-bound)
