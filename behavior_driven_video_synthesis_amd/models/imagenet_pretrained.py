@@ -44,7 +44,7 @@ class VGG19(nn.Module):
         self.features = nn.Sequential(*layers)
 
     def init_synthetic(self, seed: int = 1234):
-        """Seeded He-normal weights (no network access for the pretrained ones); mirrors the oracle's recipe."""
+        """Seeded He-normal weights (no network access for the pretrained ones)."""
         g = torch.Generator().manual_seed(seed)
         with torch.no_grad():
             for m in self.features:

@@ -1,0 +1,112 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/vunet_hip.h declares, the
+host-side mirror has the reference's construction surface / state-dict layout, schedules match the
+oracle, and the product path refuses CPU tensors (there is no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from behavior_driven_video_synthesis_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.vunet_abi_version() == 1
+
+
+def test_header_is_plain_c_abi():
+    txt = open(os.path.join(ROOT, "include", "vunet_hip.h")).read()
+    assert 'extern "C"' in txt
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", txt, flags=re.S).lower()
+    assert "at::" not in txt and "hipStream_t stream" not in txt  # streams cross the ABI as void*
+
+
+def test_ctypes_structs_match_header_field_order():
+    from behavior_driven_video_synthesis_amd import ops
+    txt = open(os.path.join(ROOT, "include", "vunet_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    for cname, cls in (("vunet_conv_desc", ops.ConvDesc), ("vunet_wgrad_desc", ops.WgradDesc),
+                       ("vunet_wn_desc", ops.WnDesc)):
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname, txt, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                typ, names = decl.split(None, 1)
+                fields += [(n.strip(), typ) for n in names.split(",")]
+        assert [f[0] for f in cls._fields_] == [f[0] for f in fields], cname
+        cmap = {"int32_t": "c_int", "uint32_t": "c_uint", "float": "c_float"}
+        for (n, ct), (_, typ) in zip(cls._fields_, fields):
+            assert ct.__name__.startswith(cmap[typ]), (cname, n)
+
+
+def test_state_dict_layout_matches_reference():
+    from behavior_driven_video_synthesis_amd.models.vunets import Regressor, VunetAlter, VunetOrg
+    from behavior_driven_video_synthesis_amd.models.synth_discriminator import PartDiscriminator, PatchGANDiscriminator
+    for tag, cls in (("g2_alter", VunetAlter), ("g2_alter_box", VunetAlter), ("g2_org", VunetOrg)):
+        meta, _ = load_golden(tag)
+        net = cls(n_channels_x=meta["n_channels_x"], **meta["cfg"])  # unknown cfg keys must be ignored
+        sd = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert list(sd.keys()) == list(meta["shapes"].keys())
+        assert sd == meta["shapes"]
+        assert hasattr(net, "eu") and hasattr(net, "ed") and hasattr(net, "du") and hasattr(net, "dd")
+    meta, _ = load_golden("g4_discriminators")
+    assert {k: list(v.shape) for k, v in PartDiscriminator(2, 16).state_dict().items()} == meta["part_shapes"]
+    assert {k: list(v.shape) for k, v in PatchGANDiscriminator(3, 8, 3).state_dict().items()} == meta["patch_shapes"]
+    meta, _ = load_golden("g2_regressor")
+    reg = Regressor(n_out=34, n_latent_scales=2, nf_max=16, latent_widths=[8, 4], linear_width_factor=1)
+    assert {k: list(v.shape) for k, v in reg.state_dict().items()} == meta["shapes"]
+
+
+def test_full_size_model_has_reference_parameter_count():
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    cfg = dict(spatial_size=256, bottleneck_factor=2, box_factor=2, n_scales=0, n_latent_scales=2,
+               conv_layer_type="l1", nf_start=32, nf_max=128, subpixel_upsampling=True)
+    net = VunetAlter(**cfg)
+    assert sum(p.numel() for p in net.parameters()) == 14601516  # SURVEY 8a, Human3.6m config
+    assert len(net.state_dict()) == 495 and net.n_scales == 7
+
+
+def test_cpu_tensors_raise_no_fallback():
+    from behavior_driven_video_synthesis_amd.lib.modules import NormConv2d
+    from behavior_driven_video_synthesis_amd.lib.losses import compute_kl_with_prior
+    with pytest.raises(RuntimeError):
+        NormConv2d(4, 4, 3, 1, 1)(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(RuntimeError):
+        compute_kl_with_prior([torch.zeros(2, 4, 2, 2)], [torch.zeros(2, 4, 2, 2)])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "behavior_driven_video_synthesis_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+.*oracle", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_schedules_match_oracle():
+    from oracle import vunet_oracle as O
+    from behavior_driven_video_synthesis_amd.lib.utils import linear_var
+    for it in (0, 1, 17, 99, 100, 150):
+        assert abs(float(linear_var(it, 0, 100, 5e-4, 0, 0, 5e-4)) - O.linear_var(it, 0, 100, 5e-4, 0, 0, 5e-4)) < 1e-15
+    assert O.update_gamma(0.0, 1e-5, 1000.0, 3000.0) == pytest.approx(0.02)
+    assert O.update_gamma(0.001, 1e-5, 1000.0, 10.0) == 0.0
+
+
+def test_dropout_hash_restatement_is_stable():
+    """The CPU restatement of the conv-prologue dropout hash used by the parity tests (known answers)."""
+    import numpy as np
+    from hip_parity_utils import dropout_keep_mask, hash_u32
+    assert [int(v) for v in hash_u32(np.array([0, 1, 2, 0xFFFFFFFF], dtype=np.uint64))] == \
+        [0, 1753845952, 3507691905, 1734902346]
+    m = dropout_keep_mask((4, 1000), 0.25, 12345)
+    assert 0.70 < float(m.mean()) < 0.80
