@@ -24,11 +24,12 @@ struct WgradTiledArgs {
   InAct in1, in2;
 };
 
-template <int MTW, int TH>
+template <int MTW, int TH, int KS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTiledArgs a) {
   constexpr int WP = 4 / MTW;        // pixel parts (waves sharing one m-tile)
   constexpr int RW = TH / WP;        // tile rows per wave
-  constexpr int IH = TH + 2, IW = 34;
+  constexpr int HALO = KS / 2, NTAP = KS * KS;
+  constexpr int IH = TH + 2 * HALO, IW = 32 + 2 * HALO;
   constexpr int CS = IH * IW + 1;    // fx channel pitch (odd)
   constexpr int PS = TH * 32 + 1;    // dy row pitch (odd)
   constexpr int MB = 32 * MTW;
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
   const int cbase = second ? ci0 - d.C1 : ci0;
   const InAct ia = second ? a.in2 : a.in1;
 
-  f32x16 acc[9];
+  f32x16 acc[NTAP];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float dsum = 0.f;
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
           const int c = e / (IH * IW);
           const int rem = e - c * (IH * IW);
           const int r = rem / IW, col = rem - r * IW;
-          const int ih = row0 - 1 + r, iw = col0 - 1 + col;
-          const bool ok = e < E && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+          const int ih = row0 - HALO + r, iw = col0 - HALO + col;
+          const bool ok = e < E && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && cbase + c < Cs;
           go[u] = ok ? ((n * Cs + cbase + c) * H + ih) * W + iw : -1;
           v[u] = ok ? xs[go[u]] : 0.f;
         }
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
         const float av = aP[rr * 32 + 2 * s];
         dsum += av;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const float bv = bP[(rr + t / 3) * IW + 2 * s + t % 3];
+        for (int t = 0; t < NTAP; ++t) {
+          const float bv = bP[(rr + t / KS) * IW + 2 * s + t % KS];
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
         }
       }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
     float* red = smem;  // [4 waves][16][64]
     float ds_other = 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NTAP; ++t) {
       __syncthreads();
       if (pw != 0) {
 #pragma unroll
@@ -167,17 +168,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
     dsum += ds_other;
   }
 
-  // ---- partial slab of this split:  [split][Coutp][9*Ctot], k order (tap, ci)
-  const size_t KT = (size_t)9 * a.Ctot;
+  // ---- partial slab of this split:  [split][Coutp][NTAP*Ctot], k order (tap, ci)
+  const size_t KT = (size_t)NTAP * a.Ctot;
   float* slab = a.slabs + (size_t)split * a.Coutp * KT;
   const int ci = ci0 + j;
   if (pw == 0) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NTAP; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < d.Cout) slab[(size_t)co * KT + (size_t)t * a.Ctot + ci] = acc[t][r];
+        if (co < d.Cout && ci < a.Ctot) slab[(size_t)co * KT + (size_t)t * a.Ctot + ci] = acc[t][r];
       }
     }
     if (blockIdx.y == 0) {
@@ -190,21 +191,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
 
 // ---- host side ----------------------------------------------------------------------------
 bool vunet_wgrad_tiled_applicable(const vunet_wgrad_desc* d) {
-  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ws % 32 == 0 && d->Hs % 4 == 0 &&
-         d->Ho == d->Hs && d->Wo == d->Ws && d->C1 % 32 == 0 && d->C2 % 32 == 0 && d->Cout % 32 == 0;
+  const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
+  return (k3 || k1) && d->stride == 1 && d->Ws % 32 == 0 && d->Hs % 4 == 0 && d->Ho == d->Hs && d->Wo == d->Ws &&
+         ((d->C1 % 32 == 0 && d->C2 % 32 == 0) || (d->C2 == 0 && d->C1 < 32)) &&
+         (d->Cout % 32 == 0 || d->Cout < 32);
 }
 
-static void tiled_geometry(const vunet_wgrad_desc* d, int& MTW, int& WP, int& ntiles, int& ciblocks, int& coblocks) {
+static void tiled_geometry(const vunet_wgrad_desc* d, int& MTW, int& ntiles, int& ciblocks, int& coblocks) {
   MTW = d->Cout >= 64 ? 2 : 1;
-  WP = 4 / MTW;
   ntiles = d->N * (d->Hs / 4) * (d->Ws / 32);
-  ciblocks = (d->C1 + d->C2) / 32;
-  coblocks = d->Cout / (32 * MTW);
+  ciblocks = (d->C1 + d->C2 + 31) / 32;
+  coblocks = (d->Cout + 32 * MTW - 1) / (32 * MTW);
 }
 
 int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d) {
-  int MTW, WP, ntiles, ciblocks, coblocks;
-  tiled_geometry(d, MTW, WP, ntiles, ciblocks, coblocks);
+  int MTW, ntiles, ciblocks, coblocks;
+  tiled_geometry(d, MTW, ntiles, ciblocks, coblocks);
   int S = 1024 / (ciblocks * coblocks);  // ~4 workgroups per CU over the whole grid
   if (S > ntiles / 2) S = ntiles / 2;
   if (S < 1) S = 1;
@@ -212,13 +214,21 @@ int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d) {
   return S;
 }
 
+template <int MTW, int KS>
+static int launch_wgrad_tiled(const WgradTiledArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int TH = 4, HALO = KS / 2;
+  const size_t lds = (size_t)(32 * ((TH + 2 * HALO) * (32 + 2 * HALO) + 1) + 32 * MTW * (TH * 32 + 1)) * sizeof(float);
+  VUNET_LAUNCH((conv_wgrad_tiled_kernel<MTW, TH, KS>), grid, dim3(256), lds < 16384 + 4096 ? 16384 + 4096 : lds, st, a);
+  return vunet_check_launch();
+}
+
 int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
                              float* slabs, float* dshift, hipStream_t st) {
   WgradTiledArgs a;
   a.d = *d;
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift;
-  int MTW, WP, ciblocks, coblocks;
-  tiled_geometry(d, MTW, WP, a.ntiles, ciblocks, coblocks);
+  int MTW, ciblocks, coblocks;
+  tiled_geometry(d, MTW, a.ntiles, ciblocks, coblocks);
   a.S = d->nsplit;
   a.HW = d->Hs * d->Ws;
   a.Ctot = d->C1 + d->C2;
@@ -228,10 +238,7 @@ int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const f
   a.tps = (a.ntiles + a.S - 1) / a.S;
   a.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
   a.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
-  dim3 grid(a.S, ciblocks, coblocks), block(256);
-  constexpr int TH = 4;
-  const size_t lds = (size_t)(32 * ((TH + 2) * 34 + 1) + 32 * MTW * (TH * 32 + 1)) * sizeof(float);
-  if (MTW == 1) VUNET_LAUNCH((conv_wgrad_tiled_kernel<1, TH>), grid, block, lds, st, a);
-  else VUNET_LAUNCH((conv_wgrad_tiled_kernel<2, TH>), grid, block, lds, st, a);
-  return vunet_check_launch();
+  dim3 grid(a.S, ciblocks, coblocks);
+  if (d->KH == 3) return MTW == 1 ? launch_wgrad_tiled<1, 3>(a, grid, st) : launch_wgrad_tiled<2, 3>(a, grid, st);
+  return MTW == 1 ? launch_wgrad_tiled<1, 1>(a, grid, st) : launch_wgrad_tiled<2, 1>(a, grid, st);
 }

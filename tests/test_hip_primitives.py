@@ -73,6 +73,10 @@ def test_primitive_vs_golden(case):
     (2, 32, 32, 8, 32, 3, 1, 1),      # LDS halo-tile wgrad path, one m-tile per workgroup
     (1, 64, 128, 12, 64, 3, 1, 1),    # LDS halo-tile wgrad path, two m-tiles, several column tiles
     (3, 32, 64, 4, 96, 3, 1, 1),      # tiled wgrad, more tiles than splits
+    (2, 32, 3, 8, 64, 3, 1, 1),       # tiled wgrad with a partial output-channel tile (out_conv)
+    (2, 32, 32, 8, 64, 1, 1, 0),      # 1x1 (nin) through the tiled wgrad kernel
+    (2, 64, 128, 4, 32, 1, 1, 0),     # 1x1, two m-tiles per workgroup
+    (2, 3, 32, 8, 64, 1, 1, 0),       # first nin: 3 input channels, masked channel block
 ])
 def test_normconv_vs_oracle(shape):
     """Fused NormConv2d fwd + dgrad + wgrad on shapes the golden file does not hold (edge cases)."""
