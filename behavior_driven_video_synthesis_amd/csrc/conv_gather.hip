@@ -66,6 +66,9 @@ __device__ __forceinline__ void k_sweep(const GatherArgs& a, const float* __rest
   const int Cp = (C + 1) & ~1;
   const int HW2 = a.HsWs;
   const float* __restrict__ wbase = a.wt + (size_t)d.m_off + m0 + j;
+  int wcol[MT];  // column offset of each m-tile; out-of-range channels read column 0 of the row and are masked
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) wcol[mt] = mok[mt] ? mt * 32 : -(d.m_off + m0 + j);
 
   if (KS == 3) {
     int toff[9];
@@ -79,14 +82,13 @@ __device__ __forceinline__ void k_sweep(const GatherArgs& a, const float* __rest
       for (int t9 = 0; t9 < 9; ++t9) {
         const float* wp = wbase + (size_t)(krow0 + t9 * Cp + ci) * d.Mpad;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[t9][mt] = mok[mt] ? wp[mt * 32] : 0.f;
+        for (int mt = 0; mt < MT; ++mt) { const float w = wp[wcol[mt]]; av[t9][mt] = mok[mt] ? w : 0.f; }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const bool ok = cok && (((vmask[t] >> (t9 / 3)) & (vmask[t] >> (8 + t9 % 3)) & 1u) != 0);
           const int off = base[t] + ci * HW2 + toff[t9];
-          float v = 0.f;
-          if (ok) v = xs[off];
-          bv[t9][t] = prologue<PRO>(ia, v, (uint32_t)off);
+          const float v = xs[ok ? off : 0];  // unconditional load (no branch / vmcnt(0) per element)
+          bv[t9][t] = ok ? prologue<PRO>(ia, v, (uint32_t)off) : 0.f;
         }
       }
 #pragma unroll
@@ -109,15 +111,16 @@ __device__ __forceinline__ void k_sweep(const GatherArgs& a, const float* __rest
       for (int u = 0; u < G; ++u) {
         const int ci = c2 + u * c2_step + h;
         const bool cok = ci < C;
-        const float* wp = wbase + (size_t)(krow0 + ci) * d.Mpad;
+        const bool rok = ci < Cp;
+        const float* wp = wbase + (size_t)(krow0 + (rok ? ci : 0)) * d.Mpad;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[u][mt] = (mok[mt] && ci < Cp) ? wp[mt * 32] : 0.f;
+        for (int mt = 0; mt < MT; ++mt) { const float w = wp[wcol[mt]]; av[u][mt] = (mok[mt] && rok) ? w : 0.f; }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int off = base[t] + ci * HW2 + toff;
-          float v = 0.f;
-          if (tv[t] && cok) v = xs[off];
-          bv[u][t] = prologue<PRO>(ia, v, (uint32_t)off);
+          const bool ok = tv[t] && cok;
+          const float v = xs[ok ? off : 0];
+          bv[u][t] = ok ? prologue<PRO>(ia, v, (uint32_t)off) : 0.f;
         }
       }
 #pragma unroll
@@ -139,14 +142,13 @@ __device__ __forceinline__ void k_sweep(const GatherArgs& a, const float* __rest
           const float* wp = wbase + (size_t)(krow0 + tap * Cp + ci) * d.Mpad;
           float av[MT], bv[NT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[mt] = mok[mt] ? wp[mt * 32] : 0.f;
+          for (int mt = 0; mt < MT; ++mt) { const float w = wp[wcol[mt]]; av[mt] = mok[mt] ? w : 0.f; }
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const bool ok = cok && (((vmask[t] >> kh) & (vmask[t] >> (8 + kw)) & 1u) != 0);
             const int off = base[t] + ci * HW2 + toff;
-            float v = 0.f;
-            if (ok) v = xs[off];
-            bv[t] = prologue<PRO>(ia, v, (uint32_t)off);
+            const float v = xs[ok ? off : 0];
+            bv[t] = ok ? prologue<PRO>(ia, v, (uint32_t)off) : 0.f;
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)

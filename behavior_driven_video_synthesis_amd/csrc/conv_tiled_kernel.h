@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
     const int r = rem / IW, col = rem - r * IW;
     const int ih = row0 - 1 + r, iw = col0 - 1 + col;
     const bool ok = e < EI && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-    rel[i] = c * HW + ih * W + iw;
+    rel[i] = ok ? c * HW + ih * W + iw : 0;  // invalid: a safe in-bounds address, the value is masked afterwards
     vbits |= (ok ? 1u : 0u) << i;
   }
   f32x16 acc[MT][NT];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
     const int C = second ? d.C2 : d.C1;
     const float* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C + cs) * HW;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) xv[i] = ((vbits >> i) & 1u) ? xs[rel[i]] : 0.f;
+    for (int i = 0; i < NI; ++i) xv[i] = xs[rel[i]];  // unconditional (no branch per load): masked in write_lds
     const int Cp = (C + 1) & ~1;
     const int krow0 = second ? 9 * ((d.C1 + 1) & ~1) : 0;
     const float* __restrict__ wp = a.wt + (size_t)(krow0 + cs) * d.Mpad + d.m_off + m0;
@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
       const int e = tid + 256 * i;            // LDS order [tap][c][m]
       const int m = e % MB, rc = e / MB;
       const int c = rc % CK, tap = rc / CK;
-      wv[i] = (m0 + m < d.M) ? wp[(size_t)(tap * Cp + c) * d.Mpad + m] : 0.f;
+      const bool mv = m0 + m < d.M;
+      const float w = wp[(size_t)(tap * Cp + c) * d.Mpad + (mv ? m : 0)];
+      wv[i] = mv ? w : 0.f;
     }
   };
   auto write_lds = [&](int ch, float* buf) {
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
       const int e = tid + 256 * i;
       if (e < EI) {
         float v = xv[i];
-        if (PRO != 0) v = ((vbits >> i) & 1u) ? prologue<PRO>(ia, v, (uint32_t)(gbase + rel[i])) : 0.f;
-        buf[e] = v;
+        if (PRO != 0) v = prologue<PRO>(ia, v, (uint32_t)(gbase + rel[i]));
+        buf[e] = ((vbits >> i) & 1u) ? v : 0.f;
       }
     }
 #pragma unroll

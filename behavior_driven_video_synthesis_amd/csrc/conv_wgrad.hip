@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll 4
     for (int i = 0; i < MB / 8; ++i) {
       const int col = rgrp + 8 * i, co = co0 + col;
-      float v = 0.f;
-      if (pv && co < d.Cout) v = a.dy[(size_t)(n * d.Cout + co) * a.HoWo + rem];
-      dyL[col * PITCH + q] = v;
+      const bool ok = pv && co < d.Cout;
+      const float v = a.dy[ok ? (size_t)(n * d.Cout + co) * a.HoWo + rem : 0];
+      dyL[col * PITCH + q] = ok ? v : 0.f;
     }
     // ---- stage im2col'ed activated input rows
     int kh = 0, kw = 0;
@@ -80,17 +80,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
         const int cl = rgrp + 8 * ii, ci = ci0 + cl;
-        float v = 0.f;
-        if (tv && ci < a.Ctot) {
-          if (ci < d.C1) {
-            const int off = (n * d.C1 + ci) * a.HsWs + sp;
-            v = apply_in_act(a.in1, a.x1[off], (uint32_t)off);
-          } else {
-            const int off = (n * d.C2 + (ci - d.C1)) * a.HsWs + sp;
-            v = apply_in_act(a.in2, a.x2[off], (uint32_t)off);
-          }
-        }
-        fxL[(tap * 32 + cl) * PITCH + q] = v;
+        const bool ok = tv && ci < a.Ctot;
+        const bool first = ci < d.C1;
+        const int off = first ? (n * d.C1 + ci) * a.HsWs + sp : (n * d.C2 + (ci - d.C1)) * a.HsWs + sp;
+        const float* __restrict__ xs = (first || !a.x2) ? a.x1 : a.x2;
+        const float raw = xs[ok ? off : 0];  // unconditional load
+        const float v = apply_in_act(first ? a.in1 : a.in2, raw, (uint32_t)off);
+        fxL[(tap * 32 + cl) * PITCH + q] = ok ? v : 0.f;
       }
       if (++kw == d.KW) { kw = 0; ++kh; }
     }

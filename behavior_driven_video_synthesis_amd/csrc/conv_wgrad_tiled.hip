@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
           const int ih = row0 - HALO + r, iw = col0 - HALO + col;
           const bool ok = e < E && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && cbase + c < Cs;
           go[u] = ok ? ((n * Cs + cbase + c) * H + ih) * W + iw : -1;
-          v[u] = ok ? xs[go[u]] : 0.f;
+          v[u] = xs[ok ? go[u] : 0];  // unconditional load; invalid elements are zeroed below
         }
 #pragma unroll
         for (int u = 0; u < BF; ++u) {
@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
           const int e = tid + 256 * (i0 + u);
           const int co = e / (TH * 32), p = e % (TH * 32);
           const int cog = co0 + co;
-          v[u] = cog < d.Cout ? a.dy[((size_t)(n * d.Cout + cog) * H + row0 + (p >> 5)) * W + col0 + (p & 31)] : 0.f;
+          const bool cv = cog < d.Cout;
+          const float t = a.dy[((size_t)(n * d.Cout + (cv ? cog : 0)) * H + row0 + (p >> 5)) * W + col0 + (p & 31)];
+          v[u] = cv ? t : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
