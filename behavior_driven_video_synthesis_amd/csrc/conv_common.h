@@ -71,3 +71,56 @@ __device__ __forceinline__ void store_out(const GatherArgs& a, const PixGeo& g, 
   }
 }
 
+
+// Epilogue of one 32x32 accumulator tile held by a wave (16 registers per lane: rows (r&3)+8(r>>2)+4h of the
+// m-tile, lane = pixel).  All residual / aux loads of the tile are issued together (no per-element branch or
+// wait), then the 16 results are computed and stored.  m_tile0 = first channel of the m-tile.
+__device__ __forceinline__ void store_tile16(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
+                                             const f32x16& acc) {
+  const vunet_conv_desc& d = a.d;
+  if (d.d2s) {  // sub-pixel store: rare (up-convs), scattered addresses
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m_tile0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (g.valid && m < d.M) store_out(a, g, m, acc[r]);
+    }
+    return;
+  }
+  const int mb = m_tile0 + 4 * h;
+  const int pix = g.oh * d.Wo + g.ow;
+  const size_t o0 = (size_t)(g.n * d.M + mb) * a.HoWo + pix;
+  const size_t rs = (size_t)a.HoWo;
+  const bool full = m_tile0 + 32 <= d.M;  // wave-uniform
+  bool ok[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ok[r] = g.valid && (full || mb + (r & 3) + 8 * (r >> 2) < d.M);
+  float auxv[16], resv[16], shv[16];
+  if (a.aux) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) auxv[r] = a.aux[ok[r] ? o0 + ((r & 3) + 8 * (r >> 2)) * rs : 0];
+  }
+  if (a.res) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) resv[r] = a.res[ok[r] ? o0 + ((r & 3) + 8 * (r >> 2)) * rs : 0];
+  }
+  if (d.mode == 0 && a.shift) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) shv[r] = a.shift[ok[r] ? mb + (r & 3) + 8 * (r >> 2) : 0];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const size_t o = o0 + ((r & 3) + 8 * (r >> 2)) * rs;
+    float v = acc[r];
+    if (d.mode == 0) {
+      if (a.shift) v += shv[r];
+      if (d.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (d.out_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+      else if (d.out_act == ACT_ELU) v = elu_f(v);
+      else if (d.out_act == ACT_LRELU) v = v > 0.f ? v : v * d.in_slope;
+    } else if (a.aux) {
+      v *= in_act_grad(a.auxa, auxv[r], (uint32_t)o);
+    }
+    if (a.res) v += resv[r];
+    if (ok[r]) a.y[o] = v;
+  }
+}

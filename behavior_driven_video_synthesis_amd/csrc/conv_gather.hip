@@ -300,7 +300,7 @@ static int dispatch_gather(const GatherArgs& ga, int pro, hipStream_t st) {
 
 // conv_tiled.hip: LDS-tiled kernel for the 3x3 / stride-1 layers on maps at least 32 wide
 bool vunet_conv_tiled_applicable(const vunet_conv_desc* d);
-int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT);
+int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT, bool valu_heavy);
 int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st);
 
 extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
@@ -332,7 +332,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   hipStream_t st = (hipStream_t)stream;
   const bool no_tiled = getenv("VUNET_NO_TILED") != nullptr;
   int mt_unused;
-  if (!no_tiled && vunet_conv_tiled_applicable(d) && (d->mode == 0 || pro == 0) && pro != 3 && vunet_conv_tiled_pick(d, &mt_unused) > 0)
+  if (!no_tiled && vunet_conv_tiled_applicable(d) && (d->mode == 0 || pro == 0) && pro != 3 && vunet_conv_tiled_pick(d, &mt_unused, true) > 0)
     return vunet_conv_tiled_launch(ga, pro, st);
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
   if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);

@@ -14,21 +14,28 @@ static long tiled_blocks(const vunet_conv_desc& d, int MT, int NT) {
   return (long)d.N * (d.Hs / (4 * NT)) * (d.Ws / 32) * ((d.M + 32 * MT - 1) / (32 * MT));
 }
 
-// largest tile that still gives >= 2 workgroups per CU; 0 if even the smallest tile cannot fill half the chip
-int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT) {
+// Tile height, from in-pipeline measurements on MI355X (tools/profile_layers.py, tools/bench_conv.py):
+//  * layers that do per-element VALU work around the MFMA loop -- the ELU/dropout prologue at staging, or the
+//    act'(aux) epilogue of the data gradient -- run best with the 4-row tile (NT = 1): ~50 KiB of LDS and ~120
+//    VGPRs give 3 workgroups per CU, and the extra waves hide the VALU bursts (75 -> 96 TF/s on 64@128^2);
+//  * plain layers (the VGG19 stack) run best with the tallest tile that still leaves >= 2 workgroups per CU
+//    (129 vs 113 TF/s on 256@64^2 and 512@32^2).
+// Returns 0 if even the smallest tile cannot give half the chip one workgroup each.
+int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT, bool valu_heavy) {
   *MT = d->M <= 32 ? 1 : 2;
-  if (const char* f = getenv("VUNET_TILED_FORCE_NT")) {  // tests: force a tile height on small tensors
+  if (const char* f = getenv("VUNET_TILED_FORCE_NT")) {  // tests / tuning: force a tile height
     const int NT = atoi(f);
     if ((NT == 1 || NT == 2 || NT == 4) && tiled_blocks(*d, *MT, NT) > 0) return NT;
   }
-  for (int NT = 4; NT >= 1; NT >>= 1)
-    if (tiled_blocks(*d, *MT, NT) >= 512) return NT;
+  if (!valu_heavy && *MT == 2)
+    for (int NT = 4; NT >= 2; NT >>= 1)
+      if (tiled_blocks(*d, *MT, NT) >= 512) return NT;
   return tiled_blocks(*d, *MT, 1) >= 128 ? 1 : 0;
 }
 
 int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st) {
   int MT;
-  const int NT = vunet_conv_tiled_pick(&ga.d, &MT);
+  const int NT = vunet_conv_tiled_pick(&ga.d, &MT, pro != 0 || (ga.d.mode == 1 && ga.aux != nullptr));
   if (pro == 3) return VUNET_ERR_UNSUPPORTED;
   return MT == 1 ? vunet_conv_tiled_launch_mt1(ga, pro, NT, st) : vunet_conv_tiled_launch_mt2(ga, pro, NT, st);
 }

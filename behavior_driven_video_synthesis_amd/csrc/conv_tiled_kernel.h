@@ -153,13 +153,20 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
     g.oh = row0 + wave * NT + q;
     g.ow = col0 + j;
     g.valid = true;
+    if constexpr (NT == 1) {
+      // small tile (the VALU-heavy layers): issue the tile's aux / residual loads together
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) store_tile16(a, g, m0 + mt * 32, h, acc[mt][q]);
+    } else {
+      // tall tiles run at the VGPR limit: keep the register-lean per-element epilogue
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < d.M) store_out(a, g, m, acc[mt][q][r]);
-      }
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < d.M) store_out(a, g, m, acc[mt][q][r]);
+        }
+    }
   }
 }
 
