@@ -14,6 +14,10 @@ struct GatherArgs {
   float* y;
   int NP, HoWo, HsWs;
   InAct in1, in2, auxa;
+  // internal (not part of the C ABI): output-parity phase of a strided transposed gather.  ph < 0: off.
+  // With ph/pw set, pixel indices enumerate the sub-grid (n, a, b) of outputs (s*a + ph, s*b + pw), NP counts
+  // that sub-grid, and only the taps whose parity matches are visited -- no MFMA is spent on structural zeros.
+  int ph, pw, subW, subHW;
 };
 
 struct PixGeo {

@@ -26,9 +26,18 @@ struct TileGeo {
   uint32_t vmask;  // bits 0..7 rows (kh), 8..15 cols (kw); 0 if the pixel is out of range
 };
 
+// output pixel of flattened index P (phase mode: P walks the sub-grid of one output parity)
+__device__ __forceinline__ PixGeo out_pixel(const GatherArgs& a, int P) {
+  if (a.ph < 0) return decompose(P, a.NP, a.HoWo, a.d.Wo);
+  PixGeo g = decompose(P, a.NP, a.subHW, a.subW);
+  g.oh = g.oh * a.d.stride + a.ph;
+  g.ow = g.ow * a.d.stride + a.pw;
+  return g;
+}
+
 __device__ __forceinline__ TileGeo tile_geometry(const GatherArgs& a, int P) {
   const vunet_conv_desc& d = a.d;
-  const PixGeo g = decompose(P, a.NP, a.HoWo, d.Wo);
+  const PixGeo g = out_pixel(a, P);
   const int s = d.stride, p = d.pad;
   uint32_t rb = 0, cb = 0;
   int sp;
@@ -132,29 +141,43 @@ __device__ __forceinline__ void k_sweep(const GatherArgs& a, const float* __rest
             acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][t], acc[mt][t], 0, 0, 0);
     }
   } else {
-    for (int c2 = c2_begin; c2 < Cp; c2 += c2_step) {
-      const int ci = c2 + h;
-      const bool cok = ci < C;
-      int tap = 0;
-      for (int kh = 0; kh < d.KH; ++kh) {
-        for (int kw = 0; kw < d.KW; ++kw, ++tap) {
-          const int toff = tap_offset(d, kh, kw);
-          const float* wp = wbase + (size_t)(krow0 + tap * Cp + ci) * d.Mpad;
-          float av[MT], bv[NT];
+    constexpr int G = 8;
+    int tap = 0;
+    for (int kh = 0; kh < d.KH; ++kh) {
+      for (int kw = 0; kw < d.KW; ++kw, ++tap) {
+        bool tv[NT];
+        bool any = false;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) { const float w = wp[wcol[mt]]; av[mt] = mok[mt] ? w : 0.f; }
+        for (int t = 0; t < NT; ++t) {
+          tv[t] = ((vmask[t] >> kh) & (vmask[t] >> (8 + kw)) & 1u) != 0;
+          any |= tv[t];
+        }
+        if (!__any(any)) continue;  // wave-uniform: a tap no lane of this wave can use (parity / border)
+        const int toff = tap_offset(d, kh, kw);
+        for (int c2 = c2_begin; c2 < Cp; c2 += G * c2_step) {
+          float av[G][MT], bv[G][NT];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const bool ok = cok && (((vmask[t] >> kh) & (vmask[t] >> (8 + kw)) & 1u) != 0);
-            const int off = base[t] + ci * HW2 + toff;
-            const float v = xs[ok ? off : 0];
-            bv[t] = ok ? prologue<PRO>(ia, v, (uint32_t)off) : 0.f;
+          for (int u = 0; u < G; ++u) {
+            const int ci = c2 + u * c2_step + h;
+            const bool cok = ci < C, rok = ci < Cp;
+            const float* wp = wbase + (size_t)(krow0 + tap * Cp + (rok ? ci : 0)) * d.Mpad;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { const float w = wp[wcol[mt]]; av[u][mt] = (mok[mt] && rok) ? w : 0.f; }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const bool ok = tv[t] && cok;
+              const int off = base[t] + ci * HW2 + toff;
+              const float v = xs[ok ? off : 0];
+              bv[u][t] = ok ? prologue<PRO>(ia, v, (uint32_t)off) : 0.f;
+            }
           }
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+          for (int u = 0; u < G; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-              acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[t], acc[mt][t], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][t], acc[mt][t], 0, 0, 0);
         }
       }
     }
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const PixGeo g = decompose((tile0 + t) * 32 + j, a.NP, a.HoWo, d.Wo);
+    const PixGeo g = out_pixel(a, (tile0 + t) * 32 + j);
     if (!g.valid) continue;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -247,7 +270,7 @@ __global__ __launch_bounds__(SW * 64) void conv_gather_splitk_kernel(const Gathe
   for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
   __syncthreads();
   // wave w finishes accumulator register r = w, w + SW, ... (fixed summation order over the waves)
-  const PixGeo g = decompose(pb * 32 + j, a.NP, a.HoWo, d.Wo);
+  const PixGeo g = out_pixel(a, pb * 32 + j);
   for (int r = wave; r < 16; r += SW) {
     float v = 0.f;
 #pragma unroll
@@ -329,7 +352,27 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   if (d->in_act == ACT_NONE && d->drop_p <= 0.f) pro = 0;
   else if (d->in_act == ACT_ELU && d->drop_p <= 0.f) pro = 1;
   else if (d->in_act == ACT_ELU) pro = 2;
+  ga.ph = ga.pw = -1;
+  ga.subW = ga.subHW = 0;
   hipStream_t st = (hipStream_t)stream;
+  if (d->mode == 1 && d->stride > 1 && getenv("VUNET_NO_PHASE") == nullptr) {
+    // strided data gradient: one launch per output parity, each visiting only its own taps
+    const int s = d->stride;
+    for (int ph = 0; ph < s; ++ph)
+      for (int pw = 0; pw < s; ++pw) {
+        GatherArgs gp = ga;
+        gp.ph = ph;
+        gp.pw = pw;
+        const int subH = (d->Ho - ph + s - 1) / s;
+        gp.subW = (d->Wo - pw + s - 1) / s;
+        gp.subHW = subH * gp.subW;
+        gp.NP = d->N * gp.subHW;
+        if (gp.NP <= 0) continue;
+        const int rc = dispatch_gather<0>(gp, pro, st);
+        if (rc != VUNET_OK) return rc;
+      }
+    return VUNET_OK;
+  }
   const bool no_tiled = getenv("VUNET_NO_TILED") != nullptr;
   int mt_unused;
   if (!no_tiled && vunet_conv_tiled_applicable(d) && (d->mode == 0 || pro == 0) && pro != 3 && vunet_conv_tiled_pick(d, &mt_unused, true) > 0)

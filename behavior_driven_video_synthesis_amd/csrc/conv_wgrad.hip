@@ -152,7 +152,7 @@ extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
   wgrad_geometry(d, T, Ctot, Coutp, nchunks, WM);
   const int ciblocks = (Ctot + 31) / 32, coblocks = (d->Cout + 32 * WM - 1) / (32 * WM);
   int S = 768 / (ciblocks * coblocks);
-  if (S > nchunks / 4) S = nchunks / 4;
+  if (S > nchunks) S = nchunks;  // small maps: one 32-pixel chunk per workgroup rather than a serial chunk loop
   if (S < 1) S = 1;
   if (S > 256) S = 256;
   return S;
