@@ -1,17 +1,20 @@
 // Host-side dispatch of the LDS-tiled 3x3 / stride-1 convolution (kernel: conv_tiled_kernel.h).
 #include "conv_common.h"
 
-int vunet_conv_tiled_launch_mt1(const GatherArgs& ga, int pro, int NT, hipStream_t st);
-int vunet_conv_tiled_launch_mt2(const GatherArgs& ga, int pro, int NT, hipStream_t st);
+int vunet_conv_tiled_launch_mt1(const GatherArgs& ga, int pro, int NT, int TW, hipStream_t st);
+int vunet_conv_tiled_launch_mt2(const GatherArgs& ga, int pro, int NT, int TW, hipStream_t st);
 
 bool vunet_conv_tiled_applicable(const vunet_conv_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hs == d->Ho && d->Ws == d->Wo &&
-         d->Ws % 32 == 0 && d->Hs % 4 == 0 && d->C1 % 8 == 0 && d->C2 % 8 == 0;
+         (d->Ws % 32 == 0 || d->Ws % 16 == 0) && d->Hs % (d->Ws % 32 == 0 ? 4 : 8) == 0 && d->C1 % 8 == 0 && d->C2 % 8 == 0;
 }
 
+static int tile_width(const vunet_conv_desc& d) { return d.Ws % 32 == 0 ? 32 : 16; }
+
 static long tiled_blocks(const vunet_conv_desc& d, int MT, int NT) {
-  if (d.Hs % (4 * NT) != 0) return 0;
-  return (long)d.N * (d.Hs / (4 * NT)) * (d.Ws / 32) * ((d.M + 32 * MT - 1) / (32 * MT));
+  const int TW = tile_width(d), TH = 4 * NT * (32 / TW);
+  if (d.Hs % TH != 0 || (TW == 16 && NT != 1)) return 0;
+  return (long)d.N * (d.Hs / TH) * (d.Ws / TW) * ((d.M + 32 * MT - 1) / (32 * MT));
 }
 
 // Tile height, from in-pipeline measurements on MI355X (tools/profile_layers.py, tools/bench_conv.py):
@@ -37,5 +40,6 @@ int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st) {
   int MT;
   const int NT = vunet_conv_tiled_pick(&ga.d, &MT, pro != 0 || (ga.d.mode == 1 && ga.aux != nullptr));
   if (pro == 3) return VUNET_ERR_UNSUPPORTED;
-  return MT == 1 ? vunet_conv_tiled_launch_mt1(ga, pro, NT, st) : vunet_conv_tiled_launch_mt2(ga, pro, NT, st);
+  const int TW = tile_width(ga.d);
+  return MT == 1 ? vunet_conv_tiled_launch_mt1(ga, pro, NT, TW, st) : vunet_conv_tiled_launch_mt2(ga, pro, NT, TW, st);
 }

@@ -20,9 +20,11 @@
 #pragma once
 #include "conv_common.h"
 
-template <int MT, int NT, int CK, int MODE, int PRO>
+// TW = 32: an MFMA pixel tile is one 32-pixel row segment; TW = 16 (16-wide maps): two 16-pixel row segments.
+template <int MT, int NT, int CK, int MODE, int PRO, int TW = 32>
 __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) {
-  constexpr int TH = 4 * NT, IH = TH + 2, IW = 34;
+  constexpr int RPT = 32 / TW;                  // rows per MFMA pixel tile
+  constexpr int TH = 4 * NT * RPT, IH = TH + 2, IW = TW + 2;
   constexpr int MB = 32 * MT;
   constexpr int EI = CK * IH * IW;          // input elements per chunk
   constexpr int EW = 9 * CK * MB;           // weight elements per chunk
@@ -41,12 +43,13 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
   const int mblocks = (d.M + MB - 1) / MB;
   const int mb = bid % mblocks;
   int t = bid / mblocks;
-  const int tiles_w = W / 32, tiles_h = H / TH;
+  const int tiles_w = W / TW, tiles_h = H / TH;
   const int tx = t % tiles_w;
   t /= tiles_w;
   const int ty = t % tiles_h;
   const int n = t / tiles_h;
-  const int row0 = ty * TH, col0 = tx * 32, m0 = mb * MB;
+  const int row0 = ty * TH, col0 = tx * TW, m0 = mb * MB;
+  const int jr = j / TW, jc = j % TW;           // this lane's row / column inside an MFMA pixel tile
 
   // ---- chunk-invariant staging geometry of this thread
   int rel[NI];
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
   __syncthreads();
 
   const int aoff = h * MB + j;                                  // A: wL[(tap*CK + 2p + h)*MB + mt*32 + j]
-  const int boff = h * IH * IW + (wave * NT) * IW + j;          // B: xL[(2p+h)*IH*IW + (row + dr)*IW + j + dc]
+  const int boff = h * IH * IW + (wave * NT * RPT + jr) * IW + jc;  // B: xL[(2p+h)*IH*IW + (row + dr)*IW + col + dc]
   for (int ch = 0; ch < nch; ++ch) {
     const float* buf = smem + (ch & 1) * BUF;
     if (ch + 1 < nch) issue_loads(ch + 1);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) av[mt] = wL[(tap * CK + 2 * p) * MB + mt * 32];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) bv[q] = xL[(2 * p) * IH * IW + (q + dr) * IW + dc];
+        for (int q = 0; q < NT; ++q) bv[q] = xL[(2 * p) * IH * IW + (q * RPT + dr) * IW + dc];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -145,13 +148,13 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
     __syncthreads();
   }
 
-  // ---- epilogue: lane j = column col0 + j of row row0 + wave*NT + q
+  // ---- epilogue: lane j = pixel (row0 + (wave*NT + q)*RPT + jr, col0 + jc)
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     PixGeo g;
     g.n = n;
-    g.oh = row0 + wave * NT + q;
-    g.ow = col0 + j;
+    g.oh = row0 + (wave * NT + q) * RPT + jr;
+    g.ow = col0 + jc;
     g.valid = true;
     if constexpr (NT == 1) {
       // small tile (the VALU-heavy layers): issue the tile's aux / residual loads together
@@ -170,40 +173,40 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
   }
 }
 
-template <int MT, int NT, int CK, int MODE>
+template <int MT, int NT, int CK, int MODE, int TW>
 static int launch_tiled_pro(const GatherArgs& ga, int pro, int blocks, hipStream_t st) {
-  constexpr int BUF = CK * (4 * NT + 2) * 34 + 9 * CK * 32 * MT;
+  constexpr int BUF = CK * (4 * NT * (32 / TW) + 2) * (TW + 2) + 9 * CK * 32 * MT;
   const size_t lds = 2 * (size_t)BUF * sizeof(float);
   dim3 grid((unsigned)blocks), block(256);
   if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (once per instantiation is enough; it is cheap)
-    hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 0, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if constexpr (MODE == 0) {
-      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 1, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 2, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
   }
   if constexpr (MODE == 1) {
-    VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 1, 0>), grid, block, lds, st, ga);
+    VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 1, 0, TW>), grid, block, lds, st, ga);
   } else {
     switch (pro) {
-      case 0: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 0>), grid, block, lds, st, ga); break;
-      case 1: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 1>), grid, block, lds, st, ga); break;
-      case 2: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 2>), grid, block, lds, st, ga); break;
+      case 0: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 0, TW>), grid, block, lds, st, ga); break;
+      case 1: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 1, TW>), grid, block, lds, st, ga); break;
+      case 2: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 2, TW>), grid, block, lds, st, ga); break;
       default: return VUNET_ERR_UNSUPPORTED;
     }
   }
   return vunet_check_launch();
 }
 
-template <int MT, int NT, int CK>
+template <int MT, int NT, int CK, int TW = 32>
 static int launch_tiled(const GatherArgs& ga, int pro, hipStream_t st) {
   const vunet_conv_desc& d = ga.d;
   const int mblocks = (d.M + 32 * MT - 1) / (32 * MT);
-  const int blocks = d.N * (d.Hs / (4 * NT)) * (d.Ws / 32) * mblocks;
+  const int blocks = d.N * (d.Hs / (4 * NT * (32 / TW))) * (d.Ws / TW) * mblocks;
   if (d.mode == 1) {
     if (pro != 0) return VUNET_ERR_UNSUPPORTED;
-    return launch_tiled_pro<MT, NT, CK, 1>(ga, pro, blocks, st);
+    return launch_tiled_pro<MT, NT, CK, 1, TW>(ga, pro, blocks, st);
   }
-  return launch_tiled_pro<MT, NT, CK, 0>(ga, pro, blocks, st);
+  return launch_tiled_pro<MT, NT, CK, 0, TW>(ga, pro, blocks, st);
 }
 
