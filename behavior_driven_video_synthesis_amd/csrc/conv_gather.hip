@@ -326,6 +326,42 @@ bool vunet_conv_tiled_applicable(const vunet_conv_desc* d);
 int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT, bool valu_heavy);
 int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st);
 
+int vunet_conv_tiled_name(const vunet_conv_desc* d, int pro, bool has_aux, char* name, int len);
+
+static int prologue_code(const vunet_conv_desc* d) {
+  if (d->in_act == ACT_NONE && d->drop_p <= 0.f) return 0;
+  if (d->in_act == ACT_ELU && d->drop_p <= 0.f) return 1;
+  if (d->in_act == ACT_ELU) return 2;
+  return 3;
+}
+
+static bool use_tiled(const vunet_conv_desc* d, int pro) {
+  int mt_unused;
+  return getenv("VUNET_NO_TILED") == nullptr && vunet_conv_tiled_applicable(d) && (d->mode == 0 || pro == 0) &&
+         pro != 3 && vunet_conv_tiled_pick(d, &mt_unused, true) > 0;
+}
+
+// Name (rocprofv3 spelling) of the kernel vunet_conv2d_gather would launch for this problem.
+extern "C" int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char* name, int32_t len) {
+  if (!d || !name || len < 8) return VUNET_ERR_ARG;
+  const int pro = prologue_code(d);
+  if (d->mode == 1 && d->stride > 1 && getenv("VUNET_NO_PHASE") == nullptr) {
+    snprintf(name, len, "conv_gather_kernel<phase x%d>", d->stride * d->stride);
+    return VUNET_OK;
+  }
+  if (use_tiled(d, pro)) {
+    vunet_conv_tiled_name(d, pro, has_aux != 0, name, len);
+    return VUNET_OK;
+  }
+  const int KS = (d->KH == 3 && d->KW == 3) ? 3 : ((d->KH == 1 && d->KW == 1) ? 1 : 0);
+  const long ntiles = ((long)d->N * d->Ho * d->Wo + 31) / 32, mtiles = (d->M + 31) / 32;
+  const int kpairs = ((d->C1 + 1) >> 1) + ((d->C2 + 1) >> 1);
+  if (ntiles * mtiles <= 768 && kpairs >= 32) snprintf(name, len, "conv_gather_splitk_kernel<16, %d, %d>", pro, KS);
+  else if (d->M <= 32) snprintf(name, len, "conv_gather_kernel<1, 4, %d, %d>", pro, KS);
+  else snprintf(name, len, "conv_gather_kernel<2, 2, %d, %d>", pro, KS);
+  return VUNET_OK;
+}
+
 extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
                                    const float* shift, const float* res, const float* aux, float* y,
                                    void* stream) {
@@ -348,10 +384,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   ga.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
   ga.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
   ga.auxa = make_inact(d->aux_act, d->aux_slope, d->aux_drop_p, d->aux_drop_seed);
-  int pro = 3;
-  if (d->in_act == ACT_NONE && d->drop_p <= 0.f) pro = 0;
-  else if (d->in_act == ACT_ELU && d->drop_p <= 0.f) pro = 1;
-  else if (d->in_act == ACT_ELU) pro = 2;
+  const int pro = prologue_code(d);
   ga.ph = ga.pw = -1;
   ga.subW = ga.subHW = 0;
   hipStream_t st = (hipStream_t)stream;
@@ -373,10 +406,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
       }
     return VUNET_OK;
   }
-  const bool no_tiled = getenv("VUNET_NO_TILED") != nullptr;
-  int mt_unused;
-  if (!no_tiled && vunet_conv_tiled_applicable(d) && (d->mode == 0 || pro == 0) && pro != 3 && vunet_conv_tiled_pick(d, &mt_unused, true) > 0)
-    return vunet_conv_tiled_launch(ga, pro, st);
+  if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
   if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);
   return dispatch_gather<0>(ga, pro, st);

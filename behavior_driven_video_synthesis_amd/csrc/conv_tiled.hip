@@ -43,3 +43,13 @@ int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st) {
   const int TW = tile_width(ga.d);
   return MT == 1 ? vunet_conv_tiled_launch_mt1(ga, pro, NT, TW, st) : vunet_conv_tiled_launch_mt2(ga, pro, NT, TW, st);
 }
+
+// kernel the tiled path would launch, in rocprofv3's spelling (bench.py matches it against the kernel trace)
+int vunet_conv_tiled_name(const vunet_conv_desc* d, int pro, bool has_aux, char* name, int len) {
+  int MT;
+  const int NT = vunet_conv_tiled_pick(d, &MT, pro != 0 || (d->mode == 1 && has_aux));
+  const int TW = tile_width(*d);
+  const int nt = TW == 16 ? 1 : NT;
+  const int CK = (MT == 2 && nt == 4) ? 4 : 8;
+  return snprintf(name, len, "conv_tiled_kernel<%d, %d, %d, %d, %d, %d>", MT, nt, CK, d->mode, d->mode == 1 ? 0 : pro, TW);
+}

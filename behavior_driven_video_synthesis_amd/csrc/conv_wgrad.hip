@@ -145,6 +145,20 @@ int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d);
 int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
                              float* slabs, float* dshift, hipStream_t st);
 
+extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len) {
+  if (!d || !name || len < 8) return VUNET_ERR_ARG;
+  if (vunet_wgrad_tiled_applicable(d)) {
+    snprintf(name, len, "conv_wgrad_tiled_kernel<%d, 4, %d>", d->Cout >= 64 ? 2 : 1, d->KH);
+    return VUNET_OK;
+  }
+  int T, Ctot, Coutp, nchunks, WM;
+  wgrad_geometry(d, T, Ctot, Coutp, nchunks, WM);
+  const int WN = 4 / WM;
+  const int NTW = T == 1 ? 1 : (T <= 9 ? (WM == 4 ? 9 : (WM == 2 ? 5 : 3)) : (WM == 2 ? 8 : 4));
+  snprintf(name, len, "conv_wgrad_kernel<%d, %d, %d>", WM, WN, NTW);
+  return VUNET_OK;
+}
+
 extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
   if (!d) return VUNET_ERR_ARG;
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_nslabs(d);

@@ -143,12 +143,14 @@ def profile_start():
     _prof["on"], _prof["recs"] = True, []
 
 
-def profile_stop(detail: bool = False):
+def profile_stop(detail: bool = False, by_kernel: bool = False):
     """-> {family: {"ms": total kernel time, "flop": algorithmic FLOPs, "n": launches}} (call after a device sync)."""
     _prof["on"] = False
     fam = {}
     for name, flop, e0, e1 in _prof["recs"]:
-        if not detail:
+        if by_kernel:
+            name = name[-1]
+        elif not detail:
             name = name[0]
         f = fam.setdefault(name, {"ms": 0.0, "flop": 0.0, "n": 0})
         f["ms"] += e0.elapsed_time(e1)
@@ -180,7 +182,13 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
         name, flop = "conv_gather_fwd", 2.0 * desc.N * desc.Ho * desc.Wo * desc.M * (desc.C1 + desc.C2) * t
     else:  # transposed gather: MACs of the forward conv restricted to this source
         name, flop = "conv_gather_dgrad", 2.0 * desc.N * desc.Hs * desc.Ws * desc.C1 * desc.M * t
-    with _Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act), flop):
+    kname = ""
+    if _prof["on"]:
+        buf = ctypes.create_string_buffer(96)
+        _call("vunet_conv2d_gather_variant", ctypes.byref(desc), 0 if aux is None else 1, buf, 96)
+        kname = buf.value.decode()
+    with _Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act, kname),
+                flop):
         _call("vunet_conv2d_gather", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(shift), _p(res), _p(aux), _p(y),
               _stream())
 
@@ -274,7 +282,12 @@ class FusedConv(torch.autograd.Function):
             ktot = k * k * (c1 + c2)
             slabs = torch.empty(ns * _r32(cout) * ktot + ns * _r32(cout), device=dy.device, dtype=torch.float32)
             dshift = slabs[ns * _r32(cout) * ktot:]
-            with _Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act),
+            kname = ""
+            if _prof["on"]:
+                buf = ctypes.create_string_buffer(96)
+                _call("vunet_conv2d_wgrad_variant", ctypes.byref(wd), buf, 96)
+                kname = buf.value.decode()
+            with _Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, kname),
                         2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
                 _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
                       _stream())

@@ -106,7 +106,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("VUNET_DP_FORCE") == "1":
         dist.init_process_group("nccl", device_id=device)
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
@@ -155,27 +155,44 @@ def main():
         for _ in range(prof_steps):
             trainer.train_fn(batch)
         torch.cuda.synchronize()
-        fam = ops.profile_stop()
+        recs = ops._prof["recs"][:]                       # raw (key, flop, ev0, ev1) records of the instrumented steps
+        fam = ops.profile_stop()                           # per family: conv_gather_fwd / conv_gather_dgrad / conv_wgrad
+        ops._prof["recs"] = recs
+        kern = ops.profile_stop(by_kernel=True)            # per kernel instantiation, rocprofv3 spelling
         tot_ms = sum(v["ms"] for v in fam.values())
-        dom = max(fam, key=lambda k: fam[k]["ms"])
-        ach = fam[dom]["flop"] / (fam[dom]["ms"] * 1e-3) / 1e12
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        ach = kern[dom]["flop"] / (kern[dom]["ms"] * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                              "launches": fam[dom]["n"] // prof_steps,
-                              "avg_launch_us": 1e3 * fam[dom]["ms"] / fam[dom]["n"],
-                              "algorithmic_gflop_per_launch": fam[dom]["flop"] / fam[dom]["n"] / 1e9,
+                              "launches_per_step": kern[dom]["n"] // prof_steps,
+                              "avg_launch_us": 1e3 * kern[dom]["ms"] / kern[dom]["n"],
+                              "algorithmic_gflop_per_launch": kern[dom]["flop"] / kern[dom]["n"] / 1e9,
+                              "share_of_conv_time": kern[dom]["ms"] / tot_ms,
                               "families": {k: {"ms_per_step": v["ms"] / prof_steps, "launches_per_step": v["n"] // prof_steps,
                                                "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
                                            for k, v in fam.items()},
+                              "kernels": {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
+                                              "avg_launch_us": round(1e3 * v["ms"] / v["n"], 1),
+                                              "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                          for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]},
                               "conv_ms_per_step": tot_ms / prof_steps,
                               "whole_step_tflops": FLOP_PER_FRAME * args.batch / (1e-3 * result["ms_per_step"]) / 1e12}
+        # HBM traffic per launch of the dominant kernel: PMC passes collected separately (tools/pmc_summary.py)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            ent = pmc["kernels"].get(dom)
+            if ent is not None:
+                result["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json: " + pmc["correction"]
+        except (OSError, ValueError, KeyError):
+            pass
     elif world > 1 and not args.no_roofline:
         pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, cfg)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -75,6 +75,10 @@ typedef struct vunet_conv_desc {
 int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
                         const float* shift, const float* res, const float* aux, float* y, void* stream);
 
+/* Name (as rocprofv3 prints it) of the kernel vunet_conv2d_gather selects for this problem; has_aux: the
+ * call passes an aux tensor.  For profiling / roofline bookkeeping only. */
+int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char* name, int32_t len);
+
 /* Weight gradient  dW[co][tap][ci] = sum_px dy[co][px] * f(x)[ci][px (+) tap]  with the same
  * prologue f as the forward; split over `nsplit` pixel ranges into partial slabs
  *   slabs[nsplit][Coutp][T*(C1+C2)]  (Coutp = Cout rounded up to 32)  and  dshift[nsplit][Coutp].
@@ -92,6 +96,7 @@ typedef struct vunet_wgrad_desc {
 
 int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
                        float* slabs, float* dshift, void* stream);
+int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len);
 /* number of pixel splits the library wants for this problem (caller sizes the slabs from it) */
 int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d);
 

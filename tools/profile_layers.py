@@ -39,6 +39,6 @@ cum = 0.0
 for key, v in rows:
     ms = v["ms"] / args.steps
     cum += ms
-    name, n, c1, c2, hs, ws, m, k, s, act = key
+    name, n, c1, c2, hs, ws, m, k, s, act, kname = key
     print(f"{name:18s} {n:3d} {c1:4d} {c2:4d} {hs:4d} {ws:4d} {m:4d} {k} {s} {act:3d} {v['n'] // args.steps:6d} {ms:8.3f} "
-          f"{1e3 * v['ms'] / v['n']:9.1f} {v['flop'] / (v['ms'] * 1e-3) / 1e12:6.1f} {100 * cum / tot:5.1f}")
+          f"{1e3 * v['ms'] / v['n']:9.1f} {v['flop'] / (v['ms'] * 1e-3) / 1e12:6.1f} {100 * cum / tot:5.1f}  {kname}")
