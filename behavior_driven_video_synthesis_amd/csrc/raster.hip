@@ -1,0 +1,227 @@
+// Pose "stickman" rasteriser on the GPU (lib/utils.py:325-512 make_joint_img; data/human36m.py:808-848).
+//
+// The reference draws each frame on the CPU with cv2.fillPoly / cv2.line, one Python call per
+// primitive.  Here every pixel decides for itself: a workgroup first reduces the frame's draw list to
+// integer parameters in LDS (clipped, left-to-right-normalised Bresenham lines; the polygon's 16.16
+// fixed-point edge table), then each thread evaluates, for four adjacent pixels, the *closed forms* of
+// the two OpenCV primitives -- "is (x, y) the pixel LineIterator visits at its major-axis step?" and
+// "does (x, y) fall in an even-odd scan-line span?" -- and keeps the colour of the last command that
+// covers it (draw order = overwrite order).  Pure integer work (plus the double-precision clip
+// intersection OpenCV itself uses): bit-exact against the sequential restatement in
+// oracle/stickman_oracle.c.  Stores are 4 bytes per lane, 256 B per wavefront; the optional fp32 output
+// applies ToTensor and *2-1 (data/base_dataset.py:183-190, data/__init__.py:23-24).
+#include "common.h"
+
+#define R_MAXCMD 32
+#define R_MAXV 8
+#define XY_SHIFT 16
+#define XY_ONE (1 << XY_SHIFT)
+
+struct RLine {
+  int x0, y0, dmaj, dmin, ystep, major_is_y, valid;
+};
+
+struct RPoly {
+  int valid, fill_valid, nv, ne, ymin, ymax;
+  int ey0[R_MAXV], ey1[R_MAXV];
+  long long ex[R_MAXV], edx[R_MAXV];
+  RLine bl[R_MAXV];
+};
+
+// OpenCV clipLine (integer region codes, double-precision intersections)
+__device__ bool r_clip(long long w, long long h, long long& x1, long long& y1, long long& x2, long long& y2) {
+  const long long right = w - 1, bottom = h - 1;
+  int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    long long a;
+    if (c1 & 12) {
+      a = c1 < 8 ? 0 : bottom;
+      x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+      y1 = a;
+      c1 = (x1 < 0) + (x1 > right) * 2;
+    }
+    if (c2 & 12) {
+      a = c2 < 8 ? 0 : bottom;
+      x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+      y2 = a;
+      c2 = (x2 < 0) + (x2 > right) * 2;
+    }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) {
+        a = c1 == 1 ? 0 : right;
+        y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+        x1 = a;
+        c1 = 0;
+      }
+      if (c2) {
+        a = c2 == 1 ? 0 : right;
+        y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+        x2 = a;
+        c2 = 0;
+      }
+    }
+  }
+  return (c1 | c2) == 0;
+}
+
+// LineIterator(pt1, pt2, 8-connected, leftToRight) reduced to its parameters
+__device__ RLine r_make_line(long long ax, long long ay, long long bx, long long by, int W, int H) {
+  RLine L;
+  L.valid = r_clip(W, H, ax, ay, bx, by) ? 1 : 0;
+  int dx = (int)(bx - ax), dy = (int)(by - ay);
+  int x = (int)ax, y = (int)ay;
+  if (dx < 0) { dx = -dx; dy = -dy; x = (int)bx; y = (int)by; }
+  L.ystep = dy < 0 ? -1 : 1;
+  if (dy < 0) dy = -dy;
+  L.major_is_y = dy > dx;
+  L.dmaj = L.major_is_y ? dy : dx;
+  L.dmin = L.major_is_y ? dx : dy;
+  L.x0 = x;
+  L.y0 = y;
+  return L;
+}
+
+// closed form of the iterator: after i major steps the minor coordinate has advanced by
+// floor((2*dmin*i + dmaj - 1) / (2*dmaj))   (checked exhaustively against the err recurrence)
+__device__ __forceinline__ bool r_on_line(const RLine& L, int x, int y) {
+  if (!L.valid) return false;
+  const int i = L.major_is_y ? (y - L.y0) * L.ystep : x - L.x0;
+  if (i < 0 || i > L.dmaj) return false;
+  const int m = L.dmaj ? (2 * L.dmin * i + L.dmaj - 1) / (2 * L.dmaj) : 0;
+  return L.major_is_y ? (x == L.x0 + m) : (y == L.y0 + L.ystep * m);
+}
+
+__device__ bool r_in_poly(const RPoly& P, int x, int y, int H) {
+  if (!P.valid) return false;
+  for (int i = 0; i < P.nv; ++i)
+    if (r_on_line(P.bl[i], x, y)) return true;  // CollectPolyEdges draws every edge with Line()
+  if (!P.fill_valid || y < P.ymin || y >= min(P.ymax, H) || y < 0) return false;
+  long long xs[R_MAXV];
+  int n = 0;
+  for (int e = 0; e < P.ne; ++e)
+    if (P.ey0[e] <= y && y < P.ey1[e]) xs[n++] = P.ex[e] + (long long)(y - P.ey0[e]) * P.edx[e];
+  for (int a = 1; a < n; ++a) {  // insertion sort, n <= 8
+    const long long v = xs[a];
+    int b = a - 1;
+    while (b >= 0 && xs[b] > v) { xs[b + 1] = xs[b]; --b; }
+    xs[b + 1] = v;
+  }
+  for (int k = 0; k + 1 < n; k += 2) {
+    const int x1 = (int)((xs[k] + XY_ONE - 1) >> XY_SHIFT), x2 = (int)(xs[k + 1] >> XY_SHIFT);
+    if (x1 <= x && x <= x2) return true;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __restrict__ kps, int J,
+                                                              const int* __restrict__ body, int n_body,
+                                                              const int* __restrict__ cmds, int n_cmds,
+                                                              uint8_t* __restrict__ out_u8, float* __restrict__ out_f32,
+                                                              int H, int W) {
+  __shared__ RLine lines[R_MAXCMD];
+  __shared__ RPoly poly;
+  __shared__ int ckind[R_MAXCMD], cplane[R_MAXCMD], ccolor[R_MAXCMD];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* k = kps + (size_t)b * J * 2;
+
+  if (tid < n_cmds) {
+    const int* c = cmds + 5 * tid;
+    ckind[tid] = c[0];
+    cplane[tid] = c[3];
+    ccolor[tid] = c[4];
+    RLine L;
+    L.valid = 0;
+    if (c[0] == 1) {
+      const float ax = k[2 * c[1]], ay = k[2 * c[1] + 1], bx = k[2 * c[2]], by = k[2 * c[2] + 1];
+      if (ax >= 0.f && ay >= 0.f && bx >= 0.f && by >= 0.f)
+        L = r_make_line((long long)ax, (long long)ay, (long long)bx, (long long)by, W, H);
+    }
+    lines[tid] = L;
+  }
+  if (tid == 255) {  // the body polygon (shared by every polygon command)
+    RPoly P;
+    P.valid = 0;
+    P.fill_valid = 0;
+    P.nv = P.ne = 0;
+    long long vx[R_MAXV], vy[R_MAXV];
+    int n = 0;
+    if (n_body > 2)
+      for (int i = 0; i < n_body && n < R_MAXV; ++i) {
+        const float x = k[2 * body[i]], y = k[2 * body[i] + 1];
+        if (x >= 0.f && y >= 0.f) { vx[n] = (long long)x; vy[n] = (long long)y; ++n; }
+      }
+    if (n > 2) {
+      P.valid = 1;
+      P.nv = n;
+      long long px = vx[n - 1] << XY_SHIFT, py = vy[n - 1];
+      int ymax = INT_MIN, ymin = INT_MAX;
+      long long xmax = -1, xmin = LLONG_MAX;
+      for (int i = 0; i < n; ++i) {
+        const long long qx = vx[i] << XY_SHIFT, qy = vy[i];
+        P.bl[i] = r_make_line((px + (XY_ONE >> 1)) >> XY_SHIFT, py, (qx + (XY_ONE >> 1)) >> XY_SHIFT, qy, W, H);
+        if (py != qy) {
+          const int e = P.ne++;
+          if (py < qy) { P.ey0[e] = (int)py; P.ey1[e] = (int)qy; P.ex[e] = px; }
+          else { P.ey0[e] = (int)qy; P.ey1[e] = (int)py; P.ex[e] = qx; }
+          P.edx[e] = (qx - px) / (qy - py);
+          const long long x1 = P.ex[e] + (long long)(P.ey1[e] - P.ey0[e]) * P.edx[e];
+          ymin = min(ymin, P.ey0[e]);
+          ymax = max(ymax, P.ey1[e]);
+          xmin = min(xmin, min(P.ex[e], x1));
+          xmax = max(xmax, max(P.ex[e], x1));
+        }
+        px = qx;
+        py = qy;
+      }
+      P.ymin = ymin;
+      P.ymax = ymax;
+      P.fill_valid = P.ne >= 2 && !(ymax < 0 || ymin >= H || xmax < 0 || xmin >= ((long long)W << XY_SHIFT));
+    }
+    poly = P;
+  }
+  __syncthreads();
+
+  const int W4 = W >> 2;  // W % 4 == 0 (checked by the host)
+  for (int q = blockIdx.y * 256 + tid; q < H * W4; q += gridDim.y * 256) {
+    const int y = q / W4, x0 = (q - y * W4) * 4;
+    uint32_t packed[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int dxp = 0; dxp < 4; ++dxp) {
+      const int x = x0 + dxp;
+      int val[3] = {0, 0, 0};
+      const bool inp = r_in_poly(poly, x, y, H);
+      for (int c = 0; c < n_cmds; ++c) {
+        const bool hit = ckind[c] == 0 ? inp : r_on_line(lines[c], x, y);
+        if (hit) val[cplane[c]] = ccolor[c];
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) packed[p] |= (uint32_t)(val[p] & 255) << (8 * dxp);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const size_t o = (((size_t)b * 3 + p) * H + y) * W + x0;
+      if (out_u8) *reinterpret_cast<uint32_t*>(out_u8 + o) = packed[p];
+      if (out_f32) {
+        float4 f;
+        f.x = ((float)(packed[p] & 255u) / 255.0f) * 2.0f - 1.0f;
+        f.y = ((float)((packed[p] >> 8) & 255u) / 255.0f) * 2.0f - 1.0f;
+        f.z = ((float)((packed[p] >> 16) & 255u) / 255.0f) * 2.0f - 1.0f;
+        f.w = ((float)(packed[p] >> 24) / 255.0f) * 2.0f - 1.0f;
+        *reinterpret_cast<float4*>(out_f32 + o) = f;
+      }
+    }
+  }
+}
+
+extern "C" int vunet_stickman_raster(const float* kps, int32_t B, int32_t J, const int32_t* body, int32_t n_body,
+                                     const int32_t* cmds, int32_t n_cmds, uint8_t* out_u8, float* out_f32, int32_t H,
+                                     int32_t W, void* stream) {
+  if (!kps || !cmds || (!out_u8 && !out_f32) || B < 1 || J < 1 || H < 1 || W < 4 || (W & 3)) return VUNET_ERR_ARG;
+  if (n_cmds < 0 || n_cmds > R_MAXCMD || n_body < 0 || n_body > R_MAXV || (n_body > 0 && !body)) return VUNET_ERR_ARG;
+  int gy = (H * (W >> 2) + 255) / 256;
+  if (gy > 64) gy = 64;
+  VUNET_LAUNCH(stickman_raster_kernel, dim3((unsigned)B, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, kps, J, body,
+               n_body, cmds, n_cmds, out_u8, out_f32, H, W);
+  return vunet_check_launch();
+}

@@ -190,6 +190,17 @@ int vunet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */
 int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* stream);
 
+/* Pose "stickman" rasteriser: lib/utils.py:325-512 (make_joint_img) for thickness-1 LINE_8 cv2.line and
+ * cv2.fillPoly of the body polygon, one launch for a batch of frames (replaces the per-frame CPU raster of
+ * data/human36m.py:808-848 and the render loop data/data_conversions_3d.py:1130-1185).
+ * kps: [B][J][2] float (x, y) in pixels (a joint is valid iff both >= 0; coordinates are truncated like np.int_);
+ * body: [n_body] joint ids of the polygon; cmds: [n_cmds][5] int32 {kind (0 polygon, 1 line), joint a, joint b,
+ * plane, colour}, executed in order (later commands overwrite); all device pointers.
+ * out_u8: [B][3][H][W] uint8 and/or out_f32: the same planes as fp32 (u/255)*2-1; W % 4 == 0.  Integer work,
+ * bit-exact. */
+int vunet_stickman_raster(const float* kps, int32_t B, int32_t J, const int32_t* body, int32_t n_body,
+                          const int32_t* cmds, int32_t n_cmds, uint8_t* out_u8, float* out_f32, int32_t H, int32_t W,
+                          void* stream);
 /* uint8 planes -> fp32 in [-1,1]  (ToTensor, *2-1; data/base_dataset.py:183-190) */
 int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* stream);
 

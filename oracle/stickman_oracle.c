@@ -1,0 +1,248 @@
+/*
+ * stickman_oracle.c -- CPU restatement of the pose "stickman" rasteriser.  TEST INFRASTRUCTURE ONLY
+ * (tests/, __graft_entry__.smoke(), bench.py cpu_baseline); the product never links or calls it.
+ *
+ * Follows lib/utils.py:325-512 (make_joint_img) of the reference with the parameters the shipped
+ * Human3.6m config actually uses: thickness 1, LINE_8, shift 0, no per-line colours;
+ * body polygon -> cv2.fillPoly on planes (0,1,2) with colours (0,127,255) (:345-355); right limbs ->
+ * cv2.line colour 255 on plane 1 (:357-380); left limbs -> 255 on plane 0 (:382-405); head lines -> 127
+ * on planes 0 and 1 (:434-462); joints are valid iff both coordinates >= 0 and are truncated with
+ * np.int_ (:358-361).
+ *
+ * cv2 itself is a third-party dependency that is absent here (pinned opencv=4.1.2 in environment.yml,
+ * not vendored): PARITY UNPINNED against OpenCV.  The two drawing primitives are restated from the
+ * published OpenCV 4.1.2 algorithm (modules/imgproc/src/drawing.cpp): clipLine (integer Cohen-Sutherland
+ * with double-precision intersection), LineIterator (8-connected Bresenham, left-to-right), and
+ * CollectPolyEdges + FillEdgeCollection (boundary lines, then an active-edge scan line in 16.16 fixed
+ * point with incremental x += dx and ceil/floor span ends).  This file keeps their *sequential* structure
+ * on purpose: the GPU kernel (csrc/raster.hip) uses closed forms per pixel, so agreement between the two
+ * is a real check.  Known-answer tests: tests/test_stickman_oracle.py.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define XY_SHIFT 16
+#define XY_ONE (1 << XY_SHIFT)
+
+typedef struct { int64_t x, y; } pt64;
+
+/* OpenCV clipLine(Size2l, Point2l&, Point2l&) */
+static int clip_line(int64_t w, int64_t h, pt64* p1, pt64* p2) {
+  int c1, c2;
+  const int64_t right = w - 1, bottom = h - 1;
+  if (w <= 0 || h <= 0) return 0;
+  int64_t x1 = p1->x, y1 = p1->y, x2 = p2->x, y2 = p2->y;
+  c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    int64_t a;
+    if (c1 & 12) {
+      a = c1 < 8 ? 0 : bottom;
+      x1 += (int64_t)((double)(a - y1) * (x2 - x1) / (y2 - y1));
+      y1 = a;
+      c1 = (x1 < 0) + (x1 > right) * 2;
+    }
+    if (c2 & 12) {
+      a = c2 < 8 ? 0 : bottom;
+      x2 += (int64_t)((double)(a - y2) * (x2 - x1) / (y2 - y1));
+      y2 = a;
+      c2 = (x2 < 0) + (x2 > right) * 2;
+    }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) {
+        a = c1 == 1 ? 0 : right;
+        y1 += (int64_t)((double)(a - x1) * (y2 - y1) / (x2 - x1));
+        x1 = a;
+        c1 = 0;
+      }
+      if (c2) {
+        a = c2 == 1 ? 0 : right;
+        y2 += (int64_t)((double)(a - x2) * (y2 - y1) / (x2 - x1));
+        x2 = a;
+        c2 = 0;
+      }
+    }
+    p1->x = x1; p1->y = y1; p2->x = x2; p2->y = y2;
+  }
+  return (c1 | c2) == 0;
+}
+
+/* OpenCV Line(): LineIterator(img, pt1, pt2, 8, leftToRight=true), every visited pixel set to colour */
+static void draw_line(uint8_t* img, int w, int h, int64_t ax, int64_t ay, int64_t bx, int64_t by, uint8_t color) {
+  pt64 p1 = {ax, ay}, p2 = {bx, by};
+  if (!clip_line(w, h, &p1, &p2)) return;
+  int dx = (int)(p2.x - p1.x), dy = (int)(p2.y - p1.y);
+  int x = (int)p1.x, y = (int)p1.y;
+  if (dx < 0) { /* start from the left end point */
+    dx = -dx;
+    dy = -dy;
+    x = (int)p2.x;
+    y = (int)p2.y;
+  }
+  int ystep = dy < 0 ? -1 : 1;
+  if (dy < 0) dy = -dy;
+  int major_is_y = dy > dx;
+  int dmaj = major_is_y ? dy : dx, dmin = major_is_y ? dx : dy;
+  int err = dmaj - (dmin + dmin);
+  const int plus = dmaj + dmaj, minus = -(dmin + dmin);
+  const int count = dmaj + 1;
+  for (int i = 0; i < count; ++i) {
+    img[(size_t)y * w + x] = color;
+    const int mask = err < 0;
+    err += minus + (mask ? plus : 0);
+    if (major_is_y) { y += ystep; if (mask) x += 1; }
+    else { x += 1; if (mask) y += ystep; }
+  }
+}
+
+typedef struct edge { int y0, y1; int64_t x, dx; struct edge* next; } edge;
+
+static int cmp_edges(const void* a, const void* b) {
+  const edge *e1 = (const edge*)a, *e2 = (const edge*)b;
+  if (e1->y0 != e2->y0) return e1->y0 < e2->y0 ? -1 : 1;
+  if (e1->x != e2->x) return e1->x < e2->x ? -1 : 1;
+  if (e1->dx != e2->dx) return e1->dx < e2->dx ? -1 : 1;
+  return 0;
+}
+
+/* OpenCV fillPoly for one contour: CollectPolyEdges (boundary lines + edge table) then FillEdgeCollection */
+static void fill_poly(uint8_t* img, int w, int h, const int64_t* vx, const int64_t* vy, int n, uint8_t color) {
+  edge edges[16 + 1];
+  int total = 0;
+  if (n < 1 || n > 16) return;
+  int64_t px = vx[n - 1] << XY_SHIFT, py = vy[n - 1];
+  for (int i = 0; i < n; ++i) {
+    const int64_t qx = vx[i] << XY_SHIFT, qy = vy[i];
+    draw_line(img, w, h, (px + (XY_ONE >> 1)) >> XY_SHIFT, py, (qx + (XY_ONE >> 1)) >> XY_SHIFT, qy, color);
+    if (py != qy) {
+      edge e;
+      if (py < qy) { e.y0 = (int)py; e.y1 = (int)qy; e.x = px; }
+      else { e.y0 = (int)qy; e.y1 = (int)py; e.x = qx; }
+      e.dx = (qx - px) / (qy - py);
+      e.next = 0;
+      edges[total++] = e;
+    }
+    px = qx; py = qy;
+  }
+  if (total < 2) return;
+  int y_max = INT32_MIN, y_min = INT32_MAX;
+  int64_t x_max = -1, x_min = INT64_MAX;
+  for (int i = 0; i < total; ++i) {
+    const edge* e = &edges[i];
+    const int64_t x1 = e->x + (int64_t)(e->y1 - e->y0) * e->dx;
+    if (e->y0 < y_min) y_min = e->y0;
+    if (e->y1 > y_max) y_max = e->y1;
+    if (e->x < x_min) x_min = e->x;
+    if (e->x > x_max) x_max = e->x;
+    if (x1 < x_min) x_min = x1;
+    if (x1 > x_max) x_max = x1;
+  }
+  if (y_max < 0 || y_min >= h || x_max < 0 || x_min >= ((int64_t)w << XY_SHIFT)) return;
+  qsort(edges, total, sizeof(edge), cmp_edges);
+  edge tmp;
+  memset(&tmp, 0, sizeof(tmp));
+  edges[total].y0 = INT32_MAX; /* sentinel */
+  int i = 0;
+  edge* e = &edges[0];
+  tmp.next = 0;
+  if (y_max > h) y_max = h;
+  for (int y = e->y0; y < y_max; ++y) {
+    edge *last, *prelast, *keep_prelast;
+    int sort_flag = 0, draw = 0;
+    const int clipline = y < 0;
+    prelast = &tmp;
+    last = tmp.next;
+    while (last || e->y0 == y) {
+      if (last && last->y1 == y) { /* the edge ends on this row: drop it */
+        prelast->next = last->next;
+        last = last->next;
+        continue;
+      }
+      keep_prelast = prelast;
+      if (last && (e->y0 > y || last->x < e->x)) { /* next active edge */
+        prelast = last;
+        last = last->next;
+      } else if (i < total) { /* a new edge starts on this row */
+        prelast->next = e;
+        e->next = last;
+        prelast = e;
+        e = &edges[++i];
+      } else {
+        break;
+      }
+      if (draw) {
+        if (!clipline) {
+          int x1, x2;
+          if (keep_prelast->x > prelast->x) {
+            x1 = (int)((prelast->x + XY_ONE - 1) >> XY_SHIFT);
+            x2 = (int)(keep_prelast->x >> XY_SHIFT);
+          } else {
+            x1 = (int)((keep_prelast->x + XY_ONE - 1) >> XY_SHIFT);
+            x2 = (int)(prelast->x >> XY_SHIFT);
+          }
+          if (x1 < w && x2 >= 0) {
+            if (x1 < 0) x1 = 0;
+            if (x2 >= w) x2 = w - 1;
+            for (int x = x1; x <= x2; ++x) img[(size_t)y * w + x] = color;
+          }
+        }
+        keep_prelast->x += keep_prelast->dx;
+        prelast->x += prelast->dx;
+      }
+      draw ^= 1;
+    }
+    /* keep the active list sorted by x (bubble sort, as upstream) */
+    keep_prelast = 0;
+    do {
+      prelast = &tmp;
+      last = tmp.next;
+      sort_flag = 0;
+      while (last != keep_prelast && last && last->next != 0) {
+        edge* te = last->next;
+        if (last->x > te->x) {
+          prelast->next = te;
+          last->next = te->next;
+          te->next = last;
+          prelast = te;
+          sort_flag = 1;
+        } else {
+          prelast = last;
+          last = te;
+        }
+      }
+      keep_prelast = prelast;
+    } while (sort_flag && keep_prelast != tmp.next && keep_prelast != &tmp);
+  }
+}
+
+/*
+ * Draw list ("commands"), executed in order, per image:
+ *   cmds[c] = { kind, a, b, plane, color }    kind 0: polygon over body[0..n_body), kind 1: line joint a -> joint b
+ * kps: [B][J][2] float (x, y); out: [B][3][H][W] uint8, zero-initialised here.
+ */
+void stickman_raster_oracle(const float* kps, int B, int J, const int32_t* body, int n_body, const int32_t* cmds,
+                            int n_cmds, uint8_t* out, int H, int W) {
+  memset(out, 0, (size_t)B * 3 * H * W);
+  for (int b = 0; b < B; ++b) {
+    const float* k = kps + (size_t)b * J * 2;
+    for (int c = 0; c < n_cmds; ++c) {
+      const int32_t* cmd = cmds + 5 * c;
+      uint8_t* plane = out + ((size_t)b * 3 + cmd[3]) * H * W;
+      if (cmd[0] == 0) {
+        int64_t vx[16], vy[16];
+        int n = 0;
+        if (n_body <= 2) continue;                            /* lib/utils.py:345 */
+        for (int i = 0; i < n_body && n < 16; ++i) {
+          const float x = k[2 * body[i]], y = k[2 * body[i] + 1];
+          if (x >= 0.f && y >= 0.f) { vx[n] = (int64_t)x; vy[n] = (int64_t)y; ++n; }  /* :347-349 */
+        }
+        if (n > 2) fill_poly(plane, W, H, vx, vy, n, (uint8_t)cmd[4]);                 /* :348 */
+      } else {
+        const float ax = k[2 * cmd[1]], ay = k[2 * cmd[1] + 1], bx = k[2 * cmd[2]], by = k[2 * cmd[2] + 1];
+        if (ax >= 0.f && ay >= 0.f && bx >= 0.f && by >= 0.f)                          /* :358-359 */
+          draw_line(plane, W, H, (int64_t)ax, (int64_t)ay, (int64_t)bx, (int64_t)by, (uint8_t)cmd[4]);
+      }
+    }
+  }
+}
