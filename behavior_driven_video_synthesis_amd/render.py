@@ -1,0 +1,62 @@
+"""Batched pose-sequence rendering (BASELINE config 5): 3-D poses -> camera projection -> stickman raster ->
+``VunetAlter.transfer``, all on the GPU.
+
+The reference renders a sequence frame by frame in Python (data/data_conversions_3d.py:1130-1185): per frame a
+numpy projection (:588-605, :892-912), a CPU cv2 raster (lib/utils.py:325-512), an H2D copy, a batch-1
+``synth_model.transfer`` and a D2H copy.  Here one raster launch draws every frame of the sequence and the
+synthesis runs in batches; results are identical frame for frame (tests/test_hip_render.py).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from .lib.utils import H36M_JOINT_MODEL, make_joint_img_batch, scale_img
+
+
+def apply_affine_transform(x: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
+    """R x + t with M = [R, t] (3x4): data/data_conversions_3d.py:588-605.  x: [..., 3]."""
+    ones = torch.ones_like(x[..., :1])
+    return torch.cat([x, ones], dim=-1) @ m.transpose(-1, -2)
+
+
+def camera_projection(poses: torch.Tensor, camera_parameters: Sequence[float]) -> torch.Tensor:
+    """Pinhole projection with (f_x, x_0, f_y, y_0): data/data_conversions_3d.py:892-912.  poses: [..., J, 3]."""
+    fx, x0, fy, y0 = [float(v) for v in camera_parameters]
+    cam = torch.tensor([[fx, 0.0, x0], [0.0, fy, y0], [0.0, 0.0, 1.0]], dtype=poses.dtype, device=poses.device)
+    p = poses / poses[..., -1:]
+    return (p @ cam.T)[..., :-1]
+
+
+def project_sequence(poses3d_world: torch.Tensor, extrinsics: torch.Tensor, intrinsics: Sequence[float],
+                     image_size: Sequence[float], spatial_size: int) -> torch.Tensor:
+    """[T, J, 3] world poses -> [T, J, 2] pixel keypoints at ``spatial_size`` (data/human36m.py:826-834)."""
+    kps2d = camera_projection(apply_affine_transform(poses3d_world, extrinsics), intrinsics)
+    scale = torch.tensor([float(spatial_size) / image_size[0], float(spatial_size) / image_size[1]],
+                         dtype=kps2d.dtype, device=kps2d.device)
+    return kps2d * scale
+
+
+@torch.no_grad()
+def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_size: Optional[int] = None,
+                    joint_model=H36M_JOINT_MODEL, chunk: int = 16, as_uint8: bool = True):
+    """Render T frames: ``app_img`` [1, C, H, W] (appearance), ``kps2d`` [T, J, 2] pixel keypoints.
+
+    Returns (frames, stickmen): frames uint8 [T, H, W, 3] as the reference builds them
+    (``scale_img(rgb) * 255``, channels last, :1160-1167; values are clamped to [0, 255] before the cast) or
+    the raw fp32 [T, 3, H, W] output when ``as_uint8`` is False; stickmen fp32 [T, 3, H, W] in [-1, 1].
+    """
+    size = spatial_size or vunet.spatial_size
+    was_training = vunet.training
+    vunet.eval()
+    stick = make_joint_img_batch((size, size), kps2d.to(app_img.device), joint_model, as_float=True)
+    outs = []
+    for s in range(0, stick.shape[0], chunk):
+        c = stick[s:s + chunk]
+        outs.append(vunet.transfer(app_img.expand(c.shape[0], -1, -1, -1).contiguous(), c))
+    rgb = torch.cat(outs, dim=0)
+    vunet.train(was_training)
+    if as_uint8:
+        rgb = (scale_img(rgb) * 255.0).clamp_(0.0, 255.0).permute(0, 2, 3, 1).to(torch.uint8)
+    return rgb, stick
