@@ -110,3 +110,35 @@ def test_dropout_hash_restatement_is_stable():
         [0, 1753845952, 3507691905, 1734902346]
     m = dropout_keep_mask((4, 1000), 0.25, 12345)
     assert 0.70 < float(m.mean()) < 0.80
+
+
+def test_fused_adam_reads_and_writes_torch_adam_checkpoints():
+    """Checkpoint interop (experiments/shape_and_pose_net.py:474-482, experiments/experiment.py:57-66): the
+    optimizer entry of a reference checkpoint is a torch.optim.Adam state dict with extra group keys."""
+    from behavior_driven_video_synthesis_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 2))
+    ref = torch.optim.Adam([{"params": net[0].parameters(), "name": "eu"}, {"params": net[1].parameters(), "name": "dd"}],
+                           lr=5e-4, betas=(0.5, 0.9))
+    for _ in range(3):
+        ref.zero_grad()
+        net(torch.randn(7, 5)).square().mean().backward()
+        ref.step()
+    for pg in ref.param_groups:
+        pg["gamma"] = 0.25          # the reference smuggles gamma through the param groups (:507-512)
+    sd = ref.state_dict()
+    net2 = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 2))
+    net2.load_state_dict(net.state_dict())
+    opt = FusedAdam([{"params": list(net2[0].parameters()), "name": "eu"},
+                     {"params": list(net2[1].parameters()), "name": "dd"}], lr=1e-3)
+    opt.load_state_dict(sd)
+    assert [b.step for b in opt.buckets] == [3, 3]
+    assert opt.param_groups[0]["lr"] == 5e-4 and opt.param_groups[1]["gamma"] == 0.25
+    assert tuple(opt.param_groups[0]["betas"]) == (0.5, 0.9)
+    out = opt.state_dict()
+    assert set(out["state"].keys()) == set(sd["state"].keys())
+    for k in sd["state"]:
+        assert torch.allclose(out["state"][k]["exp_avg"], sd["state"][k]["exp_avg"])
+        assert torch.allclose(out["state"][k]["exp_avg_sq"], sd["state"][k]["exp_avg_sq"])
+        assert int(out["state"][k]["step"]) == 3
+    assert [g["name"] for g in out["param_groups"]] == ["eu", "dd"] and out["param_groups"][0]["params"] == [0, 1]
