@@ -167,6 +167,7 @@ extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
   const int ciblocks = (Ctot + 31) / 32, coblocks = (d->Cout + 32 * WM - 1) / (32 * WM);
   int S = 768 / (ciblocks * coblocks);
   if (S > nchunks) S = nchunks;  // small maps: one 32-pixel chunk per workgroup rather than a serial chunk loop
+  // (capping S to bound the slab volume was measured slower: the serial chunk loop costs more than the reduce)
   if (S < 1) S = 1;
   if (S > 256) S = 256;
   return S;

@@ -183,23 +183,45 @@ extern "C" int vunet_l1_mean_bwd(const float* a, const float* b, const float* ad
 }
 
 // ------------------------------------------------------------------ KL / squared-difference (latents: small)
-__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* mu, const float* ls, float* out, float scale,
-                                                     float offset, int64_t n) {
+// two-stage (deterministic) sums over up to 256 workgroups; kind 0: -l + .5(e^{2l} + m^2), kind 1: .5 (p-q)^2
+__global__ __launch_bounds__(256) void pair_sum_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               float* __restrict__ partial, int kind, int64_t n) {
   __shared__ float red[4];
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const float l = ls[i], m = mu[i], e = __expf(l);
-    s += -l + 0.5f * (e * e + m * m);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (kind == 0) {
+      const float m = a[i], l = b[i], e = __expf(l);
+      s += -l + 0.5f * (e * e + m * m);
+    } else {
+      const float d = a[i] - b[i];
+      s += 0.5f * d * d;
+    }
   }
+  const float t = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void pair_sum_finish_kernel(const float* partial, int nb, float* out, float scale,
+                                                              float offset) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
   const float t = block_sum_256(s, red);
   if (threadIdx.x == 0) out[0] += scale * t - offset;
 }
-extern "C" int vunet_kl_fwd(const float* mu, const float* ls, float* out, float weight, int32_t N, int64_t D, void* st) {
-  if (!mu || !ls || !out || N <= 0) return VUNET_ERR_ARG;
-  // weight * ( (1/N) sum_all(...) - 0.5 D )
-  VUNET_LAUNCH(kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, mu, ls, out, weight / (float)N,
-                     weight * 0.5f * (float)D, (int64_t)N * D);
+static int pair_sum(const float* a, const float* b, float* partial, float* out, int kind, float scale, float offset,
+                    int64_t n, hipStream_t st) {
+  int64_t nb = (n + 2047) / 2048;
+  if (nb > 256) nb = 256;
+  if (nb < 1) nb = 1;
+  VUNET_LAUNCH(pair_sum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, b, partial, kind, n);
+  VUNET_LAUNCH(pair_sum_finish_kernel, dim3(1), dim3(256), 0, st, partial, (int)nb, out, scale, offset);
   return vunet_check_launch();
+}
+extern "C" int vunet_kl_fwd(const float* mu, const float* ls, float* partial, float* out, float weight, int32_t N,
+                            int64_t D, void* st) {
+  if (!mu || !ls || !partial || !out || N <= 0) return VUNET_ERR_ARG;
+  // weight * ( (1/N) sum_all(...) - 0.5 D )
+  return pair_sum(mu, ls, partial, out, 0, weight / (float)N, weight * 0.5f * (float)D, (int64_t)N * D, (hipStream_t)st);
 }
 __global__ void kl_bwd_kernel(const float* mu, const float* ls, float* dmu, float* dls, float gs, const float* gout,
                               int64_t n) {
@@ -216,22 +238,10 @@ extern "C" int vunet_kl_bwd(const float* mu, const float* ls, float* dmu, float*
   VUNET_LAUNCH(kl_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, ls, dmu, dls, gscale, gout, n);
   return vunet_check_launch();
 }
-__global__ __launch_bounds__(256) void sqdiff_fwd_kernel(const float* p, const float* q, float* out, float scale,
-                                                         int64_t n) {
-  __shared__ float red[4];
-  float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const float d = p[i] - q[i];
-    s += 0.5f * d * d;
-  }
-  const float t = block_sum_256(s, red);
-  if (threadIdx.x == 0) out[0] += scale * t;
-}
-extern "C" int vunet_sqdiff_fwd(const float* p, const float* q, float* out, float weight, int32_t N, int64_t D, void* st) {
-  if (!p || !q || !out || N <= 0) return VUNET_ERR_ARG;
-  VUNET_LAUNCH(sqdiff_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, p, q, out, weight / (float)N,
-                     (int64_t)N * D);
-  return vunet_check_launch();
+extern "C" int vunet_sqdiff_fwd(const float* p, const float* q, float* partial, float* out, float weight, int32_t N,
+                                int64_t D, void* st) {
+  if (!p || !q || !partial || !out || N <= 0) return VUNET_ERR_ARG;
+  return pair_sum(p, q, partial, out, 1, weight / (float)N, 0.f, (int64_t)N * D, (hipStream_t)st);
 }
 __global__ void sqdiff_bwd_kernel(const float* p, const float* q, float* dp, float* dq, float gs, const float* gout,
                                   int64_t n) {

@@ -100,6 +100,101 @@ extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, cons
   return vunet_check_launch();
 }
 
+// ---- batched form: every layer of a model in two launches (one workgroup row per layer) ----------
+struct WnItemDev {  // mirrors vunet_wn_item (include/vunet_hip.h)
+  const float *v, *g, *bias, *gamma, *beta;
+  float *wt_f, *wt_d, *scale, *shift, *invnorm;
+  vunet_wn_desc d;
+};
+
+__device__ __forceinline__ WnArgs item_args(const WnItemDev& it) {
+  WnArgs a;
+  a.d = it.d;
+  a.v = it.v; a.g = it.g; a.bias = it.bias; a.gamma = it.gamma; a.beta = it.beta;
+  a.wt_f = it.wt_f; a.wt_d = it.wt_d; a.scale = it.scale; a.shift = it.shift; a.invnorm = it.invnorm;
+  a.T = it.d.KH * it.d.KW;
+  a.Ctot = it.d.C1 + it.d.C2;
+  a.C1p = (it.d.C1 + 1) & ~1;
+  a.C2p = (it.d.C2 + 1) & ~1;
+  a.Kf = a.T * (a.C1p + a.C2p);
+  a.Mpad_f = (it.d.Cout + 31) / 32 * 32;
+  a.Coutp2 = (it.d.Cout + 1) & ~1;
+  a.Kd = a.T * a.Coutp2;
+  a.Mpad_d = (a.Ctot + 31) / 32 * 32;
+  return a;
+}
+
+__device__ __forceinline__ void wn_scale_body(const WnArgs& a, int co, int lane) {
+  const int K = a.Ctot * a.T;
+  const float* vr = a.v + (size_t)co * K;
+  float invn = 1.f, scale = 1.f;
+  if (a.d.kind != 1) {
+    float ss = 0.f;
+    for (int k = lane; k < K; k += 64) { const float t = vr[k]; ss += t * t; }
+    ss = wave_sum(ss);
+    float nrm = sqrtf(ss);
+    if (a.d.kind == 2) nrm = fmaxf(nrm, 1e-12f);
+    invn = 1.f / nrm;
+    const float gm = a.gamma ? a.gamma[co] : 1.f;
+    scale = a.d.kind == 0 ? gm * a.g[co] * invn : gm * invn;
+  }
+  if (lane == 0) {
+    const float gm = (a.d.kind != 1 && a.gamma) ? a.gamma[co] : 1.f;
+    const float b = a.bias ? a.bias[co] : 0.f;
+    const float be = (a.d.kind != 1 && a.beta) ? a.beta[co] : 0.f;
+    a.scale[co] = scale;
+    a.invnorm[co] = invn;
+    a.shift[co] = gm * b + be;
+  }
+}
+
+__device__ __forceinline__ void wn_pack_body(const WnArgs& a, size_t start, size_t stride) {
+  const size_t nf = (size_t)a.Kf * a.Mpad_f;
+  const size_t nd = a.wt_d ? (size_t)a.Kd * a.Mpad_d : 0;
+  const int T = a.T;
+  for (size_t i = start; i < nf + nd; i += stride) {
+    if (i < nf) {
+      const int krow = (int)(i / a.Mpad_f), m = (int)(i - (size_t)krow * a.Mpad_f);
+      int tap, c, cg;
+      bool ok;
+      const int k1 = T * a.C1p;
+      if (krow < k1) { tap = krow / a.C1p; c = krow - tap * a.C1p; ok = c < a.d.C1; cg = c; }
+      else { const int r = krow - k1; tap = r / a.C2p; c = r - tap * a.C2p; ok = c < a.d.C2; cg = a.d.C1 + c; }
+      float w = 0.f;
+      if (ok && m < a.d.Cout) w = a.scale[m] * a.v[((size_t)m * a.Ctot + cg) * T + tap];
+      a.wt_f[i] = w;
+    } else {
+      const size_t e = i - nf;
+      const int row = (int)(e / a.Mpad_d), ci = (int)(e - (size_t)row * a.Mpad_d);
+      const int tap = row / a.Coutp2, co = row - tap * a.Coutp2;
+      float w = 0.f;
+      if (co < a.d.Cout && ci < a.Ctot) w = a.scale[co] * a.v[((size_t)co * a.Ctot + ci) * T + tap];
+      a.wt_d[e] = w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void wn_scale_multi_kernel(const WnItemDev* __restrict__ items) {
+  const WnItemDev& it = items[blockIdx.y];
+  if ((int)blockIdx.x >= it.d.Cout) return;
+  wn_scale_body(item_args(it), blockIdx.x, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void wn_pack_multi_kernel(const WnItemDev* __restrict__ items) {
+  wn_pack_body(item_args(items[blockIdx.y]), (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+extern "C" int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_t n_items, int32_t max_cout,
+                                          void* stream) {
+  if (!items_dev || n_items < 1 || max_cout < 1) return VUNET_ERR_ARG;
+  static_assert(sizeof(WnItemDev) == sizeof(vunet_wn_item), "vunet_wn_item layout");
+  const WnItemDev* items = reinterpret_cast<const WnItemDev*>(items_dev);
+  hipStream_t st = (hipStream_t)stream;
+  VUNET_LAUNCH(wn_scale_multi_kernel, dim3((unsigned)max_cout, (unsigned)n_items), dim3(64), 0, st, items);
+  VUNET_LAUNCH(wn_pack_multi_kernel, dim3(64, (unsigned)n_items), dim3(256), 0, st, items);
+  return vunet_check_launch();
+}
+
 struct WnBwdArgs {
   vunet_wn_desc d;
   const float *slabs, *dshift, *v, *g, *bias, *gamma, *invnorm;

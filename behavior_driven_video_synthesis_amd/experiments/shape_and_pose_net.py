@@ -21,6 +21,7 @@ from typing import Dict, Optional
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from ..lib.losses import compute_kl_with_prior, vgg_loss
 from ..lib.utils import get_member, linear_var, n_parameters
 from ..models.imagenet_pretrained import PerceptualVGG, vgg19
@@ -120,6 +121,11 @@ class ShapePoseNet:
 
         self.averager.start_step()
         self.optimizer.zero_grad()
+        with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
+            return self._step(batch, it, target_img, shape_img, pose_img, eps)
+
+    def _step(self, batch, it, target_img, shape_img, pose_img, eps):
+        tr = self.config["training"]
         out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
         ld = vgg_loss(self.custom_vgg, target_img, out_img)
         likelihoods = torch.stack([ld[k] for k in ld], dim=0)

@@ -113,7 +113,7 @@ class NormConv2d(nn.Module):
         x1, x2 = _split(x)
         cfg = ops.ConvCfg(kind=self.kind, k=self.k, stride=self.stride, pad=self.padding, in_act=in_act,
                           in_slope=in_slope, drop_p=drop_p, drop_seed=ops.next_dropout_seed() if drop_p > 0 else 0,
-                          out_act=out_act, d2s=d2s)
+                          out_act=out_act, d2s=d2s, owner=self)
         v, g, b, gamma, beta = self._params()
         return ops.fused_conv(x1, x2, res, v, g, b, gamma, beta, cfg)
 

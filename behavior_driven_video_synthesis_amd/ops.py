@@ -112,6 +112,7 @@ class ConvCfg:
     out_act: int = ACT_NONE
     d2s: bool = False
     res_is_x1: bool = False  # residual tensor is source 1 itself -> its gradient is fused into the dgrad epilogue
+    owner: object = None     # the calling module (records its source split; looked up in the active prepack set)
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
@@ -215,6 +216,74 @@ def remove_grad_hook(fn):
 _frozen_pack_cache = {}
 
 
+# ------------------------------------------------------------------------------------------------
+# batched weight preparation: every layer of a model in two launches (vunet_weightnorm_fwd_multi)
+# ------------------------------------------------------------------------------------------------
+class WnItem(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("v", "g", "bias", "gamma", "beta", "wt_f", "wt_d", "scale", "shift",
+                                                "invnorm")] + [("d", WnDesc)]
+
+
+_prepack_sets = {}      # id(model) -> dict(signature, table, max_cout, entries, keep)
+_active_prepack = {}    # id(module) -> (split, wt_f, wt_d, scale, shift, invnorm), only inside `prepacked(...)`
+
+
+def _ptr_or_none(t):
+    return None if t is None else t.data_ptr()
+
+
+def _build_prepack_set(model):
+    mods = [m for m in model.modules() if hasattr(m, "_params") and getattr(m, "_last_split", None) is not None]
+    sig = tuple((id(m), m._last_split) for m in mods)
+    cur = _prepack_sets.get(id(model))
+    if cur is not None and cur["signature"] == sig:
+        return cur
+    if not mods:
+        return None
+    dev = next(model.parameters()).device
+    items, entries, keep, max_cout = (WnItem * len(mods))(), {}, [], 1
+    for i, m in enumerate(mods):
+        v, g, b, gamma, beta = m._params()
+        c1, c2, need_x = m._last_split
+        cout, ctot, kh, kw = v.shape
+        t = kh * kw
+        wt_f = torch.empty(t * (_r2(c1) + _r2(c2)), _r32(cout), device=dev, dtype=torch.float32)
+        wt_d = torch.empty(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_x else None
+        small = torch.empty(3, cout, device=dev, dtype=torch.float32)
+        it = items[i]
+        it.v, it.g, it.bias, it.gamma, it.beta = (_ptr_or_none(x) for x in (v, g, b, gamma, beta))
+        it.wt_f, it.wt_d = wt_f.data_ptr(), _ptr_or_none(wt_d)
+        it.scale, it.shift, it.invnorm = small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
+        it.d = WnDesc(cout, c1, c2, kh, kw, m.kind)
+        entries[id(m)] = ((c1, c2, need_x), wt_f, wt_d, small[0], small[1], small[2])
+        keep.append((wt_f, wt_d, small))
+        max_cout = max(max_cout, cout)
+    raw = bytes(items)
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    cur = {"signature": sig, "table": table, "n": len(mods), "max_cout": max_cout, "entries": entries, "keep": keep}
+    _prepack_sets[id(model)] = cur
+    return cur
+
+
+class prepacked:
+    """``with ops.prepacked(model):`` -- pack the weights of every already-seen conv layer of ``model`` in two
+    launches and let the fused convs inside the block use them.  The caller guarantees that parameters do not
+    change inside the block (the training step wraps forward + backward, the optimiser steps after it)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        cur = _build_prepack_set(self.model)
+        if cur is not None:
+            _call("vunet_weightnorm_fwd_multi", _p(cur["table"]), cur["n"], cur["max_cout"], _stream())
+            _active_prepack.update(cur["entries"])
+        return self
+
+    def __exit__(self, *a):
+        _active_prepack.clear()
+
+
 class FusedConv(torch.autograd.Function):
     """y = [d2s] act_out( conv( drop(act_in(cat(x1, x2))) ; w_eff ) + shift ) [+ res]."""
 
@@ -232,7 +301,15 @@ class FusedConv(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[3:8])
         frozen = not any(t is not None and t.requires_grad for t in (v, g, bias, gamma, beta))
         key = (v.data_ptr(), v._version, c1, c2, cfg.kind, need_x) if frozen else None
-        if frozen and key in _frozen_pack_cache:
+        pre = None
+        if cfg.owner is not None and not frozen:
+            cfg.owner._last_split = (c1, c2, bool(need_x) or getattr(cfg.owner, "_last_split", (0, 0, False))[2])
+            pre = _active_prepack.get(id(cfg.owner))
+            if pre is not None and (pre[0][:2] != (c1, c2) or (need_x and pre[2] is None)):
+                pre = None
+        if pre is not None:
+            _, wt_f, wt_d, scale, shift, invnorm = pre
+        elif frozen and key in _frozen_pack_cache:
             wt_f, wt_d, scale, shift, invnorm = _frozen_pack_cache[key]
         else:
             wt_f, wt_d, scale, shift, invnorm = pack_weights(v, g, bias, gamma, beta, c1, c2, cfg.kind, need_x)
@@ -443,7 +520,8 @@ class KLPrior(torch.autograd.Function):
         n = mu.shape[0]
         d = mu.numel() // n
         out = torch.zeros((), device=mu.device, dtype=torch.float32)
-        _call("vunet_kl_fwd", _p(mu), _p(logstd), _p(out), float(weight), n, d, _stream())
+        partial = torch.empty(256, device=mu.device, dtype=torch.float32)
+        _call("vunet_kl_fwd", _p(mu), _p(logstd), _p(partial), _p(out), float(weight), n, d, _stream())
         ctx.save_for_backward(mu, logstd)
         ctx.scale = float(weight) / n
         return out
@@ -465,7 +543,8 @@ class SqDiff(torch.autograd.Function):
         p, q = _c(p), _c(q)
         n = p.shape[0]
         out = torch.zeros((), device=p.device, dtype=torch.float32)
-        _call("vunet_sqdiff_fwd", _p(p), _p(q), _p(out), float(weight), n, p.numel() // n, _stream())
+        partial = torch.empty(256, device=p.device, dtype=torch.float32)
+        _call("vunet_sqdiff_fwd", _p(p), _p(q), _p(partial), _p(out), float(weight), n, p.numel() // n, _stream())
         ctx.save_for_backward(p, q)
         ctx.scale = float(weight) / n
         return out

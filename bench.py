@@ -148,13 +148,15 @@ def main():
                    "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val},
     }
 
-    if rank == 0 and not args.no_roofline:
-        # instrumented region: HIP events around every conv-family launch (same stream as the kernels)
+    if not args.no_roofline:
+        # instrumented region: HIP events around every conv-family launch (same stream as the kernels).
+        # Every rank runs these steps (train_fn contains the gradient all-reduce); only rank 0 reports.
         prof_steps = max(1, min(3, args.steps))
         ops.profile_start()
         for _ in range(prof_steps):
             trainer.train_fn(batch)
-        torch.cuda.synchronize()
+        sync_all()
+    if rank == 0 and not args.no_roofline:
         recs = ops._prof["recs"][:]                       # raw (key, flop, ev0, ev1) records of the instrumented steps
         fam = ops.profile_stop()                           # per family: conv_gather_fwd / conv_gather_dgrad / conv_wgrad
         ops._prof["recs"] = recs
@@ -186,8 +188,8 @@ def main():
                 result["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json: " + pmc["correction"]
         except (OSError, ValueError, KeyError):
             pass
-    elif world > 1 and not args.no_roofline:
-        pass
+    elif not args.no_roofline:
+        ops.profile_stop()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, cfg)
     if rank == 0:

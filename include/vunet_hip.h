@@ -120,6 +120,15 @@ int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g,
                          const float* gamma, const float* beta, float* wt_f, float* wt_d, float* scale,
                          float* shift, float* invnorm, void* stream);
 
+/* Batched form: the weights of every layer of a model in two launches.  items_dev: DEVICE array of n_items
+ * entries (the pointers are device pointers; entries with kind/NULL rules as above); max_cout = max over items. */
+typedef struct vunet_wn_item {
+  const float *v, *g, *bias, *gamma, *beta;
+  float *wt_f, *wt_d, *scale, *shift, *invnorm;
+  vunet_wn_desc d;
+} vunet_wn_item;
+int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_t n_items, int32_t max_cout, void* stream);
+
 /* backward: reduces the wgrad slabs (fixed order) and produces the parameter gradients
  * dv[Cout][Cin][KH][KW], dg[Cout], dbias[Cout], dgamma[Cout], dbeta[Cout] (NULL to skip).
  * workspace: Cout*(KH*KW*(C1+C2) + 1) floats.  accumulate != 0: add into the outputs (they are then the
@@ -157,11 +166,13 @@ int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* d
                       const float* gout, int64_t n, void* stream);
 
 /* KL(N(mu, exp(l)^2) || N(0,1)) per lib/losses.py:283-291: out[0] += weight * mean_n(sum_d(-l + .5(e^{2l}+mu^2)) - .5 D) */
-int vunet_kl_fwd(const float* mu, const float* logstd, float* out, float weight, int32_t N, int64_t D, void* stream);
+int vunet_kl_fwd(const float* mu, const float* logstd, float* partial, float* out, float weight, int32_t N, int64_t D,
+                 void* stream);  /* partial: >= 256 floats of workspace (two-stage deterministic sum) */
 int vunet_kl_bwd(const float* mu, const float* logstd, float* dmu, float* dlogstd, float gscale,
                  const float* gout, int64_t n, void* stream);
 /* 0.5*(p-q)^2 summed over CHW, batch mean (lib/losses.py:26-37) */
-int vunet_sqdiff_fwd(const float* p, const float* q, float* out, float weight, int32_t N, int64_t D, void* stream);
+int vunet_sqdiff_fwd(const float* p, const float* q, float* partial, float* out, float weight, int32_t N, int64_t D,
+                     void* stream);
 int vunet_sqdiff_bwd(const float* p, const float* q, float* dp, float* dq, float gscale, const float* gout,
                      int64_t n, void* stream);
 
