@@ -228,3 +228,37 @@ def test_full_width_vunet_vs_oracle():
             continue
         tol = 2e-3 * float(gr.abs().max()) + 1e-6
         assert_close(p.grad, gr, rtol=2e-3, atol=tol, name=k)
+
+
+@pytest.mark.parametrize("conv_layer_type", ["l2", "ln"])
+def test_vunet_alter_conv_layer_variants_vs_oracle(conv_layer_type):
+    """conv_layer_type l2 (L2NormConv2d) and anything else (LayerNormConv2d): models/vunets.py:445-453, SURVEY a15."""
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    from oracle import vunet_oracle as O
+    cfg = dict(spatial_size=32, bottleneck_factor=2, box_factor=2, n_scales=0, n_latent_scales=2,
+               conv_layer_type=conv_layer_type, nf_start=8, nf_max=16, subpixel_upsampling=True, dropout_prob=0.0)
+    net = VunetAlter(init_fn=lambda: False, **cfg)
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    sd = synth_state_dict(shapes, 8)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    x, c = synth_image("vx", (2, 3, 32, 32), 8), synth_image("vc", (2, 3, 32, 32), 8)
+    eps = [seeded_randn("ve0", (2, 16, 4, 4), 8), seeded_randn("ve1", (2, 16, 8, 8), 8)]
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    img_r, means_r, logstds_r, _ = O.vunet_alter_forward(sdr, cfg, x, c, eps)
+    wgt = seeded_randn("vw", tuple(img_r.shape), 8)
+    (img_r * wgt).sum().backward()
+    img, means, logstds, _ = net(x.cuda(), c.cuda(), [e.cuda() for e in eps])
+    scale = max(float(img_r.abs().max()), 1.0)
+    assert_close(img, img_r, rtol=2e-4, atol=2e-4 * scale, name="img")
+    assert_close(means[1], means_r[1], rtol=2e-4, atol=2e-4 * scale, name="mean1")
+    (img * wgt.cuda()).sum().backward()
+    gmax = max(float(v.grad.abs().max()) for v in sdr.values() if v.grad is not None)
+    for k, p in net.named_parameters():
+        gr = sdr[k].grad
+        if gr is None:
+            continue
+        # a conv bias in front of InstanceNorm has a mathematically zero gradient: both sides are rounding noise,
+        # so the absolute tolerance is tied to the largest gradient of the model
+        tol = 3e-3 * float(gr.abs().max()) + 1e-4 * gmax + 1e-6
+        assert_close(p.grad, gr, rtol=3e-3, atol=tol, name=k)
