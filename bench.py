@@ -72,7 +72,9 @@ def cpu_baseline(args, cfg):
     kw.update(cfg["data"])
     kw["dropout_prob"] = 0.0
     torch.manual_seed(42)
-    net = VunetAlter(**kw)  # host-side parameter container only: gives the reference's default init + key layout
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        net = VunetAlter(**kw)  # host-side parameter container only: gives the reference's default init + key layout
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     vsd = O.make_synthetic_vgg19(seed=1234)
     opt = torch.optim.Adam([{"params": [v for k, v in sd.items() if k.startswith(n + ".")], "name": n}
@@ -112,7 +114,9 @@ def main():
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
 
     cfg = make_config(args)
-    trainer = ShapePoseNet(cfg, device=device, total_steps=150000)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # the constructors print like the reference does; stdout is for the JSON line
+        trainer = ShapePoseNet(cfg, device=device, total_steps=150000)
     batch = synthetic_batch(args.batch, args.size, device, seed=42, with_regressor=args.regressor, rank=rank)
 
     def sync_all():
