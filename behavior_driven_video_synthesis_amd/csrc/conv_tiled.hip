@@ -5,16 +5,19 @@ int vunet_conv_tiled_launch_mt1(const GatherArgs& ga, int pro, int NT, int TW, h
 int vunet_conv_tiled_launch_mt2(const GatherArgs& ga, int pro, int NT, int TW, hipStream_t st);
 
 bool vunet_conv_tiled_applicable(const vunet_conv_desc* d) {
-  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hs == d->Ho && d->Ws == d->Wo &&
-         (d->Ws % 32 == 0 || d->Ws % 16 == 0) && d->Hs % (d->Ws % 32 == 0 ? 4 : 8) == 0 && d->C1 % 8 == 0 && d->C2 % 8 == 0;
+  if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->C1 % 8 != 0 || d->C2 % 8 != 0) return false;
+  if (d->stride == 2)  // Downsample conv, forward only: 4 x 32 output tiles
+    return d->mode == 0 && d->Hs == 2 * d->Ho && d->Ws == 2 * d->Wo && d->Wo % 32 == 0 && d->Ho % 4 == 0;
+  return d->stride == 1 && d->Hs == d->Ho && d->Ws == d->Wo && (d->Ws % 32 == 0 || d->Ws % 16 == 0) &&
+         d->Hs % (d->Ws % 32 == 0 ? 4 : 8) == 0;
 }
 
-static int tile_width(const vunet_conv_desc& d) { return d.Ws % 32 == 0 ? 32 : 16; }
+static int tile_width(const vunet_conv_desc& d) { return d.Wo % 32 == 0 ? 32 : 16; }
 
 static long tiled_blocks(const vunet_conv_desc& d, int MT, int NT) {
   const int TW = tile_width(d), TH = 4 * NT * (32 / TW);
-  if (d.Hs % TH != 0 || (TW == 16 && NT != 1)) return 0;
-  return (long)d.N * (d.Hs / TH) * (d.Ws / TW) * ((d.M + 32 * MT - 1) / (32 * MT));
+  if (d.Ho % TH != 0 || ((TW == 16 || d.stride == 2) && NT != 1)) return 0;
+  return (long)d.N * (d.Ho / TH) * (d.Wo / TW) * ((d.M + 32 * MT - 1) / (32 * MT));
 }
 
 // Tile height, from in-pipeline measurements on MI355X (tools/profile_layers.py, tools/bench_conv.py):
@@ -51,5 +54,6 @@ int vunet_conv_tiled_name(const vunet_conv_desc* d, int pro, bool has_aux, char*
   const int TW = tile_width(*d);
   const int nt = TW == 16 ? 1 : NT;
   const int CK = (MT == 2 && nt == 4) ? 4 : 8;
-  return snprintf(name, len, "conv_tiled_kernel<%d, %d, %d, %d, %d, %d>", MT, nt, CK, d->mode, d->mode == 1 ? 0 : pro, TW);
+  return snprintf(name, len, "conv_tiled_kernel<%d, %d, %d, %d, %d, %d, %d>", MT, d->stride == 2 ? 1 : nt, CK, d->mode,
+                  d->mode == 1 ? 0 : pro, TW, d->stride);
 }

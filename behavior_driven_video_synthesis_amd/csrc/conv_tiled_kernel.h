@@ -21,10 +21,11 @@
 #include "conv_common.h"
 
 // TW = 32: an MFMA pixel tile is one 32-pixel row segment; TW = 16 (16-wide maps): two 16-pixel row segments.
-template <int MT, int NT, int CK, int MODE, int PRO, int TW = 32>
+// S = 2: the stride-2 Downsample conv (forward only): the staged input tile is (2*TH+1) x (2*TW+1).
+template <int MT, int NT, int CK, int MODE, int PRO, int TW = 32, int S = 1>
 __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) {
   constexpr int RPT = 32 / TW;                  // rows per MFMA pixel tile
-  constexpr int TH = 4 * NT * RPT, IH = TH + 2, IW = TW + 2;
+  constexpr int TH = 4 * NT * RPT, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
   constexpr int MB = 32 * MT;
   constexpr int EI = CK * IH * IW;          // input elements per chunk
   constexpr int EW = 9 * CK * MB;           // weight elements per chunk
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
   const int mblocks = (d.M + MB - 1) / MB;
   const int mb = bid % mblocks;
   int t = bid / mblocks;
-  const int tiles_w = W / TW, tiles_h = H / TH;
+  const int tiles_w = d.Wo / TW, tiles_h = d.Ho / TH;   // tiles walk the OUTPUT map
   const int tx = t % tiles_w;
   t /= tiles_w;
   const int ty = t % tiles_h;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
     const int c = e / (IH * IW);
     const int rem = e - c * (IH * IW);
     const int r = rem / IW, col = rem - r * IW;
-    const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+    const int ih = row0 * S - 1 + r, iw = col0 * S - 1 + col;
     const bool ok = e < EI && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     rel[i] = ok ? c * HW + ih * W + iw : 0;  // invalid: a safe in-bounds address, the value is masked afterwards
     vbits |= (ok ? 1u : 0u) << i;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
   __syncthreads();
 
   const int aoff = h * MB + j;                                  // A: wL[(tap*CK + 2p + h)*MB + mt*32 + j]
-  const int boff = h * IH * IW + (wave * NT * RPT + jr) * IW + jc;  // B: xL[(2p+h)*IH*IW + (row + dr)*IW + col + dc]
+  const int boff = h * IH * IW + (wave * NT * RPT + jr) * S * IW + jc * S;  // B: xL[(2p+h)*IH*IW + (S*row + dr)*IW + S*col + dc]
   for (int ch = 0; ch < nch; ++ch) {
     const float* buf = smem + (ch & 1) * BUF;
     if (ch + 1 < nch) issue_loads(ch + 1);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) av[mt] = wL[(tap * CK + 2 * p) * MB + mt * 32];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) bv[q] = xL[(2 * p) * IH * IW + (q * RPT + dr) * IW + dc];
+        for (int q = 0; q < NT; ++q) bv[q] = xL[(2 * p) * IH * IW + (q * RPT * S + dr) * IW + dc];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -173,40 +174,40 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
   }
 }
 
-template <int MT, int NT, int CK, int MODE, int TW>
+template <int MT, int NT, int CK, int MODE, int TW, int S>
 static int launch_tiled_pro(const GatherArgs& ga, int pro, int blocks, hipStream_t st) {
-  constexpr int BUF = CK * (4 * NT * (32 / TW) + 2) * (TW + 2) + 9 * CK * 32 * MT;
+  constexpr int BUF = CK * ((4 * NT * (32 / TW) - 1) * S + 3) * ((TW - 1) * S + 3) + 9 * CK * 32 * MT;
   const size_t lds = 2 * (size_t)BUF * sizeof(float);
   dim3 grid((unsigned)blocks), block(256);
   if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (once per instantiation is enough; it is cheap)
-    hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 0, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 0, TW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if constexpr (MODE == 0) {
-      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 1, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 2, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 1, TW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 2, TW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
   }
   if constexpr (MODE == 1) {
-    VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 1, 0, TW>), grid, block, lds, st, ga);
+    VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 1, 0, TW, S>), grid, block, lds, st, ga);
   } else {
     switch (pro) {
-      case 0: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 0, TW>), grid, block, lds, st, ga); break;
-      case 1: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 1, TW>), grid, block, lds, st, ga); break;
-      case 2: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 2, TW>), grid, block, lds, st, ga); break;
+      case 0: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 0, TW, S>), grid, block, lds, st, ga); break;
+      case 1: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 1, TW, S>), grid, block, lds, st, ga); break;
+      case 2: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 2, TW, S>), grid, block, lds, st, ga); break;
       default: return VUNET_ERR_UNSUPPORTED;
     }
   }
   return vunet_check_launch();
 }
 
-template <int MT, int NT, int CK, int TW = 32>
+template <int MT, int NT, int CK, int TW = 32, int S = 1>
 static int launch_tiled(const GatherArgs& ga, int pro, hipStream_t st) {
   const vunet_conv_desc& d = ga.d;
   const int mblocks = (d.M + 32 * MT - 1) / (32 * MT);
-  const int blocks = d.N * (d.Hs / (4 * NT * (32 / TW))) * (d.Ws / TW) * mblocks;
+  const int blocks = d.N * (d.Ho / (4 * NT * (32 / TW))) * (d.Wo / TW) * mblocks;
   if (d.mode == 1) {
     if (pro != 0) return VUNET_ERR_UNSUPPORTED;
-    return launch_tiled_pro<MT, NT, CK, 1, TW>(ga, pro, blocks, st);
+    return launch_tiled_pro<MT, NT, CK, 1, TW, S>(ga, pro, blocks, st);
   }
-  return launch_tiled_pro<MT, NT, CK, 0, TW>(ga, pro, blocks, st);
+  return launch_tiled_pro<MT, NT, CK, 0, TW, S>(ga, pro, blocks, st);
 }
 

@@ -2,6 +2,7 @@
 #include "conv_tiled_kernel.h"
 
 int vunet_conv_tiled_launch_mt1(const GatherArgs& ga, int pro, int NT, int TW, hipStream_t st) {
+  if (ga.d.stride == 2) return launch_tiled<1, 1, 8, 32, 2>(ga, pro, st);
   if (TW == 16) return launch_tiled<1, 1, 8, 16>(ga, pro, st);
   if (NT == 4) return launch_tiled<1, 4, 8>(ga, pro, st);
   if (NT == 2) return launch_tiled<1, 2, 8>(ga, pro, st);

@@ -148,7 +148,8 @@ int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const f
 extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len) {
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
   if (vunet_wgrad_tiled_applicable(d)) {
-    snprintf(name, len, "conv_wgrad_tiled_kernel<%d, 4, %d>", d->Cout >= 64 ? 2 : 1, d->KH);
+    if (d->stride == 2) snprintf(name, len, "conv_wgrad_tiled_kernel<2, 2, 3, 2>");
+    else snprintf(name, len, "conv_wgrad_tiled_kernel<%d, 4, %d, 1>", d->Cout >= 64 ? 2 : 1, d->KH);
     return VUNET_OK;
   }
   int T, Ctot, Coutp, nchunks, WM;

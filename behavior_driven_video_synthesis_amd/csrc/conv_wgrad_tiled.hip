@@ -24,12 +24,14 @@ struct WgradTiledArgs {
   InAct in1, in2;
 };
 
-template <int MTW, int TH, int KS>
+// S = 2 (the stride-2 Downsample convs): tiles walk the output map, the staged input tile is (2*TH+1) x 65.
+template <int MTW, int TH, int KS, int S = 1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTiledArgs a) {
   constexpr int WP = 4 / MTW;        // pixel parts (waves sharing one m-tile)
   constexpr int RW = TH / WP;        // tile rows per wave
   constexpr int HALO = KS / 2, NTAP = KS * KS;
-  constexpr int IH = TH + 2 * HALO, IW = 32 + 2 * HALO;
+  constexpr int IH = (TH - 1) * S + 1 + 2 * HALO, IW = 31 * S + 1 + 2 * HALO;
+  static_assert(RW >= 1, "tile too small for the wave split");
   constexpr int CS = IH * IW + 1;    // fx channel pitch (odd)
   constexpr int PS = TH * 32 + 1;    // dy row pitch (odd)
   constexpr int MB = 32 * MTW;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
   const int split = blockIdx.x;
   const int ci0 = blockIdx.y * 32;
   const int co0 = blockIdx.z * MB;
-  const int H = d.Hs, W = d.Ws;
+  const int H = d.Hs, W = d.Ws, Ho = d.Ho, Wo = d.Wo;
 
   // source of this input-channel block (C1 % 32 == 0 is a precondition of this kernel)
   const bool second = ci0 >= d.C1;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
           const int c = e / (IH * IW);
           const int rem = e - c * (IH * IW);
           const int r = rem / IW, col = rem - r * IW;
-          const int ih = row0 - HALO + r, iw = col0 - HALO + col;
+          const int ih = row0 * S - HALO + r, iw = col0 * S - HALO + col;
           const bool ok = e < E && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && cbase + c < Cs;
           go[u] = ok ? ((n * Cs + cbase + c) * H + ih) * W + iw : -1;
           v[u] = xs[ok ? go[u] : 0];  // unconditional load; invalid elements are zeroed below
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
           const int co = e / (TH * 32), p = e % (TH * 32);
           const int cog = co0 + co;
           const bool cv = cog < d.Cout;
-          const float t = a.dy[((size_t)(n * d.Cout + (cv ? cog : 0)) * H + row0 + (p >> 5)) * W + col0 + (p & 31)];
+          const float t = a.dy[((size_t)(n * d.Cout + (cv ? cog : 0)) * Ho + row0 + (p >> 5)) * Wo + col0 + (p & 31)];
           v[u] = cv ? t : 0.f;
         }
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
 
     // ---- MFMA: this wave's RW rows x 32 columns = RW*16 k-steps, 9 taps each
     const float* aP = dyL + (wm * 32 + j) * PS + pw * RW * 32 + h;
-    const float* bP = fxL + j * CS + pw * RW * IW + h;
+    const float* bP = fxL + j * CS + pw * RW * S * IW + h * S;
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
 #pragma unroll 4
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
         dsum += av;
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
-          const float bv = bP[(rr + t / KS) * IW + 2 * s + t % KS];
+          const float bv = bP[(rr * S + t / KS) * IW + 2 * s * S + t % KS];
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
         }
       }
@@ -194,21 +196,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTil
 // ---- host side ----------------------------------------------------------------------------
 bool vunet_wgrad_tiled_applicable(const vunet_wgrad_desc* d) {
   const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
-  return (k3 || k1) && d->stride == 1 && d->Ws % 32 == 0 && d->Hs % 4 == 0 && d->Ho == d->Hs && d->Wo == d->Ws &&
-         ((d->C1 % 32 == 0 && d->C2 % 32 == 0) || (d->C2 == 0 && d->C1 < 32)) &&
-         (d->Cout % 32 == 0 || d->Cout < 32);
+  const bool chans = ((d->C1 % 32 == 0 && d->C2 % 32 == 0) || (d->C2 == 0 && d->C1 < 32)) &&
+                     (d->Cout % 32 == 0 || d->Cout < 32);
+  if (d->stride == 2)  // Downsample convs: 2 x 32 output tiles, two m-tiles per workgroup
+    return k3 && chans && d->Cout >= 64 && d->Hs == 2 * d->Ho && d->Ws == 2 * d->Wo && d->Wo % 32 == 0 && d->Ho % 2 == 0;
+  return (k3 || k1) && chans && d->stride == 1 && d->Ws % 32 == 0 && d->Hs % 4 == 0 && d->Ho == d->Hs && d->Wo == d->Ws;
 }
 
-static void tiled_geometry(const vunet_wgrad_desc* d, int& MTW, int& ntiles, int& ciblocks, int& coblocks) {
+static void tiled_geometry(const vunet_wgrad_desc* d, int& MTW, int& TH, int& ntiles, int& ciblocks, int& coblocks) {
   MTW = d->Cout >= 64 ? 2 : 1;
-  ntiles = d->N * (d->Hs / 4) * (d->Ws / 32);
+  TH = d->stride == 2 ? 2 : 4;
+  ntiles = d->N * (d->Ho / TH) * (d->Wo / 32);
   ciblocks = (d->C1 + d->C2 + 31) / 32;
   coblocks = (d->Cout + 32 * MTW - 1) / (32 * MTW);
 }
 
 int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d) {
-  int MTW, ntiles, ciblocks, coblocks;
-  tiled_geometry(d, MTW, ntiles, ciblocks, coblocks);
+  int MTW, TH, ntiles, ciblocks, coblocks;
+  tiled_geometry(d, MTW, TH, ntiles, ciblocks, coblocks);
   int S = 1024 / (ciblocks * coblocks);  // ~4 workgroups per CU over the whole grid
   if (S > ntiles / 2) S = ntiles / 2;
   if (S < 1) S = 1;
@@ -216,11 +221,13 @@ int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d) {
   return S;
 }
 
-template <int MTW, int KS>
+template <int MTW, int TH, int KS, int ST>
 static int launch_wgrad_tiled(const WgradTiledArgs& a, dim3 grid, hipStream_t st) {
-  constexpr int TH = 4, HALO = KS / 2;
-  const size_t lds = (size_t)(32 * ((TH + 2 * HALO) * (32 + 2 * HALO) + 1) + 32 * MTW * (TH * 32 + 1)) * sizeof(float);
-  VUNET_LAUNCH((conv_wgrad_tiled_kernel<MTW, TH, KS>), grid, dim3(256), lds < 16384 + 4096 ? 16384 + 4096 : lds, st, a);
+  constexpr int HALO = KS / 2;
+  constexpr int IH = (TH - 1) * ST + 1 + 2 * HALO, IW = 31 * ST + 1 + 2 * HALO;
+  size_t lds = (size_t)(32 * (IH * IW + 1) + 32 * MTW * (TH * 32 + 1)) * sizeof(float);
+  if (lds < 16384 + 4096) lds = 16384 + 4096;  // the in-workgroup fold needs 16 KiB + 1 KiB
+  VUNET_LAUNCH((conv_wgrad_tiled_kernel<MTW, TH, KS, ST>), grid, dim3(256), lds, st, a);
   return vunet_check_launch();
 }
 
@@ -229,18 +236,19 @@ int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const f
   WgradTiledArgs a;
   a.d = *d;
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift;
-  int MTW, ciblocks, coblocks;
-  tiled_geometry(d, MTW, a.ntiles, ciblocks, coblocks);
+  int MTW, TH, ciblocks, coblocks;
+  tiled_geometry(d, MTW, TH, a.ntiles, ciblocks, coblocks);
   a.S = d->nsplit;
   a.HW = d->Hs * d->Ws;
   a.Ctot = d->C1 + d->C2;
   a.Coutp = (d->Cout + 31) / 32 * 32;
-  a.tiles_per_img_w = d->Ws / 32;
-  a.tiles_per_img = (d->Hs / 4) * a.tiles_per_img_w;
+  a.tiles_per_img_w = d->Wo / 32;
+  a.tiles_per_img = (d->Ho / TH) * a.tiles_per_img_w;
   a.tps = (a.ntiles + a.S - 1) / a.S;
   a.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
   a.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
   dim3 grid(a.S, ciblocks, coblocks);
-  if (d->KH == 3) return MTW == 1 ? launch_wgrad_tiled<1, 3>(a, grid, st) : launch_wgrad_tiled<2, 3>(a, grid, st);
-  return MTW == 1 ? launch_wgrad_tiled<1, 1>(a, grid, st) : launch_wgrad_tiled<2, 1>(a, grid, st);
+  if (d->stride == 2) return launch_wgrad_tiled<2, 2, 3, 2>(a, grid, st);
+  if (d->KH == 3) return MTW == 1 ? launch_wgrad_tiled<1, 4, 3, 1>(a, grid, st) : launch_wgrad_tiled<2, 4, 3, 1>(a, grid, st);
+  return MTW == 1 ? launch_wgrad_tiled<1, 4, 1, 1>(a, grid, st) : launch_wgrad_tiled<2, 4, 1, 1>(a, grid, st);
 }

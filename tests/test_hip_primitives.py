@@ -77,6 +77,8 @@ def test_primitive_vs_golden(case):
     (2, 32, 32, 8, 64, 1, 1, 0),      # 1x1 (nin) through the tiled wgrad kernel
     (2, 64, 128, 4, 32, 1, 1, 0),     # 1x1, two m-tiles per workgroup
     (2, 3, 32, 8, 64, 1, 1, 0),       # first nin: 3 input channels, masked channel block
+    (8, 32, 64, 64, 128, 3, 2, 1),    # stride-2 Downsample through the LDS-tiled kernel (128 workgroups)
+    (16, 16, 32, 32, 128, 3, 2, 1),   # stride-2, one m-tile
 ])
 def test_normconv_vs_oracle(shape):
     """Fused NormConv2d fwd + dgrad + wgrad on shapes the golden file does not hold (edge cases)."""
