@@ -15,38 +15,37 @@ from .utils import get_member
 VGGOutput = namedtuple("VGGOutput", ["input", "relu1_2", "relu2_2", "relu3_2", "relu4_2", "relu5_2"])
 
 
+def _sum_terms(terms):
+    total = None
+    for t in terms:
+        total = t if total is None else total + t
+    return total
+
+
 def latent_kl(prior_mean, posterior_mean):
-    """lib/losses.py:26-37: 0.5 (p-q)^2 summed over CHW, batch mean."""
+    """:26-37 -- 0.5 (p - q)^2 summed over CHW, batch mean (one fused reduction)."""
     return ops.SqDiff.apply(prior_mean, posterior_mean, 1.0)
 
 
 def compute_kl_loss(prior_means, posterior_means):
-    """lib/losses.py:55-65 (sum over latent scales)."""
-    tot = None
-    for p, q in zip(prior_means, posterior_means):
-        t = latent_kl(p, q)
-        tot = t if tot is None else tot + t
-    return tot
+    """:55-65 -- sum of ``latent_kl`` over the latent scales."""
+    return _sum_terms(latent_kl(p, q) for p, q in zip(prior_means, posterior_means))
 
 
 def aggregate_kl_loss(prior_means, posterior_means):
-    """lib/losses.py:40-52 (dict-valued variant)."""
+    """:40-52 -- the dict-valued variant."""
     return compute_kl_loss(list(prior_means.values()), list(posterior_means.values()))
 
 
 def kl_loss(mu, logstd):
-    """lib/losses.py:283-291; mu/logstd are [N, D] (any trailing shape is flattened per sample)."""
+    """:283-291 -- KL(N(mu, exp(logstd)^2) || N(0, 1)) per sample (trailing dims flattened), batch mean."""
     return ops.KLPrior.apply(mu, logstd, 1.0)
 
 
 def compute_kl_with_prior(means, logstds):
-    """lib/losses.py:68-78: mean over the latent scales of the per-scale KL."""
-    n = len(means)
-    tot = None
-    for m, l in zip(means, logstds):
-        t = ops.KLPrior.apply(m, l, 1.0 / n)
-        tot = t if tot is None else tot + t
-    return tot
+    """:68-78 -- mean over the latent scales of the per-scale KL (the 1/S weight rides in the kernel)."""
+    w = 1.0 / len(means)
+    return _sum_terms(ops.KLPrior.apply(m, l, w) for m, l in zip(means, logstds))
 
 
 def vgg_loss(custom_vgg, target, pred, weights=None):
@@ -59,14 +58,11 @@ def vgg_loss(custom_vgg, target, pred, weights=None):
     if weights is not None:
         raise NotImplementedError("pixel-weighted vgg_loss branch (lib/losses.py:103-117) is unused upstream")
     with torch.no_grad():
-        target_feats = VGGOutput(**custom_vgg(target))
-    pred_feats = VGGOutput(**custom_vgg(pred))
-    names = list(pred_feats._asdict().keys())
-    lw = get_member(custom_vgg, "loss_weights")
-    losses = {}
-    for i, (tf, pf) in enumerate(zip(target_feats, pred_feats)):
-        losses[names[i]] = ops.L1Mean.apply(tf, pf, float(lw[i]))
-    return losses
+        wanted = VGGOutput(**custom_vgg(target))
+    got = VGGOutput(**custom_vgg(pred))
+    tap_weights = get_member(custom_vgg, "loss_weights")
+    return {name: ops.L1Mean.apply(t, p, float(w))
+            for name, t, p, w in zip(VGGOutput._fields, wanted, got, tap_weights)}
 
 
 class GANLoss(nn.Module):

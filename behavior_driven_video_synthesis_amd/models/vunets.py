@@ -1,478 +1,411 @@
 """MI355X-native counterparts of the reference's ``models/vunets.py``.
 
-Class names, constructor keywords, public attributes (``eu ed du dd n_scales spatial_size
-n_channels_x``), return tuples and state-dict keys follow the reference line by line
-(``models/vunets.py:<line>`` citations), so ``experiments.shape_and_pose_net`` can construct and
-drive these modules unchanged; all arithmetic runs in the fused gfx950 kernels of ``lib/modules.py``.
-Differences that are deliberate and invisible to callers: ``torch.cat`` of skip/latent tensors is
-never materialised (the convs read two sources), the reparametrisation is one fused kernel, and the
-encoders do not mutate the caller's list.
+Public surface kept for drop-in use by ``experiments.shape_and_pose_net`` / ``experiments.vunet``:
+class names, constructor keywords, attributes (``eu ed du dd n_scales spatial_size n_channels_x``),
+return tuples and -- because optimizer checkpoints are index-mapped -- the parameter registration
+order, hence the state-dict keys *and their order* (checked against the reference's own key list in
+tests/test_cabi_and_host.py).  ``models/vunets.py:<line>`` citations point at the upstream code each
+piece reproduces.  All arithmetic runs in the fused gfx950 kernels behind ``lib/modules.py``.
+
+Deliberate, caller-invisible differences: ``torch.cat`` of skip/latent tensors is never materialised
+(the convolutions read two sources), the reparametrisation is one fused kernel, the bottleneck
+encoders work on a copy of the caller's feature list instead of popping from it, and every sampling
+site accepts an injected noise tensor (used by the parity tests).
 """
 from __future__ import annotations
 
 from functools import partial
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
 from torch import nn
-from torch.nn import ModuleList
 
 from .. import ops
-from ..lib.modules import (DepthToSpace, Downsample, L2NormConv2d, LayerNormConv2d, NormConv2d, SpaceToDepth,
-                           Upsample, VunetRNB, Conv2d)
+from ..lib.modules import (Conv2d, DepthToSpace, Downsample, L2NormConv2d, LayerNormConv2d, NormConv2d, SpaceToDepth,
+                           Upsample, VunetRNB)
+
+RNB_PER_SCALE = 2
 
 
-def _n_scales(kwargs) -> int:
-    # models/vunets.py:22-30 / 430-438
-    if kwargs["n_scales"] < 6:
-        return 1 + int(np.round(np.log2(kwargs["spatial_size"]))) - kwargs["bottleneck_factor"]
-    return kwargs["n_scales"]
+def _count_scales(cfg) -> int:
+    """:22-30 / :430-438 -- explicit ``n_scales`` >= 6 wins, else 1 + log2(size) - bottleneck_factor."""
+    if cfg["n_scales"] >= 6:
+        return cfg["n_scales"]
+    return 1 + int(np.round(np.log2(cfg["spatial_size"]))) - cfg["bottleneck_factor"]
 
 
-def _conv_layer(kwargs, init_fn, allow_ln: bool):
-    # models/vunets.py:37-44 / 445-453
-    t = kwargs["conv_layer_type"]
-    if t == "l1":
+def _pick_conv_layer(cfg, init_fn, layer_norm_ok: bool):
+    """:37-44 / :445-453 -> (layer factory, name used in the start-up print)."""
+    kind = cfg["conv_layer_type"]
+    if kind == "l1":
         return NormConv2d, "L1NormConv2d"
-    if t == "l2":
+    if kind == "l2":
         return partial(L2NormConv2d, init=init_fn, bias=False), "L2NormConv2d"
-    if allow_ln:
-        return LayerNormConv2d, "LayerNormConv2d"
-    raise NotImplementedError("No conv layers others than l1 and l2 normalized ones are available.")
+    if not layer_norm_ok:
+        raise NotImplementedError("No conv layers others than l1 and l2 normalized ones are available.")
+    return LayerNormConv2d, "LayerNormConv2d"
 
 
-class EncUp(nn.Module):
-    """models/vunets.py:109-148 (and DecUp :222-261, identical structure)."""
+def _skip_block(width, a_width, conv_layer=NormConv2d, p=0.0):
+    return VunetRNB(channels=width, a_channels=a_width, residual=True, conv_layer=conv_layer, dropout_prob=p)
 
+
+def _noise_like(t, given):
+    return torch.randn_like(t) if given is None else given
+
+
+# ------------------------------------------------------------------------------------------------
+# feature pyramids  (EncUp :109-148, DecUp :222-261 -- the same stack on two different inputs)
+# ------------------------------------------------------------------------------------------------
+class _Pyramid(nn.Module):
     def __init__(self, n_scales, n_filters, max_filters, nf_in=3, conv_layer=NormConv2d, dropout_prob=0.0):
         super().__init__()
-        self.n_rnb = 2
-        self.n_scales = n_scales
+        self.n_rnb, self.n_scales = RNB_PER_SCALE, n_scales
         self.nin = conv_layer(in_channels=nf_in, out_channels=n_filters, kernel_size=1)
-        self.blocks = nn.ModuleList()
-        self.downs = nn.ModuleList()
-        nf = n_filters
-        for i in range(self.n_scales):
-            for _ in range(self.n_rnb):
-                self.blocks.append(VunetRNB(channels=nf, conv_layer=conv_layer, dropout_prob=dropout_prob))
-            if i + 1 < self.n_scales:
-                out_c = min(2 * nf, max_filters)
-                self.downs.append(Downsample(nf, out_c))
-                nf = out_c
+        self.blocks, self.downs = nn.ModuleList(), nn.ModuleList()
+        width = n_filters
+        for level in range(n_scales):
+            self.blocks.extend(VunetRNB(channels=width, conv_layer=conv_layer, dropout_prob=dropout_prob)
+                               for _ in range(RNB_PER_SCALE))
+            if level < n_scales - 1:
+                wider = min(2 * width, max_filters)
+                self.downs.append(Downsample(width, wider))
+                width = wider
 
+    def _run(self, image):
+        feats, h = [], self.nin(image)
+        blocks = iter(self.blocks)
+        for level in range(self.n_scales):
+            for _ in range(RNB_PER_SCALE):
+                h = next(blocks)(h)
+                feats.append(h)
+            if level < self.n_scales - 1:
+                h = self.downs[level](h)
+        return feats
+
+
+class EncUp(_Pyramid):
     def forward(self, x, **kwargs):
-        hs = []
-        h = self.nin(x)
-        for i in range(self.n_scales):
-            for n in range(self.n_rnb):
-                h = self.blocks[2 * i + n](h)
-                hs.append(h)
-            if i + 1 < self.n_scales:
-                h = self.downs[i](h)
-        return hs
+        return self._run(x)
 
 
-class DecUp(EncUp):
-    """models/vunets.py:222-261."""
-
+class DecUp(_Pyramid):
     def forward(self, c):
-        return super().forward(c)
+        return self._run(c)
 
 
 def latent_sample(p, eps: Optional[torch.Tensor] = None):
-    """models/vunets.py:151-156: mean + 1.0 * randn_like(mean)."""
-    if eps is None:
-        eps = torch.randn_like(p)
-    return ops.Reparam.apply(p, torch.zeros_like(p), eps)
+    """:151-156 -- unit-variance sample around ``p``."""
+    return ops.Reparam.apply(p, torch.zeros_like(p), _noise_like(p, eps))
 
 
-class EncDown(nn.Module):
-    """models/vunets.py:159-219 (VunetOrg bottleneck, unit-variance posterior)."""
+# ------------------------------------------------------------------------------------------------
+# bottleneck encoders  (EncDown :159-219 for VunetOrg, EncDownAlter :520-597 for VunetAlter)
+# ------------------------------------------------------------------------------------------------
+class _Bottleneck(nn.Module):
+    """Per latent scale: skip block -> posterior parameters -> sample -> skip block on (feature, sample) -> 2x up."""
 
-    def __init__(self, n_filters, nf_in, subpixel_upsampling, n_scales=2, conv_layer=NormConv2d, dropout_prob=0.0):
-        super().__init__()
-        self.nin = conv_layer(nf_in, n_filters, kernel_size=1)
-        self.n_scales = n_scales
-        self.n_rnb = 2
-        self.blocks = nn.ModuleList()
-        self.ups = nn.ModuleList()
-        self.make_latent_params = nn.ModuleList()
-        nf = n_filters
-        for i in range(self.n_scales):
-            self.blocks.append(VunetRNB(channels=nf, a_channels=nf, residual=True, dropout_prob=dropout_prob))
-            self.make_latent_params.append(conv_layer(nf, nf, kernel_size=3, padding=1))
-            self.blocks.append(VunetRNB(channels=nf, a_channels=2 * nf, residual=True, dropout_prob=dropout_prob))
-            self.ups.append(Upsample(nf, nf, subpixel=True))
-        self.fin_block = VunetRNB(channels=nf, a_channels=nf, residual=True, dropout_prob=dropout_prob)
-
-    def forward(self, gs, eps: Optional[Sequence[torch.Tensor]] = None):
-        gs = list(gs)
-        hs, qs, zs = [], [], []
-        h = self.nin(gs[-1])
-        for i in range(self.n_scales):
-            h = self.blocks[2 * i](h, gs.pop())
-            hs.append(h)
-            q = self.make_latent_params[i](h)
-            qs.append(q)
-            z = latent_sample(q, None if eps is None else eps[i])
-            zs.append(z)
-            h = self.blocks[2 * i + 1](h, (gs.pop(), z))
-            hs.append(h)
-            h = self.ups[i](h)
-        h = self.fin_block(h, gs.pop())
-        hs.append(h)
-        return hs, qs, zs
-
-
-class EncDownAlter(nn.Module):
-    """models/vunets.py:520-597: posterior ``mu, sigmoid(logstd)`` and reparametrised sample per latent scale."""
+    learn_std = False
+    second_block_dropout = True   # :548 builds the second block of EncDownAlter without dropout_prob
 
     def __init__(self, n_filters, nf_in, subpixel_upsampling, n_scales=2, conv_layer=NormConv2d, dropout_prob=0.0):
         super().__init__()
         self.nin = conv_layer(nf_in, n_filters, kernel_size=1)
-        self.n_scales = n_scales
-        self.n_rnb = 2
-        self.blocks = nn.ModuleList()
-        self.ups = nn.ModuleList()
-        self.make_latent_params = nn.ModuleList()
-        self.make_logstds = nn.ModuleList()
-        nf = n_filters
-        for i in range(self.n_scales):
-            self.blocks.append(VunetRNB(channels=nf, a_channels=nf, residual=True, dropout_prob=dropout_prob))
-            self.make_latent_params.append(conv_layer(nf, nf, kernel_size=3, padding=1))
-            self.make_logstds.append(conv_layer(nf, nf, kernel_size=3, padding=1))
-            # models/vunets.py:548: this block is built without dropout_prob
-            self.blocks.append(VunetRNB(channels=nf, a_channels=2 * nf, residual=True))
-            self.ups.append(Upsample(nf, nf, subpixel=True))
-        self.fin_block = VunetRNB(channels=nf, a_channels=nf, residual=True, dropout_prob=dropout_prob)
-        self.squash = nn.Sigmoid()
+        self.n_scales, self.n_rnb = n_scales, RNB_PER_SCALE
+        self.blocks, self.ups, self.make_latent_params = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        if self.learn_std:
+            self.make_logstds = nn.ModuleList()
+        w = n_filters
+        for _ in range(n_scales):
+            self.blocks.append(_skip_block(w, w, p=dropout_prob))
+            self.make_latent_params.append(conv_layer(w, w, kernel_size=3, padding=1))
+            if self.learn_std:
+                self.make_logstds.append(conv_layer(w, w, kernel_size=3, padding=1))
+            self.blocks.append(_skip_block(w, 2 * w, p=dropout_prob if self.second_block_dropout else 0.0))
+            self.ups.append(Upsample(w, w, subpixel=True))
+        self.fin_block = _skip_block(w, w, p=dropout_prob)
+        if self.learn_std:
+            self.squash = nn.Sigmoid()
+
+    def _encode(self, feats, eps):
+        skips = list(feats)                      # consumed from the coarsest end
+        hidden, locs, scales, samples = [], [], [], []
+        h = self.nin(skips[-1])
+        for s in range(self.n_scales):
+            h = self.blocks[2 * s](h, skips.pop())
+            hidden.append(h)
+            loc = self.make_latent_params[s](h)
+            locs.append(loc)
+            noise = None if eps is None else eps[s]
+            if self.learn_std:
+                log_sd = self.make_logstds[s].fused(h, out_act=ops.ACT_SIGMOID)   # conv + squash, :574-575
+                scales.append(log_sd)
+                z = self.reparametrize(loc, log_sd, noise)
+            else:
+                z = latent_sample(loc, noise)
+            samples.append(z)
+            h = self.blocks[2 * s + 1](h, (skips.pop(), z))   # cat([g, z]) read as two sources, :210 / :583
+            hidden.append(h)
+            h = self.ups[s](h)
+        hidden.append(self.fin_block(h, skips.pop()))
+        return hidden, locs, scales, samples
+
+
+class EncDown(_Bottleneck):
+    def forward(self, gs, eps: Optional[Sequence[torch.Tensor]] = None):
+        hidden, qs, _, zs = self._encode(gs, eps)
+        return hidden, qs, zs
+
+
+class EncDownAlter(_Bottleneck):
+    learn_std = True
+    second_block_dropout = False
 
     def forward(self, gs, eps: Optional[Sequence[torch.Tensor]] = None):
-        gs = list(gs)
-        hs, means, zs, log_stds = [], [], [], []
-        h = self.nin(gs[-1])
-        for i in range(self.n_scales):
-            h = self.blocks[2 * i](h, gs.pop())
-            hs.append(h)
-            mu = self.make_latent_params[i](h)
-            means.append(mu)
-            logstd = self.make_logstds[i].fused(h, out_act=ops.ACT_SIGMOID)  # conv + squash (:574-575)
-            log_stds.append(logstd)
-            z = self.reparametrize(mu, logstd, None if eps is None else eps[i])
-            zs.append(z)
-            h = self.blocks[2 * i + 1](h, (gs.pop(), z))  # cat([g, z]) read as two sources (:583)
-            hs.append(h)
-            h = self.ups[i](h)
-        h = self.fin_block(h, gs.pop())
-        hs.append(h)
-        return hs, means, log_stds, zs
+        hidden, means, log_stds, zs = self._encode(gs, eps)
+        return hidden, means, log_stds, zs
 
     def reparametrize(self, mu, logstd, eps: Optional[torch.Tensor] = None):
-        if eps is None:
-            eps = torch.randn_like(logstd)
-        return ops.Reparam.apply(mu, logstd, eps)
+        """:594-597 -- eps * exp(logstd) + mu."""
+        return ops.Reparam.apply(mu, logstd, _noise_like(logstd, eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# decoders  (DecDownAlter :264-424, DecDown :600-783)
+# ------------------------------------------------------------------------------------------------
+def _decoder_width(nf_in, nf_last, n_scales, level):
+    return min(nf_in, nf_last * 2 ** (n_scales - (level + 2)))
 
 
 class DecDownAlter(nn.Module):
-    """models/vunets.py:264-424."""
-
     def __init__(self, n_scales, nf_in, nf_last, nf_out, subpixel_upsampling, conv_layer=NormConv2d,
                  n_latent_scales=2, dropout_prob=0.0):
         super().__init__()
-        self.n_rnb = 2
-        self.n_scales = n_scales
-        self.n_latent_scales = n_latent_scales
+        self.n_rnb, self.n_scales, self.n_latent_scales = RNB_PER_SCALE, n_scales, n_latent_scales
         self.nin = conv_layer(nf_in, nf_in, kernel_size=1)
-        self.blocks = nn.ModuleList()
-        self.ups = nn.ModuleList()
-        self.auto_blocks = nn.ModuleList()
+        self.blocks, self.ups, self.auto_blocks = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         self.out_conv = conv_layer(nf_last, nf_out, kernel_size=3, padding=1)
-        self.depth_to_space = DepthToSpace(block_size=2)
-        self.space_to_depth = SpaceToDepth(block_size=2)
-        nf = nf_in
-        for i in range(self.n_scales):
-            self.blocks.append(VunetRNB(channels=nf, a_channels=nf, residual=True, conv_layer=conv_layer,
-                                        dropout_prob=dropout_prob))
-            if i < self.n_latent_scales:
-                self.auto_blocks.append(VunetRNB(channels=nf, a_channels=nf, residual=True, conv_layer=conv_layer,
-                                                 dropout_prob=dropout_prob))
-            self.blocks.append(VunetRNB(channels=nf, a_channels=nf, residual=True, conv_layer=conv_layer,
-                                        dropout_prob=dropout_prob))
-            if i + 1 < self.n_scales:
-                out_c = min(nf_in, nf_last * 2 ** (n_scales - (i + 2)))
-                subpixel = True if subpixel_upsampling else (i < self.n_latent_scales)
-                self.ups.append(Upsample(nf, out_c, subpixel=subpixel))
-                nf = out_c
+        self.depth_to_space, self.space_to_depth = DepthToSpace(block_size=2), SpaceToDepth(block_size=2)
+        w = nf_in
+        for level in range(n_scales):
+            self.blocks.append(_skip_block(w, w, conv_layer, dropout_prob))
+            if level < n_latent_scales:
+                self.auto_blocks.append(_skip_block(w, w, conv_layer, dropout_prob))
+            self.blocks.append(_skip_block(w, w, conv_layer, dropout_prob))
+            if level < n_scales - 1:
+                nxt = _decoder_width(nf_in, nf_last, n_scales, level)
+                self.ups.append(Upsample(w, nxt, subpixel=bool(subpixel_upsampling) or level < n_latent_scales))
+                w = nxt
 
     def forward(self, gs, zs_posterior, training, prior_eps: Optional[Sequence[torch.Tensor]] = None):
-        gs = list(gs)
-        zs_posterior = list(zs_posterior)
-        h = self.nin(gs[-1])
-        lat_count = 0
-        for i in range(self.n_scales):
-            h = self.blocks[2 * i](h, gs.pop())
-            if i < self.n_latent_scales:
+        skips, latents = list(gs), list(zs_posterior)
+        h = self.nin(skips[-1])
+        for level in range(self.n_scales):
+            h = self.blocks[2 * level](h, skips.pop())
+            if level < self.n_latent_scales:
                 if training:
-                    from_dist = zs_posterior.pop(0)
-                elif prior_eps is not None:
-                    from_dist = prior_eps[lat_count]
-                else:
-                    from_dist = torch.randn_like(h)
-                h = self.auto_blocks[lat_count](h, from_dist)
-                lat_count += 1
-            h = self.blocks[2 * i + 1](h, gs.pop())
-            if i + 1 < self.n_scales:
-                h = self.ups[i](h)
-        assert not gs
-        if training:
-            assert not zs_posterior
+                    code = latents.pop(0)
+                else:   # sample the appearance from the prior, :349-352
+                    code = _noise_like(h, None if prior_eps is None else prior_eps[level])
+                h = self.auto_blocks[level](h, code)
+            h = self.blocks[2 * level + 1](h, skips.pop())
+            if level < self.n_scales - 1:
+                h = self.ups[level](h)
+        assert not skips and not (training and latents)
         return self.out_conv(h)
 
 
-class VunetAlter(nn.Module):
-    """models/vunets.py:426-515."""
-
-    def __init__(self, init_fn=None, n_channels_x=3, **kwargs):
-        super().__init__()
-        self.spatial_size = kwargs["spatial_size"]
-        self.n_scales = _n_scales(kwargs)
-        self.n_scales_x = self.n_scales - kwargs["box_factor"] if n_channels_x > 3 else self.n_scales
-        self.n_channels_x = n_channels_x
-        n_latent_scales = kwargs["n_latent_scales"]
-        dropout_prob = kwargs["dropout_prob"] if "dropout_prob" in kwargs else 0.0
-        conv_layer, conv_t = _conv_layer(kwargs, init_fn, allow_ln=True)
-        print("Vunet using " + conv_t + " as conv layers.")
-        self.eu = EncUp(self.n_scales_x, n_filters=kwargs["nf_start"], max_filters=kwargs["nf_max"],
-                        conv_layer=conv_layer, nf_in=n_channels_x, dropout_prob=dropout_prob)
-        self.ed = EncDownAlter(n_filters=kwargs["nf_max"], nf_in=kwargs["nf_max"], conv_layer=conv_layer,
-                               n_scales=n_latent_scales, subpixel_upsampling=kwargs["subpixel_upsampling"],
-                               dropout_prob=dropout_prob)
-        self.du = DecUp(self.n_scales, n_filters=kwargs["nf_start"], max_filters=kwargs["nf_max"],
-                        conv_layer=conv_layer, dropout_prob=dropout_prob)
-        self.dd = DecDownAlter(self.n_scales, kwargs["nf_max"], kwargs["nf_start"], nf_out=3, conv_layer=conv_layer,
-                               n_latent_scales=n_latent_scales, subpixel_upsampling=kwargs["subpixel_upsampling"],
-                               dropout_prob=dropout_prob)
-
-    def forward(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None):
-        hs = self.eu(x)
-        es, means, logstds, zs_posterior = self.ed(hs, eps)
-        gs = self.du(c)
-        imgs = self.dd(gs, zs_posterior, training=True)
-        activations = hs, means, logstds
-        return imgs, means, logstds, activations
-
-    def test_forward(self, c, prior_eps: Optional[Sequence[torch.Tensor]] = None):
-        gs = self.du(c)
-        return self.dd(gs, [], training=False, prior_eps=prior_eps)
-
-    def transfer(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None):
-        hs = self.eu(x)
-        es, means, logstds, zs_posterior = self.ed(hs, eps)
-        gs = self.du(c)
-        return self.dd(gs, list(means), training=True)
-
-
 class DecDown(nn.Module):
-    """models/vunets.py:600-783: decoder with the 4-group autoregressive prior of the original VUnet."""
+    """Decoder of the original VUnet with the 4-group autoregressive prior over SpaceToDepth sub-grids."""
 
     def __init__(self, n_scales, nf_in, nf_last, nf_out, subpixel_upsampling, conv_layer=NormConv2d,
                  n_latent_scales=2, dropout_prob=0.0):
         super().__init__()
-        self.n_rnb = 2
-        self.n_scales = n_scales
-        self.n_latent_scales = n_latent_scales
+        self.n_rnb, self.n_scales, self.n_latent_scales = RNB_PER_SCALE, n_scales, n_latent_scales
         self.nin = conv_layer(nf_in, nf_in, kernel_size=1)
-        self.blocks = nn.ModuleList()
-        self.ups = nn.ModuleList()
-        self.latent_nins = nn.ModuleDict()
-        self.auto_lp = nn.ModuleDict()
-        self.auto_blocks = nn.ModuleDict()
+        self.blocks, self.ups = nn.ModuleList(), nn.ModuleList()
+        self.latent_nins, self.auto_lp, self.auto_blocks = nn.ModuleDict(), nn.ModuleDict(), nn.ModuleDict()
         self.out_conv = conv_layer(nf_last, nf_out, kernel_size=3, padding=1)
-        self.depth_to_space = DepthToSpace(block_size=2)
-        self.space_to_depth = SpaceToDepth(block_size=2)
-        nfl = nf_in
-        nf = nf_in
-        for i in range(self.n_scales):
-            self.blocks.append(VunetRNB(channels=nf, a_channels=nf, residual=True, conv_layer=conv_layer,
-                                        dropout_prob=dropout_prob))
-            if i < self.n_latent_scales:
-                scale = f"l_{i}"
-                self.latent_nins.update({scale: conv_layer(nfl * 2, nfl, kernel_size=1)})
-                clp, cb = ModuleList(), ModuleList()
-                for l in range(4):
-                    clp.append(conv_layer(4 * nfl, nfl, kernel_size=3, padding=1))
-                    if l == 0:
-                        cb.append(VunetRNB(channels=nfl, dropout_prob=dropout_prob))
-                    else:
-                        cb.append(VunetRNB(channels=4 * nfl, a_channels=nfl, residual=True,
-                                           dropout_prob=dropout_prob))
-                self.auto_lp.update({scale: clp})
-                self.auto_blocks.update({scale: cb})
-            self.blocks.append(VunetRNB(channels=nf, a_channels=nf, residual=True, conv_layer=conv_layer,
-                                        dropout_prob=dropout_prob))
-            if i + 1 < self.n_scales:
-                out_c = min(nf_in, nf_last * 2 ** (n_scales - (i + 2)))
-                subpixel = True if subpixel_upsampling else (i < self.n_latent_scales)
-                self.ups.append(Upsample(nf, out_c, subpixel=subpixel))
-                nf = out_c
+        self.depth_to_space, self.space_to_depth = DepthToSpace(block_size=2), SpaceToDepth(block_size=2)
+        lat, w = nf_in, nf_in
+        for level in range(n_scales):
+            self.blocks.append(_skip_block(w, w, conv_layer, dropout_prob))
+            if level < n_latent_scales:
+                key = f"l_{level}"
+                self.latent_nins[key] = conv_layer(2 * lat, lat, kernel_size=1)
+                self.auto_lp[key] = nn.ModuleList(conv_layer(4 * lat, lat, kernel_size=3, padding=1) for _ in range(4))
+                self.auto_blocks[key] = nn.ModuleList(
+                    [VunetRNB(channels=lat, dropout_prob=dropout_prob)] +
+                    [VunetRNB(channels=4 * lat, a_channels=lat, residual=True, dropout_prob=dropout_prob)
+                     for _ in range(3)])
+            self.blocks.append(_skip_block(w, w, conv_layer, dropout_prob))
+            if level < n_scales - 1:
+                nxt = _decoder_width(nf_in, nf_last, n_scales, level)
+                self.ups.append(Upsample(w, nxt, subpixel=bool(subpixel_upsampling) or level < n_latent_scales))
+                w = nxt
 
-    def _split_groups(self, x):
+    def _groups(self, x):
+        """split the 2x2 sub-grids of x into 4 channel groups (:776-779)"""
         return list(torch.split(self.space_to_depth(x), x.shape[1], dim=1))
 
-    def _merge_groups(self, xs):
-        return self.depth_to_space(torch.cat(xs, dim=1))
+    def _ungroup(self, parts):
+        return self.depth_to_space(torch.cat(parts, dim=1))
 
     def forward(self, gs, zs_posterior, training, prior_eps=None):
-        gs = list(gs)
-        zs_posterior = list(zs_posterior)
+        skips, latents = list(gs), list(zs_posterior)
         hs, ps, zs = [], [], []
-        h = self.nin(gs[-1])
-        for i in range(self.n_scales):
-            h = self.blocks[2 * i](h, gs.pop())
+        h = self.nin(skips[-1])
+        for level in range(self.n_scales):
+            h = self.blocks[2 * level](h, skips.pop())
             hs.append(h)
-            if i < self.n_latent_scales:
-                scale = f"l_{i}"
-                if training:
-                    zs_posterior_groups = self._split_groups(zs_posterior[0])
-                p_groups, z_groups = [], []
-                pre = self.auto_blocks[scale][0](h)
-                p_features = self.space_to_depth(pre)
-                for l in range(4):
-                    p_group = self.auto_lp[scale][l](p_features)
-                    p_groups.append(p_group)
-                    z_group = latent_sample(p_group, None if prior_eps is None else prior_eps[i][l])
-                    z_groups.append(z_group)
-                    feedback = zs_posterior_groups.pop(0) if training else z_group
-                    if l + 1 < 4:
-                        p_features = self.auto_blocks[scale][l + 1](p_features, feedback)
-                if training:
-                    assert not zs_posterior_groups
-                ps.append(self._merge_groups(p_groups))
-                z_prior = self._merge_groups(z_groups)
+            if level < self.n_latent_scales:
+                key = f"l_{level}"
+                teacher = self._groups(latents[0]) if training else None
+                feat = self.space_to_depth(self.auto_blocks[key][0](h))
+                p_parts, z_parts = [], []
+                for g in range(4):
+                    p_g = self.auto_lp[key][g](feat)
+                    z_g = latent_sample(p_g, None if prior_eps is None else prior_eps[level][g])
+                    p_parts.append(p_g)
+                    z_parts.append(z_g)
+                    fed_back = teacher.pop(0) if training else z_g
+                    if g < 3:
+                        feat = self.auto_blocks[key][g + 1](feat, fed_back)
+                assert not teacher
+                ps.append(self._ungroup(p_parts))
+                z_prior = self._ungroup(z_parts)
                 zs.append(z_prior)
-                z = zs_posterior.pop(0) if training else z_prior
-                h = self.latent_nins[scale].fused((h, z))  # cat([h, z]) read as two sources (:756-757)
-                h = self.blocks[2 * i + 1](h, gs.pop())
-                hs.append(h)
-            else:
-                h = self.blocks[2 * i + 1](h, gs.pop())
-                hs.append(h)
-            if i + 1 < self.n_scales:
-                h = self.ups[i](h)
-        assert not gs
-        if training:
-            assert not zs_posterior
-        params = self.out_conv(hs[-1])
-        return params, hs, ps, zs
+                z = latents.pop(0) if training else z_prior
+                h = self.latent_nins[key].fused((h, z))        # cat([h, z]) read as two sources, :756-757
+            h = self.blocks[2 * level + 1](h, skips.pop())
+            hs.append(h)
+            if level < self.n_scales - 1:
+                h = self.ups[level](h)
+        assert not skips and not (training and latents)
+        return self.out_conv(hs[-1]), hs, ps, zs
 
 
-class VunetOrg(nn.Module):
-    """models/vunets.py:18-106."""
+# ------------------------------------------------------------------------------------------------
+# the two generators
+# ------------------------------------------------------------------------------------------------
+class _VunetBase(nn.Module):
+    layer_norm_ok = False
+    bottleneck_cls = EncDown
+    decoder_cls = DecDown
 
     def __init__(self, init_fn=None, n_channels_x=3, **kwargs):
         super().__init__()
         self.spatial_size = kwargs["spatial_size"]
-        self.n_scales = _n_scales(kwargs)
+        self.n_scales = _count_scales(kwargs)
+        # a multi-part appearance input (n_channels_x > 3) arrives at reduced resolution: box_factor fewer scales
         self.n_scales_x = self.n_scales - kwargs["box_factor"] if n_channels_x > 3 else self.n_scales
-        dropout_prob = kwargs["dropout_prob"] if "dropout_prob" in kwargs else 0.0
         self.n_channels_x = n_channels_x
-        n_latent_scales = kwargs["n_latent_scales"]
-        conv_layer, conv_t = _conv_layer(kwargs, init_fn, allow_ln=False)
-        print("Vunet using " + conv_t + " as conv layers.")
-        self.eu = EncUp(self.n_scales_x, n_filters=kwargs["nf_start"], max_filters=kwargs["nf_max"],
-                        conv_layer=conv_layer, nf_in=self.n_channels_x, dropout_prob=dropout_prob)
-        self.ed = EncDown(n_filters=kwargs["nf_max"], nf_in=kwargs["nf_max"], conv_layer=conv_layer,
-                          n_scales=n_latent_scales, subpixel_upsampling=kwargs["subpixel_upsampling"],
-                          dropout_prob=dropout_prob)
-        self.du = DecUp(self.n_scales, n_filters=kwargs["nf_start"], max_filters=kwargs["nf_max"],
-                        conv_layer=conv_layer, dropout_prob=dropout_prob)
-        self.dd = DecDown(self.n_scales, kwargs["nf_max"], kwargs["nf_start"], nf_out=3, conv_layer=conv_layer,
-                          n_latent_scales=n_latent_scales, subpixel_upsampling=kwargs["subpixel_upsampling"],
-                          dropout_prob=dropout_prob)
+        p_drop = kwargs.get("dropout_prob", 0.0)
+        n_lat, nf0, nf1 = kwargs["n_latent_scales"], kwargs["nf_start"], kwargs["nf_max"]
+        conv_layer, label = _pick_conv_layer(kwargs, init_fn, self.layer_norm_ok)
+        print("Vunet using " + label + " as conv layers.")
+        self.eu = EncUp(self.n_scales_x, n_filters=nf0, max_filters=nf1, conv_layer=conv_layer, nf_in=n_channels_x,
+                        dropout_prob=p_drop)
+        self.ed = self.bottleneck_cls(n_filters=nf1, nf_in=nf1, conv_layer=conv_layer, n_scales=n_lat,
+                                      subpixel_upsampling=kwargs["subpixel_upsampling"], dropout_prob=p_drop)
+        self.du = DecUp(self.n_scales, n_filters=nf0, max_filters=nf1, conv_layer=conv_layer, dropout_prob=p_drop)
+        self.dd = self.decoder_cls(self.n_scales, nf1, nf0, nf_out=3, conv_layer=conv_layer, n_latent_scales=n_lat,
+                                   subpixel_upsampling=kwargs["subpixel_upsampling"], dropout_prob=p_drop)
+
+
+class VunetAlter(_VunetBase):
+    """:426-515 -- the generator ``ShapePoseNet`` trains (learned-variance posterior, no autoregressive prior)."""
+
+    layer_norm_ok = True
+    bottleneck_cls = EncDownAlter
+    decoder_cls = DecDownAlter
+
+    def forward(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None):
+        hs = self.eu(x)
+        _, means, logstds, zs = self.ed(hs, eps)
+        imgs = self.dd(self.du(c), zs, training=True)
+        return imgs, means, logstds, (hs, means, logstds)
+
+    def test_forward(self, c, prior_eps: Optional[Sequence[torch.Tensor]] = None):
+        return self.dd(self.du(c), [], training=False, prior_eps=prior_eps)
+
+    def transfer(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None):
+        _, means, _, _ = self.ed(self.eu(x), eps)
+        return self.dd(self.du(c), list(means), training=True)   # posterior means as the code, :508-515
+
+
+class VunetOrg(_VunetBase):
+    """:18-106 -- the original VUnet (``experiments/vunet.py``)."""
 
     def forward(self, x, c, eps=None, prior_eps=None):
         hs = self.eu(x)
-        es, qs, zs_posterior = self.ed(hs, eps)
+        _, qs, zs = self.ed(hs, eps)
         gs = self.du(c)
-        imgs, ds, ps, zs_prior = self.dd(gs, zs_posterior, training=True, prior_eps=prior_eps)
-        activations = hs, qs, gs, ds
-        return imgs, qs, ps, activations
+        imgs, ds, ps, _ = self.dd(gs, zs, training=True, prior_eps=prior_eps)
+        return imgs, qs, ps, (hs, qs, gs, ds)
 
     def test_forward(self, c, prior_eps=None):
-        gs = self.du(c)
-        imgs, ds, ps, zs_prior = self.dd(gs, [], training=False, prior_eps=prior_eps)
-        return imgs
+        return self.dd(self.du(c), [], training=False, prior_eps=prior_eps)[0]
 
     def transfer(self, x, c, eps=None, prior_eps=None):
-        hs = self.eu(x)
-        es, qs, zs_posterior = self.ed(hs, eps)
-        gs = self.du(c)
-        imgs, _, _, _ = self.dd(gs, list(qs), training=True, prior_eps=prior_eps)
-        return imgs
+        _, qs, _ = self.ed(self.eu(x), eps)
+        return self.dd(self.du(c), list(qs), training=True, prior_eps=prior_eps)[0]
 
 
-class Regressor(nn.Module):
-    """models/vunets.py:786-824: latent -> 2-D keypoints probe.
-
-    The embedders are full-window valid convolutions (kernel = latent width), i.e. linear maps of the
-    flattened latent; they run on the 1x1 path of the MFMA conv kernel with the weight viewed as
-    ``[out, in*k*k, 1, 1]``.  State-dict keys/shape are the reference's (``embedders.i.weight`` is
-    ``[out, in, k, k]``).
-    """
-
-    def __init__(self, n_out, n_latent_scales, nf_max, latent_widths, linear_width_factor, n_linear=2, **kwargs):
-        super().__init__()
-        self.n_stages = n_latent_scales
-        self.n_linear = n_linear
-        self.linear_width = self.n_stages * nf_max * linear_width_factor
-        self.embedders = nn.ModuleList()
-        self.linears = nn.ModuleList()
-        self.act_fn = nn.ReLU()
-        for i in range(self.n_stages):
-            self.embedders.append(Conv2d(nf_max, linear_width_factor * nf_max, kernel_size=latent_widths[i]))
-        for i in range(self.n_linear):
-            arg_in = 2 if self.linear_width // 2 ** (self.n_linear - i) > n_out else 1
-            arg_out = 2 if self.linear_width // 2 ** (self.n_linear - i - 1) > n_out else 1
-            if i == n_linear - 1:
-                self.linears.append(Linear(self.linear_width // arg_in ** i, n_out))
-            else:
-                self.linears.append(Linear(self.linear_width // arg_in ** i, self.linear_width // arg_out ** (i + 1)))
-
-    def forward(self, embeddings: list):
-        outs = []
-        for e, emb in zip(reversed(embeddings), self.embedders):
-            n = e.shape[0]
-            assert e.shape[2] == emb.k and e.shape[3] == emb.k, "embedder kernel must equal the latent width"
-            cfg = ops.ConvCfg(kind=1, k=1, out_act=ops.ACT_RELU)
-            y = ops.fused_conv(e.reshape(n, -1, 1, 1), None, None, emb.weight.reshape(emb.weight.shape[0], -1, 1, 1),
-                               None, emb.bias, None, None, cfg)
-            outs.append(y)
-        # the two embeddings are read as one concatenated source by the first linear layer
-        h = tuple(outs) if len(outs) == 2 else (outs[0] if len(outs) == 1 else torch.cat(outs, dim=1))
-        for i in range(self.n_linear):
-            h = self.linears[i].fused(h, out_act=ops.ACT_RELU if i < self.n_linear - 1 else ops.ACT_NONE)
-        return h.reshape(h.shape[0], -1)
-
-
+# ------------------------------------------------------------------------------------------------
+# Regressor  (:786-824)
+# ------------------------------------------------------------------------------------------------
 class Linear(nn.Module):
-    """nn.Linear (keys weight [out,in], bias) on the 1x1 path of the MFMA conv kernel."""
+    """nn.Linear (keys ``weight`` [out, in], ``bias``) on the 1x1 path of the MFMA conv kernel."""
 
     def __init__(self, in_features, out_features):
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
-        lin = nn.Linear(in_features, out_features)
-        self.weight = nn.Parameter(lin.weight.detach().clone())
-        self.bias = nn.Parameter(lin.bias.detach().clone())
+        ref = nn.Linear(in_features, out_features)      # default init
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone())
 
     def fused(self, x, out_act=ops.ACT_NONE):
-        if isinstance(x, (tuple, list)):
-            x1, x2 = (t.reshape(t.shape[0], -1, 1, 1) for t in x)
-        else:
-            x1, x2 = x.reshape(x.shape[0], -1, 1, 1), None
-        cfg = ops.ConvCfg(kind=1, k=1, out_act=out_act)
-        return ops.fused_conv(x1, x2, None, self.weight.reshape(self.out_features, self.in_features, 1, 1), None,
-                              self.bias, None, None, cfg)
+        parts = x if isinstance(x, (tuple, list)) else (x, None)
+        x1, x2 = (None if t is None else t.reshape(t.shape[0], -1, 1, 1) for t in parts)
+        w = self.weight.reshape(self.out_features, self.in_features, 1, 1)
+        return ops.fused_conv(x1, x2, None, w, None, self.bias, None, None, ops.ConvCfg(kind=1, k=1, out_act=out_act))
 
     def forward(self, x):
         return self.fused(x).reshape(x.shape[0], self.out_features)
+
+
+class Regressor(nn.Module):
+    """Latent -> 2-D key-point probe.  The embedders are full-window valid convolutions (kernel = latent
+    width), i.e. linear maps of the flattened latent: they run on the 1x1 path with the weight viewed as
+    ``[out, in*k*k, 1, 1]``; state-dict keys and shapes stay the reference's (``embedders.i.weight``: [out, in, k, k])."""
+
+    def __init__(self, n_out, n_latent_scales, nf_max, latent_widths, linear_width_factor, n_linear=2, **kwargs):
+        super().__init__()
+        self.n_stages, self.n_linear = n_latent_scales, n_linear
+        self.linear_width = n_latent_scales * nf_max * linear_width_factor
+        self.embedders = nn.ModuleList(Conv2d(nf_max, linear_width_factor * nf_max, kernel_size=latent_widths[i])
+                                       for i in range(n_latent_scales))
+        self.linears = nn.ModuleList()
+        self.act_fn = nn.ReLU()
+        lw = self.linear_width
+        for i in range(n_linear):
+            halve_in = 2 if lw // 2 ** (n_linear - i) > n_out else 1
+            halve_out = 2 if lw // 2 ** (n_linear - i - 1) > n_out else 1
+            fan_in = lw // halve_in ** i
+            self.linears.append(Linear(fan_in, n_out if i == n_linear - 1 else lw // halve_out ** (i + 1)))
+
+    def forward(self, embeddings: list):
+        feats = []
+        for latent, emb in zip(reversed(embeddings), self.embedders):
+            assert latent.shape[-1] == emb.k and latent.shape[-2] == emb.k, "embedder kernel must equal the latent width"
+            w = emb.weight.reshape(emb.weight.shape[0], -1, 1, 1)
+            feats.append(ops.fused_conv(latent.reshape(latent.shape[0], -1, 1, 1), None, None, w, None, emb.bias, None,
+                                        None, ops.ConvCfg(kind=1, k=1, out_act=ops.ACT_RELU)))
+        # two embeddings are read as one concatenated source by the first linear layer
+        h = tuple(feats) if len(feats) == 2 else (feats[0] if len(feats) == 1 else torch.cat(feats, dim=1))
+        last = self.n_linear - 1
+        for i, lin in enumerate(self.linears):
+            h = lin.fused(h, out_act=ops.ACT_NONE if i == last else ops.ACT_RELU)
+        return h.reshape(h.shape[0], -1)
