@@ -5,8 +5,8 @@ kernels; ``LeakyReLU(0.2)`` is applied as the *next* convolution's prologue, whi
 as the reference's in-place activation on the producer side.
 
 Upstream never instantiates any of this, so parity is pinned per module
-(tests/golden/g4_discriminators.npz).  The R1 penalty (``grad_pen=True``) needs a double backward through the
-conv kernels and is not built yet: it raises.
+(tests/golden/g4_discriminators.npz), including the R1 penalty (``grad_pen=True``), whose double backward runs
+through ``ops.ConvPlainFwd/Dgrad/Wgrad`` -- conv primitives that differentiate into each other.
 """
 from __future__ import annotations
 
@@ -93,8 +93,6 @@ class DiscTrainer(object):
 
     def __init__(self, generator, config, discriminator=PartDiscriminator, grad_pen=False, lambda_gp=10,
                  grad_weighting=False, **kwargs):
-        if grad_pen:
-            raise NotImplementedError("R1 gradient penalty needs double backward through the HIP conv kernels")
         self.disc = discriminator(n_scales=config["pd_scales"], part_size=kwargs["spatial_size"] // 4)
         self.generator = generator
         self.parallel = isinstance(generator, nn.DataParallel)
@@ -113,13 +111,22 @@ class DiscTrainer(object):
         self.opt.zero_grad()
         logits_real = self.disc(real_x.requires_grad_(True))
         real_loss = self.loss(logits_real, torch.ones_like(logits_real))
-        real_loss.backward(retain_graph=retain_graph)
+        reg = None
+        if self.use_gp:   # R1 penalty on the real batch (:148-151): double backward through the conv kernels
+            real_loss.backward(create_graph=True)
+            reg = self.lambda_gp * compute_grad2(logits_real, real_x).mean()
+            reg.backward()
+        else:
+            real_loss.backward(retain_graph=retain_graph)
         logits_fake = self.disc(fake_x.requires_grad_())
         fake_loss = self.loss(logits_fake, torch.zeros_like(logits_real))
         fake_loss.backward(retain_graph=retain_graph or self.gw)
         self.opt.step()
         self._only(False)
-        return {"dloss": (real_loss + fake_loss).item(), "dloss_r": real_loss.item(), "dloss_f": fake_loss.item()}
+        out = {"dloss": (real_loss + fake_loss).item(), "dloss_r": real_loss.item(), "dloss_f": fake_loss.item()}
+        if reg is not None:
+            out["gp"] = reg.item()
+        return out
 
     def get_genloss(self, x_fake, pre_loss, last_layer_weight):
         self._only(False)
@@ -152,5 +159,7 @@ class DiscTrainer(object):
 
 
 def compute_grad2(d_out, x_in, allow_unused=False):
-    """:244-256 (R1 regulariser) -- requires double backward through the conv kernels: not built yet."""
-    raise NotImplementedError("compute_grad2 needs double backward through the HIP conv kernels (SURVEY n2)")
+    """:244-256 -- R1 regulariser: per-sample squared norm of d(sum of logits)/d(input), differentiable."""
+    (grad_dout,) = autograd.grad(outputs=d_out.sum(), inputs=x_in, create_graph=True, only_inputs=True)
+    assert grad_dout.size() == x_in.size()
+    return grad_dout.pow(2).reshape(x_in.size(0), -1).sum(1)

@@ -194,6 +194,156 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
               _stream())
 
 
+# ------------------------------------------------------------------------------------------------
+# Plain convolution primitives that are closed under differentiation (forward / data gradient / weight
+# gradient each differentiate into the other two).  They back the *double-backward* path only (R1 penalty,
+# models/synth_discriminator.py:244-256): FusedConv.backward, when called with create_graph=True, re-expresses
+# its layer with these primitives and ordinary differentiable tensor ops and lets autograd differentiate that.
+# ------------------------------------------------------------------------------------------------
+def _plain_pack(w, need_dgrad):
+    cout, cin = w.shape[0], w.shape[1]
+    return pack_weights(w.contiguous(), None, None, None, None, cin, 0, 1, need_dgrad)
+
+
+def _plain_desc(n, cin, hs, ws, m, ho, wo, k, stride, pad, mode, mpad):
+    return ConvDesc(N=n, C1=cin, C2=0, Hs=hs, Ws=ws, M=m, m_off=0, Mpad=mpad, Ho=ho, Wo=wo, KH=k, KW=k,
+                    stride=stride, pad=pad, mode=mode, in_act=ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0,
+                    out_act=ACT_NONE, d2s=0, aux_act=ACT_NONE, aux_slope=0.0, aux_drop_p=0.0, aux_drop_seed=0)
+
+
+class ConvPlainFwd(torch.autograd.Function):
+    """y = conv2d(x, w, stride, pad), no bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        _dev(x, w)
+        x, w = _c(x), _c(w)
+        n, cin, hs, ws = x.shape
+        cout, _, k, _ = w.shape
+        ho, wo = conv_out_size(hs, k, stride, pad), conv_out_size(ws, k, stride, pad)
+        wt_f = _plain_pack(w, False)[0]
+        y = torch.empty(n, cout, ho, wo, device=x.device, dtype=torch.float32)
+        _conv_gather(_plain_desc(n, cin, hs, ws, cout, ho, wo, k, stride, pad, 0, wt_f.shape[1]), x, None, wt_f, None,
+                     None, None, y)
+        ctx.save_for_backward(x, w)
+        ctx.geo = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.geo
+        gx = ConvPlainDgrad.apply(gy, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
+        gw = ConvPlainWgrad.apply(x, gy, w.shape[2], stride, pad) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None
+
+
+class ConvPlainDgrad(torch.autograd.Function):
+    """dx = conv2d_transpose(dy, w): the data gradient of ConvPlainFwd for an input of size hs x ws."""
+
+    @staticmethod
+    def forward(ctx, dy, w, hs, ws, stride, pad):
+        _dev(dy, w)
+        dy, w = _c(dy), _c(w)
+        n, cout, ho, wo = dy.shape
+        cin, k = w.shape[1], w.shape[2]
+        wt_d = _plain_pack(w, True)[1]
+        dx = torch.empty(n, cin, hs, ws, device=dy.device, dtype=torch.float32)
+        _conv_gather(_plain_desc(n, cout, ho, wo, cin, hs, ws, k, stride, pad, 1, wt_d.shape[1]), dy, None, wt_d, None,
+                     None, None, dx)
+        ctx.save_for_backward(dy, w)
+        ctx.geo = (stride, pad)
+        return dx
+
+    @staticmethod
+    def backward(ctx, gdx):
+        dy, w = ctx.saved_tensors
+        stride, pad = ctx.geo
+        gdy = ConvPlainFwd.apply(gdx, w, stride, pad) if ctx.needs_input_grad[0] else None
+        gw = ConvPlainWgrad.apply(gdx, dy, w.shape[2], stride, pad) if ctx.needs_input_grad[1] else None
+        return gdy, gw, None, None, None, None
+
+
+class ConvPlainWgrad(torch.autograd.Function):
+    """dW[co, ci, kh, kw] = sum_px dy[co, px] x[ci, px (+) tap]: the weight gradient of ConvPlainFwd."""
+
+    @staticmethod
+    def forward(ctx, x, dy, k, stride, pad):
+        _dev(x, dy)
+        x, dy = _c(x), _c(dy)
+        n, cin, hs, ws = x.shape
+        cout, ho, wo = dy.shape[1], dy.shape[2], dy.shape[3]
+        wd = WgradDesc(N=n, C1=cin, C2=0, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=stride, pad=pad,
+                       in_act=ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0, nsplit=1)
+        ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
+        wd.nsplit = ns
+        ktot = k * k * cin
+        slabs = torch.empty(ns * _r32(cout) * (ktot + 1), device=x.device, dtype=torch.float32)
+        dshift = slabs[ns * _r32(cout) * ktot:]
+        _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x), None, _p(dy), _p(slabs), _p(dshift), _stream())
+        dw = torch.empty(cout, cin, k, k, device=x.device, dtype=torch.float32)
+        work = torch.empty(cout * (ktot + 1), device=x.device, dtype=torch.float32)
+        wn = WnDesc(cout, cin, 0, k, k, 1)
+        _call("vunet_weightnorm_bwd", ctypes.byref(wn), _p(slabs), _p(dshift), ns, _p(dw), None, None, None, None,
+              _p(dw), None, None, None, None, _p(work), 0, _stream())
+        ctx.save_for_backward(x, dy)
+        ctx.geo = (k, stride, pad)
+        return dw
+
+    @staticmethod
+    def backward(ctx, gw):
+        x, dy = ctx.saved_tensors
+        k, stride, pad = ctx.geo
+        gx = ConvPlainDgrad.apply(dy, gw, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
+        gdy = ConvPlainFwd.apply(x, gw, stride, pad) if ctx.needs_input_grad[1] else None
+        return gx, gdy, None, None, None
+
+
+def _differentiable_layer(x1, x2, res, v, g, bias, gamma, beta, cfg):
+    """The layer of FusedConv.forward re-expressed with ConvPlainFwd and differentiable tensor ops."""
+    x = x1 if x2 is None else torch.cat([x1, x2], dim=1)
+    if cfg.in_act == ACT_ELU:
+        x = torch.nn.functional.elu(x)
+    elif cfg.in_act == ACT_RELU:
+        x = torch.relu(x)
+    elif cfg.in_act == ACT_LRELU:
+        x = torch.nn.functional.leaky_relu(x, cfg.in_slope)
+    if cfg.drop_p > 0:
+        m1 = dropout_keep_mask(x1.shape, cfg.drop_p, cfg.drop_seed, x1.device)
+        mask = m1 if x2 is None else torch.cat(
+            [m1, dropout_keep_mask(x2.shape, cfg.drop_p, (cfg.drop_seed + SEED2_OFFSET) & 0xFFFFFFFF, x2.device)], dim=1)
+        x = x * mask / (1.0 - cfg.drop_p)
+    cout = v.shape[0]
+    if cfg.kind == 1:
+        w, scale_out = v, None
+    else:
+        nrm = v.flatten(1).norm(dim=1)
+        if cfg.kind == 2:
+            nrm = nrm.clamp_min(1e-12)
+        w = v * ((g.reshape(-1) if cfg.kind == 0 else 1.0) / nrm).view(-1, 1, 1, 1)
+        scale_out = gamma.reshape(1, cout, 1, 1) if gamma is not None else None
+    y = ConvPlainFwd.apply(x, w, cfg.stride, cfg.pad)
+    if bias is not None:
+        y = y + bias.view(1, cout, 1, 1)
+    if scale_out is not None:
+        y = scale_out * y
+    if cfg.kind != 1 and beta is not None:
+        y = y + beta.reshape(1, cout, 1, 1)
+    if cfg.out_act == ACT_RELU:
+        y = torch.relu(y)
+    elif cfg.out_act == ACT_SIGMOID:
+        y = torch.sigmoid(y)
+    elif cfg.out_act == ACT_ELU:
+        y = torch.nn.functional.elu(y)
+    elif cfg.out_act == ACT_LRELU:
+        y = torch.nn.functional.leaky_relu(y, cfg.in_slope)
+    if cfg.d2s:
+        y = DepthToSpace.apply(y)
+    if res is not None:
+        y = y + res
+    return y
+
+
 # Parameters whose .grad is a view of a flat bucket (optim.FlatBucket) are written in place by the
 # weight-norm backward kernel (accumulate mode); autograd then gets None for them.  Listeners (the
 # data-parallel averager) are told which parameter gradients have just been completed.
@@ -325,6 +475,7 @@ class FusedConv(torch.autograd.Function):
         _conv_gather(d, x1, x2, wt_f, shift, res, None, y)
         ctx.cfg = cfg
         ctx.param_refs = (v, g, bias, gamma, beta)  # the caller's tensors (Parameters): direct .grad writes
+        ctx.res_ref = res
         ctx.dims = (n, c1, c2, hs, ws, cout, ho, wo)
         ctx.need_w = need_w
         ctx.save_for_backward(x1, x2, v, g, bias, gamma, invnorm, wt_d,
@@ -335,6 +486,20 @@ class FusedConv(torch.autograd.Function):
     def backward(ctx, dy):
         x1, x2, v, g, bias, gamma, invnorm, wt_d, y = ctx.saved_tensors
         cfg: ConvCfg = ctx.cfg
+        if torch.is_grad_enabled():
+            # create_graph=True (e.g. the R1 penalty): build a differentiable backward by re-expressing the layer
+            # with primitives that autograd can differentiate again, and differentiating that expression
+            res, beta = ctx.res_ref, ctx.param_refs[4]
+            with torch.enable_grad():
+                y2 = _differentiable_layer(x1, x2, res, v, g, bias, gamma, beta, cfg)
+            needs = list(ctx.needs_input_grad[:8])
+            if cfg.res_is_x1:
+                needs[2] = False   # the residual IS source 1: its gradient is already part of d/dx1
+            tensors = (x1, x2, res, v, g, bias, gamma, beta)
+            wanted = [t for t, need in zip(tensors, needs) if need and t is not None]
+            grads = iter(torch.autograd.grad(y2, wanted, dy, create_graph=True, allow_unused=True))
+            out = [next(grads) if (need and t is not None) else None for t, need in zip(tensors, needs)]
+            return (*out, None)
         n, c1, c2, hs, ws, cout, ho, wo = ctx.dims
         dy = _c(dy)
         dres = dy if (ctx.needs_input_grad[2] and not cfg.res_is_x1) else None
