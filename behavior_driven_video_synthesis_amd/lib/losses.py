@@ -55,14 +55,18 @@ def vgg_loss(custom_vgg, target, pred, weights=None):
     builds both (it never disables ``requires_grad`` on VGG), which changes neither the loss nor the
     gradient reaching the generator.
     """
-    if weights is not None:
-        raise NotImplementedError("pixel-weighted vgg_loss branch (lib/losses.py:103-117) is unused upstream")
     with torch.no_grad():
         wanted = VGGOutput(**custom_vgg(target))
     got = VGGOutput(**custom_vgg(pred))
     tap_weights = get_member(custom_vgg, "loss_weights")
-    return {name: ops.L1Mean.apply(t, p, float(w))
-            for name, t, p, w in zip(VGGOutput._fields, wanted, got, tap_weights)}
+    losses = {name: ops.L1Mean.apply(t, p, float(w))
+              for name, t, p, w in zip(VGGOutput._fields, wanted, got, tap_weights)}
+    if weights is not None:
+        # :103-117 -- a pixel-weight map on the first ("input") tap only: mean(weights * |t0 - p0|).  |w t - w p| =
+        # w |t - p| for w >= 0, so the fused L1 kernel is fed the pre-weighted tensors.
+        w = weights.to(got[0].dtype).expand_as(got[0])
+        losses[VGGOutput._fields[0]] = ops.L1Mean.apply(wanted[0] * w, got[0] * w, float(tap_weights[0]))
+    return losses
 
 
 class GANLoss(nn.Module):
