@@ -20,23 +20,52 @@ static long tiled_blocks(const vunet_conv_desc& d, int MT, int NT) {
   return (long)d.N * (d.Ho / TH) * (d.Wo / TW) * ((d.M + 32 * MT - 1) / (32 * MT));
 }
 
-// Tile height, from in-pipeline measurements on MI355X (tools/profile_layers.py, tools/bench_conv.py):
-//  * layers that do per-element VALU work around the MFMA loop -- the ELU/dropout prologue at staging, or the
-//    act'(aux) epilogue of the data gradient -- run best with the 4-row tile (NT = 1): ~50 KiB of LDS and ~120
-//    VGPRs give 3 workgroups per CU, and the extra waves hide the VALU bursts (75 -> 96 TF/s on 64@128^2);
+// Tile height, from measurements on MI355X (tools/profile_layers.py, tools/bench_conv.py):
 //  * plain layers (the VGG19 stack) run best with the tallest tile that still leaves >= 2 workgroups per CU
-//    (129 vs 113 TF/s on 256@64^2 and 512@32^2).
+//    (129 vs 113 TF/s on 256@64^2 and 512@32^2);
+//  * layers that do per-element VALU work around the MFMA loop -- the ELU/dropout prologue at staging, or the
+//    act'(aux) epilogue of the data gradient -- and the narrow (<= 32 output channel) layers choose between the
+//    4-row and the 8-row tile by a cost model: a launch runs ceil(blocks / (CUs * resident workgroups)) rounds and a
+//    partly filled last round costs a whole one (128@64^2, batch 16: 1024 four-row tiles on 768 slots = 2 rounds,
+//    63 TF/s; 512 eight-row tiles on 512 slots = 1 round, 91 TF/s), times a measured per-tile efficiency.
 // Returns 0 if even the smallest tile cannot give half the chip one workgroup each.
+static int resident_workgroups(int MT, int NT) {  // per CU: min(VGPR, LDS) limits of the instantiations
+  if (MT == 1) return NT == 1 ? 3 : NT == 2 ? 4 : 2;
+  return NT == 1 ? 3 : 2;
+}
+
 int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT, bool valu_heavy) {
   *MT = d->M <= 32 ? 1 : 2;
   if (const char* f = getenv("VUNET_TILED_FORCE_NT")) {  // tests / tuning: force a tile height
     const int NT = atoi(f);
     if ((NT == 1 || NT == 2 || NT == 4) && tiled_blocks(*d, *MT, NT) > 0) return NT;
   }
-  if (!valu_heavy && *MT == 2)
+  if (!valu_heavy && *MT == 2) {
     for (int NT = 4; NT >= 2; NT >>= 1)
       if (tiled_blocks(*d, *MT, NT) >= 512) return NT;
-  return tiled_blocks(*d, *MT, 1) >= 128 ? 1 : 0;
+    return tiled_blocks(*d, *MT, 1) >= 128 ? 1 : 0;
+  }
+  const int nch = (d->C1 + d->C2) / 8;  // K chunks: the taller tile gains with a longer K loop
+  int best = 0;
+  double best_cost = 0.0;
+  for (int NT = 1; NT <= 2; ++NT) {
+    const long blocks = tiled_blocks(*d, *MT, NT);
+    if (blocks < 128) continue;
+    const int occ = resident_workgroups(*MT, NT);
+    const long slots = 256L * occ;
+    const long rounds = (blocks + slots - 1) / slots;
+    double eff = 1.0;
+    if (NT == 2) {
+      eff = d->mode == 1 ? 0.88 : (*MT == 1 ? 1.12 : 0.93);
+      if (nch >= 16) eff *= 1.08;
+    }
+    const double cost = (double)rounds * occ * NT / eff;
+    if (best == 0 || cost < best_cost) {
+      best = NT;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
 int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st) {
