@@ -7,7 +7,11 @@ ignite / wandb / dataset plumbing that is out of scope:
 * ``VunetAlter`` + frozen ``PerceptualVGG`` + Adam(4 param groups, betas (0.5,0.9), lr linearly decayed),
 * loss = ll_weight * sum_i vgg_loss_i + gamma * KL once ``iteration > n_init_batches``,
 * gamma controller ``gamma <- max(gamma - gamma_step * (imax - kl), 0)``,
-* optional regressor side loop (:407-425), which contributes no gradient to the VUnet.
+* optional regressor side loop (:407-425), which contributes no gradient to the VUnet,
+* optional adversarial term (``training.gan``): the reference ships ``DiscTrainer`` / ``PartDiscriminator``
+  (models/synth_discriminator.py:77-242) but its loop never constructs them; here they can be
+  switched on -- generator loss ``weight * w * BCE(D(fake patch), 1)`` added to the step's loss, then one
+  ``train_disc`` step on the same (detached) patches.  Off by default, so the default step is the reference's.
 
 MI355X-first differences (results unchanged): the gamma controller and every logged scalar stay on
 the device (the reference forces >= 10 host syncs per step), Adam is one fused launch per param
@@ -25,6 +29,7 @@ from .. import ops
 from ..lib.losses import compute_kl_with_prior, vgg_loss
 from ..lib.utils import get_member, linear_var, n_parameters
 from ..models.imagenet_pretrained import PerceptualVGG, vgg19
+from ..models.synth_discriminator import DiscTrainer
 from ..models.vunets import Regressor, VunetAlter
 from ..optim import FusedAdam
 from ..parallel import BucketedGradAverager, broadcast_parameters
@@ -40,7 +45,10 @@ DEFAULT_CONFIG = {
     "training": {"batch_size": 12, "vgg_weights": [1.0] * 6, "dropout_prob": 0.05, "lr": 0.0005,
                  "gamma_step": 0.00001, "n_init_batches": 4, "adam_betas": (0.5, 0.9), "end_iteration": 150000,
                  "imax_scaling": "none", "information_max": 1000, "ll_weight": 1.0, "train_regressor": True,
-                 "weight_regressor": 4.0, "reg_steps": 5},
+                 "weight_regressor": 4.0, "reg_steps": 5,
+                 # adversarial term: not part of the reference loop, off by default
+                 "gan": {"enabled": False, "weight": 1.0, "pd_scales": 3, "grad_pen": False, "lambda_gp": 10,
+                         "grad_weighting": False, "lr": 0.0002, "save_intervall": 10000}},
 }
 
 
@@ -70,6 +78,19 @@ class ShapePoseNet:
                              for i in range(arch["n_latent_scales"], 0, -1)]
             self.regressor = Regressor(n_keypoints * 2, latent_widths=latent_widths, **arch).to(self.device)
             self.optimizer_regressor = FusedAdam(list(self.regressor.parameters()), lr=0.001)
+        # ---- adversarial term (models/synth_discriminator.py:115-242), optional
+        gan = tr.get("gan") or {}
+        self.gan = None
+        if gan.get("enabled", False):
+            self.gan = DiscTrainer(self.vunet, {"pd_scales": gan.get("pd_scales", 3), "adam_beta": tuple(tr["adam_betas"]),
+                                                "save_intervall": gan.get("save_intervall", 10000)},
+                                   grad_pen=gan.get("grad_pen", False), lambda_gp=gan.get("lambda_gp", 10),
+                                   grad_weighting=gan.get("grad_weighting", False), spatial_size=data["spatial_size"])
+            self.gan.keep_generator_grads = True   # train_fn zeroes the flat gradient buckets itself
+            self.gan.init_training([self.device], lr=gan.get("lr", tr["lr"]), process_group=process_group)
+            self.gan_weight = float(gan.get("weight", 1.0))
+            self.gan_patch = data["spatial_size"] // 4 + 2   # PartDiscriminator opens with a valid 3x3 conv (:87)
+            self._gan_rng = torch.Generator().manual_seed(config["general"].get("seed", 42) + 7919)
         # ---- data parallel (replaces nn.DataParallel, :213-214)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         broadcast_parameters(self.optimizer.buckets, 0, process_group)
@@ -141,9 +162,22 @@ class ShapePoseNet:
             # pure scalar offset: no gradient path to the VUnet (:413 runs under no_grad)
             loss = loss - torch.clamp(loss_regressor.detach(), max=1.2) * tr["weight_regressor"]
             out["loss_reg"] = loss_regressor.detach()
+        patches = None
+        if self.gan is not None:
+            # one (patch x patch) window per step, the same for the real and the generated batch
+            P, S = self.gan_patch, target_img.shape[-1]
+            oy, ox = (int(v) for v in torch.randint(0, S - P + 1, (2,), generator=self._gan_rng))
+            fake_patch = out_img[:, :, oy:oy + P, ox:ox + P].contiguous()
+            real_patch = target_img[:, :, oy:oy + P, ox:ox + P].contiguous()
+            gen_loss, w = self.gan.get_genloss(fake_patch, likelihood_loss, self.vunet.dd.out_conv.conv.weight_v)
+            loss = loss + self.gan_weight * w * gen_loss
+            out["gen_loss"] = gen_loss.detach()
+            patches = (real_patch.detach(), fake_patch.detach())
         loss.backward()
         kl_avg = self.averager.finish(kl.detach().clone().reshape(1))
         self.optimizer.step()
+        if patches is not None:
+            out.update(self.gan.train_disc(*patches))
         # gamma controller on the device (:82-85,442); with DP every rank sees the averaged KL
         self.gamma = torch.clamp(self.gamma - tr["gamma_step"] * (self.imax - kl_avg.reshape(())), min=0.0)
         self.adjust_params(it)
@@ -174,7 +208,10 @@ class ShapePoseNet:
 
     # ---- checkpoint layout of :474-482
     def state_dict(self):
-        return {"model": self.vunet.state_dict(), "optimizer": self.optimizer.state_dict()}
+        sd = {"model": self.vunet.state_dict(), "optimizer": self.optimizer.state_dict()}
+        if self.gan is not None:   # DiscTrainer's own save dict (models/synth_discriminator.py:228-231) rides along
+            sd["discriminator"] = self.gan.checkpoint()
+        return sd
 
     def load_state_dict(self, ckpt):
         self.vunet.load_state_dict(ckpt["model"])
@@ -183,6 +220,9 @@ class ShapePoseNet:
             states = list(ckpt["optimizer"]["state"].values())
             if states:
                 self.iteration = int(states[-1]["step"])  # :248-255
+        if self.gan is not None and "discriminator" in ckpt:
+            self.gan.disc.load_state_dict(ckpt["discriminator"]["disc"])
+            self.gan.opt.load_state_dict(ckpt["discriminator"]["opt"])
 
 
 def synthetic_batch(batch_size: int, spatial_size: int, device, seed: int = 42, n_channels_x: int = 3,

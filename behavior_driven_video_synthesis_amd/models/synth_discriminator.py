@@ -100,6 +100,8 @@ class DiscTrainer(object):
         self.use_gp, self.lambda_gp, self.gw = grad_pen, lambda_gp, grad_weighting
         self.adam_betas, self.save_intervall = config["adam_beta"], config["save_intervall"]
         self.opt = None
+        self.averager = None                 # data parallel: set by init_training when a process group is up
+        self.keep_generator_grads = False    # a caller that zeroes the generator's flat gradient buckets itself
 
     def _only(self, train_disc: bool):
         toggle_grad(self.disc, train_disc)
@@ -108,6 +110,8 @@ class DiscTrainer(object):
     def train_disc(self, real_x, fake_x, retain_graph=False):
         self._only(True)
         self.disc.train()
+        if self.averager is not None:
+            self.averager.start_step()
         self.opt.zero_grad()
         logits_real = self.disc(real_x.requires_grad_(True))
         real_loss = self.loss(logits_real, torch.ones_like(logits_real))
@@ -121,6 +125,8 @@ class DiscTrainer(object):
         logits_fake = self.disc(fake_x.requires_grad_())
         fake_loss = self.loss(logits_fake, torch.zeros_like(logits_real))
         fake_loss.backward(retain_graph=retain_graph or self.gw)
+        if self.averager is not None:
+            self.averager.finish()
         self.opt.step()
         self._only(False)
         out = {"dloss": (real_loss + fake_loss).item(), "dloss_r": real_loss.item(), "dloss_f": fake_loss.item()}
@@ -136,18 +142,24 @@ class DiscTrainer(object):
             return gen_loss, 1.0
 
         def mean_grad(loss):   # :197-205: mean gradient of a loss term at the generator's last layer
-            self.generator.zero_grad()
-            return torch.mean(autograd.grad(loss, last_layer_weight, retain_graph=True)[0])
+            if not self.keep_generator_grads:
+                self.generator.zero_grad()
+            with ops.direct_grads(False):   # the gradient must come back as a tensor, not land in .grad
+                return torch.mean(autograd.grad(loss, last_layer_weight, retain_graph=True)[0])
         weight = torch.abs(mean_grad(pre_loss) / mean_grad(gen_loss))
         return gen_loss, weight.requires_grad_(False)
 
-    def init_training(self, devices, lr, d_ckpt=None, o_ckpt=None):
+    def init_training(self, devices, lr, d_ckpt=None, o_ckpt=None, process_group=None):
         if d_ckpt is not None:
             self.disc.load_state_dict(d_ckpt)
         self.disc.to(devices[0])
         self.opt = FusedAdam([{"params": list(self.disc.parameters()), "name": "disc"}], lr=lr, betas=self.adam_betas)
         if o_ckpt is not None:
             self.opt.load_state_dict(o_ckpt)
+        if torch.distributed.is_initialized():   # replaces nn.DataParallel(disc): replica + averaged gradients
+            from ..parallel import BucketedGradAverager, broadcast_parameters
+            broadcast_parameters(self.opt.buckets, 0, process_group)
+            self.averager = BucketedGradAverager(self.opt.buckets, process_group)
 
     def update_lr(self, lr):
         for group in self.opt.param_groups:

@@ -348,10 +348,29 @@ def _differentiable_layer(x1, x2, res, v, g, bias, gamma, beta, cfg):
 # weight-norm backward kernel (accumulate mode); autograd then gets None for them.  Listeners (the
 # data-parallel averager) are told which parameter gradients have just been completed.
 _grad_hooks = []
+_direct_grads_enabled = True
+
+
+class direct_grads:
+    """``with ops.direct_grads(False):`` around ``torch.autograd.grad`` calls that ask for parameter gradients:
+    those must come back as tensors, not be accumulated into ``.grad`` (models/synth_discriminator.py:197-205)."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _direct_grads_enabled
+        self.prev, _direct_grads_enabled = _direct_grads_enabled, self.enabled
+
+    def __exit__(self, *exc):
+        global _direct_grads_enabled
+        _direct_grads_enabled = self.prev
+        return False
 
 
 def _has_direct_grad(p) -> bool:
-    return getattr(p, "_vunet_direct_grad", False) and p.grad is not None and p.grad.is_contiguous()
+    return (_direct_grads_enabled and getattr(p, "_vunet_direct_grad", False) and p.grad is not None
+            and p.grad.is_contiguous())
 
 
 def add_grad_hook(fn):
@@ -361,9 +380,6 @@ def add_grad_hook(fn):
 def remove_grad_hook(fn):
     if fn in _grad_hooks:
         _grad_hooks.remove(fn)
-
-
-_frozen_pack_cache = {}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -450,7 +466,11 @@ class FusedConv(torch.autograd.Function):
         need_x = (ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]))
         need_w = any(ctx.needs_input_grad[3:8])
         frozen = not any(t is not None and t.requires_grad for t in (v, g, bias, gamma, beta))
-        key = (v.data_ptr(), v._version, c1, c2, cfg.kind, need_x) if frozen else None
+        # frozen feature extractor (VGG19): pack once, reuse for every pass.  The packed buffers hang off the weight
+        # tensor itself (they die with it) and are stamped with every operand's storage address and version counter.
+        sub = (c1, c2, cfg.kind, bool(need_x))
+        stamp = tuple(None if t is None else (t.data_ptr(), t._version) for t in (v, g, bias, gamma, beta))
+        hit = getattr(v, "_vunet_frozen_pack", {}).get(sub) if frozen else None
         pre = None
         if cfg.owner is not None and not frozen:
             cfg.owner._last_split = (c1, c2, bool(need_x) or getattr(cfg.owner, "_last_split", (0, 0, False))[2])
@@ -459,12 +479,14 @@ class FusedConv(torch.autograd.Function):
                 pre = None
         if pre is not None:
             _, wt_f, wt_d, scale, shift, invnorm = pre
-        elif frozen and key in _frozen_pack_cache:
-            wt_f, wt_d, scale, shift, invnorm = _frozen_pack_cache[key]
+        elif hit is not None and hit[0] == stamp:
+            wt_f, wt_d, scale, shift, invnorm = hit[1]
         else:
             wt_f, wt_d, scale, shift, invnorm = pack_weights(v, g, bias, gamma, beta, c1, c2, cfg.kind, need_x)
-            if frozen:  # frozen feature extractor (VGG19): pack once, reuse for every pass
-                _frozen_pack_cache[key] = (wt_f, wt_d, scale, shift, invnorm)
+            if frozen:
+                if not hasattr(v, "_vunet_frozen_pack"):
+                    v._vunet_frozen_pack = {}
+                v._vunet_frozen_pack[sub] = (stamp, (wt_f, wt_d, scale, shift, invnorm))
         if cfg.d2s:
             y = torch.empty(n, cout // 4, 2 * ho, 2 * wo, device=x1.device, dtype=torch.float32)
         else:

@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--regressor", action="store_true", help="run the regressor side loop as the reference config does")
+    ap.add_argument("--gan", action="store_true",
+                    help="add the PartDiscriminator adversarial term + one discriminator step (not in the reference loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
@@ -54,6 +56,7 @@ def make_config(args):
     cfg["data"]["spatial_size"] = args.size
     cfg["training"]["batch_size"] = args.batch
     cfg["training"]["train_regressor"] = bool(args.regressor)
+    cfg["training"]["gan"]["enabled"] = bool(getattr(args, "gan", False))
     return cfg
 
 
@@ -147,6 +150,7 @@ def main():
         "config": {"workload": f"Human3.6m shape_and_pose_net VunetAlter {args.size}x{args.size} per-GPU bs={args.batch} "
                                "fwd+bwd, VGG19 perceptual + KL loss, fused Adam, dropout 0.05"
                                + (", regressor side loop on" if args.regressor else ", regressor side loop off")
+                               + (", adversarial term on" if args.gan else "")
                                + ", seeded-synthetic VGG19 weights",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}",
                    "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val},

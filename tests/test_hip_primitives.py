@@ -222,3 +222,29 @@ def test_cpu_tensors_are_refused():
     mod = M.NormConv2d(4, 4, 3, 1, 1)
     with pytest.raises(RuntimeError):
         mod(torch.zeros(1, 4, 8, 8))
+
+
+def test_frozen_weight_pack_follows_the_weights():
+    """Frozen layers (the VGG19 stack) pack their weights once; the pack must never outlive or mismatch them: a new
+    layer that lands on a freed layer's address, and an in-place weight update, both have to be seen."""
+    import torch.nn.functional as F
+    M = _mods()
+    x = seeded_randn("frozen.x", (2, 8, 16, 16), 1).cuda()
+
+    def check(layer):
+        with torch.no_grad():
+            y = layer(x)
+        ref = F.conv2d(x.cpu(), layer.weight.detach().cpu(), layer.bias.detach().cpu(), padding=1)
+        assert_close(y, ref, rtol=1e-4, atol=1e-5, name="frozen conv")
+
+    for i in range(4):   # allocator reuse: each new layer is likely to sit where the previous one was
+        layer = M.Conv2d(8, 8, 3, 1, 1).cuda().requires_grad_(False)
+        with torch.no_grad():
+            layer.weight.copy_(seeded_randn(f"frozen.w{i}", (8, 8, 3, 3), 1))
+        check(layer)
+        check(layer)     # second call: served from the pack
+        with torch.no_grad():
+            layer.weight.mul_(-0.5)   # in-place update bumps the version counter
+            layer.bias.add_(1.0)
+        check(layer)
+        del layer
