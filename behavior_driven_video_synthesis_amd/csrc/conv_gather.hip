@@ -310,13 +310,20 @@ static int launch_splitk(const GatherArgs& ga, int pro, hipStream_t st) {
   return vunet_check_launch();
 }
 
+// Few output tiles and a long K: share each tile's K loop between 16 waves.  Up to 768 tiles (3 per CU) any layer
+// with >= 64 input channels; up to 2048 tiles only when K is at least 576 deep (3x3 over >= 64 channels) -- there
+// the one-wave-per-tile kernel is latency bound (25 x 256->128 @ 16^2: 582 us vs ~60 us split).
+static bool want_splitk(long ntiles, long mtiles, int kpairs, int taps) {
+  const long tiles = ntiles * mtiles;
+  return (tiles <= 768 && kpairs >= 32) || (tiles <= 2048 && (long)kpairs * taps >= 288);
+}
+
 template <int KS>
 static int dispatch_gather(const GatherArgs& ga, int pro, hipStream_t st) {
   const vunet_conv_desc& d = ga.d;
   const int ntiles = (ga.NP + 31) / 32, mtiles = (d.M + 31) / 32;
   const int kpairs = (((d.C1 + 1) >> 1) + ((d.C2 + 1) >> 1));
-  // few output tiles and a long K: share each tile's K loop between 16 waves
-  if ((long)ntiles * mtiles <= 768 && kpairs >= 32) return launch_splitk<KS>(ga, pro, st);
+  if (want_splitk(ntiles, mtiles, kpairs, d.KH * d.KW)) return launch_splitk<KS>(ga, pro, st);
   if (d.M <= 32) return launch_gather<1, 4, KS>(ga, pro, st);
   return launch_gather<2, 2, KS>(ga, pro, st);
 }
@@ -356,7 +363,7 @@ extern "C" int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has
   const int KS = (d->KH == 3 && d->KW == 3) ? 3 : ((d->KH == 1 && d->KW == 1) ? 1 : 0);
   const long ntiles = ((long)d->N * d->Ho * d->Wo + 31) / 32, mtiles = (d->M + 31) / 32;
   const int kpairs = ((d->C1 + 1) >> 1) + ((d->C2 + 1) >> 1);
-  if (ntiles * mtiles <= 768 && kpairs >= 32) snprintf(name, len, "conv_gather_splitk_kernel<16, %d, %d>", pro, KS);
+  if (want_splitk(ntiles, mtiles, kpairs, d->KH * d->KW)) snprintf(name, len, "conv_gather_splitk_kernel<16, %d, %d>", pro, KS);
   else if (d->M <= 32) snprintf(name, len, "conv_gather_kernel<1, 4, %d, %d>", pro, KS);
   else snprintf(name, len, "conv_gather_kernel<2, 2, %d, %d>", pro, KS);
   return VUNET_OK;

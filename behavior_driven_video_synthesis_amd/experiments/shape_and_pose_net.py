@@ -201,10 +201,11 @@ class ShapePoseNet:
         return loss_regressor
 
     @torch.no_grad()
-    def transfer(self, app_img, stickman):
-        """Inference path used by the render loop (models/vunets.py:508-515)."""
+    def transfer(self, app_img, stickman, dtype: str = "f32"):
+        """Inference path used by the render loop (models/vunets.py:508-515); ``dtype="bf16"``: BASELINE config 5."""
         self.vunet.eval()
-        return self.vunet.transfer(app_img, stickman)
+        with ops.inference_precision(dtype):
+            return self.vunet.transfer(app_img, stickman)
 
     # ---- checkpoint layout of :474-482
     def state_dict(self):

@@ -331,8 +331,18 @@ class VunetAlter(_VunetBase):
         return self.dd(self.du(c), [], training=False, prior_eps=prior_eps)
 
     def transfer(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None):
+        return self.transfer_code(self.appearance_code(x, eps), c)   # posterior means as the code, :508-515
+
+    def appearance_code(self, x, eps: Optional[Sequence[torch.Tensor]] = None):
+        """The appearance half of ``transfer``: the posterior means of ``ed(eu(x))``."""
         _, means, _, _ = self.ed(self.eu(x), eps)
-        return self.dd(self.du(c), list(means), training=True)   # posterior means as the code, :508-515
+        return list(means)
+
+    def transfer_code(self, means, c):
+        """The pose half of ``transfer``; a batch-1 code is broadcast over the frames of ``c`` (render loop)."""
+        n = c.shape[0]
+        means = [m if m.shape[0] == n else m.expand(n, -1, -1, -1).contiguous() for m in means]
+        return self.dd(self.du(c), means, training=True)
 
 
 class VunetOrg(_VunetBase):

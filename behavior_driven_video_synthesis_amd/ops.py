@@ -113,6 +113,7 @@ class ConvCfg:
     d2s: bool = False
     res_is_x1: bool = False  # residual tensor is source 1 itself -> its gradient is fused into the dgrad epilogue
     owner: object = None     # the calling module (records its source split; looked up in the active prepack set)
+    bf16: bool = False       # set by fused_conv: caller is under no_grad inside ops.inference_precision("bf16")
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
@@ -145,8 +146,10 @@ def profile_start():
 
 
 def profile_stop(detail: bool = False, by_kernel: bool = False):
-    """-> {family: {"ms": total kernel time, "flop": algorithmic FLOPs, "n": launches}} (call after a device sync)."""
+    """-> {family: {"ms": total kernel time, "flop": algorithmic FLOPs, "n": launches}} (synchronises the device)."""
     _prof["on"] = False
+    if _prof["recs"]:
+        torch.cuda.synchronize()
     fam = {}
     for name, flop, e0, e1 in _prof["recs"]:
         if by_kernel:
@@ -349,6 +352,27 @@ def _differentiable_layer(x1, x2, res, v, g, bias, gamma, beta, cfg):
 # data-parallel averager) are told which parameter gradients have just been completed.
 _grad_hooks = []
 _direct_grads_enabled = True
+_inference_bf16 = False
+
+
+class inference_precision:
+    """``with ops.inference_precision("bf16"):`` -- under ``torch.no_grad()`` the 3x3 convolutions the bf16 kernel
+    covers round their operands to bf16 and accumulate in fp32 (vunet_conv2d_bf16); everything else, and every call
+    that records a graph, stays fp32.  This is the precision BASELINE config 5 names for the render loop."""
+
+    def __init__(self, dtype: str = "bf16"):
+        if dtype not in ("bf16", "f32", "fp32"):
+            raise ValueError(f"unknown inference precision {dtype!r}")
+        self.on = dtype == "bf16"
+
+    def __enter__(self):
+        global _inference_bf16
+        self.prev, _inference_bf16 = _inference_bf16, self.on
+
+    def __exit__(self, *exc):
+        global _inference_bf16
+        _inference_bf16 = self.prev
+        return False
 
 
 class direct_grads:
@@ -494,7 +518,15 @@ class FusedConv(torch.autograd.Function):
         d = ConvDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, M=cout, m_off=0, Mpad=wt_f.shape[1], Ho=ho, Wo=wo, KH=k, KW=k,
                      stride=cfg.stride, pad=cfg.pad, mode=0, in_act=cfg.in_act, in_slope=cfg.in_slope,
                      drop_p=cfg.drop_p, drop_seed=cfg.drop_seed, out_act=cfg.out_act, d2s=int(cfg.d2s))
-        _conv_gather(d, x1, x2, wt_f, shift, res, None, y)
+        if cfg.bf16 and _lib.lib().vunet_conv2d_bf16_supported(ctypes.byref(d)) == 1:
+            # render path (models/vunets.py:508-515 under no_grad): bf16 operands, fp32 accumulate
+            wb = torch.empty((c1 + c2) * 9 * wt_f.shape[1], device=x1.device, dtype=torch.bfloat16)
+            _call("vunet_pack_bf16", _p(wt_f), _p(wb), c1, c2, wt_f.shape[1], _stream())
+            with _Timed(("conv_bf16_fwd", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, "conv_bf16_kernel"),
+                        2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
+                _call("vunet_conv2d_bf16", ctypes.byref(d), _p(x1), _p(x2), _p(wb), _p(shift), _p(res), _p(y), _stream())
+        else:
+            _conv_gather(d, x1, x2, wt_f, shift, res, None, y)
         ctx.cfg = cfg
         ctx.param_refs = (v, g, bias, gamma, beta)  # the caller's tensors (Parameters): direct .grad writes
         ctx.res_ref = res
@@ -608,6 +640,7 @@ class FusedConv(torch.autograd.Function):
 def fused_conv(x1, x2, res, v, g, bias, gamma, beta, cfg: ConvCfg):
     if res is not None and res is x1 and not cfg.d2s and cfg.out_act == ACT_NONE:
         cfg.res_is_x1 = True
+    cfg.bf16 = _inference_bf16 and not torch.is_grad_enabled()   # grad mode of the CALLER (forward() never records)
     return FusedConv.apply(x1, x2, res, v, g, bias, gamma, beta, cfg)
 
 

@@ -5,6 +5,12 @@ The reference renders a sequence frame by frame in Python (data/data_conversions
 numpy projection (:588-605, :892-912), a CPU cv2 raster (lib/utils.py:325-512), an H2D copy, a batch-1
 ``synth_model.transfer`` and a D2H copy.  Here one raster launch draws every frame of the sequence and the
 synthesis runs in batches; results are identical frame for frame (tests/test_hip_render.py).
+
+``dtype="bf16"`` selects the precision BASELINE config 5 names for this loop: the 3x3 convolutions round their
+operands to bf16 and accumulate in fp32 (``ops.inference_precision``, csrc/conv_bf16.hip); fp32 is the default.
+``share_appearance=True`` encodes the appearance image once per sequence instead of once per frame (the
+reference re-encodes the same image for every frame); with a fixed ``eps`` the frames are bit-identical either
+way, without one the sequence shares a single posterior sample instead of drawing one per frame.
 """
 from __future__ import annotations
 
@@ -12,6 +18,7 @@ from typing import Optional, Sequence
 
 import torch
 
+from . import ops
 from .lib.utils import H36M_JOINT_MODEL, make_joint_img_batch, scale_img
 
 
@@ -40,7 +47,8 @@ def project_sequence(poses3d_world: torch.Tensor, extrinsics: torch.Tensor, intr
 
 @torch.no_grad()
 def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_size: Optional[int] = None,
-                    joint_model=H36M_JOINT_MODEL, chunk: int = 16, as_uint8: bool = True):
+                    joint_model=H36M_JOINT_MODEL, chunk: int = 16, as_uint8: bool = True, dtype: str = "f32",
+                    share_appearance: bool = False, eps=None):
     """Render T frames: ``app_img`` [1, C, H, W] (appearance), ``kps2d`` [T, J, 2] pixel keypoints.
 
     Returns (frames, stickmen): frames uint8 [T, H, W, 3] as the reference builds them
@@ -52,9 +60,15 @@ def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_s
     vunet.eval()
     stick = make_joint_img_batch((size, size), kps2d.to(app_img.device), joint_model, as_float=True)
     outs = []
-    for s in range(0, stick.shape[0], chunk):
-        c = stick[s:s + chunk]
-        outs.append(vunet.transfer(app_img.expand(c.shape[0], -1, -1, -1).contiguous(), c))
+    with ops.inference_precision(dtype):
+        code = vunet.appearance_code(app_img, eps) if share_appearance else None
+        for s in range(0, stick.shape[0], chunk):
+            c = stick[s:s + chunk]
+            if code is not None:
+                outs.append(vunet.transfer_code(code, c))
+            else:
+                e = None if eps is None else [t.expand(c.shape[0], -1, -1, -1).contiguous() for t in eps]
+                outs.append(vunet.transfer(app_img.expand(c.shape[0], -1, -1, -1).contiguous(), c, e))
     rgb = torch.cat(outs, dim=0)
     vunet.train(was_training)
     if as_uint8:

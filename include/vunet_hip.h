@@ -79,6 +79,19 @@ int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* 
  * call passes an aux tensor.  For profiling / roofline bookkeeping only. */
 int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char* name, int32_t len);
 
+/* bf16-operand forward convolution of the inference path (models/vunets.py:508-515 `transfer`, run per frame
+ * by the render loop; BASELINE config 5): operands rounded to bf16 (RNE) on the way into LDS, fp32 accumulate
+ * on v_mfma_f32_32x32x16_bf16, fp32 NCHW tensors in HBM, same prologue / sources / epilogue as
+ * vunet_conv2d_gather mode 0.  Covers 3x3 / stride 1 / pad 1 layers with C1, C2 multiples of 16, Ws a
+ * multiple of 32 and Hs of 4, prologue none or ELU, no dropout; vunet_conv2d_bf16_supported tells (1 / 0),
+ * anything else goes through vunet_conv2d_gather in fp32.
+ *   vunet_pack_bf16: wt_f (the fp32 K-major weights of vunet_weightnorm_fwd, row pitch Mpad) ->
+ *                    wb [(C1+C2)/16][9][Mpad][16] bf16  ((C1+C2)*9*Mpad*2 bytes). */
+int vunet_conv2d_bf16_supported(const vunet_conv_desc* d);
+int vunet_pack_bf16(const float* wt_f, void* wb, int32_t C1, int32_t C2, int32_t Mpad, void* stream);
+int vunet_conv2d_bf16(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wb,
+                      const float* shift, const float* res, float* y, void* stream);
+
 /* Weight gradient  dW[co][tap][ci] = sum_px dy[co][px] * f(x)[ci][px (+) tap]  with the same
  * prologue f as the forward; split over `nsplit` pixel ranges into partial slabs
  *   slabs[nsplit][Coutp][T*(C1+C2)]  (Coutp = Cout rounded up to 32)  and  dshift[nsplit][Coutp].

@@ -248,3 +248,48 @@ def test_frozen_weight_pack_follows_the_weights():
             layer.bias.add_(1.0)
         check(layer)
         del layer
+
+
+@pytest.mark.parametrize("case", [
+    # N, C1, C2,  H,  W,   M, in_act, res, d2s, out_act
+    (2, 16, 0, 8, 32, 16, 0, False, False, 0),
+    (2, 32, 16, 16, 32, 64, 0, False, False, 0),      # two sources, two m-tiles
+    (1, 48, 0, 12, 64, 96, 0, False, False, 0),       # M = 96: the second 64-wide block is half empty
+    (3, 16, 16, 32, 32, 32, 1, True, False, 0),       # ELU prologue + residual (the RNB layer)
+    (2, 32, 0, 16, 32, 64, 1, False, True, 0),        # sub-pixel up-conv: depth-to-space store
+    (2, 16, 0, 64, 32, 24, 0, False, False, 3),       # tall map, sigmoid epilogue, ragged M
+], ids=lambda c: "-".join(str(v) for v in c))
+def test_bf16_inference_conv_vs_rounded_operand_reference(case):
+    """vunet_conv2d_bf16: the result equals an fp64 convolution of the bf16-rounded operands (layout / indexing
+    check at accumulation-order tolerance); ELU runs before the rounding, as in the kernel."""
+    import torch.nn.functional as F
+    from behavior_driven_video_synthesis_amd import ops
+    n, c1, c2, h, w, m, in_act, use_res, d2s, out_act = case
+    x1 = seeded_randn("bf.x1", (n, c1, h, w), 5).cuda()
+    x2 = seeded_randn("bf.x2", (n, c2, h, w), 5).cuda() if c2 else None
+    v = (seeded_randn("bf.v", (m, c1 + c2, 3, 3), 5) * 0.1).cuda()
+    b = seeded_randn("bf.b", (m,), 5).cuda()
+    res = seeded_randn("bf.res", (n, m, h, w), 5).cuda() if use_res else None
+    cfg = ops.ConvCfg(kind=1, k=3, stride=1, pad=1, in_act=ops.ACT_ELU if in_act else ops.ACT_NONE,
+                      out_act=out_act, d2s=d2s)
+    ops.profile_start()
+    with torch.no_grad(), ops.inference_precision("bf16"):
+        y = ops.fused_conv(x1, x2, res, v, None, b, None, None, cfg)
+    assert "conv_bf16_fwd" in ops.profile_stop()
+
+    def r16(t):
+        return t.to(torch.bfloat16).double()
+    x = x1 if x2 is None else torch.cat([x1, x2], 1)
+    x = x.cpu()
+    if in_act:
+        x = F.elu(x)
+    ref = F.conv2d(r16(x), r16(v.cpu()), b.cpu().double(), padding=1)
+    if out_act == ops.ACT_SIGMOID:
+        ref = torch.sigmoid(ref)
+    if d2s:
+        ref = F.pixel_shuffle(ref.reshape(n, 4, m // 4, h, w).transpose(1, 2).reshape(n, m, h, w), 2)
+    if use_res:
+        ref = ref + res.cpu().double()
+    # fp32 accumulation order; with ELU a few inputs may round to the neighbouring bf16 value (fast-exp ulps)
+    tol = 2e-3 if in_act else 2e-5
+    assert_close(y, ref.float(), rtol=tol, atol=tol * float(ref.abs().max()), name="bf16 conv")
