@@ -335,11 +335,23 @@ int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st);
 
 int vunet_conv_tiled_name(const vunet_conv_desc* d, int pro, bool has_aux, char* name, int len);
 
+// conv_1x1.hip: streaming kernel for the 1x1 / stride-1 layers
+bool vunet_conv_1x1_applicable(const vunet_conv_desc* d, int pro);
+int vunet_conv_1x1_launch(const GatherArgs& ga, int pro, hipStream_t st);
+int vunet_conv_1x1_name(const vunet_conv_desc* d, int pro, char* name, int len);
+
 static int prologue_code(const vunet_conv_desc* d) {
   if (d->in_act == ACT_NONE && d->drop_p <= 0.f) return 0;
   if (d->in_act == ACT_ELU && d->drop_p <= 0.f) return 1;
   if (d->in_act == ACT_ELU) return 2;
   return 3;
+}
+
+// the streaming 1x1 kernel, unless the problem is so small that splitting K over 16 waves is the better plan
+static bool use_1x1(const vunet_conv_desc* d, int pro) {
+  const long ntiles = ((long)d->N * d->Ho * d->Wo + 31) / 32, mtiles = (d->M + 31) / 32;
+  const int kpairs = ((d->C1 + 1) >> 1) + ((d->C2 + 1) >> 1);
+  return vunet_conv_1x1_applicable(d, pro) && !want_splitk(ntiles, mtiles, kpairs, 1);
 }
 
 static bool use_tiled(const vunet_conv_desc* d, int pro) {
@@ -354,6 +366,10 @@ extern "C" int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has
   const int pro = prologue_code(d);
   if (d->mode == 1 && d->stride > 1 && getenv("VUNET_NO_PHASE") == nullptr) {
     snprintf(name, len, "conv_gather_kernel<phase x%d>", d->stride * d->stride);
+    return VUNET_OK;
+  }
+  if (use_1x1(d, pro)) {
+    vunet_conv_1x1_name(d, pro, name, len);
     return VUNET_OK;
   }
   if (use_tiled(d, pro)) {
@@ -413,6 +429,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
       }
     return VUNET_OK;
   }
+  if (use_1x1(d, pro)) return vunet_conv_1x1_launch(ga, pro, st);
   if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
   if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);

@@ -36,8 +36,34 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(36, 2024), ids=lambda c: "-".join(str(int(v) if not isinstance(v, float) else v) for v in c))
+def _ids(c):
+    return "-".join(str(int(v) if not isinstance(v, float) else v) for v in c)
+
+
+@pytest.mark.parametrize("case", _cases(36, 2024), ids=_ids)
 def test_fused_conv_random_config_vs_oracle(case):
+    _check(case)
+
+
+# the streaming 1x1 kernel (csrc/conv_1x1.hip) takes channel counts in multiples of 32 on maps too large for split-K:
+# one / two / four m-tiles, ragged M, two sources, pixel tiles that straddle rows (W = 40), ELU + dropout, residual
+@pytest.mark.parametrize("case", [
+    # nb, c1, c2, cout, h,  w, k, stride, pad, act, drop, res
+    (2, 32, 0, 32, 32, 32, 1, 1, 0, True, 0.2, True),
+    (5, 64, 64, 64, 64, 64, 1, 1, 0, True, 0.0, False),
+    (3, 128, 0, 96, 64, 64, 1, 1, 0, False, 0.0, False),
+    (5, 32, 32, 128, 48, 40, 1, 1, 0, True, 0.2, False),
+    (7, 32, 0, 3, 36, 32, 1, 1, 0, False, 0.0, False),
+], ids=_ids)
+def test_streaming_1x1_conv_vs_oracle(case):
+    from behavior_driven_video_synthesis_amd import ops
+    ops.profile_start()
+    _check(case)
+    kernels = ops.profile_stop(by_kernel=True)
+    assert any(k.startswith("conv_1x1_kernel") for k in kernels), kernels
+
+
+def _check(case):
     from behavior_driven_video_synthesis_amd import ops
     nb, c1, c2, cout, h, w, k, stride, pad, act, drop, res = case
     tag = "fz" + "_".join(map(str, case))
