@@ -20,6 +20,7 @@ The checkpoint is ``{"model": state_dict, "optimizer": adam_state_dict}`` as at 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -65,6 +66,8 @@ class ShapePoseNet:
         kw.update(data)
         kw["dropout_prob"] = tr.get("dropout_prob", 0.0)
         self.vunet = VunetAlter(n_channels_x=n_channels_x, **kw).to(self.device)
+        if self.device.type == "cuda" and tr.get("two_streams", os.environ.get("VUNET_TWO_STREAMS", "1") != "0"):
+            self.vunet.enable_two_streams()   # pose encoder (du) beside appearance encoder (eu, ed)
         self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)
@@ -174,6 +177,7 @@ class ShapePoseNet:
             out["gen_loss"] = gen_loss.detach()
             patches = (real_patch.detach(), fake_patch.detach())
         loss.backward()
+        self.vunet.join_streams()
         kl_avg = self.averager.finish(kl.detach().clone().reshape(1))
         self.optimizer.step()
         if patches is not None:

@@ -8,6 +8,8 @@ device-resident scalars, bucketed RCCL gradient averaging.  Checkpoint: ``{"mode
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 import torch
@@ -44,6 +46,8 @@ class Vunet:
         kw.update(data)
         kw["dropout_prob"] = tr.get("dropout_prob", 0.0)
         self.vunet = VunetOrg(n_channels_x=n_channels_x, **kw).to(self.device)
+        if self.device.type == "cuda" and os.environ.get("VUNET_TWO_STREAMS", "1") != "0":
+            self.vunet.enable_two_streams()   # pose encoder (du) on a second HIP stream beside eu / ed
         self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)
@@ -84,6 +88,7 @@ class Vunet:
         kl_loss = compute_kl_loss(p_means, q_means)
         loss = likelihood_loss + self.kl_weight * kl_loss
         loss.backward()
+        self.vunet.join_streams()
         self.averager.finish()
         self.optimizer.step()
         it = self.iteration

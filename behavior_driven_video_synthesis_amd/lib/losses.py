@@ -48,15 +48,19 @@ def compute_kl_with_prior(means, logstds):
     return _sum_terms(ops.KLPrior.apply(m, l, w) for m, l in zip(means, logstds))
 
 
-def vgg_loss(custom_vgg, target, pred, weights=None):
+def vgg_loss(custom_vgg, target, pred, weights=None, target_features=None):
     """lib/losses.py:81-119: ``w_i * mean|t_i - p_i|`` per tap, dict of tensors shaped [1].
+
+    ``target_features``: the dict ``custom_vgg(target)`` if the caller has already computed it (e.g. a fixed target).
 
     The target pass runs without an autograd graph and the VGG weights are frozen: the reference
     builds both (it never disables ``requires_grad`` on VGG), which changes neither the loss nor the
     gradient reaching the generator.
     """
-    with torch.no_grad():
-        wanted = VGGOutput(**custom_vgg(target))
+    if target_features is None:
+        with torch.no_grad():
+            target_features = custom_vgg(target)
+    wanted = VGGOutput(**target_features)
     got = VGGOutput(**custom_vgg(pred))
     tap_weights = get_member(custom_vgg, "loss_weights")
     losses = {name: ops.L1Mean.apply(t, p, float(w))

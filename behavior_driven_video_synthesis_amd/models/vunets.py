@@ -313,6 +313,41 @@ class _VunetBase(nn.Module):
         self.dd = self.decoder_cls(self.n_scales, nf1, nf0, nf_out=3, conv_layer=conv_layer, n_latent_scales=n_lat,
                                    subpixel_upsampling=kwargs["subpixel_upsampling"], dropout_prob=p_drop)
 
+    # ---- pose encoder on a second HIP stream ---------------------------------------------------------------
+    # The small-map layers (<= 16x16) of eu and du are latency-bound launches that leave most CUs idle; run side
+    # by side they fill each other's gaps.  Autograd replays every node on the stream of its forward, so the
+    # backward passes of du and of eu/ed overlap the same way.
+    _side_stream = None
+
+    def enable_two_streams(self, on: bool = True):
+        self._side_stream = torch.cuda.Stream() if on else None
+        return self
+
+    def _fork_pose_encoder(self, c):
+        side = self._side_stream
+        if side is None or not c.is_cuda:
+            return self.du(c)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)               # inputs and the step's packed weights were produced on the main stream
+        c.record_stream(side)
+        with torch.cuda.stream(side):
+            return self.du(c)
+
+    def _join_pose_encoder(self, gs):
+        side = self._side_stream
+        if side is None or not gs[0].is_cuda:
+            return gs
+        main = torch.cuda.current_stream()
+        main.wait_stream(side)
+        for g in gs:
+            g.record_stream(main)
+        return gs
+
+    def join_streams(self):
+        """After backward(): gradients the side stream wrote in place must be visible to the optimiser's stream."""
+        if self._side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+
 
 class VunetAlter(_VunetBase):
     """:426-515 -- the generator ``ShapePoseNet`` trains (learned-variance posterior, no autoregressive prior)."""
@@ -322,9 +357,10 @@ class VunetAlter(_VunetBase):
     decoder_cls = DecDownAlter
 
     def forward(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None):
+        gs = self._fork_pose_encoder(c)      # du(c) shares nothing with eu / ed until dd: issued first, side stream
         hs = self.eu(x)
         _, means, logstds, zs = self.ed(hs, eps)
-        imgs = self.dd(self.du(c), zs, training=True)
+        imgs = self.dd(self._join_pose_encoder(gs), zs, training=True)
         return imgs, means, logstds, (hs, means, logstds)
 
     def test_forward(self, c, prior_eps: Optional[Sequence[torch.Tensor]] = None):
@@ -349,9 +385,10 @@ class VunetOrg(_VunetBase):
     """:18-106 -- the original VUnet (``experiments/vunet.py``)."""
 
     def forward(self, x, c, eps=None, prior_eps=None):
+        gs = self._fork_pose_encoder(c)
         hs = self.eu(x)
         _, qs, zs = self.ed(hs, eps)
-        gs = self.du(c)
+        gs = self._join_pose_encoder(gs)
         imgs, ds, ps, _ = self.dd(gs, zs, training=True, prior_eps=prior_eps)
         return imgs, qs, ps, (hs, qs, gs, ds)
 

@@ -153,17 +153,24 @@ def main():
                                + (", adversarial term on" if args.gan else "")
                                + ", seeded-synthetic VGG19 weights",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                   "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val},
+                   "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val,
+                   "hip_streams": 1 if trainer.vunet._side_stream is None else 2},
     }
 
     if not args.no_roofline:
         # instrumented region: HIP events around every conv-family launch (same stream as the kernels).
         # Every rank runs these steps (train_fn contains the gradient all-reduce); only rank 0 reports.
+        # The timed region runs the pose encoder on a second HIP stream beside the appearance encoder; here both are put back on one
+        # stream so that every event pair times its kernel alone on the GPU (exclusive per-kernel durations).
         prof_steps = max(1, min(3, args.steps))
+        side_stream = trainer.vunet._side_stream
+        trainer.vunet._side_stream = None
+        sync_all()
         ops.profile_start()
         for _ in range(prof_steps):
             trainer.train_fn(batch)
         sync_all()
+        trainer.vunet._side_stream = side_stream
     if rank == 0 and not args.no_roofline:
         recs = ops._prof["recs"][:]                       # raw (key, flop, ev0, ev1) records of the instrumented steps
         fam = ops.profile_stop()                           # per family: conv_gather_fwd / conv_gather_dgrad / conv_wgrad

@@ -105,3 +105,29 @@ def test_shape_pose_net_with_adversarial_term():
     assert "gp" in outs2[-1] and all(torch.isfinite(torch.as_tensor(float(o["loss"]))) for o in outs2)
     g = tr2.optimizer.buckets[0].grad
     assert torch.isfinite(g).all()
+
+
+def test_second_hip_stream_changes_nothing_but_the_schedule():
+    """The pose encoder runs on a second HIP stream beside the appearance encoder (forward and, through autograd's
+    stream replay, backward): parameters, losses and the gamma controller must be bit-identical to the one-stream run."""
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    batch = synthetic_batch(4, 32, "cuda:0")
+
+    def run(two):
+        from behavior_driven_video_synthesis_amd import ops
+        ops.set_dropout_seed(1234)          # the dropout counter is process-global: same masks for both runs
+        cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, n_init_batches=1, gamma_step=1e-3, information_max=5.0,
+                    train_regressor=False, two_streams=two)
+        tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50)
+        assert (tr.vunet._side_stream is not None) == two
+        outs = [tr.train_fn(batch) for _ in range(4)]
+        torch.cuda.synchronize()
+        return tr, outs
+
+    a, oa = run(True)
+    b, ob = run(False)
+    for x, y in zip(oa, ob):
+        assert float(x["loss"]) == float(y["loss"]) and float(x["gamma"]) == float(y["gamma"])
+    for (k, p), (_, q) in zip(a.vunet.state_dict().items(), b.vunet.state_dict().items()):
+        assert torch.equal(p, q), k
