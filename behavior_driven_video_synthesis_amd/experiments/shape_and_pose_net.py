@@ -68,6 +68,7 @@ class ShapePoseNet:
         self.vunet = VunetAlter(n_channels_x=n_channels_x, **kw).to(self.device)
         if self.device.type == "cuda" and tr.get("two_streams", os.environ.get("VUNET_TWO_STREAMS", "1") != "0"):
             self.vunet.enable_two_streams()   # pose encoder (du) beside appearance encoder (eu, ed)
+            ops.enable_wgrad_streams(True)    # weight gradients beside the data-gradient chain of backward
         self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)
@@ -178,6 +179,7 @@ class ShapePoseNet:
             patches = (real_patch.detach(), fake_patch.detach())
         loss.backward()
         self.vunet.join_streams()
+        ops.join_wgrad_streams()
         kl_avg = self.averager.finish(kl.detach().clone().reshape(1))
         self.optimizer.step()
         if patches is not None:

@@ -15,6 +15,7 @@ from typing import Dict, Optional
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from ..lib.losses import compute_kl_loss, vgg_loss
 from ..lib.utils import get_member, linear_var, n_parameters
 from ..models.imagenet_pretrained import PerceptualVGG, vgg19
@@ -48,6 +49,7 @@ class Vunet:
         self.vunet = VunetOrg(n_channels_x=n_channels_x, **kw).to(self.device)
         if self.device.type == "cuda" and os.environ.get("VUNET_TWO_STREAMS", "1") != "0":
             self.vunet.enable_two_streams()   # pose encoder (du) on a second HIP stream beside eu / ed
+            ops.enable_wgrad_streams(True)
         self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)
@@ -89,6 +91,7 @@ class Vunet:
         loss = likelihood_loss + self.kl_weight * kl_loss
         loss.backward()
         self.vunet.join_streams()
+        ops.join_wgrad_streams()
         self.averager.finish()
         self.optimizer.step()
         it = self.iteration

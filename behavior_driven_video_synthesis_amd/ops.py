@@ -352,6 +352,27 @@ def _differentiable_layer(x1, x2, res, v, g, bias, gamma, beta, cfg):
 # data-parallel averager) are told which parameter gradients have just been completed.
 _grad_hooks = []
 _direct_grads_enabled = True
+_wgrad_streams = {"on": False, "by_stream": {}}
+
+
+def enable_wgrad_streams(on: bool = True):
+    """Run the weight-gradient kernels of backward on companion HIP streams (one per stream that runs backward
+    nodes).  Only layers whose parameter gradients are written in place into flat buckets take part; the caller
+    must call ``join_wgrad_streams()`` after ``backward()`` and before reading those gradients."""
+    _wgrad_streams["on"] = bool(on)
+
+
+def _wgrad_stream_for(cur):
+    ws = _wgrad_streams["by_stream"].get(cur.cuda_stream)
+    if ws is None:
+        ws = _wgrad_streams["by_stream"][cur.cuda_stream] = torch.cuda.Stream()
+    return ws
+
+
+def join_wgrad_streams():
+    cur = torch.cuda.current_stream()
+    for ws in _wgrad_streams["by_stream"].values():
+        cur.wait_stream(ws)
 _inference_bf16 = False
 
 
@@ -567,7 +588,8 @@ class FusedConv(torch.autograd.Function):
             dconv = t
         k = cfg.k
         dv = dg = dbias = dgamma = dbeta = None
-        if ctx.need_w:
+
+        def weight_gradients():
             wd = WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=cfg.stride,
                            pad=cfg.pad, in_act=cfg.in_act, in_slope=cfg.in_slope, drop_p=cfg.drop_p,
                            drop_seed=cfg.drop_seed, nsplit=1)
@@ -619,6 +641,25 @@ class FusedConv(torch.autograd.Function):
                 if d_:
                     for hook in _grad_hooks:
                         hook(p_)
+            return dv, dg, dbias, dgamma, dbeta
+
+        if ctx.need_w:
+            ni_ = ctx.needs_input_grad
+            all_direct = all((not ni_[3 + i]) or p_ is None or _has_direct_grad(p_) for i, p_ in enumerate(ctx.param_refs))
+            if _wgrad_streams["on"] and all_direct and dy.is_cuda:
+                # weight gradients are off the critical path of backward (only the data gradient feeds the next
+                # layer): run wgrad + slab reduce + weight-norm backward on a companion stream; the results land in
+                # the flat gradient buckets, ordered before the optimiser by ops.join_wgrad_streams()
+                cur = torch.cuda.current_stream()
+                wstream = _wgrad_stream_for(cur)
+                wstream.wait_stream(cur)
+                for t_ in (x1, x2, dconv, v, g, bias, gamma, invnorm):
+                    if t_ is not None:
+                        t_.record_stream(wstream)
+                with torch.cuda.stream(wstream):
+                    weight_gradients()
+            else:
+                dv, dg, dbias, dgamma, dbeta = weight_gradients()
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             def dgrad(x, cs, m_off, seed, add):

@@ -58,6 +58,9 @@ class BucketedGradAverager:
             return
         self._launched[bi] = True
         b = self.buckets[bi]
+        if b.grad.is_cuda:
+            from . import ops
+            ops.join_wgrad_streams()   # in-place gradient writes of backward's companion streams come first
         b.gather_foreign_grads()
         self._works.append(dist.all_reduce(b.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 

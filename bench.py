@@ -154,7 +154,7 @@ def main():
                                + ", seeded-synthetic VGG19 weights",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}",
                    "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val,
-                   "hip_streams": 1 if trainer.vunet._side_stream is None else 2},
+                   "hip_streams": 1 if trainer.vunet._side_stream is None else 4},
     }
 
     if not args.no_roofline:
@@ -165,12 +165,15 @@ def main():
         prof_steps = max(1, min(3, args.steps))
         side_stream = trainer.vunet._side_stream
         trainer.vunet._side_stream = None
+        wgrad_streams = ops._wgrad_streams["on"]
+        ops.enable_wgrad_streams(False)
         sync_all()
         ops.profile_start()
         for _ in range(prof_steps):
             trainer.train_fn(batch)
         sync_all()
         trainer.vunet._side_stream = side_stream
+        ops.enable_wgrad_streams(wgrad_streams)
     if rank == 0 and not args.no_roofline:
         recs = ops._prof["recs"][:]                       # raw (key, flop, ev0, ev1) records of the instrumented steps
         fam = ops.profile_stop()                           # per family: conv_gather_fwd / conv_gather_dgrad / conv_wgrad
