@@ -80,6 +80,8 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
+        if self.buckets[0].grad.is_cuda:
+            ops.join_wgrad_streams()   # gradients written in place by backward's companion streams come first
         for g, b in zip(self.param_groups, self.buckets):
             b.gather_foreign_grads()
             b.step += 1
