@@ -193,11 +193,18 @@ class ShapePoseNet:
         return out
 
     def _regressor_steps(self, batch):
+        """:407-425.  The reference runs ``ed(eu(reg_imgs[:, i]))`` inside the loop; the encoder is frozen there
+        (``no_grad``, no VUnet update until the outer step), so the ``reg_steps`` encoder passes do not depend on the
+        regressor updates between them and run here as ONE batch of ``B * reg_steps`` samples -- the same per-sample
+        computation, far fewer (and fuller) launches on the small maps.  The regressor steps stay sequential."""
         reg_imgs, reg_targets = batch["reg_imgs"], batch["reg_targets"]
+        b, steps = reg_imgs.shape[:2]
+        with torch.no_grad():
+            flat = reg_imgs.transpose(0, 1).reshape(steps * b, *reg_imgs.shape[2:]).contiguous()   # step-major
+            _, means_all, _, _ = self.vunet.ed(self.vunet.eu(flat))
         loss_regressor = None
-        for i in range(reg_imgs.shape[1]):
-            with torch.no_grad():
-                _, means, _, _ = self.vunet.ed(self.vunet.eu(reg_imgs[:, i].contiguous()))
+        for i in range(steps):
+            means = [m[i * b:(i + 1) * b] for m in means_all]
             preds = self.regressor(means)
             tgts = reg_targets[:, i].reshape(reg_targets.shape[0], -1)
             loss_regressor = torch.norm(preds - tgts, dim=1).mean()
