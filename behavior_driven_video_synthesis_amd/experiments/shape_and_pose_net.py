@@ -66,9 +66,9 @@ class ShapePoseNet:
         kw.update(data)
         kw["dropout_prob"] = tr.get("dropout_prob", 0.0)
         self.vunet = VunetAlter(n_channels_x=n_channels_x, **kw).to(self.device)
-        if self.device.type == "cuda" and tr.get("two_streams", os.environ.get("VUNET_TWO_STREAMS", "1") != "0"):
-            self.vunet.enable_two_streams()   # pose encoder (du) beside appearance encoder (eu, ed)
-            ops.enable_wgrad_streams(True)    # weight gradients beside the data-gradient chain of backward
+        overlap = self.device.type == "cuda" and bool(tr.get("two_streams", os.environ.get("VUNET_TWO_STREAMS", "1") != "0"))
+        self.vunet.enable_two_streams(overlap)   # pose encoder (du) beside appearance encoder (eu, ed)
+        ops.enable_wgrad_streams(overlap)        # weight gradients beside the data-gradient chain (process-wide switch)
         self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)

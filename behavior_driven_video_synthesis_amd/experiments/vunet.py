@@ -47,9 +47,9 @@ class Vunet:
         kw.update(data)
         kw["dropout_prob"] = tr.get("dropout_prob", 0.0)
         self.vunet = VunetOrg(n_channels_x=n_channels_x, **kw).to(self.device)
-        if self.device.type == "cuda" and os.environ.get("VUNET_TWO_STREAMS", "1") != "0":
-            self.vunet.enable_two_streams()   # pose encoder (du) on a second HIP stream beside eu / ed
-            ops.enable_wgrad_streams(True)
+        overlap = self.device.type == "cuda" and os.environ.get("VUNET_TWO_STREAMS", "1") != "0"
+        self.vunet.enable_two_streams(overlap)   # pose encoder (du) on a second HIP stream beside eu / ed
+        ops.enable_wgrad_streams(overlap)
         self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)

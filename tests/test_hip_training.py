@@ -119,7 +119,6 @@ def test_second_hip_stream_changes_nothing_but_the_schedule():
         ops.set_dropout_seed(1234)          # the dropout counter is process-global: same masks for both runs
         cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, n_init_batches=1, gamma_step=1e-3, information_max=5.0,
                     train_regressor=False, two_streams=two)
-        ops.enable_wgrad_streams(False)     # process-global switch: the trainer turns it on together with two_streams
         tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50)
         assert (tr.vunet._side_stream is not None) == two and ops._wgrad_streams["on"] == two
         outs = [tr.train_fn(batch) for _ in range(4)]
