@@ -335,6 +335,11 @@ int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st);
 
 int vunet_conv_tiled_name(const vunet_conv_desc* d, int pro, bool has_aux, char* name, int len);
 
+// conv_thin.hip: VALU kernels for the layers with <= 4 channels on one side
+int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res);
+int vunet_conv_thin_launch(const GatherArgs& ga, int kind, hipStream_t st);
+int vunet_conv_thin_name(const vunet_conv_desc* d, int kind, char* name, int len);
+
 // conv_1x1.hip: streaming kernel for the 1x1 / stride-1 layers
 bool vunet_conv_1x1_applicable(const vunet_conv_desc* d, int pro);
 int vunet_conv_1x1_launch(const GatherArgs& ga, int pro, hipStream_t st);
@@ -366,6 +371,10 @@ extern "C" int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has
   const int pro = prologue_code(d);
   if (d->mode == 1 && d->stride > 1 && getenv("VUNET_NO_PHASE") == nullptr) {
     snprintf(name, len, "conv_gather_kernel<phase x%d>", d->stride * d->stride);
+    return VUNET_OK;
+  }
+  if (const int thin = vunet_conv_thin_kind(d, pro, has_aux != 0, false)) {
+    vunet_conv_thin_name(d, thin, name, len);
     return VUNET_OK;
   }
   if (use_1x1(d, pro)) {
@@ -429,6 +438,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
       }
     return VUNET_OK;
   }
+  if (const int thin = vunet_conv_thin_kind(d, pro, aux != nullptr, res != nullptr)) return vunet_conv_thin_launch(ga, thin, st);
   if (use_1x1(d, pro)) return vunet_conv_1x1_launch(ga, pro, st);
   if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);

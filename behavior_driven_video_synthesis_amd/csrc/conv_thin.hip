@@ -1,0 +1,172 @@
+// Convolutions with a 3-channel side: plain fp32 VALU kernels (no MFMA).
+//
+// The image ends of the networks -- VGG19 conv1_1 (3 -> 64) and its data gradient (64 -> 3), the generator's
+// out_conv (32 -> 3, models/vunets.py:188), the 1x1 input layers (3 -> 32, :118) -- put 3 channels on one side of
+// the product.  On the MFMA kernels that side is padded to a 32-row tile (>= 90 % of the matrix work multiplies
+// zeros: 8.7 TFLOP/s on 64 -> 3 @ 256^2), while the layer itself is memory bound (256^2 x 64 channels of
+// activations for 1728 FMAs per pixel).  Here one lane owns one pixel:
+//   thin_m : M <= 4 outputs per pixel, K walks the input channels; the weights of a (channel, tap) are wave-uniform
+//            (scalar loads, SGPR operands of v_fmac), the 9 taps are row-coalesced loads served by L1;
+//   thin_k : 3 input channels, the (<= 27) input values of a pixel stay in registers and M walks the outputs
+//            in blocks of 8 accumulators.
+// Same weight layout (K-major wt_f / wt_d), same epilogue (store_out) as the MFMA kernels.
+#include "conv_common.h"
+
+// ---- M <= 4, 3x3 / stride 1 / pad 1, forward (MODE 0) or data gradient (MODE 1: mirrored taps) ----------------
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_thin_m_kernel(const GatherArgs a) {
+  const vunet_conv_desc& d = a.d;
+  const int H = d.Hs, W = d.Ws, HW = a.HsWs;
+  const int tiles_w = (W + 31) / 32, tiles_h = (H + 7) / 8;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_w;
+  const int ty = (bid / tiles_w) % tiles_h;
+  const int n = bid / (tiles_w * tiles_h);
+  const int ow = tx * 32 + (threadIdx.x & 31), oh = ty * 8 + (threadIdx.x >> 5);
+  const bool inside = ow < W && oh < H;
+  // tap offsets and validity of this pixel (chunk-invariant)
+  int off[9];
+  uint32_t ok = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+    const bool v = inside && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    off[t] = v ? ih * W + iw : 0;
+    ok |= (v ? 1u : 0u) << t;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int C = d.C1, Cp = (C + 1) & ~1;
+  const float* __restrict__ xs = a.x1 + (size_t)n * C * HW;
+  const float* __restrict__ wt = a.wt + d.m_off;
+  for (int c = 0; c < C; ++c) {
+    float xv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float v = xs[(size_t)c * HW + off[t]];
+      xv[t] = ((ok >> t) & 1u) ? v : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int tap = MODE == 0 ? t : 8 - t;   // data gradient: the taps mirrored
+      const float* __restrict__ w = wt + (size_t)(tap * Cp + c) * d.Mpad;   // wave-uniform: scalar loads
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = fmaf(w[m], xv[t], acc[m]);
+    }
+  }
+  if (!inside) return;
+  PixGeo g;
+  g.n = n;
+  g.oh = oh;
+  g.ow = ow;
+  g.valid = true;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    if (m < d.M) store_out(a, g, m, acc[m]);
+}
+
+// ---- CI (= 3: RGB) input channels, 3x3 pad 1 (KS 3) or 1x1 (KS 1), stride 1, forward ----------------------------
+template <int KS, int CI>
+__global__ __launch_bounds__(256, 4) void conv_thin_k_kernel(const GatherArgs a) {
+  constexpr int T = KS * KS;
+  const vunet_conv_desc& d = a.d;
+  const int H = d.Hs, W = d.Ws, HW = a.HsWs;
+  const int tiles_w = (W + 31) / 32, tiles_h = (H + 7) / 8;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_w;
+  const int ty = (bid / tiles_w) % tiles_h;
+  const int n = bid / (tiles_w * tiles_h);
+  const int ow = tx * 32 + (threadIdx.x & 31), oh = ty * 8 + (threadIdx.x >> 5);
+  const bool inside = ow < W && oh < H;
+  constexpr int C = CI, Cp = (C + 1) & ~1;
+  float xv[CI][T];
+  const float* __restrict__ xs = a.x1 + (size_t)n * C * HW;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int ih = oh + (KS == 3 ? t / 3 - 1 : 0), iw = ow + (KS == 3 ? t % 3 - 1 : 0);
+    const bool v = inside && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    const int off = v ? ih * W + iw : 0;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const float x = xs[c * HW + off];
+      xv[c][t] = v ? x : 0.f;
+    }
+  }
+  const bool relu = d.out_act == ACT_RELU;
+  // the whole [T*CI][M] weight block (<= 27 x 128 floats) goes to LDS once; every lane then reads the same
+  // address (LDS broadcast).  Scalar loads are not an option here: the kernel stores to y between the passes.
+  __shared__ __attribute__((aligned(16))) float wL[T * CI * 128];
+  const int Mr = (d.M + 7) & ~7;
+  for (int e = threadIdx.x; e < T * CI * Mr; e += 256) {
+    const int m = e % Mr, r = e / Mr;           // r = t*CI + c
+    const int t = r / CI, c = r - t * CI;
+    wL[r * Mr + m] = m < d.M ? a.wt[(size_t)(t * Cp + c) * d.Mpad + d.m_off + m] : 0.f;
+  }
+  __syncthreads();
+  constexpr int MBK = 8;                   // outputs per pass
+#pragma unroll 1
+  for (int m0 = 0; m0 < d.M; m0 += MBK) {
+    float acc[MBK];
+#pragma unroll
+    for (int m = 0; m < MBK; ++m) acc[m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const float4 w0 = *reinterpret_cast<const float4*>(&wL[(t * CI + c) * Mr + m0]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&wL[(t * CI + c) * Mr + m0 + 4]);
+        const float x = xv[c][t];
+        acc[0] = fmaf(w0.x, x, acc[0]);
+        acc[1] = fmaf(w0.y, x, acc[1]);
+        acc[2] = fmaf(w0.z, x, acc[2]);
+        acc[3] = fmaf(w0.w, x, acc[3]);
+        acc[4] = fmaf(w1.x, x, acc[4]);
+        acc[5] = fmaf(w1.y, x, acc[5]);
+        acc[6] = fmaf(w1.z, x, acc[6]);
+        acc[7] = fmaf(w1.w, x, acc[7]);
+      }
+      asm volatile("" ::: "memory");   // keep one tap's weight reads in flight, not all 27 rows (register pressure)
+    }
+    if (inside) {   // lean epilogue (this kernel is only chosen for: + shift, optional ReLU, no residual)
+      float* __restrict__ yp = a.y + (size_t)(n * d.M + m0) * HW + oh * W + ow;
+#pragma unroll
+      for (int m = 0; m < MBK; ++m)
+        if (m0 + m < d.M) {
+          float v = acc[m] + (a.shift ? a.shift[m0 + m] : 0.f);
+          if (relu) v = fmaxf(v, 0.f);
+          yp[(size_t)m * HW] = v;
+        }
+    }
+  }
+}
+
+// which thin kernel (if any) takes this problem: 1 = thin_m, 2 = thin_k, 0 = none
+int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res) {
+  if (getenv("VUNET_NO_THIN") != nullptr || pro != 0 || has_aux || d->C2 != 0 || d->stride != 1 || d->Hs != d->Ho ||
+      d->Ws != d->Wo || d->d2s || (long)d->N * d->Hs * d->Ws < 64 * 1024)
+    return 0;
+  const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
+  if (k3 && d->M <= 4 && d->C1 >= 8) return 1;
+  // (the 3x3 form of thin_k is instantiated but not dispatched: hipcc spills ~120 VGPRs around its 27-row weight walk)
+  if (k1 && d->C1 == 3 && d->mode == 0 && d->M <= 128 && !has_res &&
+      (d->out_act == ACT_NONE || d->out_act == ACT_RELU))
+    return 2;
+  return 0;
+}
+
+int vunet_conv_thin_name(const vunet_conv_desc* d, int kind, char* name, int len) {
+  if (kind == 1) return snprintf(name, len, "conv_thin_m_kernel<%d>", d->mode);
+  return snprintf(name, len, "conv_thin_k_kernel<%d, 3>", d->KH);
+}
+
+int vunet_conv_thin_launch(const GatherArgs& ga, int kind, hipStream_t st) {
+  const vunet_conv_desc& d = ga.d;
+  dim3 grid((unsigned)(d.N * ((d.Hs + 7) / 8) * ((d.Ws + 31) / 32))), block(256);
+  if (kind == 1) {
+    if (d.mode == 0) VUNET_LAUNCH((conv_thin_m_kernel<0>), grid, block, 0, st, ga);
+    else VUNET_LAUNCH((conv_thin_m_kernel<1>), grid, block, 0, st, ga);
+  } else {
+    if (d.KH == 3) VUNET_LAUNCH((conv_thin_k_kernel<3, 3>), grid, block, 0, st, ga);
+    else VUNET_LAUNCH((conv_thin_k_kernel<1, 3>), grid, block, 0, st, ga);
+  }
+  return vunet_check_launch();
+}

@@ -106,3 +106,19 @@ def _check(case):
         assert_close(td.grad, tr.grad, rtol=1e-3, atol=1e-4 * max(1.0, float(tr.grad.abs().max())), name=name)
     for name, td, tr in [("dv", vd, vr), ("dg", gd, gr), ("dbias", bd, br), ("dgamma", gmd, gmr), ("dbeta", bed, ber)]:
         assert_close(td.grad, tr.grad, rtol=2e-3, atol=2e-4 * max(1.0, float(tr.grad.abs().max())), name=name)
+
+
+# the VALU kernels for layers with 3 channels on one side (csrc/conv_thin.hip): 3x3 with M = 3 (forward and, through
+# the backward of a 3 -> C layer, the data gradient C -> 3) and the 1x1 input layer 3 -> C; maps >= 64K pixels
+@pytest.mark.parametrize("case", [
+    # nb, c1, c2, cout, h,   w, k, stride, pad, act, drop, res
+    (2, 32, 0, 3, 192, 176, 3, 1, 1, False, 0.0, False),     # out_conv: thin_m forward (ragged tiles: 176 = 5.5 x 32)
+    (4, 3, 0, 64, 128, 128, 3, 1, 1, False, 0.0, False),     # conv1_1: its data gradient 64 -> 3 is thin_m mode 1
+    (3, 3, 0, 32, 160, 144, 1, 1, 0, False, 0.0, False),     # nin 3 -> 32: thin_k 1x1
+], ids=_ids)
+def test_three_channel_side_kernels_vs_oracle(case):
+    from behavior_driven_video_synthesis_amd import ops
+    ops.profile_start()
+    _check(case)
+    kernels = ops.profile_stop(by_kernel=True)
+    assert any(k.startswith("conv_thin_") for k in kernels), kernels
