@@ -156,3 +156,33 @@ def test_checkpoint_file_selection_matches_reference_rule(tmp_path):
     mod, opt = load_ckpt(d, "reg_ckpt")
     assert float(mod["w"]) == 2.0 and opt == {"state": {}, "param_groups": []}
     assert load_ckpt(d, "nothing_like_this") == (None, None)
+
+
+def test_kernel_selection_of_the_gather_entry_point():
+    """vunet_conv2d_gather_variant is host logic (no GPU): which kernel each kind of layer of the path is routed to."""
+    import ctypes
+    from behavior_driven_video_synthesis_amd import _lib, ops
+
+    def variant(has_aux=0, **kw):
+        base = dict(N=16, C1=64, C2=0, Hs=128, Ws=128, M=64, m_off=0, Mpad=64, Ho=128, Wo=128, KH=3, KW=3, stride=1, pad=1,
+                    mode=0, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
+        base.update(kw)
+        buf = ctypes.create_string_buffer(96)
+        assert _lib.lib().vunet_conv2d_gather_variant(ctypes.byref(ops.ConvDesc(**base)), has_aux, buf, 96) == 0
+        return buf.value.decode()
+
+    # VGG19 stack: plain 3x3 layers on the tallest LDS tile that leaves two workgroups per CU
+    assert variant(C1=256, M=256, Mpad=256, Hs=64, Ws=64, Ho=64, Wo=64) == "conv_tiled_kernel<2, 4, 4, 0, 0, 32, 1>"
+    assert variant(C1=512, M=512, Mpad=512, Hs=32, Ws=32, Ho=32, Wo=32) == "conv_tiled_kernel<2, 2, 8, 0, 0, 32, 1>"
+    assert variant(C1=512, M=512, Mpad=512, Hs=16, Ws=16, Ho=16, Wo=16) == "conv_tiled_kernel<2, 1, 8, 0, 0, 16, 1>"
+    # residual-block conv with ELU + dropout prologue; its data gradient (act'(aux) epilogue) keeps the 4-row tile
+    assert variant(in_act=ops.ACT_ELU, drop_p=0.05).startswith("conv_tiled_kernel<2, ")
+    assert variant(mode=1, has_aux=1) == "conv_tiled_kernel<2, 1, 8, 1, 0, 32, 1>"
+    # 1x1 nin layers stream; 8x8 maps share the K loop between 16 waves; stride-2 data gradient runs per output parity
+    assert variant(KH=1, KW=1, pad=0, C1=32, M=32, Mpad=32, Hs=256, Ws=256, Ho=256, Wo=256,
+                   in_act=ops.ACT_ELU) == "conv_1x1_kernel<1, 0, 1>"
+    assert variant(C1=128, M=128, Mpad=128, Hs=8, Ws=8, Ho=8, Wo=8) == "conv_gather_splitk_kernel<16, 0, 3>"
+    assert variant(mode=1, stride=2, C1=128, M=64, Hs=64, Ws=64, Ho=128, Wo=128) == "conv_gather_kernel<phase x4>"
+    # three channels on one side: VALU kernels
+    assert variant(C1=32, M=3, Mpad=32, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_m_kernel<0>"
+    assert variant(C1=3, M=32, Mpad=32, KH=1, KW=1, pad=0, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_k_kernel<1, 3>"
