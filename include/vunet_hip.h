@@ -228,6 +228,14 @@ int vunet_stickman_raster(const float* kps, int32_t B, int32_t J, const int32_t*
 /* uint8 planes -> fp32 in [-1,1]  (ToTensor, *2-1; data/base_dataset.py:183-190) */
 int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* stream);
 
+/* SSIM evaluation hook (lib/metrics.py:94-107: skimage structural_similarity with multichannel=True,
+ * data_range, gaussian_weights=True, use_sample_covariance=False): x, y [planes][H][W] fp32 (planes = N*C),
+ * window11 = the 11 normalised Gaussian taps (sigma 1.5) on the device; partial[planes * ceil(H/8) * ceil(W/32)]
+ * receives per-tile sums of the SSIM map over the 5-pixel-cropped interior; the caller sums them in order and
+ * divides by planes_per_image * (H-10) * (W-10).  H, W >= 11. */
+int vunet_ssim_partial(const float* x, const float* y, int32_t planes, int32_t H, int32_t W, float data_range,
+                       const float* window11, float* partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
