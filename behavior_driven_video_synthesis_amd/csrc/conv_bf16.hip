@@ -234,6 +234,7 @@ extern "C" int vunet_conv2d_bf16(const vunet_conv_desc* d, const float* x1, cons
   ga.auxa = make_inact(ACT_NONE, 0.f, 0.f, 0u);
   ga.ph = ga.pw = -1;
   ga.subW = ga.subHW = 0;
+  ga.mask = nullptr;
   const int pro = d->in_act == ACT_ELU ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   return d->M <= 32 ? launch_bf16<1, 1>(ga, wb, pro, st) : launch_bf16<2, 1>(ga, wb, pro, st);

@@ -18,6 +18,9 @@ struct GatherArgs {
   // With ph/pw set, pixel indices enumerate the sub-grid (n, a, b) of outputs (s*a + ph, s*b + pw), NP counts
   // that sub-grid, and only the taps whose parity matches are visited -- no MFMA is spent on structural zeros.
   int ph, pw, subW, subHW;
+  // internal: data gradient through a ReLU epilogue -- x1 (= dy) is multiplied by [mask > 0] while it is staged
+  // (prologue code 4; mask = the forward output, shaped like x1).  nullptr: off.
+  const float* mask;
 };
 
 struct PixGeo {

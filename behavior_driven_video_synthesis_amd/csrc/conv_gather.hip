@@ -361,8 +361,9 @@ static bool use_1x1(const vunet_conv_desc* d, int pro) {
 
 static bool use_tiled(const vunet_conv_desc* d, int pro) {
   int mt_unused;
-  return getenv("VUNET_NO_TILED") == nullptr && vunet_conv_tiled_applicable(d) && (d->mode == 0 || pro == 0) &&
-         pro != 3 && vunet_conv_tiled_pick(d, &mt_unused, true) > 0;
+  return getenv("VUNET_NO_TILED") == nullptr && vunet_conv_tiled_applicable(d) &&
+         (d->mode == 0 ? pro != 4 : (pro == 0 || (pro == 4 && d->stride == 1))) && pro != 3 &&
+         vunet_conv_tiled_pick(d, &mt_unused, true) > 0;
 }
 
 // Name (rocprofv3 spelling) of the kernel vunet_conv2d_gather would launch for this problem.
@@ -419,6 +420,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   const int pro = prologue_code(d);
   ga.ph = ga.pw = -1;
   ga.subW = ga.subHW = 0;
+  ga.mask = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (d->mode == 1 && d->stride > 1 && getenv("VUNET_NO_PHASE") == nullptr) {
     // strided data gradient: one launch per output parity, each visiting only its own taps
@@ -444,4 +446,27 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
   if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);
   return dispatch_gather<0>(ga, pro, st);
+}
+
+
+// Data gradient through a layer whose forward epilogue was ReLU:  dx = dgrad(dy * [y > 0]) (+ res), the mask applied
+// while dy is staged -- no separate pass over dy / y.  Only the LDS-tiled kernel implements it; every other geometry
+// returns VUNET_ERR_UNSUPPORTED and the caller runs vunet_act_bwd_from_out + vunet_conv2d_gather(mode 1) instead.
+extern "C" int vunet_conv2d_dgrad_relu(const vunet_conv_desc* d, const float* dy, const float* y, const float* wt,
+                                       const float* res, float* dx, void* stream) {
+  if (!d || !dy || !y || !wt || !dx || d->mode != 1 || d->C2 != 0 || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
+  if (d->drop_p > 0.f || d->in_act != ACT_NONE || d->aux_act != ACT_NONE || d->aux_drop_p > 0.f || !use_tiled(d, 4) ||
+      vunet_conv_thin_kind(d, 0, false, res != nullptr) != 0)   // 3-channel side: the two-pass route ends in the VALU kernel
+    return VUNET_ERR_UNSUPPORTED;
+  GatherArgs ga;
+  ga.d = *d;
+  ga.x1 = dy; ga.x2 = nullptr; ga.wt = wt; ga.shift = nullptr; ga.res = res; ga.aux = nullptr; ga.y = dx;
+  ga.NP = d->N * d->Ho * d->Wo;
+  ga.HoWo = d->Ho * d->Wo;
+  ga.HsWs = d->Hs * d->Ws;
+  ga.in1 = ga.in2 = ga.auxa = make_inact(ACT_NONE, 0.f, 0.f, 0u);
+  ga.ph = ga.pw = -1;
+  ga.subW = ga.subHW = 0;
+  ga.mask = y;
+  return vunet_conv_tiled_launch(ga, 4, (hipStream_t)stream);
 }

@@ -70,7 +70,7 @@ int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT, bool valu_heavy) {
 
 int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st) {
   int MT;
-  const int NT = vunet_conv_tiled_pick(&ga.d, &MT, pro != 0 || (ga.d.mode == 1 && ga.aux != nullptr));
+  const int NT = vunet_conv_tiled_pick(&ga.d, &MT, (pro != 0 && pro != 4) || (ga.d.mode == 1 && ga.aux != nullptr));
   if (pro == 3) return VUNET_ERR_UNSUPPORTED;
   const int TW = tile_width(ga.d);
   return MT == 1 ? vunet_conv_tiled_launch_mt1(ga, pro, NT, TW, st) : vunet_conv_tiled_launch_mt2(ga, pro, NT, TW, st);
@@ -79,10 +79,10 @@ int vunet_conv_tiled_launch(const GatherArgs& ga, int pro, hipStream_t st) {
 // kernel the tiled path would launch, in rocprofv3's spelling (bench.py matches it against the kernel trace)
 int vunet_conv_tiled_name(const vunet_conv_desc* d, int pro, bool has_aux, char* name, int len) {
   int MT;
-  const int NT = vunet_conv_tiled_pick(d, &MT, pro != 0 || (d->mode == 1 && has_aux));
+  const int NT = vunet_conv_tiled_pick(d, &MT, (pro != 0 && pro != 4) || (d->mode == 1 && has_aux));
   const int TW = tile_width(*d);
   const int nt = TW == 16 ? 1 : NT;
   const int CK = (MT == 2 && nt == 4) ? 4 : 8;
   return snprintf(name, len, "conv_tiled_kernel<%d, %d, %d, %d, %d, %d, %d>", MT, d->stride == 2 ? 1 : nt, CK, d->mode,
-                  d->mode == 1 ? 0 : pro, TW, d->stride);
+                  d->mode == 1 ? (pro == 4 ? 4 : 0) : pro, TW, d->stride);
 }

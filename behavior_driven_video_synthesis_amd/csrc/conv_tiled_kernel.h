@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
 
   const int nch1 = d.C1 / CK, nch = nch1 + d.C2 / CK;
   float xv[NI], wv[NW];
+  float mk[PRO == 4 ? NI : 1];   // PRO 4 (MODE 1 only): ReLU mask values travelling with xv
 
   auto issue_loads = [&](int ch) {
     const bool second = ch >= nch1;
@@ -84,6 +85,11 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
     const float* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C + cs) * HW;
 #pragma unroll
     for (int i = 0; i < NI; ++i) xv[i] = xs[rel[i]];  // unconditional (no branch per load): masked in write_lds
+    if constexpr (PRO == 4) {
+      const float* __restrict__ ms = a.mask + (size_t)(n * C + cs) * HW;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) mk[i] = ms[rel[i]];
+    }
     const int Cp = (C + 1) & ~1;
     const int krow0 = second ? 9 * ((d.C1 + 1) & ~1) : 0;
     const float* __restrict__ wp = a.wt + (size_t)(krow0 + cs) * d.Mpad + d.m_off + m0;
@@ -108,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) 
       const int e = tid + 256 * i;
       if (e < EI) {
         float v = xv[i];
-        if (PRO != 0) v = prologue<PRO>(ia, v, (uint32_t)(gbase + rel[i]));
+        if constexpr (PRO == 4) v = mk[i] > 0.f ? v : 0.f;
+        else if (PRO != 0) v = prologue<PRO>(ia, v, (uint32_t)(gbase + rel[i]));
         buf[e] = ((vbits >> i) & 1u) ? v : 0.f;
       }
     }
@@ -181,13 +188,20 @@ static int launch_tiled_pro(const GatherArgs& ga, int pro, int blocks, hipStream
   dim3 grid((unsigned)blocks), block(256);
   if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (once per instantiation is enough; it is cheap)
     hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 0, TW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (MODE == 1 && S == 1)
+      hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, 1, 4, TW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if constexpr (MODE == 0) {
       hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 1, TW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipFuncSetAttribute((const void*)conv_tiled_kernel<MT, NT, CK, MODE, 2, TW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
   }
   if constexpr (MODE == 1) {
-    VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 1, 0, TW, S>), grid, block, lds, st, ga);
+    if (pro == 4) {
+      if constexpr (S == 1) VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 1, 4, TW, S>), grid, block, lds, st, ga);
+      else return VUNET_ERR_UNSUPPORTED;
+    } else {
+      VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 1, 0, TW, S>), grid, block, lds, st, ga);
+    }
   } else {
     switch (pro) {
       case 0: VUNET_LAUNCH((conv_tiled_kernel<MT, NT, CK, 0, 0, TW, S>), grid, block, lds, st, ga); break;
@@ -205,7 +219,7 @@ static int launch_tiled(const GatherArgs& ga, int pro, hipStream_t st) {
   const int mblocks = (d.M + 32 * MT - 1) / (32 * MT);
   const int blocks = d.N * (d.Ho / (4 * NT * (32 / TW))) * (d.Wo / TW) * mblocks;
   if (d.mode == 1) {
-    if (pro != 0) return VUNET_ERR_UNSUPPORTED;
+    if (pro != 0 && pro != 4) return VUNET_ERR_UNSUPPORTED;
     return launch_tiled_pro<MT, NT, CK, 1, TW, S>(ga, pro, blocks, st);
   }
   return launch_tiled_pro<MT, NT, CK, 0, TW, S>(ga, pro, blocks, st);

@@ -578,6 +578,29 @@ class FusedConv(torch.autograd.Function):
         n, c1, c2, hs, ws, cout, ho, wo = ctx.dims
         dy = _c(dy)
         dres = dy if (ctx.needs_input_grad[2] and not cfg.res_is_x1) else None
+        k = cfg.k
+        # frozen ReLU layers (the VGG19 stack): the ReLU backward rides in the data-gradient kernel's staging
+        if (cfg.out_act == ACT_RELU and not ctx.need_w and not cfg.d2s and x2 is None and ctx.needs_input_grad[0]
+                and cfg.in_act == ACT_NONE and cfg.drop_p == 0 and wt_d is not None):
+            dx = torch.empty_like(x1)
+            d = ConvDesc(N=n, C1=cout, C2=0, Hs=ho, Ws=wo, M=c1, m_off=0, Mpad=wt_d.shape[1], Ho=hs, Wo=ws, KH=k, KW=k,
+                         stride=cfg.stride, pad=cfg.pad, mode=1, in_act=ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0,
+                         out_act=ACT_NONE, d2s=0)
+            kname = ""
+            if _prof["on"]:
+                buf = ctypes.create_string_buffer(96)
+                _call("vunet_conv2d_gather_variant", ctypes.byref(d), 0, buf, 96)
+                kname = buf.value.decode().replace(", 1, 0, ", ", 1, 4, ")
+            with _Timed(("conv_gather_dgrad", n, cout, 0, ho, wo, c1, k, cfg.stride, 0, kname),
+                        2.0 * n * ho * wo * cout * c1 * k * k):
+                rc = _lib.lib().vunet_conv2d_dgrad_relu(ctypes.byref(d), _p(dy), _p(y), _p(wt_d), _p(dy if cfg.res_is_x1 else None),
+                                                        _p(dx), _stream())
+            if rc == 0:
+                return dx, None, dres, None, None, None, None, None, None
+            if rc != -3:   # anything but VUNET_ERR_UNSUPPORTED is an error; unsupported geometries take the two-pass route
+                raise RuntimeError(f"vunet_conv2d_dgrad_relu failed with code {rc}")
+            if _prof["on"] and _prof["recs"]:
+                _prof["recs"].pop()
         dconv = dy
         if cfg.out_act != ACT_NONE:
             dconv = torch.empty_like(dy)
@@ -586,7 +609,6 @@ class FusedConv(torch.autograd.Function):
             t = torch.empty(n, cout, ho, wo, device=dy.device, dtype=torch.float32)
             _call("vunet_space_to_depth", _p(dconv), _p(t), n, cout // 4, 2 * ho, 2 * wo, _stream())
             dconv = t
-        k = cfg.k
         dv = dg = dbias = dgamma = dbeta = None
 
         def weight_gradients():

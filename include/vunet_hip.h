@@ -75,6 +75,13 @@ typedef struct vunet_conv_desc {
 int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
                         const float* shift, const float* res, const float* aux, float* y, void* stream);
 
+/* Data gradient through a layer whose forward epilogue was ReLU (the VGG19 stack, models/imagenet_pretrained.py:
+ * autograd's relu backward + conv backward):  dx = dgrad(dy * [y > 0]) + res, the mask applied while dy is staged.
+ * d as for vunet_conv2d_gather mode 1 (C1 = channels of dy / y, M = channels of dx, wt = wt_d).  Geometries the
+ * LDS-tiled kernel does not cover return VUNET_ERR_UNSUPPORTED (use vunet_act_bwd_from_out + vunet_conv2d_gather). */
+int vunet_conv2d_dgrad_relu(const vunet_conv_desc* d, const float* dy, const float* y, const float* wt,
+                            const float* res, float* dx, void* stream);
+
 /* Name (as rocprofv3 prints it) of the kernel vunet_conv2d_gather selects for this problem; has_aux: the
  * call passes an aux tensor.  For profiling / roofline bookkeeping only. */
 int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char* name, int32_t len);
