@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_thin_m_kernel(const GatherArgs a) {
 
 // ---- CI (= 3: RGB) input channels, 3x3 pad 1 (KS 3) or 1x1 (KS 1), stride 1, forward ----------------------------
 template <int KS, int CI>
-__global__ __launch_bounds__(256, 4) void conv_thin_k_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const GatherArgs a) {
   constexpr int T = KS * KS;
   const vunet_conv_desc& d = a.d;
   const int H = d.Hs, W = d.Ws, HW = a.HsWs;
@@ -146,8 +146,8 @@ int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool h
     return 0;
   const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
   if (k3 && d->M <= 4 && d->C1 >= 8) return 1;
-  // (the 3x3 form of thin_k is instantiated but not dispatched: hipcc spills ~120 VGPRs around its 27-row weight walk)
-  if (k1 && d->C1 == 3 && d->mode == 0 && d->M <= 128 && !has_res &&
+  // (the 3x3 form runs at two waves per SIMD: hipcc keeps all 27 weight rows of a pass in flight, ~250 VGPRs)
+  if ((k1 || k3) && d->C1 == 3 && d->mode == 0 && d->M <= 128 && !has_res &&
       (d->out_act == ACT_NONE || d->out_act == ACT_RELU))
     return 2;
   return 0;

@@ -186,3 +186,4 @@ def test_kernel_selection_of_the_gather_entry_point():
     # three channels on one side: VALU kernels
     assert variant(C1=32, M=3, Mpad=32, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_m_kernel<0>"
     assert variant(C1=3, M=32, Mpad=32, KH=1, KW=1, pad=0, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_k_kernel<1, 3>"
+    assert variant(C1=3, M=64, Mpad=64, Hs=256, Ws=256, Ho=256, Wo=256, out_act=ops.ACT_RELU) == "conv_thin_k_kernel<3, 3>"
