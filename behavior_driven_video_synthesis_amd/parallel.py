@@ -30,6 +30,7 @@ class BucketedGradAverager:
         self._expected: List[Optional[int]] = [None] * len(self.buckets)  # learnt on the first step
         self._fired: List[int] = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._fired_at_launch = [0] * len(self.buckets)
         if self.active:
             from . import ops
             self._bucket_of = {}
@@ -57,6 +58,7 @@ class BucketedGradAverager:
         if self._launched[bi]:
             return
         self._launched[bi] = True
+        self._fired_at_launch[bi] = self._fired[bi]
         b = self.buckets[bi]
         if b.grad.is_cuda:
             from . import ops
@@ -78,8 +80,13 @@ class BucketedGradAverager:
         if not self.active:
             return extra_scalars
         for bi in range(len(self.buckets)):
-            if self._expected[bi] is None:
-                self._expected[bi] = self._fired[bi]
+            if self._launched[bi] and self._fired[bi] != self._fired_at_launch[bi]:
+                # a gradient landed after the bucket's all-reduce had been launched from the hooks: the firing pattern
+                # of backward changed between steps and the reduced values are incomplete -- never continue silently
+                raise RuntimeError(f"bucket {self.buckets[bi].name!r}: {self._fired[bi]} gradient writes this step, its "
+                                   f"all-reduce was launched after {self._fired_at_launch[bi]} (pattern learnt earlier); "
+                                   "construct the averager with overlap=False for graphs that change between steps")
+            self._expected[bi] = self._fired[bi]   # learnt on the first step, re-learnt if backward fired fewer hooks
             self._launch(bi)
         if extra_scalars is not None:
             self._works.append(dist.all_reduce(extra_scalars, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
