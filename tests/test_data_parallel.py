@@ -59,8 +59,22 @@ def _worker(rank, world, port, q):
     full = ((ref(x_all) - y_all) ** 2).mean()
     full.backward()
     err = max(float((p.grad - r.grad).abs().max()) for p, r in zip(net.parameters(), ref.parameters()))
+    # a step whose backward fires MORE gradient writes than the learnt pattern (two backward passes): the hooks launch
+    # the all-reduce after the first pass, the second pass lands late -- finish() has to refuse, not average half a gradient
+    avg.start_step()
+    for b in buckets:
+        b.zero_grad()
+    (((net(xs) - ys) ** 2).mean() * 0.5).backward()
+    (((net(xs) - ys) ** 2).mean() * 0.5).backward()
+    try:
+        avg.finish()
+        refused = False
+    except RuntimeError:
+        refused = True
+    for w in avg._works:
+        w.wait()
     q.put((rank, err, float(kl), float(full), launched_early, float(dead.grad.abs().sum()),
-           [float(p.detach().sum()) for p in net.parameters()]))
+           [float(p.detach().sum()) for p in net.parameters()], refused))
     dist.destroy_process_group()
 
 
@@ -76,12 +90,13 @@ def test_two_rank_gradient_average_equals_full_batch_gradient():
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    for rank, err, kl, full, launched, dead_grad, sums in res:
+    for rank, err, kl, full, launched, dead_grad, sums, refused in res:
         assert err < 1e-6, (rank, err)
         assert abs(kl - full) < 1e-6          # scalar averaged over ranks == full-batch mean loss
         assert dead_grad == 0.0
         assert launched[0] == [False, False]  # first step: firing pattern unknown, everything flushed in finish()
         assert launched[2][0] is True         # later steps: the bucket of the last layer is launched from backward
+        assert refused                        # a changed firing pattern is an error, never a silently partial average
     assert res[0][6] == res[1][6]             # replicas identical after broadcast
 
 
