@@ -293,3 +293,29 @@ def test_bf16_inference_conv_vs_rounded_operand_reference(case):
     # fp32 accumulation order; with ELU a few inputs may round to the neighbouring bf16 value (fast-exp ulps)
     tol = 2e-3 if in_act else 2e-5
     assert_close(y, ref.float(), rtol=tol, atol=tol * float(ref.abs().max()), name="bf16 conv")
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, H,  W, k, stride  -- frozen conv + ReLU; dx through vunet_conv2d_dgrad_relu where the tiled kernel applies
+    (16, 64, 64, 64, 64, 3, 1),      # 16-row tiles
+    (16, 32, 128, 32, 32, 3, 1),     # 8-row tiles
+    (4, 64, 96, 16, 32, 3, 1),       # 4-row tiles, ragged M
+    (16, 64, 64, 16, 16, 3, 1),      # 16-wide maps (two row segments per MFMA tile)
+    (2, 16, 24, 12, 20, 3, 1),       # geometry the tiled kernel does not take: two-pass route
+    (3, 32, 32, 32, 32, 1, 1),       # 1x1: two-pass route
+], ids=lambda c: "-".join(map(str, c)))
+def test_relu_data_gradient_of_frozen_layers_vs_autograd(case):
+    import torch.nn.functional as F
+    from behavior_driven_video_synthesis_amd import ops
+    n, cin, cout, h, w, k, stride = case
+    x = seeded_randn("rd.x", (n, cin, h, w), 2)
+    v = seeded_randn("rd.v", (cout, cin, k, k), 2) * (1.0 / (cin * k * k) ** 0.5)
+    b = seeded_randn("rd.b", (cout,), 2) * 0.1
+    wgt = seeded_randn("rd.w", (n, cout, (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1), 2)
+    xr = x.clone().requires_grad_(True)
+    (F.relu(F.conv2d(xr, v, b, stride=stride, padding=k // 2)) * wgt).sum().backward()
+    xd = x.clone().cuda().requires_grad_(True)
+    cfg = ops.ConvCfg(kind=1, k=k, stride=stride, pad=k // 2, out_act=ops.ACT_RELU)
+    y = ops.fused_conv(xd, None, None, v.cuda(), None, b.cuda(), None, None, cfg)   # weights do not require grad: frozen
+    (y * wgt.cuda()).sum().backward()
+    assert_close(xd.grad, xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()), name="dx")
