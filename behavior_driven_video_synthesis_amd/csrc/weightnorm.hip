@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
   __syncthreads();
   const float D = red[0] + red[1] + red[2] + red[3];
   const float dsh = a.dsred[co];
-  const float acc = a.accumulate ? 1.f : 0.f;
+  // non-accumulate outputs may be uninitialised memory (torch.empty): select, never `0 * old` (0 * NaN = NaN)
+#define WN_OLD(ptr) (a.accumulate ? (ptr)[co] : 0.f)
 
   const int kind = a.d.kind;
   const float invn = kind == 1 ? 1.f : a.invnorm[co];
@@ -257,12 +258,12 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
   const float b = a.bias ? a.bias[co] : 0.f;
   if (tid == 0) {
     if (kind == 1) {
-      if (a.dbias) a.dbias[co] = acc * a.dbias[co] + dsh;
+      if (a.dbias) a.dbias[co] = WN_OLD(a.dbias) + dsh;
     } else {
-      if (a.dgamma) a.dgamma[co] = acc * a.dgamma[co] + gg * invn * D + b * dsh;
-      if (a.dbeta) a.dbeta[co] = acc * a.dbeta[co] + dsh;
-      if (a.dbias) a.dbias[co] = acc * a.dbias[co] + gm * dsh;
-      if (a.dg && kind == 0) a.dg[co] = acc * a.dg[co] + gm * invn * D;
+      if (a.dgamma) a.dgamma[co] = WN_OLD(a.dgamma) + (gg * invn * D + b * dsh);
+      if (a.dbeta) a.dbeta[co] = WN_OLD(a.dbeta) + dsh;
+      if (a.dbias) a.dbias[co] = WN_OLD(a.dbias) + gm * dsh;
+      if (a.dg && kind == 0) a.dg[co] = WN_OLD(a.dg) + gm * invn * D;
     }
   }
   if (a.dv) {
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
       dvr[k] = a.accumulate ? dvr[k] + val : val;
     }
   }
+#undef WN_OLD
 }
 
 extern "C" int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float* dshift, int32_t nsplit,

@@ -45,7 +45,20 @@ def save_ckpt(directory: str, key: str, iteration: int, trainer, n_saved: int = 
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, f"{key}_checkpoint_{int(iteration)}.pth")
     sd = trainer.state_dict()
-    torch.save({"model": {k: v.detach().cpu() for k, v in sd["model"].items()}, "optimizer": sd["optimizer"]}, path)
+
+    def host(o):
+        if isinstance(o, torch.Tensor):
+            return o.detach().cpu()
+        if isinstance(o, dict):
+            return {k: host(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(host(v) for v in o)
+        return o
+    out = {"model": host(sd["model"]), "optimizer": host(sd["optimizer"])}
+    for extra in ("regressor", "discriminator"):   # the reference's second checkpoint file / DiscTrainer's own dict
+        if extra in sd:
+            out[extra] = host(sd[extra])
+    torch.save(out, path)
     mine = sorted((p for p in glob.glob(os.path.join(directory, f"{key}_checkpoint_*.pth"))),
                   key=lambda p: float(os.path.basename(p).rsplit("_", 1)[-1].split(".")[0]))
     for old in mine[:-n_saved]:

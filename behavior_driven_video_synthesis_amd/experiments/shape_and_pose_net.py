@@ -56,7 +56,7 @@ DEFAULT_CONFIG = {
 class ShapePoseNet:
     def __init__(self, config: Dict, device="cuda:0", n_channels_x: int = 3, n_keypoints: int = 17,
                  vgg_weights_path: Optional[str] = None, vgg_width_div: int = 1, total_steps: Optional[int] = None,
-                 process_group=None):
+                 process_group=None, vgg_synthetic: bool = False, vgg_seed: int = 1234):
         self.config = config
         self.device = torch.device(device)
         arch, data, tr = config["architecture"], config["data"], config["training"]
@@ -65,11 +65,15 @@ class ShapePoseNet:
         kw = dict(arch)
         kw.update(data)
         kw["dropout_prob"] = tr.get("dropout_prob", 0.0)
-        self.vunet = VunetAlter(n_channels_x=n_channels_x, **kw).to(self.device)
+        self.iteration = 0
+        # :199-206: the l2 conv variant initialises gamma / beta from batch statistics during the first batches
+        init_fn = (lambda: self.iteration <= tr["n_init_batches"]) if arch.get("conv_layer_type") == "l2" else None
+        self.vunet = VunetAlter(init_fn=init_fn, n_channels_x=n_channels_x, **kw).to(self.device)
         overlap = self.device.type == "cuda" and bool(tr.get("two_streams", os.environ.get("VUNET_TWO_STREAMS", "1") != "0"))
         self.vunet.enable_two_streams(overlap)   # pose encoder (du) beside appearance encoder (eu, ed)
         ops.enable_wgrad_streams(overlap)        # weight gradients beside the data-gradient chain (process-wide switch)
-        self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div).to(self.device)
+        self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div, seed=vgg_seed,
+                         synthetic=vgg_synthetic).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)
         # ---- optimiser (:237-246)
@@ -114,7 +118,6 @@ class ShapePoseNet:
         for pg in self.optimizer.param_groups:
             pg["lr"] = self.lr
         self.gamma = torch.zeros((), device=self.device, dtype=torch.float32)  # device-resident controller state
-        self.iteration = 0
         print(f"Number of trainable params is {n_parameters(self.vunet)}")
 
     # ---- schedules
@@ -135,7 +138,9 @@ class ShapePoseNet:
             pg["gamma"] = self.gamma
 
     # ---- one training step (:360-466)
-    def train_fn(self, batch: Dict[str, torch.Tensor], eps=None) -> Dict[str, torch.Tensor]:
+    def train_fn(self, batch: Dict[str, torch.Tensor], eps=None, reg_eps=None) -> Dict[str, torch.Tensor]:
+        """``eps`` / ``reg_eps`` inject the Gaussian draws of the posterior sampling (one tensor per latent scale; for
+        the regressor side loop one such list per regressor step) -- the parity tests' hook, None in production."""
         tr = self.config["training"]
         self.vunet.train()
         self.iteration += 1
@@ -147,9 +152,9 @@ class ShapePoseNet:
         self.averager.start_step()
         self.optimizer.zero_grad()
         with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
-            return self._step(batch, it, target_img, shape_img, pose_img, eps)
+            return self._step(batch, it, target_img, shape_img, pose_img, eps, reg_eps)
 
-    def _step(self, batch, it, target_img, shape_img, pose_img, eps):
+    def _step(self, batch, it, target_img, shape_img, pose_img, eps, reg_eps=None):
         tr = self.config["training"]
         out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
         ld = vgg_loss(self.custom_vgg, target_img, out_img)
@@ -162,7 +167,7 @@ class ShapePoseNet:
             loss = loss + tuning * kl
         out = {}
         if self.train_regressor and "reg_imgs" in batch:
-            loss_regressor = self._regressor_steps(batch)
+            loss_regressor = self._regressor_steps(batch, reg_eps)
             # pure scalar offset: no gradient path to the VUnet (:413 runs under no_grad)
             loss = loss - torch.clamp(loss_regressor.detach(), max=1.2) * tr["weight_regressor"]
             out["loss_reg"] = loss_regressor.detach()
@@ -192,7 +197,7 @@ class ShapePoseNet:
         out.update({k: v.detach() for k, v in ld.items()})
         return out
 
-    def _regressor_steps(self, batch):
+    def _regressor_steps(self, batch, reg_eps=None):
         """:407-425.  The reference runs ``ed(eu(reg_imgs[:, i]))`` inside the loop; the encoder is frozen there
         (``no_grad``, no VUnet update until the outer step), so the ``reg_steps`` encoder passes do not depend on the
         regressor updates between them and run here as ONE batch of ``B * reg_steps`` samples -- the same per-sample
@@ -201,7 +206,9 @@ class ShapePoseNet:
         b, steps = reg_imgs.shape[:2]
         with torch.no_grad():
             flat = reg_imgs.transpose(0, 1).reshape(steps * b, *reg_imgs.shape[2:]).contiguous()   # step-major
-            _, means_all, _, _ = self.vunet.ed(self.vunet.eu(flat))
+            eps_all = None if reg_eps is None else [torch.cat([e[s_] for e in reg_eps], dim=0)
+                                                     for s_ in range(len(reg_eps[0]))]
+            _, means_all, _, _ = self.vunet.ed(self.vunet.eu(flat), eps_all)
         loss_regressor = None
         for i in range(steps):
             means = [m[i * b:(i + 1) * b] for m in means_all]
@@ -220,20 +227,41 @@ class ShapePoseNet:
         with ops.inference_precision(dtype):
             return self.vunet.transfer(app_img, stickman)
 
-    # ---- checkpoint layout of :474-482
+    # ---- checkpoint layout of :471-494: {"model", "optimizer"} (the "reg_ckpt" file); the regressor and its optimiser
+    # form the reference's second file ("regressor"), here the "regressor" entry of the same dict
     def state_dict(self):
-        sd = {"model": self.vunet.state_dict(), "optimizer": self.optimizer.state_dict()}
+        opt = self.optimizer.state_dict()
+        gamma = float(self.gamma)   # the reference keeps gamma as a host number in every param group (:507-512)
+        for g in opt["param_groups"]:
+            g["gamma"] = gamma
+        sd = {"model": self.vunet.state_dict(), "optimizer": opt}
+        if self.train_regressor:
+            sd["regressor"] = {"model": self.regressor.state_dict(), "optimizer": self.optimizer_regressor.state_dict()}
         if self.gan is not None:   # DiscTrainer's own save dict (models/synth_discriminator.py:228-231) rides along
             sd["discriminator"] = self.gan.checkpoint()
         return sd
 
     def load_state_dict(self, ckpt):
+        """Restart as :87-95, :248-255 do: weights, Adam state, the iteration from Adam's step count, gamma from the
+        optimiser's param groups, then the lr / imax schedules re-derived for that iteration."""
         self.vunet.load_state_dict(ckpt["model"])
         if "optimizer" in ckpt and ckpt["optimizer"] is not None:
-            self.optimizer.load_state_dict(ckpt["optimizer"])
-            states = list(ckpt["optimizer"]["state"].values())
+            op = ckpt["optimizer"]
+            gamma = None
+            for g in op["param_groups"]:
+                if "gamma" in g:
+                    gamma = g["gamma"]
+            self.optimizer.load_state_dict(op)
+            states = list(op["state"].values())
             if states:
                 self.iteration = int(states[-1]["step"])  # :248-255
+            if gamma is not None:
+                self.gamma = torch.as_tensor(float(gamma), dtype=torch.float32, device=self.device).reshape(())
+            self.adjust_params(self.iteration)
+        if self.train_regressor and ckpt.get("regressor") is not None:
+            self.regressor.load_state_dict(ckpt["regressor"]["model"])
+            if ckpt["regressor"].get("optimizer") is not None:
+                self.optimizer_regressor.load_state_dict(ckpt["regressor"]["optimizer"])
         if self.gan is not None and "discriminator" in ckpt:
             self.gan.disc.load_state_dict(ckpt["discriminator"]["disc"])
             self.gan.opt.load_state_dict(ckpt["discriminator"]["opt"])

@@ -156,11 +156,14 @@ class L2NormConv2d(nn.Module):
                 y0 = ops.fused_conv(x1, x2, None, self.weight, None, self.bias, ones, zeros, cfg0)
                 mean = y0.mean(dim=[0, 2, 3], keepdim=True)
                 var = y0.var(dim=[0, 2, 3], keepdim=True)
-                self.gamma.data = 1.0 / torch.sqrt(var + 1e-10)
-                self.beta.data = -mean * self.gamma
+                # in place: gamma / beta may be views of a flat optimiser bucket (optim.FlatBucket) -- rebinding .data
+                # would detach them from the buffer Adam updates and from the prepacked pointer table
+                self.gamma.data.copy_(1.0 / torch.sqrt(var + 1e-10))
+                self.beta.data.copy_(-mean * self.gamma)
+                ops.invalidate_active_prepack(self)
         cfg = ops.ConvCfg(kind=2, k=self.k, stride=self.stride, pad=self.padding, in_act=in_act, in_slope=in_slope,
                           drop_p=drop_p, drop_seed=ops.next_dropout_seed() if drop_p > 0 else 0, out_act=out_act,
-                          d2s=d2s)
+                          d2s=d2s, owner=self)
         v, g, b, gamma, beta = self._params()
         return ops.fused_conv(x1, x2, res, v, g, b, gamma, beta, cfg)
 

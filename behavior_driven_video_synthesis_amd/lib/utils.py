@@ -29,8 +29,9 @@ def linear_var(act_it, start_it, end_it, start_val, end_val, clip_min, clip_max)
 
 
 def scale_img(x):
-    """lib/utils.py:658-668: [-1,1] -> [0,1]."""
-    return (x + 1.0) / 2.0
+    """lib/utils.py:658-668: [-1,1] -> [0,1], clamped (:666-667) -- VunetAlter's out_conv has no tanh."""
+    import torch
+    return torch.clamp((x + 1.0) / 2.0, 0.0, 1.0)
 
 
 # ------------------------------------------------------------------------------------------------

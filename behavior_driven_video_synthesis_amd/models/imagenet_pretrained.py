@@ -55,12 +55,20 @@ class VGG19(nn.Module):
         return self
 
 
-def vgg19(pretrained: bool = False, weights_path: str = None, width_div: int = 1, seed: int = 1234) -> VGG19:
+def vgg19(pretrained: bool = False, weights_path: str = None, width_div: int = 1, seed: int = 1234,
+          synthetic: bool = False) -> VGG19:
     """Stand-in for ``torchvision.models.vgg19(pretrained=True)`` (experiments/shape_and_pose_net.py:222).
 
     ``weights_path``: a torchvision vgg19 state dict (``features.N.weight``...; classifier keys ignored).
-    Without it the weights are seeded-synthetic (stated as such by bench.py / DESIGN.md).
+    Without it the weights are seeded-synthetic (stated as such by bench.py / DESIGN.md); asking for
+    ``pretrained=True`` without a path warns unless the caller says ``synthetic=True`` -- a perceptual loss on a
+    random VGG19 is a benchmark / test workload, not the reference's loss.
     """
+    if pretrained and weights_path is None and not synthetic:
+        import warnings
+        warnings.warn("vgg19(pretrained=True) without weights_path: torchvision's weights cannot be fetched here, "
+                      "using SEEDED-SYNTHETIC VGG19 weights (pass weights_path=<torchvision vgg19 state dict>, or "
+                      "synthetic=True to silence this)", stacklevel=2)
     net = VGG19(width_div)
     if weights_path is not None:
         sd = torch.load(weights_path, map_location="cpu")

@@ -476,6 +476,12 @@ def _build_prepack_set(model):
     return cur
 
 
+def invalidate_active_prepack(module):
+    """Parameters of ``module`` changed inside a ``prepacked`` block (L2NormConv2d's data-dependent init): its
+    calls fall back to packing on the spot until the next block repacks."""
+    _active_prepack.pop(id(module), None)
+
+
 class prepacked:
     """``with ops.prepacked(model):`` -- pack the weights of every already-seen conv layer of ``model`` in two
     launches and let the fused convs inside the block use them.  The caller guarantees that parameters do not
@@ -701,6 +707,9 @@ class FusedConv(torch.autograd.Function):
 
 
 def fused_conv(x1, x2, res, v, g, bias, gamma, beta, cfg: ConvCfg):
+    # backward treats the saved output as the activation's output: a residual added after an output activation
+    # would corrupt it (no model on the path does this)
+    assert res is None or cfg.out_act == ACT_NONE, "fused_conv: residual together with an output activation"
     if res is not None and res is x1 and not cfg.d2s and cfg.out_act == ACT_NONE:
         cfg.res_is_x1 = True
     cfg.bf16 = _inference_bf16 and not torch.is_grad_enabled()   # grad mode of the CALLER (forward() never records)

@@ -119,7 +119,7 @@ def main():
     cfg = make_config(args)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # the constructors print like the reference does; stdout is for the JSON line
-        trainer = ShapePoseNet(cfg, device=device, total_steps=150000)
+        trainer = ShapePoseNet(cfg, device=device, total_steps=150000, vgg_synthetic=True)
     batch = synthetic_batch(args.batch, args.size, device, seed=42, with_regressor=args.regressor, rank=rank)
 
     def sync_all():

@@ -493,3 +493,25 @@ def train_step_losses(sd: SD, cfg: dict, vgg_sd: SD, vgg_weights, x: Tensor, c: 
     if iteration > n_init_batches:
         loss = loss + gamma * kl
     return loss, ll, kl, img
+
+
+def regressor_side_loop(sd: SD, cfg: dict, reg_sd: SD, opt_reg, reg_imgs: Tensor, reg_targets: Tensor,
+                        reg_eps: Optional[Sequence[Sequence[Tensor]]] = None) -> Tuple[Tensor, List[float]]:
+    """The regressor side loop of train_fn (experiments/shape_and_pose_net.py:407-425): for every i in
+    ``reg_imgs.shape[1]`` the frozen encoder ``ed(eu(reg_imgs[:, i]))`` (no_grad, :413), the regressor on its means,
+    the L2-norm loss (:417-419) and one step of the regressor's own Adam (:420-422).  Returns the LAST step's loss
+    (the one the caller clamps at 1.2 and scales by ``weight_regressor``, :424-425) and every step's value."""
+    d = vunet_dims(cfg)
+    values, loss_regressor = [], None
+    for i in range(reg_imgs.shape[1]):
+        with torch.no_grad():
+            hs = enc_up(sd, "eu", reg_imgs[:, i], d["n_scales_x"])
+            _, means, _, _ = enc_down_alter(sd, "ed", hs, d["n_latent_scales"], None if reg_eps is None else reg_eps[i])
+        preds = regressor(reg_sd, means)
+        tgts = reg_targets[:, i].reshape(reg_targets.shape[0], -1)
+        loss_regressor = torch.norm(preds - tgts, dim=1).mean()
+        opt_reg.zero_grad()
+        loss_regressor.backward()
+        opt_reg.step()
+        values.append(float(loss_regressor))
+    return loss_regressor.detach(), values

@@ -386,11 +386,138 @@ def g5_trajectory():
     save("g5_trajectory", meta, {"final.dd.out_conv.conv.weight_v": net.state_dict()["dd.out_conv.conv.weight_v"].numpy()})
 
 
+# ---------------------------------------------------------------- G5b trajectory with the regressor side loop on
+def g5_regressor_trajectory():
+    """experiments/shape_and_pose_net.py:360-466 with ``train_regressor: True`` driven by hand on the reference's
+    modules: per outer step, reg_steps regressor Adam(lr 1e-3) steps on ``ed(eu(reg_imgs[:, i]))`` under no_grad
+    (:407-425), then ``loss -= clamp(loss_regressor, max=1.2) * weight_regressor`` (:423-425)."""
+    from oracle.vunet_oracle import make_synthetic_vgg19
+    seed, K, R = 53, 3, 5
+    cfg = dict(ALTER_CFG)
+    net = rv.VunetAlter(n_channels_x=3, **cfg)
+    sh = load_synth(net, seed)
+    reg = rv.Regressor(n_out=34, n_latent_scales=2, nf_max=16, latent_widths=[8, 4], linear_width_factor=1)
+    rsh = load_synth(reg, seed + 1)
+    vsd = make_synthetic_vgg19(seed=77, width_div=8)
+    pv = rp.PerceptualVGG(build_vgg_features(vsd), [1.0] * 6)
+    pv.eval()
+    lr0, betas, gamma_step, imax, n_init, total_steps, w_reg = 5e-4, (0.5, 0.9), 1e-5, 1000.0, 1, 100, 4.0
+    opt = torch.optim.Adam([{"params": getattr(net, n).parameters(), "name": n} for n in ["eu", "ed", "du", "dd"]],
+                           lr=lr0, betas=betas)
+    opt_reg = torch.optim.Adam(reg.parameters(), lr=0.001)
+    gamma, lr = 0.5, lr0
+    rec = []
+    net.train()
+    for it in range(1, K + 1):
+        x = synth_image(f"rtraj.x{it}", (2, 3, 32, 32), seed)
+        c = synth_image(f"rtraj.c{it}", (2, 3, 32, 32), seed)
+        reg_imgs = synth_image(f"rtraj.r{it}", (2, R, 3, 32, 32), seed)
+        reg_targets = seeded_randn(f"rtraj.t{it}", (2, R, 17, 2), seed) * 0.25 + 0.5
+        with FixedNoise(f"rtraj.{it}", seed):
+            img, means, logstds, _ = net(x, c)
+        ld = rl.vgg_loss(pv, x, img)
+        ll = 1.0 * torch.sum(torch.stack([ld[k] for k in ld], dim=0))
+        kl = rl.compute_kl_with_prior(means, logstds)
+        loss = ll
+        if it > n_init:
+            loss = loss + torch.tensor(gamma) * kl
+        reg_losses = []
+        for i in range(R):
+            with torch.no_grad():
+                with FixedNoise(f"rtraj.{it}.reg{i}", seed):
+                    _, rmeans, _, _ = net.ed(net.eu(reg_imgs[:, i]))
+            preds = reg(rmeans)
+            tgts = reg_targets[:, i].reshape(reg_targets[:, i].shape[0], -1)
+            loss_regressor = torch.norm(preds - tgts, dim=1).mean()
+            opt_reg.zero_grad()
+            loss_regressor.backward(retain_graph=True)
+            opt_reg.step()
+            reg_losses.append(float(loss_regressor))
+        # the reference subtracts the un-detached regressor loss; on torch >= 1.5 backward() then raises (the
+        # regressor weights were stepped in place), on its own torch 1.3.1 it only produced regressor gradients that
+        # the next zero_grad() discards.  No gradient reaches the VUnet either way (:413 runs under no_grad): detached,
+        # the recorded values are the same.
+        loss = loss - torch.clamp(loss_regressor.detach(), max=1.2) * w_reg
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        gamma = max(gamma - gamma_step * (imax - float(kl)), 0)
+        rec.append({"it": it, "loss": float(loss), "ll": float(ll), "kl": float(kl), "gamma_after": gamma, "lr": lr,
+                    "reg_losses": reg_losses})
+        lr = float(np.clip(float(0 - lr0) / (total_steps - 0) * (it - 0) + lr0, 0, lr0))
+        for pg_ in opt.param_groups:
+            pg_["lr"] = lr
+    csum = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in net.state_dict().items()}
+    rsum = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in reg.state_dict().items()}
+    meta = {"seed": seed, "cfg": cfg, "shapes": sh, "reg_shapes": rsh, "reg_seed": seed + 1, "vgg_seed": 77,
+            "vgg_width_div": 8, "K": K, "reg_steps": R, "lr0": lr0, "betas": list(betas), "gamma0": 0.5,
+            "gamma_step": gamma_step, "imax": imax, "n_init_batches": n_init, "total_steps": total_steps,
+            "weight_regressor": w_reg, "steps": rec, "param_checksums": csum, "reg_checksums": rsum}
+    save("g5_regressor_trajectory", meta,
+         {"final.dd.out_conv.conv.weight_v": net.state_dict()["dd.out_conv.conv.weight_v"].numpy(),
+          "final.reg.linears.1.weight": reg.state_dict()["linears.1.weight"].numpy()})
+
+
+# ---------------------------------------------------------------- G6 full-size sanity (statistics + crops, no full tensors)
+FULL_CFGS = {
+    # BASELINE config 2: Human3.6m, 256^2 (config/shape_and_pose_net.yaml:8-37)
+    "h36m256": (dict(spatial_size=256, bottleneck_factor=2, box_factor=2, n_scales=0, n_latent_scales=2,
+                     conv_layer_type="l1", nf_start=32, nf_max=128, subpixel_upsampling=True, dropout_prob=0.0),
+                3, (2, 3, 256, 256), (2, 3, 256, 256)),
+    # BASELINE config 1: Market, 128^2, 30-channel 64x64 appearance input (README.md:103-110, data/market.py:45)
+    "market128": (dict(spatial_size=128, bottleneck_factor=1, box_factor=1, n_scales=0, n_latent_scales=2,
+                       conv_layer_type="l1", nf_start=32, nf_max=128, subpixel_upsampling=True, dropout_prob=0.0),
+                  30, (2, 30, 64, 64), (2, 3, 128, 128)),
+}
+FULL_GRAD_KEYS = ["eu.nin.conv.weight_v", "eu.blocks.0.conv.conv.weight_v", "eu.downs.0.down.conv.weight_v",
+                  "ed.make_logstds.1.conv.weight_g", "ed.blocks.1.nin.conv.weight_v", "du.blocks.3.conv.gamma",
+                  "dd.ups.0.up.conv.weight_v", "dd.blocks.11.conv.conv.weight_v", "dd.auto_blocks.1.conv.beta",
+                  "dd.out_conv.conv.weight_v", "dd.out_conv.conv.bias"]
+
+
+def g6_full_size():
+    seed = 61
+    for tag, (cfg, ncx, xshape, cshape) in FULL_CFGS.items():
+        net = rv.VunetAlter(n_channels_x=ncx, **cfg)
+        sh = load_synth(net, seed)
+        net.train()
+        x, c = synth_image(tag + ".x", xshape, seed), synth_image(tag + ".c", cshape, seed)
+        with FixedNoise(tag, seed) as fn:
+            img, means, logstds, _ = net(x, c)
+        wgt = seeded_randn(tag + ".w", tuple(img.shape), seed)
+        (img * wgt).sum().backward()
+        params = dict(net.named_parameters())
+        keys = [k for k in FULL_GRAD_KEYS if k in params]
+        arrays = {"img_crop": img.detach()[:, :, 40:56, 72:88].numpy(),
+                  "img_sum": img.detach().double().sum(dim=(2, 3)).numpy(),
+                  "img_abssum": img.detach().double().abs().sum(dim=(2, 3)).numpy(),
+                  "img_max": img.detach().amax(dim=(2, 3)).numpy(), "img_min": img.detach().amin(dim=(2, 3)).numpy()}
+        for i, (m, l) in enumerate(zip(means, logstds)):
+            arrays[f"mean{i}_sum"] = m.detach().double().sum(dim=(2, 3)).numpy()
+            arrays[f"logstd{i}_sum"] = l.detach().double().sum(dim=(2, 3)).numpy()
+        for k in keys:
+            g = params[k].grad
+            arrays["gp." + k] = g.reshape(-1)[:4096].numpy()
+        gsum = {k: (None if p.grad is None else [float(p.grad.double().sum()), float(p.grad.double().abs().sum()),
+                                                 float(p.grad.abs().max())]) for k, p in params.items()}
+        meta = {"seed": seed, "cfg": cfg, "n_channels_x": ncx, "x": list(xshape), "c": list(cshape),
+                "eps_shapes": fn.shapes, "n_params": sum(p.numel() for p in net.parameters()), "n_keys": len(sh),
+                "crop": [40, 56, 72, 88], "grad_sums": gsum}
+        save("g6_" + tag, meta, arrays)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    only = sys.argv[1:]
+    if only:   # e.g. `make_golden.py g6_full_size` regenerates one group
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     g1_primitives()
     g2_models()
     g3_losses()
     g4_discriminators()
     g5_trajectory()
+    g5_regressor_trajectory()
+    g6_full_size()

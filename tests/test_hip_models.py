@@ -315,3 +315,46 @@ def test_disc_trainer_step_vs_golden():
     gl, wgt = tr.get_genloss(fake, (fake - real).abs().mean(), gen.last.weight)
     assert_close(gl, arr["dt.gen_loss"], rtol=1e-3, atol=1e-5, name="gen_loss")
     assert_close(wgt, arr["dt.loss_weight"], rtol=2e-2, atol=1e-4, name="loss_weight")
+
+
+@pytest.mark.parametrize("tag", ["h36m256", "market128"])
+def test_full_size_vunet_vs_reference_fixture_and_oracle(tag):
+    """BASELINE config 2 (Human3.6m, 256^2, nf 32..128, 7 scales) and config 1 (Market, 128^2, 30-channel 64x64
+    appearance input, bottleneck_factor 1, box_factor 1; README.md:103-110) at bs 2: the HIP path against (i) the
+    statistics / crop / gradient slices recorded from the imported reference (G6) and (ii) the CPU oracle on every
+    output element (PSNR >= 100 dB) and every parameter gradient."""
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    from oracle import vunet_oracle as O
+    from test_oracle_golden import check_full_size
+    meta, arr = load_golden("g6_" + tag)
+    seed, cfg, ncx = meta["seed"], meta["cfg"], meta["n_channels_x"]
+    net = VunetAlter(n_channels_x=ncx, **cfg)
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert len(shapes) == meta["n_keys"] and sum(p.numel() for p in net.parameters()) == meta["n_params"]
+    sd = synth_state_dict(shapes, seed)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    x, c = synth_image(tag + ".x", tuple(meta["x"]), seed), synth_image(tag + ".c", tuple(meta["c"]), seed)
+    eps = [seeded_randn(f"{tag}.eps{i}", tuple(s), seed) for i, s in enumerate(meta["eps_shapes"])]
+    wgt = seeded_randn(tag + ".w", (x.shape[0], 3, cfg["spatial_size"], cfg["spatial_size"]), seed)
+    img, means, logstds, _ = net(x.cuda(), c.cuda(), [e.cuda() for e in eps])
+    (img * wgt.cuda()).sum().backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().cpu()) for k, p in net.named_parameters()}
+    check_full_size(meta, arr, img.detach().cpu(), [m.detach().cpu() for m in means],
+                    [l.detach().cpu() for l in logstds], grads)
+    # every element against the oracle
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    img_r, means_r, logstds_r, _ = O.vunet_alter_forward(sdr, cfg, x, c, eps, n_channels_x=ncx)
+    (img_r * wgt).sum().backward()
+    scale = float(img_r.abs().max())
+    assert_close(img, img_r, rtol=1e-4, atol=1e-4 * max(scale, 1.0), name="img")
+    assert psnr(img, img_r, peak=2 * scale) >= 100.0
+    for i in range(len(means)):
+        assert_close(means[i], means_r[i], rtol=1e-4, atol=1e-4, name=f"mean{i}")
+        assert_close(logstds[i], logstds_r[i], rtol=1e-4, atol=1e-4, name=f"logstd{i}")
+    for k, p in net.named_parameters():
+        gr = sdr[k].grad
+        if gr is None:
+            continue
+        tol = 2e-3 * float(gr.abs().max()) + 1e-6
+        assert_close(p.grad, gr, rtol=2e-3, atol=tol, name=k)

@@ -319,3 +319,59 @@ def test_relu_data_gradient_of_frozen_layers_vs_autograd(case):
     y = ops.fused_conv(xd, None, None, v.cuda(), None, b.cuda(), None, None, cfg)   # weights do not require grad: frozen
     (y * wgt.cuda()).sum().backward()
     assert_close(xd.grad, xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()), name="dx")
+
+
+def test_weightnorm_backward_ignores_stale_output_buffers():
+    """Non-accumulate mode must not read its output buffers: torch.empty blocks recycled by the caching allocator can
+    hold NaN / inf, and ``0 * NaN`` is NaN.  Pre-fill every gradient output with NaN and compare with zeros."""
+    import ctypes
+    from behavior_driven_video_synthesis_amd import ops
+    torch.manual_seed(3)
+    cout, cin, k, ns = 24, 10, 3, 3
+    K = cin * k * k
+    v = torch.randn(cout, cin, k, k, device="cuda")
+    g, bias = torch.rand(cout, 1, 1, 1, device="cuda") + 0.5, torch.randn(cout, device="cuda")
+    gamma = torch.rand(1, cout, 1, 1, device="cuda") + 0.5
+    slabs = torch.randn(ns * 32 * K + ns * 32, device="cuda")
+    dshift = slabs[ns * 32 * K:]
+    invnorm = 1.0 / v.flatten(1).norm(dim=1)
+
+    def run(fill):
+        outs = [torch.full_like(t, fill) for t in (v, g, bias, gamma, gamma)]
+        work = torch.empty(cout * (K + 1), device="cuda")
+        wn = ops.WnDesc(cout, cin, 0, k, k, 0)
+        ops._call("vunet_weightnorm_bwd", ctypes.byref(wn), ops._p(slabs), ops._p(dshift), ns, ops._p(v), ops._p(g),
+                  ops._p(bias), ops._p(gamma), ops._p(invnorm), *[ops._p(o) for o in outs], ops._p(work), 0, ops._stream())
+        return outs
+    a, b = run(float("nan")), run(0.0)
+    for x, y in zip(a, b):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
+def test_l2_data_dependent_init_keeps_parameters_in_the_optimizer_bucket():
+    """lib/modules.py:95-99 under FusedAdam: gamma / beta are views of the flat bucket; the init must write through them
+    (rebinding .data detached them -- Adam kept updating a slot the module no longer read)."""
+    from behavior_driven_video_synthesis_amd.lib.modules import L2NormConv2d
+    from behavior_driven_video_synthesis_amd.optim import FusedAdam
+    from oracle import vunet_oracle as O
+    flag = {"on": True}
+    conv = L2NormConv2d(6, 10, 3, padding=1, bias=False, init=lambda: flag["on"]).cuda().train()
+    opt = FusedAdam(list(conv.parameters()), lr=1e-2)
+    x = torch.randn(4, 6, 12, 12, device="cuda")
+    y = conv(x)
+    b = opt.buckets[0]
+    for p in (conv.gamma, conv.beta):
+        off = p.data_ptr() - b.flat.data_ptr()
+        assert 0 <= off < 4 * b.numel, "parameter left the flat bucket"
+    # the initialised layer normalises its output over (N, H, W): mean 0, variance 1 per channel
+    assert float(y.mean(dim=(0, 2, 3)).abs().max()) < 1e-4 and float((y.var(dim=(0, 2, 3)) - 1).abs().max()) < 1e-3
+    y0 = O.l2norm_conv({".weight": conv.weight.detach().cpu(), ".gamma": torch.ones(1, 10, 1, 1),
+                        ".beta": torch.zeros(1, 10, 1, 1)}, "", x.cpu(), 1, 1)
+    assert_close(conv.gamma.detach().cpu(), 1.0 / torch.sqrt(y0.var(dim=[0, 2, 3], keepdim=True) + 1e-10), rtol=1e-4,
+                 atol=1e-5, name="gamma init")
+    flag["on"] = False
+    g0 = conv.gamma.detach().clone()
+    conv(x).square().mean().backward()
+    opt.step()
+    assert not torch.equal(conv.gamma.detach(), g0)          # Adam's update is what the module reads
+    assert conv.gamma.data_ptr() - b.flat.data_ptr() < 4 * b.numel

@@ -23,7 +23,7 @@ def test_shape_pose_net_steps_checkpoint_and_gamma():
     from oracle import vunet_oracle as O
     cfg = _tiny(DEFAULT_CONFIG, n_init_batches=1, gamma_step=1e-3, information_max=5.0, train_regressor=True,
                 lr=2e-3)
-    tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50)
+    tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True)
     batch = synthetic_batch(4, 32, "cuda:0", with_regressor=True, reg_steps=2)
     gamma, losses = 0.0, []
     for it in range(1, 7):
@@ -35,13 +35,30 @@ def test_shape_pose_net_steps_checkpoint_and_gamma():
         assert "loss_reg" in out
     assert losses[-1] < losses[0]
     ckpt = tr.state_dict()
-    assert set(ckpt) == {"model", "optimizer"} and len(ckpt["model"]) == len(tr.vunet.state_dict())
+    # {"model", "optimizer"} = the reference's "reg_ckpt" file (:471-482); "regressor" = its second file (:483-494)
+    assert set(ckpt) == {"model", "optimizer", "regressor"} and len(ckpt["model"]) == len(tr.vunet.state_dict())
     assert [g["name"] for g in ckpt["optimizer"]["param_groups"]] == ["eu", "ed", "du", "dd"]
-    tr2 = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50)
+    assert all(isinstance(g["gamma"], float) and g["gamma"] == float(tr.gamma) for g in ckpt["optimizer"]["param_groups"])
+    tr2 = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True)
     tr2.load_state_dict(ckpt)
-    assert tr2.iteration == 6
+    # restart as the reference does (:87-95, :248-255): iteration from Adam's step, gamma from the param groups, lr / imax
+    # re-derived -- the KL weight must not restart from 0
+    assert tr2.iteration == 6 and float(tr2.gamma) == float(tr.gamma) and float(tr.gamma) > 0
+    assert tr2.lr == tr.lr and tr2.imax == tr.imax
     for (k, a), (_, b) in zip(tr.vunet.state_dict().items(), tr2.vunet.state_dict().items()):
         assert torch.equal(a, b), k
+    for (k, a), (_, b) in zip(tr.regressor.state_dict().items(), tr2.regressor.state_dict().items()):
+        assert torch.equal(a, b), k
+    # the step after the restart is the step the uninterrupted run takes (same dropout seeds, same noise)
+    from behavior_driven_video_synthesis_amd import ops
+    eps = [torch.randn(4, 16, 4, 4, device="cuda"), torch.randn(4, 16, 8, 8, device="cuda")]
+    reg_eps = [[torch.randn(4, 16, 4, 4, device="cuda"), torch.randn(4, 16, 8, 8, device="cuda")] for _ in range(2)]
+    ops.set_dropout_seed(99)
+    o1 = tr.train_fn(batch, eps, reg_eps)
+    ops.set_dropout_seed(99)
+    o2 = tr2.train_fn(batch, eps, reg_eps)
+    for k in ("loss", "kl_loss", "gamma", "loss_reg"):
+        assert float(o1[k]) == float(o2[k]), k
     img = tr2.transfer(batch["pose_img"], batch["stickman"])
     assert img.shape == (4, 3, 32, 32) and torch.isfinite(img).all()
 
@@ -51,7 +68,7 @@ def test_vunet_org_loop_steps_and_kl_schedule():
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import synthetic_batch
     cfg = _tiny(DEFAULT_CONFIG, lr=2e-3)
     cfg["architecture"].update(nf_start=4, nf_max=8)
-    tr = Vunet(cfg, device="cuda:0", n_channels_x=3, vgg_width_div=8, total_steps=8)
+    tr = Vunet(cfg, device="cuda:0", n_channels_x=3, vgg_width_div=8, total_steps=8, vgg_synthetic=True)
     batch = synthetic_batch(2, 32, "cuda:0")
     kls, first = [], None
     for it in range(1, 8):
@@ -85,7 +102,7 @@ def test_shape_pose_net_with_adversarial_term():
     def run(weight, **gan):
         cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, train_regressor=False,
                     gan=dict(enabled=True, weight=weight, pd_scales=2, lr=2e-3, **gan))
-        tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50)
+        tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True)
         d0 = {k: v.clone() for k, v in tr.gan.disc.state_dict().items()}
         outs = [tr.train_fn(batch) for _ in range(6)]
         return tr, d0, outs
@@ -119,7 +136,7 @@ def test_second_hip_stream_changes_nothing_but_the_schedule():
         ops.set_dropout_seed(1234)          # the dropout counter is process-global: same masks for both runs
         cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, n_init_batches=1, gamma_step=1e-3, information_max=5.0,
                     train_regressor=False, two_streams=two)
-        tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50)
+        tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True)
         assert (tr.vunet._side_stream is not None) == two and ops._wgrad_streams["on"] == two
         outs = [tr.train_fn(batch) for _ in range(4)]
         torch.cuda.synchronize()
@@ -131,3 +148,98 @@ def test_second_hip_stream_changes_nothing_but_the_schedule():
         assert float(x["loss"]) == float(y["loss"]) and float(x["gamma"]) == float(y["gamma"])
     for (k, p), (_, q) in zip(a.vunet.state_dict().items(), b.vunet.state_dict().items()):
         assert torch.equal(p, q), k
+
+
+def _drive_trajectory(name, with_regressor):
+    """ShapePoseNet.train_fn ITSELF (loss assembly, n_init_batches gate, device-resident gamma, lr schedule, prepacked
+    weights, fused Adam, the regressor side loop) against the trajectory recorded from the reference's modules driven by
+    hand with torch.optim.Adam (tests/golden/make_golden.py g5_*)."""
+    import copy
+    from conftest import load_golden
+    from hip_parity_utils import assert_close
+    from synth import seeded_randn, synth_image, synth_state_dict
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import DEFAULT_CONFIG, ShapePoseNet
+    meta, arr = load_golden(name)
+    seed, R = meta["seed"], meta.get("reg_steps", 0)
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["data"]["spatial_size"] = meta["cfg"]["spatial_size"]
+    cfg["architecture"].update(nf_start=meta["cfg"]["nf_start"], nf_max=meta["cfg"]["nf_max"])
+    cfg["training"].update(dropout_prob=0.0, lr=meta["lr0"], adam_betas=tuple(meta["betas"]), gamma_step=meta["gamma_step"],
+                           information_max=meta["imax"], n_init_batches=meta["n_init_batches"], ll_weight=1.0,
+                           train_regressor=with_regressor, weight_regressor=meta.get("weight_regressor", 4.0))
+    tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=meta["vgg_width_div"], vgg_seed=meta["vgg_seed"],
+                      vgg_synthetic=True, total_steps=meta["total_steps"])
+    tr.vunet.load_state_dict(synth_state_dict(meta["shapes"], seed))
+    if with_regressor:
+        tr.regressor.load_state_dict(synth_state_dict(meta["reg_shapes"], meta["reg_seed"]))
+    tr.gamma.fill_(meta["gamma0"])
+    lat = [(2, 16, 4, 4), (2, 16, 8, 8)]
+    pre = "rtraj" if with_regressor else "traj"
+    for rec in meta["steps"]:
+        it = rec["it"]
+        batch = {"pose_img": synth_image(f"{pre}.x{it}", (2, 3, 32, 32), seed).cuda(),
+                 "stickman": synth_image(f"{pre}.c{it}", (2, 3, 32, 32), seed).cuda()}
+        eps = [seeded_randn(f"{pre}.{it}.eps{i}", s, seed).cuda() for i, s in enumerate(lat)]
+        reg_eps = None
+        if with_regressor:
+            batch["reg_imgs"] = synth_image(f"rtraj.r{it}", (2, R, 3, 32, 32), seed).cuda()
+            batch["reg_targets"] = (seeded_randn(f"rtraj.t{it}", (2, R, 17, 2), seed) * 0.25 + 0.5).cuda()
+            reg_eps = [[seeded_randn(f"rtraj.{it}.reg{r}.eps{i}", s, seed).cuda() for i, s in enumerate(lat)]
+                       for r in range(R)]
+        assert abs(tr.lr - rec["lr"]) < 1e-12                       # the lr this step's Adam uses
+        out = tr.train_fn(batch, eps, reg_eps)
+        for key, want in (("loss", rec["loss"]), ("likelihood_loss", rec["ll"]), ("kl_loss", rec["kl"]),
+                          ("gamma", rec["gamma_after"])):
+            assert abs(float(out[key]) - want) <= 5e-4 * abs(want) + 1e-5, (it, key, float(out[key]), want)
+        if with_regressor:
+            assert abs(float(out["loss_reg"]) - rec["reg_losses"][-1]) <= 5e-4 * rec["reg_losses"][-1] + 1e-5
+    sd = tr.vunet.state_dict()
+    assert_close(sd["dd.out_conv.conv.weight_v"], arr["final.dd.out_conv.conv.weight_v"], rtol=2e-3, atol=2e-5,
+                 name="final weight")
+    for k, s in meta["param_checksums"].items():
+        got = float(sd[k].double().abs().sum())
+        assert abs(got - s[1]) <= 5e-4 * s[1] + 1e-5, (k, got, s[1])
+    if with_regressor:
+        rsd = tr.regressor.state_dict()
+        assert_close(rsd["linears.1.weight"], arr["final.reg.linears.1.weight"], rtol=2e-3, atol=2e-5, name="regressor")
+        for k, s in meta["reg_checksums"].items():
+            got = float(rsd[k].double().abs().sum())
+            assert abs(got - s[1]) <= 5e-4 * s[1] + 1e-5, (k, got, s[1])
+
+
+def test_train_fn_follows_the_reference_trajectory():
+    _drive_trajectory("g5_trajectory", with_regressor=False)
+
+
+def test_train_fn_with_regressor_side_loop_follows_the_reference_trajectory():
+    _drive_trajectory("g5_regressor_trajectory", with_regressor=True)
+
+
+def test_train_fn_at_the_benchmark_size():
+    """BASELINE config 2 at its real size (256^2, per-GPU batch 16, nf 32..128, dropout 0.05): properties that need no
+    oracle -- finite and decreasing loss, run-to-run bit-identity, and stream overlap changing nothing but the schedule."""
+    import copy
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    batch = synthetic_batch(16, 256, "cuda:0")
+
+    def run(two_streams, steps):
+        ops.set_dropout_seed(4242)
+        torch.manual_seed(7)
+        cfg = copy.deepcopy(DEFAULT_CONFIG)
+        cfg["training"].update(train_regressor=False, two_streams=two_streams, lr=2e-3, n_init_batches=1)
+        tr = ShapePoseNet(cfg, device="cuda:0", total_steps=1000, vgg_synthetic=True)
+        torch.manual_seed(7)   # the eps draws of the steps
+        outs = [tr.train_fn(batch) for _ in range(steps)]
+        torch.cuda.synchronize()
+        sums = [float(b.flat.double().abs().sum()) for b in tr.optimizer.buckets]
+        return [float(o["loss"]) for o in outs], [float(o["likelihood_loss"]) for o in outs], sums
+
+    la, lla, sa = run(True, 5)
+    assert all(v == v and abs(v) < 1e6 for v in la)
+    assert lla[-1] < lla[0]
+    lb, _, sb = run(True, 5)
+    assert la == lb and sa == sb                       # bit-identical from run to run
+    lc, _, sc = run(False, 5)
+    assert la == lc and sa == sc                       # one HIP stream == four HIP streams

@@ -12,7 +12,7 @@ from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import S
 
 args = parse()
 cfg = make_config(args)
-tr = ShapePoseNet(cfg, device="cuda:0", total_steps=150000)
+tr = ShapePoseNet(cfg, device="cuda:0", total_steps=150000, vgg_synthetic=True)
 batch = synthetic_batch(args.batch, args.size, "cuda:0", seed=42)
 for _ in range(3):
     tr.train_fn(batch)

@@ -21,7 +21,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--regressor", action="store_true")
 args = ap.parse_args()
 cfg = make_config(args)
-tr = ShapePoseNet(cfg, device="cuda:0", total_steps=150000)
+tr = ShapePoseNet(cfg, device="cuda:0", total_steps=150000, vgg_synthetic=True)
 batch = synthetic_batch(args.batch, args.size, "cuda:0", seed=42)
 for _ in range(2):
     tr.train_fn(batch)

@@ -7,7 +7,7 @@ sys.argv = [sys.argv[0]]
 args = parse()
 cfg = make_config(args)
 cfg["training"]["n_init_batches"] = 4
-tr = ShapePoseNet(cfg, device="cuda:0", total_steps=150000)
+tr = ShapePoseNet(cfg, device="cuda:0", total_steps=150000, vgg_synthetic=True)
 batches = [synthetic_batch(16, 256, "cuda:0", seed=s) for s in range(4)]
 t0 = time.perf_counter()
 for i in range(300):
