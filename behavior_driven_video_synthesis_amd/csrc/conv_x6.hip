@@ -1,0 +1,137 @@
+// Host-side dispatch of the fp32-accurate split-bf16 3x3 / stride-1 convolution (kernel: conv_x6_kernel.h) and the
+// unified convolution entry point vunet_conv2d, which picks between it and the fp32-MFMA / VALU kernels of
+// vunet_conv2d_gather.
+#include "conv_common.h"
+
+int vunet_conv_x6_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pad, int pro, int NT, hipStream_t st);
+int vunet_conv_x6_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, int pro, int NT, hipStream_t st);
+extern "C" int vunet_x6_mtiles(int32_t M);
+int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res);
+
+// VUNET_CONV_PRECISION=f32 keeps every layer on the fp32-input MFMA kernels (read once per process)
+static bool x6_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VUNET_CONV_PRECISION");
+    return !(e && (e[0] == 'f' || e[0] == 'F'));
+  }();
+  return on;
+}
+
+static int x6_prologue_code(const vunet_conv_desc* d, bool has_mask) {
+  if (has_mask) return (d->in_act == ACT_NONE && d->drop_p <= 0.f) ? 4 : 3;
+  if (d->in_act == ACT_NONE && d->drop_p <= 0.f) return 0;
+  if (d->in_act == ACT_ELU && d->drop_p <= 0.f) return 1;
+  if (d->in_act == ACT_ELU) return 2;
+  return 3;
+}
+
+// geometry the kernel family covers (nothing about whether it is the fastest choice)
+static bool x6_geometry_ok(const vunet_conv_desc* d, int pro) {
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Hs != d->Ho || d->Ws != d->Wo) return false;
+  if (d->C1 <= 0 || d->C1 % 16 || d->C2 % 16 || d->Ws % 32 || d->Hs % 4) return false;
+  if (d->M % 32 || d->m_off % 32) return false;
+  return d->mode == 0 ? (pro == 0 || pro == 1 || pro == 2) : (pro == 0 || pro == 4);
+}
+
+static long x6_blocks(const vunet_conv_desc* d, int MT, int NT) {
+  if (d->Hs % (4 * NT)) return 0;
+  return (long)d->N * (d->Hs / (4 * NT)) * (d->Ws / 32) * ((d->M + 32 * MT - 1) / (32 * MT));
+}
+
+// Tile: M <= 32 -> one m-tile and up to 16 rows (the weight slab is re-staged per workgroup: tall tiles amortise it);
+// wider layers -> two m-tiles and 8 rows (LDS: two workgroups per CU).  The tallest tile that still gives every CU its
+// two resident workgroups wins; `min_blocks` is what the caller requires of the smallest tile.
+static int x6_pick(const vunet_conv_desc* d, int* MT, long min_blocks) {
+  *MT = d->M <= 32 ? 1 : 2;
+  if (const char* f = getenv("VUNET_X6_FORCE_NT")) {  // tests / tuning
+    const int NT = atoi(f);
+    if ((NT == 1 || NT == 2 || (NT == 4 && *MT == 1)) && x6_blocks(d, *MT, NT) > 0) return NT;
+  }
+  for (int NT = (*MT == 1 ? 4 : 2); NT >= 2; NT >>= 1)
+    if (x6_blocks(d, *MT, NT) >= 512) return NT;
+  return x6_blocks(d, *MT, 1) >= min_blocks ? 1 : 0;
+}
+
+static void fill_args(GatherArgs& ga, const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
+                      const float* shift, const float* res, const float* aux, const float* mask, float* y) {
+  ga.d = *d;
+  ga.x1 = x1; ga.x2 = x2; ga.wt = wt; ga.shift = shift; ga.res = res; ga.aux = aux; ga.y = y;
+  ga.NP = d->N * d->Ho * d->Wo;
+  ga.HoWo = d->Ho * d->Wo;
+  ga.HsWs = d->Hs * d->Ws;
+  ga.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
+  ga.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
+  ga.auxa = make_inact(d->aux_act, d->aux_slope, d->aux_drop_p, d->aux_drop_seed);
+  ga.ph = ga.pw = -1;
+  ga.subW = ga.subHW = 0;
+  ga.mask = mask;
+}
+
+static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
+                     const float* res, const float* aux, const float* mask, float* y, long min_blocks, void* stream) {
+  const int pro = x6_prologue_code(d, mask != nullptr);
+  if (!x6_geometry_ok(d, pro)) return VUNET_ERR_UNSUPPORTED;
+  int MT;
+  const int NT = x6_pick(d, &MT, min_blocks);
+  if (NT == 0) return VUNET_ERR_UNSUPPORTED;
+  GatherArgs ga;
+  fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
+  // K dimension of the image = the gathered tensor's channels; M dimension = all columns of the weight matrix
+  const int mtp = vunet_x6_mtiles(d->Mpad);
+  return MT == 1 ? vunet_conv_x6_launch_mt1(ga, wx, mtp, pro, NT, (hipStream_t)stream)
+                 : vunet_conv_x6_launch_mt2(ga, wx, mtp, pro, NT, (hipStream_t)stream);
+}
+
+// would vunet_conv2d route this problem to the split-bf16 kernel?  (big enough to fill the chip, not a 3-channel layer)
+static bool x6_wanted(const vunet_conv_desc* d, bool has_wx, bool has_aux, bool has_res, bool has_mask) {
+  if (!has_wx || !x6_enabled()) return false;
+  const int pro = x6_prologue_code(d, has_mask);
+  if (!x6_geometry_ok(d, pro)) return false;
+  if (vunet_conv_thin_kind(d, pro == 4 ? 0 : pro, has_aux, has_res) != 0) return false;
+  int MT;
+  return x6_pick(d, &MT, 128) > 0;
+}
+
+extern "C" int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_mask) {
+  return d && x6_geometry_ok(d, x6_prologue_code(d, has_mask != 0)) ? 1 : 0;
+}
+
+extern "C" int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx,
+                               const float* shift, const float* res, const float* aux, const float* mask, float* y,
+                               void* stream) {
+  if (!d || !x1 || !wx || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
+  if (mask && (d->mode != 1 || d->C2 != 0)) return VUNET_ERR_ARG;
+  if (d->d2s && (d->M % 4 != 0 || d->mode != 0)) return VUNET_ERR_ARG;
+  return x6_launch(d, x1, x2, wx, shift, res, aux, mask, y, 1, stream);
+}
+
+extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
+                            const float* shift, const float* res, const float* aux, float* y, void* stream) {
+  if (!d) return VUNET_ERR_ARG;
+  if (x6_wanted(d, wx != nullptr, aux != nullptr, res != nullptr, false)) {
+    if (!x1 || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
+    return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, 128, stream);
+  }
+  return vunet_conv2d_gather(d, x1, x2, wt, shift, res, aux, y, stream);
+}
+
+extern "C" int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
+                                          const float* res, float* dx, void* stream) {
+  if (!d || !dy || !y || !wx || !dx || d->mode != 1 || d->C2 != 0 || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
+  if (d->aux_act != ACT_NONE || d->aux_drop_p > 0.f || !x6_wanted(d, true, false, res != nullptr, true))
+    return VUNET_ERR_UNSUPPORTED;
+  return x6_launch(d, dy, nullptr, wx, nullptr, res, nullptr, y, dx, 128, stream);
+}
+
+// Name (rocprofv3 spelling) of the kernel vunet_conv2d / vunet_conv2d_dgrad_relu_x6 launches for this problem.
+extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, int32_t has_wx, int32_t has_mask,
+                                    char* name, int32_t len) {
+  if (!d || !name || len < 8) return VUNET_ERR_ARG;
+  if (x6_wanted(d, has_wx != 0, has_aux != 0, false, has_mask != 0)) {
+    int MT;
+    const int NT = x6_pick(d, &MT, 128);
+    snprintf(name, len, "conv_x6_kernel<%d, %d, %d, %d>", MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
+    return VUNET_OK;
+  }
+  return vunet_conv2d_gather_variant(d, has_aux, name, len);
+}

@@ -421,4 +421,4 @@ extern "C" int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* 
   return vunet_check_launch();
 }
 
-extern "C" int vunet_abi_version(void) { return 1; }
+extern "C" int vunet_abi_version(void) { return 2; }

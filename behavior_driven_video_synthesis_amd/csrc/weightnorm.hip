@@ -10,12 +10,100 @@
 // Reductions are wavefront shuffles (64 lanes) + one LDS hop.
 #include "common.h"
 
+#define X6_SLAB_UNITS 576   // 16-byte units per (chunk, kh, m-tile): [3 kw][3 planes][2 k-halves][32]
+
 struct WnArgs {
   vunet_wn_desc d;
   const float *v, *g, *bias, *gamma, *beta;
   float *wt_f, *wt_d, *scale, *shift, *invnorm;
+  uint4 *wx_f, *wx_d;   // split-bf16 images for conv_x6_kernel (NULL: not wanted / geometry not covered)
   int T, Ctot, C1p, C2p, Kf, Mpad_f, Coutp2, Kd, Mpad_d;
 };
+
+// ---- split-bf16 weight images (conv_x6_kernel.h): units of 8 bf16 laid out
+//        [chunk of 16 K-channels][kh][m-tile of 32][kw][plane h/m/l][k-half][32 channels of the m-tile]
+//      forward image : K = input channels (source 1 chunks, then source 2 chunks), M = output channels
+//      dgrad image   : K = output channels, M = input channels (both sources, as the columns of wt_d)
+//      m-tiles are padded (zeros) to vunet_x6_mtiles(M): every workgroup may read MT = 2 tiles from any tile.
+__host__ __device__ __forceinline__ int x6_mtiles(int m) { return (((m + 31) / 32 + 1) + 1) & ~1; }
+
+__device__ __forceinline__ uint32_t wn_pack2(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 p;
+  p[0] = (__bf16)a;
+  p[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, p);
+}
+
+__device__ __forceinline__ void wn_split2(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = wn_pack2(a, b);
+  float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = wn_pack2(ra, rb);
+  ra -= __uint_as_float(m << 16);
+  rb -= __uint_as_float(m & 0xffff0000u);
+  l = wn_pack2(ra, rb);
+}
+
+// one thread = one (chunk, kh, m-tile, kw, k-half, j) position = three 16-byte units (planes)
+__device__ __forceinline__ void wn_pack_x6_body(const WnArgs& a, size_t start, size_t stride) {
+  const int T = a.T;
+  if (T != 9) return;
+  for (int img = 0; img < 2; ++img) {
+    uint4* out = img == 0 ? a.wx_f : a.wx_d;
+    if (!out) continue;
+    const int nch1 = img == 0 ? a.d.C1 / 16 : a.d.Cout / 16;
+    const int nch = img == 0 ? nch1 + a.d.C2 / 16 : nch1;
+    const int Mdim = img == 0 ? a.d.Cout : a.Ctot;
+    const int mtp = x6_mtiles(Mdim);
+    const size_t total = (size_t)nch * 3 * mtp * 3 * 64;
+    for (size_t i = start; i < total; i += stride) {
+      const int j = (int)(i & 31), half = (int)((i >> 5) & 1);
+      size_t q = i >> 6;
+      const int kw = (int)(q % 3); q /= 3;
+      const int mt = (int)(q % mtp); q /= mtp;
+      const int kh = (int)(q % 3);
+      const int ch = (int)(q / 3);
+      const int tap = kh * 3 + kw, m = mt * 32 + j;
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float val = 0.f;
+        if (m < Mdim) {
+          if (img == 0) {
+            const int cg = ch < nch1 ? ch * 16 + half * 8 + e : a.d.C1 + (ch - nch1) * 16 + half * 8 + e;
+            val = a.scale[m] * a.v[((size_t)m * a.Ctot + cg) * T + tap];
+          } else {
+            const int co = ch * 16 + half * 8 + e;
+            val = a.scale[co] * a.v[((size_t)co * a.Ctot + m) * T + tap];
+          }
+        }
+        w[e] = val;
+      }
+      uint4 ph, pm, pl;
+      wn_split2(w[0], w[1], ph.x, pm.x, pl.x);
+      wn_split2(w[2], w[3], ph.y, pm.y, pl.y);
+      wn_split2(w[4], w[5], ph.z, pm.z, pl.z);
+      wn_split2(w[6], w[7], ph.w, pm.w, pl.w);
+      // unit index: (((ch*3 + kh)*mtp + mt)*3 + kw)*3 + plane)*64 + half*32 + j
+      const size_t base = ((((size_t)(ch * 3 + kh) * mtp + mt) * 3 + kw) * 3) * 64 + half * 32 + j;
+      out[base] = ph;
+      out[base + 64] = pm;
+      out[base + 128] = pl;
+    }
+  }
+}
+
+extern "C" int vunet_x6_mtiles(int32_t M) { return x6_mtiles(M); }
+
+// does the split-bf16 kernel family cover this layer's forward / data-gradient weights?  (3x3, channel counts in 16s)
+static bool x6_fwd_ok(const vunet_wn_desc* d) { return d->KH == 3 && d->KW == 3 && d->C1 % 16 == 0 && d->C2 % 16 == 0; }
+static bool x6_dgrad_ok(const vunet_wn_desc* d) { return d->KH == 3 && d->KW == 3 && d->Cout % 16 == 0; }
+
+extern "C" int vunet_x6_image_bytes(const vunet_wn_desc* d, int32_t dgrad) {
+  if (!d) return 0;
+  if (dgrad) return x6_dgrad_ok(d) ? (d->Cout / 16) * 3 * x6_mtiles(d->C1 + d->C2) * X6_SLAB_UNITS * 16 : 0;
+  return x6_fwd_ok(d) ? ((d->C1 + d->C2) / 16) * 3 * x6_mtiles(d->Cout) * X6_SLAB_UNITS * 16 : 0;
+}
 
 __global__ __launch_bounds__(64) void wn_scale_kernel(const WnArgs a) {
   const int co = blockIdx.x, lane = threadIdx.x;
@@ -66,6 +154,7 @@ __global__ __launch_bounds__(256) void wn_pack_kernel(const WnArgs a) {
       a.wt_d[e] = w;
     }
   }
+  wn_pack_x6_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 static void wn_geometry(const vunet_wn_desc* d, WnArgs& a) {
@@ -81,8 +170,8 @@ static void wn_geometry(const vunet_wn_desc* d, WnArgs& a) {
 }
 
 extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g, const float* bias,
-                                    const float* gamma, const float* beta, float* wt_f, float* wt_d, float* scale,
-                                    float* shift, float* invnorm, void* stream) {
+                                    const float* gamma, const float* beta, float* wt_f, float* wt_d, void* wx_f,
+                                    void* wx_d, float* scale, float* shift, float* invnorm, void* stream) {
   if (!d || !v || !wt_f || !scale || !shift || !invnorm) return VUNET_ERR_ARG;
   if (d->kind == 0 && !g) return VUNET_ERR_ARG;
   if (d->Cout < 1 || d->C1 < 1 || d->C2 < 0) return VUNET_ERR_ARG;
@@ -90,6 +179,8 @@ extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, cons
   a.d = *d;
   a.v = v; a.g = g; a.bias = bias; a.gamma = gamma; a.beta = beta;
   a.wt_f = wt_f; a.wt_d = wt_d; a.scale = scale; a.shift = shift; a.invnorm = invnorm;
+  if ((wx_f && !x6_fwd_ok(d)) || (wx_d && !x6_dgrad_ok(d))) return VUNET_ERR_UNSUPPORTED;
+  a.wx_f = (uint4*)wx_f; a.wx_d = (uint4*)wx_d;
   wn_geometry(d, a);
   hipStream_t st = (hipStream_t)stream;
   VUNET_LAUNCH(wn_scale_kernel, dim3(d->Cout), dim3(64), 0, st, a);
@@ -104,6 +195,7 @@ extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, cons
 struct WnItemDev {  // mirrors vunet_wn_item (include/vunet_hip.h)
   const float *v, *g, *bias, *gamma, *beta;
   float *wt_f, *wt_d, *scale, *shift, *invnorm;
+  uint4 *wx_f, *wx_d;
   vunet_wn_desc d;
 };
 
@@ -112,6 +204,7 @@ __device__ __forceinline__ WnArgs item_args(const WnItemDev& it) {
   a.d = it.d;
   a.v = it.v; a.g = it.g; a.bias = it.bias; a.gamma = it.gamma; a.beta = it.beta;
   a.wt_f = it.wt_f; a.wt_d = it.wt_d; a.scale = it.scale; a.shift = it.shift; a.invnorm = it.invnorm;
+  a.wx_f = it.wx_f; a.wx_d = it.wx_d;
   a.T = it.d.KH * it.d.KW;
   a.Ctot = it.d.C1 + it.d.C2;
   a.C1p = (it.d.C1 + 1) & ~1;
@@ -181,7 +274,9 @@ __global__ __launch_bounds__(64) void wn_scale_multi_kernel(const WnItemDev* __r
 }
 
 __global__ __launch_bounds__(256) void wn_pack_multi_kernel(const WnItemDev* __restrict__ items) {
-  wn_pack_body(item_args(items[blockIdx.y]), (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+  const WnArgs a = item_args(items[blockIdx.y]);
+  wn_pack_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+  wn_pack_x6_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 extern "C" int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_t n_items, int32_t max_cout,

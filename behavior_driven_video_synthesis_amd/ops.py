@@ -120,19 +120,60 @@ def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
     return (h + 2 * pad - k) // stride + 1
 
 
+# ------------------------------------------------------------------------------------------------
+# convolution arithmetic: "x6" = fp32-accurate split-bf16 kernels on the bf16 matrix cores wherever they apply
+# (csrc/conv_x6_kernel.h), "f32" = fp32-input MFMA kernels everywhere.  Process-wide; the environment variable
+# VUNET_CONV_PRECISION=f32 pins the library itself to f32 regardless of this switch.
+# ------------------------------------------------------------------------------------------------
+_conv_precision = {"x6": True}
+
+
+def set_conv_precision(mode: str):
+    if mode not in ("x6", "f32"):
+        raise ValueError(f"unknown conv precision {mode!r} (x6 | f32)")
+    _conv_precision["x6"] = mode == "x6"
+
+
+def conv_precision() -> str:
+    return "x6" if _conv_precision["x6"] else "f32"
+
+
+def x6_mtiles(m: int) -> int:
+    """vunet_x6_mtiles: 32-channel tiles of a split weight image's M dimension (padded)."""
+    return (((m + 31) // 32 + 1) + 1) & ~1
+
+
+def x6_image_units(cout: int, c1: int, c2: int, k: int, dgrad: bool) -> int:
+    """16-byte units of a layer's split-bf16 weight image (vunet_x6_image_bytes / 16); 0: geometry not covered."""
+    if k != 3:
+        return 0
+    if dgrad:
+        return (cout // 16) * 3 * x6_mtiles(c1 + c2) * 576 if cout % 16 == 0 else 0
+    return ((c1 + c2) // 16) * 3 * x6_mtiles(cout) * 576 if (c1 % 16 == 0 and c2 % 16 == 0) else 0
+
+
+def _alloc_x6(cout, c1, c2, k, dgrad, dev):
+    if not _conv_precision["x6"]:
+        return None
+    n = x6_image_units(cout, c1, c2, k, dgrad)
+    return torch.empty(n * 4, device=dev, dtype=torch.int32) if n else None
+
+
 def pack_weights(v, g, bias, gamma, beta, c1: int, c2: int, kind: int, need_dgrad: bool):
-    """vunet_weightnorm_fwd -> (wt_f, wt_d, scale, shift, invnorm)."""
+    """vunet_weightnorm_fwd -> (wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d)."""
     cout, ctot, kh, kw = v.shape
     assert ctot == c1 + c2
     t = kh * kw
     dev = v.device
     wt_f = torch.empty(t * (_r2(c1) + _r2(c2)), _r32(cout), device=dev, dtype=torch.float32)
     wt_d = torch.empty(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_dgrad else None
+    wx_f = _alloc_x6(cout, c1, c2, kh, False, dev) if kh == kw else None
+    wx_d = _alloc_x6(cout, c1, c2, kh, True, dev) if (need_dgrad and kh == kw) else None
     small = torch.empty(3, cout, device=dev, dtype=torch.float32)
     d = WnDesc(cout, c1, c2, kh, kw, kind)
     _call("vunet_weightnorm_fwd", ctypes.byref(d), _p(v), _p(g), _p(bias), _p(gamma), _p(beta), _p(wt_f), _p(wt_d),
-          _p(small[0]), _p(small[1]), _p(small[2]), _stream())
-    return wt_f, wt_d, small[0], small[1], small[2]
+          _p(wx_f), _p(wx_d), _p(small[0]), _p(small[1]), _p(small[2]), _stream())
+    return wt_f, wt_d, small[0], small[1], small[2], wx_f, wx_d
 
 
 # ------------------------------------------------------------------------------------------------
@@ -180,7 +221,7 @@ class _Timed:
             _prof["recs"].append((self.name, self.flop, self.e0, self.e1))
 
 
-def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
+def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None):
     t = desc.KH * desc.KW
     if desc.mode == 0:
         name, flop = "conv_gather_fwd", 2.0 * desc.N * desc.Ho * desc.Wo * desc.M * (desc.C1 + desc.C2) * t
@@ -189,11 +230,11 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
     kname = ""
     if _prof["on"]:
         buf = ctypes.create_string_buffer(96)
-        _call("vunet_conv2d_gather_variant", ctypes.byref(desc), 0 if aux is None else 1, buf, 96)
+        _call("vunet_conv2d_variant", ctypes.byref(desc), 0 if aux is None else 1, 0 if wx is None else 1, 0, buf, 96)
         kname = buf.value.decode()
     with _Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act, kname),
                 flop):
-        _call("vunet_conv2d_gather", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(shift), _p(res), _p(aux), _p(y),
+        _call("vunet_conv2d", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), _p(aux), _p(y),
               _stream())
 
 
@@ -205,7 +246,7 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y):
 # ------------------------------------------------------------------------------------------------
 def _plain_pack(w, need_dgrad):
     cout, cin = w.shape[0], w.shape[1]
-    return pack_weights(w.contiguous(), None, None, None, None, cin, 0, 1, need_dgrad)
+    return pack_weights(w.contiguous(), None, None, None, None, cin, 0, 1, need_dgrad)   # (wt_f, wt_d, ..., wx_f, wx_d)
 
 
 def _plain_desc(n, cin, hs, ws, m, ho, wo, k, stride, pad, mode, mpad):
@@ -224,10 +265,11 @@ class ConvPlainFwd(torch.autograd.Function):
         n, cin, hs, ws = x.shape
         cout, _, k, _ = w.shape
         ho, wo = conv_out_size(hs, k, stride, pad), conv_out_size(ws, k, stride, pad)
-        wt_f = _plain_pack(w, False)[0]
+        pk = _plain_pack(w, False)
+        wt_f = pk[0]
         y = torch.empty(n, cout, ho, wo, device=x.device, dtype=torch.float32)
         _conv_gather(_plain_desc(n, cin, hs, ws, cout, ho, wo, k, stride, pad, 0, wt_f.shape[1]), x, None, wt_f, None,
-                     None, None, y)
+                     None, None, y, pk[5])
         ctx.save_for_backward(x, w)
         ctx.geo = (stride, pad)
         return y
@@ -250,10 +292,11 @@ class ConvPlainDgrad(torch.autograd.Function):
         dy, w = _c(dy), _c(w)
         n, cout, ho, wo = dy.shape
         cin, k = w.shape[1], w.shape[2]
-        wt_d = _plain_pack(w, True)[1]
+        pk = _plain_pack(w, True)
+        wt_d = pk[1]
         dx = torch.empty(n, cin, hs, ws, device=dy.device, dtype=torch.float32)
         _conv_gather(_plain_desc(n, cout, ho, wo, cin, hs, ws, k, stride, pad, 1, wt_d.shape[1]), dy, None, wt_d, None,
-                     None, None, dx)
+                     None, None, dx, pk[6])
         ctx.save_for_backward(dy, w)
         ctx.geo = (stride, pad)
         return dx
@@ -432,7 +475,7 @@ def remove_grad_hook(fn):
 # ------------------------------------------------------------------------------------------------
 class WnItem(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("v", "g", "bias", "gamma", "beta", "wt_f", "wt_d", "scale", "shift",
-                                                "invnorm")] + [("d", WnDesc)]
+                                                "invnorm", "wx_f", "wx_d")] + [("d", WnDesc)]
 
 
 _prepack_sets = {}      # id(model) -> dict(signature, table, max_cout, entries, keep)
@@ -445,7 +488,7 @@ def _ptr_or_none(t):
 
 def _build_prepack_set(model):
     mods = [m for m in model.modules() if hasattr(m, "_params") and getattr(m, "_last_split", None) is not None]
-    sig = tuple((id(m), m._last_split) for m in mods)
+    sig = (_conv_precision["x6"],) + tuple((id(m), m._last_split) for m in mods)
     cur = _prepack_sets.get(id(model))
     if cur is not None and cur["signature"] == sig:
         return cur
@@ -460,14 +503,17 @@ def _build_prepack_set(model):
         t = kh * kw
         wt_f = torch.empty(t * (_r2(c1) + _r2(c2)), _r32(cout), device=dev, dtype=torch.float32)
         wt_d = torch.empty(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_x else None
+        wx_f = _alloc_x6(cout, c1, c2, kh, False, dev) if kh == kw else None
+        wx_d = _alloc_x6(cout, c1, c2, kh, True, dev) if (need_x and kh == kw) else None
         small = torch.empty(3, cout, device=dev, dtype=torch.float32)
         it = items[i]
         it.v, it.g, it.bias, it.gamma, it.beta = (_ptr_or_none(x) for x in (v, g, b, gamma, beta))
         it.wt_f, it.wt_d = wt_f.data_ptr(), _ptr_or_none(wt_d)
+        it.wx_f, it.wx_d = _ptr_or_none(wx_f), _ptr_or_none(wx_d)
         it.scale, it.shift, it.invnorm = small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
         it.d = WnDesc(cout, c1, c2, kh, kw, m.kind)
-        entries[id(m)] = ((c1, c2, need_x), wt_f, wt_d, small[0], small[1], small[2])
-        keep.append((wt_f, wt_d, small))
+        entries[id(m)] = ((c1, c2, need_x), wt_f, wt_d, small[0], small[1], small[2], wx_f, wx_d)
+        keep.append((wt_f, wt_d, small, wx_f, wx_d))
         max_cout = max(max_cout, cout)
     raw = bytes(items)
     table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
@@ -519,7 +565,7 @@ class FusedConv(torch.autograd.Function):
         frozen = not any(t is not None and t.requires_grad for t in (v, g, bias, gamma, beta))
         # frozen feature extractor (VGG19): pack once, reuse for every pass.  The packed buffers hang off the weight
         # tensor itself (they die with it) and are stamped with every operand's storage address and version counter.
-        sub = (c1, c2, cfg.kind, bool(need_x))
+        sub = (c1, c2, cfg.kind, bool(need_x), _conv_precision["x6"])
         stamp = tuple(None if t is None else (t.data_ptr(), t._version) for t in (v, g, bias, gamma, beta))
         hit = getattr(v, "_vunet_frozen_pack", {}).get(sub) if frozen else None
         pre = None
@@ -529,15 +575,16 @@ class FusedConv(torch.autograd.Function):
             if pre is not None and (pre[0][:2] != (c1, c2) or (need_x and pre[2] is None)):
                 pre = None
         if pre is not None:
-            _, wt_f, wt_d, scale, shift, invnorm = pre
+            _, wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = pre
         elif hit is not None and hit[0] == stamp:
-            wt_f, wt_d, scale, shift, invnorm = hit[1]
+            wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = hit[1]
         else:
-            wt_f, wt_d, scale, shift, invnorm = pack_weights(v, g, bias, gamma, beta, c1, c2, cfg.kind, need_x)
+            wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = pack_weights(v, g, bias, gamma, beta, c1, c2, cfg.kind,
+                                                                          need_x)
             if frozen:
                 if not hasattr(v, "_vunet_frozen_pack"):
                     v._vunet_frozen_pack = {}
-                v._vunet_frozen_pack[sub] = (stamp, (wt_f, wt_d, scale, shift, invnorm))
+                v._vunet_frozen_pack[sub] = (stamp, (wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d))
         if cfg.d2s:
             y = torch.empty(n, cout // 4, 2 * ho, 2 * wo, device=x1.device, dtype=torch.float32)
         else:
@@ -553,19 +600,19 @@ class FusedConv(torch.autograd.Function):
                         2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
                 _call("vunet_conv2d_bf16", ctypes.byref(d), _p(x1), _p(x2), _p(wb), _p(shift), _p(res), _p(y), _stream())
         else:
-            _conv_gather(d, x1, x2, wt_f, shift, res, None, y)
+            _conv_gather(d, x1, x2, wt_f, shift, res, None, y, wx_f)
         ctx.cfg = cfg
         ctx.param_refs = (v, g, bias, gamma, beta)  # the caller's tensors (Parameters): direct .grad writes
         ctx.res_ref = res
         ctx.dims = (n, c1, c2, hs, ws, cout, ho, wo)
         ctx.need_w = need_w
         ctx.save_for_backward(x1, x2, v, g, bias, gamma, invnorm, wt_d,
-                              y if cfg.out_act in (ACT_SIGMOID, ACT_RELU, ACT_LRELU, ACT_ELU) else None)
+                              y if cfg.out_act in (ACT_SIGMOID, ACT_RELU, ACT_LRELU, ACT_ELU) else None, wx_d)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, x2, v, g, bias, gamma, invnorm, wt_d, y = ctx.saved_tensors
+        x1, x2, v, g, bias, gamma, invnorm, wt_d, y, wx_d = ctx.saved_tensors
         cfg: ConvCfg = ctx.cfg
         if torch.is_grad_enabled():
             # create_graph=True (e.g. the R1 penalty): build a differentiable backward by re-expressing the layer
@@ -595,12 +642,19 @@ class FusedConv(torch.autograd.Function):
             kname = ""
             if _prof["on"]:
                 buf = ctypes.create_string_buffer(96)
-                _call("vunet_conv2d_gather_variant", ctypes.byref(d), 0, buf, 96)
-                kname = buf.value.decode().replace(", 1, 0, ", ", 1, 4, ")
+                _call("vunet_conv2d_variant", ctypes.byref(d), 0, 0 if wx_d is None else 1, 1, buf, 96)
+                kname = buf.value.decode()
+                if kname.startswith("conv_tiled"):
+                    kname = kname.replace(", 1, 0, ", ", 1, 4, ")
             with _Timed(("conv_gather_dgrad", n, cout, 0, ho, wo, c1, k, cfg.stride, 0, kname),
                         2.0 * n * ho * wo * cout * c1 * k * k):
-                rc = _lib.lib().vunet_conv2d_dgrad_relu(ctypes.byref(d), _p(dy), _p(y), _p(wt_d), _p(dy if cfg.res_is_x1 else None),
-                                                        _p(dx), _stream())
+                rc = -3
+                if wx_d is not None:
+                    rc = _lib.lib().vunet_conv2d_dgrad_relu_x6(ctypes.byref(d), _p(dy), _p(y), _p(wx_d),
+                                                               _p(dy if cfg.res_is_x1 else None), _p(dx), _stream())
+                if rc == -3:
+                    rc = _lib.lib().vunet_conv2d_dgrad_relu(ctypes.byref(d), _p(dy), _p(y), _p(wt_d),
+                                                            _p(dy if cfg.res_is_x1 else None), _p(dx), _stream())
             if rc == 0:
                 return dx, None, dres, None, None, None, None, None, None
             if rc != -3:   # anything but VUNET_ERR_UNSUPPORTED is an error; unsupported geometries take the two-pass route
@@ -697,7 +751,7 @@ class FusedConv(torch.autograd.Function):
                              drop_p=0.0, drop_seed=0, out_act=ACT_NONE, d2s=0, aux_act=cfg.in_act,
                              aux_slope=cfg.in_slope, aux_drop_p=cfg.drop_p, aux_drop_seed=seed)
                 has_aux = cfg.in_act != ACT_NONE or cfg.drop_p > 0
-                _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx)
+                _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d)
                 return dx
             if ctx.needs_input_grad[0]:
                 dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else None)

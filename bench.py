@@ -194,7 +194,7 @@ def main():
                               "kernels": {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
                                               "avg_launch_us": round(1e3 * v["ms"] / v["n"], 1),
                                               "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                                          for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                                          for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:20]},
                               "conv_ms_per_step": tot_ms / prof_steps,
                               "whole_step_tflops": FLOP_PER_FRAME * args.batch / (1e-3 * result["ms_per_step"]) / 1e12}
         # HBM traffic per launch of the dominant kernel: PMC passes collected separately (tools/pmc_summary.py)

@@ -86,6 +86,32 @@ int vunet_conv2d_dgrad_relu(const vunet_conv_desc* d, const float* dy, const flo
  * call passes an aux tensor.  For profiling / roofline bookkeeping only. */
 int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char* name, int32_t len);
 
+/* ------------------------------------------------------------------------------------------
+ * fp32-accurate convolution on the bf16 matrix cores ("x6": exact 3-way bf16 split of both operands, the six
+ * leading partial products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- csrc/conv_x6_kernel.h).  Same
+ * operation, prologue / sources / epilogue and fp32 NCHW tensors as vunet_conv2d_gather; the dropped partial
+ * products are below fp32 rounding, so results match the fp32-MFMA kernels to fp32 accuracy at 2.67x their MFMA roof.
+ * Covers 3x3 / stride 1 / pad 1, C1 and C2 multiples of 16, M and m_off multiples of 32, Ws % 32 == 0, Hs % 4 == 0,
+ * prologue none / ELU / ELU+dropout (mode 0), none (mode 1).
+ *   wx   : split weight image written by vunet_weightnorm_fwd* (wx_f for mode 0, wx_d for mode 1);
+ *   mask : mode 1 only, tensor shaped like x1 -- x1 is multiplied by [mask > 0] while staged (ReLU backward);
+ *   vunet_conv2d          : THE convolution entry point of the host code: the split-bf16 kernel when wx != NULL, the
+ *                           geometry is covered and the launch fills the chip, else vunet_conv2d_gather.
+ *                           VUNET_CONV_PRECISION=f32 in the environment pins every layer to the fp32-MFMA kernels.
+ *   vunet_conv2d_x6       : the split-bf16 kernel or VUNET_ERR_UNSUPPORTED (no size heuristics; tests).
+ * ------------------------------------------------------------------------------------------ */
+int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
+                 const float* shift, const float* res, const float* aux, float* y, void* stream);
+int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
+                    const float* res, const float* aux, const float* mask, float* y, void* stream);
+int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_mask);
+/* vunet_conv2d_dgrad_relu on the split-bf16 kernel (wx = wx_d); VUNET_ERR_UNSUPPORTED -> use vunet_conv2d_dgrad_relu */
+int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
+                               const float* res, float* dx, void* stream);
+/* kernel name vunet_conv2d (has_mask: vunet_conv2d_dgrad_relu_x6) selects, rocprofv3 spelling */
+int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, int32_t has_wx, int32_t has_mask, char* name,
+                         int32_t len);
+
 /* bf16-operand forward convolution of the inference path (models/vunets.py:508-515 `transfer`, run per frame
  * by the render loop; BASELINE config 5): operands rounded to bf16 (RNE) on the way into LDS, fp32 accumulate
  * on v_mfma_f32_32x32x16_bf16, fp32 NCHW tensors in HBM, same prologue / sources / epilogue as
@@ -134,20 +160,26 @@ typedef struct vunet_wn_desc {
 } vunet_wn_desc;
 
 /* outputs: wt_f [T*(C1p+C2p)][Coutp32]  (forward),  wt_d [T*Coutp2][Cinp32] (dgrad; NULL to skip),
- * scale[Cout], shift[Cout], invnorm[Cout].  Any of g/bias/gamma/beta may be NULL per kind.
+ * wx_f / wx_d: the split-bf16 images of the same two matrices for vunet_conv2d (vunet_x6_image_bytes bytes each;
+ * NULL to skip), scale[Cout], shift[Cout], invnorm[Cout].  Any of g/bias/gamma/beta may be NULL per kind.
  * (CXp = CX rounded up to 2, Coutp2 = Cout rounded up to 2, Coutp32/Cinp32 rounded up to 32.) */
 int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g, const float* bias,
-                         const float* gamma, const float* beta, float* wt_f, float* wt_d, float* scale,
-                         float* shift, float* invnorm, void* stream);
+                         const float* gamma, const float* beta, float* wt_f, float* wt_d, void* wx_f, void* wx_d,
+                         float* scale, float* shift, float* invnorm, void* stream);
 
 /* Batched form: the weights of every layer of a model in two launches.  items_dev: DEVICE array of n_items
  * entries (the pointers are device pointers; entries with kind/NULL rules as above); max_cout = max over items. */
 typedef struct vunet_wn_item {
   const float *v, *g, *bias, *gamma, *beta;
   float *wt_f, *wt_d, *scale, *shift, *invnorm;
+  void *wx_f, *wx_d;
   vunet_wn_desc d;
 } vunet_wn_item;
 int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_t n_items, int32_t max_cout, void* stream);
+/* size in bytes of the split weight image of a layer (0: geometry not covered); dgrad != 0: the wx_d image */
+int vunet_x6_image_bytes(const vunet_wn_desc* d, int32_t dgrad);
+int vunet_x6_mtiles(int32_t M);
+/* (vunet_x6_mtiles: 32-channel tiles of the image's M dimension, padded so that any workgroup may read two) */
 
 /* backward: reduces the wgrad slabs (fixed order) and produces the parameter gradients
  * dv[Cout][Cin][KH][KW], dg[Cout], dbias[Cout], dgamma[Cout], dbeta[Cout] (NULL to skip).

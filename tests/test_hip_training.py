@@ -228,7 +228,7 @@ def test_train_fn_at_the_benchmark_size():
         ops.set_dropout_seed(4242)
         torch.manual_seed(7)
         cfg = copy.deepcopy(DEFAULT_CONFIG)
-        cfg["training"].update(train_regressor=False, two_streams=two_streams, lr=2e-3, n_init_batches=1)
+        cfg["training"].update(train_regressor=False, two_streams=two_streams, n_init_batches=1)   # lr 5e-4: the shipped value
         tr = ShapePoseNet(cfg, device="cuda:0", total_steps=1000, vgg_synthetic=True)
         torch.manual_seed(7)   # the eps draws of the steps
         outs = [tr.train_fn(batch) for _ in range(steps)]
@@ -236,10 +236,10 @@ def test_train_fn_at_the_benchmark_size():
         sums = [float(b.flat.double().abs().sum()) for b in tr.optimizer.buckets]
         return [float(o["loss"]) for o in outs], [float(o["likelihood_loss"]) for o in outs], sums
 
-    la, lla, sa = run(True, 5)
-    assert all(v == v and abs(v) < 1e6 for v in la)
-    assert lla[-1] < lla[0]
-    lb, _, sb = run(True, 5)
-    assert la == lb and sa == sb                       # bit-identical from run to run
-    lc, _, sc = run(False, 5)
-    assert la == lc and sa == sc                       # one HIP stream == four HIP streams
+    la, lla, sa = run(True, 6)
+    assert all(v == v and abs(v) < 1e6 for v in la), la
+    assert lla[-1] < lla[0], lla
+    lb, _, sb = run(True, 6)
+    assert la == lb and sa == sb, (la, lb)             # bit-identical from run to run
+    lc, _, sc = run(False, 6)
+    assert la == lc and sa == sc, (la, lc)             # one HIP stream == four HIP streams

@@ -1,0 +1,241 @@
+"""-m gpu: the fp32-accurate split-bf16 convolution kernels (csrc/conv_x6_kernel.h) against an fp64 convolution.
+
+The claim under test: splitting both fp32 operands exactly into three bf16 terms and accumulating the six leading
+partial products in fp32 on the bf16 matrix cores gives fp32-LEVEL accuracy (the dropped products are below 2^-24 of
+the result; what remains is accumulation rounding).  Measured on MI355X (tools/x6_accuracy.py, gpurun_out ->
+profiles/r02_x6_accuracy.txt): rms error 0.7e-7 .. 2.3e-7 of the output scale for K = 576 .. 4608, i.e. 2.5 - 3.5x
+the fp32-MFMA kernel's fmaf chain (six accumulator roundings per 16-channel step instead of one per channel pair, and
+the bf16 matrix core's own fp32 accumulation is ~1.5x noisier than the fmaf chain even on bf16-exact operands), and
+more than 400x below the 1e-4 parity tolerance.  So every case is compared (i) with an fp64 reference at a bound of
+3e-6 of the output scale -- 30x tighter than the tolerance the fp32-MFMA kernels are held to -- and (ii) with the
+fp32-MFMA kernel's own error on the same problem (never worse than 5x that error plus the rounding floor).
+"""
+import ctypes
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_parity_utils import assert_close, dropout_keep_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from behavior_driven_video_synthesis_amd import ops
+    return ops
+
+
+def _ref_forward(x1, x2, v, scale, shift, in_act, drop, seed, out_act, res, d2s):
+    """fp64 restatement of one fused layer: prologue on each source, conv, shift, activation, d2s, residual."""
+    ops = _ops()
+    xs = []
+    for i, x in enumerate((x1, x2)):
+        if x is None:
+            continue
+        t = x.double().cpu()
+        if in_act == ops.ACT_ELU:
+            t = F.elu(t)
+        if drop > 0:
+            s = seed if i == 0 else (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF
+            t = t * dropout_keep_mask(tuple(x.shape), drop, s).double() * float(torch.tensor(1.0 / (1.0 - drop),
+                                                                                             dtype=torch.float32))
+        xs.append(t)
+    xin = torch.cat(xs, dim=1)
+    w = (v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1))
+    y = F.conv2d(xin, w, None, padding=1) + shift.double().cpu().view(1, -1, 1, 1)
+    if out_act == ops.ACT_RELU:
+        y = torch.relu(y)
+    elif out_act == ops.ACT_SIGMOID:
+        y = torch.sigmoid(y)
+    if d2s:
+        from oracle import vunet_oracle as O
+        y = O.depth_to_space(y)
+    if res is not None:
+        y = y + res.double().cpu()
+    return y
+
+
+def _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_act, res, d2s, use_x6, force_nt=None):
+    n, c1, h, w = x1.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    cout = v.shape[0]
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, c1, c2, 0, True)
+    assert wx_f is not None
+    y = torch.empty((n, cout // 4, 2 * h, 2 * w) if d2s else (n, cout, h, w), device="cuda")
+    d = ops.ConvDesc(N=n, C1=c1, C2=c2, Hs=h, Ws=w, M=cout, m_off=0, Mpad=wt_f.shape[1], Ho=h, Wo=w, KH=3, KW=3,
+                     stride=1, pad=1, mode=0, in_act=in_act, in_slope=0.0, drop_p=drop, drop_seed=seed,
+                     out_act=out_act, d2s=int(d2s))
+    if force_nt is not None:
+        os.environ["VUNET_X6_FORCE_NT"] = str(force_nt)
+    try:
+        if use_x6:
+            assert ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
+            ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift),
+                      ops._p(res), None, None, ops._p(y), ops._stream())
+        else:
+            ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wt_f), ops._p(shift),
+                      ops._p(res), None, ops._p(y), ops._stream())
+    finally:
+        os.environ.pop("VUNET_X6_FORCE_NT", None)
+    torch.cuda.synchronize()
+    return y, scale, shift, (wt_d, wx_d)
+
+
+def _params(cout, cin, seed):
+    g_ = torch.Generator().manual_seed(seed)
+    v = (torch.randn(cout, cin, 3, 3, generator=g_) * 0.2).cuda()
+    g = (torch.rand(cout, 1, 1, 1, generator=g_) + 0.5).cuda()
+    bias = (torch.randn(cout, generator=g_) * 0.1).cuda()
+    gamma = (1.0 + 0.3 * torch.randn(1, cout, 1, 1, generator=g_)).cuda()
+    beta = (0.2 * torch.randn(1, cout, 1, 1, generator=g_)).cuda()
+    return v, g, bias, gamma, beta
+
+
+# (n, c1, c2, cout, h, w, in_act, drop, out_act, with_res, d2s, forced NT)
+FWD_CASES = [
+    (2, 32, 0, 32, 16, 32, 0, 0.0, 0, False, False, 4),    # MT 1, 16-row tile
+    (2, 32, 0, 32, 8, 64, 1, 0.0, 0, True, False, 2),      # MT 1, 8 rows, ELU prologue + residual
+    (1, 16, 0, 32, 4, 32, 1, 0.1, 0, True, False, 1),      # one chunk, dropout, 4-row tile
+    (2, 32, 32, 32, 16, 32, 1, 0.05, 0, True, False, 4),   # two sources (the RNB skip read), ELU + dropout
+    (2, 64, 0, 64, 8, 32, 0, 0.0, 2, False, False, 2),     # MT 2, ReLU epilogue (VGG19 layer)
+    (1, 64, 64, 64, 8, 64, 1, 0.05, 0, True, False, 2),    # MT 2, two sources
+    (1, 128, 0, 256, 8, 32, 0, 0.0, 0, False, True, 2),    # sub-pixel up-conv: depth-to-space store, 4 m-blocks
+    (1, 48, 16, 96, 12, 32, 1, 0.0, 3, False, False, 1),   # ragged: 3 + 1 chunks, M = 96 (last m-block half empty), sigmoid
+    (1, 256, 0, 128, 8, 32, 0, 0.0, 0, False, False, 2),   # long K loop (16 chunks)
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_x6_forward_vs_fp64_and_vs_fp32_mfma(case):
+    ops = _ops()
+    n, c1, c2, cout, h, w, in_act, drop, out_act, with_res, d2s, nt = case
+    g_ = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x1 = torch.randn(n, c1, h, w, generator=g_).cuda()
+    x2 = torch.randn(n, c2, h, w, generator=g_).cuda() if c2 else None
+    res = None
+    if with_res:
+        res = torch.randn((n, cout // 4, 2 * h, 2 * w) if d2s else (n, cout, h, w), generator=g_).cuda()
+    v, g, bias, gamma, beta = _params(cout, c1 + c2, 5)
+    seed = 0xC0FFEE
+    y6, scale, shift, _ = _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_act, res, d2s,
+                                       True, nt)
+    y32, _, _, _ = _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_act, res, d2s, False)
+    ref = _ref_forward(x1, x2, v, scale, shift, in_act, drop, seed, out_act, res, d2s)
+    scale_ = float(ref.abs().max())
+    e6 = float((y6.double().cpu() - ref).abs().max())
+    e32 = float((y32.double().cpu() - ref).abs().max())
+    assert_close(y6, ref.float(), rtol=1e-4, atol=1e-4 * max(scale_, 1.0), name="x6 vs fp64")
+    assert e6 <= 3e-6 * max(scale_, 1.0), (e6, scale_)
+    assert e6 <= 5.0 * e32 + 4e-7 * max(scale_, 1.0), (e6, e32, scale_)
+
+
+@pytest.mark.parametrize("cout,cin,h,w,nt,masked", [(64, 64, 8, 32, 2, False), (32, 64, 16, 32, 4, False),
+                                                     (128, 64, 8, 64, 2, True), (64, 32, 4, 32, 1, True),
+                                                     (256, 128, 8, 32, 2, True)])
+def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked):
+    """mode 1: dx = conv_transpose(dy [* (y > 0)], w_eff) * act'(aux) + res, against autograd in fp64."""
+    ops = _ops()
+    n = 2
+    g_ = torch.Generator().manual_seed(cout * 7 + cin)
+    v, g, bias, gamma, beta = _params(cout, cin, 9)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, cin, 0, 0, True)
+    assert wx_d is not None
+    dy = torch.randn(n, cout, h, w, generator=g_).cuda()
+    yfwd = torch.randn(n, cout, h, w, generator=g_).cuda()            # stands for the forward output (ReLU mask source)
+    aux = None if masked else torch.randn(n, cin, h, w, generator=g_).cuda()   # pre-activation input (ELU')
+    res = torch.randn(n, cin, h, w, generator=g_).cuda()
+    d = ops.ConvDesc(N=n, C1=cout, C2=0, Hs=h, Ws=w, M=cin, m_off=0, Mpad=wt_d.shape[1], Ho=h, Wo=w, KH=3, KW=3,
+                     stride=1, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
+                     aux_act=0 if masked else ops.ACT_ELU, aux_slope=0.0, aux_drop_p=0.0, aux_drop_seed=0)
+    dx = torch.empty(n, cin, h, w, device="cuda")
+    os.environ["VUNET_X6_FORCE_NT"] = str(nt)
+    try:
+        ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux),
+                  ops._p(yfwd) if masked else None, ops._p(dx), ops._stream())
+    finally:
+        os.environ.pop("VUNET_X6_FORCE_NT", None)
+    wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
+    dyd = dy.double().cpu()
+    if masked:
+        dyd = dyd * (yfwd.double().cpu() > 0)
+    ref = F.conv_transpose2d(dyd, wd, padding=1)
+    if aux is not None:
+        a = aux.double().cpu()
+        ref = ref * torch.where(a > 0, torch.ones_like(a), a.exp())
+    ref = ref + res.double().cpu()
+    assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0), name="dx")
+    assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * max(float(ref.abs().max()), 1.0)
+
+
+def test_x6_second_source_gradient_uses_column_offset():
+    """The data gradient of the second source of a two-source layer reads the weight image at m_off = C1."""
+    ops = _ops()
+    n, c1, c2, cout, h, w = 2, 32, 64, 64, 8, 32
+    g_ = torch.Generator().manual_seed(77)
+    v, g, bias, gamma, beta = _params(cout, c1 + c2, 3)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, c1, c2, 0, True)
+    dy = torch.randn(n, cout, h, w, generator=g_).cuda()
+    d = ops.ConvDesc(N=n, C1=cout, C2=0, Hs=h, Ws=w, M=c2, m_off=c1, Mpad=wt_d.shape[1], Ho=h, Wo=w, KH=3, KW=3,
+                     stride=1, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
+    dx = torch.empty(n, c2, h, w, device="cuda")
+    ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, None, None, None, ops._p(dx),
+              ops._stream())
+    wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
+    ref = F.conv_transpose2d(dy.double().cpu(), wd[:, c1:], padding=1)
+    assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0), name="dx2")
+
+
+def test_x6_unsupported_geometries_are_refused_not_miscomputed():
+    ops = _ops()
+    lib = ops._lib.lib()
+
+    def desc(**kw):
+        base = dict(N=1, C1=32, C2=0, Hs=8, Ws=32, M=32, m_off=0, Mpad=32, Ho=8, Wo=32, KH=3, KW=3, stride=1, pad=1,
+                    mode=0, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
+        base.update(kw)
+        return ops.ConvDesc(**base)
+    assert lib.vunet_conv2d_x6_supported(ctypes.byref(desc()), 0) == 1
+    for bad in (dict(C1=24), dict(C1=3), dict(Ws=16, Wo=16), dict(Hs=6, Ho=6), dict(stride=2, Ho=4, Wo=16),
+                dict(KH=1, KW=1, pad=0), dict(M=3), dict(in_act=4), dict(mode=1, in_act=1), dict(m_off=16)):
+        assert lib.vunet_conv2d_x6_supported(ctypes.byref(desc(**bad)), 0) == 0, bad
+    x = torch.randn(1, 24, 8, 32, device="cuda")
+    y = torch.empty(1, 32, 8, 32, device="cuda")
+    wx = torch.zeros(1024, device="cuda", dtype=torch.int32)
+    rc = lib.vunet_conv2d_x6(ctypes.byref(desc(C1=24)), ops._p(x), None, ops._p(wx), None, None, None, None, ops._p(y),
+                             ops._stream())
+    assert rc == -3   # VUNET_ERR_UNSUPPORTED
+
+
+def test_fused_conv_takes_the_x6_path_and_matches_the_f32_path():
+    """Through ops.fused_conv + autograd at a size the dispatcher routes to the split-bf16 kernels: forward, input and
+    parameter gradients agree with the fp32-MFMA path to fp32 accuracy, and the profiler sees conv_x6_kernel."""
+    ops = _ops()
+    from behavior_driven_video_synthesis_amd.lib.modules import VunetRNB
+    torch.manual_seed(5)
+    blk = VunetRNB(64, a_channels=64, residual=True, dropout_prob=0.05).cuda().train()
+    x = torch.randn(4, 64, 64, 64, device="cuda")
+    a = torch.randn(4, 64, 64, 64, device="cuda")
+    wgt = torch.randn(4, 64, 64, 64, device="cuda")
+    outs = {}
+    for mode in ("x6", "f32"):
+        ops.set_conv_precision(mode)
+        ops.set_dropout_seed(31)
+        xi, ai = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        blk.zero_grad()
+        ops.profile_start()
+        y = blk(xi, ai)
+        (y * wgt).sum().backward()
+        fam = ops.profile_stop(by_kernel=True)
+        outs[mode] = (y.detach(), xi.grad, ai.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}, fam)
+    ops.set_conv_precision("x6")
+    assert any(k.startswith("conv_x6_kernel") for k in outs["x6"][4]), list(outs["x6"][4])
+    assert not any(k.startswith("conv_x6_kernel") for k in outs["f32"][4]), list(outs["f32"][4])
+    y6, gx6, ga6, gp6, _ = outs["x6"]
+    y3, gx3, ga3, gp3, _ = outs["f32"]
+    assert_close(y6, y3, rtol=2e-5, atol=2e-5 * float(y3.abs().max()), name="y")
+    assert_close(gx6, gx3, rtol=2e-5, atol=2e-5 * float(gx3.abs().max()), name="gx")
+    assert_close(ga6, ga3, rtol=2e-5, atol=2e-5 * float(ga3.abs().max()), name="ga")
+    for k in gp3:
+        assert_close(gp6[k], gp3[k], rtol=1e-4, atol=1e-4 * float(gp3[k].abs().max()) + 1e-7, name=k)
