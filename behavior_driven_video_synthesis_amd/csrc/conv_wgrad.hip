@@ -145,8 +145,19 @@ int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d);
 int vunet_wgrad_tiled_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
                              float* slabs, float* dshift, hipStream_t st);
 
+// conv_wgrad_x6.hip: the same layers on the bf16 matrix cores (fp32-accurate split-bf16 operands)
+bool vunet_wgrad_x6_applicable(const vunet_wgrad_desc* d);
+int vunet_wgrad_x6_nslabs(const vunet_wgrad_desc* d);
+int vunet_wgrad_x6_name(const vunet_wgrad_desc* d, char* name, int len);
+int vunet_wgrad_x6_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
+                          float* dshift, hipStream_t st);
+
 extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len) {
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
+  if (vunet_wgrad_x6_applicable(d)) {
+    vunet_wgrad_x6_name(d, name, len);
+    return VUNET_OK;
+  }
   if (vunet_wgrad_tiled_applicable(d)) {
     if (d->stride == 2) snprintf(name, len, "conv_wgrad_tiled_kernel<2, 2, 3, 2>");
     else snprintf(name, len, "conv_wgrad_tiled_kernel<%d, 4, %d, 1>", d->Cout >= 64 ? 2 : 1, d->KH);
@@ -162,6 +173,7 @@ extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name,
 
 extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
   if (!d) return VUNET_ERR_ARG;
+  if (vunet_wgrad_x6_applicable(d)) return vunet_wgrad_x6_nslabs(d);
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_nslabs(d);
   int T, Ctot, Coutp, nchunks, WM;
   wgrad_geometry(d, T, Ctot, Coutp, nchunks, WM);
@@ -194,6 +206,7 @@ extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, co
   const int64_t in_elems = (int64_t)d->N * (d->C1 > d->C2 ? d->C1 : d->C2) * d->Hs * d->Ws;
   const int64_t out_elems = (int64_t)d->N * d->Cout * d->Ho * d->Wo;
   if (in_elems >= (1ll << 31) || out_elems >= (1ll << 31)) return VUNET_ERR_UNSUPPORTED;
+  if (vunet_wgrad_x6_applicable(d)) return vunet_wgrad_x6_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
   WgradArgs wa;
   wa.d = *d;

@@ -34,7 +34,7 @@ class WgradDesc(ctypes.Structure):
                 ("Ws", ctypes.c_int32), ("Cout", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
                 ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
                 ("in_act", ctypes.c_int32), ("in_slope", ctypes.c_float), ("drop_p", ctypes.c_float),
-                ("drop_seed", ctypes.c_uint32), ("nsplit", ctypes.c_int32)]
+                ("drop_seed", ctypes.c_uint32), ("nsplit", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class WnDesc(ctypes.Structure):
@@ -320,7 +320,8 @@ class ConvPlainWgrad(torch.autograd.Function):
         n, cin, hs, ws = x.shape
         cout, ho, wo = dy.shape[1], dy.shape[2], dy.shape[3]
         wd = WgradDesc(N=n, C1=cin, C2=0, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=stride, pad=pad,
-                       in_act=ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0, nsplit=1)
+                       in_act=ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0, nsplit=1,
+                       flags=0 if _conv_precision["x6"] else 1)
         ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
         wd.nsplit = ns
         ktot = k * k * cin
@@ -674,7 +675,7 @@ class FusedConv(torch.autograd.Function):
         def weight_gradients():
             wd = WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=cfg.stride,
                            pad=cfg.pad, in_act=cfg.in_act, in_slope=cfg.in_slope, drop_p=cfg.drop_p,
-                           drop_seed=cfg.drop_seed, nsplit=1)
+                           drop_seed=cfg.drop_seed, nsplit=1, flags=0 if _conv_precision["x6"] else 1)
             ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
             if ns < 1:
                 raise RuntimeError(f"vunet_conv2d_wgrad_nsplit failed with code {ns}")

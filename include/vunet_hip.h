@@ -138,6 +138,9 @@ typedef struct vunet_wgrad_desc {
   float drop_p;
   uint32_t drop_seed;
   int32_t nsplit;
+  int32_t flags;        /* bit 0: keep this problem on the fp32-input MFMA kernels (default: the fp32-accurate
+                           split-bf16 kernel csrc/conv_wgrad_x6.hip wherever it applies: 3x3 / stride 1 / pad 1,
+                           channel counts in 32s, Ws % 32 == 0, Hs % 4 == 0) */
 } vunet_wgrad_desc;
 
 int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,

@@ -239,3 +239,73 @@ def test_fused_conv_takes_the_x6_path_and_matches_the_f32_path():
     assert_close(ga6, ga3, rtol=2e-5, atol=2e-5 * float(ga3.abs().max()), name="ga")
     for k in gp3:
         assert_close(gp6[k], gp3[k], rtol=1e-4, atol=1e-4 * float(gp3[k].abs().max()) + 1e-7, name=k)
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,h,w,in_act,drop", [
+    (2, 32, 0, 32, 8, 32, 0, 0.0),      # MTW 1: four waves fold one m-tile
+    (2, 32, 32, 32, 8, 64, 1, 0.05),    # two sources, ELU + dropout prologue, two column tiles (halo columns live)
+    (1, 64, 0, 64, 12, 32, 1, 0.0),     # MTW 2, three row tiles (top / interior / bottom halo rows)
+    (3, 64, 64, 128, 4, 96, 1, 0.1),    # MTW 2, two co-blocks, three column tiles
+    (2, 32, 0, 96, 8, 32, 0, 0.0),      # Cout = 96: not a multiple of 64 -> MTW 1, three co-blocks
+])
+def test_x6_weight_gradient_vs_fp64(n, c1, c2, cout, h, w, in_act, drop):
+    """conv_wgrad_x6_kernel: slabs summed by vunet_weightnorm_bwd (kind 1: plain dW) against fp64 autograd, beside the
+    fp32-MFMA weight-gradient kernel on the same problem."""
+    ops = _ops()
+    g_ = torch.Generator().manual_seed(n * 1000 + c1 + cout)
+    x1 = torch.randn(n, c1, h, w, generator=g_).cuda()
+    x2 = torch.randn(n, c2, h, w, generator=g_).cuda() if c2 else None
+    dy = torch.randn(n, cout, h, w, generator=g_).cuda()
+    seed = 0xBEEF
+    ctot, ktot = c1 + c2, 9 * (c1 + c2)
+
+    def run(flags):
+        wd = ops.WgradDesc(N=n, C1=c1, C2=c2, Hs=h, Ws=w, Cout=cout, Ho=h, Wo=w, KH=3, KW=3, stride=1, pad=1,
+                           in_act=in_act, in_slope=0.0, drop_p=drop, drop_seed=seed, nsplit=1, flags=flags)
+        buf = ctypes.create_string_buffer(96)
+        ops._call("vunet_conv2d_wgrad_variant", ctypes.byref(wd), buf, 96)
+        ns = ops._lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
+        assert ns >= 1
+        wd.nsplit = ns
+        cp = ops._r32(cout)
+        slabs = torch.full((ns * cp * ktot + ns * cp,), float("nan"), device="cuda")
+        dshift = slabs[ns * cp * ktot:]
+        ops._call("vunet_conv2d_wgrad", ctypes.byref(wd), ops._p(x1), ops._p(x2), ops._p(dy), ops._p(slabs),
+                  ops._p(dshift), ops._stream())
+        dw = torch.empty(cout, ctot, 3, 3, device="cuda")
+        db = torch.empty(cout, device="cuda")
+        v = torch.zeros(cout, ctot, 3, 3, device="cuda")
+        work = torch.empty(cout * (ktot + 1), device="cuda")
+        wn = ops.WnDesc(cout, c1, c2, 3, 3, 1)
+        ops._call("vunet_weightnorm_bwd", ctypes.byref(wn), ops._p(slabs), ops._p(dshift), ns, ops._p(v), None, None,
+                  None, None, ops._p(dw), None, ops._p(db), None, None, ops._p(work), 0, ops._stream())
+        torch.cuda.synchronize()
+        return dw, db, buf.value.decode()
+
+    dw6, db6, name6 = run(0)
+    dw3, db3, name3 = run(1)
+    assert name6.startswith("conv_wgrad_x6_kernel") and not name3.startswith("conv_wgrad_x6_kernel"), (name6, name3)
+    # fp64 reference: the same prologue as the forward, then autograd of the convolution w.r.t. the weight
+    xs = []
+    for i, x in enumerate((x1, x2)):
+        if x is None:
+            continue
+        t = x.double().cpu()
+        if in_act == ops.ACT_ELU:
+            t = F.elu(t)
+        if drop > 0:
+            s = seed if i == 0 else (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF
+            t = t * dropout_keep_mask(tuple(x.shape), drop, s).double() * float(torch.tensor(1.0 / (1.0 - drop),
+                                                                                             dtype=torch.float32))
+        xs.append(t)
+    xin = torch.cat(xs, dim=1)
+    wz = torch.zeros(cout, ctot, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xin, wz, padding=1) * dy.double().cpu()).sum().backward()
+    ref = wz.grad
+    scale_ = float(ref.abs().max())
+    e6 = float((dw6.double().cpu() - ref).abs().max())
+    e3 = float((dw3.double().cpu() - ref).abs().max())
+    assert e6 <= 3e-6 * scale_, (e6, scale_)
+    assert e6 <= 5.0 * e3 + 4e-7 * scale_, (e6, e3, scale_)
+    refb = dy.double().cpu().sum(dim=(0, 2, 3))
+    assert_close(db6, refb.float(), rtol=1e-5, atol=1e-5 * float(refb.abs().max()), name="dshift")
