@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -82,6 +83,13 @@ static inline InAct make_inact(int act, float slope, float p, uint32_t seed) {
   }
   return a;
 }
+
+// Process-start switches (VUNET_NO_*): read once, not per launch.
+#define VUNET_ENV_FLAG(fn, name)                              \
+  static inline bool fn() {                                   \
+    static const bool on = getenv(name) != nullptr;           \
+    return on;                                                \
+  }
 
 static inline int vunet_check_launch() {
   hipError_t e = hipGetLastError();

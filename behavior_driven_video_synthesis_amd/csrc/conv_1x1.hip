@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256, 3) void conv_1x1_kernel(const GatherArgs a, co
   for (int mt = 0; mt < MT; ++mt) store_tile16(a, g, m0 + mt * 32, h, acc[mt]);
 }
 
+VUNET_ENV_FLAG(env_no_1x1, "VUNET_NO_1X1")
 bool vunet_conv_1x1_applicable(const vunet_conv_desc* d, int pro) {
-  return getenv("VUNET_NO_1X1") == nullptr && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
+  return !env_no_1x1() && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
          d->Hs == d->Ho && d->Ws == d->Wo && (d->Hs * d->Ws) % 32 == 0 && d->C1 % 32 == 0 && d->C2 % 32 == 0 &&
          pro != 3 && (d->mode == 0 || pro == 0);
 }

@@ -345,6 +345,9 @@ bool vunet_conv_1x1_applicable(const vunet_conv_desc* d, int pro);
 int vunet_conv_1x1_launch(const GatherArgs& ga, int pro, hipStream_t st);
 int vunet_conv_1x1_name(const vunet_conv_desc* d, int pro, char* name, int len);
 
+VUNET_ENV_FLAG(env_no_tiled, "VUNET_NO_TILED")
+VUNET_ENV_FLAG(env_no_phase, "VUNET_NO_PHASE")
+
 static int prologue_code(const vunet_conv_desc* d) {
   if (d->in_act == ACT_NONE && d->drop_p <= 0.f) return 0;
   if (d->in_act == ACT_ELU && d->drop_p <= 0.f) return 1;
@@ -361,7 +364,7 @@ static bool use_1x1(const vunet_conv_desc* d, int pro) {
 
 static bool use_tiled(const vunet_conv_desc* d, int pro) {
   int mt_unused;
-  return getenv("VUNET_NO_TILED") == nullptr && vunet_conv_tiled_applicable(d) &&
+  return !env_no_tiled() && vunet_conv_tiled_applicable(d) &&
          (d->mode == 0 ? pro != 4 : (pro == 0 || (pro == 4 && d->stride == 1))) && pro != 3 &&
          vunet_conv_tiled_pick(d, &mt_unused, true) > 0;
 }
@@ -370,7 +373,7 @@ static bool use_tiled(const vunet_conv_desc* d, int pro) {
 extern "C" int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char* name, int32_t len) {
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
   const int pro = prologue_code(d);
-  if (d->mode == 1 && d->stride > 1 && getenv("VUNET_NO_PHASE") == nullptr) {
+  if (d->mode == 1 && d->stride > 1 && !env_no_phase()) {
     snprintf(name, len, "conv_gather_kernel<phase x%d>", d->stride * d->stride);
     return VUNET_OK;
   }
@@ -422,7 +425,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   ga.subW = ga.subHW = 0;
   ga.mask = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (d->mode == 1 && d->stride > 1 && getenv("VUNET_NO_PHASE") == nullptr) {
+  if (d->mode == 1 && d->stride > 1 && !env_no_phase()) {
     // strided data gradient: one launch per output parity, each visiting only its own taps
     const int s = d->stride;
     for (int ph = 0; ph < s; ++ph)

@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const
 }
 
 // which thin kernel (if any) takes this problem: 1 = thin_m, 2 = thin_k, 0 = none
+VUNET_ENV_FLAG(env_no_thin, "VUNET_NO_THIN")
 int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res) {
-  if (getenv("VUNET_NO_THIN") != nullptr || pro != 0 || has_aux || d->C2 != 0 || d->stride != 1 || d->Hs != d->Ho ||
+  if (env_no_thin() || pro != 0 || has_aux || d->C2 != 0 || d->stride != 1 || d->Hs != d->Ho ||
       d->Ws != d->Wo || d->d2s || (long)d->N * d->Hs * d->Ws < 64 * 1024)
     return 0;
   const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;

@@ -267,15 +267,35 @@ class ShapePoseNet:
             self.gan.opt.load_state_dict(ckpt["discriminator"]["opt"])
 
 
+def synthetic_keypoints(batch_size: int, spatial_size: int, n_keypoints: int = 17, seed: int = 42, rank: int = 0):
+    """Synthetic 17-joint skeletons of SURVEY 8(d): joints ~ N(frame centre, (40 px * size / 256)^2), clipped to the
+    frame.  CPU tensor [B, J, 2] (x, y) in pixels."""
+    g = torch.Generator().manual_seed(seed + 1000 * rank + 17)
+    c, sd = 0.5 * spatial_size, 40.0 * spatial_size / 256.0
+    kps = torch.randn(batch_size, n_keypoints, 2, generator=g) * sd + c
+    return kps.clamp_(0.0, float(spatial_size - 1))
+
+
 def synthetic_batch(batch_size: int, spatial_size: int, device, seed: int = 42, n_channels_x: int = 3,
-                    with_regressor: bool = False, reg_steps: int = 5, n_keypoints: int = 17, rank: int = 0):
-    """Synthetic pose+appearance batch of SURVEY 8(d): U(-1,1) image, sparse {-1,+1} stickman mask."""
+                    with_regressor: bool = False, reg_steps: int = 5, n_keypoints: int = 17, rank: int = 0,
+                    stickman: str = "raster", appearance_size: Optional[int] = None):
+    """Synthetic pose + appearance batch of SURVEY 8(d): U(-1,1) target image; the stickman is drawn by the GPU
+    rasteriser (csrc/raster.hip, lib/utils.make_joint_img_batch) from synthetic_keypoints -- planes with the levels
+    {0, 127, 255} / 255 * 2 - 1 like the dataset's (data/base_dataset.py:183-190) -- or, with ``stickman="mask"`` (CPU
+    tensors, no GPU at hand), a sparse {-1, +1} mask with 5 % ones.  ``n_channels_x != 3``: the multi-part appearance
+    input of the DeepFashion / Market configs, ``appearance_size`` square (default: half the image, box_factor 1)."""
     g = torch.Generator().manual_seed(seed + 1000 * rank)
     pose = torch.rand(batch_size, 3, spatial_size, spatial_size, generator=g) * 2 - 1
-    stick = (torch.rand(batch_size, 3, spatial_size, spatial_size, generator=g) < 0.05).float() * 2 - 1
-    batch = {"pose_img": pose.to(device), "stickman": stick.to(device)}
+    mask = (torch.rand(batch_size, 3, spatial_size, spatial_size, generator=g) < 0.05).float() * 2 - 1
+    if stickman == "raster" and torch.device(device).type == "cuda":
+        from ..lib.utils import make_joint_img_batch
+        kps = synthetic_keypoints(batch_size, spatial_size, n_keypoints, seed, rank).to(device)
+        stick = make_joint_img_batch((spatial_size, spatial_size), kps)
+    else:
+        stick = mask.to(device)
+    batch = {"pose_img": pose.to(device), "stickman": stick}
     if n_channels_x != 3:
-        xs = spatial_size // 2
+        xs = appearance_size or spatial_size // 2
         batch["pose_img_inplane"] = (torch.rand(batch_size, n_channels_x, xs, xs, generator=g) * 2 - 1).to(device)
     if with_regressor:
         batch["reg_imgs"] = (torch.rand(batch_size, reg_steps, 3, spatial_size, spatial_size, generator=g) * 2 - 1

@@ -10,6 +10,7 @@ for the CPU tests.
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import List, Optional
 
@@ -26,6 +27,8 @@ class BucketedGradAverager:
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("VUNET_DP_FORCE") == "1")
         self.overlap = overlap
         self._works = []
+        self._comm_stream = None          # HIP stream the bucket all-reduces are ordered on (GPU only)
+        self._events = collections.deque(maxlen=16)   # per step: [(start, end) HIP events on that stream, one pair per collective]
         self._pending: List[int] = []
         self._expected: List[Optional[int]] = [None] * len(self.buckets)  # learnt on the first step
         self._fired: List[int] = [0] * len(self.buckets)
@@ -60,16 +63,38 @@ class BucketedGradAverager:
         self._launched[bi] = True
         self._fired_at_launch[bi] = self._fired[bi]
         b = self.buckets[bi]
-        if b.grad.is_cuda:
-            from . import ops
-            ops.join_wgrad_streams()   # in-place gradient writes of backward's companion streams come first
         b.gather_foreign_grads()
-        self._works.append(dist.all_reduce(b.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._all_reduce(b.grad)
+
+    def _all_reduce(self, t: torch.Tensor):
+        """Asynchronous SUM all-reduce of ``t``.  On the GPU the collective is ordered on ONE dedicated communication
+        stream, whichever stream the calling autograd hook happens to run on: that stream first waits for the caller's
+        stream and for the weight-gradient companion streams (the in-place gradient writes), RCCL's own stream is chained
+        to it by ``Work.wait()``, and ``finish()`` makes the optimiser's stream wait for it.  A pair of HIP events on the
+        communication stream brackets every collective (``mean_allreduce_ms``)."""
+        if not t.is_cuda:
+            self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            return
+        from . import ops
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        ops.join_wgrad_streams()   # cur now waits for the companion streams' in-place gradient writes
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            work.wait()            # stream-level: the communication stream waits for RCCL's stream, the host does not block
+            e1.record()
+        if self._events:
+            self._events[-1].append((e0, e1))
 
     def start_step(self):
         self._fired = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._events.append([])
 
     def finish(self, extra_scalars: Optional[torch.Tensor] = None):
         """Flush buckets that were not launched from the hooks, wait for all, scale by 1/world.
@@ -89,15 +114,27 @@ class BucketedGradAverager:
             self._expected[bi] = self._fired[bi]   # learnt on the first step, re-learnt if backward fired fewer hooks
             self._launch(bi)
         if extra_scalars is not None:
-            self._works.append(dist.all_reduce(extra_scalars, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._all_reduce(extra_scalars)
         for w in self._works:
             w.wait()
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
         inv = 1.0 / self.world
         for b in self.buckets:
             b.grad.mul_(inv) if not b.grad.is_cuda else _scale_(b.grad, inv)
         if extra_scalars is not None:
             extra_scalars.mul_(inv)
         return extra_scalars
+
+
+    def mean_allreduce_ms(self):
+        """Mean per-step time the communication stream spent in the gradient all-reduces (HIP events around every
+        collective, summed per step); None without a process group.  Synchronises the device."""
+        steps = [ev for ev in self._events if ev]
+        if not self.active or not steps:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for ev in steps for a, b in ev) / len(steps)
 
 
 def _scale_(t: torch.Tensor, a: float):

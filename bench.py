@@ -5,20 +5,28 @@ A "step" is one pass of the hot path over one synthetic batch: VunetAlter 256x25
 perceptual loss (target pass + prediction pass) + KL, backward (dgrad + wgrad), fused Adam -- per-GPU
 batch 16 (BASELINE.json configs[1]; weak scaling: global batch = 16 * N).  Dropout 0.05 is on, the
 regressor side loop is off (flag --regressor turns it on; it adds 5 encoder forwards per step and no
-gradient to the VUnet), VGG19 weights are seeded-synthetic (no network for the pretrained ones).
+gradient to the VUnet), VGG19 weights are seeded-synthetic (no network for the pretrained ones), the
+stickman input is drawn by the GPU rasteriser from synthetic 17-joint skeletons.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every conv-family
-launch in an extra instrumented region after the timed one (so the events do not perturb `value`);
-`cpu_baseline` times the CPU oracle (oracle/vunet_oracle.py, a port) on a bounded sample of the same
-workload on the host cores (rank 0, N=1 only).
+Rank 0 prints ONE JSON line.
+  roofline      measured live with HIP events around every conv-family launch in an extra instrumented region
+                after the timed one (so the events do not perturb `value`); `traffic` comes from the committed
+                rocprofv3 PMC summary profiles/<round>_pmc_traffic.json (tools/profile.sh), named in
+                `traffic_source` with the commit it was collected at, and is null if the dominant kernel is not in it.
+  cpu_baseline  the CPU oracle (oracle/vunet_oracle.py, a port of the reference path, pinned to the reference by
+                tests/golden) timed on this host's cores as BASELINE.md section 4 defines it: the SAME bs-16 256^2
+                step, 1 warm-up + 3 timed steps, median, all cores -- inside a stated time budget (if the budget bites
+                the bs-1 figure is reported as well and said so); plus the config-1 plumbing row (Market 128^2, bs 2,
+                30-channel 64x64 appearance input).  Rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,24 +36,29 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-FLOP_PER_FRAME = 275.6e9       # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
+X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
+FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
+PMC_TRAFFIC = ["profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--regressor", action="store_true", help="run the regressor side loop as the reference config does")
     ap.add_argument("--gan", action="store_true",
                     help="add the PartDiscriminator adversarial term + one discriminator step (not in the reference loop)")
+    ap.add_argument("--precision", choices=["x6", "f32"], default="x6",
+                    help="x6: fp32-accurate split-bf16 convolution kernels where they apply; f32: fp32-input MFMA everywhere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-config1", action="store_true", help="skip the config-1 (Market 128^2, bs 2) plumbing rows")
+    ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of CPU work allowed for the bs-16 baseline")
     return ap.parse_args()
 
 
@@ -55,51 +68,136 @@ def make_config(args):
     cfg = copy.deepcopy(DEFAULT_CONFIG)
     cfg["data"]["spatial_size"] = args.size
     cfg["training"]["batch_size"] = args.batch
-    cfg["training"]["train_regressor"] = bool(args.regressor)
+    cfg["training"]["train_regressor"] = bool(getattr(args, "regressor", False))
     cfg["training"]["gan"]["enabled"] = bool(getattr(args, "gan", False))
     return cfg
 
 
-def cpu_baseline(args, cfg):
-    """The CPU oracle (a port of the reference path) timed on this host's cores on a bounded sample."""
+def market_config():
+    """BASELINE config 1: Market1501, 128x128, bs 2, 30-channel 64x64 appearance input (README.md:103-110)."""
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import DEFAULT_CONFIG
+    import copy
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["data"].update(dataset="Market", spatial_size=128, box_factor=1, bottleneck_factor=1, inplane_normalize=True)
+    cfg["training"].update(batch_size=2, train_regressor=False)
+    return cfg
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _cpu_steps(cfg, batch, n_channels_x, warmup, timed, budget_s):
+    """Time the CPU oracle's training step (VUnet + VGG19 perceptual + KL + torch.optim.Adam) -> list of step times."""
+    import contextlib
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from oracle import vunet_oracle as O
     from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))  # PyTorch-CPU conv stops scaling (and thrashes) far below 256 threads
-    torch.set_num_threads(cores)
     kw = dict(cfg["architecture"])
     kw.update(cfg["data"])
     kw["dropout_prob"] = 0.0
     torch.manual_seed(42)
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):
-        net = VunetAlter(**kw)  # host-side parameter container only: gives the reference's default init + key layout
+        net = VunetAlter(n_channels_x=n_channels_x, **kw)  # host-side parameter container: the reference's default init + keys
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     vsd = O.make_synthetic_vgg19(seed=1234)
     opt = torch.optim.Adam([{"params": [v for k, v in sd.items() if k.startswith(n + ".")], "name": n}
                             for n in ("eu", "ed", "du", "dd")], lr=5e-4, betas=(0.5, 0.9))
-    b, s = args.cpu_batch, args.size
-    g = torch.Generator().manual_seed(42)
-    x = torch.rand(b, 3, s, s, generator=g) * 2 - 1
-    c = (torch.rand(b, 3, s, s, generator=g) < 0.05).float() * 2 - 1
-    times, budget, t_start = [], 30.0, time.perf_counter()
-    for it in range(1 + args.cpu_steps):
+    target = batch["pose_img"].cpu()
+    c = batch["stickman"].cpu()
+    x = batch.get("pose_img_inplane", batch["pose_img"]).cpu()
+    times, t_start = [], time.perf_counter()
+    for it in range(warmup + timed):
         t0 = time.perf_counter()
-        loss, ll, kl, _ = O.train_step_losses(sd, kw, vsd, [1.0] * 6, x, c, x, None, 0.0, it + 10, 4)
+        img, means, logstds, _ = O.vunet_alter_forward(sd, kw, x, c, None, n_channels_x=n_channels_x)
+        ld = O.vgg_loss(vsd, [1.0] * 6, target, img)
+        loss = torch.stack(list(ld.values()), dim=0).sum() + 1e-3 * O.compute_kl_with_prior(means, logstds)
         opt.zero_grad()
         loss.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start + times[-1] > budget:  # bounded sample: stop before exceeding ~30 s
+        spent = time.perf_counter() - t_start
+        if it + 1 >= warmup + 1 and spent + times[-1] > budget_s:   # the next step would overrun the budget
             break
-    t = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": b / t, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"fastest of {max(len(times) - 1, 1)} timed step(s) ({len(times)} run, ~30 s budget) of the same "
-                      f"training step at {s}x{s}, batch {b}, dropout off, PyTorch-CPU fp32 oracle, {cores} threads"}
+    return times[warmup:] if len(times) > warmup else times
+
+
+def cpu_baseline(args, cfg, batch, cfg1, batch1):
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    b, s = batch["pose_img"].shape[0], args.size
+    t16 = _cpu_steps(cfg, batch, 3, 1, 3, args.cpu_budget)
+    out = {"value": b / statistics.median(t16), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"median of {len(t16)} timed step(s) after 1 warm-up of the SAME training step (VunetAlter {s}x{s} batch {b} "
+                     f"fwd+bwd, VGG19 perceptual + KL, torch.optim.Adam; dropout off) on the PyTorch-CPU fp32 oracle, "
+                     f"{cores} threads, budget {args.cpu_budget:.0f} s",
+           "step_seconds": [round(t, 3) for t in t16]}
+    if len(t16) < 3:   # the budget bit: add the cheap bs-1 figure and say so
+        one = {k: v[:1] for k, v in batch.items()}
+        t1 = _cpu_steps(cfg, one, 3, 1, 2, 30.0)
+        out["batch1"] = {"value": 1.0 / statistics.median(t1), "unit": "frames/s",
+                         "sample": f"batch 1, median of {len(t1)} step(s): reported because fewer than 3 bs-{b} steps fit the budget"}
+    if cfg1 is not None:
+        t = _cpu_steps(cfg1, batch1, 30, 2, 10, 40.0)
+        out["config1"] = {"value": batch1["pose_img"].shape[0] / statistics.median(t), "unit": "frames/s",
+                          "sample": f"BASELINE config 1 (Market 128x128, batch 2, x = 30x64x64): median of {len(t)} timed "
+                                    "step(s) after 2 warm-ups, same oracle / threads"}
+    return out
+
+
+def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
+    is_x6 = "x6" in dom
+    peak = BF16_MFMA_PEAK_TFLOPS / X6_PRODUCTS if is_x6 else FP32_MFMA_PEAK_TFLOPS
+    ach = kern[dom]["flop"] / (kern[dom]["ms"] * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+         "peak_basis": ("fp32-accurate split-bf16 kernel: dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic MAC "
+                        "block (csrc/conv_x6_kernel.h); `achieved` counts ALGORITHMIC fp32 FLOPs" if is_x6 else
+                        "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"),
+         "achieved_vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+         "mfma_issued_tflops": ach * (X6_PRODUCTS if is_x6 else 1),
+         "traffic": None,
+         "launches_per_step": kern[dom]["n"] // prof_steps,
+         "avg_launch_us": 1e3 * kern[dom]["ms"] / kern[dom]["n"],
+         "algorithmic_gflop_per_launch": kern[dom]["flop"] / kern[dom]["n"] / 1e9,
+         "share_of_conv_time": kern[dom]["ms"] / tot_ms,
+         "families": {k: {"ms_per_step": v["ms"] / prof_steps, "launches_per_step": v["n"] // prof_steps,
+                          "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
+                      for k, v in fam.items()},
+         "kernels": {k: {"ms_per_step": round(v["ms"] / prof_steps, 3), "avg_launch_us": round(1e3 * v["ms"] / v["n"], 1),
+                         "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                     for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:20]},
+         "conv_ms_per_step": tot_ms / prof_steps,
+         "whole_step_tflops": FLOP_PER_FRAME * batch / (1e-3 * ms_per_step) / 1e12}
+    r["whole_step_vs_fp32_mfma_peak"] = r["whole_step_tflops"] / FP32_MFMA_PEAK_TFLOPS
+    # HBM traffic per launch of the dominant kernel: separate rocprofv3 PMC passes (tools/profile.sh), committed summary
+    for rel in PMC_TRAFFIC:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        ent = pmc.get("kernels", {}).get(dom)
+        if ent is not None:
+            r["traffic"] = ent["hbm_bytes_per_launch"]
+            r["traffic_source"] = {"file": rel, "collected_at_commit": pmc.get("head", ""), "correction": pmc.get("correction", "")}
+        else:
+            r["traffic_source"] = {"file": rel, "note": f"no entry for {dom}: traffic not reported (re-run tools/profile.sh)"}
+        break
+    return r
+
+
+def timed_steps(trainer, batch, warmup, steps, sync_all):
+    for _ in range(warmup):
+        trainer.train_fn(batch)
+    sync_all()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = trainer.train_fn(batch)
+    sync_all()
+    return time.perf_counter() - t0, out
 
 
 def main():
@@ -115,6 +213,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
+    ops.set_conv_precision(args.precision)
 
     cfg = make_config(args)
     import contextlib
@@ -127,14 +226,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.train_fn(batch)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = trainer.train_fn(batch)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed, out = timed_steps(trainer, batch, args.warmup, args.steps, sync_all)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,15 +238,21 @@ def main():
         "metric": "frames/sec VUnet 256x256 bs=16 fwd+bwd", "value": world * args.batch * args.steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": ("f32 (operands split exactly into 3 bf16 terms, 6 partial products on bf16 MFMA, fp32 accumulate; "
+                  "fp32-input MFMA / fp32 VALU for the layers the split kernels do not cover)" if args.precision == "x6"
+                  else "f32"),
+        "data": "synthetic",
         "config": {"workload": f"Human3.6m shape_and_pose_net VunetAlter {args.size}x{args.size} per-GPU bs={args.batch} "
                                "fwd+bwd, VGG19 perceptual + KL loss, fused Adam, dropout 0.05"
                                + (", regressor side loop on" if args.regressor else ", regressor side loop off")
                                + (", adversarial term on" if args.gan else "")
-                               + ", seeded-synthetic VGG19 weights",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                               + ", seeded-synthetic VGG19 weights, rasterised synthetic stickmen",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_precision": args.precision,
                    "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val,
-                   "hip_streams": 1 if trainer.vunet._side_stream is None else 4},
+                   "hip_streams": 1 if trainer.vunet._side_stream is None else 4,
+                   "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                   "allreduce_ms_per_step": trainer.averager.mean_allreduce_ms()},
     }
 
     if not args.no_roofline:
@@ -181,35 +279,24 @@ def main():
         kern = ops.profile_stop(by_kernel=True)            # per kernel instantiation, rocprofv3 spelling
         tot_ms = sum(v["ms"] for v in fam.values())
         dom = max(kern, key=lambda k: kern[k]["ms"])
-        ach = kern[dom]["flop"] / (kern[dom]["ms"] * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                              "launches_per_step": kern[dom]["n"] // prof_steps,
-                              "avg_launch_us": 1e3 * kern[dom]["ms"] / kern[dom]["n"],
-                              "algorithmic_gflop_per_launch": kern[dom]["flop"] / kern[dom]["n"] / 1e9,
-                              "share_of_conv_time": kern[dom]["ms"] / tot_ms,
-                              "families": {k: {"ms_per_step": v["ms"] / prof_steps, "launches_per_step": v["n"] // prof_steps,
-                                               "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
-                                           for k, v in fam.items()},
-                              "kernels": {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
-                                              "avg_launch_us": round(1e3 * v["ms"] / v["n"], 1),
-                                              "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                                          for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:20]},
-                              "conv_ms_per_step": tot_ms / prof_steps,
-                              "whole_step_tflops": FLOP_PER_FRAME * args.batch / (1e-3 * result["ms_per_step"]) / 1e12}
-        # HBM traffic per launch of the dominant kernel: PMC passes collected separately (tools/pmc_summary.py)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            ent = pmc["kernels"].get(dom)
-            if ent is not None:
-                result["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json: " + pmc["correction"]
-        except (OSError, ValueError, KeyError):
-            pass
+        result["roofline"] = roofline_entry(kern, fam, dom, tot_ms, prof_steps, result["ms_per_step"], args.batch)
     elif not args.no_roofline:
         ops.profile_stop()
+
+    # BASELINE config 1 (Market 128^2, bs 2, 30-channel 64x64 appearance input): plumbing rows, GPU and CPU
+    cfg1 = batch1 = None
+    if rank == 0 and world == 1 and not args.no_config1:
+        cfg1 = market_config()
+        with contextlib.redirect_stdout(sys.stderr):
+            tr1 = ShapePoseNet(cfg1, device=device, n_channels_x=30, total_steps=150000, vgg_synthetic=True)
+        batch1 = synthetic_batch(2, 128, device, seed=42, n_channels_x=30, appearance_size=64)
+        el1, out1 = timed_steps(tr1, batch1, 5, 20, torch.cuda.synchronize)
+        result["config1"] = {"workload": "Market1501 shape_and_pose_net VunetAlter 128x128 bs=2, x = 30x64x64 (BASELINE configs[0])",
+                             "value": 2 * 20 / el1, "unit": "frames/s", "ms_per_step": 1e3 * el1 / 20,
+                             "final_loss": float(out1["loss"])}
+        del tr1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, cfg)
+        result["cpu_baseline"] = cpu_baseline(args, cfg, batch, cfg1, batch1)
     if rank == 0:
         print(json.dumps(result))
     if dist.is_initialized():

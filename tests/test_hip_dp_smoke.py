@@ -21,3 +21,28 @@ def test_bench_under_torchrun_with_forced_dp_path():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+    assert out["config"]["rccl_world_size"] == 1 and out["config"]["allreduce_ms_per_step"] > 0   # events on the comm stream
+
+
+def test_forced_one_rank_rccl_run_equals_the_plain_run(tmp_path):
+    """tools/dp_check.py with one rank under torchrun (hooks, communication stream, RCCL all-reduce of every bucket, the
+    averaged KL scalar) against the same steps without a process group: a one-rank SUM / 1 changes nothing, so the
+    parameters must come out bit-identical -- any ordering bug between the weight-gradient companion streams, the
+    communication stream and the optimiser's stream would show here."""
+    import torch
+    env = dict(os.environ, VUNET_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = os.path.join(ROOT, "tools", "dp_check.py")
+    out = str(tmp_path)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29519", script, "--out", out, "--steps", "4"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env.pop("VUNET_DP_FORCE")
+    r = subprocess.run([sys.executable, script, "--single", "--world", "1", "--out", out, "--steps", "4"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = torch.load(os.path.join(out, "rank0.pt")), torch.load(os.path.join(out, "single.pt"))
+    assert a["allreduce_ms"] is not None and b["allreduce_ms"] is None
+    assert a["losses"] == b["losses"] and a["gamma"] == b["gamma"]
+    for x, y in zip(a["flat"], b["flat"]):
+        assert torch.equal(x, y)

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Profiles of the bench.py step on the GPU box (run through gpurun from the repo root):
+#
+#     gpurun --timeout 1500 -- 'bash tools/profile.sh r02'
+#
+# 1. rocprofv3 --kernel-trace --stats          -> gpurun_out/<tag>_kernel_stats.csv   (per-kernel time of the timed step)
+# 2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE   -> gpurun_out/<tag>_pmc_traffic.json   (HBM bytes per launch; separate
+#    passes and the gfx950 FETCH_SIZE x2 correction, as MI355X_MICROARCH.md "HBM" prescribes)
+# 3. rocprofv3 --pmc SQ_* (one pass)           -> gpurun_out/<tag>_pmc_sq.json        (MFMA-pipe busy / wave cycles)
+# The program itself follows `--` (no env / bash -c hop: the profiler initialises the GPU before the program starts).
+# Copy the summaries you want judged from gpurun_out/ into profiles/ and commit them.
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out
+mkdir -p $OUT
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline"
+
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+cp $(ls $OUT/${TAG}_trace/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
+
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_write.err
+python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_write/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic.json
+
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/${TAG}_sq -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_sq.err
+python3 tools/pmc_summary.py sq $(ls $OUT/${TAG}_sq/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_sq.json
+# the raw per-dispatch tables are large: keep the summaries only
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
+ls -la $OUT/${TAG}_*
