@@ -6,8 +6,11 @@
 // fixed-point edge table), then each thread evaluates, for four adjacent pixels, the *closed forms* of
 // the two OpenCV primitives -- "is (x, y) the pixel LineIterator visits at its major-axis step?" and
 // "does (x, y) fall in an even-odd scan-line span?" -- and keeps the colour of the last command that
-// covers it (draw order = overwrite order).  Pure integer work (plus the double-precision clip
-// intersection OpenCV itself uses): bit-exact against the sequential restatement in
+// covers it (draw order = overwrite order).  Command kinds: 0 body polygon, 1 line between two joints, 4 head line
+// (a line that also feeds the "throat length"), 2 neck line (midpoint of the two shoulders -> head joint, drawn
+// when the model has no head lines, lib/utils.py:407-433), 3 face line (drawn only if shorter than the throat
+// length, :468-505).  Pure integer work (plus the double-precision clip intersection OpenCV itself uses and the
+// float64 midpoint / Euclidean lengths of the neck and face rules): bit-exact against the sequential restatement in
 // oracle/stickman_oracle.c.  Stores are 4 bytes per lane, 256 B per wavefront; the optional fp32 output
 // applies ToTensor and *2-1 (data/base_dataset.py:183-190, data/__init__.py:23-24).
 #include "common.h"
@@ -122,22 +125,41 @@ __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __res
   __shared__ RLine lines[R_MAXCMD];
   __shared__ RPoly poly;
   __shared__ int ckind[R_MAXCMD], cplane[R_MAXCMD], ccolor[R_MAXCMD];
+  __shared__ double clen[R_MAXCMD];   // Euclidean length of the command's segment (float64, as np.linalg.norm)
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* k = kps + (size_t)b * J * 2;
 
   if (tid < n_cmds) {
-    const int* c = cmds + 5 * tid;
+    const int* c = cmds + 6 * tid;    // {kind, joint a, joint b, joint c, plane, colour}
     ckind[tid] = c[0];
-    cplane[tid] = c[3];
-    ccolor[tid] = c[4];
+    cplane[tid] = c[4];
+    ccolor[tid] = c[5];
     RLine L;
     L.valid = 0;
-    if (c[0] == 1) {
+    double len = 0.0;
+    if (c[0] == 1 || c[0] == 3 || c[0] == 4) {
       const float ax = k[2 * c[1]], ay = k[2 * c[1] + 1], bx = k[2 * c[2]], by = k[2 * c[2] + 1];
-      if (ax >= 0.f && ay >= 0.f && bx >= 0.f && by >= 0.f)
+      if (ax >= 0.f && ay >= 0.f && bx >= 0.f && by >= 0.f) {
         L = r_make_line((long long)ax, (long long)ay, (long long)bx, (long long)by, W, H);
+        const double dx = (double)ax - (double)bx, dy = (double)ay - (double)by;
+        len = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+        if (c[0] == 3) L.valid |= 2;   // face line: still waits for the throat-length test (bit 1)
+        if (c[0] == 4) L.valid |= 4;   // head line: clipped away or not, a valid one feeds the throat length (bit 2)
+      }
+    } else if (c[0] == 2) {
+      // neck = 0.5 * (rshoulder + lshoulder) if neither has a negative coordinate, else (-1, -1)  (:408-413)
+      const float rx = k[2 * c[1]], ry = k[2 * c[1] + 1], lx = k[2 * c[2]], ly = k[2 * c[2] + 1];
+      const float hx = k[2 * c[3]], hy = k[2 * c[3] + 1];
+      if (rx >= 0.f && ry >= 0.f && lx >= 0.f && ly >= 0.f && hx >= 0.f && hy >= 0.f) {
+        const double nx = 0.5 * ((double)rx + (double)lx), ny = 0.5 * ((double)ry + (double)ly);
+        L = r_make_line((long long)nx, (long long)ny, (long long)hx, (long long)hy, W, H);
+        const double dx = nx - (double)hx, dy = ny - (double)hy;
+        len = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+        L.valid |= 4;                  // drawn or not, a valid neck segment defines the throat length
+      }
     }
     lines[tid] = L;
+    clen[tid] = len;
   }
   if (tid == 255) {  // the body polygon (shared by every polygon command)
     RPoly P;
@@ -179,6 +201,17 @@ __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __res
       P.fill_valid = P.ne >= 2 && !(ymax < 0 || ymin >= H || xmax < 0 || xmin >= ((long long)W << XY_SHIFT));
     }
     poly = P;
+  }
+  __syncthreads();
+  if (tid == 0) {   // throat length = longest valid head / neck segment (:415-417, :466-467); then the face-line test
+    double throat = 0.0;
+    for (int c = 0; c < n_cmds; ++c)
+      if ((ckind[c] == 2 || ckind[c] == 4) && (lines[c].valid & 4)) throat = fmax(throat, clen[c]);
+    for (int c = 0; c < n_cmds; ++c) {
+      int v = lines[c].valid;
+      if (ckind[c] == 3) v = ((v & 2) && clen[c] < throat) ? (v & 1) : 0;
+      lines[c].valid = v & 1;
+    }
   }
   __syncthreads();
 

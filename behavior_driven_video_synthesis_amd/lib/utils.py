@@ -41,39 +41,85 @@ from collections import namedtuple  # noqa: E402
 
 import torch  # noqa: E402
 
-JointModel = namedtuple("JointModel", "body right_lines left_lines head_lines face")
+_JM_FIELDS = "body right_lines left_lines head_lines face rshoulder lshoulder headup"
+JointModel = namedtuple("JointModel", _JM_FIELDS, defaults=(None, None, None))
+"""The drawing fields of the reference's JointModel (lib/utils.py:23-26); any object with these attributes works."""
 
 # data/human36m.py:137-148, keypoint_type keypoints_3d_world (the shipped Human3.6m config)
 H36M_JOINT_MODEL = JointModel(body=[0, 14, 8, 11, 3],
                               right_lines=[(0, 1), (1, 2), (0, 14), (14, 15), (15, 16)],
                               left_lines=[(3, 4), (4, 5), (3, 11), (11, 12), (12, 13)],
                               head_lines=[(8, 9), (9, 10)], face=[])
+# data/deepfashion.py:25-34 (18 OpenPose-style joints; no head lines: the neck branch draws shoulder-midpoint -> nose)
+DEEPFASHION_JOINT_MODEL = JointModel(body=[8, 2, 5, 11], right_lines=[(10, 9), (9, 8), (2, 3), (3, 4)],
+                                     left_lines=[(13, 12), (12, 11), (5, 6), (6, 7)], head_lines=[],
+                                     face=[(0, 14), (0, 15), (14, 16), (15, 17)], rshoulder=2, lshoulder=5, headup=0)
+# data/market.py:24-32 (BASELINE config 1)
+MARKET_JOINT_MODEL = JointModel(body=[8, 9, 3, 2], right_lines=[(0, 1), (1, 2), (6, 7), (7, 8)],
+                                left_lines=[(3, 4), (4, 5), (9, 10), (10, 11)], head_lines=[],
+                                face=[(13, 14), (13, 15), (14, 16), (15, 17)], rshoulder=8, lshoulder=9, headup=13)
+
+K_POLY, K_LINE, K_NECK, K_FACE, K_HEAD = 0, 1, 2, 3, 4   # command kinds of csrc/raster.hip
 
 
-def stickman_draw_list(joint_model):
-    """Draw list of make_joint_img's default branch (no line_colors / color_channel, thickness 1), in the
-    reference's draw order: body polygon (0,127,255) on planes (0,1,2) (:345-355), right limbs 255 on plane 1
-    (:357-380), left limbs 255 on plane 0 (:382-405), head lines 127 on planes 0 and 1 (:434-462)."""
-    if len(joint_model.head_lines) == 0 or len(joint_model.face) > 0:
-        raise NotImplementedError("neck / face branches of make_joint_img (lib/utils.py:407-433,468-505) are not built")
+def _line_color(line_colors, group, nr):
+    """(plane, colour) of make_joint_img's ``line_colors`` rule: the plane is the index of the non-zero entry of the
+    line's colour triple, the colour that entry (lib/utils.py:365-373)."""
+    triple = np.asarray(line_colors[group][nr])
+    nz = np.nonzero(triple)[0]
+    if len(nz) != 1:
+        raise ValueError("line_colors entries must have exactly one non-zero channel (the reference calls int() on it)")
+    return int(nz[0]), int(triple[nz[0]])
+
+
+def stickman_draw_list(joint_model, line_colors=None, color_channel=None):
+    """make_joint_img (lib/utils.py:325-512) as a draw list ``[kind, a, b, c, plane, colour]`` in the reference's draw
+    order: body polygon (:345-355), right limbs (:357-380), left limbs (:382-405), then the neck line of a model
+    without head lines (:407-433) or its head lines (:434-467), then the face lines (:468-505).  Defaults: polygon
+    (0, 127, 255) on planes (0, 1, 2), right limbs 255 on plane 1, left limbs 255 on plane 0, head / neck / face
+    lines 127 on planes 0 and 1; ``line_colors`` gives every limb / head / face line its own (plane, colour);
+    ``color_channel`` draws everything with 255 on that one plane."""
     cmds = []
+    one = color_channel is not None
     if len(joint_model.body) > 2:
-        for plane, color in enumerate((0, 127, 255)):
-            cmds.append((0, 0, 0, plane, color))
-    for a, b in joint_model.right_lines:
-        cmds.append((1, a, b, 1, 255))
-    for a, b in joint_model.left_lines:
-        cmds.append((1, a, b, 0, 255))
-    for a, b in joint_model.head_lines:
-        cmds.append((1, a, b, 0, 127))
-        cmds.append((1, a, b, 1, 127))
+        if one:
+            cmds.append((K_POLY, 0, 0, 0, int(color_channel), 255))
+        else:
+            for plane, color in enumerate((0, 127, 255)):
+                cmds.append((K_POLY, 0, 0, 0, plane, color))
+
+    def lines(pairs, kind, group, default):
+        for nr, (a, b) in enumerate(pairs):
+            if one:
+                cmds.append((kind, a, b, 0, int(color_channel), 255))
+            elif line_colors is not None:
+                plane, color = _line_color(line_colors, group, nr)
+                cmds.append((kind, a, b, 0, plane, color))
+            else:
+                for plane, color in default:
+                    cmds.append((kind, a, b, 0, plane, color))
+
+    lines(joint_model.right_lines, K_LINE, 0, [(1, 255)])
+    lines(joint_model.left_lines, K_LINE, 1, [(0, 255)])
+    if len(joint_model.head_lines) == 0:
+        if joint_model.rshoulder is None or joint_model.lshoulder is None or joint_model.headup is None:
+            raise ValueError("a joint model without head lines needs rshoulder / lshoulder / headup (lib/utils.py:408-410)")
+        rs, ls, hu = int(joint_model.rshoulder), int(joint_model.lshoulder), int(joint_model.headup)
+        for plane, color in ([(int(color_channel), 255)] if one else [(0, 127), (1, 127)]):   # line_colors is not consulted here (:419-424)
+            cmds.append((K_NECK, rs, ls, hu, plane, color))
+    else:
+        lines(joint_model.head_lines, K_HEAD, 2, [(0, 127), (1, 127)])
+    lines(joint_model.face, K_FACE, 2, [(0, 127), (1, 127)])   # the reference indexes line_colors[2] for face lines too (:482)
+    if len(cmds) > 32:
+        raise ValueError("draw list longer than the rasteriser's 32 commands")
     return cmds
 
 
 _raster_tables = {}
 
 
-def make_joint_img_batch(img_shape, joints, joint_model=H36M_JOINT_MODEL, as_float=True):
+def make_joint_img_batch(img_shape, joints, joint_model=H36M_JOINT_MODEL, as_float=True, line_colors=None,
+                         color_channel=None):
     """Batched GPU make_joint_img: joints [B, J, 2] (x, y) device tensor -> [B, 3, H, W].
 
     ``as_float``: planes as fp32 in [-1, 1] (ToTensor then *2-1: data/base_dataset.py:183-190,
@@ -82,9 +128,11 @@ def make_joint_img_batch(img_shape, joints, joint_model=H36M_JOINT_MODEL, as_flo
     h, w = int(img_shape[0]), int(img_shape[1])
     joints = joints.to(torch.float32).contiguous()
     ops._dev(joints)
-    key = (id(joint_model), joints.device)
+    lc_key = None if line_colors is None else repr(np.asarray(line_colors, dtype=object).tolist())
+    key = (id(joint_model), joints.device, lc_key, color_channel)
     if key not in _raster_tables:
-        cmds = torch.tensor(stickman_draw_list(joint_model), dtype=torch.int32, device=joints.device).contiguous()
+        cmds = torch.tensor(stickman_draw_list(joint_model, line_colors, color_channel), dtype=torch.int32,
+                            device=joints.device).contiguous()
         body = torch.tensor(list(joint_model.body), dtype=torch.int32, device=joints.device)
         _raster_tables[key] = (body, cmds)
     body, cmds = _raster_tables[key]
@@ -96,9 +144,17 @@ def make_joint_img_batch(img_shape, joints, joint_model=H36M_JOINT_MODEL, as_flo
 
 
 def make_joint_img(img_shape, joints, joint_model, line_colors=None, color_channel=None, scale_factor=None):
-    """Reference signature (lib/utils.py:325-332): one frame, numpy in / HxWx3 uint8 numpy out."""
-    if line_colors is not None or color_channel is not None or scale_factor is not None:
-        raise NotImplementedError("only the default branch (thickness 1, fixed colours) is built")
+    """Reference signature (lib/utils.py:325-332): one frame, numpy in / HxWx3 uint8 numpy out (HxWx1 float mean when
+    ``img_shape[-1] == 1``, :507-509).  ``scale_factor`` selects thickness ``img_shape[1] // scale_factor`` (:334-339);
+    only thickness 1 is built -- the shipped configs never set ``stickman_scale`` (data/base_dataset.py:163-168), and a
+    thick cv2.line is OpenCV's ThickLine (FillConvexPoly + Circle caps), which this build does not restate."""
+    thickness = int(img_shape[1] // scale_factor) if scale_factor is not None else 1
+    if thickness != 1:
+        raise NotImplementedError("make_joint_img: line thickness > 1 (stickman_scale) is not built")
     j = torch.as_tensor(np.asarray(joints, dtype=np.float32)).unsqueeze(0).cuda()
-    out = make_joint_img_batch(img_shape[:2], j, joint_model, as_float=False)
-    return out[0].permute(1, 2, 0).cpu().numpy()
+    out = make_joint_img_batch(img_shape[:2], j, joint_model, as_float=False, line_colors=line_colors,
+                               color_channel=color_channel)
+    img = out[0].permute(1, 2, 0).cpu().numpy()
+    if len(img_shape) > 2 and img_shape[-1] == 1:
+        img = np.mean(img, axis=-1)[:, :, None]
+    return img

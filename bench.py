@@ -19,9 +19,11 @@ Rank 0 prints ONE JSON line.
                 `traffic_source` with the commit it was collected at, and is null if the dominant kernel is not in it.
   cpu_baseline  the CPU oracle (oracle/vunet_oracle.py, a port of the reference path, pinned to the reference by
                 tests/golden) timed on this host's cores as BASELINE.md section 4 defines it: the SAME bs-16 256^2
-                step, 1 warm-up + 3 timed steps, median, all cores -- inside a stated time budget (if the budget bites
-                the bs-1 figure is reported as well and said so); plus the config-1 plumbing row (Market 128^2, bs 2,
-                30-channel 64x64 appearance input).  Rank 0, N = 1 only.
+                step, 1 warm-up + 3 timed steps, median -- on min(host cores, --cpu-threads = 64) threads (with hundreds
+                of threads PyTorch-CPU thrashes on this path: a run with all 256 did not finish in 35 minutes), inside
+                a stated time budget and in a child process with a hard wall-clock limit (if the budget bites the bs-1
+                figure is reported as well and said so); plus the config-1 plumbing row (Market 128^2, bs 2, 30-channel
+                64x64 appearance input).  Rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -59,6 +61,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the config-1 (Market 128^2, bs 2) plumbing rows")
     ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of CPU work allowed for the bs-16 baseline")
+    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on the CPU baseline's threads")
+    ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -125,27 +129,66 @@ def _cpu_steps(cfg, batch, n_channels_x, warmup, timed, budget_s):
     return times[warmup:] if len(times) > warmup else times
 
 
-def cpu_baseline(args, cfg, batch, cfg1, batch1):
-    cores = host_cores()
+def cpu_baseline_child(path):
+    """Child-process body (no GPU is touched here): time the oracle on the batches the parent saved to ``path``."""
+    job = torch.load(path)
+    cores = job["threads"]
     torch.set_num_threads(cores)
-    b, s = batch["pose_img"].shape[0], args.size
-    t16 = _cpu_steps(cfg, batch, 3, 1, 3, args.cpu_budget)
-    out = {"value": b / statistics.median(t16), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": f"median of {len(t16)} timed step(s) after 1 warm-up of the SAME training step (VunetAlter {s}x{s} batch {b} "
-                     f"fwd+bwd, VGG19 perceptual + KL, torch.optim.Adam; dropout off) on the PyTorch-CPU fp32 oracle, "
-                     f"{cores} threads, budget {args.cpu_budget:.0f} s",
-           "step_seconds": [round(t, 3) for t in t16]}
-    if len(t16) < 3:   # the budget bit: add the cheap bs-1 figure and say so
-        one = {k: v[:1] for k, v in batch.items()}
-        t1 = _cpu_steps(cfg, one, 3, 1, 2, 30.0)
-        out["batch1"] = {"value": 1.0 / statistics.median(t1), "unit": "frames/s",
-                         "sample": f"batch 1, median of {len(t1)} step(s): reported because fewer than 3 bs-{b} steps fit the budget"}
-    if cfg1 is not None:
-        t = _cpu_steps(cfg1, batch1, 30, 2, 10, 40.0)
-        out["config1"] = {"value": batch1["pose_img"].shape[0] / statistics.median(t), "unit": "frames/s",
+    cfg, batch, budget = job["cfg"], job["batch"], job["budget"]
+    b, s = batch["pose_img"].shape[0], batch["pose_img"].shape[-1]
+    one = {k: v[:1] for k, v in batch.items()}
+    t1 = _cpu_steps(cfg, one, 3, 1, 2, 30.0)                      # cheap probe: sizes the bs-16 run against the budget
+    est = b * statistics.median(t1) * 0.8
+    n_timed = max(0, min(3, int(budget / max(est, 1e-3)) - 1))
+    out = {"unit": "frames/s", "cores": cores, "kind": "port"}
+    b1 = {"value": 1.0 / statistics.median(t1), "unit": "frames/s", "sample": f"batch 1, median of {len(t1)} timed step(s) after 1 warm-up"}
+    if n_timed >= 1:
+        t16 = _cpu_steps(cfg, batch, 3, 1, n_timed, budget)
+        out.update(value=b / statistics.median(t16), step_seconds=[round(t, 3) for t in t16],
+                   sample=f"median of {len(t16)} timed step(s) after 1 warm-up of the SAME training step (VunetAlter {s}x{s} "
+                          f"batch {b} fwd+bwd, VGG19 perceptual + KL, torch.optim.Adam; dropout off) on the PyTorch-CPU fp32 "
+                          f"oracle, {cores} threads, budget {budget:.0f} s")
+        if len(t16) < 3:
+            out["batch1"] = dict(b1, note=f"reported as well because only {len(t16)} bs-{b} step(s) fit the budget")
+    else:
+        out.update(value=b1["value"], sample=b1["sample"] + f" -- a bs-{b} step is estimated at {est:.0f} s, over the "
+                   f"{budget:.0f} s budget; same step definition, {cores} threads")
+    if job.get("cfg1") is not None:
+        t = _cpu_steps(job["cfg1"], job["batch1"], 30, 2, 10, 40.0)
+        out["config1"] = {"value": job["batch1"]["pose_img"].shape[0] / statistics.median(t), "unit": "frames/s",
                           "sample": f"BASELINE config 1 (Market 128x128, batch 2, x = 30x64x64): median of {len(t)} timed "
                                     "step(s) after 2 warm-ups, same oracle / threads"}
-    return out
+    print("CPU_BASELINE " + json.dumps(out))
+
+
+def cpu_baseline(args, cfg, batch, cfg1, batch1):
+    """Runs in a fresh child process with a hard wall-clock limit: a CPU step that thrashes (it does with hundreds of
+    threads on this path) can then cost the budget, not the run."""
+    import subprocess
+    import tempfile
+    cores = host_cores()
+    threads = max(1, min(cores, args.cpu_threads))   # PyTorch-CPU conv stops scaling -- and on the small maps thrashes -- far below 256 threads
+    cpu = lambda d: None if d is None else {k: v.detach().cpu() for k, v in d.items()}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "job.pt")
+        torch.save({"cfg": cfg, "batch": cpu(batch), "cfg1": cfg1, "batch1": cpu(batch1), "budget": args.cpu_budget,
+                    "threads": threads}, path)
+        limit = args.cpu_budget + 120.0
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", path], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True)
+        try:
+            so, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
+                    "sample": f"CPU baseline child exceeded its hard limit of {limit:.0f} s and was stopped"}
+    for line in so.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            out = json.loads(line[len("CPU_BASELINE "):])
+            out["host_cores"] = cores
+            return out
+    return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port", "sample": "CPU baseline child failed"}
 
 
 def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
@@ -202,6 +245,8 @@ def timed_steps(trainer, batch, warmup, steps, sync_all):
 
 def main():
     args = parse()
+    if args.cpu_child:
+        return cpu_baseline_child(args.cpu_child)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

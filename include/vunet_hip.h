@@ -260,8 +260,10 @@ int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* str
  * cv2.fillPoly of the body polygon, one launch for a batch of frames (replaces the per-frame CPU raster of
  * data/human36m.py:808-848 and the render loop data/data_conversions_3d.py:1130-1185).
  * kps: [B][J][2] float (x, y) in pixels (a joint is valid iff both >= 0; coordinates are truncated like np.int_);
- * body: [n_body] joint ids of the polygon; cmds: [n_cmds][5] int32 {kind (0 polygon, 1 line), joint a, joint b,
- * plane, colour}, executed in order (later commands overwrite); all device pointers.
+ * body: [n_body] joint ids of the polygon; cmds: [n_cmds][6] int32 {kind, joint a, joint b, joint c, plane, colour},
+ * executed in order (later commands overwrite); kind 0 polygon, 1 line a->b, 4 head line (a line whose length
+ * feeds the throat length, :434-467), 2 neck line midpoint(a, b)->c of the models without head lines (:407-433),
+ * 3 face line a->b drawn only if shorter than the throat length (:468-505); all device pointers.
  * out_u8: [B][3][H][W] uint8 and/or out_f32: the same planes as fp32 (u/255)*2-1; W % 4 == 0.  Integer work,
  * bit-exact. */
 int vunet_stickman_raster(const float* kps, int32_t B, int32_t J, const int32_t* body, int32_t n_body,

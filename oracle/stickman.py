@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "_build", "libstickman_oracle.so")
 def build(force: bool = False) -> str:
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-std=c99", "-o", LIB, SRC], check=True)
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-std=c99", "-o", LIB, SRC, "-lm"], check=True)
     return LIB
 
 
@@ -22,7 +22,7 @@ def raster(kps: np.ndarray, body, cmds, h: int, w: int) -> np.ndarray:
     lib = ctypes.CDLL(build())
     kps = np.ascontiguousarray(kps, dtype=np.float32)
     body = np.ascontiguousarray(body, dtype=np.int32)
-    cmds = np.ascontiguousarray(cmds, dtype=np.int32).reshape(-1, 5)
+    cmds = np.ascontiguousarray(cmds, dtype=np.int32).reshape(-1, 6)
     b, j = kps.shape[:2]
     out = np.zeros((b, 3, h, w), dtype=np.uint8)
     lib.stickman_raster_oracle(kps.ctypes.data_as(ctypes.c_void_p), b, j, body.ctypes.data_as(ctypes.c_void_p),

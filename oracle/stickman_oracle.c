@@ -2,8 +2,10 @@
  * stickman_oracle.c -- CPU restatement of the pose "stickman" rasteriser.  TEST INFRASTRUCTURE ONLY
  * (tests/, __graft_entry__.smoke(), bench.py cpu_baseline); the product never links or calls it.
  *
- * Follows lib/utils.py:325-512 (make_joint_img) of the reference with the parameters the shipped
- * Human3.6m config actually uses: thickness 1, LINE_8, shift 0, no per-line colours;
+ * Follows lib/utils.py:325-512 (make_joint_img) of the reference at thickness 1, LINE_8, shift 0 (the shipped configs
+ * never set stickman_scale) -- every branch of it: per-line colours and the single-channel mode are draw-list
+ * parameters, the neck line of the joint models without head lines and the throat-length-gated face lines are command
+ * kinds of their own (see the draw list below).  Default colours of the Human3.6m model:
  * body polygon -> cv2.fillPoly on planes (0,1,2) with colours (0,127,255) (:345-355); right limbs ->
  * cv2.line colour 255 on plane 1 (:357-380); left limbs -> 255 on plane 0 (:382-405); head lines -> 127
  * on planes 0 and 1 (:434-462); joints are valid iff both coordinates >= 0 and are truncated with
@@ -218,17 +220,50 @@ static void fill_poly(uint8_t* img, int w, int h, const int64_t* vx, const int64
 
 /*
  * Draw list ("commands"), executed in order, per image:
- *   cmds[c] = { kind, a, b, plane, color }    kind 0: polygon over body[0..n_body), kind 1: line joint a -> joint b
+ *   cmds[c] = { kind, a, b, c, plane, color }
+ *     kind 0: polygon over body[0..n_body)                      (lib/utils.py:345-355)
+ *     kind 1: line joint a -> joint b                           (:357-405)
+ *     kind 4: head line, a kind-1 line whose length also enters the throat length (:434-467)
+ *     kind 2: neck line (models without head lines): neck = 0.5 * (joint a + joint b) unless a shoulder has a negative
+ *             coordinate, drawn to joint c; its length is the throat length (:407-433)
+ *     kind 3: face line a -> b, drawn only if its length is < the throat length (:468-505)
+ *   Lengths and the neck midpoint are float64 like numpy's (np.linalg.norm = sqrt(dx*dx + dy*dy)).
  * kps: [B][J][2] float (x, y); out: [B][3][H][W] uint8, zero-initialised here.
  */
+#include <math.h>
+
+static int joint_ok(const float* k, int j) { return k[2 * j] >= 0.f && k[2 * j + 1] >= 0.f; }
+
+static double seg_len(double ax, double ay, double bx, double by) {
+  volatile double dx = ax - bx, dy = ay - by;   /* volatile: no fused multiply-add, every product rounded like numpy's */
+  volatile double sx = dx * dx, sy = dy * dy;
+  volatile double s = sx + sy;
+  return sqrt(s);
+}
+
 void stickman_raster_oracle(const float* kps, int B, int J, const int32_t* body, int n_body, const int32_t* cmds,
                             int n_cmds, uint8_t* out, int H, int W) {
   memset(out, 0, (size_t)B * 3 * H * W);
   for (int b = 0; b < B; ++b) {
     const float* k = kps + (size_t)b * J * 2;
+    /* throat length first: it only depends on the joints (:415-417, :437-467) */
+    double throat = 0.0;
     for (int c = 0; c < n_cmds; ++c) {
-      const int32_t* cmd = cmds + 5 * c;
-      uint8_t* plane = out + ((size_t)b * 3 + cmd[3]) * H * W;
+      const int32_t* cmd = cmds + 6 * c;
+      if (cmd[0] == 4 && joint_ok(k, cmd[1]) && joint_ok(k, cmd[2])) {
+        const double l = seg_len(k[2 * cmd[1]], k[2 * cmd[1] + 1], k[2 * cmd[2]], k[2 * cmd[2] + 1]);
+        if (l > throat) throat = l;
+      } else if (cmd[0] == 2 && joint_ok(k, cmd[1]) && joint_ok(k, cmd[2]) && joint_ok(k, cmd[3])) {
+        const double nx = 0.5 * ((double)k[2 * cmd[1]] + (double)k[2 * cmd[2]]);
+        const double ny = 0.5 * ((double)k[2 * cmd[1] + 1] + (double)k[2 * cmd[2] + 1]);
+        const double l = seg_len(nx, ny, k[2 * cmd[3]], k[2 * cmd[3] + 1]);
+        if (l > throat) throat = l;
+      }
+    }
+    for (int c = 0; c < n_cmds; ++c) {
+      const int32_t* cmd = cmds + 6 * c;
+      uint8_t* plane = out + ((size_t)b * 3 + cmd[4]) * H * W;
+      const uint8_t color = (uint8_t)cmd[5];
       if (cmd[0] == 0) {
         int64_t vx[16], vy[16];
         int n = 0;
@@ -237,11 +272,18 @@ void stickman_raster_oracle(const float* kps, int B, int J, const int32_t* body,
           const float x = k[2 * body[i]], y = k[2 * body[i] + 1];
           if (x >= 0.f && y >= 0.f) { vx[n] = (int64_t)x; vy[n] = (int64_t)y; ++n; }  /* :347-349 */
         }
-        if (n > 2) fill_poly(plane, W, H, vx, vy, n, (uint8_t)cmd[4]);                 /* :348 */
+        if (n > 2) fill_poly(plane, W, H, vx, vy, n, color);                           /* :348 */
+      } else if (cmd[0] == 2) {
+        if (joint_ok(k, cmd[1]) && joint_ok(k, cmd[2]) && joint_ok(k, cmd[3])) {       /* :408-416 */
+          const double nx = 0.5 * ((double)k[2 * cmd[1]] + (double)k[2 * cmd[2]]);
+          const double ny = 0.5 * ((double)k[2 * cmd[1] + 1] + (double)k[2 * cmd[2] + 1]);
+          draw_line(plane, W, H, (int64_t)nx, (int64_t)ny, (int64_t)k[2 * cmd[3]], (int64_t)k[2 * cmd[3] + 1], color);
+        }
       } else {
+        if (!(joint_ok(k, cmd[1]) && joint_ok(k, cmd[2]))) continue;                   /* :358-359 */
         const float ax = k[2 * cmd[1]], ay = k[2 * cmd[1] + 1], bx = k[2 * cmd[2]], by = k[2 * cmd[2] + 1];
-        if (ax >= 0.f && ay >= 0.f && bx >= 0.f && by >= 0.f)                          /* :358-359 */
-          draw_line(plane, W, H, (int64_t)ax, (int64_t)ay, (int64_t)bx, (int64_t)by, (uint8_t)cmd[4]);
+        if (cmd[0] == 3 && !(seg_len(ax, ay, bx, by) < throat)) continue;              /* :473-476 */
+        draw_line(plane, W, H, (int64_t)ax, (int64_t)ay, (int64_t)bx, (int64_t)by, color);
       }
     }
   }

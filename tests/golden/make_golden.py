@@ -506,6 +506,48 @@ def g6_full_size():
         save("g6_" + tag, meta, arrays)
 
 
+# ---------------------------------------------------------------- G7 evaluation statistics (lib/metrics.py:277-415)
+def g7_metrics():
+    """FID statistics (_calculate_fid on mean / np.cov of features) and the Inception score (inception_score driven with
+    a small seeded linear "classifier" in place of torchvision's inception_v3, which is absent): the reference's own
+    functions on synthetic features / images."""
+    for name in ["skimage", "skimage.metrics", "h5py", "imagesize", "umap"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+                sys.modules[name].__getattr__ = lambda k: type(k, (), {})
+    from lib import metrics as rmet
+    seed = 71
+    arrays, meta = {}, {"seed": seed}
+    # FID: two feature clouds with different means / covariances, D = 24
+    a = seeded_randn("fid.a", (400, 24), seed).double().numpy() @ seeded_randn("fid.ma", (24, 24), seed).double().numpy()
+    b = seeded_randn("fid.b", (300, 24), seed).double().numpy() @ seeded_randn("fid.mb", (24, 24), seed).double().numpy() + 0.3
+    mu1, c1 = np.mean(a, axis=0), np.cov(a, rowvar=False)
+    mu2, c2 = np.mean(b, axis=0), np.cov(b, rowvar=False)
+    meta["fid"] = float(rmet._calculate_fid(mu1, c1, mu2, c2))
+    meta["fid_same"] = float(rmet._calculate_fid(mu1, c1, mu1, c1))
+    # rank-deficient covariance (fewer samples than dimensions): the eps branch / complex sqrtm handling
+    d = seeded_randn("fid.d", (10, 24), seed).double().numpy()
+    mu3, c3 = np.mean(d, axis=0), np.cov(d, rowvar=False)
+    meta["fid_singular"] = float(rmet._calculate_fid(mu1, c1, mu3, c3))
+    # Inception score: reference function, fake classifier = seeded linear map of the 8x8-average-pooled image
+    w = seeded_randn("is.w", (3 * 8 * 8, 1000), seed) * 3.0   # 1000 classes: the reference hard-codes preds[N, 1000]
+
+    class Fake(torch.nn.Module):
+        def forward(self, x):
+            return torch.nn.functional.adaptive_avg_pool2d(x, 8).flatten(1) @ w
+    rmet.inception_v3 = lambda **kw: Fake()
+    rmet.tqdm = lambda it, **kw: it
+    imgs = synth_image("is.imgs", (96, 3, 32, 32), seed)
+    ds = torch.utils.data.TensorDataset(imgs)
+    for splits in (1, 4):
+        m, sd_ = rmet.inception_score(ds, torch.device("cpu"), batch_size=16, resize=False, splits=splits)
+        meta[f"is_{splits}"] = [float(m), float(sd_)]
+    save("g7_metrics", meta, arrays)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -521,3 +563,4 @@ if __name__ == "__main__":
     g5_trajectory()
     g5_regressor_trajectory()
     g6_full_size()
+    g7_metrics()

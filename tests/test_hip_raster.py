@@ -32,3 +32,39 @@ def test_make_joint_img_reference_signature():
     assert img.shape == (128, 128, 3) and img.dtype == np.uint8
     want = S.raster(kps[None], H36M_JOINT_MODEL.body, stickman_draw_list(H36M_JOINT_MODEL), 128, 128)[0]
     assert np.array_equal(img, want.transpose(1, 2, 0))
+
+
+@pytest.mark.parametrize("which", ["deepfashion", "market"])
+@pytest.mark.parametrize("mode", ["default", "line_colors", "color_channel"])
+def test_neck_and_face_branches_bit_exact_vs_oracle(which, mode):
+    """The joint models without head lines (DeepFashion, Market -- BASELINE config 1): neck line, throat-gated face lines,
+    per-line colours and the single-channel mode, GPU closed forms == sequential oracle."""
+    from behavior_driven_video_synthesis_amd.lib.utils import (DEEPFASHION_JOINT_MODEL, MARKET_JOINT_MODEL,
+                                                                 make_joint_img_batch, stickman_draw_list)
+    model = DEEPFASHION_JOINT_MODEL if which == "deepfashion" else MARKET_JOINT_MODEL
+    rng = np.random.default_rng(11)
+    size, b = 128, 32
+    kps = rng.normal(size / 2, 30, size=(b, 18, 2)).astype(np.float32)
+    kps[2, model.rshoulder] = (-1.0, -1.0)          # no neck -> throat 0 -> no face lines either
+    kps[3, model.headup] = (-5.0, 7.0)
+    kps[5:9, 14:18] = kps[5:9, [model.headup] * 4] + rng.normal(0, 3, size=(4, 4, 2)).astype(np.float32)   # short face lines
+    kw = {}
+    if mode == "line_colors":
+        kw["line_colors"] = [[(0, 0, 40 + 10 * i) for i in range(4)], [(0, 60 + 10 * i, 0) for i in range(4)],
+                             [(100 + 10 * i, 0, 0) for i in range(4)]]
+    elif mode == "color_channel":
+        kw["color_channel"] = 2
+    want = S.raster(kps, model.body, stickman_draw_list(model, **kw), size, size)
+    got = make_joint_img_batch((size, size), torch.from_numpy(kps).cuda(), model, as_float=False, **kw)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert want.any()
+
+
+def test_make_joint_img_single_channel_shape_and_thickness_guard():
+    from behavior_driven_video_synthesis_amd.lib.utils import MARKET_JOINT_MODEL, make_joint_img
+    rng = np.random.default_rng(6)
+    kps = rng.normal(64, 25, size=(18, 2)).astype(np.float32)
+    img = make_joint_img([128, 128, 1], kps, MARKET_JOINT_MODEL)            # lib/utils.py:507-509: channel mean
+    assert img.shape == (128, 128, 1)
+    with pytest.raises(NotImplementedError):
+        make_joint_img([128, 128, 3], kps, MARKET_JOINT_MODEL, scale_factor=32)   # thickness 4: not built

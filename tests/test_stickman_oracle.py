@@ -7,7 +7,7 @@ from oracle import stickman as S
 
 def _line(a, b, h=16, w=16, color=255):
     kps = np.array([[a, b]], dtype=np.float32)
-    return S.raster(kps, [], [(1, 0, 1, 0, color)], h, w)[0, 0]
+    return S.raster(kps, [], [(1, 0, 1, 0, 0, color)], h, w)[0, 0]
 
 
 def _pts(img):
@@ -46,7 +46,7 @@ def test_invalid_joints_draw_nothing_and_coordinates_truncate():
 
 def _poly(vs, h=16, w=16):
     kps = np.array([vs], dtype=np.float32)
-    return S.raster(kps, list(range(len(vs))), [(0, 0, 0, 2, 255)], h, w)[0, 2]
+    return S.raster(kps, list(range(len(vs))), [(0, 0, 0, 0, 2, 255)], h, w)[0, 2]
 
 
 def test_fill_rectangle_and_triangle():
@@ -65,7 +65,7 @@ def test_polygon_needs_three_valid_points_and_clips():
 
 def test_draw_order_is_overwrite_order():
     kps = np.array([[(1, 4), (9, 4), (5, 1), (5, 8)]], dtype=np.float32)
-    cmds = [(1, 0, 1, 0, 255), (1, 2, 3, 0, 127)]          # horizontal 255, then vertical 127 on the same plane
+    cmds = [(1, 0, 1, 0, 0, 255), (1, 2, 3, 0, 0, 127)]    # horizontal 255, then vertical 127 on the same plane
     img = S.raster(kps, [], cmds, 12, 12)[0, 0]
     assert img[4, 5] == 127 and img[4, 4] == 255 and img[2, 5] == 127
 
@@ -82,3 +82,86 @@ def test_h36m_draw_list_planes():
     assert set(np.unique(out[:, 2])) <= {0, 255}            # plane 2: body polygon only
     assert set(np.unique(out[:, 0])) <= {0, 127, 255}       # plane 0: left limbs 255, head 127 (body colour 0)
     assert set(np.unique(out[:, 1])) <= {0, 127, 255}
+
+
+# ---- the branches beyond the Human3.6m default: neck line, face lines, per-line colours, single channel
+def _model(**kw):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from behavior_driven_video_synthesis_amd.lib.utils import JointModel
+    base = dict(body=[], right_lines=[], left_lines=[], head_lines=[], face=[], rshoulder=0, lshoulder=1, headup=2)
+    base.update(kw)
+    return JointModel(**base)
+
+
+def _draw(model, kps, h=16, w=16, **kw):
+    from behavior_driven_video_synthesis_amd.lib.utils import stickman_draw_list
+    return S.raster(np.array([kps], dtype=np.float32), list(model.body), stickman_draw_list(model, **kw), h, w)[0]
+
+
+def test_neck_line_runs_from_the_shoulder_midpoint_to_the_head_joint():
+    # shoulders (2, 10) and (9, 10): neck = (5.5, 10) -> np.int_ truncation (5, 10); head joint (5, 3): a vertical line,
+    # colour 127 on planes 0 and 1 (lib/utils.py:407-424)
+    out = _draw(_model(), [(2, 10), (9, 10), (5, 3)])
+    want = [(5, y) for y in range(3, 11)]
+    assert _pts(out[0]) == want and _pts(out[1]) == want and not out[2].any()
+    assert set(np.unique(out[0])) == {0, 127}
+
+
+def test_neck_line_needs_both_shoulders_and_the_head_joint():
+    assert not _draw(_model(), [(-1, 10), (9, 10), (5, 3)]).any()     # an invalid shoulder -> neck = (-1, -1) (:411-412)
+    assert not _draw(_model(), [(2, 10), (9, -2), (5, 3)]).any()
+    assert not _draw(_model(), [(2, 10), (9, 10), (5, -1)]).any()     # invalid head joint (:417-418)
+
+
+def test_face_lines_are_drawn_only_if_shorter_than_the_throat():
+    # throat = |(5.5, 10) - (5, 3)| = sqrt(49.25) = 7.02; face lines 3-4 of length 4 (drawn) and 3-5 of length 8 (not)
+    m = _model(face=[(3, 4), (3, 5)])
+    kps = [(2, 10), (9, 10), (5, 3), (1, 1), (5, 1), (9, 1)]
+    out = _draw(m, kps)
+    row1 = sorted(p for p in _pts(out[0]) if p[1] == 1)
+    assert row1 == [(x, 1) for x in range(1, 6)]                       # only the short face line
+    # without a valid neck the throat length is 0: no face line at all (:414, :476)
+    out = _draw(m, [(-1, 10), (9, 10), (5, 3), (1, 1), (5, 1), (9, 1)])
+    assert not out.any()
+    # strict "<": a face line exactly as long as the throat is skipped
+    m2 = _model(face=[(3, 4)])
+    out = _draw(m2, [(5, 10), (5, 10), (5, 3), (1, 1), (8, 1)])         # throat exactly 7, face line exactly 7
+    assert not any(p[1] == 1 for p in _pts(out[0]))
+
+
+def test_head_lines_define_the_throat_for_models_that_have_them():
+    m = _model(head_lines=[(0, 1), (1, 2)], face=[(3, 4)], rshoulder=None, lshoulder=None, headup=None)
+    kps = [(2, 12), (2, 9), (2, 3), (6, 1), (11, 1)]                    # head lines of length 3 and 6 -> throat 6; face 5
+    out = _draw(m, kps)
+    assert [(x, 1) for x in range(6, 12)] == sorted(p for p in _pts(out[1]) if p[1] == 1)
+    kps[4] = (13, 1)                                                    # face length 7 >= 6: gone
+    out = _draw(m, kps)
+    assert not any(p[1] == 1 for p in _pts(out[1]))
+
+
+def test_per_line_colours_and_single_channel_mode():
+    m = _model(right_lines=[(0, 1)], left_lines=[(2, 3)], head_lines=[(4, 5)], rshoulder=None, lshoulder=None, headup=None)
+    kps = [(1, 2), (6, 2), (1, 5), (6, 5), (1, 8), (6, 8)]
+    line_colors = [[(0, 0, 200)], [(0, 90, 0)], [(33, 0, 0)]]          # plane = index of the non-zero entry (:365-373)
+    out = _draw(m, kps, line_colors=line_colors)
+    assert set(np.unique(out[2])) == {0, 200} and _pts(out[2]) == [(x, 2) for x in range(1, 7)]
+    assert set(np.unique(out[1])) == {0, 90} and _pts(out[1]) == [(x, 5) for x in range(1, 7)]
+    assert set(np.unique(out[0])) == {0, 33} and _pts(out[0]) == [(x, 8) for x in range(1, 7)]
+    m3 = _model(body=[0, 1, 3, 2], right_lines=[(0, 1)], left_lines=[(2, 3)], head_lines=[(4, 5)], rshoulder=None,
+                lshoulder=None, headup=None)
+    out = _draw(m3, kps, color_channel=1)                               # everything 255 on plane 1 (:354-355, :376-379)
+    assert not out[0].any() and not out[2].any() and set(np.unique(out[1])) == {0, 255}
+    assert (out[1][2:6, 1:7] == 255).all() and (out[1][8, 1:7] == 255).all()
+
+
+def test_deepfashion_and_market_models_draw():
+    from behavior_driven_video_synthesis_amd.lib.utils import DEEPFASHION_JOINT_MODEL, MARKET_JOINT_MODEL, stickman_draw_list
+    rng = np.random.default_rng(3)
+    for model in (DEEPFASHION_JOINT_MODEL, MARKET_JOINT_MODEL):
+        cmds = stickman_draw_list(model)
+        assert len(cmds) == 3 + 4 + 4 + 2 + 8 and [c[0] for c in cmds].count(2) == 2 and [c[0] for c in cmds].count(3) == 8
+        kps = rng.normal(64, 22, size=(4, 18, 2)).astype(np.float32)
+        out = S.raster(kps, model.body, cmds, 128, 128)
+        assert out[:, 2].any() and out[:, 0].any() and out[:, 1].any()
+        assert set(np.unique(out)) <= {0, 127, 255}
