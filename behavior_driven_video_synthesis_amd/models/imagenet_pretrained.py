@@ -78,12 +78,39 @@ def vgg19(pretrained: bool = False, weights_path: str = None, width_div: int = 1
     return net
 
 
+def _adopt_features(features: nn.Sequential) -> nn.Sequential:
+    """``features`` of this package's VGG19 pass through; a torchvision-style stack (``nn.Conv2d`` / ``nn.ReLU`` /
+    ``nn.MaxPool2d`` at torchvision's indices -- what the reference hands over, experiments/shape_and_pose_net.py:222-229)
+    is rebuilt ONCE as the fused conv + ReLU stack with the same weights, on the same device."""
+    mods = list(features)
+    if all(isinstance(m, (Conv2d, _Marker)) for m in mods):
+        return features
+    layers = []
+    for m in mods:
+        if isinstance(m, nn.Conv2d):
+            if m.kernel_size != (3, 3) or m.stride != (1, 1) or m.padding != (1, 1) or m.bias is None:
+                raise NotImplementedError("PerceptualVGG expects VGG-style 3x3 / stride 1 / pad 1 convolutions with bias")
+            c = Conv2d(m.in_channels, m.out_channels, 3, padding=1)
+            with torch.no_grad():
+                c.weight.copy_(m.weight)
+                c.bias.copy_(m.bias)
+            layers.append(c.to(m.weight.device))
+        elif isinstance(m, nn.ReLU):
+            layers.append(_Marker("relu"))
+        elif isinstance(m, nn.MaxPool2d):
+            layers.append(_Marker("pool"))
+        else:
+            raise NotImplementedError(f"PerceptualVGG: unexpected module {type(m).__name__} in vgg.features")
+    return nn.Sequential(*layers)
+
+
 class PerceptualVGG(nn.Module):
     """models/imagenet_pretrained.py:8-61: dict ``input, relu1_2, relu2_2, relu3_2, relu4_2, relu5_2``."""
 
     def __init__(self, vgg, weights):
         super().__init__()
-        self.vgg_layers = vgg.module.features if isinstance(vgg, nn.DataParallel) else vgg.features
+        feats = vgg.module.features if isinstance(vgg, nn.DataParallel) else vgg.features
+        self.vgg_layers = _adopt_features(feats)
         self.loss_weights = weights
         self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406], dtype=torch.float).view(1, 3, 1, 1))
         self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225], dtype=torch.float).view(1, 3, 1, 1))

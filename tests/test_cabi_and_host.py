@@ -187,3 +187,72 @@ def test_kernel_selection_of_the_gather_entry_point():
     assert variant(C1=32, M=3, Mpad=32, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_m_kernel<0>"
     assert variant(C1=3, M=32, Mpad=32, KH=1, KW=1, pad=0, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_k_kernel<1, 3>"
     assert variant(C1=3, M=64, Mpad=64, Hs=256, Ws=256, Ho=256, Wo=256, out_act=ops.ACT_RELU) == "conv_thin_k_kernel<3, 3>"
+
+
+def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
+    """``python -m behavior_driven_video_synthesis_amd.dropin main.py``: the reference's import lines resolve to the
+    MI355X classes, names this package does not define fall through to the checkout's own files, and ``lib`` / ``models``
+    stay the checkout's packages (other sub-modules untouched).  A miniature checkout stands in for the reference."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    co = tmp_path / "checkout"
+    (co / "lib").mkdir(parents=True)
+    (co / "models").mkdir()
+    (co / "lib" / "modules.py").write_text("class NormConv2d:\n    ORIGIN = 'checkout'\nclass ActNorm:\n    ORIGIN = 'checkout'\n")
+    (co / "lib" / "utils.py").write_text("def helper():\n    return 'checkout utils'\n")
+    (co / "lib" / "losses.py").write_text("from lib.utils import helper\nclass FlowLoss:\n    ORIGIN = helper()\n")
+    (co / "models" / "vunets.py").write_text("class VunetAlter:\n    ORIGIN = 'checkout'\n")
+    (co / "main.py").write_text(
+        "from models.vunets import VunetAlter, Regressor\n"
+        "from lib.modules import NormConv2d, ActNorm\n"
+        "from lib.losses import vgg_loss, compute_kl_with_prior, FlowLoss\n"
+        "from lib.utils import helper\n"
+        "from models.imagenet_pretrained import PerceptualVGG\n"
+        "from models.synth_discriminator import DiscTrainer\n"
+        "import sys\n"
+        "print('ARGS', sys.argv[1:])\n"
+        "print('VUNET', VunetAlter.__module__)\n"
+        "print('NORMCONV', NormConv2d.__module__)\n"
+        "print('ACTNORM', ActNorm.ORIGIN)\n"
+        "print('FLOWLOSS', FlowLoss.ORIGIN)\n"
+        "print('UTILS', helper())\n"
+        "print('VGGLOSS', vgg_loss.__module__, PerceptualVGG.__module__, DiscTrainer.__module__)\n")
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "behavior_driven_video_synthesis_amd.dropin", "main.py", "--config", "x.yaml"],
+                       cwd=str(co), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines())
+    pkg = "behavior_driven_video_synthesis_amd"
+    assert out["ARGS"] == "['--config', 'x.yaml']"
+    assert out["VUNET"] == pkg + ".models.vunets" and out["NORMCONV"] == pkg + ".lib.modules"
+    assert out["ACTNORM"] == "checkout" and out["FLOWLOSS"] == "checkout utils" and out["UTILS"] == "checkout utils"
+    assert out["VGGLOSS"] == f"{pkg}.lib.losses {pkg}.models.imagenet_pretrained {pkg}.models.synth_discriminator"
+
+
+def test_perceptual_vgg_adopts_a_torchvision_style_stack():
+    """What the reference hands over is torchvision's vgg19: nn.Conv2d / nn.ReLU / nn.MaxPool2d at torchvision's indices."""
+    import torch
+    from torch import nn
+    from behavior_driven_video_synthesis_amd.lib.modules import Conv2d
+    from behavior_driven_video_synthesis_amd.models.imagenet_pretrained import VGG19_CFG, PerceptualVGG, _Marker
+    layers, cin = [], 3
+    for v in VGG19_CFG:
+        if v == "M":
+            layers.append(nn.MaxPool2d(2, 2))
+        else:
+            layers += [nn.Conv2d(cin, max(v // 16, 4), 3, padding=1), nn.ReLU(inplace=True)]
+            cin = max(v // 16, 4)
+
+    class TV(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(*layers)
+    tv = TV()
+    pv = PerceptualVGG(tv, [1.0] * 6)
+    mods = list(pv.vgg_layers)
+    assert len(mods) == 37 and all(isinstance(m, (Conv2d, _Marker)) for m in mods)
+    for i in (0, 2, 5, 28, 34):
+        assert torch.equal(mods[i].weight, tv.features[i].weight) and torch.equal(mods[i].bias, tv.features[i].bias)
+    assert [type(m).__name__ for m in mods[:5]] == ["Conv2d", "_Marker", "Conv2d", "_Marker", "_Marker"]
+    assert not any(p.requires_grad for p in pv.vgg_layers.parameters())
