@@ -61,6 +61,8 @@ __device__ __forceinline__ wg_bf16x8 wg_frag(uint32_t a, uint32_t b, uint32_t c,
 template <int MTW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradX6Args a) {
   constexpr int TH = 4;
+  // optional register prefetch of the next tile's f(x) across the MFMA block
+  constexpr bool PREFETCH = false;   // measured: no gain from the register prefetch (r02), and two m-tiles spill with it
   constexpr int WP = 4 / MTW;        // waves sharing one m-tile (they split the tile rows)
   constexpr int RW = TH / WP;        // tile rows per wave
   constexpr int ENT = 6 * 32;        // (row, ci) entries of the staged tile
@@ -104,11 +106,85 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradX6Args
 
   const int t_begin = split * a.tps;
   const int t_end = min(t_begin + a.tps, a.ntiles);
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int n = tile / a.tiles_per_img;
+
+  // ---- f(x) staging, register-prefetched one tile ahead: the loads of tile t+1 are issued before the MFMA block of
+  //      tile t and split / written to LDS after it (the input tile is single-buffered: two barriers per tile)
+  wg_f32x4 xv[3][2];      // main units: 8 consecutive columns each
+  float hv[2];            // halo columns -1 / 32 of entry `tid` (tid < 192)
+  uint32_t gidx[3], hidx = 0;
+  uint32_t okbits = 0;    // bit i: main unit i in range; bit 4 / 5: left / right halo in range
+  auto tile_origin = [&](int tile, int& n, int& row0, int& col0) {
+    n = tile / a.tiles_per_img;
     const int tr = tile - n * a.tiles_per_img;
     const int ty = tr / a.tiles_per_img_w, tx = tr - ty * a.tiles_per_img_w;
-    const int row0 = ty * TH, col0 = tx * 32;
+    row0 = ty * TH;
+    col0 = tx * 32;
+  };
+  auto issue_x = [&](int tile) {
+    int n, row0, col0;
+    tile_origin(tile, n, row0, col0);
+    okbits = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ih = row0 - 1 + s_row[i];
+      const bool ok = (unsigned)ih < (unsigned)H;
+      okbits |= (ok ? 1u : 0u) << i;
+      gidx[i] = (uint32_t)(((n * Cs + cbase + s_ci[i]) * H + (ok ? ih : 0)) * W + col0 + 8 * s_oct[i]);
+      xv[i][0] = *reinterpret_cast<const wg_f32x4*>(xs + gidx[i]);
+      xv[i][1] = *reinterpret_cast<const wg_f32x4*>(xs + gidx[i] + 4);
+    }
+    {  // every thread loads (threads >= 192 a harmless duplicate of entry tid - 64): no divergent load
+      const int e = tid < ENT ? tid : tid - 64;
+      const int r = e >> 5, c = e & 31;
+      const int ih = row0 - 1 + r;
+      const bool rok = (unsigned)ih < (unsigned)H;
+      hidx = (uint32_t)(((n * Cs + cbase + c) * H + (rok ? ih : 0)) * W + col0);
+      const bool okl = rok && col0 > 0, okr = rok && col0 + 32 < W;
+      okbits |= (okl ? 16u : 0u) | (okr ? 32u : 0u);
+      hv[0] = xs[okl ? hidx - 1 : hidx];
+      hv[1] = xs[okr ? hidx + 32 : hidx];
+    }
+  };
+  auto write_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bool ok = (okbits >> i) & 1u;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = e < 4 ? xv[i][0][e] : xv[i][1][e - 4];
+        f[e] = ok ? apply_in_act(ia, t, gidx[i] + e) : 0.f;
+      }
+      uint32_t ph[4], pm[4], pl[4];
+      wg_split2(f[0], f[1], ph[0], pm[0], pl[0]);
+      wg_split2(f[2], f[3], ph[1], pm[1], pl[1]);
+      wg_split2(f[4], f[5], ph[2], pm[2], pl[2]);
+      wg_split2(f[6], f[7], ph[3], pm[3], pl[3]);
+      const int unit = (s_row[i] * 32 + s_ci[i]) * 5 + 1 + s_oct[i];
+      xL[unit] = wg_u32x4{ph[0], ph[1], ph[2], ph[3]};
+      xL[PL + unit] = wg_u32x4{pm[0], pm[1], pm[2], pm[3]};
+      xL[2 * PL + unit] = wg_u32x4{pl[0], pl[1], pl[2], pl[3]};
+    }
+    if (tid < ENT) {
+      const float fl = (okbits & 16u) ? apply_in_act(ia, hv[0], hidx - 1) : 0.f;
+      const float fr = (okbits & 32u) ? apply_in_act(ia, hv[1], hidx + 32) : 0.f;
+      uint32_t ph, pm, pl;
+      wg_split2(fr, fl, ph, pm, pl);   // low half = right halo (element 0 of the NEXT entry's unit 0), high = left
+      unsigned short* const base = reinterpret_cast<unsigned short*>(xL);
+      const int ul = tid * 5, ur = (tid + 1) * 5;   // halo units: this entry's (left, element 7), the next one's (right, element 0)
+      base[(size_t)(ul) * 8 + 7] = (unsigned short)(ph >> 16);
+      base[(size_t)(PL + ul) * 8 + 7] = (unsigned short)(pm >> 16);
+      base[(size_t)(2 * PL + ul) * 8 + 7] = (unsigned short)(pl >> 16);
+      base[(size_t)(ur) * 8] = (unsigned short)(ph & 0xffffu);
+      base[(size_t)(PL + ur) * 8] = (unsigned short)(pm & 0xffffu);
+      base[(size_t)(2 * PL + ur) * 8] = (unsigned short)(pl & 0xffffu);
+    }
+  };
+
+  if (PREFETCH && t_begin < t_end) issue_x(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int n, row0, col0;
+    tile_origin(tile, n, row0, col0);
 
     // ---- dy of this wave's rows: RW rows x 2 k-steps x 8 pixels per lane, straight to registers
     wg_f32x4 dyv[RW][2][2];
@@ -124,74 +200,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradX6Args
     }
 
     __syncthreads();  // the previous tile's LDS reads are done
-    // ---- stage f(x): 6 rows x 32 ci x 32 columns as aligned octets ...
-    {
-      wg_f32x4 v[3][2];
-      uint32_t gidx[3];
-      bool okr[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int ih = row0 - 1 + s_row[i];
-        okr[i] = (unsigned)ih < (unsigned)H;
-        gidx[i] = (uint32_t)(((n * Cs + cbase + s_ci[i]) * H + (okr[i] ? ih : 0)) * W + col0 + 8 * s_oct[i]);
-        v[i][0] = *reinterpret_cast<const wg_f32x4*>(xs + gidx[i]);
-        v[i][1] = *reinterpret_cast<const wg_f32x4*>(xs + gidx[i] + 4);
-      }
-      // ... and the two halo columns of every entry: thread e < 192 loads column -1 and column 32 of entry e
-      float hl = 0.f, hr = 0.f;
-      uint32_t hidx = 0;
-      bool hok_l = false, hok_r = false;
-      if (tid < ENT) {
-        const int r = tid >> 5, c = tid & 31;
-        const int ih = row0 - 1 + r;
-        const bool rok = (unsigned)ih < (unsigned)H;
-        hidx = (uint32_t)(((n * Cs + cbase + c) * H + (rok ? ih : 0)) * W + col0);
-        hok_l = rok && col0 > 0;
-        hok_r = rok && col0 + 32 < W;
-        hl = xs[hok_l ? hidx - 1 : hidx];
-        hr = xs[hok_r ? hidx + 32 : hidx];
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float f[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float t = e < 4 ? v[i][0][e] : v[i][1][e - 4];
-          f[e] = okr[i] ? apply_in_act(ia, t, gidx[i] + e) : 0.f;
-        }
-        uint32_t ph[4], pm[4], pl[4];
-        wg_split2(f[0], f[1], ph[0], pm[0], pl[0]);
-        wg_split2(f[2], f[3], ph[1], pm[1], pl[1]);
-        wg_split2(f[4], f[5], ph[2], pm[2], pl[2]);
-        wg_split2(f[6], f[7], ph[3], pm[3], pl[3]);
-        const int unit = (s_row[i] * 32 + s_ci[i]) * 5 + 1 + s_oct[i];
-        xL[unit] = wg_u32x4{ph[0], ph[1], ph[2], ph[3]};
-        xL[PL + unit] = wg_u32x4{pm[0], pm[1], pm[2], pm[3]};
-        xL[2 * PL + unit] = wg_u32x4{pl[0], pl[1], pl[2], pl[3]};
-      }
-      if (tid < ENT) {
-        const float fl = hok_l ? apply_in_act(ia, hl, hidx - 1) : 0.f;
-        const float fr = hok_r ? apply_in_act(ia, hr, hidx + 32) : 0.f;
-        uint32_t ph, pm, pl;
-        wg_split2(fr, fl, ph, pm, pl);   // low half = right halo (element 0 of the NEXT entry's unit 0), high = left
-        unsigned short* const base = reinterpret_cast<unsigned short*>(xL);
-        const int ul = tid * 5, ur = (tid + 1) * 5;   // halo units: this entry's (left, element 7), the next one's (right, element 0)
-        base[(size_t)(ul) * 8 + 7] = (unsigned short)(ph >> 16);
-        base[(size_t)(PL + ul) * 8 + 7] = (unsigned short)(pm >> 16);
-        base[(size_t)(2 * PL + ul) * 8 + 7] = (unsigned short)(pl >> 16);
-        base[(size_t)(ur) * 8] = (unsigned short)(ph & 0xffffu);
-        base[(size_t)(PL + ur) * 8] = (unsigned short)(pm & 0xffffu);
-        base[(size_t)(2 * PL + ur) * 8] = (unsigned short)(pl & 0xffffu);
-      }
-    }
+    if constexpr (!PREFETCH) issue_x(tile);
+    write_x();        // PREFETCH: this tile's f(x) was loaded during the previous tile's MFMA block
     __syncthreads();
+    if constexpr (PREFETCH) issue_x(tile + 1 < t_end ? tile + 1 : tile);   // unconditional (a conditional load is sunk to its use)
 
-    // ---- MFMA: this wave's RW rows x 2 k-steps, 9 taps x 6 products each
+    // ---- MFMA: this wave's RW rows x 2 k-steps x 3 kernel rows = RW*6 steps of 18 MFMAs (3 taps x 6 products).
+    //      The f(x) reads of step i+1 (one aligned 16-byte read + the two neighbouring edge dwords, per plane) are
+    //      issued before the MFMAs of step i: LDS latency hides behind 18 MFMAs instead of stalling every step.
     const uint32_t* const xw = reinterpret_cast<const uint32_t*>(xL);
+    struct Raw {
+      wg_u32x4 c[3];
+      uint32_t p3[3], n0[3];
+    };
+    auto load_raw = [&](int st) {
+      const int rr = st / 6, s = (st / 3) & 1, kh = st % 3;
+      // unit of (row pw*RW + rr + kh, ci j, octet 2s + h)
+      const int unit = ((pw * RW + rr + kh) * 32 + j) * 5 + 1 + 2 * s + h;
+      Raw r;
 #pragma unroll
-    for (int rr = 0; rr < RW; ++rr) {
+      for (int p = 0; p < 3; ++p) {
+        r.c[p] = xL[p * PL + unit];
+        r.p3[p] = xw[(size_t)(p * PL + unit - 1) * 4 + 3];
+        r.n0[p] = xw[(size_t)(p * PL + unit + 1) * 4];
+      }
+      return r;
+    };
+    constexpr int NSTEP = RW * 6;
+    Raw cur = load_raw(0);
+    wg_bf16x8 Ah, Am, Al;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+    for (int st = 0; st < NSTEP; ++st) {
+      const int rr = st / 6, s = (st / 3) & 1, kh = st % 3;
+      __builtin_amdgcn_sched_barrier(0);
+      Raw nxt = cur;
+      if (st + 1 < NSTEP) nxt = load_raw(st + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads up here (the scheduler otherwise sinks them to the end of the step)
+      if (kh == 0) {   // a new k-step: split this lane's 8 dy pixels once for the 9 taps
         const wg_f32x4 d0 = dyv[rr][s][0], d1 = dyv[rr][s][1];
         dsum += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
         uint32_t ah[4], am[4], al[4];
@@ -199,38 +244,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradX6Args
         wg_split2(d0[2], d0[3], ah[1], am[1], al[1]);
         wg_split2(d1[0], d1[1], ah[2], am[2], al[2]);
         wg_split2(d1[2], d1[3], ah[3], am[3], al[3]);
-        const wg_bf16x8 Ah = wg_frag(ah[0], ah[1], ah[2], ah[3]), Am = wg_frag(am[0], am[1], am[2], am[3]),
-                        Al = wg_frag(al[0], al[1], al[2], al[3]);
+        Ah = wg_frag(ah[0], ah[1], ah[2], ah[3]);
+        Am = wg_frag(am[0], am[1], am[2], am[3]);
+        Al = wg_frag(al[0], al[1], al[2], al[3]);
+      }
+      // one plane of f(x) at a time, smallest terms first: only three shifted fragments are live
+      //   plane l: Ah*Bl ; plane m: Am*Bm, Ah*Bm ; plane h: Al*Bh, Am*Bh, Ah*Bh
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          __builtin_amdgcn_sched_barrier(0);
-          // unit of (row pw*RW + rr + kh, ci j, octet 2s + h): one aligned read + the neighbours' edge dwords
-          const int unit = ((pw * RW + rr + kh) * 32 + j) * 5 + 1 + 2 * s + h;
-          wg_bf16x8 B[3][3];   // [kw][plane]
+      for (int pp = 0; pp < 3; ++pp) {
+        const int p = 2 - pp;
+        const wg_u32x4 c = cur.c[p];
+        const uint32_t s01 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s12 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                       s23 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+        wg_bf16x8 B[3];
+        B[0] = wg_frag(__builtin_amdgcn_alignbit(c.x, cur.p3[p], 16), s01, s12, s23);   // columns p - 1
+        B[1] = __builtin_bit_cast(wg_bf16x8, c);                                        // columns p
+        B[2] = wg_frag(s01, s12, s23, __builtin_amdgcn_alignbit(cur.n0[p], c.w, 16));   // columns p + 1
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            const wg_u32x4 c = xL[p * PL + unit];
-            const uint32_t p3 = xw[(size_t)(p * PL + unit - 1) * 4 + 3];
-            const uint32_t n0 = xw[(size_t)(p * PL + unit + 1) * 4];
-            const uint32_t s01 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s12 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
-                           s23 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
-            B[0][p] = wg_frag(__builtin_amdgcn_alignbit(c.x, p3, 16), s01, s12, s23);   // columns p - 1
-            B[1][p] = __builtin_bit_cast(wg_bf16x8, c);                                 // columns p
-            B[2][p] = wg_frag(s01, s12, s23, __builtin_amdgcn_alignbit(n0, c.w, 16));   // columns p + 1
-          }
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            f32x16 c = acc[kh * 3 + kw];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, B[kw][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, B[kw][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, B[kw][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, B[kw][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, B[kw][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, B[kw][0], c, 0, 0, 0);
-            acc[kh * 3 + kw] = c;
-          }
+        for (int kw = 0; kw < 3; ++kw) {
+          f32x16 cc = acc[kh * 3 + kw];
+          if (p == 0) cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, B[kw], cc, 0, 0, 0);
+          if (p <= 1) cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, B[kw], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, B[kw], cc, 0, 0, 0);
+          acc[kh * 3 + kw] = cc;
         }
       }
+      cur = nxt;
     }
   }
 
