@@ -27,9 +27,12 @@ static int x6_prologue_code(const vunet_conv_desc* d, bool has_mask) {
 
 // geometry the kernel family covers (nothing about whether it is the fastest choice)
 static bool x6_geometry_ok(const vunet_conv_desc* d, int pro) {
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Hs != d->Ho || d->Ws != d->Wo) return false;
-  if (d->C1 <= 0 || d->C1 % 16 || d->C2 % 16 || d->Ws % 32 || d->Hs % 4) return false;
+  if (d->KH != 3 || d->KW != 3 || d->pad != 1) return false;
+  if (d->C1 <= 0 || d->C1 % 16 || d->C2 % 16 || d->Ws % 32 || d->Hs % 4) return false;   // Hs, Ws: the gathered (staged) map
   if (d->M % 32 || d->m_off % 32) return false;
+  if (d->stride == 2)   // data gradient of the stride-2 Downsample conv: four parity launches over the dy map
+    return d->mode == 1 && pro == 0 && d->C2 == 0 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
+  if (d->stride != 1 || d->Hs != d->Ho || d->Ws != d->Wo) return false;
   return d->mode == 0 ? (pro == 0 || pro == 1 || pro == 2) : (pro == 0 || pro == 4);
 }
 
@@ -130,7 +133,8 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
   if (x6_wanted(d, has_wx != 0, has_aux != 0, false, has_mask != 0)) {
     int MT;
     const int NT = x6_pick(d, &MT, 128);
-    snprintf(name, len, "conv_x6_kernel<%d, %d, %d, %d>", MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
+    if (d->stride == 2) snprintf(name, len, "conv_x6_kernel<%d, %d, 1, 0, parity x4>", MT, NT);
+    else snprintf(name, len, "conv_x6_kernel<%d, %d, %d, %d>", MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     return VUNET_OK;
   }
   return vunet_conv2d_gather_variant(d, has_aux, name, len);

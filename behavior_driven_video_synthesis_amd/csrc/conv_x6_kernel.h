@@ -60,8 +60,16 @@ __device__ __forceinline__ void x6_split2(float a, float b, uint32_t& h, uint32_
 constexpr int X6_SLAB = 576;  // 16-byte units of one (chunk, kh, m-tile) weight slab: [3 kw][3 planes][2 halves][32]
 
 // MODE 0 forward, 1 data gradient (taps mirrored).  PRO 0 none, 1 ELU, 2 ELU + dropout, 4 ReLU mask (MODE 1).
-template <int MT, int NT, int MODE, int PRO>
+// PHW >= 0 (MODE 1 only): data gradient of the STRIDE-2 convolution (Downsample, lib/modules.py:152-158) for the output
+// parity (ph, pw) = (PHW >> 1, PHW & 1): dx[2a+ph][2b+pw] = sum over the taps kh = ph+1 (mod 2), kw = pw+1 (mod 2) of
+// w[kh][kw] * dy[a + (ph+1-kh)/2][b + (pw+1-kw)/2] -- a stride-1 problem on the dy map with 1, 2, 2 or 4 of the 9
+// taps, stored to every other pixel of dx.  Four launches cover the four parities; no MFMA is spent on the structural
+// zeros of a transposed strided convolution.
+template <int MT, int NT, int MODE, int PRO, int PHW = -1>
 __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const GatherArgs a, const uint4* __restrict__ wx, int mtiles_pad) {
+  static_assert(PHW < 0 || MODE == 1, "parity phases exist for the data gradient only");
+  constexpr int PH = PHW >= 0 ? (PHW >> 1) : 0, PW = PHW >= 0 ? (PHW & 1) : 0;
+  constexpr int NKH = PHW < 0 ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk
   constexpr int TW = 32, TH = 4 * NT, IH = TH + 2, IW = TW + 2, PIX = IH * IW, MB = 32 * MT;
   constexpr int XU = 2 * PIX;             // staging units of the input tile: (k-half, pixel)
   constexpr int NX = (XU + 255) / 256;
@@ -195,8 +203,14 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const GatherArgs a, con
     }
   };
 
+  // step -> weight slab (chunk * 3 + kh): all three kernel rows, or only those of this output parity
+  auto slab_of = [&](int step) {
+    if constexpr (PHW < 0) return step;
+    else if constexpr (PH == 0) return step * 3 + 1;                     // kh = 1
+    else return (step >> 1) * 3 + ((step & 1) ? 2 : 0);                  // kh = 0, 2
+  };
   issue_x(0);
-  issue_w(0);
+  issue_w(slab_of(0));
   issue_mask(0);
   write_x(0);
   write_w(0);
@@ -208,20 +222,23 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const GatherArgs a, con
   auto chunk = [&](int ch, auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int phase = ch * 3 + kh;
+    for (int ki = 0; ki < NKH; ++ki) {
+      const int kh = PHW < 0 ? ki : (PH ? 2 * ki : 1);
+      const int phase = ch * NKH + ki;
       const int buf = phase & 1;
-      const bool more_w = !(LAST && kh == 2);
-      const bool more_x = !LAST && kh == 2;
+      const bool more_w = !(LAST && ki == NKH - 1);
+      const bool more_x = !LAST && ki == NKH - 1;
       if (more_x) issue_x(ch + 1);
-      if (more_w) issue_w(phase + 1);
-      const int dr = MODE == 0 ? kh : 2 - kh;
+      if (more_w) issue_w(slab_of(phase + 1));
+      // row / column of the staged tile (origin row0-1, col0-1) that tap (kh, kw) reads for output row q, column j
+      const int dr = PHW >= 0 ? (PH + 1 - kh) / 2 + 1 : (MODE == 0 ? kh : 2 - kh);
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
+        if (PHW >= 0 && ((kw + PW) & 1) == 0) continue;   // this parity's taps only: kw = pw + 1 (mod 2)
         // two waves share a SIMD: the partner's MFMAs cover this wave's fragment reads, so nothing is gained by
         // letting the scheduler hoist the next tap's 6*(MT+NT) fragment registers above this tap's MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        const int dc = MODE == 0 ? kw : 2 - kw;
+        const int dc = PHW >= 0 ? (PW + 1 - kw) / 2 + 1 : (MODE == 0 ? kw : 2 - kw);
         X6Unit av[3][MT], bv[3][NT];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -264,8 +281,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const GatherArgs a, con
     constexpr int q = decltype(qc)::value;
     PixGeo g;
     g.n = n;
-    g.oh = row0 + wave * NT + q;
-    g.ow = col0 + j;
+    g.oh = PHW >= 0 ? 2 * (row0 + wave * NT + q) + PH : row0 + wave * NT + q;   // parity phase: every other pixel of dx
+    g.ow = PHW >= 0 ? 2 * (col0 + j) + PW : col0 + j;
     g.valid = true;
     store_tile16(a, g, m0, h, acc[0][q]);
     if constexpr (MT > 1) store_tile16(a, g, m0 + 32, h, acc[1][q]);
@@ -278,13 +295,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const GatherArgs a, con
   }
 }
 
-template <int MT, int NT, int MODE, int PRO>
+template <int MT, int NT, int MODE, int PRO, int PHW = -1>
 static int launch_x6_one(const GatherArgs& ga, const void* wx, int mtiles_pad, hipStream_t st) {
   constexpr int PIX = (4 * NT + 2) * 34;
   constexpr size_t lds = (size_t)(6 * PIX + 2 * X6_SLAB * MT) * 16;
   const vunet_conv_desc& d = ga.d;
   const int blocks = d.N * (d.Hs / (4 * NT)) * (d.Ws / 32) * ((d.M + 32 * MT - 1) / (32 * MT));
-  auto kern = conv_x6_kernel<MT, NT, MODE, PRO>;
+  auto kern = conv_x6_kernel<MT, NT, MODE, PRO, PHW>;
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   VUNET_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, st, ga, (const uint4*)wx, mtiles_pad);
   return vunet_check_launch();
@@ -292,6 +309,14 @@ static int launch_x6_one(const GatherArgs& ga, const void* wx, int mtiles_pad, h
 
 template <int MT, int NT>
 static int launch_x6(const GatherArgs& ga, const void* wx, int mtiles_pad, int pro, hipStream_t st) {
+  if (ga.d.mode == 1 && ga.d.stride == 2) {   // one launch per output parity
+    if (pro != 0) return VUNET_ERR_UNSUPPORTED;
+    int rc = launch_x6_one<MT, NT, 1, 0, 0>(ga, wx, mtiles_pad, st);
+    if (rc == VUNET_OK) rc = launch_x6_one<MT, NT, 1, 0, 1>(ga, wx, mtiles_pad, st);
+    if (rc == VUNET_OK) rc = launch_x6_one<MT, NT, 1, 0, 2>(ga, wx, mtiles_pad, st);
+    if (rc == VUNET_OK) rc = launch_x6_one<MT, NT, 1, 0, 3>(ga, wx, mtiles_pad, st);
+    return rc;
+  }
   if (ga.d.mode == 1) {
     if (pro == 4) return launch_x6_one<MT, NT, 1, 4>(ga, wx, mtiles_pad, st);
     if (pro == 0) return launch_x6_one<MT, NT, 1, 0>(ga, wx, mtiles_pad, st);

@@ -309,3 +309,42 @@ def test_x6_weight_gradient_vs_fp64(n, c1, c2, cout, h, w, in_act, drop):
     assert e6 <= 5.0 * e3 + 4e-7 * scale_, (e6, e3, scale_)
     refb = dy.double().cpu().sum(dim=(0, 2, 3))
     assert_close(db6, refb.float(), rtol=1e-5, atol=1e-5 * float(refb.abs().max()), name="dshift")
+
+
+@pytest.mark.parametrize("cout,cin,h,w,nt,with_aux", [(64, 32, 8, 32, 2, False), (64, 32, 16, 64, 4, True),
+                                                       (128, 64, 8, 32, 2, False), (128, 128, 4, 64, 1, True)])
+def test_x6_stride2_data_gradient_vs_fp64(cout, cin, h, w, nt, with_aux):
+    """Data gradient of the stride-2 Downsample conv (lib/modules.py:152-158) as four output-parity launches of the
+    split-bf16 kernel over the dy map [h, w] -> dx [2h, 2w], against autograd's transposed convolution in fp64."""
+    ops = _ops()
+    n = 2
+    g_ = torch.Generator().manual_seed(cout + 3 * cin + h)
+    v, g, bias, gamma, beta = _params(cout, cin, 13)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, cin, 0, 0, True)
+    dy = torch.randn(n, cout, h, w, generator=g_).cuda()
+    aux = torch.randn(n, cin, 2 * h, 2 * w, generator=g_).cuda() if with_aux else None
+    res = torch.randn(n, cin, 2 * h, 2 * w, generator=g_).cuda() if with_aux else None
+    d = ops.ConvDesc(N=n, C1=cout, C2=0, Hs=h, Ws=w, M=cin, m_off=0, Mpad=wt_d.shape[1], Ho=2 * h, Wo=2 * w, KH=3, KW=3,
+                     stride=2, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
+                     aux_act=ops.ACT_ELU if with_aux else 0, aux_slope=0.0, aux_drop_p=0.0, aux_drop_seed=0)
+    assert ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
+    dx = torch.full((n, cin, 2 * h, 2 * w), float("nan"), device="cuda")     # every pixel must be written by some parity
+    os.environ["VUNET_X6_FORCE_NT"] = str(nt)
+    try:
+        ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
+                  ops._p(dx), ops._stream())
+    finally:
+        os.environ.pop("VUNET_X6_FORCE_NT", None)
+    wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
+    ref = F.conv_transpose2d(dy.double().cpu(), wd, stride=2, padding=1, output_padding=1)
+    if with_aux:
+        a = aux.double().cpu()
+        ref = ref * torch.where(a > 0, torch.ones_like(a), a.exp()) + res.double().cpu()
+    assert torch.isfinite(dx).all()
+    assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0), name="dx")
+    assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * max(float(ref.abs().max()), 1.0)
+    # and the fp32 per-parity gather path on the same problem
+    dx32 = torch.empty_like(dx)
+    ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(dy), None, ops._p(wt_d), None, ops._p(res), ops._p(aux),
+              ops._p(dx32), ops._stream())
+    assert_close(dx, dx32, rtol=2e-5, atol=2e-5 * max(float(ref.abs().max()), 1.0), name="x6 vs fp32 path")
