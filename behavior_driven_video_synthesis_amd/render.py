@@ -60,7 +60,8 @@ def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_s
     vunet.eval()
     stick = make_joint_img_batch((size, size), kps2d.to(app_img.device), joint_model, as_float=True)
     outs = []
-    with ops.inference_precision(dtype):
+    # the weights do not change inside a sequence: fold / pack every layer once (two launches) instead of per call
+    with ops.inference_precision(dtype), ops.prepacked(vunet):
         code = vunet.appearance_code(app_img, eps) if share_appearance else None
         for s in range(0, stick.shape[0], chunk):
             c = stick[s:s + chunk]

@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the config-1 (Market 128^2, bs 2) plumbing rows")
+    ap.add_argument("--no-render", action="store_true", help="skip the config-5 render-loop row")
     ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of CPU work allowed for the bs-16 baseline")
     ap.add_argument("--cpu-threads", type=int, default=64, help="cap on the CPU baseline's threads")
     ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)
@@ -231,6 +232,58 @@ def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
     return r
 
 
+def render_row(vunet, device, size, frames=50, chunk=25, iters=5):
+    """BASELINE config 5 (the render half): a 50-frame pose sequence -> one raster launch -> batched VunetAlter.transfer
+    (reference: per-frame cv2 raster + batch-1 transfer, data/data_conversions_3d.py:1130-1185).  Modes: fp32-accurate
+    (split-bf16 kernels), and config 5's bf16 precision (operands rounded once to bf16) with one appearance encoding per
+    sequence.  The bf16 convolution is bound by bytes in flight, not MFMA: its roofline is HBM (algorithmic bytes / 8 TB/s)."""
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.render import render_sequence
+    g = torch.Generator().manual_seed(5)
+    app = (torch.rand(1, 3, size, size, generator=g) * 2 - 1).to(device)
+    kps = (torch.rand(frames, 17, 2, generator=g) * (size - 20) + 10).to(device)
+    was = vunet.training
+    vunet.eval()
+    with torch.no_grad():
+        eps = [torch.randn(m.shape, generator=g).to(device) for m in vunet.appearance_code(app)]
+
+    def run(**kw):
+        for _ in range(2):
+            out, _ = render_sequence(vunet, app, kps, chunk=chunk, as_uint8=False, eps=eps, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out, _ = render_sequence(vunet, app, kps, chunk=chunk, as_uint8=False, eps=eps, **kw)
+        torch.cuda.synchronize()
+        return out, (time.perf_counter() - t0) / iters
+    ref, t32 = run()
+    out, t16 = run(dtype="bf16", share_appearance=True)
+    mse = float(((out - ref) ** 2).mean())
+    peak = 2 * float(ref.abs().max())
+    row = {"workload": f"{frames}-frame pose sequence -> GPU stickman raster -> batched VunetAlter.transfer at {size}x{size} "
+                       "(BASELINE configs[4], render half)",
+           "fp32_accurate": {"frames_per_s": frames / t32, "ms_per_sequence": 1e3 * t32},
+           "bf16_shared_appearance": {"frames_per_s": frames / t16, "ms_per_sequence": 1e3 * t16,
+                                      "psnr_vs_fp32_db": None if mse == 0 else 10 * float(torch.log10(torch.tensor(peak * peak / mse)))}}
+    ops.profile_start()
+    render_sequence(vunet, app, kps, chunk=chunk, as_uint8=False, eps=eps, dtype="bf16", share_appearance=True)
+    fam = ops.profile_stop(detail=True)
+    ms = nbytes = 0.0
+    for key, v in fam.items():
+        if key[0] != "conv_bf16_fwd":
+            continue
+        _, n, c1, c2, hs, ws, m, k, s_, act, _ = key
+        ms += v["ms"]
+        nbytes += 4.0 * n * hs * ws * (c1 + c2 + m + (m if act else 0)) * v["n"]   # fp32 inputs + output (+ residual of the RNB layers)
+    if ms > 0:
+        ach = nbytes / (ms * 1e-3) / 1e9
+        row["roofline"] = {"bound": "hbm", "kernel": "conv_bf16_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                           "frac": ach / 8000.0, "traffic": None,
+                           "share_of_conv_time": ms / sum(v["ms"] for v in fam.values())}
+    vunet.train(was)
+    return row
+
+
 def timed_steps(trainer, batch, warmup, steps, sync_all):
     for _ in range(warmup):
         trainer.train_fn(batch)
@@ -328,6 +381,8 @@ def main():
     elif not args.no_roofline:
         ops.profile_stop()
 
+    if rank == 0 and world == 1 and not args.no_render and args.size % 32 == 0:
+        result["render"] = render_row(trainer.vunet, device, args.size)
     # BASELINE config 1 (Market 128^2, bs 2, 30-channel 64x64 appearance input): plumbing rows, GPU and CPU
     cfg1 = batch1 = None
     if rank == 0 and world == 1 and not args.no_config1:
