@@ -134,7 +134,7 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
     int MT;
     const int NT = x6_pick(d, &MT, 128);
     if (d->stride == 2) snprintf(name, len, "conv_x6_kernel<%d, %d, 1, 0, parity x4>", MT, NT);
-    else snprintf(name, len, "conv_x6_kernel<%d, %d, %d, %d>", MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
+    else snprintf(name, len, "conv_x6_kernel<%d, %d, %d, %d, -1>", MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     return VUNET_OK;
   }
   return vunet_conv2d_gather_variant(d, has_aux, name, len);

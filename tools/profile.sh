@@ -15,10 +15,10 @@ OUT=gpurun_out
 mkdir -p $OUT
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline"
+BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-config1 --no-render"
 
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 cp $(ls $OUT/${TAG}_trace/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_fetch.err
