@@ -421,4 +421,80 @@ extern "C" int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* 
   return vunet_check_launch();
 }
 
+// ------------------------------------------------------------------ bilinear 2x up-sampling
+// nn.Upsample(scale_factor=2, mode="bilinear") with align_corners False (lib/modules.py:172-175, the non-sub-pixel
+// branch of Upsample): source coordinate (o + 0.5) / 2 - 0.5 clamped at 0, neighbours i0 = floor, i1 = min(i0 + 1, n - 1).
+// For output 2i: (i - 1, i) with weights (0.25, 0.75) (i = 0: all on 0); for 2i + 1: (i, i + 1) with (0.75, 0.25).
+__device__ __forceinline__ void bil2_src(int o, int n, int& i0, int& i1, float& l) {
+  const int i = o >> 1;
+  if (o & 1) { i0 = i; l = 0.25f; }
+  else if (i == 0) { i0 = 0; l = 0.f; }
+  else { i0 = i - 1; l = 0.75f; }
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+}
+
+__global__ void bilinear2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t NC, int H, int W) {
+  const int H2 = 2 * H, W2 = 2 * W;
+  EW_LOOP(o, NC * H2 * W2) {
+    const int ox = (int)(o % W2);
+    const int64_t t = o / W2;
+    const int oy = (int)(t % H2);
+    const float* p = x + (t / H2) * H * W;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil2_src(oy, H, y0, y1, ly);
+    bil2_src(ox, W, x0, x1, lx);
+    // same association as ATen's upsample_bilinear2d: h0lambda * (w0lambda * a + w1lambda * b) + h1lambda * (...)
+    const float top = (1.f - lx) * p[y0 * W + x0] + lx * p[y0 * W + x1];
+    const float bot = (1.f - lx) * p[y1 * W + x0] + lx * p[y1 * W + x1];
+    y[o] = (1.f - ly) * top + ly * bot;
+  }
+}
+
+// gather form of the adjoint: input pixel i receives from outputs 2i-1 (0.25), 2i (0.75; 1 if i == 0), 2i+1 (0.75; 1 if
+// i == n-1), 2i+2 (0.25) -- deterministic, no atomics
+__device__ __forceinline__ void bil2_adj(int i, int n, int o[4], float w[4]) {
+  o[0] = 2 * i - 1; w[0] = i >= 1 ? 0.25f : 0.f;
+  o[1] = 2 * i;     w[1] = i == 0 ? 1.f : 0.75f;
+  o[2] = 2 * i + 1; w[2] = i == n - 1 ? 1.f : 0.75f;
+  o[3] = 2 * i + 2; w[3] = i <= n - 2 ? 0.25f : 0.f;
+  if (o[0] < 0) o[0] = 0;
+  if (o[3] > 2 * n - 1) o[3] = 2 * n - 1;
+}
+
+__global__ void bilinear2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t NC, int H, int W) {
+  const int W2 = 2 * W;
+  EW_LOOP(e, NC * H * W) {
+    const int ix = (int)(e % W);
+    const int64_t t = e / W;
+    const int iy = (int)(t % H);
+    const float* p = dy + (t / H) * 4 * H * W;
+    int oy[4], ox[4];
+    float wy[4], wx[4];
+    bil2_adj(iy, H, oy, wy);
+    bil2_adj(ix, W, ox, wx);
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float r = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) r += wx[b] * p[oy[a] * W2 + ox[b]];
+      s += wy[a] * r;
+    }
+    dx[e] = s;
+  }
+}
+
+extern "C" int vunet_upsample_bilinear2x_fwd(const float* x, float* y, int64_t NC, int32_t H, int32_t W, void* st) {
+  if (!x || !y || NC < 1 || H < 1 || W < 1) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(bilinear2x_fwd_kernel, ew_grid(NC * 4 * H * W), dim3(256), 0, (hipStream_t)st, x, y, NC, H, W);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_upsample_bilinear2x_bwd(const float* dy, float* dx, int64_t NC, int32_t H, int32_t W, void* st) {
+  if (!dy || !dx || NC < 1 || H < 1 || W < 1) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(bilinear2x_bwd_kernel, ew_grid(NC * H * W), dim3(256), 0, (hipStream_t)st, dy, dx, NC, H, W);
+  return vunet_check_launch();
+}
+
 extern "C" int vunet_abi_version(void) { return 2; }

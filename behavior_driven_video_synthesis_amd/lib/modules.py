@@ -66,6 +66,13 @@ class DepthToSpace(nn.Module):
         return ops.DepthToSpace.apply(x)
 
 
+class UpsampleBilinear2x(nn.Module):
+    """``nn.Upsample(scale_factor=2, mode="bilinear")`` as used at lib/modules.py:175 (parameter-free)."""
+
+    def forward(self, x):
+        return ops.UpsampleBilinear2x.apply(x)
+
+
 class IDAct(nn.Module):
     """lib/modules.py:37-39."""
 
@@ -259,11 +266,15 @@ class Upsample(nn.Module):
             self.up = conv_layer(in_channels, 4 * out_channels, 3, padding=1)
             self.op2 = DepthToSpace(block_size=2)
         else:
-            # lib/modules.py:172-175 (unreachable with subpixel_upsampling: True, the only shipped setting)
-            raise NotImplementedError("bilinear Upsample branch is not part of the MI355X hot path")
+            # lib/modules.py:172-175: 3x3 conv to out_channels, then bilinear 2x up-sampling (subpixel_upsampling: False;
+            # no shipped config selects it)
+            self.up = conv_layer(in_channels, out_channels, 3, padding=1)
+            self.op2 = UpsampleBilinear2x()
 
     def forward(self, x):
-        return self.up.fused(x, d2s=True)
+        if self.subpixel:
+            return self.up.fused(x, d2s=True)
+        return self.op2(self.up(x))
 
 
 class VunetRNB(nn.Module):

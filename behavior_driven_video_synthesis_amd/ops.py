@@ -817,6 +817,27 @@ class SpaceToDepth(torch.autograd.Function):
         return dx
 
 
+class UpsampleBilinear2x(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode="bilinear") (align_corners False): lib/modules.py:172-175."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty(n, c, 2 * h, 2 * w, device=x.device, dtype=x.dtype)
+        _call("vunet_upsample_bilinear2x_fwd", _p(x), _p(y), n * c, h, w, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        n, c, h2, w2 = dy.shape
+        dx = torch.empty(n, c, h2 // 2, w2 // 2, device=dy.device, dtype=dy.dtype)
+        _call("vunet_upsample_bilinear2x_bwd", _p(dy), _p(dx), n * c, h2 // 2, w2 // 2, _stream())
+        return dx
+
+
 class Reparam(torch.autograd.Function):
     """z = eps * exp(logstd) + mu   (models/vunets.py:594-597)."""
 

@@ -200,6 +200,11 @@ int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float
 int vunet_depth_to_space(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 int vunet_space_to_depth(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 
+/* nn.Upsample(scale_factor=2, mode="bilinear"), align_corners False -- the non-sub-pixel branch of Upsample
+ * (lib/modules.py:172-175).  x: [NC][H][W] -> y: [NC][2H][2W]; bwd: the adjoint in gather form (deterministic). */
+int vunet_upsample_bilinear2x_fwd(const float* x, float* y, int64_t NC, int32_t H, int32_t W, void* stream);
+int vunet_upsample_bilinear2x_bwd(const float* dy, float* dx, int64_t NC, int32_t H, int32_t W, void* stream);
+
 /* y = a*x + b*y_in style helpers used by the autograd glue */
 int vunet_axpby(const float* x, const float* y_in, float* y, float a, float b, int64_t n, void* stream);
 /* dx = dy * act'(.) given the activation OUTPUT (sigmoid: y(1-y); relu: y>0; lrelu) */

@@ -118,6 +118,13 @@ def downsample(sd: SD, p: str, x: Tensor) -> Tensor:
     return _conv_any(sd, p + ".down", x, stride=2, padding=1)
 
 
+def upsample_bilinear(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Upsample.forward, non-sub-pixel branch (lib/modules.py:172-182): 3x3 NormConv then bilinear 2x (align_corners
+    False, what nn.Upsample(mode="bilinear") does when the argument is left at its default)."""
+    y = _conv_any(sd, p + ".up", x, padding=1)
+    return F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=False)
+
+
 def upsample(sd: SD, p: str, x: Tensor) -> Tensor:
     """Upsample.forward, sub-pixel branch (lib/modules.py:169-171,179-182)."""
     return depth_to_space(_conv_any(sd, p + ".up", x, stride=1, padding=1), 2)
@@ -197,8 +204,9 @@ def enc_down_alter(sd: SD, p: str, gs: Sequence[Tensor], n_latent: int,
 
 def dec_down_alter(sd: SD, p: str, gs: Sequence[Tensor], zs: Sequence[Tensor], n_scales: int,
                    n_latent: int, training: bool = True,
-                   prior_eps: Optional[Sequence[Tensor]] = None) -> Tensor:
-    """DecDownAlter.forward (models/vunets.py:332-414)."""
+                   prior_eps: Optional[Sequence[Tensor]] = None, subpixel: bool = True) -> Tensor:
+    """DecDownAlter.forward (models/vunets.py:332-414).  ``subpixel`` False (``subpixel_upsampling: False``): the levels
+    past the latent scales up-sample bilinearly (models/vunets.py:325-329)."""
     gs = list(gs)
     zs = list(zs)
     h = _conv_any(sd, p + ".nin", gs[-1])
@@ -212,7 +220,7 @@ def dec_down_alter(sd: SD, p: str, gs: Sequence[Tensor], zs: Sequence[Tensor], n
             h = rnb(sd, f"{p}.auto_blocks.{i}", h, z)
         h = rnb(sd, f"{p}.blocks.{2 * i + 1}", h, gs.pop())
         if i + 1 < n_scales:
-            h = upsample(sd, f"{p}.ups.{i}", h)
+            h = upsample(sd, f"{p}.ups.{i}", h) if (subpixel or i < n_latent) else upsample_bilinear(sd, f"{p}.ups.{i}", h)
     assert not gs
     return _conv_any(sd, p + ".out_conv", h, padding=1)
 
@@ -224,7 +232,8 @@ def vunet_alter_forward(sd: SD, cfg: dict, x: Tensor, c: Tensor,
     hs = enc_up(sd, "eu", x, d["n_scales_x"])
     _, means, logstds, zs = enc_down_alter(sd, "ed", hs, d["n_latent_scales"], eps)
     gs = enc_up(sd, "du", c, d["n_scales"])
-    img = dec_down_alter(sd, "dd", gs, zs, d["n_scales"], d["n_latent_scales"], True)
+    img = dec_down_alter(sd, "dd", gs, zs, d["n_scales"], d["n_latent_scales"], True,
+                         subpixel=bool(cfg.get("subpixel_upsampling", True)))
     return img, means, logstds, hs
 
 

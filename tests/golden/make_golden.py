@@ -506,6 +506,37 @@ def g6_full_size():
         save("g6_" + tag, meta, arrays)
 
 
+# ---------------------------------------------------------------- G1b the bilinear Upsample branch (lib/modules.py:172-182)
+def g1b_upsample_bilinear():
+    seed = 13
+    arrays, meta = {}, {"seed": seed}
+    up = rm.Upsample(8, 6, subpixel=False)
+    meta["shapes"] = load_synth(up, seed)
+    up.train()
+    x = synth_image("upb.x", (2, 8, 7, 10), seed).requires_grad_(True)
+    y = up(x)
+    (y * seeded_randn("upb.w", tuple(y.shape), seed)).sum().backward()
+    arrays["y"], arrays["gx"] = y.detach().numpy(), x.grad.numpy()
+    for k, p_ in up.named_parameters():
+        arrays["gp." + k] = p_.grad.numpy()
+    # whole model with subpixel_upsampling False: sub-pixel on the latent levels, bilinear past them (models/vunets.py:325-329)
+    cfg = dict(ALTER_CFG)
+    cfg["subpixel_upsampling"] = False
+    net = rv.VunetAlter(n_channels_x=3, **cfg)
+    meta["model_shapes"] = load_synth(net, seed)
+    meta["cfg"] = cfg
+    net.train()
+    xi, c = synth_image("upb.mx", (2, 3, 32, 32), seed), synth_image("upb.mc", (2, 3, 32, 32), seed)
+    with FixedNoise("upb", seed) as fn:
+        img, means, logstds, _ = net(xi, c)
+    (img * seeded_randn("upb.mw", tuple(img.shape), seed)).sum().backward()
+    arrays["img"] = img.detach().numpy()
+    meta["eps_shapes"] = fn.shapes
+    meta["grad_sums"] = {k: (None if p_.grad is None else [float(p_.grad.double().sum()), float(p_.grad.double().abs().sum())])
+                         for k, p_ in net.named_parameters()}
+    save("g1b_upsample_bilinear", meta, arrays)
+
+
 # ---------------------------------------------------------------- G7 evaluation statistics (lib/metrics.py:277-415)
 def g7_metrics():
     """FID statistics (_calculate_fid on mean / np.cov of features) and the Inception score (inception_score driven with
@@ -564,3 +595,4 @@ if __name__ == "__main__":
     g5_regressor_trajectory()
     g6_full_size()
     g7_metrics()
+    g1b_upsample_bilinear()

@@ -301,3 +301,27 @@ def test_g6_full_size(tag):
     (img * seeded_randn(tag + ".w", tuple(img.shape), seed)).sum().backward()
     check_full_size(meta, arr, img.detach(), [m.detach() for m in means], [l.detach() for l in logstds],
                     {k: v.grad for k, v in sd.items()})
+
+
+def test_g1b_bilinear_upsample_branch():
+    """Upsample(subpixel=False) (lib/modules.py:172-182) and a VunetAlter built with subpixel_upsampling False."""
+    meta, arr = load_golden("g1b_upsample_bilinear")
+    seed = meta["seed"]
+    sd = {"." + k: v.requires_grad_(True) for k, v in synth_state_dict(meta["shapes"], seed).items()}
+    x = synth_image("upb.x", (2, 8, 7, 10), seed).requires_grad_(True)
+    y = O.upsample_bilinear(sd, "", x)
+    close(y, arr["y"])
+    (y * seeded_randn("upb.w", tuple(y.shape), seed)).sum().backward()
+    close(x.grad, arr["gx"], rtol=1e-3, atol=1e-5)
+    for k in meta["shapes"]:
+        close(sd["." + k].grad, arr["gp." + k], rtol=1e-3, atol=1e-4)
+    cfg = meta["cfg"]
+    msd = {k: v.requires_grad_(True) for k, v in synth_state_dict(meta["model_shapes"], seed).items()}
+    xi, c = synth_image("upb.mx", (2, 3, 32, 32), seed), synth_image("upb.mc", (2, 3, 32, 32), seed)
+    eps = [seeded_randn(f"upb.eps{i}", tuple(s), seed) for i, s in enumerate(meta["eps_shapes"])]
+    img, _, _, _ = O.vunet_alter_forward(msd, cfg, xi, c, eps)
+    close(img, arr["img"])
+    (img * seeded_randn("upb.mw", tuple(img.shape), seed)).sum().backward()
+    for k, s in meta["grad_sums"].items():
+        if s is not None:
+            assert abs(float(msd[k].grad.double().abs().sum()) - s[1]) <= 1e-3 * s[1] + 1e-4, k

@@ -3,7 +3,8 @@
 #
 #     gpurun --timeout 1500 -- 'bash tools/profile.sh r02'
 #
-# 1. rocprofv3 --kernel-trace --stats          -> gpurun_out/<tag>_kernel_stats.csv   (per-kernel time of the timed step)
+# 1. rocprofv3 --kernel-trace --stats          -> gpurun_out/<tag>_kernel_stats.csv   (per-kernel time of the timed step, 4 HIP streams)
+#                                                 gpurun_out/<tag>_kernel_stats_1stream.csv (same, one stream: exclusive durations)
 # 2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE   -> gpurun_out/<tag>_pmc_traffic.json   (HBM bytes per launch; separate
 #    passes and the gfx950 FETCH_SIZE x2 correction, as MI355X_MICROARCH.md "HBM" prescribes)
 # 3. rocprofv3 --pmc SQ_* (one pass)           -> gpurun_out/<tag>_pmc_sq.json        (MFMA-pipe busy / wave cycles)
@@ -20,6 +21,14 @@ BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-config
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 cp $(ls $OUT/${TAG}_trace/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
+# the same trace with everything on ONE HIP stream: per-kernel durations without the other streams' kernels beside them
+# (what bench.py's `roofline` region measures with HIP events; compare its avg_launch_us with the AverageNs here)
+export VUNET_TWO_STREAMS=0
+rm -rf $OUT/${TAG}_trace1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render > $OUT/${TAG}_trace1_bench.json 2> $OUT/${TAG}_trace1.err
+cp $(ls $OUT/${TAG}_trace1/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats_1stream.csv 2>/dev/null
+rm -rf $OUT/${TAG}_trace1
+unset VUNET_TWO_STREAMS
 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_write.err
