@@ -243,3 +243,33 @@ def test_train_fn_at_the_benchmark_size():
     assert la == lb and sa == sb, (la, lb)             # bit-identical from run to run
     lc, _, sc = run(False, 6)
     assert la == lc and sa == sc, (la, lc)             # one HIP stream == four HIP streams
+
+
+def test_shape_pose_net_l2_conv_variant_initialises_and_trains():
+    """conv_layer_type l2 through the training loop: the data-dependent init of L2NormConv2d (lib/modules.py:95-99) runs
+    while iteration <= n_init_batches (experiments/shape_and_pose_net.py:199-206), writes THROUGH the flat-bucket views
+    (ADVICE r1), and the fused Adam then trains the initialised gamma / beta."""
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    from behavior_driven_video_synthesis_amd.lib.modules import L2NormConv2d
+    cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, n_init_batches=2, train_regressor=False, dropout_prob=0.0)
+    cfg["architecture"]["conv_layer_type"] = "l2"
+    tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True)
+    l2 = [m for m in tr.vunet.modules() if isinstance(m, L2NormConv2d)]
+    assert len(l2) > 10
+    batch = synthetic_batch(4, 32, "cuda:0")
+    g_before = [m.gamma.detach().clone() for m in l2]
+    out1 = tr.train_fn(batch)
+    flat_lo = min(b.flat.data_ptr() for b in tr.optimizer.buckets)
+    flat_hi = max(b.flat.data_ptr() + 4 * b.numel for b in tr.optimizer.buckets)
+    for m in l2:
+        assert flat_lo <= m.gamma.data_ptr() < flat_hi and flat_lo <= m.beta.data_ptr() < flat_hi   # still bucket views
+    changed = sum(int(not torch.equal(a, m.gamma.detach())) for a, m in zip(g_before, l2))
+    assert changed == len(l2)                       # every reached layer re-initialised gamma from its batch statistics
+    tr.train_fn(batch)                              # iteration 2 <= n_init_batches: init again (then Adam)
+    g_init = [m.gamma.detach().clone() for m in l2]
+    outs = [tr.train_fn(batch) for _ in range(3)]   # iterations 3..5: no more init, Adam moves the parameters
+    assert all(torch.isfinite(torch.as_tensor(float(o["loss"]))) for o in [out1] + outs)
+    moved = sum(int(not torch.equal(a, m.gamma.detach())) for a, m in zip(g_init, l2))
+    assert moved > len(l2) // 2
+    assert float(outs[-1]["likelihood_loss"]) < float(out1["likelihood_loss"]) * 1.5
