@@ -33,13 +33,29 @@ struct InAct {
   uint32_t seed;
   float keep_scale;   // 1/(1-p)
   float slope;        // leaky-relu slope
+  // optional device-resident step counter (vunet_set_dropout_step): the mask of step t uses seed + t * DROP_STEP_MUL, so
+  // a launch whose arguments are frozen in a captured hipGraph still draws a fresh mask on every replay
+  const uint32_t* step;
 };
+
+#define VUNET_DROP_STEP_MUL 0x9E3779B1u
+
+__device__ __forceinline__ uint32_t inact_seed(const InAct& a) {
+  return a.step ? a.seed + (*a.step) * VUNET_DROP_STEP_MUL : a.seed;
+}
+
+// kernels resolve the step counter ONCE, at entry, into their own copy of the launch arguments (one scalar load before
+// any store; afterwards `step` is null and the hash calls below touch no memory)
+__device__ __forceinline__ void inact_resolve(InAct& a) {
+  a.seed = inact_seed(a);
+  a.step = nullptr;
+}
 
 __device__ __forceinline__ float apply_in_act(const InAct& a, float v, uint32_t idx) {
   if (a.act == ACT_ELU) v = elu_f(v);
   else if (a.act == ACT_RELU) v = v > 0.f ? v : 0.f;
   else if (a.act == ACT_LRELU) v = v > 0.f ? v : v * a.slope;
-  if (a.thresh) v = (vunet_hash_u32(idx + a.seed) >= a.thresh) ? v * a.keep_scale : 0.f;
+  if (a.thresh) v = (vunet_hash_u32(idx + inact_seed(a)) >= a.thresh) ? v * a.keep_scale : 0.f;
   return v;
 }
 
@@ -49,7 +65,7 @@ __device__ __forceinline__ float in_act_grad(const InAct& a, float v, uint32_t i
   if (a.act == ACT_ELU) g = elu_grad_f(v);
   else if (a.act == ACT_RELU) g = v > 0.f ? 1.f : 0.f;
   else if (a.act == ACT_LRELU) g = v > 0.f ? 1.f : a.slope;
-  if (a.thresh) g = (vunet_hash_u32(idx + a.seed) >= a.thresh) ? g * a.keep_scale : 0.f;
+  if (a.thresh) g = (vunet_hash_u32(idx + inact_seed(a)) >= a.thresh) ? g * a.keep_scale : 0.f;
   return g;
 }
 
@@ -67,11 +83,15 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   return start + idx;
 }
 
+// process-wide: device pointer to the dropout step counter, or nullptr (pointwise.hip: vunet_set_dropout_step)
+extern const uint32_t* g_vunet_drop_step;
+
 static inline InAct make_inact(int act, float slope, float p, uint32_t seed) {
   InAct a;
   a.act = act;
   a.slope = slope;
   a.seed = seed;
+  a.step = p > 0.f ? g_vunet_drop_step : nullptr;
   if (p > 0.f) {
     double t = (double)p * 4294967296.0;
     a.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;

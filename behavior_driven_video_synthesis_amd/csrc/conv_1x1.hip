@@ -16,7 +16,11 @@
 #include "conv_common.h"
 
 template <int MT, int MODE, int PRO>
-__global__ __launch_bounds__(256, 3) void conv_1x1_kernel(const GatherArgs a, const int ntiles, const int tiles_per_img) {
+__global__ __launch_bounds__(256, 3) void conv_1x1_kernel(const GatherArgs a_in, const int ntiles, const int tiles_per_img) {
+  GatherArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  inact_resolve(a.auxa);
   constexpr int CK = 32, MB = 32 * MT;
   constexpr int NW = CK * MB / 256;   // weight floats staged per thread per chunk
   __shared__ float wL[2][CK * MB];

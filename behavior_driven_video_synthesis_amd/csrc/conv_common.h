@@ -46,7 +46,7 @@ __device__ __forceinline__ float prologue(const InAct& a, float v, uint32_t idx)
   if (PRO == 1) return elu_f(v);
   if (PRO == 2) {
     v = elu_f(v);
-    return (vunet_hash_u32(idx + a.seed) >= a.thresh) ? v * a.keep_scale : 0.f;
+    return (vunet_hash_u32(idx + inact_seed(a)) >= a.thresh) ? v * a.keep_scale : 0.f;
   }
   return apply_in_act(a, v, idx);
 }

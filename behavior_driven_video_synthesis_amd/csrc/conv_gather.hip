@@ -202,7 +202,11 @@ __device__ __forceinline__ void k_loop(const GatherArgs& a, const TileGeo* tg, c
 }
 
 template <int MT, int NT, int PRO, int KS>
-__global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a_in) {
+  GatherArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  inact_resolve(a.auxa);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const vunet_conv_desc& d = a.d;
@@ -247,7 +251,11 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
 
 // ---- split-K variant for small maps: one 32x32 output tile per workgroup, SW waves share K
 template <int SW, int PRO, int KS>
-__global__ __launch_bounds__(SW * 64) void conv_gather_splitk_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(SW * 64) void conv_gather_splitk_kernel(const GatherArgs a_in) {
+  GatherArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  inact_resolve(a.auxa);
   extern __shared__ __attribute__((aligned(16))) float red[];  // [SW][16][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;

@@ -23,7 +23,11 @@
 // TW = 32: an MFMA pixel tile is one 32-pixel row segment; TW = 16 (16-wide maps): two 16-pixel row segments.
 // S = 2: the stride-2 Downsample conv (forward only): the staged input tile is (2*TH+1) x (2*TW+1).
 template <int MT, int NT, int CK, int MODE, int PRO, int TW = 32, int S = 1>
-__global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_tiled_kernel(const GatherArgs a_in) {
+  GatherArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  inact_resolve(a.auxa);
   constexpr int RPT = 32 / TW;                  // rows per MFMA pixel tile
   constexpr int TH = 4 * NT * RPT, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
   constexpr int MB = 32 * MT;

@@ -24,7 +24,10 @@ struct WgradArgs {
 };
 
 template <int WM, int WN, int NTW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a_in) {
+  WgradArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MB = 32 * WM;
   constexpr int PITCH = 33;

@@ -26,7 +26,10 @@ struct WgradTiledArgs {
 
 // S = 2 (the stride-2 Downsample convs): tiles walk the output map, the staged input tile is (2*TH+1) x 65.
 template <int MTW, int TH, int KS, int S = 1>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTiledArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(const WgradTiledArgs a_in) {
+  WgradTiledArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
   constexpr int WP = 4 / MTW;        // pixel parts (waves sharing one m-tile)
   constexpr int RW = TH / WP;        // tile rows per wave
   constexpr int HALO = KS / 2, NTAP = KS * KS;

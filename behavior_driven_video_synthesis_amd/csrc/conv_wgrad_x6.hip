@@ -59,7 +59,10 @@ __device__ __forceinline__ wg_bf16x8 wg_frag(uint32_t a, uint32_t b, uint32_t c,
 }
 
 template <int MTW>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradX6Args a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradX6Args a_in) {
+  WgradX6Args a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
   constexpr int TH = 4;
   // optional register prefetch of the next tile's f(x) across the MFMA block
   constexpr bool PREFETCH = false;   // measured: no gain from the register prefetch (r02), and two m-tiles spill with it

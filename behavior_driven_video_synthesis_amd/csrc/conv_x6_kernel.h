@@ -66,7 +66,11 @@ constexpr int X6_SLAB = 576;  // 16-byte units of one (chunk, kh, m-tile) weight
 // taps, stored to every other pixel of dx.  Four launches cover the four parities; no MFMA is spent on the structural
 // zeros of a transposed strided convolution.
 template <int MT, int NT, int MODE, int PRO, int PHW = -1>
-__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const GatherArgs a, const uint4* __restrict__ wx, int mtiles_pad) {
+__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const GatherArgs a_in, const uint4* __restrict__ wx, int mtiles_pad) {
+  GatherArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  inact_resolve(a.auxa);
   static_assert(PHW < 0 || MODE == 1, "parity phases exist for the data gradient only");
   constexpr int PH = PHW >= 0 ? (PHW >> 1) : 0, PW = PHW >= 0 ? (PHW & 1) : 0;
   constexpr int NKH = PHW < 0 ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk

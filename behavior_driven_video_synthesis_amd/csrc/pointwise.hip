@@ -375,6 +375,14 @@ extern "C" int vunet_instnorm_bwd(const float* y, const float* dy, const float* 
   return vunet_check_launch();
 }
 
+// ------------------------------------------------------------------ dropout step counter (see InAct::step)
+const uint32_t* g_vunet_drop_step = nullptr;
+
+extern "C" int vunet_set_dropout_step(const uint32_t* step_dev) {
+  g_vunet_drop_step = step_dev;
+  return VUNET_OK;
+}
+
 // ------------------------------------------------------------------ fused Adam over a flat buffer
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float step_size, float b1, float b2, float eps,
@@ -402,14 +410,45 @@ extern "C" int vunet_adam_step(float* param, const float* grad, float* exp_avg, 
   return vunet_check_launch();
 }
 
+// The same update with the learning rate and the step count read from DEVICE memory (float64 / int64 scalars): nothing
+// that changes from step to step is a launch argument, so the launch can sit in a captured hipGraph.  Bias corrections
+// are formed in double exactly as the host version forms them.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, int64_t n, const double* __restrict__ lr,
+                                const int64_t* __restrict__ step, float b1, float b2, float eps, float wd, float gscale) {
+  const double t = (double)*step;
+  const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+  const float step_size = (float)((double)(float)*lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  EW_LOOP(i, n) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+extern "C" int vunet_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const double* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                                   const int64_t* step_dev, float grad_scale, void* st) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(adam_dev_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, param, grad, exp_avg, exp_avg_sq, n, lr_dev,
+               step_dev, beta1, beta2, eps, weight_decay, grad_scale);
+  return vunet_check_launch();
+}
+
 // ------------------------------------------------------------------ misc
-__global__ void dropout_mask_kernel(float* mask, int64_t n, uint32_t thresh, uint32_t seed) {
+__global__ void dropout_mask_kernel(float* mask, int64_t n, uint32_t thresh, uint32_t seed, const uint32_t* step) {
+  if (step) seed += (*step) * VUNET_DROP_STEP_MUL;
   EW_LOOP(i, n) mask[i] = vunet_hash_u32((uint32_t)i + seed) >= thresh ? 1.f : 0.f;
 }
 extern "C" int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* st) {
   if (!mask) return VUNET_ERR_ARG;
   const InAct a = make_inact(ACT_NONE, 0.f, p, seed);
-  VUNET_LAUNCH(dropout_mask_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mask, n, a.thresh, seed);
+  VUNET_LAUNCH(dropout_mask_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mask, n, a.thresh, seed, a.step);
   return vunet_check_launch();
 }
 __global__ void u8_to_unit_kernel(const uint8_t* in, float* out, int64_t n) {

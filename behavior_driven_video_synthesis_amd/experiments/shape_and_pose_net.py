@@ -56,7 +56,8 @@ DEFAULT_CONFIG = {
 class ShapePoseNet:
     def __init__(self, config: Dict, device="cuda:0", n_channels_x: int = 3, n_keypoints: int = 17,
                  vgg_weights_path: Optional[str] = None, vgg_width_div: int = 1, total_steps: Optional[int] = None,
-                 process_group=None, vgg_synthetic: bool = False, vgg_seed: int = 1234):
+                 process_group=None, vgg_synthetic: bool = False, vgg_seed: int = 1234,
+                 hip_graph: Optional[bool] = None):
         self.config = config
         self.device = torch.device(device)
         arch, data, tr = config["architecture"], config["data"], config["training"]
@@ -118,6 +119,13 @@ class ShapePoseNet:
         for pg in self.optimizer.param_groups:
             pg["lr"] = self.lr
         self.gamma = torch.zeros((), device=self.device, dtype=torch.float32)  # device-resident controller state
+        # ---- hipGraph replay of the whole step (opt-in: ``training.hip_graph`` / VUNET_HIP_GRAPH=1 / the keyword)
+        self._dev_sched = False
+        self._graphs = {}
+        if hip_graph is None:
+            hip_graph = bool(tr.get("hip_graph", os.environ.get("VUNET_HIP_GRAPH", "0") == "1"))
+        if hip_graph:
+            self.enable_hip_graph()
         print(f"Number of trainable params is {n_parameters(self.vunet)}")
 
     # ---- schedules
@@ -137,25 +145,103 @@ class ShapePoseNet:
             pg["lr"] = self.lr
             pg["gamma"] = self.gamma
 
+    # ---- hipGraph mode ------------------------------------------------------------------------------------
+    # A training step is ~1900 kernel launches issued from Python (~18 ms of host time); for the small
+    # configurations (batch 1-2, 128x128 maps) the GPU finishes sooner than the host can issue.  In graph mode
+    # everything that changes from step to step lives in DEVICE memory -- the learning rate and Adam's step count
+    # (vunet_adam_step_dev), the dropout step counter (vunet_set_dropout_step), gamma and information_max of the KL
+    # controller -- so the launch arguments of a step are constants, the step is captured once (after the
+    # initialisation batches, per batch geometry) and replayed with one hipGraphLaunch.  The host still runs the
+    # schedules (:500-512) and writes the two scalars before every replay.  Same arithmetic as the eager device-schedule
+    # step, kernel for kernel (tests/test_hip_training.py::test_hip_graph_replay_is_bit_identical_to_eager).
+    def enable_hip_graph(self, capture: bool = True):
+        """``capture=False`` keeps the device-resident schedule but launches eagerly (the parity baseline of the test)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("hipGraph mode needs the GPU")
+        if self.gan is not None or self.averager.active:
+            raise RuntimeError("hipGraph mode covers the single-GPU reference step (no adversarial term, no RCCL "
+                               "all-reduce inside the capture); run those configurations eagerly")
+        if not self._dev_sched:
+            self._lr_dev = torch.full((1,), self.lr, dtype=torch.float64, device=self.device)
+            self._imax_dev = torch.full((), self.imax, dtype=torch.float32, device=self.device)
+            self._drop_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.optimizer.use_device_schedule(self._lr_dev)
+            if self.train_regressor:
+                self.optimizer_regressor.use_device_schedule()
+            ops.set_dropout_step(self._drop_step)
+            self._graph_stream = torch.cuda.Stream()
+            self._dev_sched = True
+            self._eager_dev_steps = 0
+        self._capture = bool(capture)
+        return self
+
+    def _graph_key(self, batch, it):
+        tr = self.config["training"]
+        # the KL term joins the loss (and the l2 layers stop initialising) after the init batches; two eager steps of
+        # the final shape in THIS process come first, so that lazily built state (frozen VGG packs, the prepack table,
+        # companion streams) exists before anything is recorded
+        if it <= tr["n_init_batches"] or self._eager_dev_steps < 2:
+            return None
+        return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v)))
+
+    def _train_fn_graph(self, batch, it, eps, reg_eps):
+        # host-side schedule values of THIS step -> device (two tiny launches outside the graph)
+        self._lr_dev.fill_(self.lr)
+        self._imax_dev.fill_(self.imax)
+        self._drop_step.fill_(it & 0x7FFFFFFF)
+        ops.reset_dropout_counter()
+        key = self._graph_key(batch, it) if (self._capture and eps is None and reg_eps is None) else None
+        if key is None:
+            if it > self.config["training"]["n_init_batches"]:
+                self._eager_dev_steps += 1
+            self.optimizer.zero_grad()
+            with ops.prepacked(self.vunet):
+                return self._step(batch, it, eps, reg_eps)
+        rec = self._graphs.get(key)
+        fresh = rec is None
+        if fresh:
+            static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=self._graph_stream):
+                self.optimizer.zero_grad()
+                with ops.prepacked(self.vunet):
+                    out = self._step(static, it, None, None)
+            rec = self._graphs[key] = {"graph": graph, "static": static, "out": out}
+        else:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    rec["static"][k].copy_(v, non_blocking=True)
+            # the capture pass already advanced the host-side step counts once
+            self.optimizer.note_replayed_steps(1)
+            if self.train_regressor and "reg_imgs" in batch:
+                self.optimizer_regressor.note_replayed_steps(batch["reg_imgs"].shape[1])
+        rec["graph"].replay()
+        return dict(rec["out"])   # tensors are the graph's static outputs: valid until the next train_fn call
+
     # ---- one training step (:360-466)
     def train_fn(self, batch: Dict[str, torch.Tensor], eps=None, reg_eps=None) -> Dict[str, torch.Tensor]:
         """``eps`` / ``reg_eps`` inject the Gaussian draws of the posterior sampling (one tensor per latent scale; for
         the regressor side loop one such list per regressor step) -- the parity tests' hook, None in production."""
-        tr = self.config["training"]
         self.vunet.train()
         self.iteration += 1
         it = self.iteration
+        self.averager.start_step()
+        if self._dev_sched:
+            out = self._train_fn_graph(batch, it, eps, reg_eps)
+        else:
+            self.optimizer.zero_grad()
+            with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
+                out = self._step(batch, it, eps, reg_eps)
+        self.adjust_params(it)
+        out.update({"learning_rate": self.lr, "gamma": self.gamma, "imax": self.imax})
+        return out
+
+    def _step(self, batch, it, eps, reg_eps=None):
+        tr = self.config["training"]
         target_img = batch["pose_img"]
         shape_img = batch["stickman"]
         pose_img = batch.get("pose_img_inplane", target_img)
-
-        self.averager.start_step()
-        self.optimizer.zero_grad()
-        with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
-            return self._step(batch, it, target_img, shape_img, pose_img, eps, reg_eps)
-
-    def _step(self, batch, it, target_img, shape_img, pose_img, eps, reg_eps=None):
-        tr = self.config["training"]
         out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
         ld = vgg_loss(self.custom_vgg, target_img, out_img)
         likelihoods = torch.stack([ld[k] for k in ld], dim=0)
@@ -190,10 +276,11 @@ class ShapePoseNet:
         if patches is not None:
             out.update(self.gan.train_disc(*patches))
         # gamma controller on the device (:82-85,442); with DP every rank sees the averaged KL
-        self.gamma = torch.clamp(self.gamma - tr["gamma_step"] * (self.imax - kl_avg.reshape(())), min=0.0)
-        self.adjust_params(it)
-        out.update({"loss": loss.detach(), "likelihood_loss": likelihood_loss.detach(), "kl_loss": kl.detach(),
-                    "learning_rate": self.lr, "gamma": self.gamma, "imax": self.imax})
+        if self._dev_sched:   # in place, information_max from device memory: nothing here is a per-step launch argument
+            self.gamma.copy_(torch.clamp(self.gamma - tr["gamma_step"] * (self._imax_dev - kl_avg.reshape(())), min=0.0))
+        else:
+            self.gamma = torch.clamp(self.gamma - tr["gamma_step"] * (self.imax - kl_avg.reshape(())), min=0.0)
+        out.update({"loss": loss.detach(), "likelihood_loss": likelihood_loss.detach(), "kl_loss": kl.detach()})
         out.update({k: v.detach() for k, v in ld.items()})
         return out
 
@@ -256,7 +343,7 @@ class ShapePoseNet:
             if states:
                 self.iteration = int(states[-1]["step"])  # :248-255
             if gamma is not None:
-                self.gamma = torch.as_tensor(float(gamma), dtype=torch.float32, device=self.device).reshape(())
+                self.gamma.fill_(float(gamma))   # in place: a captured step holds this tensor's address
             self.adjust_params(self.iteration)
         if self.train_regressor and ckpt.get("regressor") is not None:
             self.regressor.load_state_dict(ckpt["regressor"]["model"])

@@ -84,12 +84,30 @@ def _r32(x: int) -> int:
 # ------------------------------------------------------------------------------------------------
 # dropout seeds: one fresh 32-bit seed per fused conv call, derived from torch's seed
 # ------------------------------------------------------------------------------------------------
-_drop_state = {"base": None, "ctr": 0}
+_drop_state = {"base": None, "ctr": 0, "step": None}
 
 
 def set_dropout_seed(seed: int):
     _drop_state["base"] = int(seed) & 0xFFFFFFFF
     _drop_state["ctr"] = 0
+
+
+def reset_dropout_counter():
+    """Restart the per-call seed sequence: the n-th fused conv of every step gets the same seed again.  Used together
+    with ``set_dropout_step``: the step-to-step variation of the masks then comes from the device counter alone, so the
+    launch arguments of a step are constant and the step can be replayed from a captured hipGraph."""
+    if _drop_state["base"] is None:
+        set_dropout_seed(torch.initial_seed())
+    _drop_state["ctr"] = 0
+
+
+def set_dropout_step(counter: Optional[torch.Tensor]):
+    """Process-wide device-resident dropout step counter (one int32 element on the GPU, read as uint32; None clears it):
+    every dropout prologue launched while it is set hashes with ``seed + counter * 0x9E3779B1`` (vunet_set_dropout_step)."""
+    if counter is not None and not (counter.is_cuda and counter.dtype == torch.int32 and counter.numel() == 1):
+        raise RuntimeError("dropout step counter: one int32 element on the GPU")
+    _drop_state["step"] = counter   # keeps the allocation alive while the library points at it
+    _call("vunet_set_dropout_step", _p(counter))
 
 
 def next_dropout_seed() -> int:
@@ -401,7 +419,7 @@ def _differentiable_layer(x1, x2, res, v, g, bias, gamma, beta, cfg):
 # data-parallel averager) are told which parameter gradients have just been completed.
 _grad_hooks = []
 _direct_grads_enabled = True
-_wgrad_streams = {"on": False, "by_stream": {}}
+_wgrad_streams = {"on": False, "by_stream": {}, "dirty": set()}
 
 
 def enable_wgrad_streams(on: bool = True):
@@ -415,13 +433,19 @@ def _wgrad_stream_for(cur):
     ws = _wgrad_streams["by_stream"].get(cur.cuda_stream)
     if ws is None:
         ws = _wgrad_streams["by_stream"][cur.cuda_stream] = torch.cuda.Stream()
+    _wgrad_streams["dirty"].add(cur.cuda_stream)
     return ws
 
 
 def join_wgrad_streams():
+    """The current stream waits for every companion stream that has been handed work since the last join (only those:
+    a stream that took no part in a hipGraph capture must not be waited on from inside it)."""
     cur = torch.cuda.current_stream()
-    for ws in _wgrad_streams["by_stream"].values():
-        cur.wait_stream(ws)
+    for key in _wgrad_streams["dirty"]:
+        cur.wait_stream(_wgrad_streams["by_stream"][key])
+    _wgrad_streams["dirty"].clear()
+
+
 _inference_bf16 = False
 
 
@@ -1024,3 +1048,14 @@ def adam_step_flat(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weig
     _dev(param, grad, exp_avg, exp_avg_sq)
     _call("vunet_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(beta1),
           float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+def adam_step_flat_dev(param, grad, exp_avg, exp_avg_sq, lr_dev, beta1, beta2, eps, weight_decay, step_dev,
+                       grad_scale=1.0):
+    """``adam_step_flat`` with the learning rate (float64 [1]) and the step count (int64 [1]) read from device memory:
+    no per-step launch argument (vunet_adam_step_dev)."""
+    _dev(param, grad, exp_avg, exp_avg_sq)
+    if not (lr_dev.is_cuda and lr_dev.dtype == torch.float64 and step_dev.is_cuda and step_dev.dtype == torch.int64):
+        raise RuntimeError("adam_step_flat_dev: lr as a float64 and step as an int64 device tensor")
+    _call("vunet_adam_step_dev", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(lr_dev),
+          float(beta1), float(beta2), float(eps), float(weight_decay), _p(step_dev), float(grad_scale), _stream())

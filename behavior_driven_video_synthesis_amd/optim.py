@@ -73,6 +73,24 @@ class FusedAdam:
             b.step = 0
             self.buckets.append(b)
             self.param_groups.append(g)
+        self.lr_dev = self.step_dev = None
+
+    def use_device_schedule(self, lr_dev: torch.Tensor = None):
+        """Keep the step count (int64) and the learning rate (float64, ``lr_dev`` or a tensor of its own) on the device:
+        ``step()`` then issues no launch argument that changes between steps (vunet_adam_step_dev) and can be captured
+        in a hipGraph.  The caller writes ``lr_dev`` (outside the graph); the step count advances inside ``step()``.
+        One learning rate for all groups -- what the reference's schedule sets (:500-512)."""
+        dev = self.buckets[0].flat.device
+        self.lr_dev = lr_dev if lr_dev is not None else torch.full((1,), float(self.param_groups[0]["lr"]),
+                                                                   dtype=torch.float64, device=dev)
+        self.step_dev = torch.full((1,), int(self.buckets[0].step), dtype=torch.int64, device=dev)
+        return self
+
+    def note_replayed_steps(self, n: int = 1):
+        """A captured graph containing ``n`` calls of ``step()`` was replayed: advance the host-side step counts (the
+        checkpoint layout carries them) without launching anything."""
+        for b in self.buckets:
+            b.step += n
 
     def zero_grad(self, set_to_none: bool = False):
         for b in self.buckets:
@@ -82,6 +100,14 @@ class FusedAdam:
     def step(self, grad_scale: float = 1.0):
         if self.buckets[0].grad.is_cuda:
             ops.join_wgrad_streams()   # gradients written in place by backward's companion streams come first
+        if self.step_dev is not None:
+            self.step_dev.add_(1)
+            for g, b in zip(self.param_groups, self.buckets):
+                b.gather_foreign_grads()
+                b.step += 1
+                ops.adam_step_flat_dev(b.flat, b.grad, b.exp_avg, b.exp_avg_sq, self.lr_dev, g["betas"][0], g["betas"][1],
+                                       g["eps"], g["weight_decay"], self.step_dev, grad_scale)
+            return
         for g, b in zip(self.param_groups, self.buckets):
             b.gather_foreign_grads()
             b.step += 1
@@ -120,3 +146,5 @@ class FusedAdam:
                     steps.append(int(st["step"]))
                 idx += 1
             b.step = max(steps) if steps else 0
+        if self.step_dev is not None:
+            self.step_dev.fill_(int(self.buckets[0].step))

@@ -258,6 +258,18 @@ int vunet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                     void* stream);
 
+/* The same update with lr (float64) and the step count (int64) read from device memory: no per-step launch argument,
+ * so the launch can be captured in a hipGraph and replayed (experiments.shape_and_pose_net graph mode). */
+int vunet_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const double* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                        const int64_t* step_dev, float grad_scale, void* stream);
+
+/* Optional, process-wide: a device-resident step counter for the dropout hash.  While set (non-NULL), every dropout
+ * prologue / epilogue launched afterwards uses  seed + (*step_dev) * 0x9E3779B1  instead of seed: launches whose arguments
+ * are frozen in a captured hipGraph then draw a fresh mask on every replay, identically in the forward, data-gradient and
+ * weight-gradient kernels of a step.  NULL (the default) restores plain seeds.  The pointer must stay valid while set. */
+int vunet_set_dropout_step(const uint32_t* step_dev);
+
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */
 int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* stream);
 

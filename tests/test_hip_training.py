@@ -273,3 +273,68 @@ def test_shape_pose_net_l2_conv_variant_initialises_and_trains():
     moved = sum(int(not torch.equal(a, m.gamma.detach())) for a, m in zip(g_init, l2))
     assert moved > len(l2) // 2
     assert float(outs[-1]["likelihood_loss"]) < float(out1["likelihood_loss"]) * 1.5
+
+
+def _graph_run(capture, steps, with_regressor=False, dropout=0.05, seed=4321):
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    ops.set_dropout_seed(seed)
+    cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, n_init_batches=1, gamma_step=1e-3, information_max=5.0,
+                train_regressor=with_regressor, dropout_prob=dropout, imax_scaling="ascend")
+    tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True, hip_graph=False)
+    if capture is not None:
+        tr.enable_hip_graph(capture=capture)
+    torch.manual_seed(99)                       # the posterior draws (torch.randn_like) of both runs
+    outs = []
+    for i in range(steps):
+        batch = synthetic_batch(4, 32, "cuda:0", seed=100 + i)   # a fresh batch every step: the static inputs are refilled
+        if with_regressor:
+            g = torch.Generator().manual_seed(7 + i)
+            batch["reg_imgs"] = (torch.rand(4, 2, 3, 32, 32, generator=g) * 2 - 1).cuda()
+            batch["reg_targets"] = torch.rand(4, 2, 17, 2, generator=g).cuda()
+        o = tr.train_fn(batch)
+        outs.append({k: float(v) for k, v in o.items() if k in ("loss", "kl_loss", "gamma", "learning_rate", "imax",
+                                                                 "loss_reg")})
+    torch.cuda.synchronize()
+    ops.set_dropout_step(None)
+    return tr, outs
+
+
+@pytest.mark.parametrize("with_regressor", [False, True])
+def test_hip_graph_replay_is_bit_identical_to_eager(with_regressor):
+    """the whole step (forward, losses, backward on all HIP streams, Adam, gamma controller, regressor
+    side loop) replayed from ONE captured hipGraph.  Same device-resident schedule launched eagerly = the baseline:
+    losses, gamma, every parameter and Adam's state must be bit-identical after 7 steps (4 of them replays), with
+    dropout on (fresh mask per replay through the device step counter) and a fresh input batch per step."""
+    a, oa = _graph_run(True, 7, with_regressor)
+    assert len(a._graphs) == 1
+    b, ob = _graph_run(False, 7, with_regressor)
+    assert not b._graphs
+    assert oa == ob, (oa, ob)
+    assert len({o["loss"] for o in oa}) == len(oa)          # the replays did real, different steps
+    for (k, p), (_, q) in zip(a.vunet.state_dict().items(), b.vunet.state_dict().items()):
+        assert torch.equal(p, q), k
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["optimizer"]["param_groups"] == sb["optimizer"]["param_groups"]
+    for i, st in sa["optimizer"]["state"].items():
+        assert float(st["step"]) == float(sb["optimizer"]["state"][i]["step"]) == 7.0
+        assert torch.equal(st["exp_avg"], sb["optimizer"]["state"][i]["exp_avg"])
+    if with_regressor:
+        for (k, p), (_, q) in zip(a.regressor.state_dict().items(), b.regressor.state_dict().items()):
+            assert torch.equal(p, q), k
+        assert float(sa["regressor"]["optimizer"]["state"][0]["step"]) == 14.0
+
+
+def test_device_schedule_matches_the_host_schedule():
+    """The device-resident lr / step count / information_max path against the plain eager trainer (host scalars as
+    launch arguments), dropout off so that both draw nothing: same trajectory to fp32 rounding of Adam's bias
+    correction (device pow vs host pow)."""
+    a, oa = _graph_run(True, 6, dropout=0.0)
+    b, ob = _graph_run(None, 6, dropout=0.0)
+    for x, y in zip(oa, ob):
+        assert x["learning_rate"] == y["learning_rate"] and x["imax"] == y["imax"]
+        assert abs(x["loss"] - y["loss"]) <= 1e-5 * abs(y["loss"]), (x, y)
+        assert abs(x["gamma"] - y["gamma"]) <= 1e-5 * abs(y["gamma"]) + 1e-9
+    for (k, p), (_, q) in zip(a.vunet.state_dict().items(), b.vunet.state_dict().items()):
+        torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-6, msg=k)
