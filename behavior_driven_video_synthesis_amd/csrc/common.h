@@ -75,6 +75,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 // XCD-aware bijective block remap (blocks b and b+8 share an XCD under round-robin dispatch):
 // gives each XCD a contiguous chunk of the logical grid so neighbouring tiles hit one L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {

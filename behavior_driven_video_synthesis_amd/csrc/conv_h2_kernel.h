@@ -1,0 +1,342 @@
+// fp32-accurate 3x3 / pad 1 convolution (forward and data gradient) on the fp16 matrix cores: the "h2" scheme.
+//
+// Every fp32 operand, scaled by a power of two so that its tensor's largest magnitude lands below 2^14, is split into two
+// fp16 terms
+//       s x = xh + xl / 2^11      (xh = f16(s x), xl = f16((s x - xh) * 2^11); round-to-nearest-even: 11 + 11 significand
+//                                  bits and the sign of the remainder cover 23 of fp32's 24 bits)
+// and the product  w * x  is formed from the three partial products  wh xh + (wh xl + wl xh) / 2^11 , each exact in fp32
+// (11 x 11 significand bits) and accumulated in fp32 by v_mfma_f32_32x32x16_f16 -- the leading term in one accumulator,
+// the two cross terms in a second one, combined (and de-scaled) in the epilogue.  The dropped term (wl xl) and the
+// representation error are <= 2^-22 of the product: measured against an fp64 convolution the result is as close as the
+// three-term bf16 split (conv_x6_kernel.h) and the fp32 fmaf chain -- with HALF the matrix instructions of the former:
+// 3 MFMAs of K = 16 per 32 x 32 x 16 block, a roof of 2.5 PFLOP/s / 3 = 833 TFLOP/s fp32-equivalent.
+// The remainder keeps its own exponent (scaled by 2^11 into fp16's normal range) as long as |s x| >= 2^-14, i.e. 28
+// binades below the tensor's maximum; the scale is exact (power of two), so nothing else depends on the data.
+//   scale of x   from the tensor's |x| maximum: vunet_absmax_partials writes 1024 partial maxima (512 per source), every
+//                workgroup reduces them at entry (4 KB from L2).  The prologue (ELU / dropout / ReLU mask) never grows
+//                |x| beyond  max|x| * keep_scale.
+//   scale of w   per layer, from max |w_eff| (vunet_weightnorm_fwd*): unit 0 of the image holds its exponent.
+//
+// Work decomposition, LDS images, barriers and the fused epilogue are those of conv_h2_kernel.h with two planes
+// instead of three: xL [2 planes][2 k-halves][(TH+2) x 34 pixels], weight slab [3 kw][2 planes][2 k-halves][32].
+#pragma once
+#include <type_traits>
+
+#include "conv_common.h"
+
+#include "split_h2.h"
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of LDS starting at the
+// wave-uniform byte address `lds_addr`.  Issued as inline assembly so that the compiler does not track it: the builtin
+// form makes hipcc wait vmcnt(0) before the NEXT ds_read (it cannot tell the read from the DMA's destination), i.e.
+// before the MFMA block the transfer is meant to hide behind.  The kernel retires the DMA itself (h2_dma_wait) before the
+// barrier that publishes the slab.  M0 is saved and restored (compiler-reserved).
+__device__ __forceinline__ void h2_dma16(const void* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void h2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+union H2Unit {
+  uint4 u;
+  h2_f16x8 b;
+};
+
+// MODE 0 forward, 1 data gradient (taps mirrored).  PRO 0 none, 1 ELU, 2 ELU + dropout, 4 ReLU mask (MODE 1).
+// PHW >= 0 (MODE 1 only): data gradient of the STRIDE-2 convolution (Downsample, lib/modules.py:152-158) for the output
+// parity (ph, pw) = (PHW >> 1, PHW & 1): dx[2a+ph][2b+pw] = sum over the taps kh = ph+1 (mod 2), kw = pw+1 (mod 2) of
+// w[kh][kw] * dy[a + (ph+1-kh)/2][b + (pw+1-kw)/2] -- a stride-1 problem on the dy map with 1, 2, 2 or 4 of the 9
+// taps, stored to every other pixel of dx.  Four launches cover the four parities; no MFMA is spent on the structural
+// zeros of a transposed strided convolution.
+template <int MT, int NT, int MODE, int PRO, int PHW = -1>
+__global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, const uint4* __restrict__ wx, int mtiles_pad,
+                                                                  const float* __restrict__ amax) {
+  GatherArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  inact_resolve(a.auxa);
+  static_assert(PHW < 0 || MODE == 1, "parity phases exist for the data gradient only");
+  constexpr int PH = PHW >= 0 ? (PHW >> 1) : 0, PW = PHW >= 0 ? (PHW & 1) : 0;
+  constexpr int NKH = PHW < 0 ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk
+  constexpr int TW = 32, TH = 4 * NT, IH = TH + 2, IW = TW + 2, PIX = IH * IW, MB = 32 * MT;
+  constexpr int XU = 2 * PIX;             // staging units of the input tile: (k-half, pixel)
+  constexpr int NX = (XU + 255) / 256;
+  constexpr int WU = H2_SLAB * MT;        // units of one weight slab
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  uint4* const xL = smem4;                // [2 buffers][2 planes][2 k-halves][PIX]
+  uint4* const wL = smem4 + 8 * PIX;      // [2 buffers][WU]
+
+  const vunet_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int H = d.Hs, W = d.Ws, HW = a.HsWs;
+
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblocks = (d.M + MB - 1) / MB;
+  const int mb = bid % mblocks;
+  int t = bid / mblocks;
+  const int tiles_w = W / TW, tiles_h = H / TH;
+  const int tx = t % tiles_w;
+  t /= tiles_w;
+  const int ty = t % tiles_h;
+  const int n = t / tiles_h;
+  const int row0 = ty * TH, col0 = tx * TW, m0 = mb * MB;
+
+  // ---- scales: x by 2^ex from the tensor maximum (1024 partial maxima, reduced here), w by the exponent in the image header
+  float sx, descale;
+  {
+    const float4 pm = reinterpret_cast<const float4*>(amax)[tid];
+    float m_ = fmaxf(fmaxf(pm.x, pm.y), fmaxf(pm.z, pm.w));
+    m_ = wave_max(m_);
+    float* const redm = reinterpret_cast<float*>(smem4);
+    if (lane == 0) redm[wave] = m_;
+    __syncthreads();
+    m_ = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    __syncthreads();
+    if (a.in1.thresh) m_ *= a.in1.keep_scale;        // dropout rescales the kept values
+    const int ex = h2_scale_exp(m_);
+    const int ew = reinterpret_cast<const int*>(wx)[0];
+    sx = h2_pow2(ex);
+    descale = h2_pow2(-(ex + ew));
+  }
+
+  // ---- chunk-invariant staging geometry: unit u = (k-half c8, halo row r, halo column col), lanes walk columns
+  unsigned rel[NX];   // element offsets; loads address as scalar base + unsigned 32-bit BYTE offset (no 64-bit pairs)
+  int lds_x[NX];
+  uint32_t vbits = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    int u = tid + 256 * i;
+    if (u >= XU) u -= XU;   // the threads past the end of the tile redo its first units (same bytes): no divergent staging
+    const int c8 = u / PIX;
+    const int rem = u - c8 * PIX;
+    const int r = rem / IW, col = rem - r * IW;
+    const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    rel[i] = ok ? (unsigned)(8 * c8 * HW + ih * W + iw) : 0u;   // invalid: a safe in-bounds address, masked afterwards
+    lds_x[i] = c8 * PIX + rem;
+    vbits |= (ok ? 1u : 0u) << i;
+  }
+
+  f32x16 acc[MT][NT], acx[MT][NT];   // leading term / the two cross terms (scaled by 2^11)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][q][r] = acx[mt][q][r] = 0.f;
+
+  const int nch1 = d.C1 / 16, nch = nch1 + d.C2 / 16;
+  float xv[NX][8];
+  float mk[1][8];
+  const int mt0 = (d.m_off + m0) >> 5;   // first m-tile of this workgroup in the wx image
+
+  // The input tile of chunk c+1 is staged in NX rounds of 256 units spread over the phases of chunk c (round i in phase
+  // i * NKH / NX): its loads are issued before the phase's MFMA block and converted / written to the OTHER xL buffer
+  // after it, so only one round's 8 values are live across the MFMAs.
+  auto issue_x = [&](int ch, int i) {
+    const bool second = ch >= nch1;
+    const int cs = second ? (ch - nch1) * 16 : ch * 16;
+    const int C = second ? d.C2 : d.C1;
+    const float* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C + cs) * HW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      xv[i][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xs) +
+                                                 4u * (rel[i] + (((vbits >> i) & 1u) ? (unsigned)(k * HW) : 0u)));
+  };
+  // PRO 4: the ReLU mask travels separately and late (after the MFMA block, when the fragment registers are free)
+  auto issue_mask = [&](int ch, int i) {
+    if constexpr (PRO == 4) {
+      const float* __restrict__ ms = a.mask + (size_t)(n * d.C1 + ch * 16) * HW;   // mode 1, single source
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        mk[0][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ms) +
+                                                   4u * (rel[i] + (((vbits >> i) & 1u) ? (unsigned)(k * HW) : 0u)));
+    }
+  };
+  auto write_x = [&](int ch, int i) {
+    const bool second = ch >= nch1;
+    const int cs = second ? (ch - nch1) * 16 : ch * 16;
+    const int C = second ? d.C2 : d.C1;
+    InAct ia = a.in1;                       // the two sources differ in the dropout seed only
+    ia.seed = second ? a.in2.seed : a.in1.seed;
+    const int gbase = (n * C + cs) * HW;
+    const bool ok = (vbits >> i) & 1u;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t_ = xv[i][k];
+      if constexpr (PRO == 4) t_ = mk[0][k] > 0.f ? t_ : 0.f;
+      else if constexpr (PRO != 0) t_ = prologue<PRO>(ia, t_, (uint32_t)gbase + rel[i] + (uint32_t)(k * HW));
+      v[k] = ok ? t_ * sx : 0.f;
+    }
+    uint4 ph, pl;
+    h2_split2(v[0], v[1], ph.x, pl.x);
+    h2_split2(v[2], v[3], ph.y, pl.y);
+    h2_split2(v[4], v[5], ph.z, pl.z);
+    h2_split2(v[6], v[7], ph.w, pl.w);
+    uint4* const xb = xL + (ch & 1) * 4 * PIX;
+    xb[lds_x[i]] = ph;
+    xb[2 * PIX + lds_x[i]] = pl;
+  };
+  // Weight slab staging by LDS-DMA (global_load_lds_dwordx4: one wave-instruction copies 64 consecutive units = 1 KiB
+  // straight into LDS, no registers, no ds_write): the slab is a linear copy, WU / 64 = 6 * MT wave-instructions over
+  // the 4 waves; with MT = 1 waves 2 and 3 wrap around and rewrite units 0..127 with the same bytes.  The DMA of slab
+  // p+1 is issued before the MFMA block of phase p and retired (h2_dma_wait) just before the barrier that ends the phase.
+  constexpr int NWI = (WU / 64 + 3) / 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t wL_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)wL;
+  auto issue_w = [&](int phase, int buf) {   // phase = chunk * 3 + kh
+    const char* wp = reinterpret_cast<const char*>(wx) + 16 + ((size_t)phase * mtiles_pad + mt0) * (H2_SLAB * 16);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      int wi = wave_u + 4 * i;
+      if (wi >= WU / 64) wi -= WU / 64;
+      h2_dma16(wp + (size_t)(wi * 64 + lane) * 16, wL_addr + (uint32_t)(buf * WU + wi * 64) * 16u);
+    }
+  };
+
+  // step -> weight slab (chunk * 3 + kh): all three kernel rows, or only those of this output parity
+  auto slab_of = [&](int step) {
+    if constexpr (PHW < 0) return step;
+    else if constexpr (PH == 0) return step * 3 + 1;                     // kh = 1
+    else return (step >> 1) * 3 + ((step & 1) ? 2 : 0);                  // kh = 0, 2
+  };
+  issue_w(slab_of(0), 0);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    issue_x(0, i);
+    issue_mask(0, i);
+    write_x(0, i);
+  }
+  h2_dma_wait();
+  __syncthreads();
+
+  const uint4* const xB0 = xL + h * PIX + (wave * NT) * IW + j;  // + buffer*4*PIX + plane*2*PIX + (q + dr)*IW + dc
+  const uint4* const wA = wL + h * 32 + j;                       // + buf*WU + ((mt*3 + kw)*2 + plane)*64
+  // One chunk = three phases (kernel rows).  LAST is a compile-time flag so that every prefetch is unconditional code.
+  auto chunk = [&](int ch, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
+#pragma unroll
+    for (int ki = 0; ki < NKH; ++ki) {
+      const int kh = PHW < 0 ? ki : (PH ? 2 * ki : 1);
+      const int phase = ch * NKH + ki;
+      const int buf = phase & 1;
+      const bool more_w = !(LAST && ki == NKH - 1);
+      const uint4* const xB = xB0 + (ch & 1) * 4 * PIX;
+      if constexpr (!LAST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          if (i * NKH / NX == ki) issue_x(ch + 1, i);
+      }
+      if (more_w) issue_w(slab_of(phase + 1), buf ^ 1);
+      // row / column of the staged tile (origin row0-1, col0-1) that tap (kh, kw) reads for output row q, column j
+      const int dr = PHW >= 0 ? (PH + 1 - kh) / 2 + 1 : (MODE == 0 ? kh : 2 - kh);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        if (PHW >= 0 && ((kw + PW) & 1) == 0) continue;   // this parity's taps only: kw = pw + 1 (mod 2)
+        // two waves share a SIMD: the partner's MFMAs cover this wave's fragment reads, so nothing is gained by
+        // letting the scheduler hoist the next tap's 4*(MT+NT) fragment registers above this tap's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const int dc = PHW >= 0 ? (PW + 1 - kw) / 2 + 1 : (MODE == 0 ? kw : 2 - kw);
+        H2Unit av[2][MT], bv[2][NT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) av[p][mt].u = wA[buf * WU + ((mt * 3 + kw) * 2 + p) * 64];
+#pragma unroll
+          for (int q = 0; q < NT; ++q) bv[p][q].u = xB[p * 2 * PIX + (q + dr) * IW + dc];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            f32x16 cx = acx[mt][q];
+            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, cx, 0, 0, 0);
+            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, cx, 0, 0, 0);
+            acx[mt][q] = cx;
+            acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          if (i * NKH / NX == ki) {
+            issue_mask(ch + 1, i);
+            write_x(ch + 1, i);
+          }
+      }
+      if (more_w) {
+        h2_dma_wait();
+        __syncthreads();
+      }
+    }
+  };
+  for (int ch = 0; ch + 1 < nch; ++ch) chunk(ch, std::false_type{});
+  chunk(nch - 1, std::true_type{});
+
+  // ---- epilogue (shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The tiles are named
+  // at compile time (a runtime q would put the accumulators in scratch: the unroller gives up on this body's size).
+  auto epilogue = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    PixGeo g;
+    g.n = n;
+    g.oh = PHW >= 0 ? 2 * (row0 + wave * NT + q) + PH : row0 + wave * NT + q;   // parity phase: every other pixel of dx
+    g.ow = PHW >= 0 ? 2 * (col0 + j) + PW : col0 + j;
+    g.valid = true;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = (acc[0][q][r] + acx[0][q][r] * (1.f / 2048.f)) * descale;
+    store_tile16(a, g, m0, h, c);
+    if constexpr (MT > 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = (acc[1][q][r] + acx[1][q][r] * (1.f / 2048.f)) * descale;
+      store_tile16(a, g, m0 + 32, h, c);
+    }
+  };
+  epilogue(std::integral_constant<int, 0>{});
+  if constexpr (NT > 1) epilogue(std::integral_constant<int, 1>{});
+  if constexpr (NT > 2) {
+    epilogue(std::integral_constant<int, 2>{});
+    epilogue(std::integral_constant<int, 3>{});
+  }
+}
+
+template <int MT, int NT, int MODE, int PRO, int PHW = -1>
+static int launch_h2_one(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, hipStream_t st) {
+  constexpr int PIX = (4 * NT + 2) * 34;
+  constexpr size_t lds = (size_t)(8 * PIX + 2 * H2_SLAB * MT) * 16;
+  const vunet_conv_desc& d = ga.d;
+  const int blocks = d.N * (d.Hs / (4 * NT)) * (d.Ws / 32) * ((d.M + 32 * MT - 1) / (32 * MT));
+  auto kern = conv_h2_kernel<MT, NT, MODE, PRO, PHW>;
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  VUNET_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, st, ga, (const uint4*)wx, mtiles_pad, amax);
+  return vunet_check_launch();
+}
+
+template <int MT, int NT>
+static int launch_h2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, hipStream_t st) {
+  if (ga.d.mode == 1 && ga.d.stride == 2) {   // one launch per output parity
+    if (pro != 0) return VUNET_ERR_UNSUPPORTED;
+    int rc = launch_h2_one<MT, NT, 1, 0, 0>(ga, wx, mtiles_pad, amax, st);
+    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 1>(ga, wx, mtiles_pad, amax, st);
+    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 2>(ga, wx, mtiles_pad, amax, st);
+    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 3>(ga, wx, mtiles_pad, amax, st);
+    return rc;
+  }
+  if (ga.d.mode == 1) {
+    if (pro == 4) return launch_h2_one<MT, NT, 1, 4>(ga, wx, mtiles_pad, amax, st);
+    if (pro == 0) return launch_h2_one<MT, NT, 1, 0>(ga, wx, mtiles_pad, amax, st);
+    return VUNET_ERR_UNSUPPORTED;
+  }
+  switch (pro) {
+    case 0: return launch_h2_one<MT, NT, 0, 0>(ga, wx, mtiles_pad, amax, st);
+    case 1: return launch_h2_one<MT, NT, 0, 1>(ga, wx, mtiles_pad, amax, st);
+    case 2: return launch_h2_one<MT, NT, 0, 2>(ga, wx, mtiles_pad, amax, st);
+    default: return VUNET_ERR_UNSUPPORTED;
+  }
+}

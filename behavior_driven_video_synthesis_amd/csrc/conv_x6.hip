@@ -5,6 +5,10 @@
 
 int vunet_conv_x6_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pad, int pro, int NT, hipStream_t st);
 int vunet_conv_x6_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, int pro, int NT, hipStream_t st);
+int vunet_conv_h2_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,
+                             hipStream_t st);
+int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,
+                             hipStream_t st);
 extern "C" int vunet_x6_mtiles(int32_t M);
 int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res);
 
@@ -44,13 +48,15 @@ static long x6_blocks(const vunet_conv_desc* d, int MT, int NT) {
 // Tile: M <= 32 -> one m-tile and up to 16 rows (the weight slab is re-staged per workgroup: tall tiles amortise it);
 // wider layers -> two m-tiles and 8 rows (LDS: two workgroups per CU).  The tallest tile that still gives every CU its
 // two resident workgroups wins; `min_blocks` is what the caller requires of the smallest tile.
-static int x6_pick(const vunet_conv_desc* d, int* MT, long min_blocks) {
+static int x6_pick(const vunet_conv_desc* d, int* MT, long min_blocks, bool h2 = false) {
   *MT = d->M <= 32 ? 1 : 2;
+  const int top = (*MT == 1 && !h2) ? 4 : 2;   // the fp16 scheme keeps two accumulator sets: no 16-row tile
   if (const char* f = getenv("VUNET_X6_FORCE_NT")) {  // tests / tuning
-    const int NT = atoi(f);
-    if ((NT == 1 || NT == 2 || (NT == 4 && *MT == 1)) && x6_blocks(d, *MT, NT) > 0) return NT;
+    int NT = atoi(f);
+    if (NT > top) NT = top;
+    if ((NT == 1 || NT == 2 || NT == 4) && x6_blocks(d, *MT, NT) > 0) return NT;
   }
-  for (int NT = (*MT == 1 ? 4 : 2); NT >= 2; NT >>= 1)
+  for (int NT = top; NT >= 2; NT >>= 1)
     if (x6_blocks(d, *MT, NT) >= 512) return NT;
   return x6_blocks(d, *MT, 1) >= min_blocks ? 1 : 0;
 }
@@ -71,16 +77,20 @@ static void fill_args(GatherArgs& ga, const vunet_conv_desc* d, const float* x1,
 }
 
 static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
-                     const float* res, const float* aux, const float* mask, float* y, long min_blocks, void* stream) {
+                     const float* res, const float* aux, const float* mask, float* y, const float* amax, long min_blocks,
+                     void* stream) {
   const int pro = x6_prologue_code(d, mask != nullptr);
   if (!x6_geometry_ok(d, pro)) return VUNET_ERR_UNSUPPORTED;
   int MT;
-  const int NT = x6_pick(d, &MT, min_blocks);
+  const int NT = x6_pick(d, &MT, min_blocks, amax != nullptr);
   if (NT == 0) return VUNET_ERR_UNSUPPORTED;
   GatherArgs ga;
   fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
   // K dimension of the image = the gathered tensor's channels; M dimension = all columns of the weight matrix
   const int mtp = vunet_x6_mtiles(d->Mpad);
+  if (amax)   // two-term fp16 image
+    return MT == 1 ? vunet_conv_h2_launch_mt1(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream)
+                   : vunet_conv_h2_launch_mt2(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream);
   return MT == 1 ? vunet_conv_x6_launch_mt1(ga, wx, mtp, pro, NT, (hipStream_t)stream)
                  : vunet_conv_x6_launch_mt2(ga, wx, mtp, pro, NT, (hipStream_t)stream);
 }
@@ -99,31 +109,36 @@ extern "C" int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_m
   return d && x6_geometry_ok(d, x6_prologue_code(d, has_mask != 0)) ? 1 : 0;
 }
 
+extern "C" int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t has_mask) {
+  return d && x6_wanted(d, true, has_aux != 0, has_res != 0, has_mask != 0) ? 1 : 0;
+}
+
 extern "C" int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx,
                                const float* shift, const float* res, const float* aux, const float* mask, float* y,
-                               void* stream) {
+                               const float* amax, void* stream) {
   if (!d || !x1 || !wx || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
   if (mask && (d->mode != 1 || d->C2 != 0)) return VUNET_ERR_ARG;
   if (d->d2s && (d->M % 4 != 0 || d->mode != 0)) return VUNET_ERR_ARG;
-  return x6_launch(d, x1, x2, wx, shift, res, aux, mask, y, 1, stream);
+  return x6_launch(d, x1, x2, wx, shift, res, aux, mask, y, amax, 1, stream);
 }
 
 extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
-                            const float* shift, const float* res, const float* aux, float* y, void* stream) {
+                            const float* shift, const float* res, const float* aux, float* y, const float* amax,
+                            void* stream) {
   if (!d) return VUNET_ERR_ARG;
   if (x6_wanted(d, wx != nullptr, aux != nullptr, res != nullptr, false)) {
     if (!x1 || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
-    return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, 128, stream);
+    return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, amax, 128, stream);
   }
   return vunet_conv2d_gather(d, x1, x2, wt, shift, res, aux, y, stream);
 }
 
 extern "C" int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
-                                          const float* res, float* dx, void* stream) {
+                                          const float* res, float* dx, const float* amax, void* stream) {
   if (!d || !dy || !y || !wx || !dx || d->mode != 1 || d->C2 != 0 || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
   if (d->aux_act != ACT_NONE || d->aux_drop_p > 0.f || !x6_wanted(d, true, false, res != nullptr, true))
     return VUNET_ERR_UNSUPPORTED;
-  return x6_launch(d, dy, nullptr, wx, nullptr, res, nullptr, y, dx, 128, stream);
+  return x6_launch(d, dy, nullptr, wx, nullptr, res, nullptr, y, dx, amax, 128, stream);
 }
 
 // Name (rocprofv3 spelling) of the kernel vunet_conv2d / vunet_conv2d_dgrad_relu_x6 launches for this problem.
@@ -132,9 +147,10 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
   if (x6_wanted(d, has_wx != 0, has_aux != 0, false, has_mask != 0)) {
     int MT;
-    const int NT = x6_pick(d, &MT, 128);
-    if (d->stride == 2) snprintf(name, len, "conv_x6_kernel<%d, %d, 1, 0, parity x4>", MT, NT);
-    else snprintf(name, len, "conv_x6_kernel<%d, %d, %d, %d, -1>", MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
+    const int NT = x6_pick(d, &MT, 128, has_wx == 2);
+    const char* fam = has_wx == 2 ? "conv_h2_kernel" : "conv_x6_kernel";
+    if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4>", fam, MT, NT);
+    else snprintf(name, len, "%s<%d, %d, %d, %d, -1>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     return VUNET_OK;
   }
   return vunet_conv2d_gather_variant(d, has_aux, name, len);

@@ -440,6 +440,38 @@ extern "C" int vunet_adam_step_dev(float* param, const float* grad, float* exp_a
   return vunet_check_launch();
 }
 
+// ------------------------------------------------------------------ |x| maxima for the split-fp16 convolution scale
+// 1024 workgroups: 0..511 walk x1, 512..1023 walk x2; each writes ONE partial maximum (no atomics, nothing to clear).
+// NaNs are ignored by fmaxf (they reach the convolution's output through the data itself).
+__global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ x1, int64_t n1,
+                                                              const float* __restrict__ x2, int64_t n2,
+                                                              float* __restrict__ out) {
+  __shared__ float red[4];
+  const bool second = blockIdx.x >= 512;
+  const float* __restrict__ x = second ? x2 : x1;
+  const int64_t n = second ? n2 : n1;
+  const int b = second ? blockIdx.x - 512 : blockIdx.x;
+  float m = 0.f;
+  if (x) {
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n4; i += 512 * 256) {
+      const float4 v = x4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int64_t i = 4 * n4 + (int64_t)b * 256 + threadIdx.x; i < n; i += 512 * 256) m = fmaxf(m, fabsf(x[i]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+extern "C" int vunet_absmax_partials(const float* x1, int64_t n1, const float* x2, int64_t n2, float* out, void* st) {
+  if (!x1 || !out || n1 < 0 || n2 < 0) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(absmax_partials_kernel, dim3(1024), dim3(256), 0, (hipStream_t)st, x1, n1, x2, x2 ? n2 : 0, out);
+  return vunet_check_launch();
+}
+
 // ------------------------------------------------------------------ misc
 __global__ void dropout_mask_kernel(float* mask, int64_t n, uint32_t thresh, uint32_t seed, const uint32_t* step) {
   if (step) seed += (*step) * VUNET_DROP_STEP_MUL;
@@ -536,4 +568,4 @@ extern "C" int vunet_upsample_bilinear2x_bwd(const float* dy, float* dx, int64_t
   return vunet_check_launch();
 }
 
-extern "C" int vunet_abi_version(void) { return 2; }
+extern "C" int vunet_abi_version(void) { return 3; }

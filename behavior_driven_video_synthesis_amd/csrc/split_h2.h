@@ -1,0 +1,37 @@
+// The "h2" operand split shared by the fp16-matrix-core kernels (conv_h2_kernel.h, conv_wgrad_h2.hip) and the weight
+// pack (weightnorm.hip):  s x = h + l / 2^11  with h = f16(s x), l = f16((s x - h) * 2^11), both round-to-nearest-even.
+#pragma once
+#include "common.h"
+
+typedef _Float16 h2_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int H2_SLAB = 384;          // 16-byte units of one (chunk, kh, m-tile) weight slab: [3 kw][2 planes][2 halves][32]
+constexpr int H2_AMAX_PARTS = 1024;   // partial |x| maxima handed to a kernel: 512 per source (vunet_absmax_partials)
+constexpr int H2_TOP = 14;            // a tensor's largest magnitude is scaled into [2^13, 2^14): 4x headroom below fp16's 65504
+
+// exponent e such that  m * 2^e  lies in [2^(H2_TOP-1), 2^H2_TOP)  (m > 0; 0 for an all-zero tensor), clamped so that
+// 2^(ex + ew) and its inverse stay normal fp32 numbers
+__host__ __device__ __forceinline__ int h2_scale_exp(float m) {
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 0;      // zeros, NaN, Inf: leave the data alone (they propagate as in fp32)
+  int e;
+  frexpf(m, &e);                                   // m = f * 2^e, f in [0.5, 1)
+  e = H2_TOP - e;
+  return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+
+__host__ __device__ __forceinline__ float h2_pow2(int e) {   // exact 2^e, |e| <= 126
+  return __uint_as_float((uint32_t)(127 + e) << 23);
+}
+
+// (a, b), already scaled -> packed fp16 pairs of the two split terms (low half = a)
+__device__ __forceinline__ void h2_split2(float a, float b, uint32_t& h, uint32_t& l) {
+  h2_f16x2 ph;
+  ph[0] = (_Float16)a;
+  ph[1] = (_Float16)b;
+  h2_f16x2 pl;
+  pl[0] = (_Float16)((a - (float)ph[0]) * 2048.f);
+  pl[1] = (_Float16)((b - (float)ph[1]) * 2048.f);
+  h = __builtin_bit_cast(uint32_t, ph);
+  l = __builtin_bit_cast(uint32_t, pl);
+}

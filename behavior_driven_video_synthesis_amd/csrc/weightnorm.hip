@@ -9,6 +9,7 @@
 // turns dL/dw_eff, dL/dshift into the gradients of v, g, bias, gamma, beta.
 // Reductions are wavefront shuffles (64 lanes) + one LDS hop.
 #include "common.h"
+#include "split_h2.h"
 
 #define X6_SLAB_UNITS 576   // 16-byte units per (chunk, kh, m-tile): [3 kw][3 planes][2 k-halves][32]
 
@@ -16,7 +17,8 @@ struct WnArgs {
   vunet_wn_desc d;
   const float *v, *g, *bias, *gamma, *beta;
   float *wt_f, *wt_d, *scale, *shift, *invnorm;
-  uint4 *wx_f, *wx_d;   // split-bf16 images for conv_x6_kernel (NULL: not wanted / geometry not covered)
+  uint4 *wx_f, *wx_d;   // split images for conv_x6_kernel / conv_h2_kernel (NULL: not wanted / geometry not covered)
+  float* wmax;          // [Cout] max |w_eff| of every row (d.split == 2: the layer's scale comes from it)
   int T, Ctot, C1p, C2p, Kf, Mpad_f, Coutp2, Kd, Mpad_d;
 };
 
@@ -93,6 +95,78 @@ __device__ __forceinline__ void wn_pack_x6_body(const WnArgs& a, size_t start, s
   }
 }
 
+// ---- split-fp16 ("h2") weight images (conv_h2_kernel.h): unit 0 = header (int32 exponent ew of the layer's power-of-two
+//      scale), then units of 8 fp16 laid out
+//        [chunk of 16 K-channels][kh][m-tile of 32][kw][plane h / l][k-half][32 channels of the m-tile]
+//      with  2^ew * w = h + l / 2^11.  `ew` comes from the largest |w_eff| of the layer (wmax, written by the scale
+//      kernel), reduced here by every workgroup.
+__device__ __forceinline__ int wn_layer_exp(const WnArgs& a) {
+  __shared__ float s_wmax[4];
+  float m = 0.f;
+  for (int k = threadIdx.x; k < a.d.Cout; k += blockDim.x) m = fmaxf(m, a.wmax[k]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, s_wmax[w]);
+  return h2_scale_exp(m);
+}
+
+__device__ __forceinline__ void wn_pack_h2_body(const WnArgs& a, size_t start, size_t stride) {
+  const int T = a.T;
+  if (T != 9 || (!a.wx_f && !a.wx_d)) return;
+  const int ew = wn_layer_exp(a);
+  const float sw = h2_pow2(ew);
+  for (int img = 0; img < 2; ++img) {
+    uint4* out = img == 0 ? a.wx_f : a.wx_d;
+    if (!out) continue;
+    if (start == 0) out[0] = make_uint4((uint32_t)ew, 0u, 0u, 0u);
+    ++out;
+    const int nch1 = img == 0 ? a.d.C1 / 16 : a.d.Cout / 16;
+    const int nch = img == 0 ? nch1 + a.d.C2 / 16 : nch1;
+    const int Mdim = img == 0 ? a.d.Cout : a.Ctot;
+    const int mtp = x6_mtiles(Mdim);
+    const size_t total = (size_t)nch * 3 * mtp * 3 * 64;
+    for (size_t i = start; i < total; i += stride) {
+      const int j = (int)(i & 31), half = (int)((i >> 5) & 1);
+      size_t q = i >> 6;
+      const int kw = (int)(q % 3); q /= 3;
+      const int mt = (int)(q % mtp); q /= mtp;
+      const int kh = (int)(q % 3);
+      const int ch = (int)(q / 3);
+      const int tap = kh * 3 + kw, m = mt * 32 + j;
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float val = 0.f;
+        if (m < Mdim) {
+          if (img == 0) {
+            const int cg = ch < nch1 ? ch * 16 + half * 8 + e : a.d.C1 + (ch - nch1) * 16 + half * 8 + e;
+            val = a.scale[m] * a.v[((size_t)m * a.Ctot + cg) * T + tap];
+          } else {
+            const int co = ch * 16 + half * 8 + e;
+            val = a.scale[co] * a.v[((size_t)co * a.Ctot + m) * T + tap];
+          }
+        }
+        w[e] = val * sw;
+      }
+      uint4 ph, pl;
+      h2_split2(w[0], w[1], ph.x, pl.x);
+      h2_split2(w[2], w[3], ph.y, pl.y);
+      h2_split2(w[4], w[5], ph.z, pl.z);
+      h2_split2(w[6], w[7], ph.w, pl.w);
+      const size_t base = ((((size_t)(ch * 3 + kh) * mtp + mt) * 3 + kw) * 2) * 64 + half * 32 + j;
+      out[base] = ph;
+      out[base + 64] = pl;
+    }
+  }
+}
+
+__device__ __forceinline__ void wn_pack_split_body(const WnArgs& a, size_t start, size_t stride) {
+  if (a.d.split == 2) wn_pack_h2_body(a, start, stride);
+  else wn_pack_x6_body(a, start, stride);
+}
+
 extern "C" int vunet_x6_mtiles(int32_t M) { return x6_mtiles(M); }
 
 // does the split-bf16 kernel family cover this layer's forward / data-gradient weights?  (3x3, channel counts in 16s)
@@ -101,18 +175,21 @@ static bool x6_dgrad_ok(const vunet_wn_desc* d) { return d->KH == 3 && d->KW == 
 
 extern "C" int vunet_x6_image_bytes(const vunet_wn_desc* d, int32_t dgrad) {
   if (!d) return 0;
-  if (dgrad) return x6_dgrad_ok(d) ? (d->Cout / 16) * 3 * x6_mtiles(d->C1 + d->C2) * X6_SLAB_UNITS * 16 : 0;
-  return x6_fwd_ok(d) ? ((d->C1 + d->C2) / 16) * 3 * x6_mtiles(d->Cout) * X6_SLAB_UNITS * 16 : 0;
+  const int slab = d->split == 2 ? H2_SLAB : X6_SLAB_UNITS, hdr = d->split == 2 ? 16 : 0;
+  if (dgrad) return x6_dgrad_ok(d) ? (d->Cout / 16) * 3 * x6_mtiles(d->C1 + d->C2) * slab * 16 + hdr : 0;
+  return x6_fwd_ok(d) ? ((d->C1 + d->C2) / 16) * 3 * x6_mtiles(d->Cout) * slab * 16 + hdr : 0;
 }
 
 __global__ __launch_bounds__(64) void wn_scale_kernel(const WnArgs a) {
   const int co = blockIdx.x, lane = threadIdx.x;
   const int K = a.Ctot * a.T;
   const float* vr = a.v + (size_t)co * K;
-  float invn = 1.f, scale = 1.f;
-  if (a.d.kind != 1) {
+  float invn = 1.f, scale = 1.f, mx = 0.f;
+  if (a.d.kind != 1 || a.wmax) {
     float ss = 0.f;
-    for (int k = lane; k < K; k += 64) { const float t = vr[k]; ss += t * t; }
+    for (int k = lane; k < K; k += 64) { const float t = vr[k]; ss += t * t; mx = fmaxf(mx, fabsf(t)); }
+    if (a.wmax) mx = wave_max(mx);
+  if (a.d.kind != 1) {
     ss = wave_sum(ss);
     float nrm = sqrtf(ss);
     if (a.d.kind == 2) nrm = fmaxf(nrm, 1e-12f);
@@ -120,7 +197,9 @@ __global__ __launch_bounds__(64) void wn_scale_kernel(const WnArgs a) {
     const float gm = a.gamma ? a.gamma[co] : 1.f;
     scale = a.d.kind == 0 ? gm * a.g[co] * invn : gm * invn;
   }
+  }
   if (lane == 0) {
+    if (a.wmax) a.wmax[co] = fabsf(scale) * mx;
     const float gm = (a.d.kind != 1 && a.gamma) ? a.gamma[co] : 1.f;
     const float b = a.bias ? a.bias[co] : 0.f;
     const float be = (a.d.kind != 1 && a.beta) ? a.beta[co] : 0.f;
@@ -154,7 +233,7 @@ __global__ __launch_bounds__(256) void wn_pack_kernel(const WnArgs a) {
       a.wt_d[e] = w;
     }
   }
-  wn_pack_x6_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+  wn_pack_split_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 static void wn_geometry(const vunet_wn_desc* d, WnArgs& a) {
@@ -171,7 +250,7 @@ static void wn_geometry(const vunet_wn_desc* d, WnArgs& a) {
 
 extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g, const float* bias,
                                     const float* gamma, const float* beta, float* wt_f, float* wt_d, void* wx_f,
-                                    void* wx_d, float* scale, float* shift, float* invnorm, void* stream) {
+                                    void* wx_d, float* scale, float* shift, float* invnorm, float* wmax, void* stream) {
   if (!d || !v || !wt_f || !scale || !shift || !invnorm) return VUNET_ERR_ARG;
   if (d->kind == 0 && !g) return VUNET_ERR_ARG;
   if (d->Cout < 1 || d->C1 < 1 || d->C2 < 0) return VUNET_ERR_ARG;
@@ -180,7 +259,8 @@ extern "C" int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, cons
   a.v = v; a.g = g; a.bias = bias; a.gamma = gamma; a.beta = beta;
   a.wt_f = wt_f; a.wt_d = wt_d; a.scale = scale; a.shift = shift; a.invnorm = invnorm;
   if ((wx_f && !x6_fwd_ok(d)) || (wx_d && !x6_dgrad_ok(d))) return VUNET_ERR_UNSUPPORTED;
-  a.wx_f = (uint4*)wx_f; a.wx_d = (uint4*)wx_d;
+  if (d->split == 2 && (wx_f || wx_d) && !wmax) return VUNET_ERR_ARG;
+  a.wx_f = (uint4*)wx_f; a.wx_d = (uint4*)wx_d; a.wmax = wmax;
   wn_geometry(d, a);
   hipStream_t st = (hipStream_t)stream;
   VUNET_LAUNCH(wn_scale_kernel, dim3(d->Cout), dim3(64), 0, st, a);
@@ -196,6 +276,7 @@ struct WnItemDev {  // mirrors vunet_wn_item (include/vunet_hip.h)
   const float *v, *g, *bias, *gamma, *beta;
   float *wt_f, *wt_d, *scale, *shift, *invnorm;
   uint4 *wx_f, *wx_d;
+  float* wmax;
   vunet_wn_desc d;
 };
 
@@ -204,7 +285,7 @@ __device__ __forceinline__ WnArgs item_args(const WnItemDev& it) {
   a.d = it.d;
   a.v = it.v; a.g = it.g; a.bias = it.bias; a.gamma = it.gamma; a.beta = it.beta;
   a.wt_f = it.wt_f; a.wt_d = it.wt_d; a.scale = it.scale; a.shift = it.shift; a.invnorm = it.invnorm;
-  a.wx_f = it.wx_f; a.wx_d = it.wx_d;
+  a.wx_f = it.wx_f; a.wx_d = it.wx_d; a.wmax = it.wmax;
   a.T = it.d.KH * it.d.KW;
   a.Ctot = it.d.C1 + it.d.C2;
   a.C1p = (it.d.C1 + 1) & ~1;
@@ -220,10 +301,12 @@ __device__ __forceinline__ WnArgs item_args(const WnItemDev& it) {
 __device__ __forceinline__ void wn_scale_body(const WnArgs& a, int co, int lane) {
   const int K = a.Ctot * a.T;
   const float* vr = a.v + (size_t)co * K;
-  float invn = 1.f, scale = 1.f;
-  if (a.d.kind != 1) {
+  float invn = 1.f, scale = 1.f, mx = 0.f;
+  if (a.d.kind != 1 || a.wmax) {
     float ss = 0.f;
-    for (int k = lane; k < K; k += 64) { const float t = vr[k]; ss += t * t; }
+    for (int k = lane; k < K; k += 64) { const float t = vr[k]; ss += t * t; mx = fmaxf(mx, fabsf(t)); }
+    if (a.wmax) mx = wave_max(mx);
+  if (a.d.kind != 1) {
     ss = wave_sum(ss);
     float nrm = sqrtf(ss);
     if (a.d.kind == 2) nrm = fmaxf(nrm, 1e-12f);
@@ -231,7 +314,9 @@ __device__ __forceinline__ void wn_scale_body(const WnArgs& a, int co, int lane)
     const float gm = a.gamma ? a.gamma[co] : 1.f;
     scale = a.d.kind == 0 ? gm * a.g[co] * invn : gm * invn;
   }
+  }
   if (lane == 0) {
+    if (a.wmax) a.wmax[co] = fabsf(scale) * mx;
     const float gm = (a.d.kind != 1 && a.gamma) ? a.gamma[co] : 1.f;
     const float b = a.bias ? a.bias[co] : 0.f;
     const float be = (a.d.kind != 1 && a.beta) ? a.beta[co] : 0.f;
@@ -276,7 +361,7 @@ __global__ __launch_bounds__(64) void wn_scale_multi_kernel(const WnItemDev* __r
 __global__ __launch_bounds__(256) void wn_pack_multi_kernel(const WnItemDev* __restrict__ items) {
   const WnArgs a = item_args(items[blockIdx.y]);
   wn_pack_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
-  wn_pack_x6_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+  wn_pack_split_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 extern "C" int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_t n_items, int32_t max_cout,

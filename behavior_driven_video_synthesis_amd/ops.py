@@ -12,6 +12,7 @@ gamma controller.  There is no CPU fallback: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -44,7 +45,7 @@ class WgradDesc(ctypes.Structure):
 
 class WnDesc(ctypes.Structure):
     _fields_ = [("Cout", ctypes.c_int32), ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("KH", ctypes.c_int32),
-                ("KW", ctypes.c_int32), ("kind", ctypes.c_int32)]
+                ("KW", ctypes.c_int32), ("kind", ctypes.c_int32), ("split", ctypes.c_int32)]
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -144,21 +145,52 @@ def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
 
 
 # ------------------------------------------------------------------------------------------------
-# convolution arithmetic: "x6" = fp32-accurate split-bf16 kernels on the bf16 matrix cores wherever they apply
-# (csrc/conv_x6_kernel.h), "f32" = fp32-input MFMA kernels everywhere.  Process-wide; the environment variable
-# VUNET_CONV_PRECISION=f32 pins the library itself to f32 regardless of this switch.
+# convolution arithmetic, process-wide.  All three are fp32-accurate (tests/test_hip_x6.py, tools/x6_accuracy.py):
+#   "h2"  operands scaled by a power of two and split into two fp16 terms, three partial products on the fp16 matrix
+#         cores wherever the split kernels apply (csrc/conv_h2_kernel.h) -- the default;
+#   "x6"  operands split into three bf16 terms, six partial products on the bf16 matrix cores (csrc/conv_x6_kernel.h):
+#         no data-dependent scale, twice the matrix instructions;
+#   "f32" fp32-input MFMA kernels everywhere.
+# The environment variable VUNET_CONV_PRECISION=f32 pins the library itself to f32 regardless of this switch.
 # ------------------------------------------------------------------------------------------------
-_conv_precision = {"x6": True}
+_SCHEMES = {"f32": 0, "x6": 1, "h2": 2}
+_conv_precision = {"mode": os.environ.get("VUNET_CONV_SCHEME", "h2")}
 
 
 def set_conv_precision(mode: str):
-    if mode not in ("x6", "f32"):
-        raise ValueError(f"unknown conv precision {mode!r} (x6 | f32)")
-    _conv_precision["x6"] = mode == "x6"
+    if mode not in _SCHEMES:
+        raise ValueError(f"unknown conv precision {mode!r} (h2 | x6 | f32)")
+    _conv_precision["mode"] = mode
 
 
 def conv_precision() -> str:
-    return "x6" if _conv_precision["x6"] else "f32"
+    return _conv_precision["mode"]
+
+
+def _scheme() -> int:
+    return _SCHEMES[_conv_precision["mode"]]
+
+
+def absmax_partials(x1, x2=None):
+    """vunet_absmax_partials: the 1024 partial |x| maxima (512 per source) the split-fp16 kernels scale their input by."""
+    out = torch.empty(1024, device=x1.device, dtype=torch.float32)
+    _call("vunet_absmax_partials", _p(x1), x1.numel(), _p(x2), 0 if x2 is None else x2.numel(), _p(out), _stream())
+    return out
+
+
+_wants_split_cache = {}
+
+
+def _wants_split(desc, has_aux: bool, has_res: bool, has_mask: bool = False) -> bool:
+    """Would vunet_conv2d route this problem to a split kernel (so that the h2 scheme owes it the |x| maxima)?"""
+    key = (desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.m_off, desc.Mpad, desc.Ho, desc.Wo, desc.KH, desc.stride,
+           desc.pad, desc.mode, desc.in_act, desc.drop_p > 0, desc.out_act, desc.d2s, desc.aux_act, desc.aux_drop_p > 0,
+           has_aux, has_res, has_mask)
+    r = _wants_split_cache.get(key)
+    if r is None:
+        r = _wants_split_cache[key] = _lib.lib().vunet_conv2d_wants_split(ctypes.byref(desc), int(has_aux), int(has_res),
+                                                                          int(has_mask)) == 1
+    return r
 
 
 def x6_mtiles(m: int) -> int:
@@ -166,19 +198,21 @@ def x6_mtiles(m: int) -> int:
     return (((m + 31) // 32 + 1) + 1) & ~1
 
 
-def x6_image_units(cout: int, c1: int, c2: int, k: int, dgrad: bool) -> int:
-    """16-byte units of a layer's split-bf16 weight image (vunet_x6_image_bytes / 16); 0: geometry not covered."""
+def x6_image_units(cout: int, c1: int, c2: int, k: int, dgrad: bool, split: int = 1) -> int:
+    """16-byte units of a layer's split weight image (vunet_x6_image_bytes / 16); 0: geometry not covered.
+    ``split`` 1: three bf16 terms (576 units per slab), 2: two fp16 terms (384 per slab + the header unit)."""
     if k != 3:
         return 0
+    slab, hdr = (384, 1) if split == 2 else (576, 0)
     if dgrad:
-        return (cout // 16) * 3 * x6_mtiles(c1 + c2) * 576 if cout % 16 == 0 else 0
-    return ((c1 + c2) // 16) * 3 * x6_mtiles(cout) * 576 if (c1 % 16 == 0 and c2 % 16 == 0) else 0
+        return (cout // 16) * 3 * x6_mtiles(c1 + c2) * slab + hdr if cout % 16 == 0 else 0
+    return ((c1 + c2) // 16) * 3 * x6_mtiles(cout) * slab + hdr if (c1 % 16 == 0 and c2 % 16 == 0) else 0
 
 
 def _alloc_x6(cout, c1, c2, k, dgrad, dev):
-    if not _conv_precision["x6"]:
+    if _scheme() == 0:
         return None
-    n = x6_image_units(cout, c1, c2, k, dgrad)
+    n = x6_image_units(cout, c1, c2, k, dgrad, _scheme())
     return torch.empty(n * 4, device=dev, dtype=torch.int32) if n else None
 
 
@@ -192,10 +226,10 @@ def pack_weights(v, g, bias, gamma, beta, c1: int, c2: int, kind: int, need_dgra
     wt_d = torch.empty(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_dgrad else None
     wx_f = _alloc_x6(cout, c1, c2, kh, False, dev) if kh == kw else None
     wx_d = _alloc_x6(cout, c1, c2, kh, True, dev) if (need_dgrad and kh == kw) else None
-    small = torch.empty(3, cout, device=dev, dtype=torch.float32)
-    d = WnDesc(cout, c1, c2, kh, kw, kind)
+    small = torch.empty(4, cout, device=dev, dtype=torch.float32)   # scale, shift, invnorm, row maxima of |w_eff|
+    d = WnDesc(cout, c1, c2, kh, kw, kind, _scheme())
     _call("vunet_weightnorm_fwd", ctypes.byref(d), _p(v), _p(g), _p(bias), _p(gamma), _p(beta), _p(wt_f), _p(wt_d),
-          _p(wx_f), _p(wx_d), _p(small[0]), _p(small[1]), _p(small[2]), _stream())
+          _p(wx_f), _p(wx_d), _p(small[0]), _p(small[1]), _p(small[2]), _p(small[3]), _stream())
     return wt_f, wt_d, small[0], small[1], small[2], wx_f, wx_d
 
 
@@ -244,8 +278,17 @@ class _Timed:
             _prof["recs"].append((self.name, self.flop, self.e0, self.e1))
 
 
-def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None):
+def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=None):
+    """``amax``: the |x| partial maxima if the caller already has them (h2 scheme), else computed here when needed."""
     t = desc.KH * desc.KW
+    scheme = _scheme() if wx is not None else 0
+    if scheme == 2:
+        if not _wants_split(desc, aux is not None, res is not None):
+            wx = amax = None
+        elif amax is None:
+            amax = absmax_partials(x1, x2)
+    else:
+        amax = None
     if desc.mode == 0:
         name, flop = "conv_gather_fwd", 2.0 * desc.N * desc.Ho * desc.Wo * desc.M * (desc.C1 + desc.C2) * t
     else:  # transposed gather: MACs of the forward conv restricted to this source
@@ -253,12 +296,12 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None):
     kname = ""
     if _prof["on"]:
         buf = ctypes.create_string_buffer(96)
-        _call("vunet_conv2d_variant", ctypes.byref(desc), 0 if aux is None else 1, 0 if wx is None else 1, 0, buf, 96)
+        _call("vunet_conv2d_variant", ctypes.byref(desc), 0 if aux is None else 1, 0 if wx is None else scheme, 0, buf, 96)
         kname = buf.value.decode()
     with _Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act, kname),
                 flop):
         _call("vunet_conv2d", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), _p(aux), _p(y),
-              _stream())
+              _p(amax), _stream())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -344,7 +387,7 @@ class ConvPlainWgrad(torch.autograd.Function):
         cout, ho, wo = dy.shape[1], dy.shape[2], dy.shape[3]
         wd = WgradDesc(N=n, C1=cin, C2=0, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=stride, pad=pad,
                        in_act=ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0, nsplit=1,
-                       flags=0 if _conv_precision["x6"] else 1)
+                       flags=0 if _scheme() else 1)
         ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
         wd.nsplit = ns
         ktot = k * k * cin
@@ -353,7 +396,7 @@ class ConvPlainWgrad(torch.autograd.Function):
         _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x), None, _p(dy), _p(slabs), _p(dshift), _stream())
         dw = torch.empty(cout, cin, k, k, device=x.device, dtype=torch.float32)
         work = torch.empty(cout * (ktot + 1), device=x.device, dtype=torch.float32)
-        wn = WnDesc(cout, cin, 0, k, k, 1)
+        wn = WnDesc(cout, cin, 0, k, k, 1, 0)
         _call("vunet_weightnorm_bwd", ctypes.byref(wn), _p(slabs), _p(dshift), ns, _p(dw), None, None, None, None,
               _p(dw), None, None, None, None, _p(work), 0, _stream())
         ctx.save_for_backward(x, dy)
@@ -505,7 +548,7 @@ def remove_grad_hook(fn):
 # ------------------------------------------------------------------------------------------------
 class WnItem(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("v", "g", "bias", "gamma", "beta", "wt_f", "wt_d", "scale", "shift",
-                                                "invnorm", "wx_f", "wx_d")] + [("d", WnDesc)]
+                                                "invnorm", "wx_f", "wx_d", "wmax")] + [("d", WnDesc)]
 
 
 _prepack_sets = {}      # id(model) -> dict(signature, table, max_cout, entries, keep)
@@ -518,7 +561,7 @@ def _ptr_or_none(t):
 
 def _build_prepack_set(model):
     mods = [m for m in model.modules() if hasattr(m, "_params") and getattr(m, "_last_split", None) is not None]
-    sig = (_conv_precision["x6"],) + tuple((id(m), m._last_split) for m in mods)
+    sig = (_scheme(),) + tuple((id(m), m._last_split) for m in mods)
     cur = _prepack_sets.get(id(model))
     if cur is not None and cur["signature"] == sig:
         return cur
@@ -535,13 +578,14 @@ def _build_prepack_set(model):
         wt_d = torch.empty(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_x else None
         wx_f = _alloc_x6(cout, c1, c2, kh, False, dev) if kh == kw else None
         wx_d = _alloc_x6(cout, c1, c2, kh, True, dev) if (need_x and kh == kw) else None
-        small = torch.empty(3, cout, device=dev, dtype=torch.float32)
+        small = torch.empty(4, cout, device=dev, dtype=torch.float32)
         it = items[i]
         it.v, it.g, it.bias, it.gamma, it.beta = (_ptr_or_none(x) for x in (v, g, b, gamma, beta))
         it.wt_f, it.wt_d = wt_f.data_ptr(), _ptr_or_none(wt_d)
         it.wx_f, it.wx_d = _ptr_or_none(wx_f), _ptr_or_none(wx_d)
         it.scale, it.shift, it.invnorm = small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
-        it.d = WnDesc(cout, c1, c2, kh, kw, m.kind)
+        it.wmax = small[3].data_ptr()
+        it.d = WnDesc(cout, c1, c2, kh, kw, m.kind, _scheme())
         entries[id(m)] = ((c1, c2, need_x), wt_f, wt_d, small[0], small[1], small[2], wx_f, wx_d)
         keep.append((wt_f, wt_d, small, wx_f, wx_d))
         max_cout = max(max_cout, cout)
@@ -595,7 +639,7 @@ class FusedConv(torch.autograd.Function):
         frozen = not any(t is not None and t.requires_grad for t in (v, g, bias, gamma, beta))
         # frozen feature extractor (VGG19): pack once, reuse for every pass.  The packed buffers hang off the weight
         # tensor itself (they die with it) and are stamped with every operand's storage address and version counter.
-        sub = (c1, c2, cfg.kind, bool(need_x), _conv_precision["x6"])
+        sub = (c1, c2, cfg.kind, bool(need_x), _scheme())
         stamp = tuple(None if t is None else (t.data_ptr(), t._version) for t in (v, g, bias, gamma, beta))
         hit = getattr(v, "_vunet_frozen_pack", {}).get(sub) if frozen else None
         pre = None
@@ -672,16 +716,18 @@ class FusedConv(torch.autograd.Function):
             kname = ""
             if _prof["on"]:
                 buf = ctypes.create_string_buffer(96)
-                _call("vunet_conv2d_variant", ctypes.byref(d), 0, 0 if wx_d is None else 1, 1, buf, 96)
+                _call("vunet_conv2d_variant", ctypes.byref(d), 0, 0 if wx_d is None else _scheme(), 1, buf, 96)
                 kname = buf.value.decode()
                 if kname.startswith("conv_tiled"):
                     kname = kname.replace(", 1, 0, ", ", 1, 4, ")
             with _Timed(("conv_gather_dgrad", n, cout, 0, ho, wo, c1, k, cfg.stride, 0, kname),
                         2.0 * n * ho * wo * cout * c1 * k * k):
                 rc = -3
-                if wx_d is not None:
+                if wx_d is not None and _wants_split(d, False, cfg.res_is_x1, True):
+                    amax = absmax_partials(dy) if _scheme() == 2 else None
                     rc = _lib.lib().vunet_conv2d_dgrad_relu_x6(ctypes.byref(d), _p(dy), _p(y), _p(wx_d),
-                                                               _p(dy if cfg.res_is_x1 else None), _p(dx), _stream())
+                                                               _p(dy if cfg.res_is_x1 else None), _p(dx), _p(amax),
+                                                               _stream())
                 if rc == -3:
                     rc = _lib.lib().vunet_conv2d_dgrad_relu(ctypes.byref(d), _p(dy), _p(y), _p(wt_d),
                                                             _p(dy if cfg.res_is_x1 else None), _p(dx), _stream())
@@ -704,7 +750,7 @@ class FusedConv(torch.autograd.Function):
         def weight_gradients():
             wd = WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=cfg.stride,
                            pad=cfg.pad, in_act=cfg.in_act, in_slope=cfg.in_slope, drop_p=cfg.drop_p,
-                           drop_seed=cfg.drop_seed, nsplit=1, flags=0 if _conv_precision["x6"] else 1)
+                           drop_seed=cfg.drop_seed, nsplit=1, flags=0 if _scheme() else 1)
             ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
             if ns < 1:
                 raise RuntimeError(f"vunet_conv2d_wgrad_nsplit failed with code {ns}")
@@ -736,7 +782,7 @@ class FusedConv(torch.autograd.Function):
                     direct.append(False)
             n_direct = sum(direct)
             n_needed = sum(o is not None for o in outs)
-            wn = WnDesc(cout, c1, c2, k, k, cfg.kind)
+            wn = WnDesc(cout, c1, c2, k, k, cfg.kind, 0)
             work = torch.empty(cout * (ktot + 1), device=dy.device, dtype=torch.float32)
 
             def run(sel_direct: bool):
@@ -774,6 +820,8 @@ class FusedConv(torch.autograd.Function):
                 dv, dg, dbias, dgamma, dbeta = weight_gradients()
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            dy_amax = []   # |dconv| maxima of the h2 scheme: computed by the first data gradient that wants them, shared
+
             def dgrad(x, cs, m_off, seed, add):
                 dx = torch.empty_like(x)
                 d = ConvDesc(N=n, C1=cout, C2=0, Hs=ho, Ws=wo, M=cs, m_off=m_off, Mpad=wt_d.shape[1], Ho=hs, Wo=ws,
@@ -781,7 +829,12 @@ class FusedConv(torch.autograd.Function):
                              drop_p=0.0, drop_seed=0, out_act=ACT_NONE, d2s=0, aux_act=cfg.in_act,
                              aux_slope=cfg.in_slope, aux_drop_p=cfg.drop_p, aux_drop_seed=seed)
                 has_aux = cfg.in_act != ACT_NONE or cfg.drop_p > 0
-                _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d)
+                amax = None
+                if wx_d is not None and _scheme() == 2 and _wants_split(d, has_aux, add is not None):
+                    if not dy_amax:
+                        dy_amax.append(absmax_partials(dconv))
+                    amax = dy_amax[0]
+                _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d, amax)
                 return dx
             if ctx.needs_input_grad[0]:
                 dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else None)

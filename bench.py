@@ -55,8 +55,12 @@ def parse():
     ap.add_argument("--regressor", action="store_true", help="run the regressor side loop as the reference config does")
     ap.add_argument("--gan", action="store_true",
                     help="add the PartDiscriminator adversarial term + one discriminator step (not in the reference loop)")
-    ap.add_argument("--precision", choices=["x6", "f32"], default="x6",
-                    help="x6: fp32-accurate split-bf16 convolution kernels where they apply; f32: fp32-input MFMA everywhere")
+    ap.add_argument("--precision", choices=["h2", "x6", "f32"], default="h2",
+                    help="h2 / x6: fp32-accurate split convolution kernels where they apply (two scaled fp16 terms, three "
+                         "products / three bf16 terms, six products); f32: fp32-input MFMA everywhere")
+    ap.add_argument("--hip-graph", choices=["on", "off"], default="off",
+                    help="replay the step from a captured hipGraph (single GPU, no adversarial term); the config-1 row "
+                         "always reports both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the config-1 (Market 128^2, bs 2) plumbing rows")
@@ -194,14 +198,18 @@ def cpu_baseline(args, cfg, batch, cfg1, batch1):
 
 def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
     is_x6 = "x6" in dom
-    peak = BF16_MFMA_PEAK_TFLOPS / X6_PRODUCTS if is_x6 else FP32_MFMA_PEAK_TFLOPS
+    is_h2 = "h2" in dom
+    products = 3 if is_h2 else (X6_PRODUCTS if is_x6 else 1)
+    peak = BF16_MFMA_PEAK_TFLOPS / products if (is_x6 or is_h2) else FP32_MFMA_PEAK_TFLOPS
     ach = kern[dom]["flop"] / (kern[dom]["ms"] * 1e-3) / 1e12
     r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-         "peak_basis": ("fp32-accurate split-bf16 kernel: dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic MAC "
+         "peak_basis": ("fp32-accurate split-fp16 kernel: dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 MFMAs per algorithmic MAC "
+                        "block (csrc/conv_h2_kernel.h); `achieved` counts ALGORITHMIC fp32 FLOPs" if is_h2 else
+                        "fp32-accurate split-bf16 kernel: dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic MAC "
                         "block (csrc/conv_x6_kernel.h); `achieved` counts ALGORITHMIC fp32 FLOPs" if is_x6 else
                         "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"),
          "achieved_vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-         "mfma_issued_tflops": ach * (X6_PRODUCTS if is_x6 else 1),
+         "mfma_issued_tflops": ach * products,
          "traffic": None,
          "launches_per_step": kern[dom]["n"] // prof_steps,
          "avg_launch_us": 1e3 * kern[dom]["ms"] / kern[dom]["n"],
@@ -292,6 +300,7 @@ def timed_steps(trainer, batch, warmup, steps, sync_all):
     out = None
     for _ in range(steps):
         out = trainer.train_fn(batch)
+    timed_steps.host_issue_s = time.perf_counter() - t0     # the host's share: all launches issued, nothing awaited yet
     sync_all()
     return time.perf_counter() - t0, out
 
@@ -316,7 +325,8 @@ def main():
     cfg = make_config(args)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # the constructors print like the reference does; stdout is for the JSON line
-        trainer = ShapePoseNet(cfg, device=device, total_steps=150000, vgg_synthetic=True)
+        trainer = ShapePoseNet(cfg, device=device, total_steps=150000, vgg_synthetic=True,
+                               hip_graph=(args.hip_graph == "on" and world == 1 and not args.gan))
     batch = synthetic_batch(args.batch, args.size, device, seed=42, with_regressor=args.regressor, rank=rank)
 
     def sync_all():
@@ -325,6 +335,7 @@ def main():
         torch.cuda.synchronize()
 
     elapsed, out = timed_steps(trainer, batch, args.warmup, args.steps, sync_all)
+    host_issue_ms = 1e3 * timed_steps.host_issue_s / args.steps
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -337,9 +348,12 @@ def main():
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f32 (operands split exactly into 3 bf16 terms, 6 partial products on bf16 MFMA, fp32 accumulate; "
-                  "fp32-input MFMA / fp32 VALU for the layers the split kernels do not cover)" if args.precision == "x6"
-                  else "f32"),
+        "dtype": {"h2": "f32 (operands scaled by a power of two and split into 2 fp16 terms, 3 partial products on fp16 MFMA, "
+                        "fp32 accumulate; weight gradients and uncovered layers: 3 bf16 terms / 6 products, fp32-input "
+                        "MFMA, fp32 VALU)",
+                  "x6": "f32 (operands split exactly into 3 bf16 terms, 6 partial products on bf16 MFMA, fp32 accumulate; "
+                        "fp32-input MFMA / fp32 VALU for the layers the split kernels do not cover)",
+                  "f32": "f32"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"Human3.6m shape_and_pose_net VunetAlter {args.size}x{args.size} per-GPU bs={args.batch} "
                                "fwd+bwd, VGG19 perceptual + KL loss, fused Adam, dropout 0.05"
@@ -349,6 +363,7 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_precision": args.precision,
                    "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val,
                    "hip_streams": 1 if trainer.vunet._side_stream is None else 4,
+                   "hip_graph": bool(trainer._graphs), "host_issue_ms_per_step": host_issue_ms,
                    "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                    "allreduce_ms_per_step": trainer.averager.mean_allreduce_ms()},
     }
@@ -363,12 +378,14 @@ def main():
         trainer.vunet._side_stream = None
         wgrad_streams = ops._wgrad_streams["on"]
         ops.enable_wgrad_streams(False)
+        capture, trainer._capture = getattr(trainer, "_capture", False), False   # event pairs need eager launches
         sync_all()
         ops.profile_start()
         for _ in range(prof_steps):
             trainer.train_fn(batch)
         sync_all()
         trainer.vunet._side_stream = side_stream
+        trainer._capture = capture
         ops.enable_wgrad_streams(wgrad_streams)
     if rank == 0 and not args.no_roofline:
         recs = ops._prof["recs"][:]                       # raw (key, flop, ev0, ev1) records of the instrumented steps
@@ -393,7 +410,16 @@ def main():
         el1, out1 = timed_steps(tr1, batch1, 5, 20, torch.cuda.synchronize)
         result["config1"] = {"workload": "Market1501 shape_and_pose_net VunetAlter 128x128 bs=2, x = 30x64x64 (BASELINE configs[0])",
                              "value": 2 * 20 / el1, "unit": "frames/s", "ms_per_step": 1e3 * el1 / 20,
+                             "host_issue_ms_per_step": 1e3 * timed_steps.host_issue_s / 20,
                              "final_loss": float(out1["loss"])}
+        # the same trainer, the step replayed from a captured hipGraph (the host issues one launch instead of ~1900)
+        if not tr1.averager.active:
+            tr1.enable_hip_graph()
+            el1g, out1g = timed_steps(tr1, batch1, 5, 20, torch.cuda.synchronize)
+            result["config1"]["hip_graph"] = {"value": 2 * 20 / el1g, "unit": "frames/s", "ms_per_step": 1e3 * el1g / 20,
+                                              "host_issue_ms_per_step": 1e3 * timed_steps.host_issue_s / 20,
+                                              "captured": bool(tr1._graphs), "final_loss": float(out1g["loss"])}
+            ops.set_dropout_step(None)
         del tr1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, cfg, batch, cfg1, batch1)

@@ -99,18 +99,29 @@ int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char*
  *                           geometry is covered and the launch fills the chip, else vunet_conv2d_gather.
  *                           VUNET_CONV_PRECISION=f32 in the environment pins every layer to the fp32-MFMA kernels.
  *   vunet_conv2d_x6       : the split-bf16 kernel or VUNET_ERR_UNSUPPORTED (no size heuristics; tests).
+ *
+ * "h2": the same kernel structure on the fp16 matrix cores with HALF the matrix instructions (csrc/conv_h2_kernel.h):
+ * operands scaled by a power of two (x: from its tensor maximum; w: per layer, inside the image), split into two fp16
+ * terms, three partial products, fp32 accumulate; as accurate as x6 wherever |x| >= 2^-28 of its tensor's maximum.
+ *   amax : NULL -> wx is a three-term bf16 image (vunet_wn_desc.split 0/1);  non-NULL -> wx is a two-term fp16 image
+ *          (split 2) and amax holds the 1024 partial maxima of |x1|, |x2| written by vunet_absmax_partials.
  * ------------------------------------------------------------------------------------------ */
 int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
-                 const float* shift, const float* res, const float* aux, float* y, void* stream);
+                 const float* shift, const float* res, const float* aux, float* y, const float* amax, void* stream);
 int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
-                    const float* res, const float* aux, const float* mask, float* y, void* stream);
+                    const float* res, const float* aux, const float* mask, float* y, const float* amax, void* stream);
 int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_mask);
-/* vunet_conv2d_dgrad_relu on the split-bf16 kernel (wx = wx_d); VUNET_ERR_UNSUPPORTED -> use vunet_conv2d_dgrad_relu */
+/* 1: vunet_conv2d (has_mask: vunet_conv2d_dgrad_relu_x6) given a split image runs a split kernel for this problem --
+ * the caller of the fp16 scheme then owes it the |x| maxima (vunet_absmax_partials); 0: it will not look at amax */
+int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t has_mask);
+/* vunet_conv2d_dgrad_relu on the split kernels (wx = wx_d); VUNET_ERR_UNSUPPORTED -> use vunet_conv2d_dgrad_relu */
 int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
-                               const float* res, float* dx, void* stream);
+                               const float* res, float* dx, const float* amax, void* stream);
+/* out[0..511] / out[512..1023]: partial maxima of |x1| / |x2| (x2 may be NULL: zeros); one launch, no atomics */
+int vunet_absmax_partials(const float* x1, int64_t n1, const float* x2, int64_t n2, float* out, void* stream);
 /* kernel name vunet_conv2d (has_mask: vunet_conv2d_dgrad_relu_x6) selects, rocprofv3 spelling */
 int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, int32_t has_wx, int32_t has_mask, char* name,
-                         int32_t len);
+                         int32_t len);   /* has_wx: 0 none, 1 three-term bf16 image, 2 two-term fp16 image */
 
 /* bf16-operand forward convolution of the inference path (models/vunets.py:508-515 `transfer`, run per frame
  * by the render loop; BASELINE config 5): operands rounded to bf16 (RNE) on the way into LDS, fp32 accumulate
@@ -160,15 +171,18 @@ int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d);
 typedef struct vunet_wn_desc {
   int32_t Cout, C1, C2, KH, KW;
   int32_t kind;
+  int32_t split;        /* layout of the split weight images wx_f / wx_d: 0 or 1 = three bf16 terms (conv_x6_kernel.h),
+                           2 = two fp16 terms with a per-layer power-of-two scale (conv_h2_kernel.h) */
 } vunet_wn_desc;
 
 /* outputs: wt_f [T*(C1p+C2p)][Coutp32]  (forward),  wt_d [T*Coutp2][Cinp32] (dgrad; NULL to skip),
- * wx_f / wx_d: the split-bf16 images of the same two matrices for vunet_conv2d (vunet_x6_image_bytes bytes each;
- * NULL to skip), scale[Cout], shift[Cout], invnorm[Cout].  Any of g/bias/gamma/beta may be NULL per kind.
+ * wx_f / wx_d: the split images (d->split) of the same two matrices for vunet_conv2d (vunet_x6_image_bytes bytes each;
+ * NULL to skip), scale[Cout], shift[Cout], invnorm[Cout], wmax[Cout] = max |w_eff| per row (required when d->split == 2
+ * and an image is wanted, else may be NULL).  Any of g/bias/gamma/beta may be NULL per kind.
  * (CXp = CX rounded up to 2, Coutp2 = Cout rounded up to 2, Coutp32/Cinp32 rounded up to 32.) */
 int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g, const float* bias,
                          const float* gamma, const float* beta, float* wt_f, float* wt_d, void* wx_f, void* wx_d,
-                         float* scale, float* shift, float* invnorm, void* stream);
+                         float* scale, float* shift, float* invnorm, float* wmax, void* stream);
 
 /* Batched form: the weights of every layer of a model in two launches.  items_dev: DEVICE array of n_items
  * entries (the pointers are device pointers; entries with kind/NULL rules as above); max_cout = max over items. */
@@ -176,6 +190,7 @@ typedef struct vunet_wn_item {
   const float *v, *g, *bias, *gamma, *beta;
   float *wt_f, *wt_d, *scale, *shift, *invnorm;
   void *wx_f, *wx_d;
+  float* wmax;
   vunet_wn_desc d;
 } vunet_wn_item;
 int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_t n_items, int32_t max_cout, void* stream);

@@ -339,7 +339,7 @@ def test_weightnorm_backward_ignores_stale_output_buffers():
     def run(fill):
         outs = [torch.full_like(t, fill) for t in (v, g, bias, gamma, gamma)]
         work = torch.empty(cout * (K + 1), device="cuda")
-        wn = ops.WnDesc(cout, cin, 0, k, k, 0)
+        wn = ops.WnDesc(cout, cin, 0, k, k, 0, 0)
         ops._call("vunet_weightnorm_bwd", ctypes.byref(wn), ops._p(slabs), ops._p(dshift), ns, ops._p(v), ops._p(g),
                   ops._p(bias), ops._p(gamma), ops._p(invnorm), *[ops._p(o) for o in outs], ops._p(work), 0, ops._stream())
         return outs

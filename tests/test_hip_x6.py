@@ -27,6 +27,22 @@ def _ops():
     return ops
 
 
+@pytest.fixture(autouse=True, params=["x6", "h2"])
+def scheme(request):
+    """Every test of this module runs on both split schemes: three bf16 terms / six products (conv_x6_kernel.h) and two
+    scaled fp16 terms / three products (conv_h2_kernel.h).  Same bounds for both."""
+    ops = _ops()
+    before = ops.conv_precision()
+    ops.set_conv_precision(request.param)
+    yield request.param
+    ops.set_conv_precision(before)
+
+
+def _amax(ops, x1, x2=None):
+    """The |x| partial maxima the fp16 scheme's kernels scale by (NULL for the bf16 scheme)."""
+    return ops._p(ops.absmax_partials(x1, x2)) if ops.conv_precision() == "h2" else None
+
+
 def _ref_forward(x1, x2, v, scale, shift, in_act, drop, seed, out_act, res, d2s):
     """fp64 restatement of one fused layer: prologue on each source, conv, shift, activation, d2s, residual."""
     ops = _ops()
@@ -73,7 +89,7 @@ def _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_a
         if use_x6:
             assert ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
             ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift),
-                      ops._p(res), None, None, ops._p(y), ops._stream())
+                      ops._p(res), None, None, ops._p(y), _amax(ops, x1, x2), ops._stream())
         else:
             ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wt_f), ops._p(shift),
                       ops._p(res), None, ops._p(y), ops._stream())
@@ -153,7 +169,7 @@ def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked):
     os.environ["VUNET_X6_FORCE_NT"] = str(nt)
     try:
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux),
-                  ops._p(yfwd) if masked else None, ops._p(dx), ops._stream())
+                  ops._p(yfwd) if masked else None, ops._p(dx), _amax(ops, dy), ops._stream())
     finally:
         os.environ.pop("VUNET_X6_FORCE_NT", None)
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
@@ -181,7 +197,7 @@ def test_x6_second_source_gradient_uses_column_offset():
                      stride=1, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
     dx = torch.empty(n, c2, h, w, device="cuda")
     ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, None, None, None, ops._p(dx),
-              ops._stream())
+              _amax(ops, dy), ops._stream())
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
     ref = F.conv_transpose2d(dy.double().cpu(), wd[:, c1:], padding=1)
     assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0), name="dx2")
@@ -204,14 +220,15 @@ def test_x6_unsupported_geometries_are_refused_not_miscomputed():
     y = torch.empty(1, 32, 8, 32, device="cuda")
     wx = torch.zeros(1024, device="cuda", dtype=torch.int32)
     rc = lib.vunet_conv2d_x6(ctypes.byref(desc(C1=24)), ops._p(x), None, ops._p(wx), None, None, None, None, ops._p(y),
-                             ops._stream())
+                             _amax(ops, x), ops._stream())
     assert rc == -3   # VUNET_ERR_UNSUPPORTED
 
 
-def test_fused_conv_takes_the_x6_path_and_matches_the_f32_path():
-    """Through ops.fused_conv + autograd at a size the dispatcher routes to the split-bf16 kernels: forward, input and
-    parameter gradients agree with the fp32-MFMA path to fp32 accuracy, and the profiler sees conv_x6_kernel."""
+def test_fused_conv_takes_the_x6_path_and_matches_the_f32_path(scheme):
+    """Through ops.fused_conv + autograd at a size the dispatcher routes to the split kernels: forward, input and
+    parameter gradients agree with the fp32-MFMA path to fp32 accuracy, and the profiler sees the scheme's kernel."""
     ops = _ops()
+    fam_name = "conv_x6_kernel" if scheme == "x6" else "conv_h2_kernel"
     from behavior_driven_video_synthesis_amd.lib.modules import VunetRNB
     torch.manual_seed(5)
     blk = VunetRNB(64, a_channels=64, residual=True, dropout_prob=0.05).cuda().train()
@@ -219,7 +236,7 @@ def test_fused_conv_takes_the_x6_path_and_matches_the_f32_path():
     a = torch.randn(4, 64, 64, 64, device="cuda")
     wgt = torch.randn(4, 64, 64, 64, device="cuda")
     outs = {}
-    for mode in ("x6", "f32"):
+    for mode in (scheme, "f32"):
         ops.set_conv_precision(mode)
         ops.set_dropout_seed(31)
         xi, ai = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
@@ -229,10 +246,9 @@ def test_fused_conv_takes_the_x6_path_and_matches_the_f32_path():
         (y * wgt).sum().backward()
         fam = ops.profile_stop(by_kernel=True)
         outs[mode] = (y.detach(), xi.grad, ai.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}, fam)
-    ops.set_conv_precision("x6")
-    assert any(k.startswith("conv_x6_kernel") for k in outs["x6"][4]), list(outs["x6"][4])
-    assert not any(k.startswith("conv_x6_kernel") for k in outs["f32"][4]), list(outs["f32"][4])
-    y6, gx6, ga6, gp6, _ = outs["x6"]
+    assert any(k.startswith(fam_name) for k in outs[scheme][4]), list(outs[scheme][4])
+    assert not any(k.startswith(("conv_x6_kernel", "conv_h2_kernel")) for k in outs["f32"][4]), list(outs["f32"][4])
+    y6, gx6, ga6, gp6, _ = outs[scheme]
     y3, gx3, ga3, gp3, _ = outs["f32"]
     assert_close(y6, y3, rtol=2e-5, atol=2e-5 * float(y3.abs().max()), name="y")
     assert_close(gx6, gx3, rtol=2e-5, atol=2e-5 * float(gx3.abs().max()), name="gx")
@@ -276,7 +292,7 @@ def test_x6_weight_gradient_vs_fp64(n, c1, c2, cout, h, w, in_act, drop):
         db = torch.empty(cout, device="cuda")
         v = torch.zeros(cout, ctot, 3, 3, device="cuda")
         work = torch.empty(cout * (ktot + 1), device="cuda")
-        wn = ops.WnDesc(cout, c1, c2, 3, 3, 1)
+        wn = ops.WnDesc(cout, c1, c2, 3, 3, 1, 0)
         ops._call("vunet_weightnorm_bwd", ctypes.byref(wn), ops._p(slabs), ops._p(dshift), ns, ops._p(v), None, None,
                   None, None, ops._p(dw), None, ops._p(db), None, None, ops._p(work), 0, ops._stream())
         torch.cuda.synchronize()
@@ -332,7 +348,7 @@ def test_x6_stride2_data_gradient_vs_fp64(cout, cin, h, w, nt, with_aux):
     os.environ["VUNET_X6_FORCE_NT"] = str(nt)
     try:
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
-                  ops._p(dx), ops._stream())
+                  ops._p(dx), _amax(ops, dy), ops._stream())
     finally:
         os.environ.pop("VUNET_X6_FORCE_NT", None)
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
