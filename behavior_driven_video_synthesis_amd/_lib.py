@@ -107,7 +107,8 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(the HIP extension is mandatory, there is no CPU fallback)")
-        _LIB = ctypes.CDLL(LIB_PATH)
+        # VUNET_HIP_LIB: an alternative build of the same library (kernel tuning A/B runs: tools/ab_build.sh)
+        _LIB = ctypes.CDLL(os.environ.get("VUNET_HIP_LIB", LIB_PATH))
         for name, argtypes in declared_prototypes().items():
             fn = getattr(_LIB, name)  # AttributeError if the .so is stale
             fn.restype = ctypes.c_int

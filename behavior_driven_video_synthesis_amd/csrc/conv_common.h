@@ -80,10 +80,43 @@ __device__ __forceinline__ void store_out(const GatherArgs& a, const PixGeo& g, 
 
 
 // Epilogue of one 32x32 accumulator tile held by a wave (16 registers per lane: rows (r&3)+8(r>>2)+4h of the
-// m-tile, lane = pixel).  All residual / aux loads of the tile are issued together (no per-element branch or
-// wait), then the 16 results are computed and stored.  m_tile0 = first channel of the m-tile.
-__device__ __forceinline__ void store_tile16(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
-                                             const f32x16& acc) {
+// m-tile, lane = pixel), in two halves so that a kernel can issue the side loads of tile t+1 BEFORE the stores of tile t:
+// on gfx9 stores count in vmcnt like loads, so a load issued behind 16 stores is only "returned" (s_waitcnt) once those
+// stores have been acknowledged -- a serial load -> store -> load -> store chain costs a write round trip per tile.
+//   load_tile_side   issues every residual / aux / shift load of the tile (no per-element branch or wait)
+//   store_tile_side  computes the 16 results and stores them
+// m_tile0 = first channel of the m-tile.  (The sub-pixel store, d.d2s, is scattered and rare: one-pass store_out.)
+struct TileSide {
+  float aux[16], res[16], sh[16];
+};
+
+__device__ __forceinline__ void load_tile_side(const GatherArgs& a, const PixGeo& g, int m_tile0, int h, TileSide& s) {
+  const vunet_conv_desc& d = a.d;
+  if (d.d2s) return;
+  const int mb = m_tile0 + 4 * h;
+  const int pix = g.oh * d.Wo + g.ow;
+  const size_t o0 = (size_t)(g.n * d.M + mb) * a.HoWo + pix;
+  const size_t rs = (size_t)a.HoWo;
+  const bool full = m_tile0 + 32 <= d.M;  // wave-uniform
+  bool ok[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ok[r] = g.valid && (full || mb + (r & 3) + 8 * (r >> 2) < d.M);
+  if (a.aux) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s.aux[r] = a.aux[ok[r] ? o0 + ((r & 3) + 8 * (r >> 2)) * rs : 0];
+  }
+  if (a.res) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s.res[r] = a.res[ok[r] ? o0 + ((r & 3) + 8 * (r >> 2)) * rs : 0];
+  }
+  if (d.mode == 0 && a.shift) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s.sh[r] = a.shift[ok[r] ? mb + (r & 3) + 8 * (r >> 2) : 0];
+  }
+}
+
+__device__ __forceinline__ void store_tile_side(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
+                                                const f32x16& acc, const TileSide& s) {
   const vunet_conv_desc& d = a.d;
   if (d.d2s) {  // sub-pixel store: rare (up-convs), scattered addresses
 #pragma unroll
@@ -98,36 +131,28 @@ __device__ __forceinline__ void store_tile16(const GatherArgs& a, const PixGeo& 
   const size_t o0 = (size_t)(g.n * d.M + mb) * a.HoWo + pix;
   const size_t rs = (size_t)a.HoWo;
   const bool full = m_tile0 + 32 <= d.M;  // wave-uniform
-  bool ok[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ok[r] = g.valid && (full || mb + (r & 3) + 8 * (r >> 2) < d.M);
-  float auxv[16], resv[16], shv[16];
-  if (a.aux) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) auxv[r] = a.aux[ok[r] ? o0 + ((r & 3) + 8 * (r >> 2)) * rs : 0];
-  }
-  if (a.res) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) resv[r] = a.res[ok[r] ? o0 + ((r & 3) + 8 * (r >> 2)) * rs : 0];
-  }
-  if (d.mode == 0 && a.shift) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) shv[r] = a.shift[ok[r] ? mb + (r & 3) + 8 * (r >> 2) : 0];
-  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const size_t o = o0 + ((r & 3) + 8 * (r >> 2)) * rs;
+    const bool ok = g.valid && (full || mb + (r & 3) + 8 * (r >> 2) < d.M);
     float v = acc[r];
     if (d.mode == 0) {
-      if (a.shift) v += shv[r];
+      if (a.shift) v += s.sh[r];
       if (d.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (d.out_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
       else if (d.out_act == ACT_ELU) v = elu_f(v);
       else if (d.out_act == ACT_LRELU) v = v > 0.f ? v : v * d.in_slope;
     } else if (a.aux) {
-      v *= in_act_grad(a.auxa, auxv[r], (uint32_t)o);
+      v *= in_act_grad(a.auxa, s.aux[r], (uint32_t)o);
     }
-    if (a.res) v += resv[r];
-    if (ok[r]) a.y[o] = v;
+    if (a.res) v += s.res[r];
+    if (ok) a.y[o] = v;
   }
+}
+
+__device__ __forceinline__ void store_tile16(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
+                                             const f32x16& acc) {
+  TileSide s;
+  load_tile_side(a, g, m_tile0, h, s);
+  store_tile_side(a, g, m_tile0, h, acc, s);
 }

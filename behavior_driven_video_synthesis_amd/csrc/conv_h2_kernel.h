@@ -38,7 +38,11 @@ __device__ __forceinline__ void h2_dma16(const void* gsrc, uint32_t lds_addr) {
                : "v"(gsrc), "s"(lds_addr)
                : "memory");
 }
-__device__ __forceinline__ void h2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void h2_dma_wait() {
+#ifndef H2_ABL_NOWAIT   // (timing ablations for tools/ab_build.sh: results are wrong with any H2_ABL_* defined)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 
 union H2Unit {
   uint4 u;
@@ -51,9 +55,16 @@ union H2Unit {
 // w[kh][kw] * dy[a + (ph+1-kh)/2][b + (pw+1-kw)/2] -- a stride-1 problem on the dy map with 1, 2, 2 or 4 of the 9
 // taps, stored to every other pixel of dx.  Four launches cover the four parities; no MFMA is spent on the structural
 // zeros of a transposed strided convolution.
-template <int MT, int NT, int MODE, int PRO, int PHW = -1>
-__global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, const uint4* __restrict__ wx, int mtiles_pad,
-                                                                  const float* __restrict__ amax) {
+// NWV waves per workgroup: 4 -> 256 threads, two workgroups per CU, one weight slab (kernel row) per barrier;
+//                          8 -> 512 threads, ONE workgroup per CU owning most of the LDS: twice the tile rows (less halo,
+//                               the weight slabs shared by twice the MFMAs), the weights of a whole chunk (all kernel rows)
+//                               per stage and one barrier per chunk.  Measured on the bs-16 layers (r02, tools/time_conv.py):
+//                               within 2 % of the four-wave form everywhere -- neither the barriers nor the weight staging
+//                               are what bounds the kernel -- so only NWV = 4 is instantiated.
+template <int MT, int NT, int MODE, int PRO, int PHW = -1, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(const GatherArgs a_in,
+                                                                             const uint4* __restrict__ wx, int mtiles_pad,
+                                                                             const float* __restrict__ amax) {
   GatherArgs a = a_in;
   inact_resolve(a.in1);
   inact_resolve(a.in2);
@@ -61,13 +72,16 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
   static_assert(PHW < 0 || MODE == 1, "parity phases exist for the data gradient only");
   constexpr int PH = PHW >= 0 ? (PHW >> 1) : 0, PW = PHW >= 0 ? (PHW & 1) : 0;
   constexpr int NKH = PHW < 0 ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk
-  constexpr int TW = 32, TH = 4 * NT, IH = TH + 2, IW = TW + 2, PIX = IH * IW, MB = 32 * MT;
+  constexpr int NTHR = 64 * NWV;
+  constexpr int TW = 32, TH = NWV * NT, IH = TH + 2, IW = TW + 2, PIX = IH * IW, MB = 32 * MT;
   constexpr int XU = 2 * PIX;             // staging units of the input tile: (k-half, pixel)
-  constexpr int NX = (XU + 255) / 256;
+  constexpr int NX = (XU + NTHR - 1) / NTHR;
   constexpr int WU = H2_SLAB * MT;        // units of one weight slab
+  constexpr int GS = NWV == 8 ? NKH : 1;  // weight slabs (kernel rows) per stage = per barrier
+  constexpr int WUS = WU * GS;            // units of one stage of weights
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   uint4* const xL = smem4;                // [2 buffers][2 planes][2 k-halves][PIX]
-  uint4* const wL = smem4 + 8 * PIX;      // [2 buffers][WU]
+  uint4* const wL = smem4 + 8 * PIX;      // [2 buffers][WUS]
 
   const vunet_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,23 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
   const int n = t / tiles_h;
   const int row0 = ty * TH, col0 = tx * TW, m0 = mb * MB;
 
-  // ---- scales: x by 2^ex from the tensor maximum (1024 partial maxima, reduced here), w by the exponent in the image header
-  float sx, descale;
-  {
-    const float4 pm = reinterpret_cast<const float4*>(amax)[tid];
-    float m_ = fmaxf(fmaxf(pm.x, pm.y), fmaxf(pm.z, pm.w));
-    m_ = wave_max(m_);
-    float* const redm = reinterpret_cast<float*>(smem4);
-    if (lane == 0) redm[wave] = m_;
-    __syncthreads();
-    m_ = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
-    __syncthreads();
-    if (a.in1.thresh) m_ *= a.in1.keep_scale;        // dropout rescales the kept values
-    const int ex = h2_scale_exp(m_);
-    const int ew = reinterpret_cast<const int*>(wx)[0];
-    sx = h2_pow2(ex);
-    descale = h2_pow2(-(ex + ew));
-  }
+  float sx, descale;   // set in the prologue below, once the first loads are in flight
 
   // ---- chunk-invariant staging geometry: unit u = (k-half c8, halo row r, halo column col), lanes walk columns
   unsigned rel[NX];   // element offsets; loads address as scalar base + unsigned 32-bit BYTE offset (no 64-bit pairs)
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
   uint32_t vbits = 0;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    int u = tid + 256 * i;
+    int u = tid + NTHR * i;
     if (u >= XU) u -= XU;   // the threads past the end of the tile redo its first units (same bytes): no divergent staging
     const int c8 = u / PIX;
     const int rem = u - c8 * PIX;
@@ -183,32 +181,57 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
     xb[2 * PIX + lds_x[i]] = pl;
   };
   // Weight slab staging by LDS-DMA (global_load_lds_dwordx4: one wave-instruction copies 64 consecutive units = 1 KiB
-  // straight into LDS, no registers, no ds_write): the slab is a linear copy, WU / 64 = 6 * MT wave-instructions over
-  // the 4 waves; with MT = 1 waves 2 and 3 wrap around and rewrite units 0..127 with the same bytes.  The DMA of slab
-  // p+1 is issued before the MFMA block of phase p and retired (h2_dma_wait) just before the barrier that ends the phase.
-  constexpr int NWI = (WU / 64 + 3) / 4;
+  // straight into LDS, no registers, no ds_write): a slab is a linear copy of WU / 64 = 6 * MT wave-instructions, a
+  // stage is GS slabs, dealt round-robin to the NWV waves; the waves past the end wrap around and rewrite the first units
+  // with the same bytes.  The DMA of stage s+1 is issued before the MFMA block of stage s and retired (h2_dma_wait) just
+  // before the barrier that ends the stage.
+  constexpr int WPS = WU / 64;               // wave-instructions per slab
+  constexpr int NWI = (GS * WPS + NWV - 1) / NWV;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const uint32_t wL_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)wL;
-  auto issue_w = [&](int phase, int buf) {   // phase = chunk * 3 + kh
-    const char* wp = reinterpret_cast<const char*>(wx) + 16 + ((size_t)phase * mtiles_pad + mt0) * (H2_SLAB * 16);
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      int wi = wave_u + 4 * i;
-      if (wi >= WU / 64) wi -= WU / 64;
-      h2_dma16(wp + (size_t)(wi * 64 + lane) * 16, wL_addr + (uint32_t)(buf * WU + wi * 64) * 16u);
-    }
-  };
-
   // step -> weight slab (chunk * 3 + kh): all three kernel rows, or only those of this output parity
   auto slab_of = [&](int step) {
     if constexpr (PHW < 0) return step;
     else if constexpr (PH == 0) return step * 3 + 1;                     // kh = 1
     else return (step >> 1) * 3 + ((step & 1) ? 2 : 0);                  // kh = 0, 2
   };
-  issue_w(slab_of(0), 0);
+  auto issue_w = [&](int stage, int buf) {   // stage = GS consecutive steps (step = chunk * NKH + ki)
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      int wi = wave_u + NWV * i;
+      if (wi >= GS * WPS) wi -= GS * WPS;
+      const int g = wi / WPS, r = wi - g * WPS;
+      const char* wp = reinterpret_cast<const char*>(wx) + 16 +
+                       ((size_t)slab_of(stage * GS + g) * mtiles_pad + mt0) * (H2_SLAB * 16);
+      h2_dma16(wp + (size_t)(r * 64 + lane) * 16, wL_addr + (uint32_t)(buf * WUS + g * WU + r * 64) * 16u);
+    }
+  };
+
+  // ---- prologue: everything the first stage needs is requested at once (weight DMA, all rounds of the input tile, the
+  //      |x| maxima), converted as it arrives
+  issue_w(0, 0);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) issue_x(0, i);
+  // ---- scales: x by 2^ex from the tensor maximum (1024 partial maxima, reduced here, behind the loads issued above),
+  //      w by the exponent in the image header
+  {
+    const float4 pm = reinterpret_cast<const float4*>(amax)[tid & 255];
+    float m_ = fmaxf(fmaxf(pm.x, pm.y), fmaxf(pm.z, pm.w));
+    m_ = wave_max(m_);
+    float* const redm = reinterpret_cast<float*>(smem4);
+    if (lane == 0) redm[wave] = m_;
+    __syncthreads();
+    m_ = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));   // waves 0..3 cover all 1024 entries
+    __syncthreads();
+    if (a.in1.thresh) m_ *= a.in1.keep_scale;        // dropout rescales the kept values
+    const int ex = h2_scale_exp(m_);
+    const int ew = reinterpret_cast<const int*>(wx)[0];
+    sx = h2_pow2(ex);
+    descale = h2_pow2(-(ex + ew));
+  }
+
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    issue_x(0, i);
     issue_mask(0, i);
     write_x(0, i);
   }
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
   __syncthreads();
 
   const uint4* const xB0 = xL + h * PIX + (wave * NT) * IW + j;  // + buffer*4*PIX + plane*2*PIX + (q + dr)*IW + dc
-  const uint4* const wA = wL + h * 32 + j;                       // + buf*WU + ((mt*3 + kw)*2 + plane)*64
+  const uint4* const wA = wL + h * 32 + j;                       // + buf*WUS + g*WU + ((mt*3 + kw)*2 + plane)*64
   // One chunk = three phases (kernel rows).  LAST is a compile-time flag so that every prefetch is unconditional code.
   auto chunk = [&](int ch, auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
@@ -224,15 +247,21 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
     for (int ki = 0; ki < NKH; ++ki) {
       const int kh = PHW < 0 ? ki : (PH ? 2 * ki : 1);
       const int phase = ch * NKH + ki;
-      const int buf = phase & 1;
-      const bool more_w = !(LAST && ki == NKH - 1);
+      const int stage = phase / GS, g = phase - stage * GS;   // GS == NKH: stage = chunk, g = ki
+      const int buf = stage & 1;
+      const bool stage_begin = g == 0, stage_end = g == GS - 1;
+      const bool more_w = !(LAST && ki == NKH - 1);            // another stage follows this step's
       const uint4* const xB = xB0 + (ch & 1) * 4 * PIX;
+#ifndef H2_ABL_NOX
       if constexpr (!LAST) {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
           if (i * NKH / NX == ki) issue_x(ch + 1, i);
       }
-      if (more_w) issue_w(slab_of(phase + 1), buf ^ 1);
+#endif
+#ifndef H2_ABL_NOW
+      if (stage_begin && !(LAST && GS == NKH) && (GS == NKH || more_w)) issue_w(stage + 1, buf ^ 1);
+#endif
       // row / column of the staged tile (origin row0-1, col0-1) that tap (kh, kw) reads for output row q, column j
       const int dr = PHW >= 0 ? (PH + 1 - kh) / 2 + 1 : (MODE == 0 ? kh : 2 - kh);
 #pragma unroll
@@ -240,13 +269,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
         if (PHW >= 0 && ((kw + PW) & 1) == 0) continue;   // this parity's taps only: kw = pw + 1 (mod 2)
         // two waves share a SIMD: the partner's MFMAs cover this wave's fragment reads, so nothing is gained by
         // letting the scheduler hoist the next tap's 4*(MT+NT) fragment registers above this tap's MFMAs
+#ifndef H2_NO_TAP_BARRIER
         __builtin_amdgcn_sched_barrier(0);
+#endif
         const int dc = PHW >= 0 ? (PW + 1 - kw) / 2 + 1 : (MODE == 0 ? kw : 2 - kw);
         H2Unit av[2][MT], bv[2][NT];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[p][mt].u = wA[buf * WU + ((mt * 3 + kw) * 2 + p) * 64];
+          for (int mt = 0; mt < MT; ++mt) av[p][mt].u = wA[buf * WUS + g * WU + ((mt * 3 + kw) * 2 + p) * 64];
 #pragma unroll
           for (int q = 0; q < NT; ++q) bv[p][q].u = xB[p * 2 * PIX + (q + dr) * IW + dc];
         }
@@ -262,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
           }
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifndef H2_ABL_NOX
       if constexpr (!LAST) {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
@@ -270,7 +302,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
             write_x(ch + 1, i);
           }
       }
-      if (more_w) {
+#endif
+      if (stage_end && more_w) {
         h2_dma_wait();
         __syncthreads();
       }
@@ -279,64 +312,67 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const GatherArgs a_in, 
   for (int ch = 0; ch + 1 < nch; ++ch) chunk(ch, std::false_type{});
   chunk(nch - 1, std::true_type{});
 
-  // ---- epilogue (shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The tiles are named
-  // at compile time (a runtime q would put the accumulators in scratch: the unroller gives up on this body's size).
-  auto epilogue = [&](auto qc) {
-    constexpr int q = decltype(qc)::value;
+  // ---- epilogue (arithmetic shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The MT * NT
+  // tiles are named at compile time (a runtime index would put the accumulators in scratch) and software-pipelined: the
+  // residual / aux / shift loads of tile t+1 are issued before the stores of tile t (conv_common.h: load_tile_side).
+  auto geo = [&](int q) {
     PixGeo g;
     g.n = n;
     g.oh = PHW >= 0 ? 2 * (row0 + wave * NT + q) + PH : row0 + wave * NT + q;   // parity phase: every other pixel of dx
     g.ow = PHW >= 0 ? 2 * (col0 + j) + PW : col0 + j;
     g.valid = true;
+    return g;
+  };
+  TileSide side[2];
+  load_tile_side(a, geo(0), m0, h, side[0]);
+  auto tile = [&](auto tc) {
+    constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
+    if constexpr (t + 1 < MT * NT) load_tile_side(a, geo((t + 1) / MT), m0 + 32 * ((t + 1) % MT), h, side[(t + 1) & 1]);
     f32x16 c;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = (acc[0][q][r] + acx[0][q][r] * (1.f / 2048.f)) * descale;
-    store_tile16(a, g, m0, h, c);
-    if constexpr (MT > 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = (acc[1][q][r] + acx[1][q][r] * (1.f / 2048.f)) * descale;
-      store_tile16(a, g, m0 + 32, h, c);
-    }
+    for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale;
+    store_tile_side(a, geo(q), m0 + 32 * mt, h, c, side[t & 1]);
   };
-  epilogue(std::integral_constant<int, 0>{});
-  if constexpr (NT > 1) epilogue(std::integral_constant<int, 1>{});
-  if constexpr (NT > 2) {
-    epilogue(std::integral_constant<int, 2>{});
-    epilogue(std::integral_constant<int, 3>{});
+  tile(std::integral_constant<int, 0>{});
+  if constexpr (MT * NT > 1) tile(std::integral_constant<int, 1>{});
+  if constexpr (MT * NT > 2) {
+    tile(std::integral_constant<int, 2>{});
+    tile(std::integral_constant<int, 3>{});
   }
 }
 
-template <int MT, int NT, int MODE, int PRO, int PHW = -1>
+template <int MT, int NT, int MODE, int PRO, int PHW, int NWV>
 static int launch_h2_one(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, hipStream_t st) {
-  constexpr int PIX = (4 * NT + 2) * 34;
-  constexpr size_t lds = (size_t)(8 * PIX + 2 * H2_SLAB * MT) * 16;
+  constexpr int PIX = (NWV * NT + 2) * 34;
+  constexpr int NKH = PHW < 0 ? 3 : ((PHW >> 1) ? 2 : 1);
+  constexpr size_t lds = (size_t)(8 * PIX + 2 * H2_SLAB * MT * (NWV == 8 ? NKH : 1)) * 16;
   const vunet_conv_desc& d = ga.d;
-  const int blocks = d.N * (d.Hs / (4 * NT)) * (d.Ws / 32) * ((d.M + 32 * MT - 1) / (32 * MT));
-  auto kern = conv_h2_kernel<MT, NT, MODE, PRO, PHW>;
+  const int blocks = d.N * (d.Hs / (NWV * NT)) * (d.Ws / 32) * ((d.M + 32 * MT - 1) / (32 * MT));
+  auto kern = conv_h2_kernel<MT, NT, MODE, PRO, PHW, NWV>;
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  VUNET_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, st, ga, (const uint4*)wx, mtiles_pad, amax);
+  VUNET_LAUNCH(kern, dim3((unsigned)blocks), dim3(64 * NWV), lds, st, ga, (const uint4*)wx, mtiles_pad, amax);
   return vunet_check_launch();
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int NWV = 4>
 static int launch_h2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, hipStream_t st) {
   if (ga.d.mode == 1 && ga.d.stride == 2) {   // one launch per output parity
     if (pro != 0) return VUNET_ERR_UNSUPPORTED;
-    int rc = launch_h2_one<MT, NT, 1, 0, 0>(ga, wx, mtiles_pad, amax, st);
-    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 1>(ga, wx, mtiles_pad, amax, st);
-    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 2>(ga, wx, mtiles_pad, amax, st);
-    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 3>(ga, wx, mtiles_pad, amax, st);
+    int rc = launch_h2_one<MT, NT, 1, 0, 0, NWV>(ga, wx, mtiles_pad, amax, st);
+    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 1, NWV>(ga, wx, mtiles_pad, amax, st);
+    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 2, NWV>(ga, wx, mtiles_pad, amax, st);
+    if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 3, NWV>(ga, wx, mtiles_pad, amax, st);
     return rc;
   }
   if (ga.d.mode == 1) {
-    if (pro == 4) return launch_h2_one<MT, NT, 1, 4>(ga, wx, mtiles_pad, amax, st);
-    if (pro == 0) return launch_h2_one<MT, NT, 1, 0>(ga, wx, mtiles_pad, amax, st);
+    if (pro == 4) return launch_h2_one<MT, NT, 1, 4, -1, NWV>(ga, wx, mtiles_pad, amax, st);
+    if (pro == 0) return launch_h2_one<MT, NT, 1, 0, -1, NWV>(ga, wx, mtiles_pad, amax, st);
     return VUNET_ERR_UNSUPPORTED;
   }
   switch (pro) {
-    case 0: return launch_h2_one<MT, NT, 0, 0>(ga, wx, mtiles_pad, amax, st);
-    case 1: return launch_h2_one<MT, NT, 0, 1>(ga, wx, mtiles_pad, amax, st);
-    case 2: return launch_h2_one<MT, NT, 0, 2>(ga, wx, mtiles_pad, amax, st);
+    case 0: return launch_h2_one<MT, NT, 0, 0, -1, NWV>(ga, wx, mtiles_pad, amax, st);
+    case 1: return launch_h2_one<MT, NT, 0, 1, -1, NWV>(ga, wx, mtiles_pad, amax, st);
+    case 2: return launch_h2_one<MT, NT, 0, 2, -1, NWV>(ga, wx, mtiles_pad, amax, st);
     default: return VUNET_ERR_UNSUPPORTED;
   }
 }

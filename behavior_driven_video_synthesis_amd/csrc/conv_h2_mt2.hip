@@ -1,4 +1,4 @@
-// Instantiations of the split-fp16 3x3 convolution for MT = 2 (split per MT to compile in parallel).
+// Instantiations of the split-fp16 3x3 convolution for MT = 2, four waves (split per MT / wave count to compile in parallel).
 #include "conv_h2_kernel.h"
 
 int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,

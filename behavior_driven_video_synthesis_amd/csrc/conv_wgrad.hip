@@ -154,11 +154,20 @@ int vunet_wgrad_x6_nslabs(const vunet_wgrad_desc* d);
 int vunet_wgrad_x6_name(const vunet_wgrad_desc* d, char* name, int len);
 int vunet_wgrad_x6_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
                           float* dshift, hipStream_t st);
+// conv_wgrad_h2.hip: the same layers with two scaled fp16 terms / three products (d->flags bit 1)
+int vunet_wgrad_h2_name(const vunet_wgrad_desc* d, char* name, int len);
+int vunet_wgrad_h2_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
+                          float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st);
+
+extern "C" int vunet_conv2d_wgrad_wants_split(const vunet_wgrad_desc* d) {
+  return d && vunet_wgrad_x6_applicable(d) ? 1 : 0;
+}
 
 extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len) {
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
   if (vunet_wgrad_x6_applicable(d)) {
-    vunet_wgrad_x6_name(d, name, len);
+    if (d->flags & 2) vunet_wgrad_h2_name(d, name, len);
+    else vunet_wgrad_x6_name(d, name, len);
     return VUNET_OK;
   }
   if (vunet_wgrad_tiled_applicable(d)) {
@@ -202,14 +211,20 @@ static int launch_wgrad(const WgradArgs& wa, hipStream_t st) {
 }
 
 extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
-                                  float* slabs, float* dshift, void* stream) {
+                                  float* slabs, float* dshift, const float* amax_x, const float* amax_dy, void* stream) {
   if (!d || !x1 || !dy || !slabs || !dshift) return VUNET_ERR_ARG;
   if (d->C2 > 0 && !x2) return VUNET_ERR_ARG;
   if (d->nsplit < 1 || d->KH < 1 || d->KW < 1) return VUNET_ERR_ARG;
   const int64_t in_elems = (int64_t)d->N * (d->C1 > d->C2 ? d->C1 : d->C2) * d->Hs * d->Ws;
   const int64_t out_elems = (int64_t)d->N * d->Cout * d->Ho * d->Wo;
   if (in_elems >= (1ll << 31) || out_elems >= (1ll << 31)) return VUNET_ERR_UNSUPPORTED;
-  if (vunet_wgrad_x6_applicable(d)) return vunet_wgrad_x6_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
+  if (vunet_wgrad_x6_applicable(d)) {
+    if (d->flags & 2) {
+      if (!amax_x || !amax_dy) return VUNET_ERR_ARG;
+      return vunet_wgrad_h2_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_dy, (hipStream_t)stream);
+    }
+    return vunet_wgrad_x6_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
+  }
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
   WgradArgs wa;
   wa.d = *d;

@@ -9,6 +9,7 @@ int vunet_conv_h2_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pa
                              hipStream_t st);
 int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,
                              hipStream_t st);
+
 extern "C" int vunet_x6_mtiles(int32_t M);
 int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res);
 
@@ -149,7 +150,10 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
     int MT;
     const int NT = x6_pick(d, &MT, 128, has_wx == 2);
     const char* fam = has_wx == 2 ? "conv_h2_kernel" : "conv_x6_kernel";
-    if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4>", fam, MT, NT);
+    if (has_wx == 2) {
+      if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4, 4>", fam, MT, NT);
+      else snprintf(name, len, "%s<%d, %d, %d, %d, -1, 4>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
+    } else if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4>", fam, MT, NT);
     else snprintf(name, len, "%s<%d, %d, %d, %d, -1>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     return VUNET_OK;
   }

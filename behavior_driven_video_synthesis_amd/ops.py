@@ -181,6 +181,14 @@ def absmax_partials(x1, x2=None):
 _wants_split_cache = {}
 
 
+def _wgrad_wants_split(wd) -> bool:
+    key = ("w", wd.N, wd.C1, wd.C2, wd.Hs, wd.Ws, wd.Cout, wd.Ho, wd.Wo, wd.KH, wd.stride, wd.pad, wd.flags & 1)
+    r = _wants_split_cache.get(key)
+    if r is None:
+        r = _wants_split_cache[key] = _lib.lib().vunet_conv2d_wgrad_wants_split(ctypes.byref(wd)) == 1
+    return r
+
+
 def _wants_split(desc, has_aux: bool, has_res: bool, has_mask: bool = False) -> bool:
     """Would vunet_conv2d route this problem to a split kernel (so that the h2 scheme owes it the |x| maxima)?"""
     key = (desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.m_off, desc.Mpad, desc.Ho, desc.Wo, desc.KH, desc.stride,
@@ -279,7 +287,8 @@ class _Timed:
 
 
 def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=None):
-    """``amax``: the |x| partial maxima if the caller already has them (h2 scheme), else computed here when needed."""
+    """``amax``: the |x| partial maxima if the caller already has them (h2 scheme), else computed here when needed.
+    Returns the maxima the launch used (None if it did not need any)."""
     t = desc.KH * desc.KW
     scheme = _scheme() if wx is not None else 0
     if scheme == 2:
@@ -302,6 +311,7 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=N
                 flop):
         _call("vunet_conv2d", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), _p(aux), _p(y),
               _p(amax), _stream())
+    return amax
 
 
 # ------------------------------------------------------------------------------------------------
@@ -393,7 +403,7 @@ class ConvPlainWgrad(torch.autograd.Function):
         ktot = k * k * cin
         slabs = torch.empty(ns * _r32(cout) * (ktot + 1), device=x.device, dtype=torch.float32)
         dshift = slabs[ns * _r32(cout) * ktot:]
-        _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x), None, _p(dy), _p(slabs), _p(dshift), _stream())
+        _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x), None, _p(dy), _p(slabs), _p(dshift), None, None, _stream())
         dw = torch.empty(cout, cin, k, k, device=x.device, dtype=torch.float32)
         work = torch.empty(cout * (ktot + 1), device=x.device, dtype=torch.float32)
         wn = WnDesc(cout, cin, 0, k, k, 1, 0)
@@ -666,6 +676,7 @@ class FusedConv(torch.autograd.Function):
         d = ConvDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, M=cout, m_off=0, Mpad=wt_f.shape[1], Ho=ho, Wo=wo, KH=k, KW=k,
                      stride=cfg.stride, pad=cfg.pad, mode=0, in_act=cfg.in_act, in_slope=cfg.in_slope,
                      drop_p=cfg.drop_p, drop_seed=cfg.drop_seed, out_act=cfg.out_act, d2s=int(cfg.d2s))
+        ctx.amax_x = None
         if cfg.bf16 and _lib.lib().vunet_conv2d_bf16_supported(ctypes.byref(d)) == 1:
             # render path (models/vunets.py:508-515 under no_grad): bf16 operands, fp32 accumulate
             wb = torch.empty((c1 + c2) * 9 * wt_f.shape[1], device=x1.device, dtype=torch.bfloat16)
@@ -674,7 +685,7 @@ class FusedConv(torch.autograd.Function):
                         2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
                 _call("vunet_conv2d_bf16", ctypes.byref(d), _p(x1), _p(x2), _p(wb), _p(shift), _p(res), _p(y), _stream())
         else:
-            _conv_gather(d, x1, x2, wt_f, shift, res, None, y, wx_f)
+            ctx.amax_x = _conv_gather(d, x1, x2, wt_f, shift, res, None, y, wx_f)   # reused by the weight gradient
         ctx.cfg = cfg
         ctx.param_refs = (v, g, bias, gamma, beta)  # the caller's tensors (Parameters): direct .grad writes
         ctx.res_ref = res
@@ -746,11 +757,21 @@ class FusedConv(torch.autograd.Function):
             _call("vunet_space_to_depth", _p(dconv), _p(t), n, cout // 4, 2 * ho, 2 * wo, _stream())
             dconv = t
         dv = dg = dbias = dgamma = dbeta = None
+        dy_amax = []   # |dconv| maxima of the h2 scheme: computed once (on this stream), shared by dgrad and wgrad
+
+        def get_dy_amax():
+            if not dy_amax:
+                dy_amax.append(absmax_partials(dconv))
+            return dy_amax[0]
+
+        wd = WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=cfg.stride,
+                       pad=cfg.pad, in_act=cfg.in_act, in_slope=cfg.in_slope, drop_p=cfg.drop_p,
+                       drop_seed=cfg.drop_seed, nsplit=1, flags=(0, 0, 2)[_scheme()] if _scheme() else 1)
+        wg_amax = (None, None)
+        if ctx.need_w and _scheme() == 2 and _wgrad_wants_split(wd):
+            wg_amax = (ctx.amax_x if ctx.amax_x is not None else absmax_partials(x1, x2), get_dy_amax())
 
         def weight_gradients():
-            wd = WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=cfg.stride,
-                           pad=cfg.pad, in_act=cfg.in_act, in_slope=cfg.in_slope, drop_p=cfg.drop_p,
-                           drop_seed=cfg.drop_seed, nsplit=1, flags=0 if _scheme() else 1)
             ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
             if ns < 1:
                 raise RuntimeError(f"vunet_conv2d_wgrad_nsplit failed with code {ns}")
@@ -766,7 +787,7 @@ class FusedConv(torch.autograd.Function):
             with _Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, kname),
                         2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
                 _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
-                      _stream())
+                      _p(wg_amax[0]), _p(wg_amax[1]), _stream())
             ni = ctx.needs_input_grad
             params = (v, g, bias, gamma, gamma)  # beta has gamma's shape
             outs, direct = [], []
@@ -811,7 +832,7 @@ class FusedConv(torch.autograd.Function):
                 cur = torch.cuda.current_stream()
                 wstream = _wgrad_stream_for(cur)
                 wstream.wait_stream(cur)
-                for t_ in (x1, x2, dconv, v, g, bias, gamma, invnorm):
+                for t_ in (x1, x2, dconv, v, g, bias, gamma, invnorm, wg_amax[0], wg_amax[1]):
                     if t_ is not None:
                         t_.record_stream(wstream)
                 with torch.cuda.stream(wstream):
@@ -820,8 +841,6 @@ class FusedConv(torch.autograd.Function):
                 dv, dg, dbias, dgamma, dbeta = weight_gradients()
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
-            dy_amax = []   # |dconv| maxima of the h2 scheme: computed by the first data gradient that wants them, shared
-
             def dgrad(x, cs, m_off, seed, add):
                 dx = torch.empty_like(x)
                 d = ConvDesc(N=n, C1=cout, C2=0, Hs=ho, Ws=wo, M=cs, m_off=m_off, Mpad=wt_d.shape[1], Ho=hs, Wo=ws,
@@ -831,9 +850,7 @@ class FusedConv(torch.autograd.Function):
                 has_aux = cfg.in_act != ACT_NONE or cfg.drop_p > 0
                 amax = None
                 if wx_d is not None and _scheme() == 2 and _wants_split(d, has_aux, add is not None):
-                    if not dy_amax:
-                        dy_amax.append(absmax_partials(dconv))
-                    amax = dy_amax[0]
+                    amax = get_dy_amax()
                 _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d, amax)
                 return dx
             if ctx.needs_input_grad[0]:

@@ -149,13 +149,17 @@ typedef struct vunet_wgrad_desc {
   float drop_p;
   uint32_t drop_seed;
   int32_t nsplit;
-  int32_t flags;        /* bit 0: keep this problem on the fp32-input MFMA kernels (default: the fp32-accurate
-                           split-bf16 kernel csrc/conv_wgrad_x6.hip wherever it applies: 3x3 / stride 1 / pad 1,
-                           channel counts in 32s, Ws % 32 == 0, Hs % 4 == 0) */
+  int32_t flags;        /* bit 0: keep this problem on the fp32-input MFMA kernels (default: an fp32-accurate split
+                           kernel wherever one applies: 3x3 / stride 1 / pad 1, channel counts in 32s, Ws % 32 == 0,
+                           Hs % 4 == 0);  bit 1: the split kernel is the two-term fp16 one (csrc/conv_wgrad_h2.hip: three
+                           products, needs amax_x / amax_dy) instead of the three-term bf16 one (csrc/conv_wgrad_x6.hip) */
 } vunet_wgrad_desc;
 
+/* amax_x / amax_dy: partial maxima (vunet_absmax_partials) of |x1|, |x2| and of |dy|; read only when flags bit 1 is set
+ * and vunet_conv2d_wgrad_wants_split(d) == 1, else may be NULL */
 int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
-                       float* slabs, float* dshift, void* stream);
+                       float* slabs, float* dshift, const float* amax_x, const float* amax_dy, void* stream);
+int vunet_conv2d_wgrad_wants_split(const vunet_wgrad_desc* d);
 int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len);
 /* number of pixel splits the library wants for this problem (caller sizes the slabs from it) */
 int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d);

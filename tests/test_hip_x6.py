@@ -264,14 +264,17 @@ def test_fused_conv_takes_the_x6_path_and_matches_the_f32_path(scheme):
     (3, 64, 64, 128, 4, 96, 1, 0.1),    # MTW 2, two co-blocks, three column tiles
     (2, 32, 0, 96, 8, 32, 0, 0.0),      # Cout = 96: not a multiple of 64 -> MTW 1, three co-blocks
 ])
-def test_x6_weight_gradient_vs_fp64(n, c1, c2, cout, h, w, in_act, drop):
-    """conv_wgrad_x6_kernel: slabs summed by vunet_weightnorm_bwd (kind 1: plain dW) against fp64 autograd, beside the
-    fp32-MFMA weight-gradient kernel on the same problem."""
+@pytest.mark.parametrize("wide", [False, True])
+def test_x6_weight_gradient_vs_fp64(n, c1, c2, cout, h, w, in_act, drop, wide, scheme):
+    """conv_wgrad_x6_kernel / conv_wgrad_h2_kernel: slabs summed by vunet_weightnorm_bwd (kind 1: plain dW) against fp64
+    autograd, beside the fp32-MFMA weight-gradient kernel on the same problem.  ``wide``: the magnitudes of x and dy fall
+    by 2^-0.75 per pixel column (2^-23 across the tile) -- the data a tensor-wide scale is worst for."""
     ops = _ops()
     g_ = torch.Generator().manual_seed(n * 1000 + c1 + cout)
-    x1 = torch.randn(n, c1, h, w, generator=g_).cuda()
-    x2 = torch.randn(n, c2, h, w, generator=g_).cuda() if c2 else None
-    dy = torch.randn(n, cout, h, w, generator=g_).cuda()
+    col = torch.pow(2.0, -0.75 * (torch.arange(w, dtype=torch.float32) % 32)).view(1, 1, 1, w) if wide else 1.0
+    x1 = (torch.randn(n, c1, h, w, generator=g_) * col).cuda()
+    x2 = (torch.randn(n, c2, h, w, generator=g_) * col).cuda() if c2 else None
+    dy = (torch.randn(n, cout, h, w, generator=g_) * col).cuda()
     seed = 0xBEEF
     ctot, ktot = c1 + c2, 9 * (c1 + c2)
 
@@ -286,8 +289,10 @@ def test_x6_weight_gradient_vs_fp64(n, c1, c2, cout, h, w, in_act, drop):
         cp = ops._r32(cout)
         slabs = torch.full((ns * cp * ktot + ns * cp,), float("nan"), device="cuda")
         dshift = slabs[ns * cp * ktot:]
+        amx = ops.absmax_partials(x1, x2) if flags == 2 else None
+        amd = ops.absmax_partials(dy) if flags == 2 else None
         ops._call("vunet_conv2d_wgrad", ctypes.byref(wd), ops._p(x1), ops._p(x2), ops._p(dy), ops._p(slabs),
-                  ops._p(dshift), ops._stream())
+                  ops._p(dshift), ops._p(amx), ops._p(amd), ops._stream())
         dw = torch.empty(cout, ctot, 3, 3, device="cuda")
         db = torch.empty(cout, device="cuda")
         v = torch.zeros(cout, ctot, 3, 3, device="cuda")
@@ -298,9 +303,9 @@ def test_x6_weight_gradient_vs_fp64(n, c1, c2, cout, h, w, in_act, drop):
         torch.cuda.synchronize()
         return dw, db, buf.value.decode()
 
-    dw6, db6, name6 = run(0)
+    dw6, db6, name6 = run(2 if scheme == "h2" else 0)
     dw3, db3, name3 = run(1)
-    assert name6.startswith("conv_wgrad_x6_kernel") and not name3.startswith("conv_wgrad_x6_kernel"), (name6, name3)
+    assert name6.startswith("conv_wgrad_%s_kernel" % scheme) and not name3.startswith("conv_wgrad_%s_kernel" % scheme), (name6, name3)
     # fp64 reference: the same prologue as the forward, then autograd of the convolution w.r.t. the weight
     xs = []
     for i, x in enumerate((x1, x2)):

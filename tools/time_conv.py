@@ -62,7 +62,9 @@ for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         tf = 2.0 * n * h * w * cin * cout * 9 / (us * 1e-6) / 1e12
-        line.append(f"{sch} {us:8.1f} us {tf:6.1f} TF/s")
+        buf = ctypes.create_string_buffer(96)
+        ops._call("vunet_conv2d_variant", ctypes.byref(d), 0, {"x6": 1, "h2": 2}[sch], int(masked), buf, 96)
+        line.append(f"{sch} {us:8.1f} us {tf:6.1f} TF/s {buf.value.decode().replace('conv_', '').replace('_kernel', '')}")
         if sch == "h2":
             e0.record()
             for _ in range(20):
