@@ -312,6 +312,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   for (int ch = 0; ch + 1 < nch; ++ch) chunk(ch, std::false_type{});
   chunk(nch - 1, std::true_type{});
 
+  // What the output store costs (r02, tools/time_conv.py with -DH2_ABL_NOSTORE): every layer runs at ~305 TFLOP/s without it
+  // whatever its K; with it the short-K layers pay 15 % (C = 128) to 24 % (C = 64).  The workgroups of a launch run in
+  // lockstep, so their stores arrive in bursts the HBM write path drains at ~3 TB/s while the waves wait: on gfx9 stores
+  // count in vmcnt, in order with the loads, so no later load (or LDS-DMA) can be awaited before the stores are
+  // acknowledged.  Persistent workgroups that prefetch the next tile's first chunk across the epilogue were built and
+  // measured: no gain, for that reason (the first stage-end wait of the next tile still sits behind the stores).
   // ---- epilogue (arithmetic shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The MT * NT
   // tiles are named at compile time (a runtime index would put the accumulators in scratch) and software-pipelined: the
   // residual / aux / shift loads of tile t+1 are issued before the stores of tile t (conv_common.h: load_tile_side).
@@ -331,6 +337,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
     f32x16 c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale;
+#ifdef H2_ABL_NOSTORE   // timing ablation (tools/ab_build.sh): the output is not written
+    if (descale == 12345.f)
+#endif
     store_tile_side(a, geo(q), m0 + 32 * mt, h, c, side[t & 1]);
   };
   tile(std::integral_constant<int, 0>{});

@@ -31,6 +31,9 @@ SHAPES = [
     ("vunet rnb 64ch fwd elu", 16, 64, 64, 128, 128, 0, 1, False),
     ("vunet 32ch 256^2 fwd elu", 16, 32, 32, 256, 256, 0, 1, False),
     ("vunet 128ch 64^2 dgrad", 16, 128, 128, 64, 64, 1, 0, False),
+    ("vgg conv4_x fwd", 16, 512, 512, 32, 32, 0, 0, False),
+    ("vgg conv2_2 fwd, N = 32", 32, 128, 128, 128, 128, 0, 0, False),
+    ("K = 4608, 64^2", 16, 512, 128, 64, 64, 0, 0, False),
 ]
 for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
     g = torch.Generator().manual_seed(1)
