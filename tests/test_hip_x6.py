@@ -369,3 +369,38 @@ def test_x6_stride2_data_gradient_vs_fp64(cout, cin, h, w, nt, with_aux):
     ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(dy), None, ops._p(wt_d), None, ops._p(res), ops._p(aux),
               ops._p(dx32), ops._stream())
     assert_close(dx, dx32, rtol=2e-5, atol=2e-5 * max(float(ref.abs().max()), 1.0), name="x6 vs fp32 path")
+
+
+def test_absmax_partials_and_the_h2_weight_image(scheme):
+    """The two data-dependent inputs of the fp16 scheme: vunet_absmax_partials (512 partial |x| maxima per source, NaNs
+    ignored, odd sizes and unaligned tails) and the weight image's header exponent (the layer's largest |w_eff| lands in
+    [2^13, 2^14)) with planes that reassemble the scaled weight to 2^-22."""
+    if scheme != "h2":
+        pytest.skip("fp16 scheme only")
+    ops = _ops()
+    g_ = torch.Generator().manual_seed(3)
+    for n1, n2 in ((1000003, 0), (4096, 77), (5, 5)):
+        x1 = torch.randn(n1, generator=g_).cuda() * 3.0
+        x2 = (torch.randn(n2, generator=g_).cuda() * 0.01) if n2 else None
+        x1[n1 // 2] = float("nan")                      # ignored: NaNs travel with the data, not with the scale
+        p = ops.absmax_partials(x1, x2)
+        want1 = float(torch.nan_to_num(x1, nan=0.0).abs().max())
+        assert float(p[:512].max()) == want1
+        assert float(p[512:].max()) == (float(x2.abs().max()) if n2 else 0.0)
+    cout, cin = 64, 32
+    v, g, bias, gamma, beta = _params(cout, cin, 21)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, cin, 0, 0, True)
+    w_eff = (v * scale.view(-1, 1, 1, 1)).cpu()
+    wmax = float(w_eff.abs().max())
+    for wx in (wx_f, wx_d):
+        ew = int(wx[0].item())
+        assert 2.0 ** 13 <= wmax * 2.0 ** ew < 2.0 ** 14, (wmax, ew)
+    # forward image: [chunk][kh][m-tile][kw][plane][k-half][32] units of 8 fp16 behind the 16-byte header
+    img = wx_f[4:].view(torch.float16).view(cin // 16, 3, ops.x6_mtiles(cout), 3, 2, 2, 32, 8).float().cpu()
+    ew = int(wx_f[0].item())
+    rec = (img[:, :, :, :, 0] + img[:, :, :, :, 1] / 2048.0) / 2.0 ** ew          # [ch][kh][mt][kw][half][j][e]
+    for (co, ci, kh, kw) in ((0, 0, 0, 0), (63, 31, 2, 2), (17, 9, 1, 2), (40, 24, 0, 1)):
+        got = float(rec[ci // 16, kh, co // 32, kw, (ci % 16) // 8, co % 32, ci % 8])
+        want = float(w_eff[co, ci, kh, kw])
+        assert abs(got - want) <= 2.0 ** -21 * abs(want) + 1e-12, (co, ci, kh, kw, got, want)
+    assert float(img[:, :, 2:].abs().max()) == 0.0     # the padding m-tiles are zeros
