@@ -3,7 +3,7 @@
 PyTorch is plumbing here: it owns device memory, streams and the autograd tape; every convolution,
 normalisation, reduction, loss term and optimiser update of the hot path is a kernel of libvunet_hip.so,
 called through ctypes with raw device pointers.  What PyTorch itself still launches inside a training
-step (measured, tools/aten_in_step.py: 0.85 ms of a 34 ms step): the autograd engine's accumulation of
+step (measured, tools/aten_in_step.py: 0.85 ms of a 29 ms step): the autograd engine's accumulation of
 fan-out gradients (~29 `add_` per step -- skip tensors with two consumers; fusing them into the data-gradient
 epilogue would mean writing into buffers the engine owns), gradient-bucket / scalar zero-fills, the two
 `randn_like` draws of the posterior noise and a dozen one-element scalar ops of the loss assembly and the
