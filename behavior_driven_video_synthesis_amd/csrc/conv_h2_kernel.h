@@ -61,7 +61,10 @@ union H2Unit {
 //                               per stage and one barrier per chunk.  Measured on the bs-16 layers (r02, tools/time_conv.py):
 //                               within 2 % of the four-wave form everywhere -- neither the barriers nor the weight staging
 //                               are what bounds the kernel -- so only NWV = 4 is instantiated.
-template <int MT, int NT, int MODE, int PRO, int PHW = -1, int NWV = 4>
+// TW: tile width in pixels.  32: an MFMA column tile is 32 consecutive pixels of one row; 16 (maps 16 wide: VGG19 conv5,
+//     the decoder's 16 x 16 level): it is 16 pixels of two consecutive rows, lane j -> (row j / 16, column j % 16); the
+//     staged rows are then 32 units apart (18 used), which keeps the two half-rows of a fragment read on distinct banks.
+template <int MT, int NT, int MODE, int PRO, int PHW = -1, int NWV = 4, int TW = 32>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(const GatherArgs a_in,
                                                                              const uint4* __restrict__ wx, int mtiles_pad,
                                                                              const float* __restrict__ amax) {
@@ -73,8 +76,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   constexpr int PH = PHW >= 0 ? (PHW >> 1) : 0, PW = PHW >= 0 ? (PHW & 1) : 0;
   constexpr int NKH = PHW < 0 ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk
   constexpr int NTHR = 64 * NWV;
-  constexpr int TW = 32, TH = NWV * NT, IH = TH + 2, IW = TW + 2, PIX = IH * IW, MB = 32 * MT;
-  constexpr int XU = 2 * PIX;             // staging units of the input tile: (k-half, pixel)
+  static_assert(TW == 32 || TW == 16, "tile width");
+  constexpr int RPQ = 32 / TW;            // image rows per 32-pixel MFMA column tile
+  constexpr int TH = NWV * NT * RPQ, IH = TH + 2, CW = TW + 2, IW = TW == 32 ? CW : 32, PIX = IH * IW, MB = 32 * MT;
+  constexpr int XU = 2 * IH * CW;         // staging units of the input tile: (k-half, halo row, halo column)
   constexpr int NX = (XU + NTHR - 1) / NTHR;
   constexpr int WU = H2_SLAB * MT;        // units of one weight slab
   constexpr int GS = NWV == 8 ? NKH : 1;  // weight slabs (kernel rows) per stage = per barrier
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   const vunet_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
+  const int jr = j / TW, jc = j % TW;     // this lane's pixel inside its column tile
   const int H = d.Hs, W = d.Ws, HW = a.HsWs;
 
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -109,13 +115,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   for (int i = 0; i < NX; ++i) {
     int u = tid + NTHR * i;
     if (u >= XU) u -= XU;   // the threads past the end of the tile redo its first units (same bytes): no divergent staging
-    const int c8 = u / PIX;
-    const int rem = u - c8 * PIX;
-    const int r = rem / IW, col = rem - r * IW;
+    const int c8 = u / (IH * CW);
+    const int rem = u - c8 * (IH * CW);
+    const int r = rem / CW, col = rem - r * CW;
     const int ih = row0 - 1 + r, iw = col0 - 1 + col;
     const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     rel[i] = ok ? (unsigned)(8 * c8 * HW + ih * W + iw) : 0u;   // invalid: a safe in-bounds address, masked afterwards
-    lds_x[i] = c8 * PIX + rem;
+    lds_x[i] = c8 * PIX + r * IW + col;
     vbits |= (ok ? 1u : 0u) << i;
   }
 
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   h2_dma_wait();
   __syncthreads();
 
-  const uint4* const xB0 = xL + h * PIX + (wave * NT) * IW + j;  // + buffer*4*PIX + plane*2*PIX + (q + dr)*IW + dc
+  const uint4* const xB0 = xL + h * PIX + (wave * NT * RPQ + jr) * IW + jc;  // + buffer*4*PIX + plane*2*PIX + (q*RPQ + dr)*IW + dc
   const uint4* const wA = wL + h * 32 + j;                       // + buf*WUS + g*WU + ((mt*3 + kw)*2 + plane)*64
   // One chunk = three phases (kernel rows).  LAST is a compile-time flag so that every prefetch is unconditional code.
   auto chunk = [&](int ch, auto last_c) {
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) av[p][mt].u = wA[buf * WUS + g * WU + ((mt * 3 + kw) * 2 + p) * 64];
 #pragma unroll
-          for (int q = 0; q < NT; ++q) bv[p][q].u = xB[p * 2 * PIX + (q + dr) * IW + dc];
+          for (int q = 0; q < NT; ++q) bv[p][q].u = xB[p * 2 * PIX + (q * RPQ + dr) * IW + dc];
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -324,8 +330,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   auto geo = [&](int q) {
     PixGeo g;
     g.n = n;
-    g.oh = PHW >= 0 ? 2 * (row0 + wave * NT + q) + PH : row0 + wave * NT + q;   // parity phase: every other pixel of dx
-    g.ow = PHW >= 0 ? 2 * (col0 + j) + PW : col0 + j;
+    const int orow = row0 + (wave * NT + q) * RPQ + jr, ocol = col0 + jc;
+    g.oh = PHW >= 0 ? 2 * orow + PH : orow;   // parity phase: every other pixel of dx
+    g.ow = PHW >= 0 ? 2 * ocol + PW : ocol;
     g.valid = true;
     return g;
   };
@@ -350,17 +357,35 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   }
 }
 
-template <int MT, int NT, int MODE, int PRO, int PHW, int NWV>
+template <int MT, int NT, int MODE, int PRO, int PHW, int NWV, int TW = 32>
 static int launch_h2_one(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, hipStream_t st) {
-  constexpr int PIX = (NWV * NT + 2) * 34;
+  constexpr int RPQ = 32 / TW;
+  constexpr int PIX = (NWV * NT * RPQ + 2) * (TW == 32 ? 34 : 32);
   constexpr int NKH = PHW < 0 ? 3 : ((PHW >> 1) ? 2 : 1);
   constexpr size_t lds = (size_t)(8 * PIX + 2 * H2_SLAB * MT * (NWV == 8 ? NKH : 1)) * 16;
   const vunet_conv_desc& d = ga.d;
-  const int blocks = d.N * (d.Hs / (NWV * NT)) * (d.Ws / 32) * ((d.M + 32 * MT - 1) / (32 * MT));
-  auto kern = conv_h2_kernel<MT, NT, MODE, PRO, PHW, NWV>;
+  const int blocks = d.N * (d.Hs / (NWV * NT * RPQ)) * (d.Ws / TW) * ((d.M + 32 * MT - 1) / (32 * MT));
+  auto kern = conv_h2_kernel<MT, NT, MODE, PRO, PHW, NWV, TW>;
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   VUNET_LAUNCH(kern, dim3((unsigned)blocks), dim3(64 * NWV), lds, st, ga, (const uint4*)wx, mtiles_pad, amax);
   return vunet_check_launch();
+}
+
+// 16-wide maps: forward (no prologue / ELU / ELU + dropout) and data gradient (plain / ReLU mask), NT = 1
+template <int MT>
+static int launch_h2_w16(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, hipStream_t st) {
+  if (ga.d.mode == 1) {
+    if (ga.d.stride != 1) return VUNET_ERR_UNSUPPORTED;
+    if (pro == 4) return launch_h2_one<MT, 1, 1, 4, -1, 4, 16>(ga, wx, mtiles_pad, amax, st);
+    if (pro == 0) return launch_h2_one<MT, 1, 1, 0, -1, 4, 16>(ga, wx, mtiles_pad, amax, st);
+    return VUNET_ERR_UNSUPPORTED;
+  }
+  switch (pro) {
+    case 0: return launch_h2_one<MT, 1, 0, 0, -1, 4, 16>(ga, wx, mtiles_pad, amax, st);
+    case 1: return launch_h2_one<MT, 1, 0, 1, -1, 4, 16>(ga, wx, mtiles_pad, amax, st);
+    case 2: return launch_h2_one<MT, 1, 0, 2, -1, 4, 16>(ga, wx, mtiles_pad, amax, st);
+    default: return VUNET_ERR_UNSUPPORTED;
+  }
 }
 
 template <int MT, int NT, int NWV = 4>

@@ -9,6 +9,8 @@ int vunet_conv_h2_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pa
                              hipStream_t st);
 int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,
                              hipStream_t st);
+int vunet_conv_h2_launch_w16(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int MT,
+                             hipStream_t st);
 
 extern "C" int vunet_x6_mtiles(int32_t M);
 int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res);
@@ -30,10 +32,14 @@ static int x6_prologue_code(const vunet_conv_desc* d, bool has_mask) {
   return 3;
 }
 
+// 16-wide staged maps (fp16 scheme only): column tiles of two rows x 16 pixels, 8-row workgroup tiles, stride 1
+static bool h2_w16(const vunet_conv_desc* d) { return d->Ws % 32 != 0 && d->Ws % 16 == 0 && d->Hs % 8 == 0 && d->stride == 1; }
+
 // geometry the kernel family covers (nothing about whether it is the fastest choice)
-static bool x6_geometry_ok(const vunet_conv_desc* d, int pro) {
+static bool x6_geometry_ok(const vunet_conv_desc* d, int pro, bool h2 = false) {
   if (d->KH != 3 || d->KW != 3 || d->pad != 1) return false;
-  if (d->C1 <= 0 || d->C1 % 16 || d->C2 % 16 || d->Ws % 32 || d->Hs % 4) return false;   // Hs, Ws: the gathered (staged) map
+  if (d->C1 <= 0 || d->C1 % 16 || d->C2 % 16 || d->Hs % 4) return false;   // Hs, Ws: the gathered (staged) map
+  if (d->Ws % 32 && !(h2 && h2_w16(d))) return false;
   if (d->M % 32 || d->m_off % 32) return false;
   if (d->stride == 2)   // data gradient of the stride-2 Downsample conv: four parity launches over the dy map
     return d->mode == 1 && pro == 0 && d->C2 == 0 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
@@ -42,6 +48,7 @@ static bool x6_geometry_ok(const vunet_conv_desc* d, int pro) {
 }
 
 static long x6_blocks(const vunet_conv_desc* d, int MT, int NT) {
+  if (d->Ws % 32) return NT == 1 ? (long)d->N * (d->Hs / 8) * (d->Ws / 16) * ((d->M + 32 * MT - 1) / (32 * MT)) : 0;  // h2_w16
   if (d->Hs % (4 * NT)) return 0;
   return (long)d->N * (d->Hs / (4 * NT)) * (d->Ws / 32) * ((d->M + 32 * MT - 1) / (32 * MT));
 }
@@ -81,7 +88,7 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
                      const float* res, const float* aux, const float* mask, float* y, const float* amax, long min_blocks,
                      void* stream) {
   const int pro = x6_prologue_code(d, mask != nullptr);
-  if (!x6_geometry_ok(d, pro)) return VUNET_ERR_UNSUPPORTED;
+  if (!x6_geometry_ok(d, pro, amax != nullptr)) return VUNET_ERR_UNSUPPORTED;
   int MT;
   const int NT = x6_pick(d, &MT, min_blocks, amax != nullptr);
   if (NT == 0) return VUNET_ERR_UNSUPPORTED;
@@ -89,6 +96,7 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
   fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
   // K dimension of the image = the gathered tensor's channels; M dimension = all columns of the weight matrix
   const int mtp = vunet_x6_mtiles(d->Mpad);
+  if (amax && d->Ws % 32) return vunet_conv_h2_launch_w16(ga, wx, mtp, amax, pro, MT, (hipStream_t)stream);
   if (amax)   // two-term fp16 image
     return MT == 1 ? vunet_conv_h2_launch_mt1(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream)
                    : vunet_conv_h2_launch_mt2(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream);
@@ -97,21 +105,22 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
 }
 
 // would vunet_conv2d route this problem to the split-bf16 kernel?  (big enough to fill the chip, not a 3-channel layer)
-static bool x6_wanted(const vunet_conv_desc* d, bool has_wx, bool has_aux, bool has_res, bool has_mask) {
+static bool x6_wanted(const vunet_conv_desc* d, bool has_wx, bool has_aux, bool has_res, bool has_mask, bool h2 = false) {
   if (!has_wx || !x6_enabled()) return false;
   const int pro = x6_prologue_code(d, has_mask);
-  if (!x6_geometry_ok(d, pro)) return false;
+  if (!x6_geometry_ok(d, pro, h2)) return false;
   if (vunet_conv_thin_kind(d, pro == 4 ? 0 : pro, has_aux, has_res) != 0) return false;
   int MT;
-  return x6_pick(d, &MT, 128) > 0;
+  return x6_pick(d, &MT, 128, h2) > 0;
 }
 
 extern "C" int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_mask) {
   return d && x6_geometry_ok(d, x6_prologue_code(d, has_mask != 0)) ? 1 : 0;
 }
 
-extern "C" int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t has_mask) {
-  return d && x6_wanted(d, true, has_aux != 0, has_res != 0, has_mask != 0) ? 1 : 0;
+extern "C" int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t has_mask,
+                                        int32_t split) {
+  return d && x6_wanted(d, true, has_aux != 0, has_res != 0, has_mask != 0, split == 2) ? 1 : 0;
 }
 
 extern "C" int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx,
@@ -127,7 +136,7 @@ extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const flo
                             const float* shift, const float* res, const float* aux, float* y, const float* amax,
                             void* stream) {
   if (!d) return VUNET_ERR_ARG;
-  if (x6_wanted(d, wx != nullptr, aux != nullptr, res != nullptr, false)) {
+  if (x6_wanted(d, wx != nullptr, aux != nullptr, res != nullptr, false, amax != nullptr)) {
     if (!x1 || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
     return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, amax, 128, stream);
   }
@@ -137,7 +146,7 @@ extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const flo
 extern "C" int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
                                           const float* res, float* dx, const float* amax, void* stream) {
   if (!d || !dy || !y || !wx || !dx || d->mode != 1 || d->C2 != 0 || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
-  if (d->aux_act != ACT_NONE || d->aux_drop_p > 0.f || !x6_wanted(d, true, false, res != nullptr, true))
+  if (d->aux_act != ACT_NONE || d->aux_drop_p > 0.f || !x6_wanted(d, true, false, res != nullptr, true, amax != nullptr))
     return VUNET_ERR_UNSUPPORTED;
   return x6_launch(d, dy, nullptr, wx, nullptr, res, nullptr, y, dx, amax, 128, stream);
 }
@@ -146,11 +155,13 @@ extern "C" int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float*
 extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, int32_t has_wx, int32_t has_mask,
                                     char* name, int32_t len) {
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
-  if (x6_wanted(d, has_wx != 0, has_aux != 0, false, has_mask != 0)) {
+  if (x6_wanted(d, has_wx != 0, has_aux != 0, false, has_mask != 0, has_wx == 2)) {
     int MT;
     const int NT = x6_pick(d, &MT, 128, has_wx == 2);
     const char* fam = has_wx == 2 ? "conv_h2_kernel" : "conv_x6_kernel";
-    if (has_wx == 2) {
+    if (has_wx == 2 && d->Ws % 32) {
+      snprintf(name, len, "%s<%d, 1, %d, %d, -1, 4, 16>", fam, MT, d->mode, x6_prologue_code(d, has_mask != 0));
+    } else if (has_wx == 2) {
       if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4, 4>", fam, MT, NT);
       else snprintf(name, len, "%s<%d, %d, %d, %d, -1, 4>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     } else if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4>", fam, MT, NT);

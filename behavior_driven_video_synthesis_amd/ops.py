@@ -193,11 +193,11 @@ def _wants_split(desc, has_aux: bool, has_res: bool, has_mask: bool = False) -> 
     """Would vunet_conv2d route this problem to a split kernel (so that the h2 scheme owes it the |x| maxima)?"""
     key = (desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.m_off, desc.Mpad, desc.Ho, desc.Wo, desc.KH, desc.stride,
            desc.pad, desc.mode, desc.in_act, desc.drop_p > 0, desc.out_act, desc.d2s, desc.aux_act, desc.aux_drop_p > 0,
-           has_aux, has_res, has_mask)
+           has_aux, has_res, has_mask, _scheme())
     r = _wants_split_cache.get(key)
     if r is None:
         r = _wants_split_cache[key] = _lib.lib().vunet_conv2d_wants_split(ctypes.byref(desc), int(has_aux), int(has_res),
-                                                                          int(has_mask)) == 1
+                                                                          int(has_mask), _scheme()) == 1
     return r
 
 

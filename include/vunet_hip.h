@@ -91,7 +91,8 @@ int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char*
  * leading partial products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- csrc/conv_x6_kernel.h).  Same
  * operation, prologue / sources / epilogue and fp32 NCHW tensors as vunet_conv2d_gather; the dropped partial
  * products are below fp32 rounding, so results match the fp32-MFMA kernels to fp32 accuracy at 2.67x their MFMA roof.
- * Covers 3x3 / stride 1 / pad 1, C1 and C2 multiples of 16, M and m_off multiples of 32, Ws % 32 == 0, Hs % 4 == 0,
+ * Covers 3x3 / stride 1 / pad 1, C1 and C2 multiples of 16, M and m_off multiples of 32, Ws % 32 == 0, Hs % 4 == 0
+ * (the two-term fp16 form below also Ws % 16 == 0 with Hs % 8 == 0),
  * prologue none / ELU / ELU+dropout (mode 0), none (mode 1).
  *   wx   : split weight image written by vunet_weightnorm_fwd* (wx_f for mode 0, wx_d for mode 1);
  *   mask : mode 1 only, tensor shaped like x1 -- x1 is multiplied by [mask > 0] while staged (ReLU backward);
@@ -113,7 +114,8 @@ int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, 
 int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_mask);
 /* 1: vunet_conv2d (has_mask: vunet_conv2d_dgrad_relu_x6) given a split image runs a split kernel for this problem --
  * the caller of the fp16 scheme then owes it the |x| maxima (vunet_absmax_partials); 0: it will not look at amax */
-int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t has_mask);
+int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t has_mask, int32_t split);
+/* (split: vunet_wn_desc.split of the image the caller holds -- the fp16 scheme also covers 16-wide maps) */
 /* vunet_conv2d_dgrad_relu on the split kernels (wx = wx_d); VUNET_ERR_UNSUPPORTED -> use vunet_conv2d_dgrad_relu */
 int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
                                const float* res, float* dx, const float* amax, void* stream);

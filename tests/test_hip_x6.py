@@ -86,8 +86,13 @@ def _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_a
     if force_nt is not None:
         os.environ["VUNET_X6_FORCE_NT"] = str(force_nt)
     try:
+        if use_x6 and w % 32 and ops.conv_precision() != "h2":   # 16-pixel column tiles exist in the fp16 scheme only
+            rc = ops._lib.lib().vunet_conv2d_x6(ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift),
+                                                ops._p(res), None, None, ops._p(y), None, ops._stream())
+            assert rc == -3
+            pytest.skip("16-wide maps: fp16 scheme only (the bf16 kernel refuses them)")
         if use_x6:
-            assert ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
+            assert w % 32 != 0 or ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
             ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift),
                       ops._p(res), None, None, ops._p(y), _amax(ops, x1, x2), ops._stream())
         else:
@@ -120,6 +125,9 @@ FWD_CASES = [
     (1, 128, 0, 256, 8, 32, 0, 0.0, 0, False, True, 2),    # sub-pixel up-conv: depth-to-space store, 4 m-blocks
     (1, 48, 16, 96, 12, 32, 1, 0.0, 3, False, False, 1),   # ragged: 3 + 1 chunks, M = 96 (last m-block half empty), sigmoid
     (1, 256, 0, 128, 8, 32, 0, 0.0, 0, False, False, 2),   # long K loop (16 chunks)
+    (2, 64, 0, 64, 16, 16, 0, 0.0, 2, False, False, 1),    # 16-wide map (VGG19 conv5): two rows per column tile, fp16 scheme only
+    (1, 32, 32, 32, 8, 16, 1, 0.05, 0, True, False, 1),    # 16-wide, two sources, ELU + dropout, residual, MT 1
+    (3, 16, 0, 96, 24, 48, 1, 0.0, 0, True, False, 1),     # 48 wide: three 16-pixel column tiles per row pair
 ]
 
 
@@ -149,8 +157,9 @@ def test_x6_forward_vs_fp64_and_vs_fp32_mfma(case):
 
 @pytest.mark.parametrize("cout,cin,h,w,nt,masked", [(64, 64, 8, 32, 2, False), (32, 64, 16, 32, 4, False),
                                                      (128, 64, 8, 64, 2, True), (64, 32, 4, 32, 1, True),
-                                                     (256, 128, 8, 32, 2, True)])
-def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked):
+                                                     (256, 128, 8, 32, 2, True), (64, 64, 16, 16, 1, True),
+                                                     (32, 64, 8, 16, 1, False)])
+def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked, scheme):
     """mode 1: dx = conv_transpose(dy [* (y > 0)], w_eff) * act'(aux) + res, against autograd in fp64."""
     ops = _ops()
     n = 2
@@ -166,6 +175,8 @@ def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked):
                      stride=1, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
                      aux_act=0 if masked else ops.ACT_ELU, aux_slope=0.0, aux_drop_p=0.0, aux_drop_seed=0)
     dx = torch.empty(n, cin, h, w, device="cuda")
+    if w % 32 and scheme != "h2":
+        pytest.skip("16-wide maps: fp16 scheme only")
     os.environ["VUNET_X6_FORCE_NT"] = str(nt)
     try:
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux),
