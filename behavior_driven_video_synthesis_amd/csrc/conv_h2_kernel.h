@@ -323,7 +323,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   // lockstep, so their stores arrive in bursts the HBM write path drains at ~3 TB/s while the waves wait: on gfx9 stores
   // count in vmcnt, in order with the loads, so no later load (or LDS-DMA) can be awaited before the stores are
   // acknowledged.  Persistent workgroups that prefetch the next tile's first chunk across the epilogue were built and
-  // measured: no gain, for that reason (the first stage-end wait of the next tile still sits behind the stores).
+  // measured: no gain, for that reason (the first stage-end wait of the next tile still sits behind the stores).  Nor is
+  // it the lockstep alone: starting the first round of workgroups in eight phases spread over a tile period (later rounds
+  // inherit the offsets) changed nothing either (conv1_2 353 -> 363 us, the C = 32 layer 131 -> 138 us), and non-temporal
+  // stores are within noise.  The C = 32 layers at 256^2: 135 us as shipped, 87 us without the store, 66 us without
+  // store and staging -- the 134 MB output costs ~48 us = 2.8 TB/s wherever it is placed in time.
   // ---- epilogue (arithmetic shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The MT * NT
   // tiles are named at compile time (a runtime index would put the accumulators in scratch) and software-pipelined: the
   // residual / aux / shift loads of tile t+1 are issued before the stores of tile t (conv_common.h: load_tile_side).

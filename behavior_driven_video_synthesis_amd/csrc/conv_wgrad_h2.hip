@@ -55,7 +55,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradH2Args
   inact_resolve(a.in2);
   constexpr int TH = 4;
   // optional register prefetch of the next tile's f(x) across the MFMA block
+#ifdef WG_H2_PREFETCH
+  constexpr bool PREFETCH = true;
+#else
   constexpr bool PREFETCH = false;   // measured: no gain from the register prefetch (r02), and two m-tiles spill with it
+#endif
   constexpr int WP = 4 / MTW;        // waves sharing one m-tile (they split the tile rows)
   constexpr int RW = TH / WP;        // tile rows per wave
   constexpr int ENT = 6 * 32;        // (row, ci) entries of the staged tile
