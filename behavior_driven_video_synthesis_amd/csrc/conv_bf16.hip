@@ -218,6 +218,7 @@ extern "C" int vunet_conv2d_bf16(const vunet_conv_desc* d, const float* x1, cons
   if (!d || !x1 || !wb || !y || (d->C2 > 0 && !x2)) return VUNET_ERR_ARG;
   if (!vunet_conv2d_bf16_supported(d)) return VUNET_ERR_UNSUPPORTED;
   GatherArgs ga;
+  ga.wide = 0;
   ga.d = *d;
   ga.x1 = x1;
   ga.x2 = x2;

@@ -18,6 +18,9 @@ struct GatherArgs {
   // With ph/pw set, pixel indices enumerate the sub-grid (n, a, b) of outputs (s*a + ph, s*b + pw), NP counts
   // that sub-grid, and only the taps whose parity matches are visited -- no MFMA is spent on structural zeros.
   int ph, pw, subW, subHW;
+  // internal: y / res / aux are 16-byte aligned, no depth-to-space store, no output-parity phase: the split kernels may
+  // use the lane-transposed 16-byte epilogue (load_tile_side4 / store_tile_side4)
+  int wide;
   // internal: data gradient through a ReLU epilogue -- x1 (= dy) is multiplied by [mask > 0] while it is staged
   // (prologue code 4; mask = the forward output, shaped like x1).  nullptr: off.
   const float* mask;
@@ -147,6 +150,88 @@ __device__ __forceinline__ void store_tile_side(const GatherArgs& a, const PixGe
     }
     if (a.res) v += s.res[r];
     if (ok) a.y[o] = v;
+  }
+}
+
+// ---- the same epilogue with 16-byte accesses.  An accumulator tile has lane = pixel, register = channel, so a plain
+// store writes 4 bytes per lane: 64 store instructions per wave and tile pair, and the per-CU store path takes ~40 cycles
+// for each whatever its width (measured: the output store costs 15 - 36 % of the split kernels, tools/time_conv.py).
+// Each group of four lanes (four consecutive pixels) therefore TRANSPOSES its 4 pixels x 4 channels block through two
+// DPP exchanges (lane ^ 1, lane ^ 2), after which lane k of the group holds four consecutive pixels of channel
+// base + k: one global_store_dwordx4 (and one dwordx4 load of the residual / aux tensor) per four registers.
+//   k = lane & 3;  channels of register group q4 (registers 4 q4 .. 4 q4 + 3): m_tile0 + 8 q4 + 4 h + {0..3}
+// Not for the depth-to-space store or the output-parity phases (their pixels are not contiguous): GatherArgs::wide.
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+// in: lane k holds (r0..r3) = row k of a 4x4 block spread over four lanes; out: lane k holds column k
+__device__ __forceinline__ void quad_transpose(float& r0, float& r1, float& r2, float& r3, int k) {
+  const bool odd = k & 1, hi = k & 2;
+  const float g0 = dpp_xor1(odd ? r0 : r1), g1 = dpp_xor1(odd ? r2 : r3);
+  r0 = odd ? g0 : r0;
+  r1 = odd ? r1 : g0;
+  r2 = odd ? g1 : r2;
+  r3 = odd ? r3 : g1;
+  const float u0 = dpp_xor2(hi ? r0 : r2), u1 = dpp_xor2(hi ? r1 : r3);
+  r0 = hi ? u0 : r0;
+  r1 = hi ? u1 : r1;
+  r2 = hi ? r2 : u0;
+  r3 = hi ? r3 : u1;
+}
+
+struct TileSide4 {
+  float4 aux[4], res[4];
+  float sh[4];
+};
+
+// g: the pixel of THIS lane (as for store_tile_side); the group's four pixels start at g.ow - (lane & 3)
+template <int MODE>
+__device__ __forceinline__ void load_tile_side4(const GatherArgs& a, const PixGeo& g, int m_tile0, int h, int k, TileSide4& s) {
+  const vunet_conv_desc& d = a.d;
+  const size_t pix0 = (size_t)g.oh * d.Wo + (g.ow - k);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const int ch = m_tile0 + 8 * q4 + 4 * h + k;
+    const bool ok = ch < d.M;
+    const size_t o = ok ? (size_t)(g.n * d.M + ch) * a.HoWo + pix0 : 0;
+    if (MODE == 1 && a.aux) s.aux[q4] = *reinterpret_cast<const float4*>(a.aux + o);
+    if (a.res) s.res[q4] = *reinterpret_cast<const float4*>(a.res + o);
+    if (MODE == 0 && a.shift) s.sh[q4] = a.shift[ok ? ch : 0];
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_tile_side4(const GatherArgs& a, const PixGeo& g, int m_tile0, int h, int k, f32x16 acc,
+                                                 const TileSide4& s) {
+  const vunet_conv_desc& d = a.d;
+  const size_t pix0 = (size_t)g.oh * d.Wo + (g.ow - k);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    float v[4] = {acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+    quad_transpose(v[0], v[1], v[2], v[3], k);
+    const int ch = m_tile0 + 8 * q4 + 4 * h + k;
+    const size_t o = (size_t)(g.n * d.M + ch) * a.HoWo + pix0;
+    const float auxv[4] = {s.aux[q4].x, s.aux[q4].y, s.aux[q4].z, s.aux[q4].w};
+    const float resv[4] = {s.res[q4].x, s.res[q4].y, s.res[q4].z, s.res[q4].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[e];
+      if (MODE == 0) {
+        if (a.shift) t += s.sh[q4];
+        if (d.out_act == ACT_RELU) t = t > 0.f ? t : 0.f;
+        else if (d.out_act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+        else if (d.out_act == ACT_ELU) t = elu_f(t);
+        else if (d.out_act == ACT_LRELU) t = t > 0.f ? t : t * d.in_slope;
+      } else if (a.aux) {
+        t *= in_act_grad(a.auxa, auxv[e], (uint32_t)(o + e));
+      }
+      if (a.res) t += resv[e];
+      v[e] = t;
+    }
+    if (ch < d.M) *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 

@@ -420,6 +420,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
   if (in_elems >= (1ll << 31) || out_elems >= (1ll << 31)) return VUNET_ERR_UNSUPPORTED;
 
   GatherArgs ga;
+  ga.wide = 0;
   ga.d = *d;
   ga.x1 = x1; ga.x2 = x2; ga.wt = wt; ga.shift = shift; ga.res = res; ga.aux = aux; ga.y = y;
   ga.NP = d->N * d->Ho * d->Wo;
@@ -470,6 +471,7 @@ extern "C" int vunet_conv2d_dgrad_relu(const vunet_conv_desc* d, const float* dy
       vunet_conv_thin_kind(d, 0, false, res != nullptr) != 0)   // 3-channel side: the two-pass route ends in the VALU kernel
     return VUNET_ERR_UNSUPPORTED;
   GatherArgs ga;
+  ga.wide = 0;
   ga.d = *d;
   ga.x1 = dy; ga.x2 = nullptr; ga.wt = wt; ga.shift = nullptr; ga.res = res; ga.aux = nullptr; ga.y = dx;
   ga.NP = d->N * d->Ho * d->Wo;

@@ -340,18 +340,40 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
     g.valid = true;
     return g;
   };
+  auto combined = [&](auto tc) {
+    constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale;
+    return c;
+  };
+  if (PHW < 0 && a.wide) {   // 16-byte epilogue: four lanes transpose their 4 pixels x 4 channels blocks (conv_common.h)
+    const int k = lane & 3;
+    TileSide4 side[2];
+    load_tile_side4<MODE>(a, geo(0), m0, h, k, side[0]);
+    auto tile = [&](auto tc) {
+      constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
+      if constexpr (t + 1 < MT * NT)
+        load_tile_side4<MODE>(a, geo((t + 1) / MT), m0 + 32 * ((t + 1) % MT), h, k, side[(t + 1) & 1]);
+#ifdef H2_ABL_NOSTORE   // timing ablation (tools/ab_build.sh): the output is not written
+      if (descale == 12345.f)
+#endif
+      store_tile_side4<MODE>(a, geo(q), m0 + 32 * mt, h, k, combined(tc), side[t & 1]);
+    };
+    tile(std::integral_constant<int, 0>{});
+    if constexpr (MT * NT > 1) tile(std::integral_constant<int, 1>{});
+    if constexpr (MT * NT > 2) {
+      tile(std::integral_constant<int, 2>{});
+      tile(std::integral_constant<int, 3>{});
+    }
+    return;
+  }
   TileSide side[2];
   load_tile_side(a, geo(0), m0, h, side[0]);
   auto tile = [&](auto tc) {
     constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
     if constexpr (t + 1 < MT * NT) load_tile_side(a, geo((t + 1) / MT), m0 + 32 * ((t + 1) % MT), h, side[(t + 1) & 1]);
-    f32x16 c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale;
-#ifdef H2_ABL_NOSTORE   // timing ablation (tools/ab_build.sh): the output is not written
-    if (descale == 12345.f)
-#endif
-    store_tile_side(a, geo(q), m0 + 32 * mt, h, c, side[t & 1]);
+    store_tile_side(a, geo(q), m0 + 32 * mt, h, combined(tc), side[t & 1]);
   };
   tile(std::integral_constant<int, 0>{});
   if constexpr (MT * NT > 1) tile(std::integral_constant<int, 1>{});

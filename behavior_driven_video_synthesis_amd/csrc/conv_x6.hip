@@ -82,6 +82,8 @@ static void fill_args(GatherArgs& ga, const vunet_conv_desc* d, const float* x1,
   ga.ph = ga.pw = -1;
   ga.subW = ga.subHW = 0;
   ga.mask = mask;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(aux);
+  ga.wide = (al & 15) == 0 && !d->d2s && d->stride == 1 && d->Wo % 4 == 0;
 }
 
 static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
