@@ -318,16 +318,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   for (int ch = 0; ch + 1 < nch; ++ch) chunk(ch, std::false_type{});
   chunk(nch - 1, std::true_type{});
 
-  // What the output store costs (r02, tools/time_conv.py with -DH2_ABL_NOSTORE): every layer runs at ~305 TFLOP/s without it
-  // whatever its K; with it the short-K layers pay 15 % (C = 128) to 24 % (C = 64).  The workgroups of a launch run in
-  // lockstep, so their stores arrive in bursts the HBM write path drains at ~3 TB/s while the waves wait: on gfx9 stores
-  // count in vmcnt, in order with the loads, so no later load (or LDS-DMA) can be awaited before the stores are
-  // acknowledged.  Persistent workgroups that prefetch the next tile's first chunk across the epilogue were built and
-  // measured: no gain, for that reason (the first stage-end wait of the next tile still sits behind the stores).  Nor is
-  // it the lockstep alone: starting the first round of workgroups in eight phases spread over a tile period (later rounds
-  // inherit the offsets) changed nothing either (conv1_2 353 -> 363 us, the C = 32 layer 131 -> 138 us), and non-temporal
-  // stores are within noise.  The C = 32 layers at 256^2: 135 us as shipped, 87 us without the store, 66 us without
-  // store and staging -- the 134 MB output costs ~48 us = 2.8 TB/s wherever it is placed in time.
+  // What the output store costs (r02, tools/time_conv.py with -DH2_ABL_NOSTORE): without it every layer runs at ~305
+  // TFLOP/s whatever its K; with 4-byte stores (lane = pixel, one store instruction per accumulator register) the
+  // short-K layers paid 15 % (C = 128) to 36 % (C = 32 at 256^2: 135 us, 87 us without the store) -- ~2.8 TB/s of output
+  // wherever the stores were placed in time.  It is the per-CU memory path, ~40 cycles per store INSTRUCTION whatever
+  // its width: an address pattern of 16-byte stores (same bytes, a quarter of the instructions) recovered half of it, so
+  // the epilogue now transposes 4 pixels x 4 channels blocks across lane quads and stores dwordx4 (conv_common.h:
+  // store_tile_side4; conv2_2 281 -> 270 us, conv1_2 353 -> 335, the 64-channel RNB conv 82 -> 74, C = 32 131 -> 121).
+  // Measured and discarded on the way (no gain): persistent workgroups prefetching the next tile's first chunk across
+  // the epilogue; 512-thread workgroups with whole-chunk weight stages; starting the first round of workgroups in eight
+  // phases spread over a tile period; non-temporal stores.
   // ---- epilogue (arithmetic shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The MT * NT
   // tiles are named at compile time (a runtime index would put the accumulators in scratch) and software-pipelined: the
   // residual / aux / shift loads of tile t+1 are issued before the stores of tile t (conv_common.h: load_tile_side).
