@@ -164,8 +164,8 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
     if (has_wx == 2 && d->Ws % 32) {
       snprintf(name, len, "%s<%d, 1, %d, %d, -1, 4, 16>", fam, MT, d->mode, x6_prologue_code(d, has_mask != 0));
     } else if (has_wx == 2) {
-      if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4, 4>", fam, MT, NT);
-      else snprintf(name, len, "%s<%d, %d, %d, %d, -1, 4>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
+      if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4, 4, 32>", fam, MT, NT);
+      else snprintf(name, len, "%s<%d, %d, %d, %d, -1, 4, 32>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     } else if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4>", fam, MT, NT);
     else snprintf(name, len, "%s<%d, %d, %d, %d, -1>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     return VUNET_OK;
