@@ -21,6 +21,9 @@ struct GatherArgs {
   // internal: y / res / aux are 16-byte aligned, no depth-to-space store, no output-parity phase: the split kernels may
   // use the lane-transposed 16-byte epilogue (load_tile_side4 / store_tile_side4)
   int wide;
+  // optional (split-fp16 kernel): 512 zero-initialised floats that receive partial maxima of |y| (atomic max on the bit
+  // patterns: |y| >= 0), so that the consumer of y needs no pass of its own over it (vunet_absmax_partials).  nullptr: off.
+  float* amax_out;
   // internal: data gradient through a ReLU epilogue -- x1 (= dy) is multiplied by [mask > 0] while it is staged
   // (prologue code 4; mask = the forward output, shaped like x1).  nullptr: off.
   const float* mask;
@@ -118,16 +121,18 @@ __device__ __forceinline__ void load_tile_side(const GatherArgs& a, const PixGeo
   }
 }
 
-__device__ __forceinline__ void store_tile_side(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
-                                                const f32x16& acc, const TileSide& s) {
+// -> max |stored value| of this lane (0 for the sub-pixel store: the callers do not publish maxima for it)
+__device__ __forceinline__ float store_tile_side(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
+                                                 const f32x16& acc, const TileSide& s) {
   const vunet_conv_desc& d = a.d;
+  float vmax = 0.f;
   if (d.d2s) {  // sub-pixel store: rare (up-convs), scattered addresses
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m_tile0 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (g.valid && m < d.M) store_out(a, g, m, acc[r]);
     }
-    return;
+    return vmax;
   }
   const int mb = m_tile0 + 4 * h;
   const int pix = g.oh * d.Wo + g.ow;
@@ -149,8 +154,12 @@ __device__ __forceinline__ void store_tile_side(const GatherArgs& a, const PixGe
       v *= in_act_grad(a.auxa, s.aux[r], (uint32_t)o);
     }
     if (a.res) v += s.res[r];
-    if (ok) a.y[o] = v;
+    if (ok) {
+      a.y[o] = v;
+      vmax = fmaxf(vmax, fabsf(v));
+    }
   }
+  return vmax;
 }
 
 // ---- the same epilogue with 16-byte accesses.  An accumulator tile has lane = pixel, register = channel, so a plain
@@ -204,8 +213,9 @@ __device__ __forceinline__ void load_tile_side4(const GatherArgs& a, const PixGe
 }
 
 template <int MODE>
-__device__ __forceinline__ void store_tile_side4(const GatherArgs& a, const PixGeo& g, int m_tile0, int h, int k, f32x16 acc,
-                                                 const TileSide4& s) {
+__device__ __forceinline__ float store_tile_side4(const GatherArgs& a, const PixGeo& g, int m_tile0, int h, int k, f32x16 acc,
+                                                  const TileSide4& s) {   // -> max |stored value| of this lane
+  float vmax = 0.f;
   const vunet_conv_desc& d = a.d;
   const size_t pix0 = (size_t)g.oh * d.Wo + (g.ow - k);
 #pragma unroll
@@ -231,8 +241,12 @@ __device__ __forceinline__ void store_tile_side4(const GatherArgs& a, const PixG
       if (a.res) t += resv[e];
       v[e] = t;
     }
-    if (ch < d.M) *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+    if (ch < d.M) {
+      *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
   }
+  return vmax;
 }
 
 __device__ __forceinline__ void store_tile16(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,

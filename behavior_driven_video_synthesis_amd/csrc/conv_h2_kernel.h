@@ -347,6 +347,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
     for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale;
     return c;
   };
+  float ymax = 0.f;   // max |y| over what this lane stores (published below if the caller asked for it)
+  auto publish = [&]() {
+    if (a.amax_out) {
+      const float m_ = wave_max(ymax);
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(a.amax_out) + ((blockIdx.x * 4u + wave) & 511u), __float_as_uint(m_));
+    }
+  };
   if (PHW < 0 && a.wide) {   // 16-byte epilogue: four lanes transpose their 4 pixels x 4 channels blocks (conv_common.h)
     const int k = lane & 3;
     TileSide4 side[2];
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
 #ifdef H2_ABL_NOSTORE   // timing ablation (tools/ab_build.sh): the output is not written
       if (descale == 12345.f)
 #endif
-      store_tile_side4<MODE>(a, geo(q), m0 + 32 * mt, h, k, combined(tc), side[t & 1]);
+      ymax = fmaxf(ymax, store_tile_side4<MODE>(a, geo(q), m0 + 32 * mt, h, k, combined(tc), side[t & 1]));
     };
     tile(std::integral_constant<int, 0>{});
     if constexpr (MT * NT > 1) tile(std::integral_constant<int, 1>{});
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
       tile(std::integral_constant<int, 2>{});
       tile(std::integral_constant<int, 3>{});
     }
+    publish();
     return;
   }
   TileSide side[2];
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   auto tile = [&](auto tc) {
     constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
     if constexpr (t + 1 < MT * NT) load_tile_side(a, geo((t + 1) / MT), m0 + 32 * ((t + 1) % MT), h, side[(t + 1) & 1]);
-    store_tile_side(a, geo(q), m0 + 32 * mt, h, combined(tc), side[t & 1]);
+    ymax = fmaxf(ymax, store_tile_side(a, geo(q), m0 + 32 * mt, h, combined(tc), side[t & 1]));
   };
   tile(std::integral_constant<int, 0>{});
   if constexpr (MT * NT > 1) tile(std::integral_constant<int, 1>{});
@@ -381,6 +389,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
     tile(std::integral_constant<int, 2>{});
     tile(std::integral_constant<int, 3>{});
   }
+  publish();
 }
 
 template <int MT, int NT, int MODE, int PRO, int PHW, int NWV, int TW = 32>

@@ -84,11 +84,12 @@ static void fill_args(GatherArgs& ga, const vunet_conv_desc* d, const float* x1,
   ga.mask = mask;
   const uintptr_t al = reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(aux);
   ga.wide = (al & 15) == 0 && !d->d2s && d->stride == 1 && d->Wo % 4 == 0;
+  ga.amax_out = nullptr;
 }
 
 static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
-                     const float* res, const float* aux, const float* mask, float* y, const float* amax, long min_blocks,
-                     void* stream) {
+                     const float* res, const float* aux, const float* mask, float* y, const float* amax, float* amax_out,
+                     long min_blocks, void* stream) {
   const int pro = x6_prologue_code(d, mask != nullptr);
   if (!x6_geometry_ok(d, pro, amax != nullptr)) return VUNET_ERR_UNSUPPORTED;
   int MT;
@@ -96,6 +97,7 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
   if (NT == 0) return VUNET_ERR_UNSUPPORTED;
   GatherArgs ga;
   fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
+  if (amax && !d->d2s) ga.amax_out = amax_out;   // only the fp16 kernels publish |y| maxima (not through the sub-pixel store)
   // K dimension of the image = the gathered tensor's channels; M dimension = all columns of the weight matrix
   const int mtp = vunet_x6_mtiles(d->Mpad);
   if (amax && d->Ws % 32) return vunet_conv_h2_launch_w16(ga, wx, mtp, amax, pro, MT, (hipStream_t)stream);
@@ -127,30 +129,30 @@ extern "C" int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_au
 
 extern "C" int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx,
                                const float* shift, const float* res, const float* aux, const float* mask, float* y,
-                               const float* amax, void* stream) {
+                               const float* amax, float* amax_out, void* stream) {
   if (!d || !x1 || !wx || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
   if (mask && (d->mode != 1 || d->C2 != 0)) return VUNET_ERR_ARG;
   if (d->d2s && (d->M % 4 != 0 || d->mode != 0)) return VUNET_ERR_ARG;
-  return x6_launch(d, x1, x2, wx, shift, res, aux, mask, y, amax, 1, stream);
+  return x6_launch(d, x1, x2, wx, shift, res, aux, mask, y, amax, amax_out, 1, stream);
 }
 
 extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
                             const float* shift, const float* res, const float* aux, float* y, const float* amax,
-                            void* stream) {
+                            float* amax_out, void* stream) {
   if (!d) return VUNET_ERR_ARG;
   if (x6_wanted(d, wx != nullptr, aux != nullptr, res != nullptr, false, amax != nullptr)) {
     if (!x1 || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
-    return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, amax, 128, stream);
+    return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, amax, amax_out, 128, stream);
   }
   return vunet_conv2d_gather(d, x1, x2, wt, shift, res, aux, y, stream);
 }
 
 extern "C" int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
-                                          const float* res, float* dx, const float* amax, void* stream) {
+                                          const float* res, float* dx, const float* amax, float* amax_out, void* stream) {
   if (!d || !dy || !y || !wx || !dx || d->mode != 1 || d->C2 != 0 || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
   if (d->aux_act != ACT_NONE || d->aux_drop_p > 0.f || !x6_wanted(d, true, false, res != nullptr, true, amax != nullptr))
     return VUNET_ERR_UNSUPPORTED;
-  return x6_launch(d, dy, nullptr, wx, nullptr, res, nullptr, y, dx, amax, 128, stream);
+  return x6_launch(d, dy, nullptr, wx, nullptr, res, nullptr, y, dx, amax, amax_out, 128, stream);
 }
 
 // Name (rocprofv3 spelling) of the kernel vunet_conv2d / vunet_conv2d_dgrad_relu_x6 launches for this problem.

@@ -185,6 +185,45 @@ def absmax_partials(x1, x2=None):
     return out
 
 
+# ---- |y| maxima published by the producer.  The fp16 split kernels can leave the partial maxima of what they store in a
+# caller-provided buffer (vunet_conv2d: amax_out); the tensor is then TAGGED with that buffer (and its version counter:
+# an in-place change invalidates the tag) and a later convolution that reads it alone skips its own pass over it.
+# Max-pool passes the tag on (|max-pool(x)| <= max|x|, in both directions).  Buffers come from a per-stream arena that is
+# zeroed once per training step (ops.prepacked) -- one memset instead of one per convolution.
+_amax_arena = {}
+
+
+def _new_amax_out(dev):
+    key = _raw_stream(torch.cuda.current_device()) if _raw_stream is not None else 0
+    a = _amax_arena.get(key)
+    if a is None or a[1] >= a[0].shape[0]:
+        a = _amax_arena[key] = [torch.zeros(128, 1024, device=dev, dtype=torch.float32), 0]
+    a[1] += 1
+    return a[0][a[1] - 1]
+
+
+def _reset_amax_arena():
+    _amax_arena.clear()   # the slices handed out keep their arenas alive for as long as they are referenced
+
+
+def _tag_amax(t, buf):
+    t._vunet_amax = (buf, t._version)
+
+
+def _tagged_amax(t):
+    rec = getattr(t, "_vunet_amax", None)
+    return rec[0] if rec is not None and rec[1] == t._version else None
+
+
+def _amax_for(x1, x2=None):
+    """The |x| partial maxima of a convolution's input: the producer's tag if x1 is the only source and carries one."""
+    if x2 is None:
+        tagged = _tagged_amax(x1)
+        if tagged is not None:
+            return tagged
+    return absmax_partials(x1, x2)
+
+
 _wants_split_cache = {}
 
 
@@ -294,15 +333,20 @@ class _Timed:
 
 
 def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=None):
-    """``amax``: the |x| partial maxima if the caller already has them (h2 scheme), else computed here when needed.
-    Returns the maxima the launch used (None if it did not need any)."""
+    """``amax``: the |x| partial maxima if the caller already has them (h2 scheme), else taken from the producer's tag or
+    computed here when needed.  Returns the maxima the launch used (None if it did not need any).  When the fp16 kernel
+    runs (and does not store through depth-to-space) y is tagged with the maxima of what it wrote."""
     t = desc.KH * desc.KW
     scheme = _scheme() if wx is not None else 0
+    amax_out = None
     if scheme == 2:
         if not _wants_split(desc, aux is not None, res is not None):
             wx = amax = None
-        elif amax is None:
-            amax = absmax_partials(x1, x2)
+        else:
+            if amax is None:
+                amax = _amax_for(x1, x2)
+            if not desc.d2s:
+                amax_out = _new_amax_out(y.device)
     else:
         amax = None
     if desc.mode == 0:
@@ -317,7 +361,9 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=N
     with _Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act, kname),
                 flop):
         _call("vunet_conv2d", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), _p(aux), _p(y),
-              _p(amax), _stream())
+              _p(amax), _p(amax_out), _stream())
+    if amax_out is not None:
+        _tag_amax(y, amax_out)
     return amax
 
 
@@ -632,6 +678,7 @@ class prepacked:
         self.model = model
 
     def __enter__(self):
+        _reset_amax_arena()
         cur = _build_prepack_set(self.model)
         if cur is not None:
             _call("vunet_weightnorm_fwd_multi", _p(cur["table"]), cur["n"], cur["max_cout"], _stream())
@@ -749,10 +796,13 @@ class FusedConv(torch.autograd.Function):
                         2.0 * n * ho * wo * cout * c1 * k * k):
                 rc = -3
                 if wx_d is not None and _wants_split(d, False, cfg.res_is_x1, True):
-                    amax = absmax_partials(dy) if _scheme() == 2 else None
+                    amax = _amax_for(dy) if _scheme() == 2 else None
+                    amax_out = _new_amax_out(dx.device) if _scheme() == 2 else None
                     rc = _lib.lib().vunet_conv2d_dgrad_relu_x6(ctypes.byref(d), _p(dy), _p(y), _p(wx_d),
                                                                _p(dy if cfg.res_is_x1 else None), _p(dx), _p(amax),
-                                                               _stream())
+                                                               _p(amax_out), _stream())
+                    if rc == 0 and amax_out is not None:
+                        _tag_amax(dx, amax_out)
                 if rc == -3:
                     rc = _lib.lib().vunet_conv2d_dgrad_relu(ctypes.byref(d), _p(dy), _p(y), _p(wt_d),
                                                             _p(dy if cfg.res_is_x1 else None), _p(dx), _stream())
@@ -775,7 +825,7 @@ class FusedConv(torch.autograd.Function):
 
         def get_dy_amax():
             if not dy_amax:
-                dy_amax.append(absmax_partials(dconv))
+                dy_amax.append(_amax_for(dconv))
             return dy_amax[0]
 
         wd = WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=cfg.stride,
@@ -1067,6 +1117,9 @@ class MaxPool2(torch.autograd.Function):
         y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=x.dtype)
         _call("vunet_maxpool2_fwd", _p(x), _p(y), n * c, h, w, _stream())
         ctx.save_for_backward(x, y)
+        tag = _tagged_amax(x)
+        if tag is not None:
+            _tag_amax(y, tag)   # |max-pool(x)| <= max|x|
         return y
 
     @staticmethod
@@ -1076,6 +1129,9 @@ class MaxPool2(torch.autograd.Function):
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
         _call("vunet_maxpool2_bwd", _p(x), _p(y), _p(dy), _p(dx), n * c, h, w, _stream())
+        tag = _tagged_amax(dy)
+        if tag is not None:
+            _tag_amax(dx, tag)  # the gradient is routed, not scaled
         return dx
 
 

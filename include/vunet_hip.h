@@ -106,11 +106,16 @@ int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char*
  * terms, three partial products, fp32 accumulate; as accurate as x6 wherever |x| >= 2^-28 of its tensor's maximum.
  *   amax : NULL -> wx is a three-term bf16 image (vunet_wn_desc.split 0/1);  non-NULL -> wx is a two-term fp16 image
  *          (split 2) and amax holds the 1024 partial maxima of |x1|, |x2| written by vunet_absmax_partials.
+ *   amax_out : optional, >= 512 floats ZEROED by the caller: when the two-term fp16 kernel runs (amax != NULL,
+ *          vunet_conv2d_wants_split, no depth-to-space store) its epilogue leaves partial maxima of |y| there -- the
+ *          `amax` of the next convolution that reads y alone (slots 512..1023 of that argument must then be zeros).
  * ------------------------------------------------------------------------------------------ */
 int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
-                 const float* shift, const float* res, const float* aux, float* y, const float* amax, void* stream);
+                 const float* shift, const float* res, const float* aux, float* y, const float* amax, float* amax_out,
+                 void* stream);
 int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
-                    const float* res, const float* aux, const float* mask, float* y, const float* amax, void* stream);
+                    const float* res, const float* aux, const float* mask, float* y, const float* amax, float* amax_out,
+                    void* stream);
 int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_mask);
 /* 1: vunet_conv2d (has_mask: vunet_conv2d_dgrad_relu_x6) given a split image runs a split kernel for this problem --
  * the caller of the fp16 scheme then owes it the |x| maxima (vunet_absmax_partials); 0: it will not look at amax */
@@ -118,7 +123,7 @@ int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t 
 /* (split: vunet_wn_desc.split of the image the caller holds -- the fp16 scheme also covers 16-wide maps) */
 /* vunet_conv2d_dgrad_relu on the split kernels (wx = wx_d); VUNET_ERR_UNSUPPORTED -> use vunet_conv2d_dgrad_relu */
 int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
-                               const float* res, float* dx, const float* amax, void* stream);
+                               const float* res, float* dx, const float* amax, float* amax_out, void* stream);
 /* out[0..511] / out[512..1023]: partial maxima of |x1| / |x2| (x2 may be NULL: zeros); one launch, no atomics */
 int vunet_absmax_partials(const float* x1, int64_t n1, const float* x2, int64_t n2, float* out, void* stream);
 /* kernel name vunet_conv2d (has_mask: vunet_conv2d_dgrad_relu_x6) selects, rocprofv3 spelling */

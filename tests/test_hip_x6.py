@@ -88,13 +88,13 @@ def _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_a
     try:
         if use_x6 and w % 32 and ops.conv_precision() != "h2":   # 16-pixel column tiles exist in the fp16 scheme only
             rc = ops._lib.lib().vunet_conv2d_x6(ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift),
-                                                ops._p(res), None, None, ops._p(y), None, ops._stream())
+                                                ops._p(res), None, None, ops._p(y), None, None, ops._stream())
             assert rc == -3
             pytest.skip("16-wide maps: fp16 scheme only (the bf16 kernel refuses them)")
         if use_x6:
             assert w % 32 != 0 or ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
             ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift),
-                      ops._p(res), None, None, ops._p(y), _amax(ops, x1, x2), ops._stream())
+                      ops._p(res), None, None, ops._p(y), _amax(ops, x1, x2), None, ops._stream())
         else:
             ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wt_f), ops._p(shift),
                       ops._p(res), None, ops._p(y), ops._stream())
@@ -180,7 +180,7 @@ def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked, scheme):
     os.environ["VUNET_X6_FORCE_NT"] = str(nt)
     try:
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux),
-                  ops._p(yfwd) if masked else None, ops._p(dx), _amax(ops, dy), ops._stream())
+                  ops._p(yfwd) if masked else None, ops._p(dx), _amax(ops, dy), None, ops._stream())
     finally:
         os.environ.pop("VUNET_X6_FORCE_NT", None)
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
@@ -208,7 +208,7 @@ def test_x6_second_source_gradient_uses_column_offset():
                      stride=1, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
     dx = torch.empty(n, c2, h, w, device="cuda")
     ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, None, None, None, ops._p(dx),
-              _amax(ops, dy), ops._stream())
+              _amax(ops, dy), None, ops._stream())
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
     ref = F.conv_transpose2d(dy.double().cpu(), wd[:, c1:], padding=1)
     assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0), name="dx2")
@@ -231,7 +231,7 @@ def test_x6_unsupported_geometries_are_refused_not_miscomputed():
     y = torch.empty(1, 32, 8, 32, device="cuda")
     wx = torch.zeros(1024, device="cuda", dtype=torch.int32)
     rc = lib.vunet_conv2d_x6(ctypes.byref(desc(C1=24)), ops._p(x), None, ops._p(wx), None, None, None, None, ops._p(y),
-                             _amax(ops, x), ops._stream())
+                             _amax(ops, x), None, ops._stream())
     assert rc == -3   # VUNET_ERR_UNSUPPORTED
 
 
@@ -364,7 +364,7 @@ def test_x6_stride2_data_gradient_vs_fp64(cout, cin, h, w, nt, with_aux):
     os.environ["VUNET_X6_FORCE_NT"] = str(nt)
     try:
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
-                  ops._p(dx), _amax(ops, dy), ops._stream())
+                  ops._p(dx), _amax(ops, dy), None, ops._stream())
     finally:
         os.environ.pop("VUNET_X6_FORCE_NT", None)
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)

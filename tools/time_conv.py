@@ -60,7 +60,7 @@ for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
 
         def launch():
             ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x), None, ops._p(wx), None, None, None, ops._p(m), ops._p(y),
-                      ops._p(amax), ops._stream())
+                      ops._p(amax), None, ops._stream())
         for _ in range(3):
             launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -35,7 +35,7 @@ def run(x, v, mode, nt):
     if mode != "f32":
         amax = ops.absmax_partials(x) if mode == "h2" else None
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x), None, ops._p(wx_f), None, None, None, None, ops._p(y),
-                  ops._p(amax), ops._stream())
+                  ops._p(amax), None, ops._stream())
     else:
         ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(x), None, ops._p(wt_f), None, None, None, ops._p(y),
                   ops._stream())
