@@ -361,7 +361,10 @@ static void x6_geometry(const vunet_wgrad_desc* d, int& MTW, int& ntiles, int& c
 int vunet_wgrad_x6_nslabs(const vunet_wgrad_desc* d) {
   int MTW, ntiles, ciblocks, coblocks;
   x6_geometry(d, MTW, ntiles, ciblocks, coblocks);
-  int S = 1024 / (ciblocks * coblocks);  // ~4 workgroups per CU over the whole grid (2 resident)
+  // 512 workgroups = exactly the two resident per CU, one round: measured best with the fp16 kernel (r02: 1024 -> 512:
+  // conv_wgrad_h2_kernel<2> 2.08 -> 1.87 ms per step, half the slab volume for the reduce; 768 and 256 are worse)
+  static const int target = [] { const char* e = getenv("VUNET_WGRAD_SPLIT_WGS"); return e ? atoi(e) : 512; }();   // tuning
+  int S = target / (ciblocks * coblocks);
   if (S > ntiles / 2) S = ntiles / 2;
   if (S < 1) S = 1;
   if (S > 512) S = 512;
