@@ -1,14 +1,18 @@
-"""-m gpu: the fp32-accurate split-bf16 convolution kernels (csrc/conv_x6_kernel.h) against an fp64 convolution.
+"""-m gpu: the fp32-accurate split convolution kernels against an fp64 convolution, every case on BOTH schemes:
 
-The claim under test: splitting both fp32 operands exactly into three bf16 terms and accumulating the six leading
-partial products in fp32 on the bf16 matrix cores gives fp32-LEVEL accuracy (the dropped products are below 2^-24 of
-the result; what remains is accumulation rounding).  Measured on MI355X (tools/x6_accuracy.py, gpurun_out ->
-profiles/r02_x6_accuracy.txt): rms error 0.7e-7 .. 2.3e-7 of the output scale for K = 576 .. 4608, i.e. 2.5 - 3.5x
-the fp32-MFMA kernel's fmaf chain (six accumulator roundings per 16-channel step instead of one per channel pair, and
-the bf16 matrix core's own fp32 accumulation is ~1.5x noisier than the fmaf chain even on bf16-exact operands), and
-more than 400x below the 1e-4 parity tolerance.  So every case is compared (i) with an fp64 reference at a bound of
-3e-6 of the output scale -- 30x tighter than the tolerance the fp32-MFMA kernels are held to -- and (ii) with the
-fp32-MFMA kernel's own error on the same problem (never worse than 5x that error plus the rounding floor).
+  h2  two scaled fp16 terms / three partial products, csrc/conv_h2_kernel.h + conv_wgrad_h2.hip  (the default)
+  x6  three bf16 terms / six partial products,        csrc/conv_x6_kernel.h + conv_wgrad_x6.hip
+
+The claim under test: splitting both fp32 operands into 16-bit terms whose partial products are exact in fp32 and
+accumulating them in fp32 on the matrix cores gives fp32-LEVEL accuracy (what is dropped is <= 2^-22 / 2^-24 of the
+result; what remains is accumulation rounding).  Measured on MI355X (tools/x6_accuracy.py ->
+profiles/r02_split_accuracy.txt): rms error of h2 2.4e-8 .. 9.4e-8, of x6 3.6e-8 .. 2.3e-7 of the output scale for
+K = 144 .. 4608 (the fp32-MFMA kernel's fmaf chain: 2.7e-8 .. 6.8e-8), more than 100x below the 1e-4 parity tolerance.
+So every case is compared (i) with an fp64 reference at a bound of 3e-6 of the output scale -- 30x tighter than the
+tolerance the fp32-MFMA kernels are held to -- and (ii) with the fp32-MFMA kernel's own error on the same problem (never
+worse than 5x that error plus the rounding floor).  The fp16 scheme's data-dependent pieces (|x| maxima, their
+producer-side tags, the weight image's scale exponent, inputs spanning 2^-23 in magnitude, 16-wide maps) have their own
+cases below.
 """
 import ctypes
 import os
@@ -415,3 +419,40 @@ def test_absmax_partials_and_the_h2_weight_image(scheme):
         want = float(w_eff[co, ci, kh, kw])
         assert abs(got - want) <= 2.0 ** -21 * abs(want) + 1e-12, (co, ci, kh, kw, got, want)
     assert float(img[:, :, 2:].abs().max()) == 0.0     # the padding m-tiles are zeros
+
+
+def test_producer_maxima_tag_equals_a_pass_over_the_tensor(scheme):
+    """The h2 kernel's epilogue publishes max|y| of what it stores (vunet_conv2d: amax_out) and ops tags y with it: the
+    tag must equal what vunet_absmax_partials finds in y (forward with residual, data gradient with act' and residual,
+    through max-pool), a single-source consumer must use it (no absmax launch), and an in-place change must void it."""
+    if scheme != "h2":
+        pytest.skip("fp16 scheme only")
+    ops = _ops()
+    from behavior_driven_video_synthesis_amd.lib.modules import NormConv2d
+    torch.manual_seed(11)
+    conv1 = NormConv2d(64, 64, 3, padding=1).cuda()
+    conv2 = NormConv2d(64, 64, 3, padding=1).cuda()
+    x = (torch.randn(8, 64, 64, 64, device="cuda") * 3.0).requires_grad_(True)
+    y = conv1(x)
+    tag = ops._tagged_amax(y)
+    assert tag is not None and float(tag.max()) == float(y.detach().abs().max()) and float(tag[512:].max()) == 0.0
+    p = ops.MaxPool2.apply(y)
+    assert ops._tagged_amax(p) is tag                                   # a bound for the pooled tensor, passed on
+    calls = []
+    orig = ops.absmax_partials
+    ops.absmax_partials = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        z = conv2(y)                                                     # single tagged source: no pass of its own
+        assert not calls
+        z.square().mean().backward()                                     # |dy| of conv2 comes from autograd: one pass
+        n_bwd = len(calls)
+        y2 = y.detach().clone()
+        assert ops._tagged_amax(y2) is None
+        y3 = y.detach()
+        y3.mul_(2.0)                                                     # in place: the tag (same storage) is void
+        assert ops._tagged_amax(y) is None
+        conv2(y3)
+        assert len(calls) == n_bwd + 1
+    finally:
+        ops.absmax_partials = orig
+    assert x.grad is not None and torch.isfinite(x.grad).all()
