@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   const int n = t / tiles_h;
   const int row0 = ty * TH, col0 = tx * TW, m0 = mb * MB;
 
-  float sx, descale;   // set in the prologue below, once the first loads are in flight
+  float sx, descale, descale2;   // set in the prologue below, once the first loads are in flight
 
   // ---- chunk-invariant staging geometry: unit u = (k-half c8, halo row r, halo column col), lanes walk columns
   unsigned rel[NX];   // element offsets; loads address as scalar base + unsigned 32-bit BYTE offset (no 64-bit pairs)
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
     const int ex = h2_scale_exp(m_);
     const int ew = reinterpret_cast<const int*>(wx)[0];
     sx = h2_pow2(ex);
-    descale = h2_pow2(-(ex + ew));
+    h2_pow2_pair(-(ex + ew), descale, descale2);
   }
 
 #pragma unroll
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
     constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
     f32x16 c;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale;
+    for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale * descale2;
     return c;
   };
   float ymax = 0.f;   // max |y| over what this lane stores (published below if the caller asked for it)

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradH2Args
   const int H = d.Hs, W = d.Ws;
 
   // ---- operand scales (powers of two) from the tensor maxima
-  float sx, sdy, descale;
+  float sx, sdy, descale, descale2;
   {
     const float4 px = reinterpret_cast<const float4*>(a.amax_x)[tid], pd = reinterpret_cast<const float4*>(a.amax_dy)[tid];
     float mx = wave_max(fmaxf(fmaxf(px.x, px.y), fmaxf(px.z, px.w)));
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradH2Args
     const int ex = h2_scale_exp(mx), ed = h2_scale_exp(md);
     sx = h2_pow2(ex);
     sdy = h2_pow2(ed);
-    descale = h2_pow2(-(ex + ed));
+    h2_pow2_pair(-(ex + ed), descale, descale2);
   }
 
   const bool second = ci0 >= d.C1;   // C1 % 32 == 0 is a precondition
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradH2Args
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        slab[(size_t)co * KT + (size_t)t * a.Ctot + ci] = acc[t][r] * descale;
+        slab[(size_t)co * KT + (size_t)t * a.Ctot + ci] = acc[t][r] * descale * descale2;
       }
     };
     store(std::integral_constant<int, 0>{});

@@ -10,18 +10,27 @@ constexpr int H2_SLAB = 384;          // 16-byte units of one (chunk, kh, m-tile
 constexpr int H2_AMAX_PARTS = 1024;   // partial |x| maxima handed to a kernel: 512 per source (vunet_absmax_partials)
 constexpr int H2_TOP = 14;            // a tensor's largest magnitude is scaled into [2^13, 2^14): 4x headroom below fp16's 65504
 
-// exponent e such that  m * 2^e  lies in [2^(H2_TOP-1), 2^H2_TOP)  (m > 0; 0 for an all-zero tensor), clamped so that
-// 2^(ex + ew) and its inverse stay normal fp32 numbers
+// exponent e such that  m * 2^e  lies in [2^(H2_TOP-1), 2^H2_TOP)  (m > 0; 0 for an all-zero tensor).  The largest fp32
+// magnitudes need e = 14 - 128 = -114 (never clamped: a too-small down-scale would overflow fp16); tiny tensors are capped
+// at 2^126 (below ~2^-112 the data is under-scaled and loses relative precision gradually, as fp32 subnormals do).
 __host__ __device__ __forceinline__ int h2_scale_exp(float m) {
-  if (!(m > 0.f) || !(m < 3.0e38f)) return 0;      // zeros, NaN, Inf: leave the data alone (they propagate as in fp32)
+  if (!(m > 0.f) || !(m < 3.4e38f)) return 0;      // zeros, NaN, Inf: leave the data alone (they propagate as in fp32)
   int e;
   frexpf(m, &e);                                   // m = f * 2^e, f in [0.5, 1)
   e = H2_TOP - e;
-  return e < -60 ? -60 : (e > 60 ? 60 : e);
+  return e > 126 ? 126 : e;
 }
 
 __host__ __device__ __forceinline__ float h2_pow2(int e) {   // exact 2^e, |e| <= 126
   return __uint_as_float((uint32_t)(127 + e) << 23);
+}
+
+// 2^etot for |etot| <= 252 as two factors of the same sign (each a normal fp32 power of two): v * f1 * f2 overflows /
+// underflows only if v * 2^etot itself does
+__host__ __device__ __forceinline__ void h2_pow2_pair(int etot, float& f1, float& f2) {
+  const int e1 = etot < -126 ? -126 : (etot > 126 ? 126 : etot);
+  f1 = h2_pow2(e1);
+  f2 = h2_pow2(etot - e1);
 }
 
 // (a, b), already scaled -> packed fp16 pairs of the two split terms (low half = a)

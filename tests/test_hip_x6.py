@@ -456,3 +456,31 @@ def test_producer_maxima_tag_equals_a_pass_over_the_tensor(scheme):
     finally:
         ops.absmax_partials = orig
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.parametrize("mag", [0.0, 1e-30, 1e-12, 1e12, 1e30])
+def test_h2_scale_handles_extreme_magnitudes(mag, scheme):
+    """The power-of-two scale of the fp16 scheme at the ends of the fp32 range: an all-zero input gives exactly the shift,
+    tensors around 1e-30 / 1e+30 are scaled into fp16's range and back without loss (the exponent is clamped to +-60 per
+    operand: beyond that the relative accuracy degrades gracefully, it never overflows), NaN and Inf propagate."""
+    if scheme != "h2":
+        pytest.skip("fp16 scheme only")
+    ops = _ops()
+    n, c, h, w, cout = 2, 32, 8, 32, 32
+    g_ = torch.Generator().manual_seed(5)
+    x = (torch.randn(n, c, h, w, generator=g_) * mag).cuda()
+    v, g, bias, gamma, beta = _params(cout, c, 17)
+    y, scale, shift, _ = _run_forward(ops, x, None, v, g, bias, gamma, beta, 0, 0.0, 0, 0, None, False, True, 2)
+    ref = _ref_forward(x, None, v, scale, shift, 0, 0.0, 0, 0, None, False)
+    conv_part = (ref - shift.double().cpu().view(1, -1, 1, 1))
+    tol = 3e-6 * float(conv_part.abs().max()) + 2e-7 * float(shift.abs().max())   # fp32 rounding of  conv + shift
+    assert torch.isfinite(y).all()
+    assert float((y.double().cpu() - ref).abs().max()) <= tol, (mag, float((y.double().cpu() - ref).abs().max()), tol)
+    if mag == 0.0:
+        assert torch.equal(y, shift.view(1, -1, 1, 1).expand_as(y))
+    if mag == 1e12:   # NaN / Inf travel with the data (the |x| maxima ignore NaN; an Inf maximum leaves the data unscaled)
+        xn = x.clone()
+        xn[0, 3, 4, 5] = float("nan")
+        yn, _, _, _ = _run_forward(ops, xn, None, v, g, bias, gamma, beta, 0, 0.0, 0, 0, None, False, True, 2)
+        assert torch.isnan(yn[0, :, 3:6, 4:7]).all() and torch.isfinite(yn[1]).all()
+        assert torch.isfinite(yn[0, :, :, 16:]).all()
