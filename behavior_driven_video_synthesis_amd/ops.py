@@ -194,7 +194,8 @@ _amax_arena = {}
 
 
 def _new_amax_out(dev):
-    key = _raw_stream(torch.cuda.current_device()) if _raw_stream is not None else 0
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, _raw_stream(idx) if _raw_stream is not None else 0)
     a = _amax_arena.get(key)
     if a is None or a[1] >= a[0].shape[0]:
         a = _amax_arena[key] = [torch.zeros(128, 1024, device=dev, dtype=torch.float32), 0]
