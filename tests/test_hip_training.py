@@ -338,3 +338,52 @@ def test_device_schedule_matches_the_host_schedule():
         assert abs(x["gamma"] - y["gamma"]) <= 1e-5 * abs(y["gamma"]) + 1e-9
     for (k, p), (_, q) in zip(a.vunet.state_dict().items(), b.vunet.state_dict().items()):
         torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-6, msg=k)
+
+
+def test_split_schemes_match_fp32_on_a_full_size_step():
+    """One training step of the benchmark configuration (VunetAlter 256x256, full widths, batch 4, VGG19 perceptual + KL
+    loss, dropout on) under the three convolution schemes from identical weights, batch, noise and dropout masks: the
+    loss and every gradient bucket of the fp16 (h2) and bf16 (x6) split schemes must agree with the fp32-MFMA run to
+    fp32 accuracy -- the whole-model statement of tests/test_hip_x6.py."""
+    import copy
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    batch = synthetic_batch(4, 256, "cuda:0", seed=7)
+    res = {}
+    before = ops.conv_precision()
+    try:
+        for mode in ("f32", "h2", "x6"):
+            ops.set_conv_precision(mode)
+            ops.set_dropout_seed(99)
+            cfg = copy.deepcopy(DEFAULT_CONFIG)
+            cfg["training"]["n_init_batches"] = 0            # the KL term is part of the loss from the first step
+            tr = ShapePoseNet(cfg, device="cuda:0", total_steps=1000, vgg_synthetic=True)
+            tr.gamma.fill_(0.5)
+            torch.manual_seed(1234)                          # the posterior draws
+            # gradients without the optimiser step: run the step's own pieces
+            tr.vunet.train()
+            tr.optimizer.zero_grad()
+            with ops.prepacked(tr.vunet):
+                out_img, means, logstds, _ = tr.vunet(batch["pose_img"], batch["stickman"], None)
+                from behavior_driven_video_synthesis_amd.lib.losses import compute_kl_with_prior, vgg_loss
+                ld = vgg_loss(tr.custom_vgg, batch["pose_img"], out_img)
+                loss = sum(ld.values()).sum() + tr.gamma * compute_kl_with_prior(means, logstds)
+                loss.backward()
+                tr.vunet.join_streams()
+                ops.join_wgrad_streams()
+            torch.cuda.synchronize()
+            res[mode] = (float(loss.detach()), [b.grad.clone() for b in tr.optimizer.buckets], out_img.detach().clone())
+            del tr
+    finally:
+        ops.set_conv_precision(before)
+    l32, g32, y32 = res["f32"]
+    for mode in ("h2", "x6"):
+        l, g, y = res[mode]
+        assert abs(l - l32) <= 2e-5 * abs(l32), (mode, l, l32)
+        assert float((y - y32).abs().max()) <= 2e-5 * float(y32.abs().max()), mode
+        for a, b in zip(g, g32):
+            rel = float((a - b).norm() / b.norm())
+            assert rel <= 2e-4, (mode, rel)       # fp32 backward through ~100 layers: the fp32 run itself is this far from fp64
+            print(f"{mode}: loss rel {abs(l - l32) / abs(l32):.2e}, image max {float((y - y32).abs().max() / y32.abs().max()):.2e}, "
+                  f"bucket grad rel {rel:.2e}")
