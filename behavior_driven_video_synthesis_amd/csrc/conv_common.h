@@ -249,9 +249,22 @@ __device__ __forceinline__ float store_tile_side4(const GatherArgs& a, const Pix
   return vmax;
 }
 
+__device__ __forceinline__ void publish_amax(const GatherArgs& a, float vmax) {   // whole wave; see GatherArgs::amax_out
+  const float m_ = wave_max(vmax);
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned*>(a.amax_out) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 511u), __float_as_uint(m_));
+}
+
 __device__ __forceinline__ void store_tile16(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
                                              const f32x16& acc) {
   TileSide s;
   load_tile_side(a, g, m_tile0, h, s);
-  store_tile_side(a, g, m_tile0, h, acc, s);
+  const float vmax = store_tile_side(a, g, m_tile0, h, acc, s);
+  if (a.amax_out) publish_amax(a, vmax);   // (wave-uniform branch; the 1x1 / LDS-tiled kernels publish through here)
 }
+
+// vunet_conv2d_gather with the optional |y| maxima output: set for the kernels that publish (1x1, LDS-tiled), ignored by
+// the others -- vunet_conv2d_publishes_amax tells the caller which it will be
+int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const float* shift,
+                             const float* res, const float* aux, float* y, float* amax_out, void* stream);
+bool vunet_conv2d_gather_publishes(const vunet_conv_desc* d, bool has_aux, bool has_res);

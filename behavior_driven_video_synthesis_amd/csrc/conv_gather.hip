@@ -409,6 +409,19 @@ extern "C" int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has
 extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt,
                                    const float* shift, const float* res, const float* aux, float* y,
                                    void* stream) {
+  return vunet_conv2d_gather_amax(d, x1, x2, wt, shift, res, aux, y, nullptr, stream);
+}
+
+// kernels of this dispatcher whose epilogue publishes |y| maxima (store_tile16): the streaming 1x1 and the LDS-tiled one
+bool vunet_conv2d_gather_publishes(const vunet_conv_desc* d, bool has_aux, bool has_res) {
+  if (d->d2s || (d->mode == 1 && d->stride > 1 && !env_no_phase())) return false;
+  const int pro = prologue_code(d);
+  if (vunet_conv_thin_kind(d, pro, has_aux, has_res)) return false;
+  return use_1x1(d, pro) || use_tiled(d, pro);
+}
+
+int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const float* shift,
+                             const float* res, const float* aux, float* y, float* amax_out, void* stream) {
   if (!d || !x1 || !wt || !y) return VUNET_ERR_ARG;
   if (d->N <= 0 || d->C1 <= 0 || d->C2 < 0 || d->M <= 0 || d->KH <= 0 || d->KW <= 0 || d->KH > 8 || d->KW > 8 ||
       d->stride <= 0 || d->Mpad % 32 != 0)
@@ -421,6 +434,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
 
   GatherArgs ga;
   ga.wide = 0;
+  ga.amax_out = nullptr;
   ga.d = *d;
   ga.x1 = x1; ga.x2 = x2; ga.wt = wt; ga.shift = shift; ga.res = res; ga.aux = aux; ga.y = y;
   ga.NP = d->N * d->Ho * d->Wo;
@@ -453,8 +467,10 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
     return VUNET_OK;
   }
   if (const int thin = vunet_conv_thin_kind(d, pro, aux != nullptr, res != nullptr)) return vunet_conv_thin_launch(ga, thin, st);
+  if (!d->d2s) ga.amax_out = amax_out;   // read by the two kernels below only
   if (use_1x1(d, pro)) return vunet_conv_1x1_launch(ga, pro, st);
   if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);
+  ga.amax_out = nullptr;
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
   if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);
   return dispatch_gather<0>(ga, pro, st);
@@ -472,6 +488,7 @@ extern "C" int vunet_conv2d_dgrad_relu(const vunet_conv_desc* d, const float* dy
     return VUNET_ERR_UNSUPPORTED;
   GatherArgs ga;
   ga.wide = 0;
+  ga.amax_out = nullptr;
   ga.d = *d;
   ga.x1 = dy; ga.x2 = nullptr; ga.wt = wt; ga.shift = nullptr; ga.res = res; ga.aux = nullptr; ga.y = dx;
   ga.NP = d->N * d->Ho * d->Wo;

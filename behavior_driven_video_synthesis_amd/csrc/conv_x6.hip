@@ -144,7 +144,13 @@ extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const flo
     if (!x1 || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
     return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, amax, amax_out, 128, stream);
   }
-  return vunet_conv2d_gather(d, x1, x2, wt, shift, res, aux, y, stream);
+  return vunet_conv2d_gather_amax(d, x1, x2, wt, shift, res, aux, y, amax_out, stream);
+}
+
+extern "C" int vunet_conv2d_publishes_amax(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t split) {
+  if (!d || d->d2s) return 0;
+  if (split != 0 && x6_wanted(d, true, has_aux != 0, has_res != 0, false, split == 2)) return split == 2 ? 1 : 0;
+  return vunet_conv2d_gather_publishes(d, has_aux != 0, has_res != 0) ? 1 : 0;
 }
 
 extern "C" int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,

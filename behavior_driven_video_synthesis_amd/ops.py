@@ -217,15 +217,32 @@ def _tagged_amax(t):
 
 
 def _amax_for(x1, x2=None):
-    """The |x| partial maxima of a convolution's input: the producer's tag if x1 is the only source and carries one."""
+    """The |x| partial maxima of a convolution's input ([x1: 512 | x2: 512]): the producers' tags where the sources
+    carry one, a pass over the tensor (vunet_absmax_partials) where they do not."""
+    t1 = _tagged_amax(x1)
     if x2 is None:
-        tagged = _tagged_amax(x1)
-        if tagged is not None:
-            return tagged
-    return absmax_partials(x1, x2)
+        return t1 if t1 is not None else absmax_partials(x1)
+    t2 = _tagged_amax(x2)
+    if t1 is None and t2 is None:
+        return absmax_partials(x1, x2)
+    h1 = t1[:512] if t1 is not None else absmax_partials(x1)[:512]
+    h2 = t2[:512] if t2 is not None else absmax_partials(x2)[:512]
+    return torch.cat([h1, h2])
 
 
 _wants_split_cache = {}
+
+
+def _publishes_amax(desc, has_aux: bool, has_res: bool, has_wx: bool) -> bool:
+    """Will vunet_conv2d leave the |y| maxima in amax_out for this problem (fp16 scheme)?"""
+    key = ("p", desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.m_off, desc.Mpad, desc.Ho, desc.Wo, desc.KH,
+           desc.stride, desc.pad, desc.mode, desc.in_act, desc.drop_p > 0, desc.out_act, desc.d2s, desc.aux_act,
+           desc.aux_drop_p > 0, has_aux, has_res, has_wx)
+    r = _wants_split_cache.get(key)
+    if r is None:
+        r = _wants_split_cache[key] = _lib.lib().vunet_conv2d_publishes_amax(ctypes.byref(desc), int(has_aux),
+                                                                             int(has_res), 2 if has_wx else 0) == 1
+    return r
 
 
 def _wgrad_wants_split(wd) -> bool:
@@ -341,15 +358,15 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=N
     scheme = _scheme() if wx is not None else 0
     amax_out = None
     if scheme == 2:
-        if not _wants_split(desc, aux is not None, res is not None):
-            wx = amax = None
-        else:
+        if _wants_split(desc, aux is not None, res is not None):
             if amax is None:
                 amax = _amax_for(x1, x2)
-            if not desc.d2s:
-                amax_out = _new_amax_out(y.device)
+        else:
+            wx = amax = None
     else:
         amax = None
+    if _scheme() == 2 and _publishes_amax(desc, aux is not None, res is not None, wx is not None):
+        amax_out = _new_amax_out(y.device)   # the h2, 1x1 and LDS-tiled kernels leave max|y| there
     if desc.mode == 0:
         name, flop = "conv_gather_fwd", 2.0 * desc.N * desc.Ho * desc.Wo * desc.M * (desc.C1 + desc.C2) * t
     else:  # transposed gather: MACs of the forward conv restricted to this source

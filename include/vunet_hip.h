@@ -106,9 +106,9 @@ int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char*
  * terms, three partial products, fp32 accumulate; as accurate as x6 wherever |x| >= 2^-28 of its tensor's maximum.
  *   amax : NULL -> wx is a three-term bf16 image (vunet_wn_desc.split 0/1);  non-NULL -> wx is a two-term fp16 image
  *          (split 2) and amax holds the 1024 partial maxima of |x1|, |x2| written by vunet_absmax_partials.
- *   amax_out : optional, >= 512 floats ZEROED by the caller: when the two-term fp16 kernel runs (amax != NULL,
- *          vunet_conv2d_wants_split, no depth-to-space store) its epilogue leaves partial maxima of |y| there -- the
- *          `amax` of the next convolution that reads y alone (slots 512..1023 of that argument must then be zeros).
+ *   amax_out : optional, >= 512 floats ZEROED by the caller: when amax != NULL and vunet_conv2d_publishes_amax(d, ...) the
+ *          kernel's epilogue leaves partial maxima of |y| there -- slots 0..511 of the `amax` of a convolution that reads
+ *          y as its first source (512..1023: the second source's maxima, zeros if there is none).
  * ------------------------------------------------------------------------------------------ */
 int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
                  const float* shift, const float* res, const float* aux, float* y, const float* amax, float* amax_out,
@@ -124,6 +124,10 @@ int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t 
 /* vunet_conv2d_dgrad_relu on the split kernels (wx = wx_d); VUNET_ERR_UNSUPPORTED -> use vunet_conv2d_dgrad_relu */
 int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
                                const float* res, float* dx, const float* amax, float* amax_out, void* stream);
+/* 1: vunet_conv2d, given a split image of layout `split` (0: none) and (for split 2) the maxima, will fill amax_out for this problem
+ * (the two-term fp16 kernel, the streaming 1x1 kernel, the LDS-tiled kernel; never through depth-to-space); 0: it will
+ * leave amax_out untouched */
+int vunet_conv2d_publishes_amax(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t split);
 /* out[0..511] / out[512..1023]: partial maxima of |x1| / |x2| (x2 may be NULL: zeros); one launch, no atomics */
 int vunet_absmax_partials(const float* x1, int64_t n1, const float* x2, int64_t n2, float* out, void* stream);
 /* kernel name vunet_conv2d (has_mask: vunet_conv2d_dgrad_relu_x6) selects, rocprofv3 spelling */
