@@ -58,7 +58,10 @@ static long x6_blocks(const vunet_conv_desc* d, int MT, int NT) {
 // two resident workgroups wins; `min_blocks` is what the caller requires of the smallest tile.
 static int x6_pick(const vunet_conv_desc* d, int* MT, long min_blocks, bool h2 = false) {
   *MT = d->M <= 32 ? 1 : 2;
-  const int top = (*MT == 1 && !h2) ? 4 : 2;   // the fp16 scheme keeps two accumulator sets: no 16-row tile
+  // bf16 scheme: up to 16 rows for one m-tile.  fp16 scheme (two accumulator sets): 8 rows for two m-tiles; one m-tile
+  // runs best on 4-row tiles -- 113 VGPRs and 38 KB of LDS let FOUR workgroups share a CU, which hides more of the short-K
+  // layers' load / store phases (32 channels at 256^2: 120 -> 112 us, r02)
+  const int top = h2 ? (*MT == 1 ? 1 : 2) : (*MT == 1 ? 4 : 2);
   if (const char* f = getenv("VUNET_X6_FORCE_NT")) {  // tests / tuning
     int NT = atoi(f);
     if (NT > top) NT = top;
