@@ -17,8 +17,19 @@
 //                |x| beyond  max|x| * keep_scale.
 //   scale of w   per layer, from max |w_eff| (vunet_weightnorm_fwd*): unit 0 of the image holds its exponent.
 //
-// Work decomposition, LDS images, barriers and the fused epilogue are those of conv_h2_kernel.h with two planes
-// instead of three: xL [2 planes][2 k-halves][(TH+2) x 34 pixels], weight slab [3 kw][2 planes][2 k-halves][32].
+// Work decomposition (256 threads = 4 waves; 2 workgroups per CU, 4 for the one-m-tile 4-row form):
+//   tile      MT*32 output channels x (4*NT rows x 32 columns) of one image; wave w owns rows w*NT .. w*NT+NT-1
+//             (TW = 16: a column tile is 16 pixels of two rows, see the template comment)
+//   K loop    input channels in chunks of 16 (one fp16 MFMA K step per tap); per chunk three PHASES, one per kernel
+//             row kh, each 3 taps x 3 products x MT x NT MFMAs per wave; one barrier per phase
+//   xL        [2 buffers][2 planes][2 k-halves][(TH+2) x 34 pixels] 16-byte units of 8 fp16: a B-fragment read is 32
+//             consecutive units per k-half (conflict-free ds_read_b128, tap shift = immediate).  The NEXT chunk's tile is
+//             staged into the other buffer in three rounds, one per phase: loads before the phase's MFMAs, prologue +
+//             scale + split + ds_write after them -- 8 live staging registers.
+//   wL        [2 buffers] the phase's weight slab [3 kw][2 planes][2 k-halves][32], copied by LDS-DMA (no registers)
+//   epilogue  combine the two accumulators, de-scale, then shift / activation / residual (data gradient: * act'(aux) +
+//             res) through 16-byte accesses after a lane-quad transpose; publishes max|y| if asked (GatherArgs::amax_out)
+// What was measured to bound it -- and what did not help -- is recorded at the epilogue below and in DESIGN.md section 5.
 #pragma once
 #include <type_traits>
 
