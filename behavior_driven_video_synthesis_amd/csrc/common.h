@@ -117,6 +117,9 @@ static inline InAct make_inact(int act, float slope, float p, uint32_t seed) {
     return on;                                                \
   }
 
+// process-wide tuning knobs (vunet_set_tuning, pointwise.hip): plain loads on the launch path
+extern int g_vunet_tune[4];
+
 static inline int vunet_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VUNET_OK : VUNET_ERR_LAUNCH;

@@ -57,8 +57,8 @@ __device__ __forceinline__ float prologue(const InAct& a, float v, uint32_t idx)
   return apply_in_act(a, v, idx);
 }
 
-// epilogue of one accumulator element
-__device__ __forceinline__ void store_out(const GatherArgs& a, const PixGeo& g, int m, float v) {
+// epilogue of one accumulator element -> the value stored
+__device__ __forceinline__ float store_out(const GatherArgs& a, const PixGeo& g, int m, float v) {
   const vunet_conv_desc& d = a.d;
   const int pix = g.oh * d.Wo + g.ow;
   if (d.mode == 0) {
@@ -82,6 +82,7 @@ __device__ __forceinline__ void store_out(const GatherArgs& a, const PixGeo& g, 
     if (a.res) v += a.res[o];
     a.y[o] = v;
   }
+  return v;
 }
 
 

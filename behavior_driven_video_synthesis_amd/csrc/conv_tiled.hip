@@ -36,8 +36,7 @@ static int resident_workgroups(int MT, int NT) {  // per CU: min(VGPR, LDS) limi
 
 int vunet_conv_tiled_pick(const vunet_conv_desc* d, int* MT, bool valu_heavy) {
   *MT = d->M <= 32 ? 1 : 2;
-  if (const char* f = getenv("VUNET_TILED_FORCE_NT")) {  // tests / tuning: force a tile height
-    const int NT = atoi(f);
+  if (const int NT = g_vunet_tune[VUNET_TUNE_TILED_FORCE_NT]) {  // tests / tuning: force a tile height
     if ((NT == 1 || NT == 2 || NT == 4) && tiled_blocks(*d, *MT, NT) > 0) return NT;
   }
   if (!valu_heavy && *MT == 2) {

@@ -12,6 +12,13 @@ int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pa
 int vunet_conv_h2_launch_w16(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int MT,
                              hipStream_t st);
 
+// conv_h2_small.hip: K-split workgroups for the small maps (fp16 scheme)
+bool vunet_conv_h2_small_ok(const vunet_conv_desc* d, int pro);
+bool vunet_conv_h2_small_wanted(const vunet_conv_desc* d, int pro);
+int vunet_conv_h2_small_launch(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro,
+                               hipStream_t st);
+int vunet_conv_h2_small_name(const vunet_conv_desc* d, int pro, char* name, int len);
+
 extern "C" int vunet_x6_mtiles(int32_t M);
 int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res);
 
@@ -62,8 +69,7 @@ static int x6_pick(const vunet_conv_desc* d, int* MT, long min_blocks, bool h2 =
   // runs best on 4-row tiles -- 113 VGPRs and 38 KB of LDS let FOUR workgroups share a CU, which hides more of the short-K
   // layers' load / store phases (32 channels at 256^2: 120 -> 112 us, r02)
   const int top = h2 ? (*MT == 1 ? 1 : 2) : (*MT == 1 ? 4 : 2);
-  if (const char* f = getenv("VUNET_X6_FORCE_NT")) {  // tests / tuning
-    int NT = atoi(f);
+  if (int NT = g_vunet_tune[VUNET_TUNE_SPLIT_FORCE_NT]) {  // tests / tuning (vunet_set_tuning)
     if (NT > top) NT = top;
     if ((NT == 1 || NT == 2 || NT == 4) && x6_blocks(d, *MT, NT) > 0) return NT;
   }
@@ -94,13 +100,17 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
                      const float* res, const float* aux, const float* mask, float* y, const float* amax, float* amax_out,
                      long min_blocks, void* stream) {
   const int pro = x6_prologue_code(d, mask != nullptr);
-  if (!x6_geometry_ok(d, pro, amax != nullptr)) return VUNET_ERR_UNSUPPORTED;
-  int MT;
-  const int NT = x6_pick(d, &MT, min_blocks, amax != nullptr);
-  if (NT == 0) return VUNET_ERR_UNSUPPORTED;
+  int MT = 0;
+  int NT = x6_geometry_ok(d, pro, amax != nullptr) ? x6_pick(d, &MT, min_blocks, amax != nullptr) : 0;
+  if (g_vunet_tune[VUNET_TUNE_FORCE_SMALL] && amax && !mask && vunet_conv_h2_small_ok(d, pro)) NT = 0;   // tests
   GatherArgs ga;
   fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
   if (amax && !d->d2s) ga.amax_out = amax_out;   // only the fp16 kernels publish |y| maxima (not through the sub-pixel store)
+  if (NT == 0) {   // the row-tiled kernels do not cover / cannot fill the chip with this problem: the small-map form (fp16 scheme)
+    if (!amax || mask || !(min_blocks <= 1 ? vunet_conv_h2_small_ok(d, pro) : vunet_conv_h2_small_wanted(d, pro)))
+      return VUNET_ERR_UNSUPPORTED;
+    return vunet_conv_h2_small_launch(ga, wx, vunet_x6_mtiles(d->Mpad), amax, pro, (hipStream_t)stream);
+  }
   // K dimension of the image = the gathered tensor's channels; M dimension = all columns of the weight matrix
   const int mtp = vunet_x6_mtiles(d->Mpad);
   if (amax && d->Ws % 32) return vunet_conv_h2_launch_w16(ga, wx, mtp, amax, pro, MT, (hipStream_t)stream);
@@ -115,10 +125,16 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
 static bool x6_wanted(const vunet_conv_desc* d, bool has_wx, bool has_aux, bool has_res, bool has_mask, bool h2 = false) {
   if (!has_wx || !x6_enabled()) return false;
   const int pro = x6_prologue_code(d, has_mask);
-  if (!x6_geometry_ok(d, pro, h2)) return false;
   if (vunet_conv_thin_kind(d, pro == 4 ? 0 : pro, has_aux, has_res) != 0) return false;
   int MT;
-  return x6_pick(d, &MT, 128, h2) > 0;
+  if (x6_geometry_ok(d, pro, h2) && x6_pick(d, &MT, 128, h2) > 0) return true;
+  return h2 && !has_mask && vunet_conv_h2_small_wanted(d, pro);   // the small-map form (conv_h2_small.hip)
+}
+
+static bool x6_uses_small(const vunet_conv_desc* d, bool has_mask, bool h2) {
+  const int pro = x6_prologue_code(d, has_mask);
+  int MT;
+  return h2 && !has_mask && !(x6_geometry_ok(d, pro, h2) && x6_pick(d, &MT, 128, h2) > 0);
 }
 
 extern "C" int vunet_conv2d_x6_supported(const vunet_conv_desc* d, int32_t has_mask) {
@@ -169,6 +185,8 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
                                     char* name, int32_t len) {
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
   if (x6_wanted(d, has_wx != 0, has_aux != 0, false, has_mask != 0, has_wx == 2)) {
+    if (x6_uses_small(d, has_mask != 0, has_wx == 2))
+      return vunet_conv_h2_small_name(d, x6_prologue_code(d, has_mask != 0), name, len);
     int MT;
     const int NT = x6_pick(d, &MT, 128, has_wx == 2);
     const char* fam = has_wx == 2 ? "conv_h2_kernel" : "conv_x6_kernel";

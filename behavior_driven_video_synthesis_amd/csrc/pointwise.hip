@@ -383,6 +383,15 @@ extern "C" int vunet_set_dropout_step(const uint32_t* step_dev) {
   return VUNET_OK;
 }
 
+// ------------------------------------------------------------------ tuning knobs (tests / kernel tuning)
+int g_vunet_tune[4] = {0, 0, 0, 0};
+
+extern "C" int vunet_set_tuning(int32_t key, int32_t value) {
+  if (key < 0 || key >= 4) return VUNET_ERR_ARG;
+  g_vunet_tune[key] = value;
+  return VUNET_OK;
+}
+
 // ------------------------------------------------------------------ fused Adam over a flat buffer
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float step_size, float b1, float b2, float eps,

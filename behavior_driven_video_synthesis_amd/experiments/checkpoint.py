@@ -59,8 +59,32 @@ def save_ckpt(directory: str, key: str, iteration: int, trainer, n_saved: int = 
         if extra in sd:
             out[extra] = host(sd[extra])
     torch.save(out, path)
-    mine = sorted((p for p in glob.glob(os.path.join(directory, f"{key}_checkpoint_*.pth"))),
-                  key=lambda p: float(os.path.basename(p).rsplit("_", 1)[-1].split(".")[0]))
-    for old in mine[:-n_saved]:
-        os.remove(old)
+    written = [key]
+    if "regressor" in out:
+        # the reference keeps the regressor and its optimiser in a file of their own, ``regressor_*_<it>.pth`` holding
+        # {"model", "optimizer"}, and restarts with ``_load_ckpt("regressor")`` (experiments/shape_and_pose_net.py:87-95,
+        # 486-497): write that file too, so that ``load_ckpt(dir, "regressor")`` -- and the reference's loader -- find it
+        torch.save({"model": out["regressor"]["model"], "optimizer": out["regressor"].get("optimizer")},
+                   os.path.join(directory, f"regressor_checkpoint_{int(iteration)}.pth"))
+        written.append("regressor")
+    for k in written:
+        mine = sorted((p for p in glob.glob(os.path.join(directory, f"{k}_checkpoint_*.pth"))),
+                      key=lambda p: float(os.path.basename(p).rsplit("_", 1)[-1].split(".")[0]))
+        for old in mine[:-n_saved]:
+            os.remove(old)
     return path
+
+
+def restore(directory: str, trainer, key: str = "reg_ckpt") -> bool:
+    """Restart ``trainer`` (a ``ShapePoseNet``) from the newest checkpoint of ``directory`` the way the reference does
+    (:87-95, :248-255): the ``key`` file for the VUnet + Adam, the ``regressor`` file for the regressor + its Adam
+    (falling back to the ``regressor`` entry older files of this package carried inside the ``key`` file)."""
+    path = latest_checkpoint(directory, key) if os.path.isdir(directory) else None
+    if path is None:
+        return False
+    ckpt = torch.load(path, map_location="cpu")
+    reg_model, reg_opt = load_ckpt(directory, "regressor")
+    if reg_model is not None:
+        ckpt["regressor"] = {"model": reg_model, "optimizer": reg_opt}
+    trainer.load_state_dict(ckpt)
+    return True

@@ -189,6 +189,9 @@ class ShapePoseNet:
         self._lr_dev.fill_(self.lr)
         self._imax_dev.fill_(self.imax)
         self._drop_step.fill_(it & 0x7FFFFFFF)
+        # the library keeps ONE process-wide counter pointer: another graph-mode trainer (or set_dropout_step(None)) may
+        # have replaced it since this trainer's last step -- re-assert ours (host-only, no launch) before anything draws
+        ops.set_dropout_step(self._drop_step)
         ops.reset_dropout_counter()
         key = self._graph_key(batch, it) if (self._capture and eps is None and reg_eps is None) else None
         if key is None:
@@ -231,6 +234,8 @@ class ShapePoseNet:
         if self._dev_sched:
             out = self._train_fn_graph(batch, it, eps, reg_eps)
         else:
+            if ops.dropout_step_counter() is not None:   # left behind by a graph-mode trainer of this process
+                ops.set_dropout_step(None)
             self.optimizer.zero_grad()
             with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
                 out = self._step(batch, it, eps, reg_eps)

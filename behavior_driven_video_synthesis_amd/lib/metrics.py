@@ -114,7 +114,7 @@ def fid_from_features(gt_features: np.ndarray, gen_features: np.ndarray) -> floa
 
 @torch.no_grad()
 def compute_fid(model: torch.nn.Module, batches: Iterable[Dict[str, torch.Tensor]], feature_extractor: Callable,
-                gt_features: Optional[np.ndarray] = None, max_n_samples: int = 12000,
+                gt_features: Optional[np.ndarray] = None, max_n_samples: int = 8000,
                 inplane_normalize: bool = False) -> float:
     """lib/metrics.py:119-282 on an iterable of batches.  ``feature_extractor(images) -> [N, D]`` stands for the
     reference's ``FIDInceptionModel`` (user-supplied pretrained Inception-v3 pool features); ground-truth features are

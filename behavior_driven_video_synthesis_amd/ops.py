@@ -118,6 +118,11 @@ def set_dropout_step(counter: Optional[torch.Tensor]):
     _call("vunet_set_dropout_step", _p(counter))
 
 
+def dropout_step_counter() -> Optional[torch.Tensor]:
+    """The device counter the library currently hashes with (None: plain per-call seeds)."""
+    return _drop_state["step"]
+
+
 def next_dropout_seed() -> int:
     if _drop_state["base"] is None:
         set_dropout_seed(torch.initial_seed())
@@ -178,6 +183,16 @@ def _scheme() -> int:
     return _SCHEMES[_conv_precision["mode"]]
 
 
+_wants_split_cache = {}
+_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2}
+
+
+def set_tuning(key: str, value: int):
+    """vunet_set_tuning: process-wide dispatcher overrides for tests / kernel tuning (0 = the dispatcher's own choice)."""
+    _call("vunet_set_tuning", _TUNING_KEYS[key], int(value))
+    _wants_split_cache.clear()
+
+
 def absmax_partials(x1, x2=None):
     """vunet_absmax_partials: the 1024 partial |x| maxima (512 per source) the split-fp16 kernels scale their input by."""
     out = torch.empty(1024, device=x1.device, dtype=torch.float32)
@@ -203,8 +218,17 @@ def _new_amax_out(dev):
     return a[0][a[1] - 1]
 
 
+_amax_retired = []
+
+
 def _reset_amax_arena():
-    _amax_arena.clear()   # the slices handed out keep their arenas alive for as long as they are referenced
+    """Start a new step's arenas.  The previous step's stay allocated for one more step: their slices are read by
+    kernels on OTHER streams than the one that allocated them (the pose encoder's side stream, the weight-gradient
+    companions), which the caching allocator does not know about -- it could hand a freed 4 KB slice to a new kernel of
+    the allocating stream while such a reader is still in flight.  Every step ends with all streams joined, so one step
+    of grace is enough (and costs no record_stream call per launch)."""
+    _amax_retired[:] = [list(_amax_arena.values())]
+    _amax_arena.clear()
 
 
 def _tag_amax(t, buf):
@@ -228,9 +252,6 @@ def _amax_for(x1, x2=None):
     h1 = t1[:512] if t1 is not None else absmax_partials(x1)[:512]
     h2 = t2[:512] if t2 is not None else absmax_partials(x2)[:512]
     return torch.cat([h1, h2])
-
-
-_wants_split_cache = {}
 
 
 def _publishes_amax(desc, has_aux: bool, has_res: bool, has_wx: bool) -> bool:

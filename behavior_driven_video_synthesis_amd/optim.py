@@ -81,8 +81,10 @@ class FusedAdam:
         in a hipGraph.  The caller writes ``lr_dev`` (outside the graph); the step count advances inside ``step()``.
         One learning rate for all groups -- what the reference's schedule sets (:500-512)."""
         dev = self.buckets[0].flat.device
-        self.lr_dev = lr_dev if lr_dev is not None else torch.full((1,), float(self.param_groups[0]["lr"]),
-                                                                   dtype=torch.float64, device=dev)
+        self._lr_dev_own = lr_dev is None      # nobody else writes it: step() mirrors param_groups[*]["lr"] into it
+        self._lr_mirrored = float(self.param_groups[0]["lr"])
+        self.lr_dev = lr_dev if lr_dev is not None else torch.full((1,), self._lr_mirrored, dtype=torch.float64,
+                                                                   device=dev)
         self.step_dev = torch.full((1,), int(self.buckets[0].step), dtype=torch.int64, device=dev)
         return self
 
@@ -101,6 +103,15 @@ class FusedAdam:
         if self.buckets[0].grad.is_cuda:
             ops.join_wgrad_streams()   # gradients written in place by backward's companion streams come first
         if self.step_dev is not None:
+            lrs = {float(g["lr"]) for g in self.param_groups}
+            if len(lrs) != 1:
+                raise RuntimeError("device-schedule mode keeps ONE learning rate for all param groups "
+                                   f"(vunet_adam_step_dev); the groups carry {sorted(lrs)}")
+            if self._lr_dev_own and not torch.cuda.is_current_stream_capturing():
+                lr = lrs.pop()
+                if lr != self._lr_mirrored:   # a later pg["lr"] change / load_state_dict: one fill outside any capture
+                    self.lr_dev.fill_(lr)
+                    self._lr_mirrored = lr
             self.step_dev.add_(1)
             for g, b in zip(self.param_groups, self.buckets):
                 b.gather_foreign_grads()

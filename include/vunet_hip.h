@@ -300,6 +300,17 @@ int vunet_adam_step_dev(float* param, const float* grad, float* exp_avg, float* 
  * weight-gradient kernels of a step.  NULL (the default) restores plain seeds.  The pointer must stay valid while set. */
 int vunet_set_dropout_step(const uint32_t* step_dev);
 
+/* Process-wide tuning knobs (tests / kernel tuning; the defaults are what production runs).  Replaces per-launch getenv()
+ * lookups: read with a plain load on every launch.  key: VUNET_TUNE_*; value 0 restores the dispatcher's own choice.
+ *   VUNET_TUNE_SPLIT_FORCE_NT  tile height (32-pixel rows per wave: 1, 2 or 4) of the split-fp16 / split-bf16 3x3 kernels
+ *   VUNET_TUNE_TILED_FORCE_NT  the same for the LDS-tiled fp32 kernel
+ *   VUNET_TUNE_FORCE_SMALL     1: vunet_conv2d_x6 takes the small-map K-split kernel wherever it covers the geometry
+ * Returns VUNET_ERR_ARG for an unknown key. */
+#define VUNET_TUNE_SPLIT_FORCE_NT 0
+#define VUNET_TUNE_TILED_FORCE_NT 1
+#define VUNET_TUNE_FORCE_SMALL 2
+int vunet_set_tuning(int32_t key, int32_t value);
+
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */
 int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* stream);
 

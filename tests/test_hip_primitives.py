@@ -174,14 +174,14 @@ def test_rnb_dual_source_tiled_wgrad_vs_oracle():
 @pytest.mark.parametrize("cin,cout,dual", [(32, 32, False), (16, 64, True), (64, 128, False), (8, 3, False)])
 def test_lds_tiled_conv_vs_oracle(nt, cin, cout, dual, monkeypatch):
     """LDS-tiled 3x3 kernel (forward with ELU+dropout prologue, data gradient with mirrored taps), every tile
-    height, one and two m-tiles, single and dual source; forced on small tensors through VUNET_TILED_FORCE_NT."""
+    height, one and two m-tiles, single and dual source; forced on small tensors through ops.set_tuning("tiled_force_nt")."""
     from oracle import vunet_oracle as O
     from behavior_driven_video_synthesis_amd import ops
     M = _mods()
-    monkeypatch.setenv("VUNET_TILED_FORCE_NT", str(nt))
+    ops.set_tuning("tiled_force_nt", nt)
     n, h, w, p = 2, 16, (64 if nt != 16 else 16), 0.1
     if nt == 16:  # 16-wide maps: two 16-pixel row segments per MFMA pixel tile
-        monkeypatch.setenv("VUNET_TILED_FORCE_NT", "1")
+        ops.set_tuning("tiled_force_nt", 1)
     if dual:
         mod = M.VunetRNB(cout, a_channels=cin, residual=True, dropout_prob=p)
     else:

@@ -1,0 +1,185 @@
+"""-m gpu: the small-map K-split convolution kernel (csrc/conv_h2_small.hip) against an fp64 convolution.
+
+The kernel serves the VUnet's bottleneck (models/vunets.py:520-597, :264-424: 4 x 4 ... 16 x 16 maps at 128 channels) and
+the Downsample convolutions that lead there (lib/modules.py:148-161): forward at stride 1 and 2, data gradient at stride
+1 and of the stride-2 convolution (output parity classes), with every prologue / epilogue of the fused layer.  Same
+bounds as tests/test_hip_x6.py: 3e-6 of the output scale against fp64 (fp32-level accuracy from two fp16 terms / three
+products), and the 1e-4 parity tolerance.  Ragged cases: a batch whose pixels do not fill the last 32-pixel tile, tiles
+spanning two and three images, odd map sizes.
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_parity_utils import assert_close, dropout_keep_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from behavior_driven_video_synthesis_amd import ops
+    return ops
+
+
+@pytest.fixture(autouse=True)
+def h2_scheme_and_small_kernel():
+    ops = _ops()
+    before = ops.conv_precision()
+    ops.set_conv_precision("h2")
+    ops.set_tuning("force_small", 1)
+    yield
+    ops.set_tuning("force_small", 0)
+    ops.set_conv_precision(before)
+
+
+def _params(cout, cin, seed):
+    g_ = torch.Generator().manual_seed(seed)
+    v = (torch.randn(cout, cin, 3, 3, generator=g_) * 0.2).cuda()
+    g = (torch.rand(cout, 1, 1, 1, generator=g_) + 0.5).cuda()
+    bias = (torch.randn(cout, generator=g_) * 0.1).cuda()
+    gamma = (1.0 + 0.3 * torch.randn(1, cout, 1, 1, generator=g_)).cuda()
+    beta = (0.2 * torch.randn(1, cout, 1, 1, generator=g_)).cuda()
+    return v, g, bias, gamma, beta
+
+
+def _kernel_name(ops, d, has_aux=False):
+    buf = ctypes.create_string_buffer(96)
+    ops._call("vunet_conv2d_variant", ctypes.byref(d), int(has_aux), 2, 0, buf, 96)
+    return buf.value.decode()
+
+
+# (n, c1, c2, cout, h, w, stride, in_act, drop, out_act, with_res, d2s)
+FWD = [
+    (16, 128, 0, 128, 4, 4, 1, 1, 0.05, 0, True, False),    # the bottleneck RNB conv at 4 x 4: tiles of two images
+    (16, 128, 128, 128, 8, 8, 1, 1, 0.05, 0, True, False),  # two sources (skip read), 8 x 8: 16 chunks over 8 waves
+    (4, 128, 0, 128, 16, 16, 1, 1, 0.0, 0, True, False),    # 16 x 16: two rows per tile
+    (2, 128, 0, 512, 4, 4, 1, 0, 0.0, 0, False, True),      # sub-pixel up-conv through the depth-to-space store
+    (2, 64, 0, 64, 8, 8, 1, 0, 0.0, 3, False, False),       # sigmoid epilogue (the log-std head)
+    (1, 32, 0, 32, 4, 4, 1, 0, 0.0, 0, False, False),       # 16 pixels in all: half a tile, waves without a chunk
+    (3, 48, 16, 96, 4, 4, 1, 1, 0.1, 0, True, False),       # 48 pixels: a tile over two images and a ragged last tile
+    (5, 32, 0, 64, 7, 7, 1, 1, 0.0, 0, True, False),        # odd map: tiles start anywhere, up to two images each
+    (16, 128, 0, 128, 8, 8, 2, 0, 0.0, 0, False, False),    # Downsample 8 -> 4
+    (4, 64, 0, 128, 16, 16, 2, 0, 0.0, 0, False, False),    # Downsample 16 -> 8
+    (2, 32, 0, 64, 32, 32, 2, 0, 0.0, 0, False, False),     # Downsample 32 -> 16: five staging rounds
+    (3, 16, 0, 32, 5, 7, 2, 1, 0.0, 0, False, False),       # stride 2 on an odd, non-square map (tiles over 3 images)
+]
+
+
+@pytest.mark.parametrize("case", FWD)
+def test_small_forward_vs_fp64(case):
+    ops = _ops()
+    n, c1, c2, cout, h, w, stride, in_act, drop, out_act, with_res, d2s = case
+    g_ = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x1 = torch.randn(n, c1, h, w, generator=g_).cuda()
+    x2 = torch.randn(n, c2, h, w, generator=g_).cuda() if c2 else None
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = None
+    if with_res:
+        res = torch.randn((n, cout // 4, 2 * ho, 2 * wo) if d2s else (n, cout, ho, wo), generator=g_).cuda()
+    v, g, bias, gamma, beta = _params(cout, c1 + c2, 5)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, c1, c2, 0, True)
+    seed = 0xBEEF01
+    y = torch.empty((n, cout // 4, 2 * ho, 2 * wo) if d2s else (n, cout, ho, wo), device="cuda")
+    d = ops.ConvDesc(N=n, C1=c1, C2=c2, Hs=h, Ws=w, M=cout, m_off=0, Mpad=wt_f.shape[1], Ho=ho, Wo=wo, KH=3, KW=3,
+                     stride=stride, pad=1, mode=0, in_act=in_act, in_slope=0.0, drop_p=drop, drop_seed=seed,
+                     out_act=out_act, d2s=int(d2s))
+    amax_out = torch.zeros(1024, device="cuda")
+    ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift), ops._p(res), None,
+              None, ops._p(y), ops._p(ops.absmax_partials(x1, x2)), None if d2s else ops._p(amax_out), ops._stream())
+    torch.cuda.synchronize()
+    xs = []
+    for i, x in enumerate((x1, x2)):
+        if x is None:
+            continue
+        t = x.double().cpu()
+        if in_act == ops.ACT_ELU:
+            t = F.elu(t)
+        if drop > 0:
+            s = seed if i == 0 else (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF
+            t = t * dropout_keep_mask(tuple(x.shape), drop, s).double() * float(torch.tensor(1.0 / (1.0 - drop),
+                                                                                             dtype=torch.float32))
+        xs.append(t)
+    wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
+    ref = F.conv2d(torch.cat(xs, dim=1), wd, None, stride=stride, padding=1) + shift.double().cpu().view(1, -1, 1, 1)
+    if out_act == ops.ACT_SIGMOID:
+        ref = torch.sigmoid(ref)
+    if d2s:
+        from oracle import vunet_oracle as O
+        ref = O.depth_to_space(ref)
+    if res is not None:
+        ref = ref + res.double().cpu()
+    sc = max(float(ref.abs().max()), 1.0)
+    assert_close(y, ref.float(), rtol=1e-4, atol=1e-4 * sc, name="y")
+    assert float((y.double().cpu() - ref).abs().max()) <= 3e-6 * sc
+    if not d2s:   # the published |y| maxima bound the tensor from above and are attained
+        assert float(amax_out.max()) == float(y.abs().max())
+
+
+def test_dispatcher_routes_the_bottleneck_layers_to_the_small_kernel():
+    """vunet_conv2d's own choice (no forcing) for the bs-16 layers of BASELINE config 2 the row-tiled kernels cannot fill
+    the chip with."""
+    ops = _ops()
+    ops.set_tuning("force_small", 0)
+    for (c1, c2, cout, hs, stride, mode) in [(128, 0, 128, 4, 1, 0), (128, 128, 128, 8, 1, 0), (128, 0, 128, 16, 1, 0),
+                                              (128, 0, 128, 16, 2, 0), (128, 0, 128, 32, 2, 0), (128, 0, 128, 8, 1, 1),
+                                              (128, 0, 128, 4, 2, 1), (128, 0, 128, 16, 2, 1), (512, 0, 128, 8, 1, 1)]:
+        ho = hs if stride == 1 else (hs // 2 if mode == 0 else hs * 2)
+        d = ops.ConvDesc(N=16, C1=c1, C2=c2, Hs=hs, Ws=hs, M=cout, m_off=0, Mpad=128, Ho=ho, Wo=ho, KH=3, KW=3,
+                         stride=stride, pad=1, mode=mode, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
+        assert ops._lib.lib().vunet_conv2d_wants_split(ctypes.byref(d), 0, 0, 0, 2) == 1, (c1, c2, cout, hs, stride, mode)
+        assert _kernel_name(ops, d).startswith("conv_h2_small_kernel"), (_kernel_name(ops, d), hs, stride, mode)
+    # big maps stay on the row-tiled kernel
+    d = ops.ConvDesc(N=16, C1=128, C2=0, Hs=32, Ws=32, M=128, m_off=0, Mpad=128, Ho=32, Wo=32, KH=3, KW=3, stride=1, pad=1,
+                     mode=0, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
+    assert _kernel_name(ops, d).startswith("conv_h2_kernel")
+
+
+# (n, cout(forward), cin(forward), h, w of dy, stride, aux_act, aux_drop, with_res, second source offset)
+DGRAD = [
+    (16, 128, 128, 4, 4, 1, 1, 0.05, True, 0),     # data gradient of the 4 x 4 RNB conv: ELU' * dropout mask, + residual
+    (4, 128, 128, 16, 16, 1, 1, 0.0, True, 0),
+    (2, 512, 128, 8, 8, 1, 0, 0.0, False, 0),      # through the sub-pixel up-conv (dy arrives space-to-depth'ed): 32 chunks
+    (3, 32, 96, 4, 4, 1, 1, 0.0, False, 32),       # second source of a two-source layer: weight columns from m_off
+    (16, 128, 128, 4, 4, 2, 0, 0.0, False, 0),     # Downsample 8 -> 4 backwards: four parity classes, 2 images per tile
+    (4, 128, 64, 8, 8, 2, 0, 0.0, False, 0),       # dy 8 x 8 -> dx 16 x 16
+    (2, 64, 32, 16, 16, 2, 0, 0.0, False, 0),      # dy 16 x 16 -> dx 32 x 32
+]
+
+
+@pytest.mark.parametrize("case", DGRAD)
+def test_small_data_gradient_vs_fp64(case):
+    ops = _ops()
+    n, cout, cin, h, w, stride, aux_act, aux_drop, with_res, m_off = case
+    g_ = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    ctot = cin + m_off
+    v, g, bias, gamma, beta = _params(cout, ctot, 9)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, m_off if m_off else ctot,
+                                                                      cin if m_off else 0, 0, True)
+    ho, wo = h * stride, w * stride
+    dy = torch.randn(n, cout, h, w, generator=g_).cuda()
+    aux = torch.randn(n, cin, ho, wo, generator=g_).cuda() if (aux_act or aux_drop) else None
+    res = torch.randn(n, cin, ho, wo, generator=g_).cuda() if with_res else None
+    seed = 0xD06F00D
+    d = ops.ConvDesc(N=n, C1=cout, C2=0, Hs=h, Ws=w, M=cin, m_off=m_off, Mpad=wt_d.shape[1], Ho=ho, Wo=wo, KH=3, KW=3,
+                     stride=stride, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
+                     aux_act=aux_act, aux_slope=0.0, aux_drop_p=aux_drop, aux_drop_seed=seed)
+    dx = torch.empty(n, cin, ho, wo, device="cuda")
+    ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
+              ops._p(dx), ops._p(ops.absmax_partials(dy)), None, ops._stream())
+    torch.cuda.synchronize()
+    wd = (v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1))[:, m_off:m_off + cin]
+    ref = F.conv_transpose2d(dy.double().cpu(), wd, stride=stride, padding=1, output_padding=stride - 1)
+    if aux is not None:
+        a = aux.double().cpu()
+        gr = torch.where(a > 0, torch.ones_like(a), a.exp()) if aux_act == ops.ACT_ELU else torch.ones_like(a)
+        if aux_drop > 0:
+            gr = gr * dropout_keep_mask(tuple(aux.shape), aux_drop, seed).double() * float(
+                torch.tensor(1.0 / (1.0 - aux_drop), dtype=torch.float32))
+        ref = ref * gr
+    if res is not None:
+        ref = ref + res.double().cpu()
+    sc = max(float(ref.abs().max()), 1.0)
+    assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * sc, name="dx")
+    assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * sc

@@ -88,7 +88,7 @@ def _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_a
                      stride=1, pad=1, mode=0, in_act=in_act, in_slope=0.0, drop_p=drop, drop_seed=seed,
                      out_act=out_act, d2s=int(d2s))
     if force_nt is not None:
-        os.environ["VUNET_X6_FORCE_NT"] = str(force_nt)
+        ops.set_tuning("split_force_nt", force_nt)
     try:
         if use_x6 and w % 32 and ops.conv_precision() != "h2":   # 16-pixel column tiles exist in the fp16 scheme only
             rc = ops._lib.lib().vunet_conv2d_x6(ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wx_f), ops._p(shift),
@@ -103,7 +103,7 @@ def _run_forward(ops, x1, x2, v, g, bias, gamma, beta, in_act, drop, seed, out_a
             ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wt_f), ops._p(shift),
                       ops._p(res), None, ops._p(y), ops._stream())
     finally:
-        os.environ.pop("VUNET_X6_FORCE_NT", None)
+        ops.set_tuning("split_force_nt", 0)
     torch.cuda.synchronize()
     return y, scale, shift, (wt_d, wx_d)
 
@@ -181,12 +181,12 @@ def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked, scheme):
     dx = torch.empty(n, cin, h, w, device="cuda")
     if w % 32 and scheme != "h2":
         pytest.skip("16-wide maps: fp16 scheme only")
-    os.environ["VUNET_X6_FORCE_NT"] = str(nt)
+    ops.set_tuning("split_force_nt", nt)
     try:
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux),
                   ops._p(yfwd) if masked else None, ops._p(dx), _amax(ops, dy), None, ops._stream())
     finally:
-        os.environ.pop("VUNET_X6_FORCE_NT", None)
+        ops.set_tuning("split_force_nt", 0)
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
     dyd = dy.double().cpu()
     if masked:
@@ -365,12 +365,12 @@ def test_x6_stride2_data_gradient_vs_fp64(cout, cin, h, w, nt, with_aux):
                      aux_act=ops.ACT_ELU if with_aux else 0, aux_slope=0.0, aux_drop_p=0.0, aux_drop_seed=0)
     assert ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
     dx = torch.full((n, cin, 2 * h, 2 * w), float("nan"), device="cuda")     # every pixel must be written by some parity
-    os.environ["VUNET_X6_FORCE_NT"] = str(nt)
+    ops.set_tuning("split_force_nt", nt)
     try:
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
                   ops._p(dx), _amax(ops, dy), None, ops._stream())
     finally:
-        os.environ.pop("VUNET_X6_FORCE_NT", None)
+        ops.set_tuning("split_force_nt", 0)
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
     ref = F.conv_transpose2d(dy.double().cpu(), wd, stride=2, padding=1, output_padding=1)
     if with_aux:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the split convolution kernels on the layer shapes that dominate the bs-16 256x256 step (needs an MI355X).
 
-    python tools/time_conv.py [--modes h2,x6] [--nt 0]      (--nt: VUNET_X6_FORCE_NT, 0 = the dispatcher's choice)
+    python tools/time_conv.py [--modes h2,x6] [--nt 0]      (--nt: ops.set_tuning("split_force_nt"), 0 = the dispatcher's choice)
 
 Per shape and scheme: average launch time over 20 launches (HIP events on the launch stream), algorithmic TFLOP/s."""
 import argparse
@@ -20,7 +20,7 @@ ap.add_argument("--modes", default="h2,x6")
 ap.add_argument("--nt", type=int, default=0)
 args = ap.parse_args()
 if args.nt:
-    os.environ["VUNET_X6_FORCE_NT"] = str(args.nt)
+    ops.set_tuning("split_force_nt", args.nt)
 
 # (name, n, cin, cout, h, w, mode, in_act, masked)
 SHAPES = [

@@ -31,7 +31,7 @@ def run(x, v, mode, nt):
     y = torch.empty(n, cout, h, w, device="cuda")
     d = ops.ConvDesc(N=n, C1=c1, C2=0, Hs=h, Ws=w, M=cout, m_off=0, Mpad=wt_f.shape[1], Ho=h, Wo=w, KH=3, KW=3,
                      stride=1, pad=1, mode=0, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
-    os.environ["VUNET_X6_FORCE_NT"] = str(nt)
+    ops.set_tuning("split_force_nt", nt)
     if mode != "f32":
         amax = ops.absmax_partials(x) if mode == "h2" else None
         ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x), None, ops._p(wx_f), None, None, None, None, ops._p(y),
