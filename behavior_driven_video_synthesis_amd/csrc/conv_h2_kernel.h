@@ -75,8 +75,11 @@ union H2Unit {
 // TW: tile width in pixels.  32: an MFMA column tile is 32 consecutive pixels of one row; 16 (maps 16 wide: VGG19 conv5,
 //     the decoder's 16 x 16 level): it is 16 pixels of two consecutive rows, lane j -> (row j / 16, column j % 16); the
 //     staged rows are then 32 units apart (18 used), which keeps the two half-rows of a fragment read on distinct banks.
+// MT * NT >= 8 (128 channels x 8 rows, or 64 channels x 16 rows, per four-wave workgroup): ONE workgroup per CU, one wave
+// per SIMD with the whole 512-entry register file -- 256 accumulator registers and room to keep the next tap's
+// fragments in flight, so the fragment reads are left to the scheduler instead of being fenced per tap.
 template <int MT, int NT, int MODE, int PRO, int PHW = -1, int NWV = 4, int TW = 32>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(const GatherArgs a_in,
+__global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void conv_h2_kernel(const GatherArgs a_in,
                                                                              const uint4* __restrict__ wx, int mtiles_pad,
                                                                              const float* __restrict__ amax) {
   GatherArgs a = a_in;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
         // two waves share a SIMD: the partner's MFMAs cover this wave's fragment reads, so nothing is gained by
         // letting the scheduler hoist the next tap's 4*(MT+NT) fragment registers above this tap's MFMAs
 #ifndef H2_NO_TAP_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MT * NT < 8) __builtin_amdgcn_sched_barrier(0);
 #endif
         const int dc = PHW >= 0 ? (PW + 1 - kw) / 2 + 1 : (MODE == 0 ? kw : 2 - kw);
         H2Unit av[2][MT], bv[2][NT];
@@ -384,6 +387,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
       tile(std::integral_constant<int, 2>{});
       tile(std::integral_constant<int, 3>{});
     }
+    if constexpr (MT * NT > 4) {
+      tile(std::integral_constant<int, 4>{});
+      tile(std::integral_constant<int, 5>{});
+      tile(std::integral_constant<int, 6>{});
+      tile(std::integral_constant<int, 7>{});
+    }
+    static_assert(MT * NT <= 8, "epilogue tiles are named at compile time");
     publish();
     return;
   }
@@ -399,6 +409,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void conv_h2_kernel(con
   if constexpr (MT * NT > 2) {
     tile(std::integral_constant<int, 2>{});
     tile(std::integral_constant<int, 3>{});
+  }
+  if constexpr (MT * NT > 4) {
+    tile(std::integral_constant<int, 4>{});
+    tile(std::integral_constant<int, 5>{});
+    tile(std::integral_constant<int, 6>{});
+    tile(std::integral_constant<int, 7>{});
   }
   publish();
 }
@@ -453,6 +469,23 @@ static int launch_h2(const GatherArgs& ga, const void* wx, int mtiles_pad, const
     case 0: return launch_h2_one<MT, NT, 0, 0, -1, NWV>(ga, wx, mtiles_pad, amax, st);
     case 1: return launch_h2_one<MT, NT, 0, 1, -1, NWV>(ga, wx, mtiles_pad, amax, st);
     case 2: return launch_h2_one<MT, NT, 0, 2, -1, NWV>(ga, wx, mtiles_pad, amax, st);
+    default: return VUNET_ERR_UNSUPPORTED;
+  }
+}
+
+// the big tiles (MT * NT = 8): stride-1 forward and data gradient only (no output-parity forms)
+template <int MT, int NT>
+static int launch_h2_big(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, hipStream_t st) {
+  if (ga.d.stride != 1) return VUNET_ERR_UNSUPPORTED;
+  if (ga.d.mode == 1) {
+    if (pro == 4) return launch_h2_one<MT, NT, 1, 4, -1, 4>(ga, wx, mtiles_pad, amax, st);
+    if (pro == 0) return launch_h2_one<MT, NT, 1, 0, -1, 4>(ga, wx, mtiles_pad, amax, st);
+    return VUNET_ERR_UNSUPPORTED;
+  }
+  switch (pro) {
+    case 0: return launch_h2_one<MT, NT, 0, 0, -1, 4>(ga, wx, mtiles_pad, amax, st);
+    case 1: return launch_h2_one<MT, NT, 0, 1, -1, 4>(ga, wx, mtiles_pad, amax, st);
+    case 2: return launch_h2_one<MT, NT, 0, 2, -1, 4>(ga, wx, mtiles_pad, amax, st);
     default: return VUNET_ERR_UNSUPPORTED;
   }
 }

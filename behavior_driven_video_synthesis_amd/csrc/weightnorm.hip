@@ -385,12 +385,11 @@ struct WnBwdArgs {
 
 // Stage 1: sum the split-K slabs.  One workgroup = 64 consecutive K entries of one output channel (coalesced
 // 256-B rows of every slab) x 4 waves that each take a quarter of the slabs; fixed summation order.
-__global__ __launch_bounds__(256) void wn_slab_reduce_kernel(const WnBwdArgs a) {
-  __shared__ float part[4][64];
+__device__ __forceinline__ void wn_slab_reduce_body(const WnBwdArgs& a, int block, float (*part)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int K = a.T * a.Ctot;
   const int kchunks = (K + 63) / 64;
-  const int co = blockIdx.x / kchunks, kc = blockIdx.x - co * kchunks;
+  const int co = block / kchunks, kc = block - co * kchunks;
   const int k = kc * 64 + lane;  // slab order (tap, ci)
   float s = 0.f;
   if (k < K) {
@@ -414,10 +413,14 @@ __global__ __launch_bounds__(256) void wn_slab_reduce_kernel(const WnBwdArgs a) 
   }
 }
 
+__global__ __launch_bounds__(256) void wn_slab_reduce_kernel(const WnBwdArgs a) {
+  __shared__ float part[4][64];
+  wn_slab_reduce_body(a, blockIdx.x, part);
+}
+
 // Stage 2: per output channel, D = <dW, v> and the parameter gradients.
-__global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
-  __shared__ float red[4];
-  const int co = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void wn_bwd_body(const WnBwdArgs& a, int co, float* red) {
+  const int tid = threadIdx.x;
   const int K = a.T * a.Ctot;
   const float* vr = a.v + (size_t)co * K;
   const float* dwr = a.dwred + (size_t)co * K;
@@ -456,6 +459,70 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
     }
   }
 #undef WN_OLD
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const WnBwdArgs a) {
+  __shared__ float red[4];
+  wn_bwd_body(a, blockIdx.x, red);
+}
+
+// ---- batched form: the slab reduction + parameter gradients of MANY layers in two launches (one grid row per layer).
+// The per-layer launch pair was 188 launches and 1.56 ms of a 26 ms step (r02 profile), almost all of it launch latency.
+struct WnBwdItemDev {  // mirrors vunet_wn_bwd_item (include/vunet_hip.h)
+  const float *slabs, *dshift, *v, *g, *bias, *gamma, *invnorm;
+  float *dv, *dg, *dbias, *dgamma, *dbeta;
+  float* workspace;
+  vunet_wn_desc d;
+  int32_t nsplit, accumulate;
+};
+
+__device__ __forceinline__ WnBwdArgs bwd_item_args(const WnBwdItemDev& it) {
+  WnBwdArgs a;
+  a.d = it.d;
+  a.slabs = it.slabs; a.dshift = it.dshift; a.v = it.v; a.g = it.g; a.bias = it.bias; a.gamma = it.gamma;
+  a.invnorm = it.invnorm;
+  a.dv = it.dv; a.dg = it.dg; a.dbias = it.dbias; a.dgamma = it.dgamma; a.dbeta = it.dbeta;
+  a.nsplit = it.nsplit;
+  a.T = it.d.KH * it.d.KW;
+  a.Ctot = it.d.C1 + it.d.C2;
+  a.Coutp = (it.d.Cout + 31) / 32 * 32;
+  a.accumulate = it.accumulate;
+  a.dwred = it.workspace;
+  a.dsred = it.workspace + (size_t)it.d.Cout * a.T * a.Ctot;
+  return a;
+}
+
+__global__ __launch_bounds__(256) void wn_slab_reduce_multi_kernel(const WnBwdItemDev* __restrict__ items) {
+  __shared__ float part[4][64];
+  const WnBwdArgs a = bwd_item_args(items[blockIdx.y]);
+  const int nb = a.d.Cout * ((a.T * a.Ctot + 63) / 64);
+  for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+    wn_slab_reduce_body(a, b, part);
+    __syncthreads();   // `part` is reused by the next block of work
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_multi_kernel(const WnBwdItemDev* __restrict__ items) {
+  __shared__ float red[4];
+  const WnBwdItemDev& it = items[blockIdx.y];
+  if ((int)blockIdx.x >= it.d.Cout) return;
+  wn_bwd_body(bwd_item_args(it), blockIdx.x, red);
+}
+
+extern "C" int vunet_weightnorm_bwd_multi(const vunet_wn_bwd_item* items_dev, int32_t n_items, int32_t max_cout,
+                                          int32_t max_reduce_blocks, void* stream) {
+  if (!items_dev || n_items < 1 || max_cout < 1 || max_reduce_blocks < 1) return VUNET_ERR_ARG;
+  static_assert(sizeof(WnBwdItemDev) == sizeof(vunet_wn_bwd_item), "vunet_wn_bwd_item layout");
+  const WnBwdItemDev* items = reinterpret_cast<const WnBwdItemDev*>(items_dev);
+  hipStream_t st = (hipStream_t)stream;
+  // every layer gets the same number of workgroups, each walking its layer's (channel, K chunk) blocks with a stride:
+  // enough of them in total to fill the chip several times over, no empty workgroups for the small layers
+  int gx = 4096 / n_items;
+  if (gx < 16) gx = 16;
+  if (gx > max_reduce_blocks) gx = max_reduce_blocks;
+  VUNET_LAUNCH(wn_slab_reduce_multi_kernel, dim3((unsigned)gx, (unsigned)n_items), dim3(256), 0, st, items);
+  VUNET_LAUNCH(wn_bwd_multi_kernel, dim3((unsigned)max_cout, (unsigned)n_items), dim3(256), 0, st, items);
+  return vunet_check_launch();
 }
 
 extern "C" int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float* dshift, int32_t nsplit,

@@ -48,6 +48,12 @@ class WnDesc(ctypes.Structure):
                 ("KW", ctypes.c_int32), ("kind", ctypes.c_int32), ("split", ctypes.c_int32)]
 
 
+class WnBwdItem(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("slabs", "dshift", "v", "g", "bias", "gamma", "invnorm", "dv", "dg", "dbias",
+                                                "dgamma", "dbeta", "workspace")] +
+                [("d", WnDesc), ("nsplit", ctypes.c_int32), ("accumulate", ctypes.c_int32)])
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -184,7 +190,7 @@ def _scheme() -> int:
 
 
 _wants_split_cache = {}
-_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2}
+_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2, "h2_big": 3}
 
 
 def set_tuning(key: str, value: int):
@@ -585,6 +591,7 @@ def _wgrad_stream_for(cur):
 def join_wgrad_streams():
     """The current stream waits for every companion stream that has been handed work since the last join (only those:
     a stream that took no part in a hipGraph capture must not be waited on from inside it)."""
+    flush_weight_grads()
     cur = torch.cuda.current_stream()
     for key in _wgrad_streams["dirty"]:
         cur.wait_stream(_wgrad_streams["by_stream"][key])
@@ -728,6 +735,99 @@ class prepacked:
         _active_prepack.clear()
 
 
+# ------------------------------------------------------------------------------------------------
+# deferred, batched weight-norm backward (vunet_weightnorm_bwd_multi).  A layer whose parameter gradients are all
+# written in place into flat buckets only launches its weight-gradient kernel during backward; the slab reduction and
+# the (dv, dg, dbias, dgamma, dbeta) arithmetic of up to _WN_GROUP such layers then run as ONE pair of launches on the
+# stream that produced the slabs -- at the latest when backward ends (autograd engine callback) or when
+# ``flush_weight_grads`` / ``join_wgrad_streams`` is called.  Slabs and workspaces are per-layer persistent buffers, so
+# the device-side item table of a group is identical from step to step and is uploaded once.
+# ------------------------------------------------------------------------------------------------
+_WN_GROUP = 16                  # layers per batched launch pair, at most
+_WN_ARENA_FLOATS = 48 << 20     # 192 MB of slabs per stream between two flushes: they stay in the 256 MB Infinity Cache
+_wn_batch = {"on": os.environ.get("VUNET_WN_BATCH", "1") != "0", "pending": {}, "arena": {}, "tables": {},
+             "callback_queued": False}
+
+
+def enable_wn_batching(on: bool = True):
+    flush_weight_grads()
+    _wn_batch["on"] = bool(on)
+
+
+def _wn_buffers(n_slab: int, n_work: int, dev):
+    """Slabs + workspace of one deferred layer: the next slice of the current stream's arena.  Backward visits the layers
+    in the same order every step, so a layer gets the same addresses every step (the item tables stay valid); the arena
+    restarts after every flush -- the flush kernels are ordered before the next writers on the same stream -- so a
+    step's slab traffic recycles the same cache-resident memory instead of streaming gigabytes through HBM."""
+    idx = torch.cuda.current_device()
+    key = (idx, _raw_stream(idx))
+    need = ((n_slab + 63) & ~63) + ((n_work + 63) & ~63)
+    ar = _wn_batch["arena"].get(key)
+    if ar is None or ar[0].numel() < need:
+        flush_weight_grads()
+        ar = _wn_batch["arena"][key] = [torch.empty(max(_WN_ARENA_FLOATS, need), device=dev, dtype=torch.float32), 0]
+    if ar[1] + need > ar[0].numel():
+        _wn_flush_stream(key)
+    off = ar[1]
+    ar[1] = off + need
+    return ar[0][off:off + n_slab], ar[0][off + ((n_slab + 63) & ~63):off + ((n_slab + 63) & ~63) + n_work]
+
+
+def _wn_flush_stream(stream_key):
+    items = _wn_batch["pending"].pop(stream_key, None)
+    ar = _wn_batch["arena"].get(stream_key)
+    if ar is not None:
+        ar[1] = 0
+    if not items:
+        return
+    dev_idx, raw = stream_key
+    sig = tuple(it[0] for it in items)
+    tab = _wn_batch["tables"].get(sig)
+    if tab is None:
+        arr = (WnBwdItem * len(items))()
+        max_cout = max_blocks = 1
+        for i, (fields, _params, _keep) in enumerate(items):
+            (slabs, dshift, v, g, bias, gamma, invnorm, dv, dg, dbias, dgamma, dbeta, work, dsc, ns) = fields
+            it = arr[i]
+            it.slabs, it.dshift, it.v, it.g, it.bias, it.gamma, it.invnorm = slabs, dshift, v, g, bias, gamma, invnorm
+            it.dv, it.dg, it.dbias, it.dgamma, it.dbeta, it.workspace = dv, dg, dbias, dgamma, dbeta, work
+            cout, c1, c2, kh, kw, kind = dsc
+            it.d = WnDesc(cout, c1, c2, kh, kw, kind, 0)
+            it.nsplit, it.accumulate = ns, 1
+            max_cout = max(max_cout, cout)
+            max_blocks = max(max_blocks, cout * ((kh * kw * (c1 + c2) + 63) // 64))
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(torch.device("cuda", dev_idx))
+        tab = _wn_batch["tables"][sig] = (table, len(items), max_cout, max_blocks)
+    table, n, max_cout, max_blocks = tab
+    _call("vunet_weightnorm_bwd_multi", _p(table), n, max_cout, max_blocks, ctypes.c_void_p(raw))
+    for _fields, params, _keep in items:
+        for p_ in params:
+            for hook in _grad_hooks:
+                hook(p_)
+
+
+def flush_weight_grads():
+    """Launch the deferred weight-norm backward of every stream that has pending layers (idempotent)."""
+    for key in list(_wn_batch["pending"].keys()):
+        _wn_flush_stream(key)
+    _wn_batch["callback_queued"] = False
+
+
+def _wn_defer(fields, params, keep):
+    """``keep``: tensors the item points at that nothing else is guaranteed to hold until the flush."""
+    idx = torch.cuda.current_device()
+    key = (idx, _raw_stream(idx))
+    lst = _wn_batch["pending"].setdefault(key, [])
+    lst.append((fields, params, keep))
+    if len(lst) >= _WN_GROUP:
+        _wn_flush_stream(key)
+    elif not _wn_batch["callback_queued"]:
+        # the end of this backward pass flushes whatever is still pending (the engine runs the callback in the thread
+        # that called backward(), after every node has run)
+        _wn_batch["callback_queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+
+
 class FusedConv(torch.autograd.Function):
     """y = [d2s] act_out( conv( drop(act_in(cat(x1, x2))) ; w_eff ) + shift ) [+ res]."""
 
@@ -787,6 +887,9 @@ class FusedConv(torch.autograd.Function):
         else:
             ctx.amax_x = _conv_gather(d, x1, x2, wt_f, shift, res, None, y, wx_f)   # reused by the weight gradient
         ctx.cfg = cfg
+        # packed by ops.prepacked: invnorm lives in the model's persistent pack set (the batched weight-norm backward keeps
+        # raw pointers to it in a table that is uploaded once)
+        ctx.prepacked = pre is not None
         ctx.param_refs = (v, g, bias, gamma, beta)  # the caller's tensors (Parameters): direct .grad writes
         ctx.res_ref = res
         ctx.dims = (n, c1, c2, hs, ws, cout, ho, wo)
@@ -874,13 +977,17 @@ class FusedConv(torch.autograd.Function):
         if ctx.need_w and _scheme() == 2 and _wgrad_wants_split(wd):
             wg_amax = (ctx.amax_x if ctx.amax_x is not None else absmax_partials(x1, x2), get_dy_amax())
 
-        def weight_gradients():
+        def weight_gradients(defer: bool = False):
             ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
             if ns < 1:
                 raise RuntimeError(f"vunet_conv2d_wgrad_nsplit failed with code {ns}")
             wd.nsplit = ns
             ktot = k * k * (c1 + c2)
-            slabs = torch.empty(ns * _r32(cout) * ktot + ns * _r32(cout), device=dy.device, dtype=torch.float32)
+            n_slab = ns * _r32(cout) * ktot + ns * _r32(cout)
+            if defer:   # per-layer persistent buffers: the batched reduction reads them after backward has moved on
+                slabs, work = _wn_buffers(n_slab, cout * (ktot + 1), dy.device)
+            else:
+                slabs = torch.empty(n_slab, device=dy.device, dtype=torch.float32)
             dshift = slabs[ns * _r32(cout) * ktot:]
             kname = ""
             if _prof["on"]:
@@ -892,6 +999,13 @@ class FusedConv(torch.autograd.Function):
                 _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
                       _p(wg_amax[0]), _p(wg_amax[1]), _stream())
             ni = ctx.needs_input_grad
+            if defer:   # every needed gradient is a view of a flat bucket: hand the layer to the batched backward
+                outs = [p_.grad if (p_ is not None and need) else None for p_, need in zip(ctx.param_refs, ni[3:8])]
+                ptrs = tuple(None if t is None else t.data_ptr() for t in
+                             (slabs, dshift, v, g, bias, gamma, invnorm, outs[0], outs[1], outs[2], outs[3], outs[4], work))
+                _wn_defer(ptrs + ((cout, c1, c2, k, k, cfg.kind), ns),
+                          [p_ for p_, o in zip(ctx.param_refs, outs) if o is not None], (invnorm,))
+                return None, None, None, None, None
             params = (v, g, bias, gamma, gamma)  # beta has gamma's shape
             outs, direct = [], []
             for idx, (p_, need) in enumerate(zip(ctx.param_refs, ni[3:8])):
@@ -928,6 +1042,10 @@ class FusedConv(torch.autograd.Function):
         if ctx.need_w:
             ni_ = ctx.needs_input_grad
             all_direct = all((not ni_[3 + i]) or p_ is None or _has_direct_grad(p_) for i, p_ in enumerate(ctx.param_refs))
+            # batched weight-norm backward: not while a hipGraph is being captured (its item tables are uploaded from host
+            # memory on first use; a captured step keeps the per-layer launches -- same arithmetic, bit for bit)
+            defer_ok = (_wn_batch["on"] and ctx.prepacked and all_direct and dy.is_cuda
+                        and not torch.cuda.is_current_stream_capturing())
             if _wgrad_streams["on"] and all_direct and dy.is_cuda:
                 # weight gradients are off the critical path of backward (only the data gradient feeds the next
                 # layer): run wgrad + slab reduce + weight-norm backward on a companion stream; the results land in
@@ -939,9 +1057,9 @@ class FusedConv(torch.autograd.Function):
                     if t_ is not None:
                         t_.record_stream(wstream)
                 with torch.cuda.stream(wstream):
-                    weight_gradients()
+                    weight_gradients(defer_ok)
             else:
-                dv, dg, dbias, dgamma, dbeta = weight_gradients()
+                dv, dg, dbias, dgamma, dbeta = weight_gradients(defer_ok)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             def dgrad(x, cs, m_off, seed, add):

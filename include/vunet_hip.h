@@ -223,6 +223,20 @@ int vunet_weightnorm_bwd(const vunet_wn_desc* d, const float* slabs, const float
                          const float* invnorm, float* dv, float* dg, float* dbias, float* dgamma,
                          float* dbeta, float* workspace, int32_t accumulate, void* stream);
 
+/* Batched form: the slab reduction and parameter gradients of many layers in two launches (one grid row per layer).
+ * items_dev: DEVICE array of n_items entries, fields as the arguments of vunet_weightnorm_bwd; max_cout = max Cout over
+ * the items, max_reduce_blocks = max over the items of Cout * ceil(KH*KW*(C1+C2) / 64).  Replaces, per training step,
+ * the 2 launches per layer the autograd of torch._weight_norm + the gamma/beta affine issue (lib/modules.py:120-145). */
+typedef struct vunet_wn_bwd_item {
+  const float *slabs, *dshift, *v, *g, *bias, *gamma, *invnorm;
+  float *dv, *dg, *dbias, *dgamma, *dbeta;
+  float* workspace;
+  vunet_wn_desc d;
+  int32_t nsplit, accumulate;
+} vunet_wn_bwd_item;
+int vunet_weightnorm_bwd_multi(const vunet_wn_bwd_item* items_dev, int32_t n_items, int32_t max_cout,
+                               int32_t max_reduce_blocks, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Pointwise / index / reduction kernels (HBM-bound)
  * ------------------------------------------------------------------------------------------ */
@@ -305,10 +319,12 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *   VUNET_TUNE_SPLIT_FORCE_NT  tile height (32-pixel rows per wave: 1, 2 or 4) of the split-fp16 / split-bf16 3x3 kernels
  *   VUNET_TUNE_TILED_FORCE_NT  the same for the LDS-tiled fp32 kernel
  *   VUNET_TUNE_FORCE_SMALL     1: vunet_conv2d_x6 takes the small-map K-split kernel wherever it covers the geometry
+ *   VUNET_TUNE_H2_BIG          1: the fp16 scheme's big workgroup tiles (128 ch x 8 rows / 64 ch x 16 rows, one workgroup per CU)
  * Returns VUNET_ERR_ARG for an unknown key. */
 #define VUNET_TUNE_SPLIT_FORCE_NT 0
 #define VUNET_TUNE_TILED_FORCE_NT 1
 #define VUNET_TUNE_FORCE_SMALL 2
+#define VUNET_TUNE_H2_BIG 3
 int vunet_set_tuning(int32_t key, int32_t value);
 
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */
