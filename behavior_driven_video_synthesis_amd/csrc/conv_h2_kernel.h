@@ -139,6 +139,15 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     vbits |= (ok ? 1u : 0u) << i;
   }
 
+#ifdef H2_SINGLE   // (experiment, tools/ab_build.sh: one accumulator set, low terms at natural scale)
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
+#else
   f32x16 acc[MT][NT], acx[MT][NT];   // leading term / the two cross terms (scaled by 2^11)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     for (int q = 0; q < NT; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][q][r] = acx[mt][q][r] = 0.f;
+#endif
 
   const int nch1 = d.C1 / 16, nch = nch1 + d.C2 / 16;
   float xv[NX][8];
@@ -284,6 +294,39 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
 #endif
       // row / column of the staged tile (origin row0-1, col0-1) that tap (kh, kw) reads for output row q, column j
       const int dr = PHW >= 0 ? (PH + 1 - kh) / 2 + 1 : (MODE == 0 ? kh : 2 - kh);
+#if defined(H2_PIPE)
+      // (experiment) fragment reads software-pipelined inside the phase: tap kw + 1 is read while tap kw multiplies
+      if constexpr (PHW < 0) {
+        H2Unit fa[2][2][MT], fb[2][2][NT];
+        auto rd = [&](int kw, H2Unit (&av)[2][MT], H2Unit (&bv)[2][NT]) {
+          const int dc = MODE == 0 ? kw : 2 - kw;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[p][mt].u = wA[buf * WUS + g * WU + ((mt * 3 + kw) * 2 + p) * 64];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) bv[p][q].u = xB[p * 2 * PIX + (q * RPQ + dr) * IW + dc];
+          }
+        };
+        rd(0, fa[0], fb[0]);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (kw + 1 < 3) rd(kw + 1, fa[(kw + 1) & 1], fb[(kw + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+              f32x16 cx = acc[mt][q];
+              cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][1][mt].b, fb[kw & 1][0][q].b, cx, 0, 0, 0);
+              cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][0][mt].b, fb[kw & 1][1][q].b, cx, 0, 0, 0);
+              cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][0][mt].b, fb[kw & 1][0][q].b, cx, 0, 0, 0);
+              acc[mt][q] = cx;
+            }
+        }
+      } else
+#endif
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         if (PHW >= 0 && ((kw + PW) & 1) == 0) continue;   // this parity's taps only: kw = pw + 1 (mod 2)
@@ -305,11 +348,19 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int q = 0; q < NT; ++q) {
+#ifdef H2_SINGLE
+            f32x16 cx = acc[mt][q];
+            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, cx, 0, 0, 0);
+            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, cx, 0, 0, 0);
+            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, cx, 0, 0, 0);
+            acc[mt][q] = cx;
+#else
             f32x16 cx = acx[mt][q];
             cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, cx, 0, 0, 0);
             cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, cx, 0, 0, 0);
             acx[mt][q] = cx;
             acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+#endif
           }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -358,7 +409,11 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
     f32x16 c;
 #pragma unroll
+#ifdef H2_SINGLE
+    for (int r = 0; r < 16; ++r) c[r] = acc[mt][q][r] * descale * descale2;
+#else
     for (int r = 0; r < 16; ++r) c[r] = (acc[mt][q][r] + acx[mt][q][r] * (1.f / 2048.f)) * descale * descale2;
+#endif
     return c;
   };
   float ymax = 0.f;   // max |y| over what this lane stores (published below if the caller asked for it)

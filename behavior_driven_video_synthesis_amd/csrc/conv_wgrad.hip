@@ -159,8 +159,15 @@ int vunet_wgrad_h2_name(const vunet_wgrad_desc* d, char* name, int len);
 int vunet_wgrad_h2_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
                           float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st);
 
+// conv_wgrad_direct.hip: small maps, stride 2, 1x1 on the fp16 matrix cores (d->flags bit 1), operands straight from global
+bool vunet_wgrad_direct_applicable(const vunet_wgrad_desc* d);
+int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d);
+int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len);
+int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
+                              float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st);
+
 extern "C" int vunet_conv2d_wgrad_wants_split(const vunet_wgrad_desc* d) {
-  return d && vunet_wgrad_x6_applicable(d) ? 1 : 0;
+  return d && (vunet_wgrad_x6_applicable(d) || vunet_wgrad_direct_applicable(d)) ? 1 : 0;
 }
 
 extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len) {
@@ -168,6 +175,10 @@ extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name,
   if (vunet_wgrad_x6_applicable(d)) {
     if (d->flags & 2) vunet_wgrad_h2_name(d, name, len);
     else vunet_wgrad_x6_name(d, name, len);
+    return VUNET_OK;
+  }
+  if (vunet_wgrad_direct_applicable(d)) {
+    vunet_wgrad_direct_name(d, name, len);
     return VUNET_OK;
   }
   if (vunet_wgrad_tiled_applicable(d)) {
@@ -186,6 +197,7 @@ extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name,
 extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
   if (!d) return VUNET_ERR_ARG;
   if (vunet_wgrad_x6_applicable(d)) return vunet_wgrad_x6_nslabs(d);
+  if (vunet_wgrad_direct_applicable(d)) return vunet_wgrad_direct_nslabs(d);
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_nslabs(d);
   int T, Ctot, Coutp, nchunks, WM;
   wgrad_geometry(d, T, Ctot, Coutp, nchunks, WM);
@@ -224,6 +236,10 @@ extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, co
       return vunet_wgrad_h2_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_dy, (hipStream_t)stream);
     }
     return vunet_wgrad_x6_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
+  }
+  if (vunet_wgrad_direct_applicable(d)) {
+    if (!amax_x || !amax_dy) return VUNET_ERR_ARG;
+    return vunet_wgrad_direct_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_dy, (hipStream_t)stream);
   }
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
   WgradArgs wa;

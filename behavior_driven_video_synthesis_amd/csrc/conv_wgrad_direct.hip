@@ -1,0 +1,303 @@
+// Weight gradient on the fp16 matrix cores for the geometries conv_wgrad_h2.hip does not take: small maps (4 x 4 ... 16 x 16,
+// the VUnet bottleneck: models/vunets.py:520-597), the stride-2 Downsample convolutions (lib/modules.py:148-161) at every
+// map size, and the 1 x 1 `nin` layers (lib/modules.py:201-205) -- 3.5 ms and ~80 launches of fp32-input MFMA kernels at
+// 10 - 50 TFLOP/s per bs-16 step before round 3.
+//
+//   dW[co][tap][ci] = sum_px dy[co][px] * f(x)[ci][px (+) tap]          (K = output pixels)
+//
+// "Direct": no LDS.  Both MFMA operands of v_mfma_f32_32x32x16_f16 want, per lane, 8 consecutive K entries of one row /
+// column -- here 8 consecutive output pixels of one channel, which is how NCHW stores them.  So a lane loads its dy octet
+// (A: lane = output channel) and, for B (lane = input channel), the 3 (or S + 3) input rows its octet's taps touch -- the
+// row segment plus a halo column, 16-byte loads -- applies the prologue and the operand scale ONCE per loaded element, and
+// builds the nine tap fragments by selecting elements of those rows in registers (a tap is a column / row offset; at
+// stride 2 every other element).  Same operand split as conv_wgrad_h2.hip: power-of-two scales from the tensor maxima, two
+// fp16 terms with the low one at natural scale, three products into ONE accumulator per tap, nine accumulators per wave.
+// One wave owns a 32 x 32 (co, ci) tile for all taps and a contiguous range of pixel octets (split-K); slabs in the layout
+// vunet_weightnorm_bwd* reduces.  Channel counts need not be multiples of 32 (rows / columns past the end are zero).
+#include <type_traits>
+
+#include "common.h"
+#include "split_h2.h"
+
+struct WgradDirectArgs {
+  vunet_wgrad_desc d;
+  const float* x1;
+  const float* x2;
+  const float* dy;
+  float* slabs;
+  float* dshift;
+  const float* amax_x;
+  const float* amax_dy;
+  int Ctot, Coutp, ncot, noct, ops;   // co tiles; pixel octets in all; octets per split (even)
+  int opr, opi;                       // octets per output row / per image
+  InAct in1, in2;
+};
+
+typedef uint32_t wd_u32x4 __attribute__((ext_vector_type(4)));
+typedef float wd_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wd_split2(float a, float b, uint32_t& h, uint32_t& l) {   // low term at natural scale
+  h2_f16x2 ph, pl;
+  ph[0] = (_Float16)a;
+  ph[1] = (_Float16)b;
+  pl[0] = (_Float16)(a - (float)ph[0]);
+  pl[1] = (_Float16)(b - (float)ph[1]);
+  h = __builtin_bit_cast(uint32_t, ph);
+  l = __builtin_bit_cast(uint32_t, pl);
+}
+
+__device__ __forceinline__ h2_f16x8 wd_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  wd_u32x4 u = {a, b, c, d};
+  return __builtin_bit_cast(h2_f16x8, u);
+}
+
+// S: stride (1, 2).  W4: output maps 4 wide (an octet is two output rows of 4).  T: 9 (3x3, pad 1) or 1 (1x1, S = 1).
+template <int S, bool W4, int T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDirectArgs a_in) {
+  WgradDirectArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  // rows / loaded columns of the input one octet touches
+  constexpr int R = T == 1 ? 1 : (W4 ? S + 3 : 3);
+  constexpr int L = T == 1 ? 8 : (W4 ? 4 * S + 2 : 8 * S + 2);   // L - 1 used at S = 2 (no right halo)
+  const vunet_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int unit = blockIdx.x * 4 + wave;          // (split, co tile), co tile fastest: the waves of a workgroup share x
+  const int cot = unit % a.ncot, split = unit / a.ncot;
+  const int ci0 = blockIdx.y * 32;
+  const int H = d.Hs, W = d.Ws, HW = H * W, HoWo = d.Ho * d.Wo;
+
+  // ---- operand scales
+  float sx, sdy, descale, descale2;
+  {
+    __shared__ float redm[8];
+    const float4 px = reinterpret_cast<const float4*>(a.amax_x)[tid], pd = reinterpret_cast<const float4*>(a.amax_dy)[tid];
+    float mx = wave_max(fmaxf(fmaxf(px.x, px.y), fmaxf(px.z, px.w)));
+    float md = wave_max(fmaxf(fmaxf(pd.x, pd.y), fmaxf(pd.z, pd.w)));
+    if (lane == 0) { redm[wave] = mx; redm[4 + wave] = md; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    md = fmaxf(fmaxf(redm[4], redm[5]), fmaxf(redm[6], redm[7]));
+    if (a.in1.thresh) mx *= a.in1.keep_scale;
+    const int ex = h2_scale_exp(mx), ed = h2_scale_exp(md);
+    sx = h2_pow2(ex);
+    sdy = h2_pow2(ed);
+    h2_pow2_pair(-(ex + ed), descale, descale2);
+  }
+  if (split >= d.nsplit) return;   // (grid rounded up to whole workgroups; after the only barrier)
+
+  const int ci = ci0 + j;
+  const bool ci_ok = ci < a.Ctot;
+  const bool second = ci_ok && ci >= d.C1;
+  const float* __restrict__ xs = second ? a.x2 : a.x1;
+  const int Cs = second ? d.C2 : d.C1;
+  const int cl = ci_ok ? (second ? ci - d.C1 : ci) : 0;
+  InAct ia = a.in1;
+  ia.seed = second ? a.in2.seed : a.in1.seed;
+  const int co = cot * 32 + j;
+  const bool co_ok = co < d.Cout;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float dsum = 0.f;
+
+  const int o_begin = split * a.ops, o_end = min(o_begin + a.ops, a.noct);
+  // (1x1: four K steps unrolled, so that their loads -- the whole cost of this HBM-bound case -- are in flight together)
+#pragma unroll(T == 1 ? 4 : 1)
+  for (int o2 = o_begin; o2 < o_end; o2 += 2) {
+    const int o = o2 + h;                     // this lane's octet (the k-half of the lane)
+    const bool ov = o < o_end;
+    const int oc = ov ? o : o_begin;
+    const int n = oc / a.opi, rem = oc - n * a.opi;
+    int r0, c0;                               // first output row / column of the octet
+    if (T == 1) { r0 = 0; c0 = rem * 8; }     // (1x1: a flat pixel offset inside the image)
+    else if (W4) { r0 = rem * 2; c0 = 0; }
+    else { r0 = rem / a.opr; c0 = (rem - r0 * a.opr) * 8; }
+
+    // ---- A: 8 consecutive dy pixels of channel co
+    h2_f16x8 Ah, Al;
+    {
+      const float* dp = a.dy + (size_t)(n * d.Cout + (co_ok ? co : 0)) * HoWo + (T == 1 ? c0 : r0 * d.Wo + c0);
+      wd_f32x4 d0 = *reinterpret_cast<const wd_f32x4*>(dp), d1 = *reinterpret_cast<const wd_f32x4*>(dp + 4);
+      if (!(ov && co_ok)) { d0 = wd_f32x4{0.f, 0.f, 0.f, 0.f}; d1 = d0; }
+      dsum += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
+      uint32_t ah[4], al[4];
+      wd_split2(d0[0] * sdy, d0[1] * sdy, ah[0], al[0]);
+      wd_split2(d0[2] * sdy, d0[3] * sdy, ah[1], al[1]);
+      wd_split2(d1[0] * sdy, d1[1] * sdy, ah[2], al[2]);
+      wd_split2(d1[2] * sdy, d1[3] * sdy, ah[3], al[3]);
+      Ah = wd_frag(ah[0], ah[1], ah[2], ah[3]);
+      Al = wd_frag(al[0], al[1], al[2], al[3]);
+    }
+
+    // ---- B source: R input rows x L columns of channel ci, prologue applied, scaled; seg[rr][0] is input column
+    //      S * c0 - 1 (the left halo), rows start at S * r0 - 1
+    float seg[R][L];
+    {
+      const uint32_t cbase = (uint32_t)(n * Cs + cl) * (uint32_t)HW;
+      const float* xp = xs + cbase;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const int ih = T == 1 ? 0 : S * r0 - 1 + rr;
+        const bool rok = ov && ci_ok && (T == 1 || (unsigned)ih < (unsigned)H);
+        const int ihc = rok ? ih : 0;
+        if (T == 1) {
+          const uint32_t off = (uint32_t)c0;
+          const wd_f32x4 v0 = *reinterpret_cast<const wd_f32x4*>(xp + off), v1 = *reinterpret_cast<const wd_f32x4*>(xp + off + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t_ = e < 4 ? v0[e] : v1[e - 4];
+            seg[rr][e] = rok ? apply_in_act(ia, t_, cbase + off + e) * sx : 0.f;
+          }
+        } else {
+          constexpr int NV = (L - 2) / 4;      // aligned 16-byte loads per row: columns S*c0 .. S*c0 + 4*NV - 1
+          const uint32_t off = (uint32_t)(ihc * W + S * c0);
+          wd_f32x4 v[NV];
+#pragma unroll
+          for (int q = 0; q < NV; ++q) v[q] = *reinterpret_cast<const wd_f32x4*>(xp + off + 4 * q);
+          const bool lok = rok && c0 > 0, hok = rok && S == 1 && S * c0 + 4 * NV < W;
+          const float lv = xp[lok ? off - 1 : off];
+          const float hv = xp[hok ? off + 4 * NV : off];
+          seg[rr][0] = lok ? apply_in_act(ia, lv, cbase + off - 1) * sx : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4 * NV; ++e)
+            seg[rr][1 + e] = rok ? apply_in_act(ia, v[e >> 2][e & 3], cbase + off + e) * sx : 0.f;
+          seg[rr][L - 1] = hok ? apply_in_act(ia, hv, cbase + off + 4 * NV) * sx : 0.f;
+        }
+      }
+    }
+
+    // ---- nine taps: fragment = 8 elements selected from the rows, split, three products
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int kh = t / 3, kw = t % 3;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (T == 1) f[e] = seg[0][e];
+        else if (W4) f[e] = seg[(e >> 2) * S + kh][(e & 3) * S + kw];
+        else f[e] = seg[kh][e * S + kw];
+      }
+      uint32_t bh[4], bl[4];
+      wd_split2(f[0], f[1], bh[0], bl[0]);
+      wd_split2(f[2], f[3], bh[1], bl[1]);
+      wd_split2(f[4], f[5], bh[2], bl[2]);
+      wd_split2(f[6], f[7], bh[3], bl[3]);
+      const h2_f16x8 Bh = wd_frag(bh[0], bh[1], bh[2], bh[3]), Bl = wd_frag(bl[0], bl[1], bl[2], bl[3]);
+      f32x16 cc = acc[t];
+      cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, cc, 0, 0, 0);
+      cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, cc, 0, 0, 0);
+      cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, cc, 0, 0, 0);
+      acc[t] = cc;
+    }
+  }
+
+  // ---- partial slab of this split:  [split][Coutp][T * Ctot], k order (tap, ci)
+  const size_t KT = (size_t)T * a.Ctot;
+  float* slab = a.slabs + (size_t)split * a.Coutp * KT;
+  if (ci_ok) {
+    auto store = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cr = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (cr < d.Cout) slab[(size_t)cr * KT + (size_t)t * a.Ctot + ci] = acc[t][r] * descale * descale2;
+      }
+    };
+    store(std::integral_constant<int, 0>{});
+    if constexpr (T == 9) {
+      store(std::integral_constant<int, 1>{});
+      store(std::integral_constant<int, 2>{});
+      store(std::integral_constant<int, 3>{});
+      store(std::integral_constant<int, 4>{});
+      store(std::integral_constant<int, 5>{});
+      store(std::integral_constant<int, 6>{});
+      store(std::integral_constant<int, 7>{});
+      store(std::integral_constant<int, 8>{});
+    }
+  }
+  if (blockIdx.y == 0) {
+    const float tot = dsum + __shfl_xor(dsum, 32, 64);
+    if (h == 0 && co < a.Coutp) a.dshift[(size_t)split * a.Coutp + co] = co_ok ? tot : 0.f;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// geometry class: 0 not covered; else (S, W4, T) packed
+static int direct_class(const vunet_wgrad_desc* d) {
+  if (!(d->flags & 2) || (d->flags & 1)) return 0;   // the fp16 scheme only
+  if (d->C1 <= 0 || d->Cout <= 0 || (d->C2 > 0 && d->C1 % 32 != 0)) return 0;
+  if (d->Cout < 16 && d->KH == 3) return 0;          // (out_conv, 3 output channels: a 32-row tile would multiply 90 % zeros)
+  if (d->KH == 1 && d->KW == 1) {
+    if (d->stride != 1 || d->pad != 0 || d->Ho != d->Hs || d->Wo != d->Ws || (d->Hs * d->Ws) % 8) return 0;
+    return 1;
+  }
+  if (d->KH != 3 || d->KW != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2)) return 0;
+  if (d->Ho != (d->Hs - 1) / d->stride + 1 || d->Wo != (d->Ws - 1) / d->stride + 1) return 0;
+  if (d->Ws % 4) return 0;                           // 16-byte row loads
+  if (d->Wo == 4 && d->Ws == 4 * d->stride && d->Ho % 2 == 0) return d->stride == 1 ? 2 : 3;
+  if (d->Wo % 8 == 0 && d->Ws == d->Wo * d->stride) return d->stride == 1 ? 4 : 5;
+  return 0;
+}
+
+bool vunet_wgrad_direct_applicable(const vunet_wgrad_desc* d) { return direct_class(d) != 0; }
+
+static void direct_geometry(const vunet_wgrad_desc* d, WgradDirectArgs& a) {
+  const int cls = direct_class(d);
+  a.Ctot = d->C1 + d->C2;
+  a.Coutp = (d->Cout + 31) / 32 * 32;
+  a.ncot = a.Coutp / 32;
+  if (cls == 1) { a.opr = 0; a.opi = d->Hs * d->Ws / 8; }
+  else if (cls == 2 || cls == 3) { a.opr = 0; a.opi = d->Ho / 2; }
+  else { a.opr = d->Wo / 8; a.opi = d->Ho * a.opr; }
+  a.noct = d->N * a.opi;
+}
+
+// Pixel splits: about 2048 waves in all (eight per CU), every wave at least four K steps (eight octets) where the
+// problem has them; few splits for the tiny maps (a slab is written per split).
+int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d) {
+  WgradDirectArgs a;
+  direct_geometry(d, a);
+  const int ncit = (a.Ctot + 31) / 32;
+  int S = 2048 / (a.ncot * ncit);
+  const int by_work = (a.noct + 7) / 8;
+  if (S > by_work) S = by_work;
+  if (S < 1) S = 1;
+  const int cap = d->KH == 1 ? 2048 : 512;   // (a 1x1 slab is one 4 KB tile: many splits cost nothing)
+  if (S > cap) S = cap;
+  return S;
+}
+
+int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len) {
+  const int cls = direct_class(d);
+  const int S = (cls == 3 || cls == 5) ? 2 : 1, W4 = (cls == 2 || cls == 3), T = cls == 1 ? 1 : 9;
+  return snprintf(name, len, "conv_wgrad_direct_kernel<%d, %s, %d>", S, W4 ? "true" : "false", T);
+}
+
+int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
+                              float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st) {
+  const int cls = direct_class(d);
+  if (!cls) return VUNET_ERR_UNSUPPORTED;
+  WgradDirectArgs a;
+  a.d = *d;
+  a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift; a.amax_x = amax_x; a.amax_dy = amax_dy;
+  direct_geometry(d, a);
+  a.ops = (a.noct + d->nsplit - 1) / d->nsplit;
+  a.ops = (a.ops + 1) & ~1;   // whole K steps of two octets
+  a.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
+  a.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
+  const int units = d->nsplit * a.ncot;
+  dim3 grid((unsigned)((units + 3) / 4), (unsigned)((a.Ctot + 31) / 32)), block(256);
+  switch (cls) {
+    case 1: VUNET_LAUNCH((conv_wgrad_direct_kernel<1, false, 1>), grid, block, 0, st, a); break;
+    case 2: VUNET_LAUNCH((conv_wgrad_direct_kernel<1, true, 9>), grid, block, 0, st, a); break;
+    case 3: VUNET_LAUNCH((conv_wgrad_direct_kernel<2, true, 9>), grid, block, 0, st, a); break;
+    case 4: VUNET_LAUNCH((conv_wgrad_direct_kernel<1, false, 9>), grid, block, 0, st, a); break;
+    default: VUNET_LAUNCH((conv_wgrad_direct_kernel<2, false, 9>), grid, block, 0, st, a); break;
+  }
+  return vunet_check_launch();
+}

@@ -183,3 +183,87 @@ def test_small_data_gradient_vs_fp64(case):
     sc = max(float(ref.abs().max()), 1.0)
     assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * sc, name="dx")
     assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * sc
+
+
+# ---- weight gradient of the same layers: conv_wgrad_direct_kernel (csrc/conv_wgrad_direct.hip)
+# (n, c1, c2, cout, hs, ws, k, stride, in_act, drop)
+WGRAD = [
+    (16, 128, 0, 128, 4, 4, 3, 1, 1, 0.05),     # 4 x 4 bottleneck conv: octets of two rows
+    (4, 128, 128, 128, 8, 8, 3, 1, 1, 0.05),    # two sources at 8 x 8
+    (2, 64, 0, 96, 16, 16, 3, 1, 1, 0.0),       # 16 x 16, Cout = 96 (three co tiles, the last unit of a workgroup idle)
+    (2, 32, 0, 32, 6, 24, 3, 1, 0, 0.0),        # non-square, three octets per row: left / interior / right halo columns
+    (16, 128, 0, 128, 8, 8, 3, 2, 0, 0.0),      # Downsample 8 -> 4: 4-wide output, five input rows per octet
+    (4, 64, 0, 128, 16, 16, 3, 2, 0, 0.0),      # Downsample 16 -> 8
+    (2, 32, 0, 64, 64, 64, 3, 2, 0, 0.0),       # Downsample on a large map (the 256 -> 128 layer at reduced size)
+    (2, 32, 0, 32, 7, 16, 3, 2, 1, 0.0),        # odd input height: the last tap row falls outside
+    (2, 32, 0, 32, 32, 32, 1, 1, 1, 0.0),       # 1 x 1 nin, ELU prologue
+    (3, 64, 32, 128, 8, 8, 1, 1, 1, 0.05),      # 1 x 1, two sources, dropout
+    (2, 3, 0, 32, 16, 16, 1, 1, 0, 0.0),        # 1 x 1 on the 3-channel input (columns past the end are zero)
+    (2, 32, 0, 16, 16, 16, 3, 1, 0, 0.0),       # 16 output channels: half of the co tile is zero rows
+]
+
+
+@pytest.mark.parametrize("case", WGRAD)
+def test_direct_weight_gradient_vs_fp64(case):
+    ops = _ops()
+    n, c1, c2, cout, hs, ws, k, stride, in_act, drop = case
+    pad = 1 if k == 3 else 0
+    ho, wo = (hs + 2 * pad - k) // stride + 1, (ws + 2 * pad - k) // stride + 1
+    g_ = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x1 = torch.randn(n, c1, hs, ws, generator=g_).cuda()
+    x2 = torch.randn(n, c2, hs, ws, generator=g_).cuda() if c2 else None
+    dy = torch.randn(n, cout, ho, wo, generator=g_).cuda()
+    seed = 0xFACE
+    ctot, ktot = c1 + c2, k * k * (c1 + c2)
+
+    def run(flags):
+        wd = ops.WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=stride, pad=pad,
+                           in_act=in_act, in_slope=0.0, drop_p=drop, drop_seed=seed, nsplit=1, flags=flags)
+        buf = ctypes.create_string_buffer(96)
+        ops._call("vunet_conv2d_wgrad_variant", ctypes.byref(wd), buf, 96)
+        ns = ops._lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
+        assert ns >= 1
+        wd.nsplit = ns
+        cp = ops._r32(cout)
+        slabs = torch.full((ns * cp * ktot + ns * cp,), float("nan"), device="cuda")
+        dshift = slabs[ns * cp * ktot:]
+        amx = ops.absmax_partials(x1, x2) if flags == 2 else None
+        amd = ops.absmax_partials(dy) if flags == 2 else None
+        ops._call("vunet_conv2d_wgrad", ctypes.byref(wd), ops._p(x1), ops._p(x2), ops._p(dy), ops._p(slabs),
+                  ops._p(dshift), ops._p(amx), ops._p(amd), ops._stream())
+        dw = torch.empty(cout, ctot, k, k, device="cuda")
+        db = torch.empty(cout, device="cuda")
+        v = torch.zeros(cout, ctot, k, k, device="cuda")
+        work = torch.empty(cout * (ktot + 1), device="cuda")
+        wn = ops.WnDesc(cout, c1, c2, k, k, 1, 0)
+        ops._call("vunet_weightnorm_bwd", ctypes.byref(wn), ops._p(slabs), ops._p(dshift), ns, ops._p(v), None, None,
+                  None, None, ops._p(dw), None, ops._p(db), None, None, ops._p(work), 0, ops._stream())
+        torch.cuda.synchronize()
+        return dw, db, buf.value.decode()
+
+    dwh, dbh, name = run(2)
+    dw3, db3, name3 = run(1)
+    assert name.startswith("conv_wgrad_direct_kernel"), name
+    assert not name3.startswith("conv_wgrad_direct_kernel"), name3
+    xs = []
+    for i, x in enumerate((x1, x2)):
+        if x is None:
+            continue
+        t = x.double().cpu()
+        if in_act == ops.ACT_ELU:
+            t = F.elu(t)
+        if drop > 0:
+            s = seed if i == 0 else (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF
+            t = t * dropout_keep_mask(tuple(x.shape), drop, s).double() * float(torch.tensor(1.0 / (1.0 - drop),
+                                                                                             dtype=torch.float32))
+        xs.append(t)
+    wz = torch.zeros(cout, ctot, k, k, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(torch.cat(xs, dim=1), wz, stride=stride, padding=pad) * dy.double().cpu()).sum().backward()
+    ref = wz.grad
+    sc = float(ref.abs().max())
+    eh = float((dwh.double().cpu() - ref).abs().max())
+    e3 = float((dw3.double().cpu() - ref).abs().max())
+    assert eh <= 3e-6 * sc, (eh, sc)
+    assert eh <= 5.0 * e3 + 4e-7 * sc, (eh, e3, sc)
+    refb = dy.double().cpu().sum(dim=(0, 2, 3))
+    assert float((dbh.double().cpu() - refb).abs().max()) <= 1e-5 * max(float(refb.abs().max()), 1.0)
