@@ -275,6 +275,7 @@ class ShapePoseNet:
             out["gen_loss"] = gen_loss.detach()
             patches = (real_patch.detach(), fake_patch.detach())
         loss.backward()
+        self.averager.mark_backward_end()
         ops.flush_weight_grads()   # (normally already done by the end-of-backward callback) before the streams are joined
         self.vunet.join_streams()
         ops.join_wgrad_streams()

@@ -29,11 +29,20 @@ class BucketedGradAverager:
         self._works = []
         self._comm_stream = None          # HIP stream the bucket all-reduces are ordered on (GPU only)
         self._events = collections.deque(maxlen=16)   # per step: [(start, end) HIP events on that stream, one pair per collective]
+        self._bwd_end = collections.deque(maxlen=16)  # per step: the HIP event recorded where backward ended (or None)
         self._pending: List[int] = []
         self._expected: List[Optional[int]] = [None] * len(self.buckets)  # learnt on the first step
         self._fired: List[int] = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._fired_at_launch = [0] * len(self.buckets)
+        # Collectives pair up across ranks by ISSUE ORDER, so every rank must launch the bucket all-reduces in the same
+        # order whatever order its own backward completes them in: the order is learnt on the first step (completion
+        # order on rank 0, broadcast once) and from then on a bucket is launched only after its predecessors in it.
+        self._order: Optional[List[int]] = None
+        self._next_pos = 0
+        self._ready = [False] * len(self.buckets)
+        self._last_fire_seq = [1 << 60] * len(self.buckets)
+        self._seq = 0
         if self.active:
             from . import ops
             self._bucket_of = {}
@@ -48,14 +57,25 @@ class BucketedGradAverager:
     def _make_hook(self, bi):
         def hook(param):
             self._fired[bi] += 1
+            self._seq += 1
+            self._last_fire_seq[bi] = self._seq
             if self.overlap and self._expected[bi] is not None and self._fired[bi] == self._expected[bi]:
-                self._launch(bi)
+                self._ready[bi] = True
+                self._launch_ready()
         return hook
 
     def _direct_hook(self, param):
         bi = self._bucket_of.get(id(param))
         if bi is not None:
             self._make_hook(bi)(param)
+
+    def _launch_ready(self):
+        """Launch, in the agreed order, every bucket that is complete and whose predecessors have been launched."""
+        if self._order is None:
+            return
+        while self._next_pos < len(self._order) and self._ready[self._order[self._next_pos]]:
+            self._launch(self._order[self._next_pos])
+            self._next_pos += 1
 
     def _launch(self, bi):
         if self._launched[bi]:
@@ -95,6 +115,19 @@ class BucketedGradAverager:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._events.append([])
+        self._bwd_end.append(None)
+        self._next_pos = 0
+        self._ready = [False] * len(self.buckets)
+        self._seq = 0
+        self._last_fire_seq = [1 << 60] * len(self.buckets)
+
+    def mark_backward_end(self):
+        """Called by the training step right after ``loss.backward()``: a HIP event on the current stream that marks where
+        backward ended, against which ``overlap_fraction`` places the collectives."""
+        if self.active and self._bwd_end and torch.cuda.is_available() and self.buckets[0].grad.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._bwd_end[-1] = ev
 
     def finish(self, extra_scalars: Optional[torch.Tensor] = None):
         """Flush buckets that were not launched from the hooks, wait for all, scale by 1/world.
@@ -112,6 +145,14 @@ class BucketedGradAverager:
                                    f"all-reduce was launched after {self._fired_at_launch[bi]} (pattern learnt earlier); "
                                    "construct the averager with overlap=False for graphs that change between steps")
             self._expected[bi] = self._fired[bi]   # learnt on the first step, re-learnt if backward fired fewer hooks
+        if self._order is None:
+            # first step: agree on ONE launch order -- rank 0's completion order (buckets without gradients last)
+            order = sorted(range(len(self.buckets)), key=lambda i: (self._last_fire_seq[i], i))
+            t = torch.tensor(order, dtype=torch.int64, device=self.buckets[0].grad.device)
+            if self.world > 1:
+                dist.broadcast(t, src=0, group=self.pg)
+            self._order = [int(v) for v in t.tolist()]
+        for bi in self._order:                     # everything the hooks have not launched, in the agreed order
             self._launch(bi)
         if extra_scalars is not None:
             self._all_reduce(extra_scalars)
@@ -135,6 +176,40 @@ class BucketedGradAverager:
             return None
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for ev in steps for a, b in ev) / len(steps)
+
+
+    def overlap_fraction(self):
+        """Fraction of the gradient all-reduce time that ran BEFORE backward had finished on the compute stream, over
+        the recorded steps (HIP events: each collective's start / end on the communication stream against the
+        end-of-backward marker).  None without a process group or without markers.  Synchronises the device."""
+        if not self.active:
+            return None
+        torch.cuda.synchronize()
+        tot = hidden = 0.0
+        for evs, end in zip(self._events, self._bwd_end):
+            if end is None:
+                continue
+            for e0, e1 in evs:
+                dur = e0.elapsed_time(e1)
+                tot += dur
+                hidden += min(max(e0.elapsed_time(end), 0.0), dur)
+        return hidden / tot if tot > 0 else None
+
+    def replica_checksums(self):
+        """Bit-exact checksum of every flat parameter bucket (the int32 view summed in int64): equal across ranks iff the
+        replicas hold identical parameters."""
+        return torch.stack([b.flat.view(torch.int32).to(torch.int64).sum() for b in self.buckets])
+
+    def replicas_consistent(self) -> Optional[bool]:
+        """All-gather the bucket checksums and compare: True iff every rank holds bit-identical parameters -- the
+        invariant of synchronous data parallelism (same initial broadcast, same averaged gradients, same Adam)."""
+        if not dist.is_initialized():
+            return None
+        mine = self.replica_checksums()
+        world = dist.get_world_size(self.pg)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=self.pg)
+        return all(bool(torch.equal(g, gathered[0])) for g in gathered)
 
 
 def _scale_(t: torch.Tensor, a: float):

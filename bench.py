@@ -42,7 +42,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
 X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
 FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
-PMC_TRAFFIC = ["profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
+PMC_TRAFFIC = ["profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
 
 
 def parse():
@@ -224,6 +224,11 @@ def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
          "conv_ms_per_step": tot_ms / prof_steps,
          "whole_step_tflops": FLOP_PER_FRAME * batch / (1e-3 * ms_per_step) / 1e12}
     r["whole_step_vs_fp32_mfma_peak"] = r["whole_step_tflops"] / FP32_MFMA_PEAK_TFLOPS
+    # the same denominators for the WHOLE step: algorithmic FLOPs of the step / step time against the split kernel's roof,
+    # and the fp16 / bf16 MFMA FLOPs actually issued (products x algorithmic) against the dense 2.5 PFLOP/s peak
+    r["whole_step_frac"] = r["whole_step_tflops"] / peak
+    r["mfma_issued_frac_of_fp16_peak"] = ach * products / BF16_MFMA_PEAK_TFLOPS
+    r["whole_step_mfma_issued_frac_of_fp16_peak"] = r["whole_step_tflops"] * products / BF16_MFMA_PEAK_TFLOPS
     # HBM traffic per launch of the dominant kernel: separate rocprofv3 PMC passes (tools/profile.sh), committed summary
     for rel in PMC_TRAFFIC:
         try:
@@ -312,6 +317,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line.  Native libraries write there too (RCCL prints a version banner through C stdio when
+    # its first communicator comes up): keep the real stdout aside for the JSON line and point fd 1 at stderr meanwhile.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -365,8 +375,17 @@ def main():
                    "hip_streams": 1 if trainer.vunet._side_stream is None else 4,
                    "hip_graph": bool(trainer._graphs), "host_issue_ms_per_step": host_issue_ms,
                    "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
-                   "allreduce_ms_per_step": trainer.averager.mean_allreduce_ms()},
+                   "allreduce_ms_per_step": trainer.averager.mean_allreduce_ms(),
+                   # share of the all-reduce time that ran while backward was still computing (HIP events)
+                   "allreduce_overlap_frac": trainer.averager.overlap_fraction()},
     }
+    if dist.is_initialized():
+        # self-validation of the data-parallel run: after the timed steps every rank must hold bit-identical parameters
+        # (bucket checksums all-gathered and compared); a number from diverged replicas is not a result
+        ok = trainer.averager.replicas_consistent()
+        result["config"]["dp_consistent"] = ok
+        if not ok:
+            raise SystemExit(f"rank {rank}: replicas diverged after {args.warmup + args.steps} steps (bucket checksums differ)")
 
     if not args.no_roofline:
         # instrumented region: HIP events around every conv-family launch (same stream as the kernels).
@@ -424,7 +443,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, cfg, batch, cfg1, batch1)
     if rank == 0:
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

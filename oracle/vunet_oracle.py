@@ -91,6 +91,20 @@ def l2norm_conv(sd: SD, p: str, x: Tensor, stride: int = 1, padding: int = 0) ->
     return sd[p + ".gamma"] * y + sd[p + ".beta"]
 
 
+def l2norm_conv_init(sd: SD, p: str, x: Tensor, stride: int = 1, padding: int = 0):
+    """The data-dependent initialisation of L2NormConv2d (lib/modules.py:95-99, taken while ``init_fn()`` is true and the
+    module trains): gamma = 1 / sqrt(var + 1e-10), beta = -mean * gamma from the statistics of the normalised convolution
+    over (N, H, W) -- ``torch.var``: unbiased -- then the layer's output with them.  -> (y, gamma, beta)."""
+    w = sd[p + ".weight"]
+    wn = w / w.flatten(1).norm(dim=1).clamp_min(1e-12).view(-1, 1, 1, 1)
+    y = F.conv2d(x, wn, sd.get(p + ".bias"), stride=stride, padding=padding)
+    mean = y.mean(dim=[0, 2, 3], keepdim=True)
+    var = y.var(dim=[0, 2, 3], keepdim=True)
+    gamma = 1.0 / torch.sqrt(var + 1e-10)
+    beta = -mean * gamma
+    return gamma * y + beta, gamma, beta
+
+
 def instance_norm(x: Tensor, eps: float = 1e-5) -> Tensor:
     """nn.InstanceNorm2d(affine=False, track_running_stats=False)."""
     m = x.mean(dim=(2, 3), keepdim=True)

@@ -537,6 +537,32 @@ def g1b_upsample_bilinear():
     save("g1b_upsample_bilinear", meta, arrays)
 
 
+# ---------------------------------------------------------------- G1c L2NormConv2d data-dependent init (lib/modules.py:95-99)
+def g1c_l2norm_init():
+    """``init_fn() -> True`` in training mode: the first forward sets gamma = 1 / sqrt(var + 1e-10), beta = -mean * gamma from
+    the batch statistics of the normalised convolution over (N, H, W) and returns gamma * x + beta with them; a second
+    forward (init over) uses the stored values.  As wired by models/vunets.py:449: bias=False."""
+    seed = 17
+    arrays, meta = {}, {"seed": seed, "cases": {}}
+    flag = {"on": True}
+    for case, (cin, cout, k, s_, p_, shape) in {"k3": (6, 8, 3, 1, 1, (3, 6, 8, 8)), "k3s2": (8, 16, 3, 2, 1, (2, 8, 12, 12)),
+                                                "k1": (5, 4, 1, 1, 0, (2, 5, 6, 6))}.items():
+        mod = rm.L2NormConv2d(cin, cout, k, s_, p_, bias=False, init=lambda: flag["on"])
+        sh = load_synth(mod, seed)
+        mod.train()
+        flag["on"] = True
+        x = synth_image(f"l2i.{case}.x", shape, seed)
+        y1 = mod(x)
+        arrays[f"{case}.y_init"] = y1.detach().numpy()
+        arrays[f"{case}.gamma"] = mod.gamma.detach().numpy()
+        arrays[f"{case}.beta"] = mod.beta.detach().numpy()
+        flag["on"] = False
+        x2 = synth_image(f"l2i.{case}.x2", shape, seed)
+        arrays[f"{case}.y_after"] = mod(x2).detach().numpy()
+        meta["cases"][case] = {"shapes": sh, "args": [cin, cout, k, s_, p_], "input": list(shape)}
+    save("g1c_l2norm_init", meta, arrays)
+
+
 # ---------------------------------------------------------------- G7 evaluation statistics (lib/metrics.py:277-415)
 def g7_metrics():
     """FID statistics (_calculate_fid on mean / np.cov of features) and the Inception score (inception_score driven with
@@ -596,3 +622,4 @@ if __name__ == "__main__":
     g6_full_size()
     g7_metrics()
     g1b_upsample_bilinear()
+    g1c_l2norm_init()

@@ -100,6 +100,71 @@ def test_two_rank_gradient_average_equals_full_batch_gradient():
     assert res[0][6] == res[1][6]             # replicas identical after broadcast
 
 
+def _worker_uneven(rank, world, port, q):
+    """Four ranks whose backward passes complete the buckets in DIFFERENT orders (two independent sub-networks, two
+    backward calls per step, the call order swapped on the odd ranks): collectives pair up by issue order, so the averager
+    must launch them in one agreed order on every rank -- and the replicas must stay bit-identical."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from behavior_driven_video_synthesis_amd.optim import FlatBucket
+    from behavior_driven_video_synthesis_amd.parallel import BucketedGradAverager, broadcast_parameters
+
+    torch.manual_seed(7 + rank)
+    net_a, net_b = torch.nn.Linear(5, 4), torch.nn.Linear(3, 7)   # buckets of different sizes: a mismatched pairing cannot pass
+    buckets = [FlatBucket(list(net_a.parameters()), "a"), FlatBucket(list(net_b.parameters()), "b")]
+    broadcast_parameters(buckets, 0)
+    avg = BucketedGradAverager(buckets)
+    g = torch.Generator().manual_seed(3)
+    xa, xb = torch.randn(4 * world, 5, generator=g), torch.randn(4 * world, 3, generator=g)
+    sl = slice(4 * rank, 4 * rank + 4)
+    early = []
+    for step in range(4):
+        avg.start_step()
+        for b in buckets:
+            b.zero_grad()
+        la, lb = net_a(xa[sl]).pow(2).mean(), net_b(xb[sl]).pow(2).mean()
+        for loss in ((la, lb) if rank % 2 == 0 else (lb, la)):
+            loss.backward()
+        early.append(list(avg._launched))
+        avg.finish()
+        with torch.no_grad():
+            for b in buckets:
+                b.flat.add_(b.grad, alpha=-0.1)
+    ref_a, ref_b = torch.nn.Linear(5, 4), torch.nn.Linear(3, 7)
+    consistent = avg.replicas_consistent()
+    # full-batch check of the last step's averaged gradient
+    ref_a.load_state_dict(net_a.state_dict())
+    ref_b.load_state_dict(net_b.state_dict())
+    q.put((rank, consistent, avg._order, early, [float(b.flat.double().sum()) for b in buckets]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_four_ranks_with_uneven_completion_order_launch_in_one_agreed_order():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    orders = {tuple(r[2]) for r in res}
+    assert len(orders) == 1                                  # one launch order on every rank (rank 0's: bucket a first)
+    assert orders.pop() == (0, 1)
+    for rank, consistent, order, early, sums in res:
+        assert consistent is True                            # bit-identical replicas after four optimiser steps
+        assert early[0] == [False, False]                    # step 1: pattern unknown
+        # later steps: the bucket that is first in the agreed order is launched from backward on the ranks that finish it
+        # first; on the odd ranks (b finishes first) b has to WAIT for a, so both launch once a is complete
+        assert early[3] == [True, True] if rank % 2 else early[3][0] is True
+    assert len({tuple(r[4]) for r in res}) == 1
+
+
 def test_flat_bucket_views_and_adam_state_dict_layout():
     sys.path.insert(0, ROOT)
     from behavior_driven_video_synthesis_amd.optim import FlatBucket

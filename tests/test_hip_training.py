@@ -387,3 +387,93 @@ def test_split_schemes_match_fp32_on_a_full_size_step():
             assert rel <= 2e-4, (mode, rel)       # fp32 backward through ~100 layers: the fp32 run itself is this far from fp64
             print(f"{mode}: loss rel {abs(l - l32) / abs(l32):.2e}, image max {float((y - y32).abs().max() / y32.abs().max()):.2e}, "
                   f"bucket grad rel {rel:.2e}")
+
+
+def test_reference_shaped_loop_through_dropin_follows_the_trajectory(tmp_path):
+    """VERDICT r2 #8b: what the reference's OWN loop does with these modules -- imported under the reference's names through
+    ``dropin.install()``, a plain ``torch.optim.Adam`` over ``get_member`` param groups (autograd accumulates the
+    gradients: no flat buckets, no prepacked weights), ``vgg_loss`` dict, ``compute_kl_with_prior``, the host-side gamma /
+    lr rules of experiments/shape_and_pose_net.py:82-85,500-512, ``torch.randn_like`` for the posterior noise -- for the 3
+    steps of g5_trajectory.npz, which the reference's modules produced under the same loop on the CPU."""
+    import sys
+    import numpy as np
+    from conftest import load_golden
+    from hip_parity_utils import assert_close
+    from synth import seeded_randn, synth_image, synth_state_dict
+    from behavior_driven_video_synthesis_amd import dropin
+    co = tmp_path / "checkout"
+    (co / "lib").mkdir(parents=True)
+    (co / "models").mkdir()
+    (co / "lib" / "utils.py").write_text(
+        "from torch.nn import DataParallel\n"
+        "def get_member(model, name):\n"
+        "    return getattr(model.module, name) if isinstance(model, DataParallel) else getattr(model, name)\n")
+    for f in ("lib/modules.py", "lib/losses.py", "models/vunets.py", "models/imagenet_pretrained.py"):
+        (co / f).write_text("# the checkout's own file: every name the loop below uses comes from the MI355X package\n")
+    before_path, before_mods = list(sys.path), set(sys.modules)
+    orig_randn_like = torch.randn_like
+    try:
+        dropin.install(str(co))
+        from models.vunets import VunetAlter                      # the reference's import lines, verbatim
+        from models.imagenet_pretrained import PerceptualVGG, vgg19
+        from lib.losses import vgg_loss, compute_kl_with_prior
+        from lib.utils import get_member
+        meta, arr = load_golden("g5_trajectory")
+        seed = meta["seed"]
+        net = VunetAlter(n_channels_x=3, **meta["cfg"])
+        net.load_state_dict(synth_state_dict(meta["shapes"], seed))
+        net = net.to("cuda:0")
+        vgg = vgg19(pretrained=True, width_div=meta["vgg_width_div"], seed=meta["vgg_seed"], synthetic=True).to("cuda:0")
+        vgg.eval()
+        custom_vgg = PerceptualVGG(vgg, [1.0] * 6).to("cuda:0")
+        opt = torch.optim.Adam([{"params": get_member(net, n).parameters(), "name": n} for n in ("eu", "ed", "du", "dd")],
+                               lr=meta["lr0"], betas=tuple(meta["betas"]))
+        gamma, lr = meta["gamma0"], meta["lr0"]
+        net.train()
+        for rec in meta["steps"]:
+            it = rec["it"]
+            x = synth_image(f"traj.x{it}", (2, 3, 32, 32), seed).cuda()
+            c = synth_image(f"traj.c{it}", (2, 3, 32, 32), seed).cuda()
+            draws = {"i": 0}
+
+            def fake_randn_like(t, **kw):
+                e = seeded_randn(f"traj.{it}.eps{draws['i']}", tuple(t.shape), seed).to(t.device)
+                draws["i"] += 1
+                return e
+            torch.randn_like = fake_randn_like
+            img, means, logstds, _ = net(x, c)
+            torch.randn_like = orig_randn_like
+            assert draws["i"] == 2
+            ld = vgg_loss(custom_vgg, x, img)
+            ll = 1.0 * torch.sum(torch.stack([ld[k] for k in ld], dim=0))
+            kl = compute_kl_with_prior(means, logstds)
+            loss = ll
+            if it > meta["n_init_batches"]:
+                loss = loss + torch.tensor(gamma, device=kl.device) * kl
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            gamma = max(gamma - meta["gamma_step"] * (meta["imax"] - float(kl)), 0)
+            for key, got, want in (("loss", float(loss), rec["loss"]), ("ll", float(ll), rec["ll"]),
+                                   ("kl", float(kl), rec["kl"]), ("gamma", gamma, rec["gamma_after"])):
+                assert abs(got - want) <= 5e-4 * abs(want) + 1e-5, (it, key, got, want)
+            assert abs(lr - rec["lr"]) < 1e-12
+            lr = float(np.clip(float(0 - meta["lr0"]) / (meta["total_steps"] - 0) * (it - 0) + meta["lr0"], 0, meta["lr0"]))
+            for pg in opt.param_groups:
+                pg["lr"] = lr
+        sd = net.state_dict()
+        assert_close(sd["dd.out_conv.conv.weight_v"], arr["final.dd.out_conv.conv.weight_v"], rtol=2e-3, atol=2e-5,
+                     name="final weight")
+        for k, s in meta["param_checksums"].items():
+            got = float(sd[k].double().abs().sum())
+            assert abs(got - s[1]) <= 5e-4 * s[1] + 1e-5, (k, got, s[1])
+        # the regressor side loop's call shape (:413): encoder on encoder, four return values
+        with torch.no_grad():
+            hs, mu, ls, zs = net.ed(net.eu(x))
+        assert len(mu) == len(ls) == len(zs) == 2 and mu[0].shape == (2, 16, 4, 4)
+    finally:
+        torch.randn_like = orig_randn_like
+        sys.path[:] = before_path
+        for name in set(sys.modules) - before_mods:
+            if name.split(".")[0] in ("lib", "models") or name.startswith("_vunet_ref_"):
+                del sys.modules[name]

@@ -55,6 +55,24 @@ def test_g1_primitives(case):
         close(p.grad, arr[f"{case}.gp.{k}"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("case", ["k3", "k3s2", "k1"])
+def test_g1c_l2norm_data_dependent_init(case):
+    """lib/modules.py:95-99 with ``init_fn() -> True``: gamma / beta from the batch statistics, the output with them, and
+    the next forward with the stored values -- oracle against what the reference's L2NormConv2d produced."""
+    meta, arr = load_golden("g1c_l2norm_init")
+    seed, info = meta["seed"], meta["cases"][case]
+    cin, cout, k, stride, pad = info["args"]
+    sd = _prefixed(synth_state_dict(info["shapes"], seed))
+    x = synth_image(f"l2i.{case}.x", tuple(info["input"]), seed)
+    y, gamma, beta = O.l2norm_conv_init(sd, "", x, stride, pad)
+    close(gamma, arr[f"{case}.gamma"], rtol=1e-5, atol=1e-6)
+    close(beta, arr[f"{case}.beta"], rtol=1e-5, atol=1e-6)
+    close(y, arr[f"{case}.y_init"])
+    sd[".gamma"], sd[".beta"] = gamma, beta
+    x2 = synth_image(f"l2i.{case}.x2", tuple(info["input"]), seed)
+    close(O.l2norm_conv(sd, "", x2, stride, pad), arr[f"{case}.y_after"])
+
+
 def _model_loss(outs, tag, seed):
     flat = []
     for o in outs:
