@@ -117,11 +117,171 @@ __device__ bool r_in_poly(const RPoly& P, int x, int y, int H) {
   return false;
 }
 
+
+// ---- thick lines (cv2.line thickness > 1, lib/utils.py:334-339): OpenCV's ThickLine = FillConvexPoly of a quad in 16.16
+// fixed point (outline by Line2, then the two-chain scan line) + a filled Circle at both end points, restated as per-pixel
+// closed forms.  One thread per command walks FillConvexPoly's edge chains once and records, per chain, the rows at which a
+// new edge segment starts and its (x, dx): a pixel then evaluates x_chain(y) = xs + (y - ybeg) * dx directly.  The circle's
+// midpoint iteration only depends on the radius: one half-width table per frame.
+#define R_MAXSEG 5
+#define R_MAXRAD 40
+struct RLine2 {
+  int valid, xmajor, m0, ecount, ex, ey;
+  long long f0, step;
+};
+struct RThick {
+  int quad, fill, ymin, ylast;
+  int nseg[2];
+  int ybeg[2][R_MAXSEG];
+  long long xs[2][R_MAXSEG], dx[2][R_MAXSEG];
+  RLine2 ol[4];
+  int cx[2], cy[2];
+};
+
+// OpenCV Line2 between two 16.16 points reduced to its parameters
+__device__ RLine2 r_make_line2(long long x1, long long y1, long long x2, long long y2, int W, int H) {
+  RLine2 L;
+  L.valid = r_clip((long long)W << XY_SHIFT, (long long)H << XY_SHIFT, x1, y1, x2, y2) ? 1 : 0;
+  long long dx = x2 - x1, dy = y2 - y1;
+  const long long j = dx < 0 ? -1 : 0, ax = (dx ^ j) - j;
+  const long long i = dy < 0 ? -1 : 0, ay = (dy ^ i) - i;
+  L.xmajor = ax > ay;
+  if (L.xmajor) {
+    dy = (dy ^ j) - j;
+    if (j) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+    L.step = (dy << XY_SHIFT) / (ax | 1);
+    L.ecount = (int)((x2 - x1) >> XY_SHIFT);
+    L.m0 = (int)((x1 + (XY_ONE >> 1)) >> XY_SHIFT);
+    L.f0 = y1 + (XY_ONE >> 1);
+  } else {
+    dx = (dx ^ i) - i;
+    if (i) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+    L.step = (dx << XY_SHIFT) / (ay | 1);
+    L.ecount = (int)((y2 - y1) >> XY_SHIFT);
+    L.m0 = (int)((y1 + (XY_ONE >> 1)) >> XY_SHIFT);
+    L.f0 = x1 + (XY_ONE >> 1);
+  }
+  L.ex = (int)((x2 + (XY_ONE >> 1)) >> XY_SHIFT);
+  L.ey = (int)((y2 + (XY_ONE >> 1)) >> XY_SHIFT);
+  return L;
+}
+
+__device__ __forceinline__ bool r_on_line2(const RLine2& L, int x, int y) {
+  if (!L.valid) return false;
+  if (x == L.ex && y == L.ey) return true;
+  const int k = (L.xmajor ? x : y) - L.m0;
+  if (k < 0 || k > L.ecount) return false;
+  const int minor = (int)((L.f0 + (long long)k * L.step) >> XY_SHIFT);
+  return L.xmajor ? (y == minor) : (x == minor);
+}
+
+// ThickLine's quad + FillConvexPoly's chain walk for the segment (ax, ay) -> (bx, by) (integer pixel coordinates)
+__device__ void r_make_thick(RThick& T, long long ax, long long ay, long long bx, long long by, int thickness, int W, int H) {
+  const long long p0x = ax << XY_SHIFT, p0y = ay << XY_SHIFT, p1x = bx << XY_SHIFT, p1y = by << XY_SHIFT;
+  T.cx[0] = (int)((p0x + (XY_ONE >> 1)) >> XY_SHIFT);
+  T.cy[0] = (int)((p0y + (XY_ONE >> 1)) >> XY_SHIFT);
+  T.cx[1] = (int)((p1x + (XY_ONE >> 1)) >> XY_SHIFT);
+  T.cy[1] = (int)((p1y + (XY_ONE >> 1)) >> XY_SHIFT);
+  T.quad = T.fill = 0;
+  T.nseg[0] = T.nseg[1] = 0;
+  const double dx = (double)(p0x - p1x) * (1.0 / XY_ONE), dy = (double)(p1y - p0y) * (1.0 / XY_ONE);
+  double r = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+  const int odd = thickness & 1;
+  const int th = thickness << (XY_SHIFT - 1);
+  if (!(fabs(r) > 2.220446049250313e-16)) return;
+  r = __ddiv_rn((double)th + odd * XY_ONE * 0.5, __dsqrt_rn(r));
+  const long long dpx = __double2ll_rn(__dmul_rn(dy, r)), dpy = __double2ll_rn(__dmul_rn(dx, r));   // cvRound: half to even
+  long long vx[4] = {p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx};
+  long long vy[4] = {p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy};
+  T.quad = 1;
+  const int delta = XY_ONE >> 1;
+  int imin = 0;
+  long long xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+  long long qx = vx[3], qy = vy[3];
+  for (int i = 0; i < 4; ++i) {
+    if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+    ymax = max(ymax, vy[i]);
+    xmax = max(xmax, vx[i]);
+    xmin = min(xmin, vx[i]);
+    T.ol[i] = r_make_line2(qx, qy, vx[i], vy[i], W, H);
+    qx = vx[i];
+    qy = vy[i];
+  }
+  xmin = (xmin + delta) >> XY_SHIFT;
+  xmax = (xmax + delta) >> XY_SHIFT;
+  ymin = (ymin + delta) >> XY_SHIFT;
+  ymax = (ymax + delta) >> XY_SHIFT;
+  if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= W || (int)ymin >= H) return;
+  if (ymax > H - 1) ymax = H - 1;
+  // the two edge chains from the top vertex: chain 0 walks the vertices forwards, chain 1 backwards
+  int idxc[2] = {imin, imin}, yec[2], di[2] = {1, 3};
+  int y = (int)ymin, edges = 4;
+  yec[0] = yec[1] = y;
+  T.ymin = y;
+  T.ylast = y - 1;
+  do {
+    for (int i = 0; i < 2; ++i) {
+      if (y >= yec[i]) {
+        int idx0 = idxc[i], idx = idx0 + di[i];
+        if (idx >= 4) idx -= 4;
+        for (; edges-- > 0;) {
+          const int ty = (int)((vy[idx] + delta) >> XY_SHIFT);
+          if (ty > y) {
+            const long long xs = vx[idx0], xe = vx[idx];
+            yec[i] = ty;
+            const int s = T.nseg[i] < R_MAXSEG ? T.nseg[i]++ : R_MAXSEG - 1;
+            T.ybeg[i][s] = y;
+            T.xs[i][s] = xs;
+            T.dx[i][s] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+            idxc[i] = idx;
+            break;
+          }
+          idx0 = idx;
+          idx += di[i];
+          if (idx >= 4) idx -= 4;
+        }
+      }
+    }
+    if (edges < 0) break;
+    T.ylast = y;
+  } while (++y <= (int)ymax);
+  T.fill = T.nseg[0] > 0 && T.nseg[1] > 0;
+}
+
+__device__ bool r_in_thick(const RThick& T, const int* __restrict__ hw, int radius, int x, int y, int W) {
+  // end caps: filled circles (rows cy +- ry with |x - cx| <= hw[ry])
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int ry = abs(y - T.cy[e]);
+    if (ry <= radius && abs(x - T.cx[e]) <= hw[ry]) return true;
+  }
+  if (!T.quad) return false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (r_on_line2(T.ol[i], x, y)) return true;
+  if (!T.fill || y < T.ymin || y > T.ylast || y < 0) return false;
+  long long xe[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int s = 0;
+    for (int q = 1; q < T.nseg[i]; ++q)
+      if (T.ybeg[i][q] <= y) s = q;
+    xe[i] = T.xs[i][s] + (long long)(y - T.ybeg[i][s]) * T.dx[i][s];
+  }
+  const long long lo = min(xe[0], xe[1]), hi = max(xe[0], xe[1]);
+  const int xx1 = (int)((lo + (XY_ONE >> 1)) >> XY_SHIFT), xx2 = (int)((hi + (XY_ONE >> 1)) >> XY_SHIFT);
+  return xx2 >= 0 && xx1 < W && xx1 <= x && x <= xx2;
+}
+
 __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __restrict__ kps, int J,
                                                               const int* __restrict__ body, int n_body,
                                                               const int* __restrict__ cmds, int n_cmds,
                                                               uint8_t* __restrict__ out_u8, float* __restrict__ out_f32,
-                                                              int H, int W) {
+                                                              int H, int W, int thickness) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char thick_raw[];   // RThick[n_cmds] when thickness > 1
+  RThick* const thick = reinterpret_cast<RThick*>(thick_raw);
+  __shared__ int chw[R_MAXRAD + 1];   // filled-circle half widths per row offset (thickness > 1)
+  const int radius = thickness > 1 ? ((thickness << (XY_SHIFT - 1)) + (XY_ONE >> 1)) >> XY_SHIFT : 0;
   __shared__ RLine lines[R_MAXCMD];
   __shared__ RPoly poly;
   __shared__ int ckind[R_MAXCMD], cplane[R_MAXCMD], ccolor[R_MAXCMD];
@@ -141,6 +301,10 @@ __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __res
       const float ax = k[2 * c[1]], ay = k[2 * c[1] + 1], bx = k[2 * c[2]], by = k[2 * c[2] + 1];
       if (ax >= 0.f && ay >= 0.f && bx >= 0.f && by >= 0.f) {
         L = r_make_line((long long)ax, (long long)ay, (long long)bx, (long long)by, W, H);
+        if (thickness > 1) {
+          r_make_thick(thick[tid], (long long)ax, (long long)ay, (long long)bx, (long long)by, thickness, W, H);
+          L.valid |= 1;   // a thick line is drawn whether or not its centre line survives the clip
+        }
         const double dx = (double)ax - (double)bx, dy = (double)ay - (double)by;
         len = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
         if (c[0] == 3) L.valid |= 2;   // face line: still waits for the throat-length test (bit 1)
@@ -153,6 +317,10 @@ __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __res
       if (rx >= 0.f && ry >= 0.f && lx >= 0.f && ly >= 0.f && hx >= 0.f && hy >= 0.f) {
         const double nx = 0.5 * ((double)rx + (double)lx), ny = 0.5 * ((double)ry + (double)ly);
         L = r_make_line((long long)nx, (long long)ny, (long long)hx, (long long)hy, W, H);
+        if (thickness > 1) {
+          r_make_thick(thick[tid], (long long)nx, (long long)ny, (long long)hx, (long long)hy, thickness, W, H);
+          L.valid |= 1;
+        }
         const double dx = nx - (double)hx, dy = ny - (double)hy;
         len = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
         L.valid |= 4;                  // drawn or not, a valid neck segment defines the throat length
@@ -160,6 +328,21 @@ __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __res
     }
     lines[tid] = L;
     clen[tid] = len;
+  }
+  if (tid == 254 && thickness > 1) {   // OpenCV Circle(fill): the midpoint iteration, widest span per row offset
+    for (int r = 0; r <= radius; ++r) chw[r] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+      chw[dy] = max(chw[dy], dx);
+      chw[dx] = max(chw[dx], dy);
+      dy++;
+      err += plus;
+      plus += 2;
+      const int mask = (err <= 0) - 1;
+      err -= minus & mask;
+      dx += mask;
+      minus -= mask & 2;
+    }
   }
   if (tid == 255) {  // the body polygon (shared by every polygon command)
     RPoly P;
@@ -225,7 +408,9 @@ __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __res
       int val[3] = {0, 0, 0};
       const bool inp = r_in_poly(poly, x, y, H);
       for (int c = 0; c < n_cmds; ++c) {
-        const bool hit = ckind[c] == 0 ? inp : r_on_line(lines[c], x, y);
+        const bool hit = ckind[c] == 0 ? inp
+                         : (thickness > 1 ? (lines[c].valid && r_in_thick(thick[c], chw, radius, x, y, W))
+                                          : r_on_line(lines[c], x, y));
         if (hit) val[cplane[c]] = ccolor[c];
       }
 #pragma unroll
@@ -247,14 +432,22 @@ __global__ __launch_bounds__(256) void stickman_raster_kernel(const float* __res
   }
 }
 
+extern "C" int vunet_stickman_raster_thick(const float* kps, int32_t B, int32_t J, const int32_t* body, int32_t n_body,
+                                           const int32_t* cmds, int32_t n_cmds, uint8_t* out_u8, float* out_f32, int32_t H,
+                                           int32_t W, int32_t thickness, void* stream) {
+  if (!kps || !cmds || (!out_u8 && !out_f32) || B < 1 || J < 1 || H < 1 || W < 4 || (W & 3)) return VUNET_ERR_ARG;
+  if (n_cmds < 0 || n_cmds > R_MAXCMD || n_body < 0 || n_body > R_MAXV || (n_body > 0 && !body)) return VUNET_ERR_ARG;
+  if (thickness < 1 || thickness > 2 * R_MAXRAD - 1) return VUNET_ERR_ARG;
+  int gy = (H * (W >> 2) + 255) / 256;
+  if (gy > 64) gy = 64;
+  const size_t lds = thickness > 1 ? (size_t)n_cmds * sizeof(RThick) : 0;
+  VUNET_LAUNCH(stickman_raster_kernel, dim3((unsigned)B, (unsigned)gy), dim3(256), lds, (hipStream_t)stream, kps, J, body,
+               n_body, cmds, n_cmds, out_u8, out_f32, H, W, thickness);
+  return vunet_check_launch();
+}
+
 extern "C" int vunet_stickman_raster(const float* kps, int32_t B, int32_t J, const int32_t* body, int32_t n_body,
                                      const int32_t* cmds, int32_t n_cmds, uint8_t* out_u8, float* out_f32, int32_t H,
                                      int32_t W, void* stream) {
-  if (!kps || !cmds || (!out_u8 && !out_f32) || B < 1 || J < 1 || H < 1 || W < 4 || (W & 3)) return VUNET_ERR_ARG;
-  if (n_cmds < 0 || n_cmds > R_MAXCMD || n_body < 0 || n_body > R_MAXV || (n_body > 0 && !body)) return VUNET_ERR_ARG;
-  int gy = (H * (W >> 2) + 255) / 256;
-  if (gy > 64) gy = 64;
-  VUNET_LAUNCH(stickman_raster_kernel, dim3((unsigned)B, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, kps, J, body,
-               n_body, cmds, n_cmds, out_u8, out_f32, H, W);
-  return vunet_check_launch();
+  return vunet_stickman_raster_thick(kps, B, J, body, n_body, cmds, n_cmds, out_u8, out_f32, H, W, 1, stream);
 }

@@ -119,11 +119,12 @@ _raster_tables = {}
 
 
 def make_joint_img_batch(img_shape, joints, joint_model=H36M_JOINT_MODEL, as_float=True, line_colors=None,
-                         color_channel=None):
+                         color_channel=None, thickness: int = 1):
     """Batched GPU make_joint_img: joints [B, J, 2] (x, y) device tensor -> [B, 3, H, W].
 
     ``as_float``: planes as fp32 in [-1, 1] (ToTensor then *2-1: data/base_dataset.py:183-190,
-    data/__init__.py:23-24) -- the tensor VunetAlter takes as ``c``; else the raw uint8 planes."""
+    data/__init__.py:23-24) -- the tensor VunetAlter takes as ``c``; else the raw uint8 planes.
+    ``thickness``: cv2.line's thickness for every line of the frame (lib/utils.py:334-339)."""
     from .. import ops
     h, w = int(img_shape[0]), int(img_shape[1])
     joints = joints.to(torch.float32).contiguous()
@@ -138,22 +139,22 @@ def make_joint_img_batch(img_shape, joints, joint_model=H36M_JOINT_MODEL, as_flo
     body, cmds = _raster_tables[key]
     b, j = joints.shape[0], joints.shape[1]
     out = torch.empty(b, 3, h, w, device=joints.device, dtype=torch.float32 if as_float else torch.uint8)
-    ops._call("vunet_stickman_raster", ops._p(joints), b, j, ops._p(body), body.numel(), ops._p(cmds), cmds.shape[0],
-              None if as_float else ops._p(out), ops._p(out) if as_float else None, h, w, ops._stream())
+    ops._call("vunet_stickman_raster_thick", ops._p(joints), b, j, ops._p(body), body.numel(), ops._p(cmds), cmds.shape[0],
+              None if as_float else ops._p(out), ops._p(out) if as_float else None, h, w, int(thickness), ops._stream())
     return out
 
 
 def make_joint_img(img_shape, joints, joint_model, line_colors=None, color_channel=None, scale_factor=None):
     """Reference signature (lib/utils.py:325-332): one frame, numpy in / HxWx3 uint8 numpy out (HxWx1 float mean when
-    ``img_shape[-1] == 1``, :507-509).  ``scale_factor`` selects thickness ``img_shape[1] // scale_factor`` (:334-339);
-    only thickness 1 is built -- the shipped configs never set ``stickman_scale`` (data/base_dataset.py:163-168), and a
-    thick cv2.line is OpenCV's ThickLine (FillConvexPoly + Circle caps), which this build does not restate."""
+    ``img_shape[-1] == 1``, :507-509).  ``scale_factor`` selects thickness ``img_shape[1] // scale_factor`` (:334-339, the
+    ``stickman_scale`` of data/base_dataset.py:163-168): a thick cv2.line is OpenCV's ThickLine (FillConvexPoly quad +
+    Circle caps), restated in csrc/raster.hip; cv2.line treats thickness 0 like 1."""
     thickness = int(img_shape[1] // scale_factor) if scale_factor is not None else 1
-    if thickness != 1:
-        raise NotImplementedError("make_joint_img: line thickness > 1 (stickman_scale) is not built")
+    if thickness < 0:
+        raise ValueError("make_joint_img: negative line thickness")   # (cv2.line raises too)
     j = torch.as_tensor(np.asarray(joints, dtype=np.float32)).unsqueeze(0).cuda()
     out = make_joint_img_batch(img_shape[:2], j, joint_model, as_float=False, line_colors=line_colors,
-                               color_channel=color_channel)
+                               color_channel=color_channel, thickness=max(thickness, 1))
     img = out[0].permute(1, 2, 0).cpu().numpy()
     if len(img_shape) > 2 and img_shape[-1] == 1:
         img = np.mean(img, axis=-1)[:, :, None]

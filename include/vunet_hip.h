@@ -343,6 +343,13 @@ int vunet_dropout_mask(float* mask, int64_t n, float p, uint32_t seed, void* str
 int vunet_stickman_raster(const float* kps, int32_t B, int32_t J, const int32_t* body, int32_t n_body,
                           const int32_t* cmds, int32_t n_cmds, uint8_t* out_u8, float* out_f32, int32_t H, int32_t W,
                           void* stream);
+/* The same with cv2.line's ``thickness`` (lib/utils.py:334-339: img_shape[1] // scale_factor, the `stickman_scale` of
+ * data/base_dataset.py:163-168) handed to every line of the frame: thickness > 1 is OpenCV's ThickLine -- a quad filled by
+ * FillConvexPoly in 16.16 fixed point (outline by Line2) plus a filled Circle at both end points -- as per-pixel closed
+ * forms; 1 <= thickness <= 79.  The body polygon (cv2.fillPoly) does not depend on it. */
+int vunet_stickman_raster_thick(const float* kps, int32_t B, int32_t J, const int32_t* body, int32_t n_body,
+                                const int32_t* cmds, int32_t n_cmds, uint8_t* out_u8, float* out_f32, int32_t H, int32_t W,
+                                int32_t thickness, void* stream);
 /* uint8 planes -> fp32 in [-1,1]  (ToTensor, *2-1; data/base_dataset.py:183-190) */
 int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* stream);
 

@@ -17,15 +17,16 @@ def build(force: bool = False) -> str:
     return LIB
 
 
-def raster(kps: np.ndarray, body, cmds, h: int, w: int) -> np.ndarray:
-    """kps [B, J, 2] float32 -> uint8 [B, 3, H, W] by the sequential OpenCV-4.1.2-style restatement."""
+def raster(kps: np.ndarray, body, cmds, h: int, w: int, thickness: int = 1) -> np.ndarray:
+    """kps [B, J, 2] float32 -> uint8 [B, 3, H, W] by the sequential OpenCV-4.1.2-style restatement; ``thickness``: the
+    cv2.line thickness of every line of the frame (lib/utils.py:334-339)."""
     lib = ctypes.CDLL(build())
     kps = np.ascontiguousarray(kps, dtype=np.float32)
     body = np.ascontiguousarray(body, dtype=np.int32)
     cmds = np.ascontiguousarray(cmds, dtype=np.int32).reshape(-1, 6)
     b, j = kps.shape[:2]
     out = np.zeros((b, 3, h, w), dtype=np.uint8)
-    lib.stickman_raster_oracle(kps.ctypes.data_as(ctypes.c_void_p), b, j, body.ctypes.data_as(ctypes.c_void_p),
-                               len(body), cmds.ctypes.data_as(ctypes.c_void_p), len(cmds),
-                               out.ctypes.data_as(ctypes.c_void_p), h, w)
+    lib.stickman_raster_oracle_thick(kps.ctypes.data_as(ctypes.c_void_p), b, j, body.ctypes.data_as(ctypes.c_void_p),
+                                     len(body), cmds.ctypes.data_as(ctypes.c_void_p), len(cmds),
+                                     out.ctypes.data_as(ctypes.c_void_p), h, w, int(thickness))
     return out

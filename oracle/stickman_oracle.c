@@ -20,6 +20,7 @@
  * on purpose: the GPU kernel (csrc/raster.hip) uses closed forms per pixel, so agreement between the two
  * is a real check.  Known-answer tests: tests/test_stickman_oracle.py.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -218,6 +219,196 @@ static void fill_poly(uint8_t* img, int w, int h, const int64_t* vx, const int64
   }
 }
 
+/* ---- thick lines: cv2.line(..., thickness > 1) = OpenCV ThickLine(flags 3, shift 0): a quad filled by FillConvexPoly in
+ * 16.16 fixed point (whose outline is first drawn with Line2), then a filled Circle at both end points.
+ * Restated from the published OpenCV 4.1.2 drawing.cpp; PARITY UNPINNED against OpenCV like the rest of this file. */
+static void put_point(uint8_t* img, int w, int h, int x, int y, uint8_t color) {
+  if (0 <= x && x < w && 0 <= y && y < h) img[(size_t)y * w + x] = color;
+}
+
+static void hline(uint8_t* img, int w, int y, int x1, int x2, uint8_t color) {
+  for (int x = x1; x <= x2; ++x) img[(size_t)y * w + x] = color;
+}
+
+/* OpenCV Line2(): fixed-point DDA between two 16.16 points, one pixel per major-axis step, plus the rounded end point */
+static void draw_line2(uint8_t* img, int w, int h, pt64 pt1, pt64 pt2, uint8_t color) {
+  if (!clip_line((int64_t)w << XY_SHIFT, (int64_t)h << XY_SHIFT, &pt1, &pt2)) return;
+  int64_t dx = pt2.x - pt1.x, dy = pt2.y - pt1.y;
+  int64_t j = dx < 0 ? -1 : 0, ax = (dx ^ j) - j;
+  int64_t i = dy < 0 ? -1 : 0, ay = (dy ^ i) - i;
+  int64_t x_step, y_step;
+  int ecount;
+  if (ax > ay) {
+    dy = (dy ^ j) - j;
+    pt1.x ^= pt2.x & j; pt2.x ^= pt1.x & j; pt1.x ^= pt2.x & j;
+    pt1.y ^= pt2.y & j; pt2.y ^= pt1.y & j; pt1.y ^= pt2.y & j;
+    x_step = XY_ONE;
+    y_step = (dy << XY_SHIFT) / (ax | 1);
+    ecount = (int)((pt2.x - pt1.x) >> XY_SHIFT);
+  } else {
+    dx = (dx ^ i) - i;
+    pt1.x ^= pt2.x & i; pt2.x ^= pt1.x & i; pt1.x ^= pt2.x & i;
+    pt1.y ^= pt2.y & i; pt2.y ^= pt1.y & i; pt1.y ^= pt2.y & i;
+    x_step = (dx << XY_SHIFT) / (ay | 1);
+    y_step = XY_ONE;
+    ecount = (int)((pt2.y - pt1.y) >> XY_SHIFT);
+  }
+  pt1.x += (XY_ONE >> 1);
+  pt1.y += (XY_ONE >> 1);
+  put_point(img, w, h, (int)((pt2.x + (XY_ONE >> 1)) >> XY_SHIFT), (int)((pt2.y + (XY_ONE >> 1)) >> XY_SHIFT), color);
+  if (ax > ay) {
+    pt1.x >>= XY_SHIFT;
+    while (ecount >= 0) {
+      put_point(img, w, h, (int)pt1.x, (int)(pt1.y >> XY_SHIFT), color);
+      pt1.x++;
+      pt1.y += y_step;
+      ecount--;
+    }
+  } else {
+    pt1.y >>= XY_SHIFT;
+    while (ecount >= 0) {
+      put_point(img, w, h, (int)(pt1.x >> XY_SHIFT), (int)pt1.y, color);
+      pt1.x += x_step;
+      pt1.y++;
+      ecount--;
+    }
+  }
+}
+
+/* OpenCV FillConvexPoly(v, npts, color, LINE_8, shift = XY_SHIFT) */
+static void fill_convex_poly(uint8_t* img, int w, int h, const pt64* v, int npts, uint8_t color) {
+  struct { int idx, di; int64_t x, dx; int ye; } edge[2];
+  const int shift = XY_SHIFT;
+  const int delta = 1 << shift >> 1;
+  int i, y, imin = 0, edges = npts;
+  int64_t xmin, xmax, ymin, ymax;
+  const int delta1 = XY_ONE >> 1, delta2 = XY_ONE >> 1;
+  pt64 p0 = v[npts - 1];
+  xmin = xmax = v[0].x;
+  ymin = ymax = v[0].y;
+  for (i = 0; i < npts; i++) {
+    pt64 p = v[i];
+    if (p.y < ymin) { ymin = p.y; imin = i; }
+    if (p.y > ymax) ymax = p.y;
+    if (p.x > xmax) xmax = p.x;
+    if (p.x < xmin) xmin = p.x;
+    draw_line2(img, w, h, p0, p, color);
+    p0 = p;
+  }
+  xmin = (xmin + delta) >> shift;
+  xmax = (xmax + delta) >> shift;
+  ymin = (ymin + delta) >> shift;
+  ymax = (ymax + delta) >> shift;
+  if (npts < 3 || (int)xmax < 0 || (int)ymax < 0 || (int)xmin >= w || (int)ymin >= h) return;
+  if (ymax > h - 1) ymax = h - 1;
+  edge[0].idx = edge[1].idx = imin;
+  edge[0].ye = edge[1].ye = y = (int)ymin;
+  edge[0].di = 1;
+  edge[1].di = npts - 1;
+  edge[0].x = edge[1].x = -XY_ONE;
+  edge[0].dx = edge[1].dx = 0;
+  do {
+    for (i = 0; i < 2; i++) {
+      if (y >= edge[i].ye) {
+        int idx0 = edge[i].idx, di = edge[i].di;
+        int idx = idx0 + di;
+        if (idx >= npts) idx -= npts;
+        int ty = 0;
+        for (; edges-- > 0;) {
+          ty = (int)((v[idx].y + delta) >> shift);
+          if (ty > y) {
+            const int64_t xs = v[idx0].x, xe = v[idx].x;
+            edge[i].ye = ty;
+            edge[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+            edge[i].x = xs;
+            edge[i].idx = idx;
+            break;
+          }
+          idx0 = idx;
+          idx += di;
+          if (idx >= npts) idx -= npts;
+        }
+      }
+    }
+    if (edges < 0) break;
+    if (y >= 0) {
+      int left = 0, right = 1;
+      if (edge[0].x > edge[1].x) { left = 1; right = 0; }
+      int xx1 = (int)((edge[left].x + delta1) >> XY_SHIFT);
+      int xx2 = (int)((edge[right].x + delta2) >> XY_SHIFT);
+      if (xx2 >= 0 && xx1 < w) {
+        if (xx1 < 0) xx1 = 0;
+        if (xx2 >= w) xx2 = w - 1;
+        hline(img, w, y, xx1, xx2, color);
+      }
+    }
+    edge[0].x += edge[0].dx;
+    edge[1].x += edge[1].dx;
+  } while (++y <= (int)ymax);
+}
+
+/* OpenCV Circle(center, radius, color, fill = 1): the midpoint iteration, every step filling four row spans */
+static void fill_circle(uint8_t* img, int w, int h, int cx, int cy, int radius, uint8_t color) {
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    int mask;
+    const int y11 = cy - dy, y12 = cy + dy, y21 = cy - dx, y22 = cy + dx;
+    int x11 = cx - dx, x12 = cx + dx, x21 = cx - dy, x22 = cx + dy;
+    if (x11 < w && x12 >= 0 && y21 < h && y22 >= 0) {   /* (the "inside" fast path draws the same pixels) */
+      if (x11 < 0) x11 = 0;
+      if (x12 > w - 1) x12 = w - 1;
+      if ((unsigned)y11 < (unsigned)h) hline(img, w, y11, x11, x12, color);
+      if ((unsigned)y12 < (unsigned)h) hline(img, w, y12, x11, x12, color);
+      if (x21 < w && x22 >= 0) {
+        if (x21 < 0) x21 = 0;
+        if (x22 > w - 1) x22 = w - 1;
+        if ((unsigned)y21 < (unsigned)h) hline(img, w, y21, x21, x22, color);
+        if ((unsigned)y22 < (unsigned)h) hline(img, w, y22, x21, x22, color);
+      }
+    }
+    dy++;
+    err += plus;
+    plus += 2;
+    mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+}
+
+static int64_t cv_round(double v) { return (int64_t)llrint(v); }   /* cvRound: round half to even (SSE2 cvtsd2si) */
+
+/* OpenCV ThickLine(p0, p1, thickness, LINE_8, flags = 3, shift = 0); thickness <= 1: the thin line above */
+static void draw_thick_line(uint8_t* img, int w, int h, int64_t ax, int64_t ay, int64_t bx, int64_t by, uint8_t color,
+                            int thickness) {
+  if (thickness <= 1) {
+    draw_line(img, w, h, ax, ay, bx, by, color);
+    return;
+  }
+  static const double INV_XY_ONE = 1. / XY_ONE;
+  pt64 p0 = {ax << XY_SHIFT, ay << XY_SHIFT}, p1 = {bx << XY_SHIFT, by << XY_SHIFT};
+  pt64 pt[4], dp = {0, 0};
+  const double dx = (p0.x - p1.x) * INV_XY_ONE, dy = (p1.y - p0.y) * INV_XY_ONE;
+  double r = dx * dx + dy * dy;
+  const int odd = thickness & 1;
+  thickness <<= XY_SHIFT - 1;
+  if (fabs(r) > 2.220446049250313e-16) {
+    r = (thickness + odd * XY_ONE * 0.5) / sqrt(r);
+    dp.x = cv_round(dy * r);
+    dp.y = cv_round(dx * r);
+    pt[0].x = p0.x + dp.x; pt[0].y = p0.y + dp.y;
+    pt[1].x = p0.x - dp.x; pt[1].y = p0.y - dp.y;
+    pt[2].x = p1.x - dp.x; pt[2].y = p1.y - dp.y;
+    pt[3].x = p1.x + dp.x; pt[3].y = p1.y + dp.y;
+    fill_convex_poly(img, w, h, pt, 4, color);
+  }
+  for (int i = 0; i < 2; i++) {
+    const int cx = (int)((p0.x + (XY_ONE >> 1)) >> XY_SHIFT), cy = (int)((p0.y + (XY_ONE >> 1)) >> XY_SHIFT);
+    fill_circle(img, w, h, cx, cy, (thickness + (XY_ONE >> 1)) >> XY_SHIFT, color);
+    p0 = p1;
+  }
+}
+
 /*
  * Draw list ("commands"), executed in order, per image:
  *   cmds[c] = { kind, a, b, c, plane, color }
@@ -241,8 +432,17 @@ static double seg_len(double ax, double ay, double bx, double by) {
   return sqrt(s);
 }
 
+void stickman_raster_oracle_thick(const float* kps, int B, int J, const int32_t* body, int n_body, const int32_t* cmds,
+                                  int n_cmds, uint8_t* out, int H, int W, int thickness);
+
 void stickman_raster_oracle(const float* kps, int B, int J, const int32_t* body, int n_body, const int32_t* cmds,
                             int n_cmds, uint8_t* out, int H, int W) {
+  stickman_raster_oracle_thick(kps, B, J, body, n_body, cmds, n_cmds, out, H, W, 1);
+}
+
+/* thickness: lib/utils.py:334-339 (img_shape[1] // scale_factor), handed to every cv2.line of the frame */
+void stickman_raster_oracle_thick(const float* kps, int B, int J, const int32_t* body, int n_body, const int32_t* cmds,
+                                  int n_cmds, uint8_t* out, int H, int W, int thickness) {
   memset(out, 0, (size_t)B * 3 * H * W);
   for (int b = 0; b < B; ++b) {
     const float* k = kps + (size_t)b * J * 2;
@@ -277,13 +477,14 @@ void stickman_raster_oracle(const float* kps, int B, int J, const int32_t* body,
         if (joint_ok(k, cmd[1]) && joint_ok(k, cmd[2]) && joint_ok(k, cmd[3])) {       /* :408-416 */
           const double nx = 0.5 * ((double)k[2 * cmd[1]] + (double)k[2 * cmd[2]]);
           const double ny = 0.5 * ((double)k[2 * cmd[1] + 1] + (double)k[2 * cmd[2] + 1]);
-          draw_line(plane, W, H, (int64_t)nx, (int64_t)ny, (int64_t)k[2 * cmd[3]], (int64_t)k[2 * cmd[3] + 1], color);
+          draw_thick_line(plane, W, H, (int64_t)nx, (int64_t)ny, (int64_t)k[2 * cmd[3]], (int64_t)k[2 * cmd[3] + 1], color,
+                          thickness);
         }
       } else {
         if (!(joint_ok(k, cmd[1]) && joint_ok(k, cmd[2]))) continue;                   /* :358-359 */
         const float ax = k[2 * cmd[1]], ay = k[2 * cmd[1] + 1], bx = k[2 * cmd[2]], by = k[2 * cmd[2] + 1];
         if (cmd[0] == 3 && !(seg_len(ax, ay, bx, by) < throat)) continue;              /* :473-476 */
-        draw_line(plane, W, H, (int64_t)ax, (int64_t)ay, (int64_t)bx, (int64_t)by, color);
+        draw_thick_line(plane, W, H, (int64_t)ax, (int64_t)ay, (int64_t)bx, (int64_t)by, color, thickness);
       }
     }
   }

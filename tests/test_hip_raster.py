@@ -60,11 +60,35 @@ def test_neck_and_face_branches_bit_exact_vs_oracle(which, mode):
     assert want.any()
 
 
-def test_make_joint_img_single_channel_shape_and_thickness_guard():
-    from behavior_driven_video_synthesis_amd.lib.utils import MARKET_JOINT_MODEL, make_joint_img
+def test_make_joint_img_single_channel_shape_and_scale_factor():
+    from behavior_driven_video_synthesis_amd.lib.utils import MARKET_JOINT_MODEL, make_joint_img, stickman_draw_list
     rng = np.random.default_rng(6)
     kps = rng.normal(64, 25, size=(18, 2)).astype(np.float32)
     img = make_joint_img([128, 128, 1], kps, MARKET_JOINT_MODEL)            # lib/utils.py:507-509: channel mean
     assert img.shape == (128, 128, 1)
-    with pytest.raises(NotImplementedError):
-        make_joint_img([128, 128, 3], kps, MARKET_JOINT_MODEL, scale_factor=32)   # thickness 4: not built
+    img = make_joint_img([128, 128, 3], kps, MARKET_JOINT_MODEL, scale_factor=32)   # thickness 128 // 32 = 4 (:334-339)
+    want = S.raster(kps[None], MARKET_JOINT_MODEL.body, stickman_draw_list(MARKET_JOINT_MODEL), 128, 128, thickness=4)[0]
+    assert np.array_equal(img, want.transpose(1, 2, 0))
+
+
+@pytest.mark.parametrize("thickness", [2, 3, 4, 5, 8, 13])
+@pytest.mark.parametrize("size,spread,seed", [(256, 60, 0), (64, 40, 1), (32, 10, 3)])
+def test_thick_lines_bit_exact_vs_oracle(thickness, size, spread, seed):
+    """cv2.line thickness > 1 (``stickman_scale``, lib/utils.py:334-339): the quad scan line, its Line2 outline and the two
+    end-cap circles as per-pixel closed forms == the sequential ThickLine restatement, joints far outside the frame (clipped
+    quads, caps cut by the border), coincident joints (caps only), draw order over the body polygon."""
+    from behavior_driven_video_synthesis_amd.lib.utils import (H36M_JOINT_MODEL, MARKET_JOINT_MODEL, make_joint_img_batch,
+                                                                 stickman_draw_list)
+    rng = np.random.default_rng(100 * thickness + seed)
+    b = 24
+    for model, nj in ((H36M_JOINT_MODEL, 17), (MARKET_JOINT_MODEL, 18)):
+        kps = rng.normal(size / 2, spread, size=(b, nj, 2)).astype(np.float32)
+        kps[3, 5] = (-3.0, 10.0)
+        kps[6, 1] = kps[6, 2]                      # zero-length limb: no quad, two coincident caps
+        kps[7, 1] = kps[7, 0] + np.float32(0.4)    # same pixel after truncation
+        kps[8] = np.abs(kps[8]) + size * 3         # everything far outside
+        want = S.raster(kps, model.body, stickman_draw_list(model), size, size, thickness=thickness)
+        got = make_joint_img_batch((size, size), torch.from_numpy(kps).cuda(), model, as_float=False, thickness=thickness)
+        diff = got.cpu().numpy() != want
+        assert not diff.any(), (int(diff.sum()), np.argwhere(diff)[:5])
+        assert want.any()

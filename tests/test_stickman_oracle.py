@@ -165,3 +165,50 @@ def test_deepfashion_and_market_models_draw():
         out = S.raster(kps, model.body, cmds, 128, 128)
         assert out[:, 2].any() and out[:, 0].any() and out[:, 1].any()
         assert set(np.unique(out)) <= {0, 127, 255}
+
+
+# ---- thick lines (cv2.line thickness > 1 = OpenCV ThickLine): known answers derived by hand from the published algorithm
+def _thick(a, b, t, h=16, w=16, color=255):
+    kps = np.array([[a, b]], dtype=np.float32)
+    return S.raster(kps, [], [(1, 0, 1, 0, 0, color)], h, w, thickness=t)[0, 0]
+
+
+def test_thick_horizontal_line_thickness_2():
+    """t = 2: half width t * 2^15 = 1.0 in 16.16, dp = (0, -1): quad (4,3) (4,5) (10,5) (10,3) -> FillConvexPoly rows 3..5,
+    columns 4..10 (both ends rounded to nearest); cap radius (2^16 + 2^15) >> 16 = 1: the midpoint iteration of Circle fills
+    (cx-1..cx+1, cy) and (cx, cy +- 1) -> one extra pixel left of 4 and right of 10 on the centre row."""
+    want = {(x, y) for y in (3, 4, 5) for x in range(4, 11)} | {(3, 4), (11, 4)}
+    assert set(_pts(_thick((4, 4), (10, 4), 2))) == want
+
+
+def test_thick_degenerate_line_is_two_coincident_caps():
+    """Both end points on one pixel: r = 0, no quad (ThickLine's DBL_EPSILON test), only the caps.  t = 3: radius
+    (3 * 2^15 + 2^15) >> 16 = 2; Circle(fill) iterates (dx, dy) = (2, 0), (1, 1): rows cy: cx-2..cx+2; cy +- 2: cx;
+    cy +- 1: cx-1..cx+1."""
+    want = {(x, 5) for x in range(3, 8)} | {(5, 3), (5, 7)} | {(x, y) for y in (4, 6) for x in (4, 5, 6)}
+    assert set(_pts(_thick((5, 5), (5, 5), 3))) == want
+    assert set(_pts(_thick((5.2, 5.9), (5.7, 5.1), 3))) == want      # same pixel after np.int_ truncation
+
+
+def test_thick_line_clipped_at_the_border_and_cap_overlap():
+    """t = 3 from (0,2) to (14,2) on a 16-wide image: half width 1.5 + 0.5 (odd thickness) = 2.0 -> quad rows 0..4,
+    columns 0..14; radius-2 caps: the left one is cut by the border (columns -2..-1 dropped), the right one adds column 15
+    on rows 1..3 and nothing on rows 0 / 4 (its one-pixel tips at column 14 are already inside the quad)."""
+    img = _thick((0, 2), (14, 2), 3)
+    want = {(x, y) for y in range(5) for x in range(15)} | {(15, 1), (15, 2), (15, 3)}
+    assert set(_pts(img)) == want
+    assert not _thick((40, 40), (60, 40), 3).any()                    # completely outside: quad rejected, caps outside
+    # the far end point outside the image: the quad is clipped row by row, the far cap vanishes
+    img = _thick((10, 8), (40, 8), 2)
+    assert set(_pts(img)) == {(x, y) for y in (7, 8, 9) for x in range(10, 16)} | {(9, 8)}
+
+
+def test_thick_lines_overwrite_in_draw_order():
+    """Later commands win per pixel, thick or thin: a thick limb over the body polygon, then a second limb over the first."""
+    kps = np.array([[(2, 2), (12, 2), (12, 12), (2, 12), (1, 7), (14, 7)]], dtype=np.float32)
+    cmds = [(0, 0, 0, 0, 0, 99), (1, 4, 5, 0, 0, 200), (1, 0, 2, 0, 0, 50)]
+    out = S.raster(kps, [0, 1, 2, 3], cmds, 16, 16, thickness=2)[0, 0]
+    assert out[4, 4] == 50 and out[7, 7] == 50          # the diagonal limb drawn last
+    assert out[7, 3] == 200 and out[6, 10] == 200       # the horizontal limb (rows 6..8) over the polygon
+    assert out[10, 4] == 99 and out[3, 10] == 99        # polygon where no limb passes
+    assert out[7, 0] == 200 and out[7, 15] == 200       # caps of the horizontal limb reach beyond the polygon
