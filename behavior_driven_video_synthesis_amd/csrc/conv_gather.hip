@@ -279,13 +279,15 @@ __global__ __launch_bounds__(SW * 64) void conv_gather_splitk_kernel(const Gathe
   __syncthreads();
   // wave w finishes accumulator register r = w, w + SW, ... (fixed summation order over the waves)
   const PixGeo g = out_pixel(a, pb * 32 + j);
+  float vmax = 0.f;
   for (int r = wave; r < 16; r += SW) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < SW; ++w) v += red[(w * 16 + r) * 64 + lane];
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (g.valid && m < d.M) store_out(a, g, m, v);
+    if (g.valid && m < d.M) vmax = fmaxf(vmax, fabsf(store_out(a, g, m, v)));
   }
+  if (a.amax_out) publish_amax(a, vmax);   // |y| maxima for the consumer's fp16 scale (GatherArgs::amax_out)
 }
 
 template <int MT, int NT, int KS>
@@ -327,13 +329,23 @@ static bool want_splitk(long ntiles, long mtiles, int kpairs, int taps) {
 }
 
 template <int KS>
-static int dispatch_gather(const GatherArgs& ga, int pro, hipStream_t st) {
+static int dispatch_gather(const GatherArgs& ga_in, int pro, hipStream_t st, float* amax_out = nullptr) {
+  GatherArgs ga = ga_in;
   const vunet_conv_desc& d = ga.d;
   const int ntiles = (ga.NP + 31) / 32, mtiles = (d.M + 31) / 32;
   const int kpairs = (((d.C1 + 1) >> 1) + ((d.C2 + 1) >> 1));
-  if (want_splitk(ntiles, mtiles, kpairs, d.KH * d.KW)) return launch_splitk<KS>(ga, pro, st);
+  if (want_splitk(ntiles, mtiles, kpairs, d.KH * d.KW)) {
+    ga.amax_out = amax_out;   // the split-K kernel publishes |y| maxima (the others of this dispatcher do not)
+    return launch_splitk<KS>(ga, pro, st);
+  }
   if (d.M <= 32) return launch_gather<1, 4, KS>(ga, pro, st);
   return launch_gather<2, 2, KS>(ga, pro, st);
+}
+
+static bool gather_uses_splitk(const vunet_conv_desc* d) {
+  const long ntiles = ((long)d->N * d->Ho * d->Wo + 31) / 32, mtiles = (d->M + 31) / 32;
+  const int kpairs = ((d->C1 + 1) >> 1) + ((d->C2 + 1) >> 1);
+  return want_splitk(ntiles, mtiles, kpairs, d->KH * d->KW);
 }
 
 // conv_tiled.hip: LDS-tiled kernel for the 3x3 / stride-1 layers on maps at least 32 wide
@@ -417,7 +429,7 @@ bool vunet_conv2d_gather_publishes(const vunet_conv_desc* d, bool has_aux, bool 
   if (d->d2s || (d->mode == 1 && d->stride > 1 && !env_no_phase())) return false;
   const int pro = prologue_code(d);
   if (vunet_conv_thin_kind(d, pro, has_aux, has_res)) return false;
-  return use_1x1(d, pro) || use_tiled(d, pro);
+  return use_1x1(d, pro) || use_tiled(d, pro) || gather_uses_splitk(d);
 }
 
 int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const float* shift,
@@ -470,10 +482,11 @@ int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const fl
   if (!d->d2s) ga.amax_out = amax_out;   // read by the two kernels below only
   if (use_1x1(d, pro)) return vunet_conv_1x1_launch(ga, pro, st);
   if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);
+  float* const amax_keep = ga.amax_out;
   ga.amax_out = nullptr;
-  if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st);
-  if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st);
-  return dispatch_gather<0>(ga, pro, st);
+  if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st, amax_keep);
+  if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st, amax_keep);
+  return dispatch_gather<0>(ga, pro, st, amax_keep);
 }
 
 

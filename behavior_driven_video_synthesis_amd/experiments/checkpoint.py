@@ -88,3 +88,44 @@ def restore(directory: str, trainer, key: str = "reg_ckpt") -> bool:
         ckpt["regressor"] = {"model": reg_model, "optimizer": reg_opt}
     trainer.load_state_dict(ckpt)
     return True
+
+
+def load_pretrained(pretrained_model: str, device="cuda:0", run_dir: Optional[str] = None, key: str = "reg_ckpt", **trainer_kw):
+    """The reference's ``--pretrained_model <dir>`` flow (main.py:38-47, experiments/experiment.py:39-95,
+    experiments/shape_and_pose_net.py:87-95, 248-255): read ``<dir>/config.yaml`` (the YAML the authors ship beside
+    their checkpoints; ``!!python/tuple`` tags as the reference's FullLoader reads them), build the trainer that
+    config describes, and restore -- strictly -- the newest ``*.pth`` of the directory whose name contains ``key``:
+    ``{"model": VunetAlter.state_dict(), "optimizer": torch.optim.Adam.state_dict()}``, Adam's per-parameter state
+    included (iteration, gamma, lr / imax schedules follow from it as on a restart).  ``run_dir``: also do what
+    main.py does with the directory -- copy the config to ``run_dir/config/config.yaml`` and every ``*.pth`` to
+    ``run_dir/ckpt``.  -> (trainer, config dict).  ``trainer_kw`` goes to ``ShapePoseNet`` (e.g. ``vgg_weights_path``)."""
+    import shutil
+    import yaml
+    from .shape_and_pose_net import ShapePoseNet
+    cfg_path = os.path.join(pretrained_model, "config.yaml")
+    if not os.path.isfile(cfg_path):
+        raise FileNotFoundError("No saved config file found but model is intended to be restarted. Aborting....")
+    with open(cfg_path, "r") as f:
+        cdict = yaml.load(f, Loader=yaml.FullLoader)
+    path = latest_checkpoint(pretrained_model, key)
+    if path is None:
+        raise FileNotFoundError(f"no *{key}*.pth in {pretrained_model}")
+    if run_dir is not None:
+        for sub in ("config", "ckpt"):
+            os.makedirs(os.path.join(run_dir, sub), exist_ok=True)
+        with open(os.path.join(run_dir, "config", "config.yaml"), "w") as f:
+            yaml.dump(cdict, f, default_flow_style=False)
+        for c in glob.glob(os.path.join(pretrained_model, "*.pth")):
+            shutil.copy(c, os.path.join(run_dir, "ckpt"))
+    config = {k: dict(v) if isinstance(v, dict) else v for k, v in cdict.items()}
+    config.setdefault("general", {}).setdefault("seed", 42)
+    trainer = ShapePoseNet(config, device=device, **trainer_kw)
+    ckpt = torch.load(path, map_location="cpu")
+    if "model" not in ckpt:
+        raise KeyError(f"{path}: no 'model' entry (the reference's checkpoint layout is {{'model', 'optimizer'}})")
+    reg_model, reg_opt = load_ckpt(pretrained_model, "regressor")
+    if reg_model is not None:
+        ckpt["regressor"] = {"model": reg_model, "optimizer": reg_opt}
+    trainer.load_state_dict(ckpt)   # strict for the VUnet; Adam state, iteration, gamma, schedules as on a restart
+    return trainer, config
+

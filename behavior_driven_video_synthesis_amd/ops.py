@@ -975,7 +975,8 @@ class FusedConv(torch.autograd.Function):
                        drop_seed=cfg.drop_seed, nsplit=1, flags=(0, 0, 2)[_scheme()] if _scheme() else 1)
         wg_amax = (None, None)
         if ctx.need_w and _scheme() == 2 and _wgrad_wants_split(wd):
-            wg_amax = (ctx.amax_x if ctx.amax_x is not None else absmax_partials(x1, x2), get_dy_amax())
+            # (the forward may not have needed the |x| maxima -- 1x1 / fp32 kernels -- but the producers' tags are still there)
+            wg_amax = (ctx.amax_x if ctx.amax_x is not None else _amax_for(x1, x2), get_dy_amax())
 
         def weight_gradients(defer: bool = False):
             ns = _lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))

@@ -563,6 +563,61 @@ def g1c_l2norm_init():
     save("g1c_l2norm_init", meta, arrays)
 
 
+# ---------------------------------------------------------------- G8 a pretrained-model directory as the reference writes it
+def g8_pretrained_dir():
+    """main.py:38-47 / experiments/experiment.py:39-95, experiments/shape_and_pose_net.py:471-482: a directory holding
+    ``config.yaml`` (the reference's own YAML with the sizes of a small model) and ``reg_ckpt_*_<it>.pth`` files
+    ``{"model": VunetAlter.state_dict(), "optimizer": torch.optim.Adam.state_dict()}`` -- written HERE by the reference's
+    classes and torch.optim.Adam after two training steps.  Recorded with it: what the restored reference model computes (``transfer``) on a seeded pair."""
+    import yaml
+    from oracle.vunet_oracle import make_synthetic_vgg19
+    seed = 81
+    with open(os.path.join(REF, "config", "shape_and_pose_net.yaml")) as f:
+        cdict = yaml.load(f, Loader=yaml.FullLoader)
+    cdict["data"].update(spatial_size=32)
+    cdict["architecture"].update(nf_start=4, nf_max=8)
+    cdict["training"].update(dropout_prob=0.0, train_regressor=False)
+    cdict["general"].update(base_dir="/tmp/vunet_pretrained_fixture")
+    out_dir = os.path.join(HERE, "g8_pretrained")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "config.yaml"), "w") as f:
+        yaml.dump(cdict, f, default_flow_style=False)
+    kw = dict(cdict["architecture"])
+    kw.update(cdict["data"])
+    kw["dropout_prob"] = cdict["training"]["dropout_prob"]
+    torch.manual_seed(seed)
+    net = rv.VunetAlter(n_channels_x=3, **kw)          # the reference's default initialisation
+    vsd = make_synthetic_vgg19(seed=77, width_div=8)
+    pv = rp.PerceptualVGG(build_vgg_features(vsd), [1.0] * 6)
+    pv.eval()
+    opt = torch.optim.Adam([{"params": getattr(net, n).parameters(), "name": n} for n in ["eu", "ed", "du", "dd"]],
+                           lr=cdict["training"]["lr"], betas=tuple(cdict["training"]["adam_betas"]))
+    net.train()
+    for it in (1, 2):
+        x, c = synth_image(f"pre.x{it}", (2, 3, 32, 32), seed), synth_image(f"pre.c{it}", (2, 3, 32, 32), seed)
+        with FixedNoise(f"pre.{it}", seed):
+            img, means, logstds, _ = net(x, c)
+        ld = rl.vgg_loss(pv, x, img)
+        loss = torch.sum(torch.stack([ld[k] for k in ld], dim=0)) + 0.01 * rl.compute_kl_with_prior(means, logstds)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for pg_ in opt.param_groups:      # :507-512: gamma rides in the param groups
+            pg_["gamma"] = 0.25 * it
+        if it == 2:   # (one file is committed; the test puts an older decoy beside it for the selection rule)
+            torch.save({"model": net.state_dict(), "optimizer": opt.state_dict()},
+                       os.path.join(out_dir, f"reg_ckpt_model_{it}.pth"))
+    net.eval()
+    x, c = synth_image("pre.tx", (2, 3, 32, 32), seed), synth_image("pre.tc", (2, 3, 32, 32), seed)
+    with torch.no_grad():
+        with FixedNoise("pre.t", seed):
+            img = net.transfer(x, c)
+    meta = {"seed": seed, "newest": "reg_ckpt_model_2.pth", "iteration": 2, "gamma": 0.5,
+            "n_tensors": len(net.state_dict()),
+            "checksums": {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in net.state_dict().items()}}
+    save("g8_pretrained_outputs", meta, {"transfer": img.numpy()})
+
+
 # ---------------------------------------------------------------- G7 evaluation statistics (lib/metrics.py:277-415)
 def g7_metrics():
     """FID statistics (_calculate_fid on mean / np.cov of features) and the Inception score (inception_score driven with
@@ -623,3 +678,4 @@ if __name__ == "__main__":
     g7_metrics()
     g1b_upsample_bilinear()
     g1c_l2norm_init()
+    g8_pretrained_dir()
