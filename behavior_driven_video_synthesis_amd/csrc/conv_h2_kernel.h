@@ -60,6 +60,21 @@ union H2Unit {
   h2_f16x8 b;
 };
 
+// Timing-only builds (tools/ab_build.sh -DH2_ABL_* / -DH2_PROBE_* / -DH2_SINGLE / -DH2_PIPE) compile parts of the kernel out or
+// change its arithmetic: their results are WRONG by construction.  Such a library refuses every launch of this kernel unless
+// the process says it knows (VUNET_ALLOW_TIMING_BUILD=1, set by the timing tools) -- a product build defines none of them.
+#if defined(H2_ABL_NOX) || defined(H2_ABL_NOW) || defined(H2_ABL_NOSTORE) || defined(H2_ABL_NOWAIT) || \
+    defined(H2_PROBE_VLOAD) || defined(H2_SINGLE) || defined(H2_PIPE) || defined(H2_NO_TAP_BARRIER)
+#define VUNET_H2_TIMING_BUILD 1
+#else
+#define VUNET_H2_TIMING_BUILD 0
+#endif
+static inline bool h2_launch_allowed() {
+  if (!VUNET_H2_TIMING_BUILD) return true;
+  static const bool ok = [] { const char* e = getenv("VUNET_ALLOW_TIMING_BUILD"); return e && e[0] == '1'; }();
+  return ok;
+}
+
 // MODE 0 forward, 1 data gradient (taps mirrored).  PRO 0 none, 1 ELU, 2 ELU + dropout, 4 ReLU mask (MODE 1).
 // PHW >= 0 (MODE 1 only): data gradient of the STRIDE-2 convolution (Downsample, lib/modules.py:152-158) for the output
 // parity (ph, pw) = (PHW >> 1, PHW & 1): dx[2a+ph][2b+pw] = sum over the taps kh = ph+1 (mod 2), kw = pw+1 (mod 2) of
@@ -76,8 +91,10 @@ union H2Unit {
 //     the decoder's 16 x 16 level): it is 16 pixels of two consecutive rows, lane j -> (row j / 16, column j % 16); the
 //     staged rows are then 32 units apart (18 used), which keeps the two half-rows of a fragment read on distinct banks.
 // MT * NT >= 8 (128 channels x 8 rows, or 64 channels x 16 rows, per four-wave workgroup): ONE workgroup per CU, one wave
-// per SIMD with the whole 512-entry register file -- 256 accumulator registers and room to keep the next tap's
-// fragments in flight, so the fragment reads are left to the scheduler instead of being fenced per tap.
+// per SIMD with the whole 512-entry register file (256 accumulator registers in AGPRs).  Built and measured in round 3
+// (tools/time_conv.py): 10 - 25 % SLOWER than the 64 x 8 tile at two waves per SIMD -- with nothing to switch to, every
+// fragment read's latency is exposed unless the reads are pipelined by hand, and the compiler's schedule is read -> wait ->
+// MFMA; not instantiated.
 template <int MT, int NT, int MODE, int PRO, int PHW = -1, int NWV = 4, int TW = 32>
 __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void conv_h2_kernel(const GatherArgs a_in,
                                                                              const uint4* __restrict__ wx, int mtiles_pad,
@@ -170,10 +187,20 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     const int cs = second ? (ch - nch1) * 16 : ch * 16;
     const int C = second ? d.C2 : d.C1;
     const float* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C + cs) * HW;
+#ifdef H2_PROBE_VLOAD   // (timing probe, tools/ab_build.sh: two 16-byte loads instead of eight dword loads; WRONG data)
+    {
+      const float4 va = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs) + 4u * (rel[i] & ~3u));
+      const float4 vb = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs) +
+                                                         4u * ((rel[i] & ~3u) + (((vbits >> i) & 1u) ? (unsigned)(4 * HW) : 0u)));
+      xv[i][0] = va.x; xv[i][1] = va.y; xv[i][2] = va.z; xv[i][3] = va.w;
+      xv[i][4] = vb.x; xv[i][5] = vb.y; xv[i][6] = vb.z; xv[i][7] = vb.w;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       xv[i][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xs) +
                                                  4u * (rel[i] + (((vbits >> i) & 1u) ? (unsigned)(k * HW) : 0u)));
+#endif
   };
   // PRO 4: the ReLU mask travels separately and late (after the MFMA block, when the fragment registers are free)
   auto issue_mask = [&](int ch, int i) {
@@ -482,8 +509,11 @@ static int launch_h2_one(const GatherArgs& ga, const void* wx, int mtiles_pad, c
   constexpr size_t lds = (size_t)(8 * PIX + 2 * H2_SLAB * MT * (NWV == 8 ? NKH : 1)) * 16;
   const vunet_conv_desc& d = ga.d;
   const int blocks = d.N * (d.Hs / (NWV * NT * RPQ)) * (d.Ws / TW) * ((d.M + 32 * MT - 1) / (32 * MT));
+  if (!h2_launch_allowed()) return VUNET_ERR_UNSUPPORTED;
   auto kern = conv_h2_kernel<MT, NT, MODE, PRO, PHW, NWV, TW>;
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VUNET_ERR_LAUNCH;
   VUNET_LAUNCH(kern, dim3((unsigned)blocks), dim3(64 * NWV), lds, st, ga, (const uint4*)wx, mtiles_pad, amax);
   return vunet_check_launch();
 }
@@ -524,23 +554,6 @@ static int launch_h2(const GatherArgs& ga, const void* wx, int mtiles_pad, const
     case 0: return launch_h2_one<MT, NT, 0, 0, -1, NWV>(ga, wx, mtiles_pad, amax, st);
     case 1: return launch_h2_one<MT, NT, 0, 1, -1, NWV>(ga, wx, mtiles_pad, amax, st);
     case 2: return launch_h2_one<MT, NT, 0, 2, -1, NWV>(ga, wx, mtiles_pad, amax, st);
-    default: return VUNET_ERR_UNSUPPORTED;
-  }
-}
-
-// the big tiles (MT * NT = 8): stride-1 forward and data gradient only (no output-parity forms)
-template <int MT, int NT>
-static int launch_h2_big(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, hipStream_t st) {
-  if (ga.d.stride != 1) return VUNET_ERR_UNSUPPORTED;
-  if (ga.d.mode == 1) {
-    if (pro == 4) return launch_h2_one<MT, NT, 1, 4, -1, 4>(ga, wx, mtiles_pad, amax, st);
-    if (pro == 0) return launch_h2_one<MT, NT, 1, 0, -1, 4>(ga, wx, mtiles_pad, amax, st);
-    return VUNET_ERR_UNSUPPORTED;
-  }
-  switch (pro) {
-    case 0: return launch_h2_one<MT, NT, 0, 0, -1, 4>(ga, wx, mtiles_pad, amax, st);
-    case 1: return launch_h2_one<MT, NT, 0, 1, -1, 4>(ga, wx, mtiles_pad, amax, st);
-    case 2: return launch_h2_one<MT, NT, 0, 2, -1, 4>(ga, wx, mtiles_pad, amax, st);
     default: return VUNET_ERR_UNSUPPORTED;
   }
 }

@@ -9,8 +9,6 @@ int vunet_conv_h2_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pa
                              hipStream_t st);
 int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,
                              hipStream_t st);
-int vunet_conv_h2_launch_big(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int MT,
-                             hipStream_t st);
 int vunet_conv_h2_launch_w16(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int MT,
                              hipStream_t st);
 
@@ -54,18 +52,6 @@ static bool x6_geometry_ok(const vunet_conv_desc* d, int pro, bool h2 = false) {
     return d->mode == 1 && pro == 0 && d->C2 == 0 && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws;
   if (d->stride != 1 || d->Hs != d->Ho || d->Ws != d->Wo) return false;
   return d->mode == 0 ? (pro == 0 || pro == 1 || pro == 2) : (pro == 0 || pro == 4);
-}
-
-// the big workgroup tiles of the fp16 scheme (one workgroup per CU): 128 channels x 8 rows where the layer has 128-channel
-// blocks, 64 channels x 16 rows for the 64-channel layers; at least one workgroup per CU.  0: not for this problem.
-static int h2_big_tile(const vunet_conv_desc* d, int pro) {
-  if (!g_vunet_tune[VUNET_TUNE_H2_BIG]) return 0;
-  if (d->stride != 1 || d->Ws % 32 || d->d2s) return 0;
-  if (d->mode == 0 ? !(pro == 0 || pro == 1 || pro == 2) : !(pro == 0 || pro == 4)) return 0;
-  const long tiles32 = (long)d->N * (d->Ws / 32);
-  if (d->M % 128 == 0 && d->Hs % 8 == 0 && tiles32 * (d->Hs / 8) * (d->M / 128) >= 256) return 4;
-  if (d->M % 64 == 0 && d->Hs % 16 == 0 && tiles32 * (d->Hs / 16) * (d->M / 64) >= 256) return 2;
-  return 0;
 }
 
 static long x6_blocks(const vunet_conv_desc* d, int MT, int NT) {
@@ -129,9 +115,6 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
   // K dimension of the image = the gathered tensor's channels; M dimension = all columns of the weight matrix
   const int mtp = vunet_x6_mtiles(d->Mpad);
   if (amax && d->Ws % 32) return vunet_conv_h2_launch_w16(ga, wx, mtp, amax, pro, MT, (hipStream_t)stream);
-  if (amax) {
-    if (const int bigMT = h2_big_tile(d, pro)) return vunet_conv_h2_launch_big(ga, wx, mtp, amax, pro, bigMT, (hipStream_t)stream);
-  }
   if (amax)   // two-term fp16 image
     return MT == 1 ? vunet_conv_h2_launch_mt1(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream)
                    : vunet_conv_h2_launch_mt2(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream);

@@ -190,7 +190,7 @@ def _scheme() -> int:
 
 
 _wants_split_cache = {}
-_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2, "h2_big": 3}
+_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2}
 
 
 def set_tuning(key: str, value: int):

@@ -319,12 +319,10 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *   VUNET_TUNE_SPLIT_FORCE_NT  tile height (32-pixel rows per wave: 1, 2 or 4) of the split-fp16 / split-bf16 3x3 kernels
  *   VUNET_TUNE_TILED_FORCE_NT  the same for the LDS-tiled fp32 kernel
  *   VUNET_TUNE_FORCE_SMALL     1: vunet_conv2d_x6 takes the small-map K-split kernel wherever it covers the geometry
- *   VUNET_TUNE_H2_BIG          1: the fp16 scheme's big workgroup tiles (128 ch x 8 rows / 64 ch x 16 rows, one workgroup per CU)
  * Returns VUNET_ERR_ARG for an unknown key. */
 #define VUNET_TUNE_SPLIT_FORCE_NT 0
 #define VUNET_TUNE_TILED_FORCE_NT 1
 #define VUNET_TUNE_FORCE_SMALL 2
-#define VUNET_TUNE_H2_BIG 3
 int vunet_set_tuning(int32_t key, int32_t value);
 
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */

@@ -9,6 +9,8 @@ import ctypes
 import os
 import sys
 
+os.environ.setdefault("VUNET_ALLOW_TIMING_BUILD", "1")   # A/B libraries of tools/ab_build.sh may be timing-only builds
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,9 +20,7 @@ from behavior_driven_video_synthesis_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--modes", default="h2,x6")
 ap.add_argument("--nt", type=int, default=0)
-ap.add_argument("--big", type=int, default=0, help="1: the fp16 scheme's big workgroup tiles (ops.set_tuning h2_big)")
 args = ap.parse_args()
-ops.set_tuning("h2_big", args.big)
 if args.nt:
     ops.set_tuning("split_force_nt", args.nt)
 
