@@ -42,6 +42,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
 X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
 FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
+PMC_TRAFFIC_RENDER = ["profiles/r03_pmc_traffic_render.json"]
 PMC_TRAFFIC = ["profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
 
 
@@ -293,6 +294,20 @@ def render_row(vunet, device, size, frames=50, chunk=25, iters=5):
         row["roofline"] = {"bound": "hbm", "kernel": "conv_bf16_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                            "frac": ach / 8000.0, "traffic": None,
                            "share_of_conv_time": ms / sum(v["ms"] for v in fam.values())}
+        # mean HBM bytes per launch of that kernel over the sequence: rocprofv3 PMC passes of tools/bench_render.py
+        # (tools/profile.sh step 4), committed summary
+        for rel in PMC_TRAFFIC_RENDER:
+            try:
+                pmc = json.load(open(os.path.join(ROOT, rel)))
+            except (OSError, ValueError):
+                continue
+            ents = [v for k, v in pmc.get("kernels", {}).items() if k.startswith("conv_bf16_kernel")]
+            if ents:   # every instantiation of the kernel, weighted by its launches
+                nl = sum(e["launches_sampled"] for e in ents)
+                row["roofline"]["traffic"] = sum(e["hbm_bytes_per_launch"] * e["launches_sampled"] for e in ents) / nl
+                row["roofline"]["traffic_source"] = {"file": rel, "collected_at_commit": pmc.get("head", ""),
+                                                     "launches_sampled": nl, "unit": "mean HBM bytes per launch"}
+            break
     vunet.train(was)
     return row
 
@@ -345,7 +360,16 @@ def main():
         torch.cuda.synchronize()
 
     elapsed, out = timed_steps(trainer, batch, args.warmup, args.steps, sync_all)
-    host_issue_ms = 1e3 * timed_steps.host_issue_s / args.steps
+    # host time to ISSUE one step: measured on steps that start with an empty device queue (inside the timed loop the host
+    # runs ahead until the launch queue is full and is then throttled to the GPU's pace, which says nothing about the host)
+    issue = []
+    for _ in range(3):
+        sync_all()
+        t0 = time.perf_counter()
+        trainer.train_fn(batch)
+        issue.append(time.perf_counter() - t0)
+    sync_all()
+    host_issue_ms = 1e3 * statistics.median(issue)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -8,6 +8,7 @@
 # 2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE   -> gpurun_out/<tag>_pmc_traffic.json   (HBM bytes per launch; separate
 #    passes and the gfx950 FETCH_SIZE x2 correction, as MI355X_MICROARCH.md "HBM" prescribes)
 # 3. rocprofv3 --pmc SQ_* (one pass)           -> gpurun_out/<tag>_pmc_sq.json        (MFMA-pipe busy / wave cycles)
+# 4. the same FETCH / WRITE passes over tools/bench_render.py -> gpurun_out/<tag>_pmc_traffic_render.json
 # The program itself follows `--` (no env / bash -c hop: the profiler initialises the GPU before the program starts).
 # Copy the summaries you want judged from gpurun_out/ into profiles/ and commit them.
 set -u
@@ -36,6 +37,12 @@ python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_fetch/*/*_counter_collecti
 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/${TAG}_sq -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_sq.err
 python3 tools/pmc_summary.py sq $(ls $OUT/${TAG}_sq/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_sq.json
+# 4. the render loop (BASELINE config 5): HBM bytes per launch of its bf16 convolution, same two separate passes
+rm -rf $OUT/${TAG}_rfetch $OUT/${TAG}_rwrite
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rfetch -- python3 tools/bench_render.py --iters 1 > /dev/null 2> $OUT/${TAG}_rfetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rwrite -- python3 tools/bench_render.py --iters 1 > /dev/null 2> $OUT/${TAG}_rwrite.err
+python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_rfetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_rwrite/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic_render.json
+rm -rf $OUT/${TAG}_rfetch $OUT/${TAG}_rwrite
 # the raw per-dispatch tables are large: keep the summaries only
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
 ls -la $OUT/${TAG}_*
