@@ -287,3 +287,43 @@ def test_pretrained_model_flow_reads_a_reference_written_directory(tmp_path):
     assert os.path.isfile(tmp_path / "run" / "config" / "config.yaml")
     with pytest.raises(FileNotFoundError):
         load_pretrained(str(tmp_path / "nowhere"), device="cpu")
+
+
+def test_checkpoint_round_trip_keeps_the_regressor_file(tmp_path):
+    """the reference keeps the regressor + its optimiser in a file of their own and restarts with
+    ``_load_ckpt("regressor")`` (experiments/shape_and_pose_net.py:87-95, 486-497).  save_ckpt writes both files,
+    ``load_ckpt(dir, "regressor")`` finds the second one, and ``restore`` brings a fresh trainer back to the saved state."""
+    import copy
+    import torch
+    from behavior_driven_video_synthesis_amd.experiments.checkpoint import load_ckpt, restore, save_ckpt
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import DEFAULT_CONFIG, ShapePoseNet
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["data"]["spatial_size"] = 32
+    cfg["architecture"].update(nf_start=4, nf_max=8)
+    cfg["training"].update(train_regressor=True)
+    a = ShapePoseNet(cfg, device="cpu", vgg_width_div=8, total_steps=50, vgg_synthetic=True)
+    with torch.no_grad():   # pretend two optimiser steps happened (no kernels on this host)
+        for tr_opt in (a.optimizer, a.optimizer_regressor):
+            for b in tr_opt.buckets:
+                b.step = 2
+                b.exp_avg.normal_(generator=torch.Generator().manual_seed(b.numel))
+                b.exp_avg_sq.uniform_(generator=torch.Generator().manual_seed(b.numel + 1))
+        a.gamma.fill_(0.375)
+    d = str(tmp_path / "ckpt")
+    save_ckpt(d, "reg_ckpt", 2, a)
+    assert sorted(os.listdir(d)) == ["reg_ckpt_checkpoint_2.pth", "regressor_checkpoint_2.pth"]
+    reg_model, reg_opt = load_ckpt(d, "regressor")
+    assert set(reg_model) == set(a.regressor.state_dict()) and reg_opt is not None and len(reg_opt["state"]) > 0
+    torch.manual_seed(123)
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["general"]["seed"] = 7        # a differently initialised trainer
+    b_ = ShapePoseNet(cfg2, device="cpu", vgg_width_div=8, total_steps=50, vgg_synthetic=True)
+    assert restore(d, b_)
+    for (k, p), (_, q) in zip(a.regressor.state_dict().items(), b_.regressor.state_dict().items()):
+        assert torch.equal(p, q), k
+    for (k, p), (_, q) in zip(a.vunet.state_dict().items(), b_.vunet.state_dict().items()):
+        assert torch.equal(p, q), k
+    assert b_.iteration == 2 and float(b_.gamma) == 0.375
+    for x, y in zip(a.optimizer_regressor.buckets, b_.optimizer_regressor.buckets):
+        assert y.step == 2 and torch.equal(x.exp_avg, y.exp_avg) and torch.equal(x.exp_avg_sq, y.exp_avg_sq)
+    assert not restore(str(tmp_path / "empty"), b_)

@@ -477,3 +477,46 @@ def test_reference_shaped_loop_through_dropin_follows_the_trajectory(tmp_path):
         for name in set(sys.modules) - before_mods:
             if name.split(".")[0] in ("lib", "models") or name.startswith("_vunet_ref_"):
                 del sys.modules[name]
+
+
+def test_two_graph_mode_trainers_keep_their_own_dropout_counters():
+    """the dropout step counter is ONE process-wide pointer inside the library.  A second graph-mode
+    trainer -- or ``ops.set_dropout_step(None)`` -- used to replace / clear the first trainer's, after which its steps drew
+    the same mask every step (or another trainer's sequence) without any error.  Every step now re-asserts the trainer's
+    own counter: a trainer interleaved with another one, with the pointer cleared in between, must follow exactly the
+    trajectory it follows alone."""
+    import copy
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    def make():
+        cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, n_init_batches=1, gamma_step=1e-3, information_max=5.0,
+                    train_regressor=False, dropout_prob=0.3)
+        tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True, hip_graph=False)
+        tr.enable_hip_graph(capture=False)     # device-resident schedule, eager launches
+        return tr
+    batches = [synthetic_batch(4, 32, "cuda:0", seed=300 + i) for i in range(5)]
+    eps = [[torch.randn(4, 16, 4, 4, generator=torch.Generator().manual_seed(i)).cuda(),
+            torch.randn(4, 16, 8, 8, generator=torch.Generator().manual_seed(50 + i)).cuda()] for i in range(5)]
+
+    ops.set_dropout_seed(77)
+    torch.manual_seed(5)
+    alone = make()
+    ref = [float(alone.train_fn(b, e)["loss"]) for b, e in zip(batches, eps)]
+    assert len(set(ref)) == len(ref)
+    ops.set_dropout_step(None)
+
+    ops.set_dropout_seed(77)
+    torch.manual_seed(5)
+    a = make()
+    torch.manual_seed(6)
+    other = make()                              # takes over the library's pointer at construction
+    got = []
+    for i, (b, e) in enumerate(zip(batches, eps)):
+        got.append(float(a.train_fn(b, e)["loss"]))
+        other.train_fn(batches[-1 - i], eps[-1 - i])   # the other trainer steps in between ...
+        if i % 2:
+            ops.set_dropout_step(None)          # ... and somebody clears the pointer
+    torch.cuda.synchronize()
+    ops.set_dropout_step(None)
+    assert got == ref, (got, ref)
