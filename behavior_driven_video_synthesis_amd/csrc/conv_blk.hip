@@ -1,0 +1,474 @@
+// Inference convolutions on CHANNEL-BLOCKED bf16 activations -- the render loop of BASELINE config 5
+// (models/vunets.py:508-515 `transfer`, driven frame by frame by data/data_conversions_3d.py:1130-1185; "bf16").
+//
+// Layout "blk": [N][C/8][H][W][8] bf16 -- 16-byte units of 8 consecutive channels of one pixel.  That unit IS the B
+// fragment of v_mfma_f32_32x32x16_bf16 for lane (k-half, pixel), so staging an input tile is a 16-byte copy per unit
+// (one load instruction where the fp32 NCHW path of conv_bf16.hip needs eight dword loads and a pack), every layer reads
+// and writes HALF the bytes of fp32, and the epilogue writes 8 bytes per lane into 512-byte contiguous runs.  Products
+// accumulate in fp32; activations are rounded to bf16 once, when stored (the operands of the next convolution would be
+// rounded to bf16 anyway: measured on the CPU oracle, storing the block outputs in bf16 costs 0.7 dB of PSNR on top of
+// bf16 operands).  Two kernels cover every layer of VunetAlter.transfer:
+//   conv_blk_tiled_kernel   3x3 / stride 1 / pad 1 on maps >= 32 wide: LDS-tiled like conv_bf16_kernel (4-row tiles, the
+//                           ELU prologue applied once per staged element), two sources (the skip concat), residual,
+//                           depth-to-space store, optional fp32 NCHW store (the 3-channel output layer)
+//   conv_blk_direct_kernel  everything else -- 1x1 `nin` layers, the stride-2 Downsample convolutions, 3x3 on the small
+//                           maps: no LDS, the B fragment of a tap is ONE 16-byte load per lane straight from the tensor
+//                           (lane = pixel of the flattened batch, per-lane tap offsets computed once)
+// plus fp32 NCHW <-> blk converters and the 3 -> C first layer, which reads the fp32 stickman planes directly.
+// Weights: [chunk of 16 K-channels][tap][Mpad][16] bf16 (vunet_pack_bf16_taps), the A fragment layout.
+#include "common.h"
+
+typedef __bf16 bk_bf16x8 __attribute__((ext_vector_type(8)));
+
+union BkUnit {
+  uint4 u;
+  bk_bf16x8 b;
+};
+
+struct BlkArgs {
+  vunet_conv_desc d;
+  const uint4* x1;
+  const uint4* x2;
+  const uint4* wb;
+  const float* shift;
+  const void* res;
+  void* y;
+  int y_nchw;   // 1: y is fp32 NCHW (the network's output layer)
+  int NP;
+};
+
+__device__ __forceinline__ float bk_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bk_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t bk_pack(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 p;
+  p[0] = (__bf16)a;
+  p[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ uint32_t bk_elu2(uint32_t u) { return bk_pack(elu_f(bk_lo(u)), elu_f(bk_hi(u))); }
+__device__ __forceinline__ uint4 bk_elu8(uint4 v) { return make_uint4(bk_elu2(v.x), bk_elu2(v.y), bk_elu2(v.z), bk_elu2(v.w)); }
+
+// Epilogue.  Lane = pixel; accumulator register r of a 32 x 32 tile is channel (r&3) + 8(r>>2) + 4h of the m-tile, so per
+// register quad the lane owns 4 consecutive channels of its pixel = 8 bytes of a blk unit.  bk_store_quad finishes one
+// quad: + shift, activation, + residual, rounding to bf16, plain / depth-to-space / fp32 NCHW addressing.
+__device__ __forceinline__ void bk_store_quad(const BlkArgs& a, int n, int oh, int ow, int cb, const float (&q)[4]) {
+  const vunet_conv_desc& d = a.d;
+  if (cb >= d.M) return;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = q[e];
+    if (a.shift && cb + e < d.M) t += a.shift[cb + e];
+    if (d.out_act == ACT_RELU) t = t > 0.f ? t : 0.f;
+    else if (d.out_act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+    else if (d.out_act == ACT_ELU) t = elu_f(t);
+    v[e] = t;
+  }
+  if (a.y_nchw) {
+    float* y = reinterpret_cast<float*>(a.y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (cb + e < d.M) y[((size_t)(n * d.M + cb + e) * d.Ho + oh) * d.Wo + ow] = v[e];
+    return;
+  }
+  size_t unit;
+  int sub;   // bf16 index inside the unit: 0 or 4
+  if (d.d2s) {
+    const int Cq = d.M >> 2, blk = cb / Cq, c = cb - blk * Cq;
+    unit = ((size_t)(n * (Cq >> 3) + (c >> 3)) * (2 * d.Ho) + 2 * oh + (blk >> 1)) * (2 * d.Wo) + 2 * ow + (blk & 1);
+    sub = c & 7;
+  } else {
+    unit = ((size_t)(n * (d.M >> 3) + (cb >> 3)) * d.Ho + oh) * d.Wo + ow;
+    sub = cb & 7;
+  }
+  if (a.res) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.res) + unit * 16 + sub * 2);
+    v[0] += bk_lo(r.x);
+    v[1] += bk_hi(r.x);
+    v[2] += bk_lo(r.y);
+    v[3] += bk_hi(r.y);
+  }
+  *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.y) + unit * 16 + sub * 2) = make_uint2(bk_pack(v[0], v[1]), bk_pack(v[2], v[3]));
+}
+
+__device__ __forceinline__ void bk_store_tile(const BlkArgs& a, int n, int oh, int ow, bool valid, int m_tile0, int h,
+                                              const f32x16& acc) {
+  if (!valid) return;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const float q[4] = {acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+    bk_store_quad(a, n, oh, ow, m_tile0 + 8 * q4 + 4 * h, q);
+  }
+}
+
+// ---- 3x3 / stride 1 / pad 1, maps a multiple of 32 wide and of 4 high: LDS-tiled
+template <int MT, int PRO>
+__global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a) {
+  constexpr int TW = 32, TH = 4, IH = TH + 2, IW = TW + 2, MB = 32 * MT;
+  constexpr int XU = IH * IW * 2;   // 16-byte units of the input tile: (pixel, channel half)
+  constexpr int WU = 9 * MB * 2;    // 16-byte units of a weight chunk: (tap, channel, k half)
+  constexpr int NX = (XU + 255) / 256, NW = (WU + 255) / 256;
+  constexpr int BUF = XU + WU;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+
+  const vunet_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int H = d.Hs, W = d.Ws;
+
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblocks = (d.M + MB - 1) / MB;
+  const int mb = bid % mblocks;
+  int t = bid / mblocks;
+  const int tiles_w = W / TW, tiles_h = H / TH;
+  const int tx = t % tiles_w;
+  t /= tiles_w;
+  const int ty = t % tiles_h;
+  const int n = t / tiles_h;
+  const int row0 = ty * TH, col0 = tx * TW, m0 = mb * MB;
+
+  // staging geometry: unit u = (half c8, halo row r, halo column col); consecutive lanes walk columns (16 B apart)
+  int rel[NX], lds_x[NX];
+  uint32_t vbits = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int u = tid + 256 * i;
+    const int c8 = u / (IH * IW);
+    const int rem = u - c8 * (IH * IW);
+    const int r = rem / IW, col = rem - r * IW;
+    const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+    const bool ok = u < XU && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    rel[i] = ok ? (c8 * H + ih) * W + iw : 0;   // in units, relative to the chunk's first channel block
+    lds_x[i] = 2 * rem + c8;
+    vbits |= (ok ? 1u : 0u) << i;
+  }
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  const int nch1 = d.C1 / 16, nch = nch1 + d.C2 / 16;
+  uint4 xv[NX], wv[NW];
+  auto issue_loads = [&](int ch) {
+    const bool second = ch >= nch1;
+    const int cb = second ? (ch - nch1) * 2 : ch * 2;   // first channel block of the chunk
+    const int C8 = (second ? d.C2 : d.C1) >> 3;
+    const uint4* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C8 + cb) * H * W;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xv[i] = xs[rel[i]];
+    const uint4* __restrict__ wp = a.wb + ((size_t)ch * 9 * d.Mpad + d.m_off + m0) * 2;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int w = tid + 256 * i;   // (tap, m, half)
+      const int tap = w / (2 * MB), rem = w - tap * 2 * MB;
+      const bool ok = w < WU && d.m_off + m0 + (rem >> 1) < d.Mpad;
+      const uint4 v = wp[ok ? (size_t)tap * d.Mpad * 2 + rem : 0];
+      wv[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto write_lds = [&](uint4* buf) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      if (tid + 256 * i < XU) {
+        uint4 v = xv[i];
+        if (PRO != 0) v = bk_elu8(v);
+        buf[lds_x[i]] = ((vbits >> i) & 1u) ? v : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (tid + 256 * i < WU) buf[XU + tid + 256 * i] = wv[i];
+  };
+
+  issue_loads(0);
+  write_lds(smem4);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const uint4* buf = smem4 + (ch & 1) * BUF;
+    if (ch + 1 < nch) issue_loads(ch + 1);
+    const uint4* xL = buf + 2 * (wave * IW + j) + h;
+    const uint4* wL = buf + XU + 2 * j + h;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dr = tap / 3, dc = tap % 3;
+      BkUnit av[MT], bv;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt].u = wL[2 * (tap * MB + mt * 32)];
+      bv.u = xL[2 * (dr * IW + dc)];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt].b, bv.b, acc[mt], 0, 0, 0);
+    }
+    if (ch + 1 < nch) write_lds(smem4 + ((ch + 1) & 1) * BUF);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bk_store_tile(a, n, row0 + wave, col0 + j, true, m0 + mt * 32, h, acc[mt]);
+}
+
+// ---- every other geometry: taps 1 or 9, stride 1 or 2, any map size; operands straight from global memory.
+// KS = 1: the four waves of a workgroup own four 32-pixel tiles and walk all of K.  KS = 4 (small maps: a 4x4 .. 16x16
+// map of 25 frames has 13 .. 200 pixel tiles for 256 CUs): the four waves share ONE pixel tile, wave w walks the K chunks
+// w, w+4, ... and the partial sums meet in LDS; each wave then finishes one quarter of the accumulator registers.
+// In the K-split and 1x1 forms the loads of the next chunk are in flight while the current one multiplies.
+template <int MT, int T, int PRO, int KS>
+__global__ __launch_bounds__(256) void conv_blk_direct_kernel(const BlkArgs a) {
+  static_assert(KS == 1 || (KS == 4 && MT == 1), "the K-split form reduces one 32 x 32 tile");
+  const vunet_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int mblocks = (d.M + 32 * MT - 1) / (32 * MT);
+  const int mb = blockIdx.x % mblocks, pb = blockIdx.x / mblocks;
+  const int m0 = mb * 32 * MT;
+  const int ptile = KS == 1 ? pb * 4 + wave : pb;
+  if (KS == 1 && ptile * 32 >= a.NP) return;   // whole wave out of range (no barriers in the KS == 1 form)
+  const int P = ptile * 32 + j;
+  const bool valid = P < a.NP;
+  const int Pc = valid ? P : 0;
+  const int HoWo = d.Ho * d.Wo;
+  const int n = Pc / HoWo, rem = Pc - n * HoWo;
+  const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+  const int H = d.Hs, W = d.Ws, HW = H * W;
+
+  int toff[T];   // unit offset of the tap inside a channel block, -1: outside the map
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int ih = oh * d.stride - d.pad + (T == 1 ? 0 : t / 3), iw = ow * d.stride - d.pad + (T == 1 ? 0 : t % 3);
+    const bool ok = valid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    toff[t] = ok ? ih * W + iw : -1;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  const int nch1 = d.C1 / 16, nch = nch1 + d.C2 / 16;
+  bool mok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) mok[mt] = d.m_off + m0 + mt * 32 + j < d.Mpad;
+
+  auto load = [&](int ch, uint4 (&A)[T][MT], uint4 (&B)[T]) {
+    const bool second = ch >= nch1;
+    const int cb = second ? (ch - nch1) * 2 : ch * 2;
+    const int C8 = (second ? d.C2 : d.C1) >> 3;
+    const uint4* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C8 + cb + h) * HW;   // this lane's k-half
+    const uint4* __restrict__ wp = a.wb + ((size_t)ch * T * d.Mpad + d.m_off + m0 + j) * 2 + h;
+#pragma unroll
+    for (int t = 0; t < T; ++t) B[t] = xs[toff[t] >= 0 ? toff[t] : 0];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) A[t][mt] = wp[mok[mt] ? ((size_t)t * d.Mpad + mt * 32) * 2 : 0];
+  };
+  auto mma = [&](uint4 (&A)[T][MT], uint4 (&B)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      BkUnit bv;
+      bv.u = toff[t] >= 0 ? (PRO != 0 ? bk_elu8(B[t]) : B[t]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        BkUnit av;
+        av.u = mok[mt] ? A[t][mt] : make_uint4(0, 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.b, bv.b, acc[mt], 0, 0, 0);
+      }
+    }
+  };
+
+  if (KS == 1 && T == 9) {
+    // large maps: occupancy hides the latency; one chunk in registers keeps 3-4 waves per SIMD resident
+    uint4 A0[T][MT], B0[T];
+    for (int ch = 0; ch < nch; ++ch) {
+      load(ch, A0, B0);
+      mma(A0, B0);
+    }
+  } else {
+    uint4 A0[T][MT], B0[T], A1[T][MT], B1[T];
+    int ch = KS == 1 ? 0 : wave;
+    if (ch < nch) load(ch, A0, B0);
+    for (; ch < nch; ch += 2 * KS) {
+      const bool more = ch + KS < nch;
+      if (more) load(ch + KS, A1, B1);
+      mma(A0, B0);
+      if (more) {
+        if (ch + 2 * KS < nch) load(ch + 2 * KS, A0, B0);
+        mma(A1, B1);
+      }
+    }
+  }
+
+  if (KS == 1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bk_store_tile(a, n, oh, ow, valid, m0 + mt * 32, h, acc[mt]);
+  } else {
+    __shared__ float red[4][16][64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[0][r];
+    __syncthreads();
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * wave + e;   // this wave finishes register quad `wave`
+      v[e] = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+    }
+    if (valid) bk_store_quad(a, n, oh, ow, m0 + 8 * wave + 4 * h, v);
+  }
+}
+
+// ---- converters and the first layer
+__global__ void nchw_to_blk_kernel(const float* __restrict__ x, uint4* __restrict__ y, int C8, int HW, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one unit: (n, c8, pixel)
+  if (i >= total) return;
+  const int p = (int)(i % HW);
+  const long q = i / HW;   // n * C8 + c8
+  const float* s = x + (q * 8) * HW + p;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = s[(long)e * HW];
+  y[i] = make_uint4(bk_pack(v[0], v[1]), bk_pack(v[2], v[3]), bk_pack(v[4], v[5]), bk_pack(v[6], v[7]));
+}
+
+__global__ void blk_to_nchw_kernel(const uint4* __restrict__ x, float* __restrict__ y, int C8, int HW, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int p = (int)(i % HW);
+  const long q = i / HW;
+  const uint4 u = x[i];
+  float* o = y + (q * 8) * HW + p;
+  o[0] = bk_lo(u.x); o[(long)HW] = bk_hi(u.x); o[2L * HW] = bk_lo(u.y); o[3L * HW] = bk_hi(u.y);
+  o[4L * HW] = bk_lo(u.z); o[5L * HW] = bk_hi(u.z); o[6L * HW] = bk_lo(u.w); o[7L * HW] = bk_hi(u.w);
+}
+
+// 1x1 convolution from a fp32 NCHW tensor with C <= 4 channels (the stickman planes) to a blk tensor:
+// wt_f rows = input channel (row pitch Mpad, fp32 effective weights), one thread per (pixel, output octet)
+__global__ void conv1x1_few_to_blk_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ shift,
+                                          uint4* __restrict__ y, int C, int M8, int Mpad, int HW, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (n, m8, pixel)
+  if (i >= total) return;
+  const int p = (int)(i % HW);
+  const long q = i / HW;
+  const int m8 = (int)(q % M8);
+  const long n = q / M8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = shift ? shift[m8 * 8 + e] : 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float xc = x[(n * C + c) * HW + p];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += xc * wt[(long)c * Mpad + m8 * 8 + e];
+  }
+  y[i] = make_uint4(bk_pack(v[0], v[1]), bk_pack(v[2], v[3]), bk_pack(v[4], v[5]), bk_pack(v[6], v[7]));
+}
+
+// wt_f [T*(C1p + C2p)][Mpad] fp32 (rows: source, tap, channel)  ->  wb [chunk][tap][Mpad][16] bf16
+__global__ void pack_bf16_taps_kernel(const float* __restrict__ wt, __bf16* __restrict__ wb, int C1, int C2, int Mpad, int T) {
+  const long total = (long)(C1 + C2) * T * Mpad;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i & 15);
+  long q = i >> 4;
+  const int m = (int)(q % Mpad);
+  q /= Mpad;
+  const int tap = (int)(q % T);
+  const int ch = (int)(q / T);
+  const int nch1 = C1 / 16;
+  const int C1p = (C1 + 1) & ~1, C2p = (C2 + 1) & ~1;
+  const long krow = ch < nch1 ? (long)tap * C1p + ch * 16 + c : (long)T * C1p + (long)tap * C2p + (ch - nch1) * 16 + c;
+  wb[i] = (__bf16)wt[krow * Mpad + m];
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+extern "C" int vunet_pack_bf16_taps(const float* wt_f, void* wb, int32_t C1, int32_t C2, int32_t Mpad, int32_t taps,
+                                    void* stream) {
+  if (!wt_f || !wb || C1 <= 0 || C1 % 16 || C2 % 16 || Mpad % 32 || (taps != 1 && taps != 9)) return VUNET_ERR_ARG;
+  const long total = (long)(C1 + C2) * taps * Mpad;
+  VUNET_LAUNCH(pack_bf16_taps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt_f,
+               (__bf16*)wb, C1, C2, Mpad, taps);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_nchw_to_blk(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+  if (!x || !y || N < 1 || C < 8 || C % 8 || H < 1 || W < 1) return VUNET_ERR_ARG;
+  const long total = (long)N * (C / 8) * H * W;
+  VUNET_LAUNCH(nchw_to_blk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (uint4*)y,
+               C / 8, H * W, total);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_blk_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+  if (!x || !y || N < 1 || C < 8 || C % 8 || H < 1 || W < 1) return VUNET_ERR_ARG;
+  const long total = (long)N * (C / 8) * H * W;
+  VUNET_LAUNCH(blk_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+               (const uint4*)x, y, C / 8, H * W, total);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_conv1x1_few_to_blk(const float* x, const float* wt_f, const float* shift, void* y, int32_t N, int32_t C,
+                                        int32_t H, int32_t W, int32_t M, int32_t Mpad, void* stream) {
+  if (!x || !wt_f || !y || N < 1 || C < 1 || C > 4 || M < 8 || M % 8 || Mpad < M) return VUNET_ERR_ARG;
+  const long total = (long)N * (M / 8) * H * W;
+  VUNET_LAUNCH(conv1x1_few_to_blk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, wt_f,
+               shift, (uint4*)y, C, M / 8, Mpad, H * W, total);
+  return vunet_check_launch();
+}
+
+static bool blk_tiled_ok(const vunet_conv_desc* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hs == d->Ho && d->Ws == d->Wo &&
+         d->Ws % 32 == 0 && d->Hs % 4 == 0;
+}
+
+extern "C" int vunet_conv2d_blk_tiled(const vunet_conv_desc* d) { return d && blk_tiled_ok(d) ? 1 : 0; }
+
+extern "C" int vunet_conv2d_blk(const vunet_conv_desc* d, const void* x1, const void* x2, const void* wb, const float* shift,
+                                const void* res, void* y, int32_t y_fp32_nchw, void* stream) {
+  if (!d || !x1 || !wb || !y || (d->C2 > 0 && !x2)) return VUNET_ERR_ARG;
+  if (d->mode != 0 || d->C1 <= 0 || d->C1 % 16 || d->C2 % 16 || d->Mpad % 32 || d->m_off != 0) return VUNET_ERR_UNSUPPORTED;
+  if (!((d->KH == 1 && d->KW == 1 && d->pad == 0) || (d->KH == 3 && d->KW == 3 && d->pad == 1))) return VUNET_ERR_UNSUPPORTED;
+  if (d->stride != 1 && d->stride != 2) return VUNET_ERR_UNSUPPORTED;
+  if ((d->in_act != ACT_NONE && d->in_act != ACT_ELU) || d->drop_p != 0.f) return VUNET_ERR_UNSUPPORTED;
+  if (!y_fp32_nchw && (d->M % 8 != 0 || (d->d2s && (d->M % 32 != 0)))) return VUNET_ERR_UNSUPPORTED;
+  if (d->d2s && (res || y_fp32_nchw)) return VUNET_ERR_UNSUPPORTED;
+  if (d->Ho != (d->Hs + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->Ws + 2 * d->pad - d->KW) / d->stride + 1)
+    return VUNET_ERR_ARG;
+  BlkArgs a;
+  a.d = *d;
+  a.x1 = (const uint4*)x1; a.x2 = (const uint4*)x2; a.wb = (const uint4*)wb; a.shift = shift; a.res = res; a.y = y;
+  a.y_nchw = y_fp32_nchw ? 1 : 0;
+  a.NP = d->N * d->Ho * d->Wo;
+  hipStream_t st = (hipStream_t)stream;
+  const int pro = d->in_act == ACT_ELU ? 1 : 0;
+  const int MT = d->M <= 32 ? 1 : 2;
+  if (blk_tiled_ok(d)) {
+    const int blocks = d->N * (d->Hs / 4) * (d->Ws / 32) * ((d->M + 32 * MT - 1) / (32 * MT));
+    const size_t lds = 2 * (size_t)(6 * 34 * 2 + 9 * 32 * MT * 2) * sizeof(uint4);
+    if (MT == 1) {
+      if (pro) VUNET_LAUNCH((conv_blk_tiled_kernel<1, 1>), dim3(blocks), dim3(256), lds, st, a);
+      else VUNET_LAUNCH((conv_blk_tiled_kernel<1, 0>), dim3(blocks), dim3(256), lds, st, a);
+    } else {
+      if (pro) VUNET_LAUNCH((conv_blk_tiled_kernel<2, 1>), dim3(blocks), dim3(256), lds, st, a);
+      else VUNET_LAUNCH((conv_blk_tiled_kernel<2, 0>), dim3(blocks), dim3(256), lds, st, a);
+    }
+    return vunet_check_launch();
+  }
+  const int ptiles = (a.NP + 31) / 32;
+  // small launches (the 4x4 .. 16x16 maps): one pixel tile per workgroup, K split over its four waves
+  const bool ksplit = (d->C1 + d->C2) >= 64 && (size_t)((ptiles + 3) / 4) * ((d->M + 63) / 64) < 1024;
+  const int MTd = ksplit ? 1 : MT;
+  const int blocks = (ksplit ? ptiles : (ptiles + 3) / 4) * ((d->M + 32 * MTd - 1) / (32 * MTd));
+#define BLK_DIRECT(MT_, T_, PRO_, KS_) \
+  VUNET_LAUNCH((conv_blk_direct_kernel<MT_, T_, PRO_, KS_>), dim3(blocks), dim3(256), 0, st, a)
+#define BLK_DIRECT_T(T_)                                                      \
+  do {                                                                        \
+    if (ksplit) { if (pro) BLK_DIRECT(1, T_, 1, 4); else BLK_DIRECT(1, T_, 0, 4); } \
+    else if (MT == 1) { if (pro) BLK_DIRECT(1, T_, 1, 1); else BLK_DIRECT(1, T_, 0, 1); } \
+    else { if (pro) BLK_DIRECT(2, T_, 1, 1); else BLK_DIRECT(2, T_, 0, 1); }   \
+  } while (0)
+  if (d->KH == 1) BLK_DIRECT_T(1);
+  else BLK_DIRECT_T(9);
+#undef BLK_DIRECT_T
+#undef BLK_DIRECT
+  return vunet_check_launch();
+}

@@ -577,4 +577,4 @@ extern "C" int vunet_upsample_bilinear2x_bwd(const float* dy, float* dx, int64_t
   return vunet_check_launch();
 }
 
-extern "C" int vunet_abi_version(void) { return 4; }
+extern "C" int vunet_abi_version(void) { return 5; }

@@ -6,8 +6,11 @@ numpy projection (:588-605, :892-912), a CPU cv2 raster (lib/utils.py:325-512), 
 ``synth_model.transfer`` and a D2H copy.  Here one raster launch draws every frame of the sequence and the
 synthesis runs in batches; results are identical frame for frame (tests/test_hip_render.py).
 
-``dtype="bf16"`` selects the precision BASELINE config 5 names for this loop: the 3x3 convolutions round their
-operands to bf16 and accumulate in fp32 (``ops.inference_precision``, csrc/conv_bf16.hip); fp32 is the default.
+``dtype="bf16"`` selects the precision BASELINE config 5 names for this loop; fp32 is the default.  The pose half of
+``transfer`` (``du`` + ``dd``, the part that runs per frame) then executes on channel-blocked bf16 activations
+(``render_blk.BlockedTransfer``, csrc/conv_blk.hip: bf16 operands and stored activations, fp32 accumulation);
+``layout="nchw"`` keeps fp32 NCHW activations and only rounds the operands of the 3x3 convolutions
+(``ops.inference_precision``, csrc/conv_bf16.hip) -- also what models outside ``BlockedTransfer.supported`` get.
 ``share_appearance=True`` encodes the appearance image once per sequence instead of once per frame (the
 reference re-encodes the same image for every frame); with a fixed ``eps`` the frames are bit-identical either
 way, without one the sequence shares a single posterior sample instead of drawing one per frame.
@@ -19,6 +22,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import ops
+from .render_blk import engine_for
 from .lib.utils import H36M_JOINT_MODEL, make_joint_img_batch, scale_img
 
 
@@ -48,7 +52,7 @@ def project_sequence(poses3d_world: torch.Tensor, extrinsics: torch.Tensor, intr
 @torch.no_grad()
 def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_size: Optional[int] = None,
                     joint_model=H36M_JOINT_MODEL, chunk: int = 16, as_uint8: bool = True, dtype: str = "f32",
-                    share_appearance: bool = False, eps=None):
+                    share_appearance: bool = False, eps=None, layout: str = "auto"):
     """Render T frames: ``app_img`` [1, C, H, W] (appearance), ``kps2d`` [T, J, 2] pixel keypoints.
 
     Returns (frames, stickmen): frames uint8 [T, H, W, 3] as the reference builds them
@@ -59,17 +63,27 @@ def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_s
     was_training = vunet.training
     vunet.eval()
     stick = make_joint_img_batch((size, size), kps2d.to(app_img.device), joint_model, as_float=True)
+    if layout not in ("auto", "nchw", "blk"):
+        raise ValueError(f"unknown activation layout {layout!r}")
+    engine = engine_for(vunet) if (dtype == "bf16" and layout != "nchw") else None
+    if layout == "blk" and engine is None:
+        raise ValueError("layout='blk' needs dtype='bf16' and a model BlockedTransfer.supported covers")
     outs = []
     # the weights do not change inside a sequence: fold / pack every layer once (two launches) instead of per call
     with ops.inference_precision(dtype), ops.prepacked(vunet):
         code = vunet.appearance_code(app_img, eps) if share_appearance else None
+        if code is not None and engine is not None:
+            code = engine.encode_code(code)
         for s in range(0, stick.shape[0], chunk):
             c = stick[s:s + chunk]
-            if code is not None:
-                outs.append(vunet.transfer_code(code, c))
-            else:
+            if code is None:
                 e = None if eps is None else [t.expand(c.shape[0], -1, -1, -1).contiguous() for t in eps]
-                outs.append(vunet.transfer(app_img.expand(c.shape[0], -1, -1, -1).contiguous(), c, e))
+                frame_code = vunet.appearance_code(app_img.expand(c.shape[0], -1, -1, -1).contiguous(), e)
+                if engine is not None:
+                    frame_code = engine.encode_code(frame_code)
+            else:
+                frame_code = code
+            outs.append(engine.transfer_code(frame_code, c) if engine is not None else vunet.transfer_code(frame_code, c))
     rgb = torch.cat(outs, dim=0)
     vunet.train(was_training)
     if as_uint8:

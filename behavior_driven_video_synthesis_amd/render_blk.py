@@ -1,0 +1,193 @@
+"""``VunetAlter.transfer_code`` on channel-blocked bf16 activations (the render loop of BASELINE config 5).
+
+The pose half of ``transfer`` (models/vunets.py:508-515: ``dd(du(c), means, training=True)``) is what the render loop
+runs once per frame (data/data_conversions_3d.py:1130-1185).  Executed layer by layer through ``vunet_conv2d_blk``
+(csrc/conv_blk.hip): every activation lives in HBM as ``[N][C/8][H][W][8]`` bf16, the layout the bf16 matrix-core
+instruction consumes directly, so each layer moves half the bytes of the fp32 NCHW path and nothing is re-packed between
+layers.  The module structure, the order of operations and the parameters are the model's own (``vunet.du`` /
+``vunet.dd``: the same ``VunetRNB`` / ``Downsample`` / ``Upsample`` objects the training step uses); only the tensor
+layout and the rounding of stored activations (bf16, round to nearest even) differ from ``ops.inference_precision``.
+
+Weights are folded (weight norm, gamma, beta -> effective weights + shift: ``vunet_weightnorm_fwd``) and packed once
+per parameter version; nothing here runs without the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+from .lib.modules import NormConv2d, _act_code
+from .ops import ACT_ELU, ACT_NONE, ConvDesc, _call, _p, _stream, conv_out_size
+
+
+class _Packed:
+    __slots__ = ("stamp", "wb", "shift", "wt_f", "cout", "mpad", "k", "stride", "pad", "c1", "c2")
+
+
+def blk_empty(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
+    assert c % 8 == 0
+    return torch.empty(n, c // 8, h, w, 8, device=device, dtype=torch.bfloat16)
+
+
+def to_blk(x: torch.Tensor) -> torch.Tensor:
+    """fp32 NCHW -> blk (round to nearest even)."""
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = blk_empty(n, c, h, w, x.device)
+    _call("vunet_nchw_to_blk", _p(x), _p(y), n, c, h, w, _stream())
+    return y
+
+
+def from_blk(x: torch.Tensor) -> torch.Tensor:
+    """blk -> fp32 NCHW (exact)."""
+    n, c8, h, w, _ = x.shape
+    y = torch.empty(n, c8 * 8, h, w, device=x.device, dtype=torch.float32)
+    _call("vunet_blk_to_nchw", _p(x), _p(y), n, c8 * 8, h, w, _stream())
+    return y
+
+
+class BlockedTransfer:
+    """Executor bound to one ``VunetAlter``; ``transfer_code(codes, stickmen)`` mirrors the model's method."""
+
+    def __init__(self, vunet):
+        if not self.supported(vunet):
+            raise ValueError("this model is outside the blocked render path (see BlockedTransfer.supported)")
+        self.vunet = vunet
+        self._packs = {}
+
+    @staticmethod
+    def supported(vunet) -> bool:
+        """Weight-normalised layers (``conv_layer_type: l1``), ELU blocks, sub-pixel up-sampling, widths that are
+        multiples of 16 -- i.e. every shipped VunetAlter configuration."""
+        from .models.vunets import DecDownAlter
+        dd, du = getattr(vunet, "dd", None), getattr(vunet, "du", None)
+        if not isinstance(dd, DecDownAlter) or du is None:
+            return False
+        for m in list(du.modules()) + list(dd.modules()):
+            if hasattr(m, "_params") and type(m) is not NormConv2d:
+                return False
+            if hasattr(m, "act_fn") and hasattr(m, "dout") and _act_code(m.act_fn)[0] != ACT_ELU:
+                return False
+            if hasattr(m, "subpixel") and not m.subpixel:
+                return False
+        if du.nin.conv.in_channels > 4:
+            return False
+        for m in list(du.modules()) + list(dd.modules()):
+            if type(m) is NormConv2d and m is not du.nin:
+                cin, cout = m.conv.in_channels, m.conv.out_channels
+                if cin % 16 or (cout % 8 and m is not dd.out_conv):
+                    return False
+        return True
+
+    # ---- weights ------------------------------------------------------------------------------------------------
+    def _pack(self, m, c1: int, c2: int = 0) -> _Packed:
+        params = m._params()
+        stamp = (c1, c2) + tuple((t.data_ptr(), t._version) for t in params)
+        hit = self._packs.get(id(m))
+        if hit is not None and hit.stamp == stamp:
+            return hit
+        v = params[0]
+        wt_f, _, _, shift, _, _, _ = ops.pack_weights(*[t.detach() for t in params], c1, c2, m.kind, False)
+        L = _Packed()
+        L.stamp, L.shift, L.cout, L.mpad = stamp, shift, v.shape[0], wt_f.shape[1]
+        L.k, L.stride, L.pad, L.c1, L.c2 = m.k, m.stride, m.padding, c1, c2
+        L.wt_f, L.wb = wt_f, None
+        if c1 % 16 == 0:
+            L.wb = torch.empty((c1 + c2) * m.k * m.k * L.mpad, device=v.device, dtype=torch.bfloat16)
+            _call("vunet_pack_bf16_taps", _p(wt_f), _p(L.wb), c1, c2, L.mpad, m.k * m.k, _stream())
+            L.wt_f = None
+        self._packs[id(m)] = L
+        return L
+
+    # ---- layers -------------------------------------------------------------------------------------------------
+    def _conv(self, m, x1, x2=None, res=None, in_act=ACT_NONE, d2s=False, out_nchw=False):
+        n, c8, hs, ws, _ = x1.shape
+        c1, c2 = c8 * 8, 0 if x2 is None else x2.shape[1] * 8
+        L = self._pack(m, c1, c2)
+        ho, wo = conv_out_size(hs, L.k, L.stride, L.pad), conv_out_size(ws, L.k, L.stride, L.pad)
+        if out_nchw:
+            y = torch.empty(n, L.cout, ho, wo, device=x1.device, dtype=torch.float32)
+        elif d2s:
+            y = blk_empty(n, L.cout // 4, 2 * ho, 2 * wo, x1.device)
+        else:
+            y = blk_empty(n, L.cout, ho, wo, x1.device)
+        d = ConvDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, M=L.cout, m_off=0, Mpad=L.mpad, Ho=ho, Wo=wo, KH=L.k, KW=L.k,
+                     stride=L.stride, pad=L.pad, mode=0, in_act=in_act, in_slope=0.0, drop_p=0.0, drop_seed=0,
+                     out_act=ACT_NONE, d2s=int(d2s))
+        tiled = _lib.lib().vunet_conv2d_blk_tiled(ctypes.byref(d)) == 1
+        with ops._Timed(("conv_blk_fwd", n, c1, c2, hs, ws, L.cout, L.k, L.stride, int(res is not None), int(out_nchw),
+                         "conv_blk_tiled_kernel" if tiled else "conv_blk_direct_kernel"),
+                        2.0 * n * ho * wo * L.cout * (c1 + c2) * L.k * L.k):
+            _call("vunet_conv2d_blk", ctypes.byref(d), _p(x1), _p(x2), _p(L.wb), _p(L.shift), _p(res), _p(y),
+                  int(out_nchw), _stream())
+        return y
+
+    def _first(self, m, image):
+        """``nin`` of the pose encoder: 1x1 from the fp32 stickman planes, computed in fp32, stored blocked."""
+        image = image.contiguous()
+        n, c, h, w = image.shape
+        L = self._pack(m, c, 0)
+        y = blk_empty(n, L.cout, h, w, image.device)
+        _call("vunet_conv1x1_few_to_blk", _p(image), _p(L.wt_f), _p(L.shift), _p(y), n, c, h, w, L.cout, L.mpad, _stream())
+        return y
+
+    def _rnb(self, blk, x, a=None):
+        # lib/modules.py:185-233 with the model in eval mode (no dropout): x + conv3x3(elu(cat(x, nin(elu(a)))))
+        if a is not None:
+            a = self._conv(blk.nin, a, in_act=ACT_ELU)
+            return self._conv(blk.conv, x, a, res=x, in_act=ACT_ELU)
+        return self._conv(blk.conv, x, res=x, in_act=ACT_ELU)
+
+    def _pyramid(self, p, image):
+        # models/vunets.py:222-261 (DecUp)
+        feats, h = [], self._first(p.nin, image)
+        blocks = iter(p.blocks)
+        for level in range(p.n_scales):
+            for _ in range(p.n_rnb):
+                h = self._rnb(next(blocks), h)
+                feats.append(h)
+            if level < p.n_scales - 1:
+                h = self._conv(p.downs[level].down, h)
+        return feats
+
+    def _decode(self, d, feats, codes):
+        # models/vunets.py:264-424 (DecDownAlter.forward, training=True: the posterior means are the latent code)
+        skips, latents = list(feats), list(codes)
+        h = self._conv(d.nin, skips[-1])
+        for level in range(d.n_scales):
+            h = self._rnb(d.blocks[2 * level], h, skips.pop())
+            if level < d.n_latent_scales:
+                h = self._rnb(d.auto_blocks[level], h, latents.pop(0))
+            h = self._rnb(d.blocks[2 * level + 1], h, skips.pop())
+            if level < d.n_scales - 1:
+                h = self._conv(d.ups[level].up, h, d2s=True)
+        assert not skips and not latents
+        return self._conv(d.out_conv, h, out_nchw=True)
+
+    # ---- the model's surface ------------------------------------------------------------------------------------
+    def encode_code(self, means: Sequence[torch.Tensor]):
+        """fp32 NCHW posterior means (``VunetAlter.appearance_code``) -> blocked code."""
+        return [to_blk(m) for m in means]
+
+    @torch.no_grad()
+    def transfer_code(self, code_blk: Sequence[torch.Tensor], c: torch.Tensor) -> torch.Tensor:
+        """``VunetAlter.transfer_code``; a batch-1 code is broadcast over the frames of ``c``.  -> fp32 [N, 3, H, W]."""
+        if self.vunet.training:
+            raise RuntimeError("the blocked render path has no dropout: call vunet.eval() first")
+        n = c.shape[0]
+        code = [m if m.shape[0] == n else m.expand(n, -1, -1, -1, -1).contiguous() for m in code_blk]
+        return self._decode(self.vunet.dd, self._pyramid(self.vunet.du, c), code)
+
+
+def engine_for(vunet) -> Optional[BlockedTransfer]:
+    """The model's executor (created on first use, kept on the module), or None if the model is not covered."""
+    eng = vunet.__dict__.get("_vunet_blk_engine")
+    if eng is None:
+        if not BlockedTransfer.supported(vunet):
+            return None
+        eng = BlockedTransfer(vunet)
+        object.__setattr__(vunet, "_vunet_blk_engine", eng)
+    return eng

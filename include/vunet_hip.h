@@ -147,6 +147,29 @@ int vunet_pack_bf16(const float* wt_f, void* wb, int32_t C1, int32_t C2, int32_t
 int vunet_conv2d_bf16(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wb,
                       const float* shift, const float* res, float* y, void* stream);
 
+/* The same inference path on CHANNEL-BLOCKED bf16 activations (csrc/conv_blk.hip): tensors are
+ *   blk [N][C/8][H][W][8] bf16  -- 16-byte units of 8 consecutive channels of one pixel (C a multiple of 8),
+ * half the bytes of fp32 NCHW per layer and one 16-byte load per matrix-core B fragment.  Every layer of
+ * VunetAlter.transfer (models/vunets.py:508-515) is covered: 3x3 / 1x1, stride 1 / 2, two sources (the skip concat),
+ * ELU prologue, residual, depth-to-space store; products accumulate in fp32, activations are rounded to bf16 (RNE)
+ * once, when stored.  d as for vunet_conv2d_gather mode 0 with C1, C2 multiples of 16, M of 8 (32 with d2s), m_off 0,
+ * no dropout; x1 / x2 / res / y blk tensors; y_fp32_nchw != 0: y is a fp32 NCHW tensor instead (any M; the network's
+ * 3-channel output layer).
+ *   vunet_pack_bf16_taps     wt_f (fp32 K-major weights of vunet_weightnorm_fwd, row pitch Mpad) ->
+ *                            wb [(C1+C2)/16][taps][Mpad][16] bf16, taps = 1 or 9
+ *   vunet_nchw_to_blk / vunet_blk_to_nchw   fp32 NCHW <-> blk (RNE / exact)
+ *   vunet_conv1x1_few_to_blk 1x1 convolution of a fp32 NCHW tensor with C <= 4 channels (the stickman planes; wt_f rows =
+ *                            input channel) in fp32, stored as blk -- the first layer of the pose encoder */
+int vunet_conv2d_blk(const vunet_conv_desc* d, const void* x1, const void* x2, const void* wb, const float* shift,
+                     const void* res, void* y, int32_t y_fp32_nchw, void* stream);
+/* 1: vunet_conv2d_blk runs the LDS-tiled kernel for this problem (conv_blk_tiled_kernel), 0: the direct one */
+int vunet_conv2d_blk_tiled(const vunet_conv_desc* d);
+int vunet_pack_bf16_taps(const float* wt_f, void* wb, int32_t C1, int32_t C2, int32_t Mpad, int32_t taps, void* stream);
+int vunet_nchw_to_blk(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int vunet_blk_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int vunet_conv1x1_few_to_blk(const float* x, const float* wt_f, const float* shift, void* y, int32_t N, int32_t C,
+                             int32_t H, int32_t W, int32_t M, int32_t Mpad, void* stream);
+
 /* Weight gradient  dW[co][tap][ci] = sum_px dy[co][px] * f(x)[ci][px (+) tap]  with the same
  * prologue f as the forward; split over `nsplit` pixel ranges into partial slabs
  *   slabs[nsplit][Coutp][T*(C1+C2)]  (Coutp = Cout rounded up to 32)  and  dshift[nsplit][Coutp].

@@ -1,0 +1,229 @@
+"""Channel-blocked bf16 inference convolutions (csrc/conv_blk.hip, include/vunet_hip.h: vunet_conv2d_blk and friends)
+and the render executor built on them (render_blk.BlockedTransfer = VunetAlter.transfer_code, models/vunets.py:508-515).
+
+Floating point: the kernels multiply bf16 operands exactly and accumulate in fp32, so against a float64 convolution of
+the SAME bf16-rounded operands the only differences are the accumulation order (<= 1e-5 of the output scale here) and
+the final rounding of the stored activation to bf16 (half an ulp = 2^-9 relative).  Tolerances below are those two.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_parity_utils import assert_close, psnr
+from synth import synth_image, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _wt_rows(w, c1, c2, mpad):
+    """[M, C1+C2, k, k] -> the K-major layout of vunet_weightnorm_fwd: rows (source, tap, channel), pitch Mpad."""
+    m, _, k, _ = w.shape
+    t = k * k
+    c1p, c2p = (c1 + 1) // 2 * 2, (c2 + 1) // 2 * 2
+    out = torch.zeros(t * (c1p + c2p), mpad, device=w.device)
+    wf = w.reshape(m, c1 + c2, t)
+    for tap in range(t):
+        out[tap * c1p:tap * c1p + c1, :m] = wf[:, :c1, tap].T
+        if c2:
+            out[t * c1p + tap * c2p:t * c1p + tap * c2p + c2, :m] = wf[:, c1:, tap].T
+    return out
+
+
+def _d2s(y):
+    n, c4, h, w = y.shape
+    cq = c4 // 4
+    return y.view(n, 2, 2, cq, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, cq, 2 * h, 2 * w)
+
+
+CASES = [
+    # name, N, C1, C2, H, W, M, k, stride, elu, res, d2s, nchw
+    ("tiled_two_sources_res", 2, 32, 16, 32, 32, 64, 3, 1, True, True, False, False),
+    ("tiled_single_mt1", 1, 16, 0, 8, 64, 32, 3, 1, False, False, False, False),
+    ("tiled_d2s", 2, 32, 0, 32, 32, 128, 3, 1, False, False, True, False),
+    ("tiled_out_layer_nchw", 2, 32, 0, 32, 32, 3, 3, 1, False, False, False, True),
+    ("tiled_m48", 1, 16, 16, 4, 32, 48, 3, 1, True, True, False, False),
+    ("direct_1x1_elu", 3, 32, 0, 16, 16, 48, 1, 1, True, False, False, False),
+    ("direct_1x1_ragged", 3, 16, 0, 5, 7, 16, 1, 1, False, False, False, False),
+    ("direct_3x3_small_map", 5, 32, 32, 8, 8, 32, 3, 1, True, True, False, False),
+    ("direct_3x3_4x4_d2s", 3, 32, 0, 4, 4, 128, 3, 1, False, False, True, False),
+    ("direct_stride2", 2, 32, 0, 32, 32, 64, 3, 2, False, False, False, False),
+    ("direct_stride2_ragged", 3, 16, 0, 10, 6, 24, 3, 2, False, False, False, False),
+    ("direct_16_wide", 2, 64, 64, 16, 16, 64, 3, 1, True, True, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv2d_blk_matches_bf16_operand_convolution(case):
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.render_blk import blk_empty, from_blk, to_blk
+    _, n, c1, c2, h, w, m, k, stride, elu, res, d2s, nchw = case
+    g = torch.Generator().manual_seed(100 + CASES.index(case))
+    dev = "cuda"
+    x1 = _bf(torch.randn(n, c1, h, w, generator=g)).to(dev)
+    x2 = _bf(torch.randn(n, c2, h, w, generator=g)).to(dev) if c2 else None
+    wgt = (torch.randn(m, c1 + c2, k, k, generator=g) / np.sqrt((c1 + c2) * k * k)).to(dev)
+    shift = torch.randn(m, generator=g).to(dev)
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = _bf(torch.randn(n, m, ho, wo, generator=g)).to(dev) if res else None
+    mpad = (m + 31) // 32 * 32
+
+    wt_f = _wt_rows(wgt, c1, c2, mpad)
+    wb = torch.empty((c1 + c2) * k * k * mpad, device=dev, dtype=torch.bfloat16)
+    ops._call("vunet_pack_bf16_taps", ops._p(wt_f), ops._p(wb), c1, c2, mpad, k * k, ops._stream())
+    b1, b2, br = to_blk(x1), (to_blk(x2) if c2 else None), (to_blk(r) if res else None)
+    assert torch.equal(from_blk(b1), x1)                       # converters are exact on bf16-representable values
+    if nchw:
+        y = torch.full((n, m, ho, wo), float("nan"), device=dev)
+    elif d2s:
+        y = blk_empty(n, m // 4, 2 * ho, 2 * wo, dev)
+    else:
+        y = blk_empty(n, m, ho, wo, dev)
+    d = ops.ConvDesc(N=n, C1=c1, C2=c2, Hs=h, Ws=w, M=m, m_off=0, Mpad=mpad, Ho=ho, Wo=wo, KH=k, KW=k, stride=stride,
+                     pad=pad, mode=0, in_act=ops.ACT_ELU if elu else ops.ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0,
+                     out_act=ops.ACT_NONE, d2s=int(d2s))
+    ops._call("vunet_conv2d_blk", ctypes.byref(d), ops._p(b1), ops._p(b2), ops._p(wb), ops._p(shift), ops._p(br), ops._p(y),
+              int(nchw), ops._stream())
+    got = y if nchw else from_blk(y)
+
+    x = x1 if x2 is None else torch.cat([x1, x2], 1)
+    if elu:
+        x = _bf(F.elu(x))
+    want = F.conv2d(x.double(), _bf(wgt).double(), None, stride, pad).float() + shift.view(1, -1, 1, 1)
+    if res:
+        want = want + r
+    if d2s:
+        want = _d2s(want)
+    scale = float(want.abs().max())
+    err = (got - want).abs()
+    if nchw:
+        assert float(err.max()) <= 2e-5 * scale, (float(err.max()), scale)
+    else:
+        bound = want.abs() * 2.0 ** -8 + 2e-5 * scale      # one bf16 rounding of the stored value + accumulation order
+        assert bool((err <= bound).all()), float((err - bound).max())
+
+
+def test_layout_converters_round_to_nearest_even():
+    from behavior_driven_video_synthesis_amd.render_blk import from_blk, to_blk
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(3, 24, 5, 7, generator=g) * 3).cuda()
+    b = to_blk(x)
+    assert b.shape == (3, 3, 5, 7, 8) and b.dtype == torch.bfloat16
+    want = x.to(torch.bfloat16).view(3, 3, 8, 5, 7).permute(0, 1, 3, 4, 2).contiguous()
+    assert torch.equal(b, want)
+    assert torch.equal(from_blk(b), want.permute(0, 1, 4, 2, 3).reshape(3, 24, 5, 7).float())
+
+
+def test_first_layer_reads_fp32_planes():
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.render_blk import blk_empty, from_blk
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 9, 11, generator=g).cuda()
+    w = torch.randn(16, 3, 1, 1, generator=g).cuda()
+    shift = torch.randn(16, generator=g).cuda()
+    wt_f = _wt_rows(w, 3, 0, 32)
+    y = blk_empty(2, 16, 9, 11, "cuda")
+    ops._call("vunet_conv1x1_few_to_blk", ops._p(x), ops._p(wt_f), ops._p(shift), ops._p(y), 2, 3, 9, 11, 16, 32, ops._stream())
+    want = F.conv2d(x, w) + shift.view(1, -1, 1, 1)
+    err = (from_blk(y) - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -8 + 1e-6).all())
+
+
+def test_unsupported_problems_are_refused():
+    from behavior_driven_video_synthesis_amd import _lib, ops
+    lib = _lib.lib()
+    t = torch.zeros(4096, device="cuda")
+    base = dict(N=1, C1=16, C2=0, Hs=8, Ws=8, M=16, m_off=0, Mpad=32, Ho=8, Wo=8, KH=3, KW=3, stride=1, pad=1, mode=0,
+                in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
+    for bad in (dict(C1=12), dict(M=12), dict(drop_p=0.1), dict(mode=1), dict(KH=5, KW=5, pad=2), dict(Ho=7), dict(m_off=32)):
+        d = ops.ConvDesc(**{**base, **bad})
+        rc = lib.vunet_conv2d_blk(ctypes.byref(d), ops._p(t), None, ops._p(t), None, None, ops._p(t), 0, ops._stream())
+        assert rc != 0, bad
+
+
+def _tiny_net(seed=9, size=64):
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    cfg = dict(spatial_size=size, bottleneck_factor=2, box_factor=2, n_scales=0, n_latent_scales=2,
+               conv_layer_type="l1", nf_start=16, nf_max=32, subpixel_upsampling=True, dropout_prob=0.05)
+    net = VunetAlter(**cfg)
+    net.load_state_dict(synth_state_dict({k: list(v.shape) for k, v in net.state_dict().items()}, seed))
+    return net.cuda().eval()
+
+
+def test_blocked_transfer_follows_the_model():
+    """BlockedTransfer.transfer_code vs VunetAlter.transfer_code (fp32-accurate kernels) on the same code and stickmen."""
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.render_blk import BlockedTransfer, engine_for
+    net = _tiny_net()
+    assert BlockedTransfer.supported(net)
+    eng = engine_for(net)
+    assert engine_for(net) is eng
+    app = synth_image("app16", (1, 3, 64, 64), 9).cuda()
+    c = synth_image("stick", (3, 3, 64, 64), 4).cuda()
+    with torch.no_grad():
+        code = net.appearance_code(app)
+        want = net.transfer_code(code, c)
+        ops.profile_start()
+        got = eng.transfer_code(eng.encode_code(code), c)
+        fam = ops.profile_stop(by_kernel=True)
+    assert got.shape == want.shape and got.dtype == torch.float32
+    assert {"conv_blk_tiled_kernel", "conv_blk_direct_kernel"} <= set(fam)
+    scale = float(want.abs().max())
+    assert psnr(got, want, peak=2 * scale) >= 40.0
+    assert float((got - want).abs().max()) <= 0.03 * scale
+    # weights are re-packed when (and only when) a parameter changes
+    n_packs = len(eng._packs)
+    stamps = {k: v.stamp for k, v in eng._packs.items()}
+    with torch.no_grad():
+        eng.transfer_code(eng.encode_code(code), c)
+        assert {k: v.stamp for k, v in eng._packs.items()} == stamps and len(eng._packs) == n_packs
+        net.dd.out_conv.beta.add_(0.5)
+        moved = eng.transfer_code(eng.encode_code(code), c)
+    assert_close(moved, got + 0.5, rtol=0, atol=1e-5 * scale + 1e-6, name="beta shift reaches the output")
+    net.train()
+    with pytest.raises(RuntimeError):
+        eng.transfer_code(eng.encode_code(code), c)
+
+
+def test_render_sequence_layouts_agree():
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.render import render_sequence
+    net = _tiny_net()
+    app = synth_image("app16", (1, 3, 64, 64), 9).cuda()
+    rng = np.random.default_rng(3)
+    kps = torch.from_numpy(rng.uniform(6, 58, size=(5, 17, 2))).float().cuda()
+    with torch.no_grad():
+        shapes = [tuple(m.shape) for m in net.appearance_code(app)]
+    eps = [synth_image(f"eps{i}", s, 9).cuda() for i, s in enumerate(shapes)]
+    f32, _ = render_sequence(net, app, kps, chunk=2, as_uint8=False, eps=eps)
+    scale = float(f32.abs().max())
+    for kw in (dict(share_appearance=True), dict(share_appearance=False)):
+        ops.profile_start()
+        blk, _ = render_sequence(net, app, kps, chunk=3, as_uint8=False, eps=eps, dtype="bf16", layout="blk", **kw)
+        fam = ops.profile_stop()
+        assert fam["conv_blk_fwd"]["n"] >= 2 * 30
+        nchw, _ = render_sequence(net, app, kps, chunk=3, as_uint8=False, eps=eps, dtype="bf16", layout="nchw", **kw)
+        assert psnr(blk, f32, peak=2 * scale) >= 40.0
+        assert psnr(blk, nchw, peak=2 * scale) >= 40.0
+    with pytest.raises(ValueError):
+        render_sequence(net, app, kps, as_uint8=False, eps=eps, layout="blk")        # fp32 has no blocked layout
+    u8, _ = render_sequence(net, app, kps, chunk=5, eps=eps, dtype="bf16")
+    ref8, _ = render_sequence(net, app, kps, chunk=5, eps=eps)
+    assert u8.dtype == torch.uint8 and int((u8.int() - ref8.int()).abs().max()) <= 8
+
+
+def test_models_outside_the_blocked_path_fall_back_to_nchw_kernels():
+    from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
+    from behavior_driven_video_synthesis_amd.render_blk import BlockedTransfer
+    cfg = dict(spatial_size=64, bottleneck_factor=2, box_factor=2, n_scales=0, n_latent_scales=2,
+               conv_layer_type="l1", nf_start=8, nf_max=24, subpixel_upsampling=True, dropout_prob=0.0)
+    assert not BlockedTransfer.supported(VunetAlter(**cfg))
+    cfg.update(nf_start=16, nf_max=32, subpixel_upsampling=False)
+    assert not BlockedTransfer.supported(VunetAlter(**cfg))

@@ -66,7 +66,7 @@ def test_render_bf16_precision_and_shared_appearance():
     assert_close(shared, f32, rtol=1e-4, atol=1e-5, name="shared appearance code")
 
     ops.profile_start()
-    bf16, _ = render_sequence(net, app, kps, chunk=5, as_uint8=False, eps=eps, dtype="bf16")
+    bf16, _ = render_sequence(net, app, kps, chunk=5, as_uint8=False, eps=eps, dtype="bf16", layout="nchw")
     fam = ops.profile_stop()
     assert "conv_bf16_fwd" in fam and fam["conv_bf16_fwd"]["n"] >= 8        # the bf16 kernel really ran
     scale = float(f32.abs().max())

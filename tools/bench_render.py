@@ -24,6 +24,8 @@ ap.add_argument("--frames", type=int, default=50)
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--chunk", type=int, default=25)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--layers", action="store_true", help="per-layer kernel times of the bf16 modes on stderr")
+ap.add_argument("--only", default="", help="run just this mode (the PMC passes of tools/profile.sh)")
 a = ap.parse_args()
 
 torch.manual_seed(0)
@@ -35,6 +37,13 @@ app = (torch.rand(1, 3, a.size, a.size, device="cuda") * 2 - 1)
 kps = torch.rand(a.frames, 17, 2, device="cuda") * (a.size - 20) + 10
 with torch.no_grad():
     eps = [torch.randn_like(m) for m in net.appearance_code(app)]
+
+
+def blk_bytes(key):
+    """Algorithmic bytes of one conv_blk launch: bf16 sources + output (+ residual); the fp32 output layer 4 B/value."""
+    _, n, c1, c2, hs, ws, m, k, s, has_res, nchw, _ = key
+    ho, wo = (hs - 1) // s + 1, (ws - 1) // s + 1
+    return 2.0 * n * hs * ws * (c1 + c2) + (4.0 if nchw else 2.0) * n * ho * wo * m + (2.0 * n * ho * wo * m if has_res else 0.0)
 
 
 def run(**kwargs):
@@ -50,9 +59,14 @@ def run(**kwargs):
 
 ref, t32 = run()
 peak = 2 * float(ref.abs().max())
-for name, kwargs in (("fp32", {}), ("bf16", {"dtype": "bf16"}),
-                     ("bf16+shared_appearance", {"dtype": "bf16", "share_appearance": True}),
-                     ("fp32+shared_appearance", {"share_appearance": True})):
+MODES = (("fp32", {}), ("bf16 operands, fp32 NCHW activations", {"dtype": "bf16", "layout": "nchw"}),
+         ("bf16 operands, fp32 NCHW activations+shared_appearance", {"dtype": "bf16", "layout": "nchw", "share_appearance": True}),
+         ("bf16 blocked", {"dtype": "bf16"}),
+         ("bf16 blocked+shared_appearance", {"dtype": "bf16", "share_appearance": True}),
+         ("fp32+shared_appearance", {"share_appearance": True}))
+if a.only:
+    MODES = tuple(m for m in MODES if m[0] == a.only)
+for name, kwargs in MODES:
     out, t = run(**kwargs)
     mse = float(((out - ref) ** 2).mean())
     rec = {"mode": name, "frames": a.frames, "size": a.size, "ms_per_sequence": round(1e3 * t, 2),
@@ -62,18 +76,27 @@ for name, kwargs in (("fp32", {}), ("bf16", {"dtype": "bf16"}),
         ops.profile_start()
         render_sequence(net, app, kps, chunk=a.chunk, as_uint8=False, eps=eps, **kwargs)
         fam = ops.profile_stop(detail=True)
-        ms = nbytes = flop = 0.0
-        for key, v in fam.items():
-            if key[0] != "conv_bf16_fwd":
-                continue
-            _, n, c1, c2, hs, ws, m, k, s, act, _ = key
-            per = 4.0 * n * hs * ws * (c1 + c2 + m + (m if act else 0))   # RNB layers (ELU prologue) add the residual
-            ms += v["ms"]
-            nbytes += per * v["n"]
-            flop += v["flop"]
         tot = sum(v["ms"] for v in fam.values())
-        rec["conv_bf16_kernel"] = {"ms_per_sequence": round(ms, 2), "share_of_conv_time": round(ms / tot, 3),
-                                   "algorithmic_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                                   "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 8e12, 3),
-                                   "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1)}
+        per_kernel = {}
+        for key, v in fam.items():
+            if key[0] == "conv_bf16_fwd":
+                _, n, c1, c2, hs, ws, m, k, s, act, kern = key
+                per = 4.0 * n * hs * ws * (c1 + c2 + m + (m if act else 0))   # RNB layers (ELU prologue) add the residual
+            elif key[0] == "conv_blk_fwd":
+                per, kern = blk_bytes(key), key[-1]
+            else:
+                continue
+            e = per_kernel.setdefault(kern, {"ms": 0.0, "bytes": 0.0, "flop": 0.0, "n": 0})
+            e["ms"] += v["ms"]
+            e["bytes"] += per * v["n"]
+            e["flop"] += v["flop"]
+            e["n"] += v["n"]
+        for kern, e in per_kernel.items():
+            rec[kern] = {"ms_per_sequence": round(e["ms"], 2), "launches": e["n"], "share_of_conv_time": round(e["ms"] / tot, 3),
+                         "algorithmic_GBps": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(e["bytes"] / (e["ms"] * 1e-3) / 8e12, 3),
+                         "TFLOPs": round(e["flop"] / (e["ms"] * 1e-3) / 1e12, 1)}
+        if a.layers:
+            for key, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:24]:
+                print("#", key, round(v["ms"], 3), "ms", v["n"], "launches", file=sys.stderr)
     print(json.dumps(rec))
