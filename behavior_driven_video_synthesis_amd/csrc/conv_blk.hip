@@ -15,7 +15,9 @@
 //                           maps: no LDS, the B fragment of a tap is ONE 16-byte load per lane straight from the tensor
 //                           (lane = pixel of the flattened batch, per-lane tap offsets computed once)
 // plus fp32 NCHW <-> blk converters and the 3 -> C first layer, which reads the fp32 stickman planes directly.
-// Weights: [chunk of 16 K-channels][tap][Mpad][16] bf16 (vunet_pack_bf16_taps), the A fragment layout.
+// Weights: [chunk of 16 K-channels][k half][tap][Mpad][8] bf16 (vunet_pack_bf16_taps): 16-byte A-fragment units, k-half
+// planes -- like the LDS images, so that the 16 lanes a ds_read_b128 serves together read 16 consecutive units
+// (interleaving the halves put every lane group on 8 of the 16 slots of the 256-byte bank row: 2-way conflicts).
 #include "common.h"
 
 typedef __bf16 bk_bf16x8 __attribute__((ext_vector_type(8)));
@@ -103,9 +105,9 @@ __device__ __forceinline__ void bk_store_tile(const BlkArgs& a, int n, int oh, i
 }
 
 // ---- 3x3 / stride 1 / pad 1, maps a multiple of 32 wide and of 4 high: LDS-tiled
-template <int MT, int PRO>
+template <int MT, int NT, int PRO>
 __global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a) {
-  constexpr int TW = 32, TH = 4, IH = TH + 2, IW = TW + 2, MB = 32 * MT;
+  constexpr int TW = 32, TH = 4 * NT, IH = TH + 2, IW = TW + 2, MB = 32 * MT;   // wave w owns rows w*NT .. w*NT + NT-1
   constexpr int XU = IH * IW * 2;   // 16-byte units of the input tile: (pixel, channel half)
   constexpr int WU = 9 * MB * 2;    // 16-byte units of a weight chunk: (tap, channel, k half)
   constexpr int NX = (XU + 255) / 256, NW = (WU + 255) / 256;
@@ -140,41 +142,44 @@ __global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a)
     const int ih = row0 - 1 + r, iw = col0 - 1 + col;
     const bool ok = u < XU && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     rel[i] = ok ? (c8 * H + ih) * W + iw : 0;   // in units, relative to the chunk's first channel block
-    lds_x[i] = 2 * rem + c8;
+    lds_x[i] = c8 * (IH * IW) + rem;             // k-half planes: consecutive lanes -> consecutive 16-byte units
     vbits |= (ok ? 1u : 0u) << i;
   }
 
-  f32x16 acc[MT];
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const int nch1 = d.C1 / 16, nch = nch1 + d.C2 / 16;
-  uint4 xv[NX], wv[NW];
-  auto issue_loads = [&](int ch) {
+  auto issue_loads = [&](int ch, uint4 (&xv)[NX], uint4 (&wv)[NW]) {
     const bool second = ch >= nch1;
     const int cb = second ? (ch - nch1) * 2 : ch * 2;   // first channel block of the chunk
     const int C8 = (second ? d.C2 : d.C1) >> 3;
     const uint4* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C8 + cb) * H * W;
 #pragma unroll
     for (int i = 0; i < NX; ++i) xv[i] = xs[rel[i]];
-    const uint4* __restrict__ wp = a.wb + ((size_t)ch * 9 * d.Mpad + d.m_off + m0) * 2;
+    const uint4* __restrict__ wp = a.wb + (size_t)ch * 18 * d.Mpad + d.m_off + m0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      const int w = tid + 256 * i;   // (tap, m, half)
-      const int tap = w / (2 * MB), rem = w - tap * 2 * MB;
-      const bool ok = w < WU && d.m_off + m0 + (rem >> 1) < d.Mpad;
-      const uint4 v = wp[ok ? (size_t)tap * d.Mpad * 2 + rem : 0];
+      const int w = tid + 256 * i;   // (half, tap, m): the order of the packed image and of the LDS image
+      const int ht = w / MB, m = w - ht * MB;
+      const bool ok = w < WU && d.m_off + m0 + m < d.Mpad;
+      const uint4 v = wp[ok ? (size_t)ht * d.Mpad + m : 0];
       wv[i] = ok ? v : make_uint4(0, 0, 0, 0);
     }
   };
-  auto write_lds = [&](uint4* buf) {
+  auto write_lds = [&](uint4* buf, const uint4 (&xv)[NX], const uint4 (&wv)[NW]) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       if (tid + 256 * i < XU) {
         uint4 v = xv[i];
+#ifndef BLK_ABL_NOELU   // timing ablations (tools/ab_build.sh): results are wrong, only the clock is read
         if (PRO != 0) v = bk_elu8(v);
+#endif
         buf[lds_x[i]] = ((vbits >> i) & 1u) ? v : make_uint4(0, 0, 0, 0);
       }
     }
@@ -182,31 +187,46 @@ __global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a)
     for (int i = 0; i < NW; ++i)
       if (tid + 256 * i < WU) buf[XU + tid + 256 * i] = wv[i];
   };
-
-  issue_loads(0);
-  write_lds(smem4);
-  __syncthreads();
-  for (int ch = 0; ch < nch; ++ch) {
-    const uint4* buf = smem4 + (ch & 1) * BUF;
-    if (ch + 1 < nch) issue_loads(ch + 1);
-    const uint4* xL = buf + 2 * (wave * IW + j) + h;
-    const uint4* wL = buf + XU + 2 * j + h;
+  auto multiply = [&](const uint4* buf) {
+    const uint4* wL = buf + XU + h * (9 * MB) + j;
+    const uint4* xL = buf + h * (IH * IW) + wave * NT * IW + j;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dr = tap / 3, dc = tap % 3;
-      BkUnit av[MT], bv;
+      BkUnit av[MT], bv[NT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[mt].u = wL[2 * (tap * MB + mt * 32)];
-      bv.u = xL[2 * (dr * IW + dc)];
+      for (int mt = 0; mt < MT; ++mt) av[mt].u = wL[tap * MB + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt].u = xL[(dr + nt) * IW + dc];
+#ifndef BLK_ABL_NOMFMA
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt].b, bv.b, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt].b, bv[nt].b, acc[mt][nt], 0, 0, 0);
+#endif
     }
-    if (ch + 1 < nch) write_lds(smem4 + ((ch + 1) & 1) * BUF);
+  };
+
+  // One chunk of lookahead.  Measured and rejected on the render shapes (tools/time_blk.py): two chunks of lookahead
+  // through a second register set (no faster, +40-60 VGPRs), and staging the next chunk piecewise between the taps
+  // (5-25 % slower); staggering the start of co-resident workgroups (no effect).  Removing any ONE of {matrix
+  // instructions + LDS reads, weight staging, input loads, ELU} from the 128-channel 64x64 layer shortens it by
+  // 25 / 16 / 11 / 8 %: no single resource bounds the kernel.
+  uint4 xv[NX], wv[NW];
+  issue_loads(0, xv, wv);
+  write_lds(smem4, xv, wv);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) issue_loads(ch + 1, xv, wv);
+    multiply(smem4 + (ch & 1) * BUF);
+    if (ch + 1 < nch) write_lds(smem4 + ((ch + 1) & 1) * BUF, xv, wv);
     __syncthreads();
   }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) bk_store_tile(a, n, row0 + wave, col0 + j, true, m0 + mt * 32, h, acc[mt]);
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bk_store_tile(a, n, row0 + wave * NT + nt, col0 + j, true, m0 + mt * 32, h, acc[mt][nt]);
 }
 
 // ---- every other geometry: taps 1 or 9, stride 1 or 2, any map size; operands straight from global memory.
@@ -256,13 +276,13 @@ __global__ __launch_bounds__(256) void conv_blk_direct_kernel(const BlkArgs a) {
     const int cb = second ? (ch - nch1) * 2 : ch * 2;
     const int C8 = (second ? d.C2 : d.C1) >> 3;
     const uint4* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C8 + cb + h) * HW;   // this lane's k-half
-    const uint4* __restrict__ wp = a.wb + ((size_t)ch * T * d.Mpad + d.m_off + m0 + j) * 2 + h;
+    const uint4* __restrict__ wp = a.wb + ((size_t)(ch * 2 + h) * T) * d.Mpad + d.m_off + m0 + j;
 #pragma unroll
     for (int t = 0; t < T; ++t) B[t] = xs[toff[t] >= 0 ? toff[t] : 0];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) A[t][mt] = wp[mok[mt] ? ((size_t)t * d.Mpad + mt * 32) * 2 : 0];
+      for (int mt = 0; mt < MT; ++mt) A[t][mt] = wp[mok[mt] ? (size_t)t * d.Mpad + mt * 32 : 0];
   };
   auto mma = [&](uint4 (&A)[T][MT], uint4 (&B)[T]) {
 #pragma unroll
@@ -363,17 +383,20 @@ __global__ void conv1x1_few_to_blk_kernel(const float* __restrict__ x, const flo
   y[i] = make_uint4(bk_pack(v[0], v[1]), bk_pack(v[2], v[3]), bk_pack(v[4], v[5]), bk_pack(v[6], v[7]));
 }
 
-// wt_f [T*(C1p + C2p)][Mpad] fp32 (rows: source, tap, channel)  ->  wb [chunk][tap][Mpad][16] bf16
+// wt_f [T*(C1p + C2p)][Mpad] fp32 (rows: source, tap, channel)  ->  wb [chunk of 16][k half][tap][Mpad][8] bf16
 __global__ void pack_bf16_taps_kernel(const float* __restrict__ wt, __bf16* __restrict__ wb, int C1, int C2, int Mpad, int T) {
   const long total = (long)(C1 + C2) * T * Mpad;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i & 15);
-  long q = i >> 4;
+  const int e = (int)(i & 7);
+  long q = i >> 3;
   const int m = (int)(q % Mpad);
   q /= Mpad;
   const int tap = (int)(q % T);
-  const int ch = (int)(q / T);
+  q /= T;
+  const int half = (int)(q & 1);
+  const int ch = (int)(q >> 1);
+  const int c = 8 * half + e;
   const int nch1 = C1 / 16;
   const int C1p = (C1 + 1) & ~1, C2p = (C2 + 1) & ~1;
   const long krow = ch < nch1 ? (long)tap * C1p + ch * 16 + c : (long)T * C1p + (long)tap * C2p + (ch - nch1) * 16 + c;
@@ -442,15 +465,25 @@ extern "C" int vunet_conv2d_blk(const vunet_conv_desc* d, const void* x1, const 
   const int pro = d->in_act == ACT_ELU ? 1 : 0;
   const int MT = d->M <= 32 ? 1 : 2;
   if (blk_tiled_ok(d)) {
-    const int blocks = d->N * (d->Hs / 4) * (d->Ws / 32) * ((d->M + 32 * MT - 1) / (32 * MT));
-    const size_t lds = 2 * (size_t)(6 * 34 * 2 + 9 * 32 * MT * 2) * sizeof(uint4);
-    if (MT == 1) {
-      if (pro) VUNET_LAUNCH((conv_blk_tiled_kernel<1, 1>), dim3(blocks), dim3(256), lds, st, a);
-      else VUNET_LAUNCH((conv_blk_tiled_kernel<1, 0>), dim3(blocks), dim3(256), lds, st, a);
-    } else {
-      if (pro) VUNET_LAUNCH((conv_blk_tiled_kernel<2, 1>), dim3(blocks), dim3(256), lds, st, a);
-      else VUNET_LAUNCH((conv_blk_tiled_kernel<2, 0>), dim3(blocks), dim3(256), lds, st, a);
-    }
+    // Tile height, measured per render shape (tools/time_blk.py, profiles/r03_time_blk.txt): 8-row tiles (two rows per
+    // wave) win 3-9 % on the 32-wide layers (one m-tile: the weight image is staged half as often per pixel); with two
+    // m-tiles the 4-row tile is 0-18 % faster (3 workgroups per CU instead of 2)
+    int NT = (MT == 1 && d->Hs % 8 == 0) ? 2 : 1;
+    if (NT == 2 && (size_t)d->N * (d->Hs / 8) * (d->Ws / 32) * ((d->M + 32 * MT - 1) / (32 * MT)) < 1024) NT = 1;
+    if (g_vunet_tune[VUNET_TUNE_BLK_FORCE_NT] == 1 || (g_vunet_tune[VUNET_TUNE_BLK_FORCE_NT] == 2 && d->Hs % 8 == 0))
+      NT = g_vunet_tune[VUNET_TUNE_BLK_FORCE_NT];
+    const int blocks = d->N * (d->Hs / (4 * NT)) * (d->Ws / 32) * ((d->M + 32 * MT - 1) / (32 * MT));
+    const size_t lds = 2 * (size_t)((4 * NT + 2) * 34 * 2 + 9 * 32 * MT * 2) * sizeof(uint4);
+#define BLK_TILED(MT_, NT_)                                                                                   \
+  do {                                                                                                        \
+    if (pro) VUNET_LAUNCH((conv_blk_tiled_kernel<MT_, NT_, 1>), dim3(blocks), dim3(256), lds, st, a);         \
+    else VUNET_LAUNCH((conv_blk_tiled_kernel<MT_, NT_, 0>), dim3(blocks), dim3(256), lds, st, a);             \
+  } while (0)
+    if (MT == 1 && NT == 1) BLK_TILED(1, 1);
+    else if (MT == 1) BLK_TILED(1, 2);
+    else if (NT == 1) BLK_TILED(2, 1);
+    else BLK_TILED(2, 2);
+#undef BLK_TILED
     return vunet_check_launch();
   }
   const int ptiles = (a.NP + 31) / 32;

@@ -190,7 +190,7 @@ def _scheme() -> int:
 
 
 _wants_split_cache = {}
-_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2}
+_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2, "blk_force_nt": 3}
 
 
 def set_tuning(key: str, value: int):

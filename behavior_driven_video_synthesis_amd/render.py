@@ -49,6 +49,16 @@ def project_sequence(poses3d_world: torch.Tensor, extrinsics: torch.Tensor, intr
     return kps2d * scale
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 @torch.no_grad()
 def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_size: Optional[int] = None,
                     joint_model=H36M_JOINT_MODEL, chunk: int = 16, as_uint8: bool = True, dtype: str = "f32",
@@ -62,28 +72,45 @@ def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_s
     size = spatial_size or vunet.spatial_size
     was_training = vunet.training
     vunet.eval()
-    stick = make_joint_img_batch((size, size), kps2d.to(app_img.device), joint_model, as_float=True)
     if layout not in ("auto", "nchw", "blk"):
         raise ValueError(f"unknown activation layout {layout!r}")
     engine = engine_for(vunet) if (dtype == "bf16" and layout != "nchw") else None
     if layout == "blk" and engine is None:
         raise ValueError("layout='blk' needs dtype='bf16' and a model BlockedTransfer.supported covers")
     outs = []
-    # the weights do not change inside a sequence: fold / pack every layer once (two launches) instead of per call
-    with ops.inference_precision(dtype), ops.prepacked(vunet):
-        code = vunet.appearance_code(app_img, eps) if share_appearance else None
-        if code is not None and engine is not None:
-            code = engine.encode_code(code)
+    if engine is not None and share_appearance and app_img.is_cuda:
+        # One appearance encoding per sequence: ~100 batch-1 launches that leave most of the chip idle.  They run on a
+        # side stream, next to the raster and the pose pyramid of the first chunk, which need nothing from them.
+        main, side = torch.cuda.current_stream(), _side_stream(app_img.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), ops.inference_precision(dtype), ops.prepacked(vunet):
+            code = engine.encode_code(vunet.appearance_code(app_img, eps))
+        stick = make_joint_img_batch((size, size), kps2d.to(app_img.device), joint_model, as_float=True)
         for s in range(0, stick.shape[0], chunk):
-            c = stick[s:s + chunk]
-            if code is None:
-                e = None if eps is None else [t.expand(c.shape[0], -1, -1, -1).contiguous() for t in eps]
-                frame_code = vunet.appearance_code(app_img.expand(c.shape[0], -1, -1, -1).contiguous(), e)
-                if engine is not None:
-                    frame_code = engine.encode_code(frame_code)
-            else:
-                frame_code = code
-            outs.append(engine.transfer_code(frame_code, c) if engine is not None else vunet.transfer_code(frame_code, c))
+            feats = engine.pose_features(stick[s:s + chunk])
+            if s == 0:
+                main.wait_stream(side)
+                for t in code:
+                    t.record_stream(main)
+            outs.append(engine.decode(feats, code))
+    else:
+        stick = make_joint_img_batch((size, size), kps2d.to(app_img.device), joint_model, as_float=True)
+        # the weights do not change inside a sequence: fold / pack every layer once (two launches) instead of per call
+        with ops.inference_precision(dtype), ops.prepacked(vunet):
+            code = vunet.appearance_code(app_img, eps) if share_appearance else None
+            if code is not None and engine is not None:
+                code = engine.encode_code(code)
+            for s in range(0, stick.shape[0], chunk):
+                c = stick[s:s + chunk]
+                if code is None:
+                    e = None if eps is None else [t.expand(c.shape[0], -1, -1, -1).contiguous() for t in eps]
+                    frame_code = vunet.appearance_code(app_img.expand(c.shape[0], -1, -1, -1).contiguous(), e)
+                    if engine is not None:
+                        frame_code = engine.encode_code(frame_code)
+                else:
+                    frame_code = code
+                outs.append(engine.transfer_code(frame_code, c) if engine is not None
+                            else vunet.transfer_code(frame_code, c))
     rgb = torch.cat(outs, dim=0)
     vunet.train(was_training)
     if as_uint8:

@@ -173,13 +173,22 @@ class BlockedTransfer:
         return [to_blk(m) for m in means]
 
     @torch.no_grad()
-    def transfer_code(self, code_blk: Sequence[torch.Tensor], c: torch.Tensor) -> torch.Tensor:
-        """``VunetAlter.transfer_code``; a batch-1 code is broadcast over the frames of ``c``.  -> fp32 [N, 3, H, W]."""
+    def pose_features(self, c: torch.Tensor):
+        """``du(c)``: the pose pyramid of the stickmen ``c`` (fp32 [N, 3, H, W]) as blocked tensors."""
         if self.vunet.training:
             raise RuntimeError("the blocked render path has no dropout: call vunet.eval() first")
-        n = c.shape[0]
+        return self._pyramid(self.vunet.du, c)
+
+    @torch.no_grad()
+    def decode(self, feats, code_blk: Sequence[torch.Tensor]) -> torch.Tensor:
+        """``dd(feats, code, training=True)``; a batch-1 code is broadcast over the frames.  -> fp32 [N, 3, H, W]."""
+        n = feats[0].shape[0]
         code = [m if m.shape[0] == n else m.expand(n, -1, -1, -1, -1).contiguous() for m in code_blk]
-        return self._decode(self.vunet.dd, self._pyramid(self.vunet.du, c), code)
+        return self._decode(self.vunet.dd, feats, code)
+
+    def transfer_code(self, code_blk: Sequence[torch.Tensor], c: torch.Tensor) -> torch.Tensor:
+        """``VunetAlter.transfer_code`` (models/vunets.py:508-515, the pose half)."""
+        return self.decode(self.pose_features(c), code_blk)
 
 
 def engine_for(vunet) -> Optional[BlockedTransfer]:

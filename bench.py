@@ -246,11 +246,12 @@ def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
     return r
 
 
-def render_row(vunet, device, size, frames=50, chunk=25, iters=5):
+def render_row(vunet, device, size, frames=50, chunk=50, iters=5):
     """BASELINE config 5 (the render half): a 50-frame pose sequence -> one raster launch -> batched VunetAlter.transfer
     (reference: per-frame cv2 raster + batch-1 transfer, data/data_conversions_3d.py:1130-1185).  Modes: fp32-accurate
-    (split-bf16 kernels), and config 5's bf16 precision (operands rounded once to bf16) with one appearance encoding per
-    sequence.  The bf16 convolution is bound by bytes in flight, not MFMA: its roofline is HBM (algorithmic bytes / 8 TB/s)."""
+    (split-fp16 kernels), and config 5's bf16 precision -- channel-blocked bf16 activations, fp32 accumulation
+    (render_blk.BlockedTransfer) -- with one appearance encoding per sequence.  Roofline of its dominant kernel: HBM
+    (algorithmic bytes / 8 TB/s); the layers sit between the HBM and the matrix-core bound, see DESIGN.md 5.3."""
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.render import render_sequence
     g = torch.Generator().manual_seed(5)
@@ -282,17 +283,23 @@ def render_row(vunet, device, size, frames=50, chunk=25, iters=5):
     ops.profile_start()
     render_sequence(vunet, app, kps, chunk=chunk, as_uint8=False, eps=eps, dtype="bf16", share_appearance=True)
     fam = ops.profile_stop(detail=True)
-    ms = nbytes = 0.0
+    # dominant kernel of the bf16 render: the LDS-tiled convolution on channel-blocked bf16 activations (csrc/conv_blk.hip).
+    # Algorithmic bytes per launch: bf16 sources + output (+ residual); the fp32 output layer writes 4 B per value.
+    ms = nbytes = n_l = 0.0
     for key, v in fam.items():
-        if key[0] != "conv_bf16_fwd":
+        if key[0] != "conv_blk_fwd" or key[-1] != "conv_blk_tiled_kernel":
             continue
-        _, n, c1, c2, hs, ws, m, k, s_, act, _ = key
+        _, n, c1, c2, hs, ws, m, k, s_, has_res, nchw, _ = key
+        ho, wo = (hs - 1) // s_ + 1, (ws - 1) // s_ + 1
+        per = 2.0 * n * hs * ws * (c1 + c2) + (4.0 if nchw else 2.0) * n * ho * wo * m + (2.0 * n * ho * wo * m if has_res else 0.0)
         ms += v["ms"]
-        nbytes += 4.0 * n * hs * ws * (c1 + c2 + m + (m if act else 0)) * v["n"]   # fp32 inputs + output (+ residual of the RNB layers)
+        nbytes += per * v["n"]
+        n_l += v["n"]
     if ms > 0:
         ach = nbytes / (ms * 1e-3) / 1e9
-        row["roofline"] = {"bound": "hbm", "kernel": "conv_bf16_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                           "frac": ach / 8000.0, "traffic": None,
+        row["roofline"] = {"bound": "hbm", "kernel": "conv_blk_tiled_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                           "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nbytes / n_l,
+                           "avg_launch_us": 1e3 * ms / n_l,
                            "share_of_conv_time": ms / sum(v["ms"] for v in fam.values())}
         # mean HBM bytes per launch of that kernel over the sequence: rocprofv3 PMC passes of tools/bench_render.py
         # (tools/profile.sh step 4), committed summary
@@ -301,7 +308,7 @@ def render_row(vunet, device, size, frames=50, chunk=25, iters=5):
                 pmc = json.load(open(os.path.join(ROOT, rel)))
             except (OSError, ValueError):
                 continue
-            ents = [v for k, v in pmc.get("kernels", {}).items() if k.startswith("conv_bf16_kernel")]
+            ents = [v for k, v in pmc.get("kernels", {}).items() if k.startswith("conv_blk_tiled_kernel")]
             if ents:   # every instantiation of the kernel, weighted by its launches
                 nl = sum(e["launches_sampled"] for e in ents)
                 row["roofline"]["traffic"] = sum(e["hbm_bytes_per_launch"] * e["launches_sampled"] for e in ents) / nl

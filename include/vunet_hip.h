@@ -156,7 +156,7 @@ int vunet_conv2d_bf16(const vunet_conv_desc* d, const float* x1, const float* x2
  * no dropout; x1 / x2 / res / y blk tensors; y_fp32_nchw != 0: y is a fp32 NCHW tensor instead (any M; the network's
  * 3-channel output layer).
  *   vunet_pack_bf16_taps     wt_f (fp32 K-major weights of vunet_weightnorm_fwd, row pitch Mpad) ->
- *                            wb [(C1+C2)/16][taps][Mpad][16] bf16, taps = 1 or 9
+ *                            wb [(C1+C2)/16][2 k-halves][taps][Mpad][8] bf16, taps = 1 or 9
  *   vunet_nchw_to_blk / vunet_blk_to_nchw   fp32 NCHW <-> blk (RNE / exact)
  *   vunet_conv1x1_few_to_blk 1x1 convolution of a fp32 NCHW tensor with C <= 4 channels (the stickman planes; wt_f rows =
  *                            input channel) in fp32, stored as blk -- the first layer of the pose encoder */
@@ -342,10 +342,12 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *   VUNET_TUNE_SPLIT_FORCE_NT  tile height (32-pixel rows per wave: 1, 2 or 4) of the split-fp16 / split-bf16 3x3 kernels
  *   VUNET_TUNE_TILED_FORCE_NT  the same for the LDS-tiled fp32 kernel
  *   VUNET_TUNE_FORCE_SMALL     1: vunet_conv2d_x6 takes the small-map K-split kernel wherever it covers the geometry
+ *   VUNET_TUNE_BLK_FORCE_NT    tile height (rows per wave: 1 or 2) of the LDS-tiled blocked-bf16 kernel (vunet_conv2d_blk)
  * Returns VUNET_ERR_ARG for an unknown key. */
 #define VUNET_TUNE_SPLIT_FORCE_NT 0
 #define VUNET_TUNE_TILED_FORCE_NT 1
 #define VUNET_TUNE_FORCE_SMALL 2
+#define VUNET_TUNE_BLK_FORCE_NT 3
 int vunet_set_tuning(int32_t key, int32_t value);
 
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */

@@ -39,8 +39,8 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_A
 python3 tools/pmc_summary.py sq $(ls $OUT/${TAG}_sq/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_sq.json
 # 4. the render loop (BASELINE config 5): HBM bytes per launch of its bf16 convolution, same two separate passes
 rm -rf $OUT/${TAG}_rfetch $OUT/${TAG}_rwrite
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rfetch -- python3 tools/bench_render.py --iters 1 > /dev/null 2> $OUT/${TAG}_rfetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rwrite -- python3 tools/bench_render.py --iters 1 > /dev/null 2> $OUT/${TAG}_rwrite.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rfetch -- python3 tools/bench_render.py --iters 1 --chunk 50 --no-ref --only "bf16 blocked+shared_appearance" > /dev/null 2> $OUT/${TAG}_rfetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rwrite -- python3 tools/bench_render.py --iters 1 --chunk 50 --no-ref --only "bf16 blocked+shared_appearance" > /dev/null 2> $OUT/${TAG}_rwrite.err
 python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_rfetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_rwrite/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic_render.json
 rm -rf $OUT/${TAG}_rfetch $OUT/${TAG}_rwrite
 # the raw per-dispatch tables are large: keep the summaries only
