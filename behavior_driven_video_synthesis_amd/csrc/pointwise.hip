@@ -167,19 +167,32 @@ extern "C" int vunet_l1_mean_fwd(const float* a, const float* b, float* partial,
   return vunet_check_launch();
 }
 __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ add,
-                              float* __restrict__ db, float gs, const float* __restrict__ gout, int64_t n) {
+                              float* __restrict__ db, float gs, const float* __restrict__ gout, int64_t n,
+                              float* __restrict__ amax_out) {
   if (gout) gs *= gout[0];
+  float vmax = 0.f;
   EW_LOOP(i, n) {
     const float d = b[i] - a[i];
     const float g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
-    db[i] = (add ? add[i] : 0.f) + g;
+    const float v = (add ? add[i] : 0.f) + g;
+    db[i] = v;
+    vmax = fmaxf(vmax, fabsf(v));
   }
+  if (amax_out) {   // partial maxima of |db| for the convolution that reads it (as the conv epilogues publish theirs)
+    const float m = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(reinterpret_cast<unsigned*>(amax_out) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 511u), __float_as_uint(m));
+  }
+}
+extern "C" int vunet_l1_mean_bwd_amax(const float* a, const float* b, const float* add, float* db, float gscale,
+                                      const float* gout, int64_t n, float* amax_out, void* st) {
+  if (!a || !b || !db) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(l1_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, add, db, gscale, gout, n, amax_out);
+  return vunet_check_launch();
 }
 extern "C" int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* db, float gscale,
                                  const float* gout, int64_t n, void* st) {
-  if (!a || !b || !db) return VUNET_ERR_ARG;
-  VUNET_LAUNCH(l1_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, add, db, gscale, gout, n);
-  return vunet_check_launch();
+  return vunet_l1_mean_bwd_amax(a, b, add, db, gscale, gout, n, nullptr, st);
 }
 
 // ------------------------------------------------------------------ KL / squared-difference (latents: small)

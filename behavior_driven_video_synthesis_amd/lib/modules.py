@@ -116,11 +116,13 @@ class NormConv2d(nn.Module):
         return self.conv.weight_v, self.conv.weight_g, self.conv.bias, self.gamma, self.beta
 
     def fused(self, x: TensorOrPair, res: Optional[torch.Tensor] = None, in_act: int = ops.ACT_NONE,
-              in_slope: float = 0.0, drop_p: float = 0.0, out_act: int = ops.ACT_NONE, d2s: bool = False):
+              in_slope: float = 0.0, drop_p: float = 0.0, out_act: int = ops.ACT_NONE, d2s: bool = False,
+              passthrough: bool = False):
+        """``passthrough``: returns (y, x_alias) -- see ``ops.ConvCfg.passthrough``."""
         x1, x2 = _split(x)
         cfg = ops.ConvCfg(kind=self.kind, k=self.k, stride=self.stride, pad=self.padding, in_act=in_act,
                           in_slope=in_slope, drop_p=drop_p, drop_seed=ops.next_dropout_seed() if drop_p > 0 else 0,
-                          out_act=out_act, d2s=d2s, owner=self)
+                          out_act=out_act, d2s=d2s, owner=self, passthrough=passthrough)
         v, g, b, gamma, beta = self._params()
         return ops.fused_conv(x1, x2, res, v, g, b, gamma, beta, cfg)
 
@@ -252,8 +254,12 @@ class Downsample(nn.Module):
         self.down = conv_layer(channels, channels if out_channels is None else out_channels, kernel_size=3,
                                stride=2, padding=1)
 
-    def forward(self, x):
-        return self.down(x)
+    def forward(self, x, passthrough: bool = False):
+        """``passthrough`` (weight-normalised layers): -> (y, x_alias); a skip connection that also reads ``x`` should read
+        the alias -- its gradient is then added in this layer's data-gradient kernel (``ops.ConvCfg.passthrough``)."""
+        if passthrough and isinstance(self.down, NormConv2d):
+            return self.down.fused(x, passthrough=True)
+        return (self.down(x), x) if passthrough else self.down(x)
 
 
 class Upsample(nn.Module):

@@ -118,9 +118,9 @@ class PerceptualVGG(nn.Module):
         for p in self.vgg_layers.parameters():  # frozen feature extractor
             p.requires_grad_(False)
 
-    def forward(self, x):
-        x = ops.VggPreprocess.apply(x)  # ((x+1)/2 - mean)/std, :43-44
-        out = {"input": x}
+    def _walk(self, x, on_tap):
+        """The feature pass, :41-61; ``on_tap(name, x) -> x`` sees every tapped feature before the next layer reads it."""
+        x = on_tap("input", ops.VggPreprocess.apply(x))  # ((x+1)/2 - mean)/std, :43-44
         last = max(int(k) for k in self.target_layers)
         mods = list(self.vgg_layers._modules.items())
         i = 0
@@ -141,6 +141,30 @@ class PerceptualVGG(nn.Module):
             else:
                 x = ops.Activation.apply(x, ops.ACT_RELU, 0.0)
             if name in self.target_layers:
-                out[self.target_layers[name]] = x
+                x = on_tap(self.target_layers[name], x)
             i += 1
+
+    def forward(self, x):
+        out = {}
+
+        def keep(name, t):
+            out[name] = t
+            return t
+        self._walk(x, keep)
         return out
+
+    def loss_terms(self, pred, target_features):
+        """``{tap: w_tap * mean|target_tap - pred_tap|}`` of lib/losses.py:81-119 in ONE pass over ``pred``: each term is
+        formed when its tap is computed and the next layer reads the alias ``ops.L1MeanThrough`` hands back, so a tap's
+        two gradients (loss term, next layer) meet inside the L1 backward kernel instead of in an autograd add over
+        the tensor.  Same values as ``forward`` + one ``L1Mean`` per tap."""
+        weights = dict(zip(["input"] + [self.target_layers[k] for k in sorted(self.target_layers, key=int)],
+                           self.loss_weights))
+        losses = {}
+
+        def term(name, t):
+            losses[name], alias = ops.L1MeanThrough.apply(target_features[name], t, float(weights[name]))
+            ops.carry_amax_tag(t, alias)
+            return alias
+        self._walk(pred, term)
+        return losses

@@ -81,7 +81,9 @@ class _Pyramid(nn.Module):
                 h = next(blocks)(h)
                 feats.append(h)
             if level < self.n_scales - 1:
-                h = self.downs[level](h)
+                # the skip connection reads the alias the down-sampling layer hands back: one gradient chain, the skip's
+                # gradient added inside that layer's data-gradient kernel instead of by an autograd add over the tensor
+                h, feats[-1] = self.downs[level](h, passthrough=True)
         return feats
 
 

@@ -156,6 +156,7 @@ class ConvCfg:
     res_is_x1: bool = False  # residual tensor is source 1 itself -> its gradient is fused into the dgrad epilogue
     owner: object = None     # the calling module (records its source split; looked up in the active prepack set)
     bf16: bool = False       # set by fused_conv: caller is under no_grad inside ops.inference_precision("bf16")
+    passthrough: bool = False   # also return x1 (an alias): its gradient is added in the data-gradient epilogue
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
@@ -244,6 +245,13 @@ def _tag_amax(t, buf):
 def _tagged_amax(t):
     rec = getattr(t, "_vunet_amax", None)
     return rec[0] if rec is not None and rec[1] == t._version else None
+
+
+def carry_amax_tag(src, dst):
+    """``dst`` is an alias of ``src`` (a pass-through output): it holds the same values, so the same maxima."""
+    tag = _tagged_amax(src)
+    if tag is not None:
+        _tag_amax(dst, tag)
 
 
 def _amax_for(x1, x2=None):
@@ -896,12 +904,22 @@ class FusedConv(torch.autograd.Function):
         ctx.need_w = need_w
         ctx.save_for_backward(x1, x2, v, g, bias, gamma, invnorm, wt_d,
                               y if cfg.out_act in (ACT_SIGMOID, ACT_RELU, ACT_LRELU, ACT_ELU) else None, wx_d)
+        if cfg.passthrough:
+            # second output: x1 itself (autograd makes it an alias with this node as grad_fn).  Whoever else reads the
+            # tensor reads the alias, so that gradient arrives HERE (g_alias) and is added in the data-gradient
+            # kernel's epilogue -- no aten::add_ over the full tensor when autograd would have summed the two.
+            ctx.set_materialize_grads(False)
+            return y, x1
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         x1, x2, v, g, bias, gamma, invnorm, wt_d, y, wx_d = ctx.saved_tensors
         cfg: ConvCfg = ctx.cfg
+        if dy is None:   # (pass-through layers only: the convolution's own output was not used)
+            return g_alias, None, None, None, None, None, None, None, None
+        if g_alias is not None:
+            g_alias = _c(g_alias)
         if torch.is_grad_enabled():
             # create_graph=True (e.g. the R1 penalty): build a differentiable backward by re-expressing the layer
             # with primitives that autograd can differentiate again, and differentiating that expression
@@ -915,6 +933,8 @@ class FusedConv(torch.autograd.Function):
             wanted = [t for t, need in zip(tensors, needs) if need and t is not None]
             grads = iter(torch.autograd.grad(y2, wanted, dy, create_graph=True, allow_unused=True))
             out = [next(grads) if (need and t is not None) else None for t, need in zip(tensors, needs)]
+            if g_alias is not None:
+                out[0] = g_alias if out[0] is None else out[0] + g_alias
             return (*out, None)
         n, c1, c2, hs, ws, cout, ho, wo = ctx.dims
         dy = _c(dy)
@@ -941,14 +961,16 @@ class FusedConv(torch.autograd.Function):
                     amax = _amax_for(dy) if _scheme() == 2 else None
                     amax_out = _new_amax_out(dx.device) if _scheme() == 2 else None
                     rc = _lib.lib().vunet_conv2d_dgrad_relu_x6(ctypes.byref(d), _p(dy), _p(y), _p(wx_d),
-                                                               _p(dy if cfg.res_is_x1 else None), _p(dx), _p(amax),
+                                                               _p(dy if cfg.res_is_x1 else g_alias), _p(dx), _p(amax),
                                                                _p(amax_out), _stream())
                     if rc == 0 and amax_out is not None:
                         _tag_amax(dx, amax_out)
                 if rc == -3:
                     rc = _lib.lib().vunet_conv2d_dgrad_relu(ctypes.byref(d), _p(dy), _p(y), _p(wt_d),
-                                                            _p(dy if cfg.res_is_x1 else None), _p(dx), _stream())
+                                                            _p(dy if cfg.res_is_x1 else g_alias), _p(dx), _stream())
             if rc == 0:
+                if cfg.res_is_x1 and g_alias is not None:
+                    dx.add_(g_alias)
                 return dx, None, dres, None, None, None, None, None, None
             if rc != -3:   # anything but VUNET_ERR_UNSUPPORTED is an error; unsupported geometries take the two-pass route
                 raise RuntimeError(f"vunet_conv2d_dgrad_relu failed with code {rc}")
@@ -1076,9 +1098,14 @@ class FusedConv(torch.autograd.Function):
                 _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d, amax)
                 return dx
             if ctx.needs_input_grad[0]:
-                dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else None)
+                dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else g_alias)
+                if cfg.res_is_x1 and g_alias is not None:   # (the epilogue adds one tensor)
+                    dx1.add_(g_alias)
+                g_alias = None
             if x2 is not None and ctx.needs_input_grad[1]:
                 dx2 = dgrad(x2, c2, c1, (cfg.drop_seed + SEED2_OFFSET) & 0xFFFFFFFF, None)
+        if g_alias is not None:   # x1 itself needed no gradient from this layer
+            dx1 = g_alias
         return dx1, dx2, dres, dv, dg, dbias, dgamma, dbeta, None
 
 
@@ -1089,7 +1116,25 @@ def fused_conv(x1, x2, res, v, g, bias, gamma, beta, cfg: ConvCfg):
     if res is not None and res is x1 and not cfg.d2s and cfg.out_act == ACT_NONE:
         cfg.res_is_x1 = True
     cfg.bf16 = _inference_bf16 and not torch.is_grad_enabled()   # grad mode of the CALLER (forward() never records)
+    if cfg.passthrough and not (torch.is_grad_enabled() and x1.requires_grad and x1.is_contiguous() and _grad_passthrough):
+        cfg.passthrough = False
+        return FusedConv.apply(x1, x2, res, v, g, bias, gamma, beta, cfg), x1
+    if cfg.passthrough:
+        y, alias = FusedConv.apply(x1, x2, res, v, g, bias, gamma, beta, cfg)
+        carry_amax_tag(x1, alias)
+        return y, alias
     return FusedConv.apply(x1, x2, res, v, g, bias, gamma, beta, cfg)
+
+
+_grad_passthrough = os.environ.get("VUNET_GRAD_PASSTHROUGH", "1") != "0"
+
+
+def enable_grad_passthrough(on: bool = True):
+    """Fan-out gradients of tensors read by a loss term / skip connection AND the next layer are added inside that
+    layer's (or the loss's) backward kernel (``ConvCfg.passthrough``, ``L1MeanThrough``) instead of by autograd.  Off:
+    the plain graph -- same values (tests/test_hip_training.py compares the two bit for bit)."""
+    global _grad_passthrough
+    _grad_passthrough = bool(on)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1192,11 +1237,47 @@ class L1Mean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         target, pred = ctx.saved_tensors
-        db = torch.empty_like(pred)
-        # the upstream scalar gradient stays on the device (no host sync): the kernel reads gout[0]
-        _call("vunet_l1_mean_bwd", _p(target), _p(pred), None, _p(db), ctx.weight / pred.numel(), _p(_c(gout)),
-              pred.numel(), _stream())
-        return None, db, None
+        return None, _l1_backward(target, pred, None, ctx.weight, gout), None
+
+
+def _l1_backward(target, pred, add, weight, gout):
+    """db = add + weight/n * gout * sign(pred - target); under the fp16 scheme the kernel also leaves the partial maxima
+    of |db| for the data gradient that reads it (one pass over the tensor less per VGG tap)."""
+    db = torch.empty_like(pred)
+    amax_out = _new_amax_out(db.device) if (_scheme() == 2 and db.is_cuda) else None
+    # the upstream scalar gradient stays on the device (no host sync): the kernel reads gout[0]
+    _call("vunet_l1_mean_bwd_amax", _p(target), _p(pred), _p(add), _p(db), weight / pred.numel(), _p(_c(gout)),
+          pred.numel(), _p(amax_out), _stream())
+    if amax_out is not None:
+        _tag_amax(db, amax_out)
+    return db
+
+
+class L1MeanThrough(torch.autograd.Function):
+    """``L1Mean`` that also hands ``pred`` on: (loss, pred_alias).  A feature that feeds BOTH a loss term and the next
+    layer then has ONE gradient consumer chain -- the next layer's gradient arrives here as ``g_alias`` and is added
+    inside the L1 backward kernel, instead of autograd summing two full-size tensors (``aten::add_``, one extra pass
+    over the largest activations of the step per VGG tap)."""
+
+    @staticmethod
+    def forward(ctx, target, pred, weight: float):
+        _dev(target, pred)
+        assert pred.is_contiguous()
+        target = _c(target)
+        out = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        partial = torch.empty(1024, device=pred.device, dtype=torch.float32)
+        _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
+        ctx.save_for_backward(target, pred)
+        ctx.weight = float(weight)
+        ctx.set_materialize_grads(False)
+        return out, pred
+
+    @staticmethod
+    def backward(ctx, gout, g_alias):
+        target, pred = ctx.saved_tensors
+        if gout is None:
+            return None, g_alias, None
+        return None, _l1_backward(target, pred, None if g_alias is None else _c(g_alias), ctx.weight, gout), None
 
 
 class KLPrior(torch.autograd.Function):

@@ -291,6 +291,10 @@ int vunet_l1_mean_fwd(const float* a, const float* b, float* partial, float* out
                       void* stream);
 int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* db, float gscale,
                       const float* gout, int64_t n, void* stream);
+/* the same; amax_out (optional, >= 512 floats zeroed by the caller) receives partial maxima of |db|, in the form
+ * vunet_conv2d's `amax` expects of the tensor it reads (the gradient enters the last VGG layer's data gradient) */
+int vunet_l1_mean_bwd_amax(const float* a, const float* b, const float* add, float* db, float gscale,
+                           const float* gout, int64_t n, float* amax_out, void* stream);
 
 /* KL(N(mu, exp(l)^2) || N(0,1)) per lib/losses.py:283-291: out[0] += weight * mean_n(sum_d(-l + .5(e^{2l}+mu^2)) - .5 D) */
 int vunet_kl_fwd(const float* mu, const float* logstd, float* partial, float* out, float weight, int32_t N, int64_t D,

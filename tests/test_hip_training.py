@@ -520,3 +520,41 @@ def test_two_graph_mode_trainers_keep_their_own_dropout_counters():
     torch.cuda.synchronize()
     ops.set_dropout_step(None)
     assert got == ref, (got, ref)
+
+
+def test_gradient_pass_through_changes_nothing_but_the_launch_count():
+    """ops.ConvCfg.passthrough / ops.L1MeanThrough: the gradients of a tensor read by a loss term (VGG taps) or a skip
+    connection (the pose pyramid) AND by the next layer meet inside a kernel epilogue instead of in an autograd add.
+    Same operands, same additions: the trained weights are bit-identical, and the ATen adds are gone."""
+    from torch.profiler import ProfilerActivity, profile
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    cfg = _tiny(DEFAULT_CONFIG, lr=1e-3)
+    cfg["data"]["spatial_size"] = 64          # wide enough for the fp16 kernels (and their published maxima) to run
+    cfg["architecture"].update(nf_start=16, nf_max=32)
+    batch = synthetic_batch(2, 64, "cuda:0")
+
+    def run(on):
+        ops.enable_grad_passthrough(on)
+        try:
+            torch.manual_seed(3)
+            tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=4, total_steps=10, vgg_synthetic=True)
+            ops.set_dropout_seed(5)
+            eps = [torch.randn(2, 32, 4, 4, device="cuda", generator=torch.Generator("cuda").manual_seed(1)),
+                   torch.randn(2, 32, 8, 8, device="cuda", generator=torch.Generator("cuda").manual_seed(2))]
+            tr.train_fn(batch, eps)
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                out = tr.train_fn(batch, eps)
+                torch.cuda.synchronize()
+            adds = sum(e.count for e in prof.key_averages() if e.key in ("aten::add_", "aten::add") and e.device_time_total > 0)
+            return out, {k: v.clone() for k, v in tr.vunet.state_dict().items()}, adds
+        finally:
+            ops.enable_grad_passthrough(True)
+    out_on, sd_on, adds_on = run(True)
+    out_off, sd_off, adds_off = run(False)
+    assert float(out_on["loss"]) == float(out_off["loss"])
+    for k in sd_on:
+        assert torch.equal(sd_on[k], sd_off[k]), k
+    # 5 VGG taps (the last has one reader) + one skip per pyramid level that is followed by a down-sampling layer
+    assert adds_off - adds_on >= 4 + 3, (adds_on, adds_off)
