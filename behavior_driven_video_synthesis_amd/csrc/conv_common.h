@@ -122,7 +122,7 @@ __device__ __forceinline__ void load_tile_side(const GatherArgs& a, const PixGeo
   }
 }
 
-// -> max |stored value| of this lane (0 for the sub-pixel store: the callers do not publish maxima for it)
+// -> max |stored value| of this lane
 __device__ __forceinline__ float store_tile_side(const GatherArgs& a, const PixGeo& g, int m_tile0, int h,
                                                  const f32x16& acc, const TileSide& s) {
   const vunet_conv_desc& d = a.d;
@@ -131,7 +131,7 @@ __device__ __forceinline__ float store_tile_side(const GatherArgs& a, const PixG
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m_tile0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (g.valid && m < d.M) store_out(a, g, m, acc[r]);
+      if (g.valid && m < d.M) vmax = fmaxf(vmax, fabsf(store_out(a, g, m, acc[r])));
     }
     return vmax;
   }

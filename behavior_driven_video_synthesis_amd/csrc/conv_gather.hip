@@ -428,7 +428,7 @@ extern "C" int vunet_conv2d_gather(const vunet_conv_desc* d, const float* x1, co
 bool vunet_conv2d_gather_publishes(const vunet_conv_desc* d, bool has_aux, bool has_res) {
   if (d->d2s || (d->mode == 1 && d->stride > 1 && !env_no_phase())) return false;
   const int pro = prologue_code(d);
-  if (vunet_conv_thin_kind(d, pro, has_aux, has_res)) return false;
+  if (const int thin = vunet_conv_thin_kind(d, pro, has_aux, has_res)) return thin == 2;   // the 3-channel-input kernel publishes
   return use_1x1(d, pro) || use_tiled(d, pro) || gather_uses_splitk(d);
 }
 
@@ -478,7 +478,10 @@ int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const fl
       }
     return VUNET_OK;
   }
-  if (const int thin = vunet_conv_thin_kind(d, pro, aux != nullptr, res != nullptr)) return vunet_conv_thin_launch(ga, thin, st);
+  if (const int thin = vunet_conv_thin_kind(d, pro, aux != nullptr, res != nullptr)) {
+    if (thin == 2) ga.amax_out = amax_out;
+    return vunet_conv_thin_launch(ga, thin, st);
+  }
   if (!d->d2s) ga.amax_out = amax_out;   // read by the two kernels below only
   if (use_1x1(d, pro)) return vunet_conv_1x1_launch(ga, pro, st);
   if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const
   }
   __syncthreads();
   constexpr int MBK = 8;                   // outputs per pass
+  float ymax = 0.f;                        // max |y| of what this lane stores (published below: GatherArgs::amax_out)
 #pragma unroll 1
   for (int m0 = 0; m0 < d.M; m0 += MBK) {
     float acc[MBK];
@@ -134,9 +135,11 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const
           float v = acc[m] + (a.shift ? a.shift[m0 + m] : 0.f);
           if (relu) v = fmaxf(v, 0.f);
           yp[(size_t)m * HW] = v;
+          ymax = fmaxf(ymax, fabsf(v));
         }
     }
   }
+  if (a.amax_out) publish_amax(a, ymax);   // (whole waves reach this point: `inside` only guards the stores)
 }
 
 // which thin kernel (if any) takes this problem: 1 = thin_m, 2 = thin_k, 0 = none

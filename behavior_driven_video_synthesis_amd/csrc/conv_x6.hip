@@ -105,7 +105,7 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
   if (g_vunet_tune[VUNET_TUNE_FORCE_SMALL] && amax && !mask && vunet_conv_h2_small_ok(d, pro)) NT = 0;   // tests
   GatherArgs ga;
   fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
-  if (amax && !d->d2s) ga.amax_out = amax_out;   // only the fp16 kernels publish |y| maxima (not through the sub-pixel store)
+  if (amax) ga.amax_out = amax_out;   // only the fp16 kernels publish |y| maxima
   if (NT == 0) {
     if (amax) ga.amax_out = amax_out;   // (the small-map kernel publishes through every store, depth-to-space included)   // the row-tiled kernels do not cover / cannot fill the chip with this problem: the small-map form (fp16 scheme)
     if (!amax || mask || !(min_blocks <= 1 ? vunet_conv_h2_small_ok(d, pro) : vunet_conv_h2_small_wanted(d, pro)))
@@ -169,8 +169,8 @@ extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const flo
 
 extern "C" int vunet_conv2d_publishes_amax(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t split) {
   if (!d) return 0;
-  if (d->d2s)   // through the sub-pixel store only the small-map fp16 kernel publishes
-    return split == 2 && x6_wanted(d, true, has_aux != 0, has_res != 0, false, true) && x6_uses_small(d, false, true) ? 1 : 0;
+  if (d->d2s)   // through the sub-pixel store only the fp16 kernels publish
+    return split == 2 && x6_wanted(d, true, has_aux != 0, has_res != 0, false, true) ? 1 : 0;
   if (split != 0 && x6_wanted(d, true, has_aux != 0, has_res != 0, false, split == 2)) return split == 2 ? 1 : 0;
   return vunet_conv2d_gather_publishes(d, has_aux != 0, has_res != 0) ? 1 : 0;
 }

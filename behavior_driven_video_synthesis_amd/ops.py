@@ -983,6 +983,7 @@ class FusedConv(torch.autograd.Function):
         if cfg.d2s:
             t = torch.empty(n, cout, ho, wo, device=dy.device, dtype=torch.float32)
             _call("vunet_space_to_depth", _p(dconv), _p(t), n, cout // 4, 2 * ho, 2 * wo, _stream())
+            carry_amax_tag(dconv, t)   # a permutation: the same values, the same maxima
             dconv = t
         dv = dg = dbias = dgamma = dbeta = None
         dy_amax = []   # |dconv| maxima of the h2 scheme: computed once (on this stream), shared by dgrad and wgrad

@@ -125,8 +125,8 @@ int vunet_conv2d_wants_split(const vunet_conv_desc* d, int32_t has_aux, int32_t 
 int vunet_conv2d_dgrad_relu_x6(const vunet_conv_desc* d, const float* dy, const float* y, const void* wx,
                                const float* res, float* dx, const float* amax, float* amax_out, void* stream);
 /* 1: vunet_conv2d, given a split image of layout `split` (0: none) and (for split 2) the maxima, will fill amax_out for this problem
- * (the two-term fp16 kernel, the streaming 1x1 kernel, the LDS-tiled kernel; never through depth-to-space); 0: it will
- * leave amax_out untouched */
+ * (the two-term fp16 kernels -- also through depth-to-space --, the streaming 1x1 kernel, the LDS-tiled kernel, the split-K
+ * kernel, the 3-channel-input kernel); 0: it will leave amax_out untouched */
 int vunet_conv2d_publishes_amax(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t split);
 /* out[0..511] / out[512..1023]: partial maxima of |x1| / |x2| (x2 may be NULL: zeros); one launch, no atomics */
 int vunet_absmax_partials(const float* x1, int64_t n1, const float* x2, int64_t n2, float* out, void* stream);
