@@ -250,6 +250,37 @@ __device__ __forceinline__ float store_tile_side4(const GatherArgs& a, const Pix
   return vmax;
 }
 
+// Data-gradient epilogue for TWO horizontally adjacent output pixels per lane (the fused stride-2 form of conv_h2_kernel:
+// parities pw = 0 / 1 of output row oh, columns ow, ow + 1 with ow even): * act'(aux) + res through 8-byte accesses; 32
+// lanes cover 256 contiguous bytes of a channel row.  -> max |stored value| of this lane.
+__device__ __forceinline__ float store_tile_pair(const GatherArgs& a, int n, int oh, int ow, int m_tile0, int h,
+                                                 const f32x16& c0, const f32x16& c1) {
+  const vunet_conv_desc& d = a.d;
+  float vmax = 0.f;
+  const size_t pix = (size_t)oh * d.Wo + ow;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = m_tile0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (ch < d.M) {
+      const size_t o = (size_t)(n * d.M + ch) * a.HoWo + pix;
+      float v0 = c0[r], v1 = c1[r];
+      if (a.aux) {
+        const float2 x = *reinterpret_cast<const float2*>(a.aux + o);
+        v0 *= in_act_grad(a.auxa, x.x, (uint32_t)o);
+        v1 *= in_act_grad(a.auxa, x.y, (uint32_t)(o + 1));
+      }
+      if (a.res) {
+        const float2 x = *reinterpret_cast<const float2*>(a.res + o);
+        v0 += x.x;
+        v1 += x.y;
+      }
+      *reinterpret_cast<float2*>(a.y + o) = make_float2(v0, v1);
+      vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
+    }
+  }
+  return vmax;
+}
+
 __device__ __forceinline__ void publish_amax(const GatherArgs& a, float vmax) {   // whole wave; see GatherArgs::amax_out
   const float m_ = wave_max(vmax);
   if ((threadIdx.x & 63) == 0)

@@ -81,6 +81,11 @@ static inline bool h2_launch_allowed() {
 // w[kh][kw] * dy[a + (ph+1-kh)/2][b + (pw+1-kw)/2] -- a stride-1 problem on the dy map with 1, 2, 2 or 4 of the 9
 // taps, stored to every other pixel of dx.  Four launches cover the four parities; no MFMA is spent on the structural
 // zeros of a transposed strided convolution.
+// PHW == 4: ALL FOUR parities in one launch (NT = 1).  Every tap (kh, kw) belongs to exactly one parity class
+// (ph, pw) = ((kh+1) & 1, (kw+1) & 1), so a workgroup stages its dy tile ONCE, walks all nine taps like a stride-1 layer and
+// keeps one accumulator tile per parity (the register budget of NT = 4); the epilogue pairs the pw = 0 / 1 tiles of an
+// output row into 8-byte stores.  The four-launch form staged the dy tile four times for 1 + 2 + 2 + 4 taps and wrote
+// every other dword of dx per launch: 54 TFLOP/s against ~250 for the stride-1 layers of the same size (r03).
 // NWV waves per workgroup: 4 -> 256 threads, two workgroups per CU, one weight slab (kernel row) per barrier;
 //                          8 -> 512 threads, ONE workgroup per CU owning most of the LDS: twice the tile rows (less halo,
 //                               the weight slabs shared by twice the MFMAs), the weights of a whole chunk (all kernel rows)
@@ -104,8 +109,11 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   inact_resolve(a.in2);
   inact_resolve(a.auxa);
   static_assert(PHW < 0 || MODE == 1, "parity phases exist for the data gradient only");
-  constexpr int PH = PHW >= 0 ? (PHW >> 1) : 0, PW = PHW >= 0 ? (PHW & 1) : 0;
-  constexpr int NKH = PHW < 0 ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk
+  constexpr bool ALLP = PHW == 4;         // every output parity in this launch
+  static_assert(!ALLP || (NT == 1 && TW == 32 && NWV == 4 && PRO == 0), "fused parities: one dy row per wave");
+  constexpr int NQ = ALLP ? 4 : NT;       // accumulator tiles per m-tile: pixel-row tiles, or the four parities
+  constexpr int PH = (PHW >= 0 && !ALLP) ? (PHW >> 1) : 0, PW = (PHW >= 0 && !ALLP) ? (PHW & 1) : 0;
+  constexpr int NKH = (PHW < 0 || ALLP) ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk
   constexpr int NTHR = 64 * NWV;
   static_assert(TW == 32 || TW == 16, "tile width");
   constexpr int RPQ = 32 / TW;            // image rows per 32-pixel MFMA column tile
@@ -157,19 +165,19 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   }
 
 #ifdef H2_SINGLE   // (experiment, tools/ab_build.sh: one accumulator set, low terms at natural scale)
-  f32x16 acc[MT][NT];
+  f32x16 acc[MT][NQ];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < NT; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
 #else
-  f32x16 acc[MT][NT], acx[MT][NT];   // leading term / the two cross terms (scaled by 2^11)
+  f32x16 acc[MT][NQ], acx[MT][NQ];   // leading term / the two cross terms (scaled by 2^11)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < NT; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][q][r] = acx[mt][q][r] = 0.f;
 #endif
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   const uint32_t wL_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)wL;
   // step -> weight slab (chunk * 3 + kh): all three kernel rows, or only those of this output parity
   auto slab_of = [&](int step) {
-    if constexpr (PHW < 0) return step;
+    if constexpr (PHW < 0 || ALLP) return step;
     else if constexpr (PH == 0) return step * 3 + 1;                     // kh = 1
     else return (step >> 1) * 3 + ((step & 1) ? 2 : 0);                  // kh = 0, 2
   };
@@ -302,7 +310,8 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
     for (int ki = 0; ki < NKH; ++ki) {
-      const int kh = PHW < 0 ? ki : (PH ? 2 * ki : 1);
+      const int kh = (PHW < 0 || ALLP) ? ki : (PH ? 2 * ki : 1);
+      const int ph_t = ALLP ? ((kh + 1) & 1) : PH;   // the output-row parity this kernel row feeds
       const int phase = ch * NKH + ki;
       const int stage = phase / GS, g = phase - stage * GS;   // GS == NKH: stage = chunk, g = ki
       const int buf = stage & 1;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
       if (stage_begin && !(LAST && GS == NKH) && (GS == NKH || more_w)) issue_w(stage + 1, buf ^ 1);
 #endif
       // row / column of the staged tile (origin row0-1, col0-1) that tap (kh, kw) reads for output row q, column j
-      const int dr = PHW >= 0 ? (PH + 1 - kh) / 2 + 1 : (MODE == 0 ? kh : 2 - kh);
+      const int dr = PHW >= 0 ? (ph_t + 1 - kh) / 2 + 1 : (MODE == 0 ? kh : 2 - kh);
 #if defined(H2_PIPE)
       // (experiment) fragment reads software-pipelined inside the phase: tap kw + 1 is read while tap kw multiplies
       if constexpr (PHW < 0) {
@@ -356,13 +365,15 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
 #endif
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        if (PHW >= 0 && ((kw + PW) & 1) == 0) continue;   // this parity's taps only: kw = pw + 1 (mod 2)
+        if (PHW >= 0 && !ALLP && ((kw + PW) & 1) == 0) continue;   // this parity's taps only: kw = pw + 1 (mod 2)
+        const int pw_t = ALLP ? ((kw + 1) & 1) : PW;
+        const int par = ph_t * 2 + pw_t;   // (fused parities) the accumulator tile of this tap
         // two waves share a SIMD: the partner's MFMAs cover this wave's fragment reads, so nothing is gained by
         // letting the scheduler hoist the next tap's 4*(MT+NT) fragment registers above this tap's MFMAs
 #ifndef H2_NO_TAP_BARRIER
         if constexpr (MT * NT < 8) __builtin_amdgcn_sched_barrier(0);
 #endif
-        const int dc = PHW >= 0 ? (PW + 1 - kw) / 2 + 1 : (MODE == 0 ? kw : 2 - kw);
+        const int dc = PHW >= 0 ? (pw_t + 1 - kw) / 2 + 1 : (MODE == 0 ? kw : 2 - kw);
         H2Unit av[2][MT], bv[2][NT];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -375,18 +386,19 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int q = 0; q < NT; ++q) {
+            const int qa = ALLP ? par : q;   // accumulator tile (compile-time after unrolling)
 #ifdef H2_SINGLE
-            f32x16 cx = acc[mt][q];
+            f32x16 cx = acc[mt][qa];
             cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, cx, 0, 0, 0);
             cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, cx, 0, 0, 0);
             cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, cx, 0, 0, 0);
-            acc[mt][q] = cx;
+            acc[mt][qa] = cx;
 #else
-            f32x16 cx = acx[mt][q];
+            f32x16 cx = acx[mt][qa];
             cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, cx, 0, 0, 0);
             cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, cx, 0, 0, 0);
-            acx[mt][q] = cx;
-            acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+            acx[mt][qa] = cx;
+            acc[mt][qa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][qa], 0, 0, 0);
 #endif
           }
       }
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     g.n = n;
     const int orow = row0 + (wave * NT + q) * RPQ + jr, ocol = col0 + jc;
     g.oh = PHW >= 0 ? 2 * orow + PH : orow;   // parity phase: every other pixel of dx
-    g.ow = PHW >= 0 ? 2 * ocol + PW : ocol;
+    g.ow = PHW >= 0 ? 2 * ocol + PW : ocol;   // (PHW == 4 never gets here: its epilogue is above)
     g.valid = true;
     return g;
   };
@@ -450,6 +462,28 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
       if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(a.amax_out) + ((blockIdx.x * 4u + wave) & 511u), __float_as_uint(m_));
     }
   };
+  if constexpr (ALLP) {   // fused parities: lane = dy pixel (orow, ocol) -> dx pixels (2 orow + ph, 2 ocol + {0, 1})
+    const int orow = row0 + wave + jr, ocol = col0 + jc;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        f32x16 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#ifdef H2_SINGLE
+          c0[r] = acc[mt][2 * ph][r] * descale * descale2;
+          c1[r] = acc[mt][2 * ph + 1][r] * descale * descale2;
+#else
+          c0[r] = (acc[mt][2 * ph][r] + acx[mt][2 * ph][r] * (1.f / 2048.f)) * descale * descale2;
+          c1[r] = (acc[mt][2 * ph + 1][r] + acx[mt][2 * ph + 1][r] * (1.f / 2048.f)) * descale * descale2;
+#endif
+        }
+        ymax = fmaxf(ymax, store_tile_pair(a, n, 2 * orow + ph, 2 * ocol, m0 + 32 * mt, h, c0, c1));
+      }
+    publish();
+    return;
+  }
   if (PHW < 0 && a.wide) {   // 16-byte epilogue: four lanes transpose their 4 pixels x 4 channels blocks (conv_common.h)
     const int k = lane & 3;
     TileSide4 side[2];
@@ -505,7 +539,7 @@ template <int MT, int NT, int MODE, int PRO, int PHW, int NWV, int TW = 32>
 static int launch_h2_one(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, hipStream_t st) {
   constexpr int RPQ = 32 / TW;
   constexpr int PIX = (NWV * NT * RPQ + 2) * (TW == 32 ? 34 : 32);
-  constexpr int NKH = PHW < 0 ? 3 : ((PHW >> 1) ? 2 : 1);
+  constexpr int NKH = (PHW < 0 || PHW == 4) ? 3 : ((PHW >> 1) ? 2 : 1);
   constexpr size_t lds = (size_t)(8 * PIX + 2 * H2_SLAB * MT * (NWV == 8 ? NKH : 1)) * 16;
   const vunet_conv_desc& d = ga.d;
   const int blocks = d.N * (d.Hs / (NWV * NT * RPQ)) * (d.Ws / TW) * ((d.M + 32 * MT - 1) / (32 * MT));
@@ -537,7 +571,7 @@ static int launch_h2_w16(const GatherArgs& ga, const void* wx, int mtiles_pad, c
 
 template <int MT, int NT, int NWV = 4>
 static int launch_h2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, hipStream_t st) {
-  if (ga.d.mode == 1 && ga.d.stride == 2) {   // one launch per output parity
+  if (ga.d.mode == 1 && ga.d.stride == 2) {   // one launch per output parity (tests / A-B: VUNET_TUNE_PARITY_LAUNCHES)
     if (pro != 0) return VUNET_ERR_UNSUPPORTED;
     int rc = launch_h2_one<MT, NT, 1, 0, 0, NWV>(ga, wx, mtiles_pad, amax, st);
     if (rc == VUNET_OK) rc = launch_h2_one<MT, NT, 1, 0, 1, NWV>(ga, wx, mtiles_pad, amax, st);

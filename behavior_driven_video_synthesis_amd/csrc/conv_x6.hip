@@ -9,6 +9,7 @@ int vunet_conv_h2_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pa
                              hipStream_t st);
 int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,
                              hipStream_t st);
+int vunet_conv_h2_launch_par(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, hipStream_t st);
 int vunet_conv_h2_launch_w16(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int MT,
                              hipStream_t st);
 
@@ -115,6 +116,8 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
   // K dimension of the image = the gathered tensor's channels; M dimension = all columns of the weight matrix
   const int mtp = vunet_x6_mtiles(d->Mpad);
   if (amax && d->Ws % 32) return vunet_conv_h2_launch_w16(ga, wx, mtp, amax, pro, MT, (hipStream_t)stream);
+  if (amax && d->mode == 1 && d->stride == 2 && !g_vunet_tune[VUNET_TUNE_PARITY_LAUNCHES])
+    return vunet_conv_h2_launch_par(ga, wx, mtp, amax, (hipStream_t)stream);   // all four output parities in one launch
   if (amax)   // two-term fp16 image
     return MT == 1 ? vunet_conv_h2_launch_mt1(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream)
                    : vunet_conv_h2_launch_mt2(ga, wx, mtp, amax, pro, NT, (hipStream_t)stream);
@@ -196,7 +199,8 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
     if (has_wx == 2 && d->Ws % 32) {
       snprintf(name, len, "%s<%d, 1, %d, %d, -1, 4, 16>", fam, MT, d->mode, x6_prologue_code(d, has_mask != 0));
     } else if (has_wx == 2) {
-      if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4, 4, 32>", fam, MT, NT);
+      if (d->stride == 2 && !g_vunet_tune[VUNET_TUNE_PARITY_LAUNCHES]) snprintf(name, len, "%s<1, 1, 1, 0, 4, 4, 32>", fam);
+      else if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4, 4, 32>", fam, MT, NT);
       else snprintf(name, len, "%s<%d, %d, %d, %d, -1, 4, 32>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));
     } else if (d->stride == 2) snprintf(name, len, "%s<%d, %d, 1, 0, parity x4>", fam, MT, NT);
     else snprintf(name, len, "%s<%d, %d, %d, %d, -1>", fam, MT, NT, d->mode, x6_prologue_code(d, has_mask != 0));

@@ -364,21 +364,29 @@ def test_x6_stride2_data_gradient_vs_fp64(cout, cin, h, w, nt, with_aux):
                      stride=2, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
                      aux_act=ops.ACT_ELU if with_aux else 0, aux_slope=0.0, aux_drop_p=0.0, aux_drop_seed=0)
     assert ops._lib.lib().vunet_conv2d_x6_supported(ctypes.byref(d), 0) == 1
-    dx = torch.full((n, cin, 2 * h, 2 * w), float("nan"), device="cuda")     # every pixel must be written by some parity
-    ops.set_tuning("split_force_nt", nt)
-    try:
-        ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
-                  ops._p(dx), _amax(ops, dy), None, ops._stream())
-    finally:
-        ops.set_tuning("split_force_nt", 0)
     wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
     ref = F.conv_transpose2d(dy.double().cpu(), wd, stride=2, padding=1, output_padding=1)
     if with_aux:
         a = aux.double().cpu()
         ref = ref * torch.where(a > 0, torch.ones_like(a), a.exp()) + res.double().cpu()
-    assert torch.isfinite(dx).all()
-    assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0), name="dx")
-    assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * max(float(ref.abs().max()), 1.0)
+    # the fp16 scheme has two forms: all four parities fused in one launch (default) and one launch per parity
+    for per_parity in (0, 1):
+        dx = torch.full((n, cin, 2 * h, 2 * w), float("nan"), device="cuda")     # every pixel must be written by some parity
+        amax_out = torch.zeros(1024, device="cuda")
+        ops.set_tuning("split_force_nt", nt)
+        ops.set_tuning("parity_launches", per_parity)
+        try:
+            am = _amax(ops, dy)
+            ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
+                      ops._p(dx), am, ops._p(amax_out) if am is not None else None, ops._stream())
+        finally:
+            ops.set_tuning("split_force_nt", 0)
+            ops.set_tuning("parity_launches", 0)
+        assert torch.isfinite(dx).all()
+        assert_close(dx, ref.float(), rtol=1e-4, atol=1e-4 * max(float(ref.abs().max()), 1.0), name="dx")
+        assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * max(float(ref.abs().max()), 1.0)
+        if am is not None:   # the published maxima are those of what was stored
+            assert float(amax_out.max()) == float(dx.abs().max())
     # and the fp32 per-parity gather path on the same problem
     dx32 = torch.empty_like(dx)
     ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(dy), None, ops._p(wt_d), None, ops._p(res), ops._p(aux),
