@@ -229,6 +229,141 @@ __global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a)
     for (int nt = 0; nt < NT; ++nt) bk_store_tile(a, n, row0 + wave * NT + nt, col0 + j, true, m0 + mt * 32, h, acc[mt][nt]);
 }
 
+// ---- the same tile, WAVE-SPECIALISED: 512 threads = four matrix waves (w = 0..3: the taps of chunk c from LDS buffer c & 1,
+// rows w*NT .. as above) beside four staging waves (loads two chunks ahead through two register sets, ELU, the LDS writes
+// of chunk c + 1 into the other buffer), one barrier per chunk for all eight.  In the uniform kernel above every wave does
+// load -> multiply -> convert -> write -> barrier in sequence and the phases of co-resident workgroups do not interleave
+// by themselves (ablations: each of {MFMA + LDS reads, weight staging, input loads, ELU} costs 8-25 %, their sum is the
+// kernel); here a SIMD always holds a wave of each kind, so its matrix pipe and its VALU / LDS-write path run side by side.
+template <int MT, int NT, int PRO>
+__global__ __launch_bounds__(512, 4) void conv_blk_ws_kernel(const BlkArgs a) {
+  constexpr int TW = 32, TH = 4 * NT, IH = TH + 2, IW = TW + 2, MB = 32 * MT;
+  constexpr int XU = IH * IW * 2, WU = 9 * MB * 2;
+  constexpr int NX = (XU + 255) / 256, NW = (WU + 255) / 256;
+  constexpr int BUF = XU + WU;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+
+  const vunet_conv_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = d.Hs, W = d.Ws;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblocks = (d.M + MB - 1) / MB;
+  const int mb = bid % mblocks;
+  int t = bid / mblocks;
+  const int tiles_w = W / TW, tiles_h = H / TH;
+  const int tx = t % tiles_w;
+  t /= tiles_w;
+  const int ty = t % tiles_h;
+  const int n = t / tiles_h;
+  const int row0 = ty * TH, col0 = tx * TW, m0 = mb * MB;
+  const int nch1 = d.C1 / 16, nch = nch1 + d.C2 / 16;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ staging waves
+    const int tid = threadIdx.x - 256;
+    int rel[NX], lds_x[NX];
+    uint32_t vbits = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int u = tid + 256 * i;
+      const int c8 = u / (IH * IW);
+      const int rem = u - c8 * (IH * IW);
+      const int r = rem / IW, col = rem - r * IW;
+      const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+      const bool ok = u < XU && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      rel[i] = ok ? (c8 * H + ih) * W + iw : 0;
+      lds_x[i] = c8 * (IH * IW) + rem;
+      vbits |= (ok ? 1u : 0u) << i;
+    }
+    auto issue_loads = [&](int ch, uint4 (&xv)[NX], uint4 (&wv)[NW]) {
+      const bool second = ch >= nch1;
+      const int cb = second ? (ch - nch1) * 2 : ch * 2;
+      const int C8 = (second ? d.C2 : d.C1) >> 3;
+      const uint4* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C8 + cb) * H * W;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xv[i] = xs[rel[i]];
+      const uint4* __restrict__ wp = a.wb + (size_t)ch * 18 * d.Mpad + d.m_off + m0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int w = tid + 256 * i;   // (half, tap, m)
+        const int ht = w / MB, m = w - ht * MB;
+        const bool ok = w < WU && d.m_off + m0 + m < d.Mpad;
+        const uint4 v = wp[ok ? (size_t)ht * d.Mpad + m : 0];
+        wv[i] = ok ? v : make_uint4(0, 0, 0, 0);
+      }
+    };
+    auto write_lds = [&](uint4* buf, const uint4 (&xv)[NX], const uint4 (&wv)[NW]) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        if (tid + 256 * i < XU) {
+          uint4 v = xv[i];
+          if (PRO != 0) v = bk_elu8(v);
+          buf[lds_x[i]] = ((vbits >> i) & 1u) ? v : make_uint4(0, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        if (tid + 256 * i < WU) buf[XU + tid + 256 * i] = wv[i];
+    };
+    // chunk c travels in register set c & 1 (A: even, B: odd); iteration c writes chunk c + 1 and requests chunk c + 3
+    uint4 xa[NX], wa[NW], xb[NX], wb2[NW];
+    issue_loads(0, xa, wa);
+    if (nch > 1) issue_loads(1, xb, wb2);
+    write_lds(smem4, xa, wa);
+    if (nch > 2) issue_loads(2, xa, wa);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch += 2) {
+      if (ch + 1 < nch) {
+        write_lds(smem4 + BUF, xb, wb2);
+        if (ch + 3 < nch) issue_loads(ch + 3, xb, wb2);
+      }
+      __syncthreads();
+      if (ch + 1 >= nch) break;
+      if (ch + 2 < nch) {
+        write_lds(smem4, xa, wa);
+        if (ch + 4 < nch) issue_loads(ch + 4, xa, wa);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- matrix waves
+  const int j = lane & 31, h = lane >> 5;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const uint4* buf = smem4 + (ch & 1) * BUF;
+    const uint4* wL = buf + XU + h * (9 * MB) + j;
+    const uint4* xL = buf + h * (IH * IW) + wave * NT * IW + j;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dr = tap / 3, dc = tap % 3;
+      BkUnit av[MT], bv[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt].u = wL[tap * MB + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt].u = xL[(dr + nt) * IW + dc];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt].b, bv[nt].b, acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bk_store_tile(a, n, row0 + wave * NT + nt, col0 + j, true, m0 + mt * 32, h, acc[mt][nt]);
+}
+
 // ---- every other geometry: taps 1 or 9, stride 1 or 2, any map size; operands straight from global memory.
 // KS = 1: the four waves of a workgroup own four 32-pixel tiles and walk all of K.  KS = 4 (small maps: a 4x4 .. 16x16
 // map of 25 frames has 13 .. 200 pixel tiles for 256 CUs): the four waves share ONE pixel tile, wave w walks the K chunks
@@ -474,10 +609,20 @@ extern "C" int vunet_conv2d_blk(const vunet_conv_desc* d, const void* x1, const 
       NT = g_vunet_tune[VUNET_TUNE_BLK_FORCE_NT];
     const int blocks = d->N * (d->Hs / (4 * NT)) * (d->Ws / 32) * ((d->M + 32 * MT - 1) / (32 * MT));
     const size_t lds = 2 * (size_t)((4 * NT + 2) * 34 * 2 + 9 * 32 * MT * 2) * sizeof(uint4);
+    // wave-specialised form: measured 3-18 % faster on the 128-channel layers (64^2, 32^2 maps), 10-20 % SLOWER on the
+    // HBM-bound 32- / 64-channel ones (half the threads of a workgroup issue loads); tools/time_blk.py [--uniform].
+    // VUNET_TUNE_BLK_WS: 1 = never, 2 = always (tests, A/B)
+    const int ws_knob = g_vunet_tune[VUNET_TUNE_BLK_WS];
+    const bool ws = ws_knob == 2 || (ws_knob != 1 && d->C1 >= 128);
 #define BLK_TILED(MT_, NT_)                                                                                   \
   do {                                                                                                        \
-    if (pro) VUNET_LAUNCH((conv_blk_tiled_kernel<MT_, NT_, 1>), dim3(blocks), dim3(256), lds, st, a);         \
-    else VUNET_LAUNCH((conv_blk_tiled_kernel<MT_, NT_, 0>), dim3(blocks), dim3(256), lds, st, a);             \
+    if (ws) {                                                                                                 \
+      if (pro) VUNET_LAUNCH((conv_blk_ws_kernel<MT_, NT_, 1>), dim3(blocks), dim3(512), lds, st, a);          \
+      else VUNET_LAUNCH((conv_blk_ws_kernel<MT_, NT_, 0>), dim3(blocks), dim3(512), lds, st, a);              \
+    } else {                                                                                                  \
+      if (pro) VUNET_LAUNCH((conv_blk_tiled_kernel<MT_, NT_, 1>), dim3(blocks), dim3(256), lds, st, a);       \
+      else VUNET_LAUNCH((conv_blk_tiled_kernel<MT_, NT_, 0>), dim3(blocks), dim3(256), lds, st, a);           \
+    }                                                                                                         \
   } while (0)
     if (MT == 1 && NT == 1) BLK_TILED(1, 1);
     else if (MT == 1) BLK_TILED(1, 2);

@@ -92,6 +92,18 @@ def test_conv2d_blk_matches_bf16_operand_convolution(case):
     ops._call("vunet_conv2d_blk", ctypes.byref(d), ops._p(b1), ops._p(b2), ops._p(wb), ops._p(shift), ops._p(br), ops._p(y),
               int(nchw), ops._stream())
     got = y if nchw else from_blk(y)
+    if ops._lib.lib().vunet_conv2d_blk_tiled(ctypes.byref(d)) == 1:
+        # the LDS-tiled kernel has two forms (uniform; wave-specialised: four staging + four matrix waves, chosen for the
+        # wide layers): same arithmetic, bit for bit
+        for knob in (1, 2):
+            y2 = torch.full_like(y, float("nan")) if nchw else torch.empty_like(y)
+            ops.set_tuning("blk_ws", knob)
+            try:
+                ops._call("vunet_conv2d_blk", ctypes.byref(d), ops._p(b1), ops._p(b2), ops._p(wb), ops._p(shift), ops._p(br),
+                          ops._p(y2), int(nchw), ops._stream())
+            finally:
+                ops.set_tuning("blk_ws", 0)
+            assert torch.equal(y2, y)
 
     x = x1 if x2 is None else torch.cat([x1, x2], 1)
     if elu:
