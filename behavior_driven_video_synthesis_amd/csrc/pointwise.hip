@@ -168,13 +168,15 @@ extern "C" int vunet_l1_mean_fwd(const float* a, const float* b, float* partial,
 }
 __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ add,
                               float* __restrict__ db, float gs, const float* __restrict__ gout, int64_t n,
-                              float* __restrict__ amax_out) {
+                              float* __restrict__ amax_out, int relu_mask) {
   if (gout) gs *= gout[0];
   float vmax = 0.f;
   EW_LOOP(i, n) {
-    const float d = b[i] - a[i];
+    const float bi = b[i];
+    const float d = bi - a[i];
     const float g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
-    const float v = (add ? add[i] : 0.f) + g;
+    float v = (add ? add[i] : 0.f) + g;
+    if (relu_mask && !(bi > 0.f)) v = 0.f;   // b is a ReLU output: the layer that produced it would zero this entry anyway
     db[i] = v;
     vmax = fmaxf(vmax, fabsf(v));
   }
@@ -185,14 +187,15 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
   }
 }
 extern "C" int vunet_l1_mean_bwd_amax(const float* a, const float* b, const float* add, float* db, float gscale,
-                                      const float* gout, int64_t n, float* amax_out, void* st) {
+                                      const float* gout, int64_t n, float* amax_out, int32_t relu_mask, void* st) {
   if (!a || !b || !db) return VUNET_ERR_ARG;
-  VUNET_LAUNCH(l1_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, add, db, gscale, gout, n, amax_out);
+  VUNET_LAUNCH(l1_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, add, db, gscale, gout, n, amax_out,
+               (int)relu_mask);
   return vunet_check_launch();
 }
 extern "C" int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* db, float gscale,
                                  const float* gout, int64_t n, void* st) {
-  return vunet_l1_mean_bwd_amax(a, b, add, db, gscale, gout, n, nullptr, st);
+  return vunet_l1_mean_bwd_amax(a, b, add, db, gscale, gout, n, nullptr, 0, st);
 }
 
 // ------------------------------------------------------------------ KL / squared-difference (latents: small)
@@ -316,7 +319,8 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                    const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int64_t n) {
+                                    const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int64_t n,
+                                    int relu_mask) {
   const int Ho = H >> 1, Wo = W >> 1;
   EW_LOOP(o, n) {
     const int ow = (int)(o % Wo);
@@ -324,7 +328,8 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
     const int oh = (int)(t % Ho);
     const int64_t nc = t / Ho;
     const int64_t i0 = (nc * H + 2 * oh) * W + 2 * ow;
-    const float m = y[o], g = dy[o];
+    const float m = y[o];
+    const float g = (relu_mask && !(m > 0.f)) ? 0.f : dy[o];   // x is a ReLU output: its layer's backward zeroes x <= 0
     const float2 a = *reinterpret_cast<const float2*>(x + i0);
     const float2 b = *reinterpret_cast<const float2*>(x + i0 + W);
     // first maximum in window scan order gets the gradient (ATen max_pool2d semantics)
@@ -339,12 +344,20 @@ extern "C" int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t 
   VUNET_LAUNCH(maxpool2_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H, W, n);
   return vunet_check_launch();
 }
-extern "C" int vunet_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H,
-                                  int32_t W, void* st) {
+static int maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
+                        int relu_mask, void* st) {
   if (!x || !y || !dy || !dx || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
   const int64_t n = (int64_t)NC * (H / 2) * (W / 2);
-  VUNET_LAUNCH(maxpool2_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, dy, dx, H, W, n);
+  VUNET_LAUNCH(maxpool2_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, dy, dx, H, W, n, relu_mask);
   return vunet_check_launch();
+}
+extern "C" int vunet_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H,
+                                  int32_t W, void* st) {
+  return maxpool2_bwd(x, y, dy, dx, NC, H, W, 0, st);
+}
+extern "C" int vunet_maxpool2_bwd_relu(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H,
+                                       int32_t W, void* st) {
+  return maxpool2_bwd(x, y, dy, dx, NC, H, W, 1, st);
 }
 
 // ------------------------------------------------------------------ InstanceNorm2d (affine=False)

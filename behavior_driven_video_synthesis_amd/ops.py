@@ -248,10 +248,44 @@ def _tagged_amax(t):
 
 
 def carry_amax_tag(src, dst):
-    """``dst`` is an alias of ``src`` (a pass-through output): it holds the same values, so the same maxima."""
+    """``dst`` is an alias of ``src`` (a pass-through output): it holds the same values, so the same maxima (and it is
+    as much the output of a ReLU layer as ``src`` is)."""
     tag = _tagged_amax(src)
     if tag is not None:
         _tag_amax(dst, tag)
+    if _is_relu_out(src):
+        _tag_relu_out(dst)
+
+
+# ---- ReLU masks applied by the PRODUCER of a gradient.  A frozen conv + ReLU layer (the VGG19 stack) whose input x is
+# itself the output of a conv + ReLU layer multiplies its data gradient by [x > 0] in the kernel epilogue (16-byte reads of
+# x) -- the mask the layer below would otherwise apply while STAGING its dy tile (dword loads of a second tensor, 1.5x
+# with the halo).  Max-pool and the L1 taps do the same for their inputs.  The gradient is tagged with the address of the
+# ReLU output it was masked by; the layer below checks the tag and runs the plain data-gradient kernel.  A mask applied
+# twice changes nothing, so correctness never rests on a tag -- a missing one only costs the old path.
+_relu_premask = os.environ.get("VUNET_RELU_PREMASK", "1") != "0"
+
+
+def enable_relu_premask(on: bool = True):
+    global _relu_premask
+    _relu_premask = bool(on)
+
+
+def _tag_relu_out(t):
+    t._vunet_relu_out = t._version
+
+
+def _is_relu_out(t) -> bool:
+    return t is not None and getattr(t, "_vunet_relu_out", None) == t._version
+
+
+def _tag_masked(g, by):
+    g._vunet_masked = (by.data_ptr(), g._version)
+
+
+def _is_masked_by(g, y) -> bool:
+    rec = getattr(g, "_vunet_masked", None)
+    return rec is not None and y is not None and rec[0] == y.data_ptr() and rec[1] == g._version
 
 
 def _amax_for(x1, x2=None):
@@ -904,6 +938,9 @@ class FusedConv(torch.autograd.Function):
         ctx.need_w = need_w
         ctx.save_for_backward(x1, x2, v, g, bias, gamma, invnorm, wt_d,
                               y if cfg.out_act in (ACT_SIGMOID, ACT_RELU, ACT_LRELU, ACT_ELU) else None, wx_d)
+        if cfg.out_act == ACT_RELU:
+            _tag_relu_out(y)
+        ctx.x1_relu_out = _relu_premask and _is_relu_out(x1)
         if cfg.passthrough:
             # second output: x1 itself (autograd makes it an alias with this node as grad_fn).  Whoever else reads the
             # tensor reads the alias, so that gradient arrives HERE (g_alias) and is added in the data-gradient
@@ -941,8 +978,9 @@ class FusedConv(torch.autograd.Function):
         dres = dy if (ctx.needs_input_grad[2] and not cfg.res_is_x1) else None
         k = cfg.k
         # frozen ReLU layers (the VGG19 stack): the ReLU backward rides in the data-gradient kernel's staging
-        if (cfg.out_act == ACT_RELU and not ctx.need_w and not cfg.d2s and x2 is None and ctx.needs_input_grad[0]
-                and cfg.in_act == ACT_NONE and cfg.drop_p == 0 and wt_d is not None):
+        premasked = cfg.out_act == ACT_RELU and _is_masked_by(dy, y)   # the producer of dy already applied [y > 0]
+        if (cfg.out_act == ACT_RELU and not premasked and not ctx.need_w and not cfg.d2s and x2 is None
+                and ctx.needs_input_grad[0] and cfg.in_act == ACT_NONE and cfg.drop_p == 0 and wt_d is not None):
             dx = torch.empty_like(x1)
             d = ConvDesc(N=n, C1=cout, C2=0, Hs=ho, Ws=wo, M=c1, m_off=0, Mpad=wt_d.shape[1], Ho=hs, Wo=ws, KH=k, KW=k,
                          stride=cfg.stride, pad=cfg.pad, mode=1, in_act=ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0,
@@ -977,7 +1015,7 @@ class FusedConv(torch.autograd.Function):
             if _prof["on"] and _prof["recs"]:
                 _prof["recs"].pop()
         dconv = dy
-        if cfg.out_act != ACT_NONE:
+        if cfg.out_act != ACT_NONE and not premasked:
             dconv = torch.empty_like(dy)
             _call("vunet_act_bwd_from_out", _p(y), _p(dy), _p(dconv), cfg.out_act, cfg.in_slope, dy.numel(), _stream())
         if cfg.d2s:
@@ -1086,20 +1124,27 @@ class FusedConv(torch.autograd.Function):
                 dv, dg, dbias, dgamma, dbeta = weight_gradients(defer_ok)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
-            def dgrad(x, cs, m_off, seed, add):
+            def dgrad(x, cs, m_off, seed, add, mask_by_x=False):
                 dx = torch.empty_like(x)
+                has_aux = cfg.in_act != ACT_NONE or cfg.drop_p > 0
+                # x is a ReLU output and this layer has no prologue of its own: the epilogue's act'(aux) slot applies
+                # [x > 0] for the layer below (see _relu_premask)
+                mask_by_x = mask_by_x and not has_aux
                 d = ConvDesc(N=n, C1=cout, C2=0, Hs=ho, Ws=wo, M=cs, m_off=m_off, Mpad=wt_d.shape[1], Ho=hs, Wo=ws,
                              KH=k, KW=k, stride=cfg.stride, pad=cfg.pad, mode=1, in_act=ACT_NONE, in_slope=0.0,
-                             drop_p=0.0, drop_seed=0, out_act=ACT_NONE, d2s=0, aux_act=cfg.in_act,
+                             drop_p=0.0, drop_seed=0, out_act=ACT_NONE, d2s=0,
+                             aux_act=ACT_RELU if mask_by_x else cfg.in_act,
                              aux_slope=cfg.in_slope, aux_drop_p=cfg.drop_p, aux_drop_seed=seed)
-                has_aux = cfg.in_act != ACT_NONE or cfg.drop_p > 0
+                has_aux = has_aux or mask_by_x
                 amax = None
                 if wx_d is not None and _scheme() == 2 and _wants_split(d, has_aux, add is not None):
                     amax = get_dy_amax()
                 _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d, amax)
+                if mask_by_x:
+                    _tag_masked(dx, x)
                 return dx
             if ctx.needs_input_grad[0]:
-                dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else g_alias)
+                dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else g_alias, ctx.x1_relu_out)
                 if cfg.res_is_x1 and g_alias is not None:   # (the epilogue adds one tensor)
                     dx1.add_(g_alias)
                 g_alias = None
@@ -1233,24 +1278,28 @@ class L1Mean(torch.autograd.Function):
         _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
         ctx.save_for_backward(target, pred)
         ctx.weight = float(weight)
+        ctx.pred_relu_out = _relu_premask and _is_relu_out(pred)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         target, pred = ctx.saved_tensors
-        return None, _l1_backward(target, pred, None, ctx.weight, gout), None
+        return None, _l1_backward(target, pred, None, ctx.weight, gout, ctx.pred_relu_out), None
 
 
-def _l1_backward(target, pred, add, weight, gout):
+def _l1_backward(target, pred, add, weight, gout, relu_mask=False):
     """db = add + weight/n * gout * sign(pred - target); under the fp16 scheme the kernel also leaves the partial maxima
-    of |db| for the data gradient that reads it (one pass over the tensor less per VGG tap)."""
+    of |db| for the data gradient that reads it (one pass over the tensor less per VGG tap).  ``relu_mask``: ``pred`` is
+    a ReLU layer's output -- db is zeroed where pred <= 0 and tagged so (see _relu_premask)."""
     db = torch.empty_like(pred)
     amax_out = _new_amax_out(db.device) if (_scheme() == 2 and db.is_cuda) else None
     # the upstream scalar gradient stays on the device (no host sync): the kernel reads gout[0]
     _call("vunet_l1_mean_bwd_amax", _p(target), _p(pred), _p(add), _p(db), weight / pred.numel(), _p(_c(gout)),
-          pred.numel(), _p(amax_out), _stream())
+          pred.numel(), _p(amax_out), int(relu_mask), _stream())
     if amax_out is not None:
         _tag_amax(db, amax_out)
+    if relu_mask:
+        _tag_masked(db, pred)
     return db
 
 
@@ -1270,6 +1319,7 @@ class L1MeanThrough(torch.autograd.Function):
         _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
         ctx.save_for_backward(target, pred)
         ctx.weight = float(weight)
+        ctx.pred_relu_out = _relu_premask and _is_relu_out(pred)
         ctx.set_materialize_grads(False)
         return out, pred
 
@@ -1278,7 +1328,8 @@ class L1MeanThrough(torch.autograd.Function):
         target, pred = ctx.saved_tensors
         if gout is None:
             return None, g_alias, None
-        return None, _l1_backward(target, pred, None if g_alias is None else _c(g_alias), ctx.weight, gout), None
+        return None, _l1_backward(target, pred, None if g_alias is None else _c(g_alias), ctx.weight, gout,
+                                  ctx.pred_relu_out), None
 
 
 class KLPrior(torch.autograd.Function):
@@ -1357,6 +1408,7 @@ class MaxPool2(torch.autograd.Function):
         y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=x.dtype)
         _call("vunet_maxpool2_fwd", _p(x), _p(y), n * c, h, w, _stream())
         ctx.save_for_backward(x, y)
+        ctx.x_relu_out = _relu_premask and _is_relu_out(x)
         tag = _tagged_amax(x)
         if tag is not None:
             _tag_amax(y, tag)   # |max-pool(x)| <= max|x|
@@ -1368,10 +1420,13 @@ class MaxPool2(torch.autograd.Function):
         dy = _c(dy)
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
-        _call("vunet_maxpool2_bwd", _p(x), _p(y), _p(dy), _p(dx), n * c, h, w, _stream())
+        _call("vunet_maxpool2_bwd_relu" if ctx.x_relu_out else "vunet_maxpool2_bwd", _p(x), _p(y), _p(dy), _p(dx), n * c, h,
+              w, _stream())
         tag = _tagged_amax(dy)
         if tag is not None:
-            _tag_amax(dx, tag)  # the gradient is routed, not scaled
+            _tag_amax(dx, tag)  # the gradient is routed (or zeroed), not scaled
+        if ctx.x_relu_out:
+            _tag_masked(dx, x)   # (see _relu_premask)
         return dx
 
 

@@ -292,9 +292,11 @@ int vunet_l1_mean_fwd(const float* a, const float* b, float* partial, float* out
 int vunet_l1_mean_bwd(const float* a, const float* b, const float* add, float* db, float gscale,
                       const float* gout, int64_t n, void* stream);
 /* the same; amax_out (optional, >= 512 floats zeroed by the caller) receives partial maxima of |db|, in the form
- * vunet_conv2d's `amax` expects of the tensor it reads (the gradient enters the last VGG layer's data gradient) */
+ * vunet_conv2d's `amax` expects of the tensor it reads (the gradient enters the last VGG layer's data gradient);
+ * relu_mask != 0: b is the output of a ReLU layer and db is zeroed where b <= 0 -- the mask that layer's backward
+ * (autograd's relu backward, models/imagenet_pretrained.py) would apply next, applied here in passing */
 int vunet_l1_mean_bwd_amax(const float* a, const float* b, const float* add, float* db, float gscale,
-                           const float* gout, int64_t n, float* amax_out, void* stream);
+                           const float* gout, int64_t n, float* amax_out, int32_t relu_mask, void* stream);
 
 /* KL(N(mu, exp(l)^2) || N(0,1)) per lib/losses.py:283-291: out[0] += weight * mean_n(sum_d(-l + .5(e^{2l}+mu^2)) - .5 D) */
 int vunet_kl_fwd(const float* mu, const float* logstd, float* partial, float* out, float weight, int32_t N, int64_t D,
@@ -314,6 +316,9 @@ int vunet_vgg_preprocess_bwd(const float* dy, const float* add, float* dx, int32
                              void* stream);
 /* MaxPool2d(2,2) forward / backward (recomputes the argmax from x) */
 int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t H, int32_t W, void* stream);
+/* (vunet_maxpool2_bwd_relu: x is a ReLU output -- dx additionally zeroed where x <= 0, as for vunet_l1_mean_bwd_amax) */
+int vunet_maxpool2_bwd_relu(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
+                            void* stream);
 int vunet_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H,
                        int32_t W, void* stream);
 

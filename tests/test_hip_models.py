@@ -378,3 +378,36 @@ def test_pretrained_directory_written_by_the_reference_restores_and_renders():
     with torch.no_grad():
         img = tr.vunet.transfer(x, c, eps)
     assert_close(img, arr["transfer"], name="transfer")
+
+
+def test_relu_masks_applied_by_the_gradient_producer_change_nothing():
+    """ops.enable_relu_premask: inside the VGG stack the [x > 0] mask of a conv + ReLU layer's backward is applied by
+    whoever PRODUCES that layer's output gradient (the next layer's data-gradient epilogue, max-pool, the L1 tap), and the
+    layer then runs the plain data-gradient kernel instead of masking while it stages.  Same gradient (the fp16 scheme
+    scales by the maxima of the masked instead of the unmasked tensor: fp32 rounding apart), different kernels."""
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.lib.losses import vgg_loss
+    from behavior_driven_video_synthesis_amd.models.imagenet_pretrained import PerceptualVGG, vgg19
+    pv = PerceptualVGG(vgg19(seed=3, width_div=2), [1.0, 0.5, 1.5, 1.0, 2.0, 1.0]).cuda()
+    g = torch.Generator().manual_seed(11)
+    target = (torch.rand(2, 3, 128, 128, generator=g) * 2 - 1).cuda()
+    pred0 = (torch.rand(2, 3, 128, 128, generator=g) * 2 - 1).cuda()
+
+    def run(on):
+        ops.enable_relu_premask(on)
+        try:
+            pred = pred0.clone().requires_grad_(True)
+            ops.profile_start()
+            losses = vgg_loss(pv, target, pred)
+            torch.stack([v.sum() for v in losses.values()]).sum().backward()
+            fam = ops.profile_stop(by_kernel=True)
+            return pred.grad.clone(), {k: float(v.sum()) for k, v in losses.items()}, fam
+        finally:
+            ops.enable_relu_premask(True)
+    g_on, l_on, k_on = run(True)
+    g_off, l_off, k_off = run(False)
+    assert l_on == l_off
+    scale = float(g_off.abs().max())
+    assert float((g_on - g_off).abs().max()) <= 2e-5 * scale, (float((g_on - g_off).abs().max()), scale)
+    masked = lambda fam: sum(v["n"] for k, v in fam.items() if ", 1, 4, " in k)     # data gradient masking in its staging
+    assert masked(k_off) >= 1 and masked(k_on) == 0, (sorted(k_on), sorted(k_off))
