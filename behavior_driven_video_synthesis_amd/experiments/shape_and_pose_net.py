@@ -122,6 +122,7 @@ class ShapePoseNet:
         # ---- hipGraph replay of the whole step (opt-in: ``training.hip_graph`` / VUNET_HIP_GRAPH=1 / the keyword)
         self._dev_sched = False
         self._graphs = {}
+        self._pack_overlap = os.environ.get("VUNET_PACK_OVERLAP", "1") != "0"   # weight folds beside the VGG target pass
         if hip_graph is None:
             hip_graph = bool(tr.get("hip_graph", os.environ.get("VUNET_HIP_GRAPH", "0") == "1"))
         if hip_graph:
@@ -237,19 +238,38 @@ class ShapePoseNet:
             if ops.dropout_step_counter() is not None:   # left behind by a graph-mode trainer of this process
                 ops.set_dropout_step(None)
             self.optimizer.zero_grad()
-            with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
-                out = self._step(batch, it, eps, reg_eps)
+            target_features = None
+            side = self.vunet._side_stream
+            if side is not None and self.device.type == "cuda" and self._pack_overlap:
+                # the step's weight folds (two launches over every layer, ~0.3 ms with nothing else to run) go to the side
+                # stream; the main stream meanwhile runs the one part of the step that needs none of them -- the frozen
+                # VGG19's pass over the target image (lib/losses.py:88-92: no graph, no generator weights)
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    packed = ops.prepacked(self.vunet)
+                    packed.__enter__()
+                try:
+                    with torch.no_grad():
+                        target_features = self.custom_vgg(batch["pose_img"])
+                    main.wait_stream(side)
+                    out = self._step(batch, it, eps, reg_eps, target_features)
+                finally:
+                    packed.__exit__(None, None, None)
+            else:
+                with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
+                    out = self._step(batch, it, eps, reg_eps)
         self.adjust_params(it)
         out.update({"learning_rate": self.lr, "gamma": self.gamma, "imax": self.imax})
         return out
 
-    def _step(self, batch, it, eps, reg_eps=None):
+    def _step(self, batch, it, eps, reg_eps=None, target_features=None):
         tr = self.config["training"]
         target_img = batch["pose_img"]
         shape_img = batch["stickman"]
         pose_img = batch.get("pose_img_inplane", target_img)
         out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
-        ld = vgg_loss(self.custom_vgg, target_img, out_img)
+        ld = vgg_loss(self.custom_vgg, target_img, out_img, target_features=target_features)
         likelihoods = torch.stack([ld[k] for k in ld], dim=0)
         likelihood_loss = tr["ll_weight"] * torch.sum(likelihoods)
         kl = compute_kl_with_prior(means, logstds)

@@ -28,6 +28,8 @@ def switch(on):
         ops.enable_grad_passthrough(on)
     elif what == "wn_batch":
         ops.enable_wn_batching(on)
+    elif what == "pack_overlap":
+        tr._pack_overlap = on
     elif what == "relu_premask":
         ops.enable_relu_premask(on)
     elif what == "fused_parity":          # the stride-2 data gradient: one fused launch (on) / four per-parity launches
