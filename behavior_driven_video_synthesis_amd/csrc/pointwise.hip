@@ -344,6 +344,55 @@ extern "C" int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t 
   VUNET_LAUNCH(maxpool2_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, x, y, H, W, n);
   return vunet_check_launch();
 }
+// L1 tap + the 2x2 max-pool that reads the same tensor, backward in ONE pass (VGG19 relu1_2 / relu2_2, which feed both a loss
+// term and a pool): db = route(dy_pool) + gs * sign(b - a), optionally zeroed where b <= 0 (b is a ReLU output), partial
+// maxima of |db| published.  One thread per pool window; the window maximum is recomputed from b (no read of the pooled y).
+__global__ void l1_pool_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dyp,
+                                   float* __restrict__ db, float gs, const float* __restrict__ gout, int H, int W, int64_t n,
+                                   float* __restrict__ amax_out, int relu_mask) {
+  if (gout) gs *= gout[0];
+  const int Ho = H >> 1, Wo = W >> 1;
+  float vmax = 0.f;
+  EW_LOOP(o, n) {
+    const int ow = (int)(o % Wo);
+    const int64_t t = o / Wo;
+    const int oh = (int)(t % Ho);
+    const int64_t nc = t / Ho;
+    const int64_t i0 = (nc * H + 2 * oh) * W + 2 * ow;
+    const float2 b0 = *reinterpret_cast<const float2*>(b + i0), b1 = *reinterpret_cast<const float2*>(b + i0 + W);
+    const float2 a0 = *reinterpret_cast<const float2*>(a + i0), a1 = *reinterpret_cast<const float2*>(a + i0 + W);
+    const float m = fmaxf(fmaxf(b0.x, b0.y), fmaxf(b1.x, b1.y));
+    const float g = dyp ? dyp[o] : 0.f;
+    const int k = b0.x == m ? 0 : (b0.y == m ? 1 : (b1.x == m ? 2 : 3));   // first maximum in scan order (ATen max_pool2d)
+    const float bv[4] = {b0.x, b0.y, b1.x, b1.y}, av[4] = {a0.x, a0.y, a1.x, a1.y};
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = bv[e] - av[e];
+      float r = (k == e ? g : 0.f) + (d > 0.f ? gs : (d < 0.f ? -gs : 0.f));
+      if (relu_mask && !(bv[e] > 0.f)) r = 0.f;
+      v[e] = r;
+      vmax = fmaxf(vmax, fabsf(r));
+    }
+    *reinterpret_cast<float2*>(db + i0) = make_float2(v[0], v[1]);
+    *reinterpret_cast<float2*>(db + i0 + W) = make_float2(v[2], v[3]);
+  }
+  if (amax_out) {
+    const float m_ = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(reinterpret_cast<unsigned*>(amax_out) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 511u), __float_as_uint(m_));
+  }
+}
+extern "C" int vunet_l1_pool_bwd(const float* a, const float* b, const float* dy_pool, float* db, float gscale,
+                                 const float* gout, int32_t NC, int32_t H, int32_t W, float* amax_out, int32_t relu_mask,
+                                 void* st) {
+  if (!a || !b || !db || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
+  const int64_t n = (int64_t)NC * (H / 2) * (W / 2);
+  VUNET_LAUNCH(l1_pool_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, a, b, dy_pool, db, gscale, gout, H, W, n,
+               amax_out, (int)relu_mask);
+  return vunet_check_launch();
+}
+
 static int maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
                         int relu_mask, void* st) {
   if (!x || !y || !dy || !dx || (H & 1) || (W & 1)) return VUNET_ERR_ARG;

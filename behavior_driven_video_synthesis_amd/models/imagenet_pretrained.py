@@ -118,8 +118,9 @@ class PerceptualVGG(nn.Module):
         for p in self.vgg_layers.parameters():  # frozen feature extractor
             p.requires_grad_(False)
 
-    def _walk(self, x, on_tap):
-        """The feature pass, :41-61; ``on_tap(name, x) -> x`` sees every tapped feature before the next layer reads it."""
+    def _walk(self, x, on_tap, on_tap_pool=None):
+        """The feature pass, :41-61; ``on_tap(name, x) -> x`` sees every tapped feature before the next layer reads it;
+        ``on_tap_pool(name, x) -> pooled`` (optional) takes a tap that is followed by a max-pool together with the pool."""
         x = on_tap("input", ops.VggPreprocess.apply(x))  # ((x+1)/2 - mean)/std, :43-44
         last = max(int(k) for k in self.target_layers)
         mods = list(self.vgg_layers._modules.items())
@@ -141,7 +142,13 @@ class PerceptualVGG(nn.Module):
             else:
                 x = ops.Activation.apply(x, ops.ACT_RELU, 0.0)
             if name in self.target_layers:
-                x = on_tap(self.target_layers[name], x)
+                nxt = mods[i + 1][1] if i + 1 < len(mods) else None
+                if (on_tap_pool is not None and isinstance(nxt, _Marker) and nxt.kind == "pool"
+                        and int(mods[i + 1][0]) <= last):
+                    x = on_tap_pool(self.target_layers[name], x)   # the tap and the pool behind it as one node
+                    i += 1
+                else:
+                    x = on_tap(self.target_layers[name], x)
             i += 1
 
     def forward(self, x):
@@ -166,5 +173,8 @@ class PerceptualVGG(nn.Module):
             losses[name], alias = ops.L1MeanThrough.apply(target_features[name], t, float(weights[name]))
             ops.carry_amax_tag(t, alias)
             return alias
-        self._walk(pred, term)
+        def term_pool(name, t):
+            losses[name], pooled = ops.L1ThroughPool.apply(target_features[name], t, float(weights[name]))
+            return pooled
+        self._walk(pred, term, term_pool if ops.l1_pool_fusion["on"] else None)
         return losses

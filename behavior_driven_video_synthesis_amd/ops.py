@@ -1332,6 +1332,49 @@ class L1MeanThrough(torch.autograd.Function):
                                   ctx.pred_relu_out), None
 
 
+l1_pool_fusion = {"on": os.environ.get("VUNET_L1_POOL_FUSE", "1") != "0"}   # (A/B switch: tools/ab_step.py l1_pool)
+
+
+class L1ThroughPool(torch.autograd.Function):
+    """``L1Mean(target, pred)`` and ``MaxPool2(pred)`` as one node: (loss, pooled).  Both read ``pred`` (VGG19's relu1_2 /
+    relu2_2 feed a loss term and the next pool); their two gradients -- the routed pool gradient and the L1 sign term --
+    are formed in ONE pass over the tensor (vunet_l1_pool_bwd) instead of pool backward + L1 backward-with-add."""
+
+    @staticmethod
+    def forward(ctx, target, pred, weight: float):
+        _dev(target, pred)
+        target, pred = _c(target), _c(pred)
+        n, c, h, w = pred.shape
+        out = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        partial = torch.empty(1024, device=pred.device, dtype=torch.float32)
+        _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
+        y = torch.empty(n, c, h // 2, w // 2, device=pred.device, dtype=pred.dtype)
+        _call("vunet_maxpool2_fwd", _p(pred), _p(y), n * c, h, w, _stream())
+        tag = _tagged_amax(pred)
+        if tag is not None:
+            _tag_amax(y, tag)   # |max-pool(x)| <= max|x|
+        ctx.save_for_backward(target, pred)
+        ctx.weight = float(weight)
+        ctx.pred_relu_out = _relu_premask and _is_relu_out(pred)
+        ctx.set_materialize_grads(False)
+        return out, y
+
+    @staticmethod
+    def backward(ctx, gout, gy):
+        target, pred = ctx.saved_tensors
+        n, c, h, w = pred.shape
+        db = torch.empty_like(pred)
+        amax_out = _new_amax_out(db.device) if _scheme() == 2 else None
+        scale = ctx.weight / pred.numel() if gout is not None else 0.0
+        _call("vunet_l1_pool_bwd", _p(target), _p(pred), _p(None if gy is None else _c(gy)), _p(db), scale,
+              _p(None if gout is None else _c(gout)), n * c, h, w, _p(amax_out), int(ctx.pred_relu_out), _stream())
+        if amax_out is not None:
+            _tag_amax(db, amax_out)
+        if ctx.pred_relu_out:
+            _tag_masked(db, pred)
+        return None, db, None
+
+
 class KLPrior(torch.autograd.Function):
     """weight * kl_loss(mu, logstd) of lib/losses.py:283-291 (inputs [N, ...] flattened per sample)."""
 

@@ -316,6 +316,12 @@ int vunet_vgg_preprocess_bwd(const float* dy, const float* add, float* dx, int32
                              void* stream);
 /* MaxPool2d(2,2) forward / backward (recomputes the argmax from x) */
 int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t H, int32_t W, void* stream);
+/* Backward of an L1 tap (vunet_l1_mean_*) and of the 2x2 max-pool that reads the same tensor b [NC, H, W], in one pass
+ * (models/imagenet_pretrained.py: relu1_2 / relu2_2 feed a loss term AND the next pool):
+ *   db = route(dy_pool) + gscale * gout[0] * sign(b - a)   (dy_pool [NC, H/2, W/2] or NULL; routing as vunet_maxpool2_bwd),
+ * zeroed where b <= 0 if relu_mask, |db| maxima to amax_out (optional) -- as vunet_l1_mean_bwd_amax */
+int vunet_l1_pool_bwd(const float* a, const float* b, const float* dy_pool, float* db, float gscale, const float* gout,
+                      int32_t NC, int32_t H, int32_t W, float* amax_out, int32_t relu_mask, void* stream);
 /* (vunet_maxpool2_bwd_relu: x is a ReLU output -- dx additionally zeroed where x <= 0, as for vunet_l1_mean_bwd_amax) */
 int vunet_maxpool2_bwd_relu(const float* x, const float* y, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
                             void* stream);

@@ -431,3 +431,43 @@ def test_bilinear_upsample_branch_vs_golden():
         if s is not None:
             got = float(params[k].grad.double().abs().sum())
             assert abs(got - s[1]) <= 1e-3 * s[1] + 1e-4, (k, got, s[1])
+
+
+def test_l1_tap_and_pool_backward_in_one_pass():
+    """vunet_l1_pool_bwd (the VGG taps that feed a loss term AND a max-pool) == vunet_maxpool2_bwd followed by
+    vunet_l1_mean_bwd with its `add` input, bit for bit, with and without the ReLU mask; maxima published."""
+    import ctypes
+    from behavior_driven_video_synthesis_amd import ops
+    g = torch.Generator().manual_seed(21)
+    n, c, h, w = 2, 5, 12, 10
+    pred = torch.relu(torch.randn(n, c, h, w, generator=g)).cuda()          # a ReLU output: zeros and ties included
+    target = torch.relu(torch.randn(n, c, h, w, generator=g)).cuda()
+    dyp = torch.randn(n, c, h // 2, w // 2, generator=g).cuda()
+    gout = torch.tensor([0.7], device="cuda")
+    y = torch.empty(n, c, h // 2, w // 2, device="cuda")
+    ops._call("vunet_maxpool2_fwd", ops._p(pred), ops._p(y), n * c, h, w, ops._stream())
+    scale = 1.5 / pred.numel()
+    for mask in (0, 1):
+        dx = torch.empty_like(pred)
+        ops._call("vunet_maxpool2_bwd_relu" if mask else "vunet_maxpool2_bwd", ops._p(pred), ops._p(y), ops._p(dyp), ops._p(dx),
+                  n * c, h, w, ops._stream())
+        want = torch.empty_like(pred)
+        ops._call("vunet_l1_mean_bwd_amax", ops._p(target), ops._p(pred), ops._p(dx), ops._p(want), scale, ops._p(gout),
+                  pred.numel(), None, mask, ops._stream())
+        got = torch.full_like(pred, float("nan"))
+        amax = torch.zeros(1024, device="cuda")
+        ops._call("vunet_l1_pool_bwd", ops._p(target), ops._p(pred), ops._p(dyp), ops._p(got), scale, ops._p(gout), n * c, h, w,
+                  ops._p(amax), mask, ops._stream())
+        assert torch.equal(got, want)
+        assert float(amax.max()) == float(want.abs().max())
+        if mask:
+            assert float(got[pred <= 0].abs().max()) == 0.0
+    # and against autograd on the CPU (the unmasked form is exactly d/dpred of  w * mean|t - p| + <maxpool(p), dy>)
+    p_ = pred.cpu().clone().requires_grad_(True)
+    loss = 1.5 * (target.cpu() - p_).abs().mean() * 0.7 + (torch.nn.functional.max_pool2d(p_, 2) * dyp.cpu()).sum()
+    loss.backward()
+    got = torch.empty_like(pred)
+    ops._call("vunet_l1_pool_bwd", ops._p(target), ops._p(pred), ops._p(dyp), ops._p(got), scale, ops._p(gout), n * c, h, w,
+              None, 0, ops._stream())
+    nz = (pred != target).cpu()       # (sign(0) is 0 here and in ATen alike; ties of the max go to the first element in both)
+    assert torch.allclose(got.cpu()[nz], p_.grad[nz], rtol=1e-6, atol=1e-7)

@@ -28,6 +28,8 @@ def switch(on):
         ops.enable_grad_passthrough(on)
     elif what == "wn_batch":
         ops.enable_wn_batching(on)
+    elif what == "l1_pool":
+        ops.l1_pool_fusion["on"] = on
     elif what == "pack_overlap":
         tr._pack_overlap = on
     elif what == "relu_premask":
