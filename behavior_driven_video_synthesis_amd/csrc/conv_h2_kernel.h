@@ -382,6 +382,9 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
 #pragma unroll
           for (int q = 0; q < NT; ++q) bv[p][q].u = xB[p * 2 * PIX + (q * RPQ + dr) * IW + dc];
         }
+#ifdef H2_SETPRIO   // (experiment, tools/ab_build.sh: raised issue priority around the tap's MFMA cluster)
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -401,6 +404,9 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
             acc[mt][qa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][qa], 0, 0, 0);
 #endif
           }
+#ifdef H2_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
 #ifndef H2_ABL_NOX
@@ -431,7 +437,8 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   // store_tile_side4; conv2_2 281 -> 270 us, conv1_2 353 -> 335, the 64-channel RNB conv 82 -> 74, C = 32 131 -> 121).
   // Measured and discarded on the way (no gain): persistent workgroups prefetching the next tile's first chunk across
   // the epilogue; 512-thread workgroups with whole-chunk weight stages; starting the first round of workgroups in eight
-  // phases spread over a tile period; non-temporal stores.
+  // phases spread over a tile period; non-temporal stores; s_setprio 1 around every tap's MFMA cluster (-DH2_SETPRIO, r03:
+  // within +-3 % on every layer shape of tools/time_conv.py).
   // ---- epilogue (arithmetic shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The MT * NT
   // tiles are named at compile time (a runtime index would put the accumulators in scratch) and software-pipelined: the
   // residual / aux / shift loads of tile t+1 are issued before the stores of tile t (conv_common.h: load_tile_side).
