@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void conv_thin_m_kernel(const GatherArgs a) {
     if (m < d.M) store_out(a, g, m, acc[m]);
 }
 
-// ---- CI (= 3: RGB) input channels, 3x3 pad 1 (KS 3) or 1x1 (KS 1), stride 1, forward ----------------------------
+// ---- CI (= 3: RGB) input channels, 3x3 pad 1 (KS 3) or 1x1 (KS 1), stride 1; forward, or (3x3) the data gradient of
+//      a layer with 3 OUTPUT channels (dd.out_conv, models/vunets.py:281: dy has 3 channels) with the taps mirrored ------
 template <int KS, int CI>
 __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const GatherArgs a) {
   constexpr int T = KS * KS;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const
       xv[c][t] = v ? x : 0.f;
     }
   }
-  const bool relu = d.out_act == ACT_RELU;
+  const bool relu = d.mode == 0 && d.out_act == ACT_RELU;
   // the whole [T*CI][M] weight block (<= 27 x 128 floats) goes to LDS once; every lane then reads the same
   // address (LDS broadcast).  Scalar loads are not an option here: the kernel stores to y between the passes.
   __shared__ __attribute__((aligned(16))) float wL[T * CI * 128];
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const
   for (int e = threadIdx.x; e < T * CI * Mr; e += 256) {
     const int m = e % Mr, r = e / Mr;           // r = t*CI + c
     const int t = r / CI, c = r - t * CI;
-    wL[r * Mr + m] = m < d.M ? a.wt[(size_t)(t * Cp + c) * d.Mpad + d.m_off + m] : 0.f;
+    const int tw = d.mode == 0 ? t : T - 1 - t;   // data gradient: the weight of tap t is stored under the mirrored tap
+    wL[r * Mr + m] = m < d.M ? a.wt[(size_t)(tw * Cp + c) * d.Mpad + d.m_off + m] : 0.f;
   }
   __syncthreads();
   constexpr int MBK = 8;                   // outputs per pass
@@ -151,8 +153,8 @@ int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool h
   const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
   if (k3 && d->M <= 4 && d->C1 >= 8) return 1;
   // (the 3x3 form runs at two waves per SIMD: hipcc keeps all 27 weight rows of a pass in flight, ~250 VGPRs)
-  if ((k1 || k3) && d->C1 == 3 && d->mode == 0 && d->M <= 128 && !has_res &&
-      (d->out_act == ACT_NONE || d->out_act == ACT_RELU))
+  if ((k1 || k3) && d->C1 == 3 && (d->mode == 0 || k3) && d->M <= 128 && !has_res &&
+      (d->mode == 1 || d->out_act == ACT_NONE || d->out_act == ACT_RELU))
     return 2;
   return 0;
 }

@@ -142,6 +142,13 @@ static void wgrad_geometry(const vunet_wgrad_desc* d, int& T, int& Ctot, int& Co
   if (T > 9 && WM == 4) WM = 2;
 }
 
+// conv_wgrad_thin.hip: 3x3 layers with <= 4 output channels at full resolution (out_conv): fp32 FMA kernel
+bool vunet_wgrad_thin_applicable(const vunet_wgrad_desc* d);
+int vunet_wgrad_thin_nslabs(const vunet_wgrad_desc* d);
+int vunet_wgrad_thin_name(const vunet_wgrad_desc* d, char* name, int len);
+int vunet_wgrad_thin_launch(const vunet_wgrad_desc* d, const float* x1, const float* dy, float* slabs, float* dshift,
+                            hipStream_t st);
+
 // conv_wgrad_tiled.hip: LDS halo-tile kernel for the 3x3 / stride-1 layers that carry the FLOPs
 bool vunet_wgrad_tiled_applicable(const vunet_wgrad_desc* d);
 int vunet_wgrad_tiled_nslabs(const vunet_wgrad_desc* d);
@@ -181,6 +188,10 @@ extern "C" int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name,
     vunet_wgrad_direct_name(d, name, len);
     return VUNET_OK;
   }
+  if (vunet_wgrad_thin_applicable(d)) {
+    vunet_wgrad_thin_name(d, name, len);
+    return VUNET_OK;
+  }
   if (vunet_wgrad_tiled_applicable(d)) {
     if (d->stride == 2) snprintf(name, len, "conv_wgrad_tiled_kernel<2, 2, 3, 2>");
     else snprintf(name, len, "conv_wgrad_tiled_kernel<%d, 4, %d, 1>", d->Cout >= 64 ? 2 : 1, d->KH);
@@ -198,6 +209,7 @@ extern "C" int vunet_conv2d_wgrad_nsplit(const vunet_wgrad_desc* d) {
   if (!d) return VUNET_ERR_ARG;
   if (vunet_wgrad_x6_applicable(d)) return vunet_wgrad_x6_nslabs(d);
   if (vunet_wgrad_direct_applicable(d)) return vunet_wgrad_direct_nslabs(d);
+  if (vunet_wgrad_thin_applicable(d)) return vunet_wgrad_thin_nslabs(d);
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_nslabs(d);
   int T, Ctot, Coutp, nchunks, WM;
   wgrad_geometry(d, T, Ctot, Coutp, nchunks, WM);
@@ -241,6 +253,7 @@ extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, co
     if (!amax_x || !amax_dy) return VUNET_ERR_ARG;
     return vunet_wgrad_direct_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_dy, (hipStream_t)stream);
   }
+  if (vunet_wgrad_thin_applicable(d)) return vunet_wgrad_thin_launch(d, x1, dy, slabs, dshift, (hipStream_t)stream);
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
   WgradArgs wa;
   wa.d = *d;

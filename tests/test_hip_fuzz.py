@@ -116,10 +116,18 @@ def _check(case):
     (4, 3, 0, 64, 128, 128, 3, 1, 1, False, 0.0, False),     # conv1_1: its data gradient 64 -> 3 is thin_m mode 1
     (3, 3, 0, 32, 160, 144, 1, 1, 0, False, 0.0, False),     # nin 3 -> 32: thin_k 1x1
     (2, 3, 0, 40, 200, 168, 3, 1, 1, False, 0.0, False),     # 3 -> 40, 3x3: thin_k forward, ragged M and tiles
+    (2, 32, 0, 3, 256, 128, 3, 1, 1, False, 0.0, False),     # out_conv at tile-aligned size: thin_k data gradient (3 -> 32,
+                                                             # mirrored taps) and the FMA weight-gradient kernel
+    (1, 64, 0, 4, 264, 256, 3, 1, 1, True, 0.0, False),      # 64 -> 4 with an ELU prologue: three items per thread
 ], ids=_ids)
 def test_three_channel_side_kernels_vs_oracle(case):
     from behavior_driven_video_synthesis_amd import ops
     ops.profile_start()
     _check(case)
     kernels = ops.profile_stop(by_kernel=True)
-    assert any(k.startswith("conv_thin_") for k in kernels), kernels
+    if not case[9]:   # (a prologue keeps the forward / data gradient off the VALU kernels)
+        assert any(k.startswith("conv_thin_") for k in kernels), kernels
+    if case[3] <= 4 and case[4] % 8 == 0 and case[5] % 32 == 0:
+        assert any(k.startswith("conv_wgrad_thin_kernel") for k in kernels), kernels
+    if case[3] == 3 and case[6] == 3:
+        assert any(k.startswith("conv_thin_k_kernel<3") for k in kernels), kernels     # the 3 -> C data gradient
