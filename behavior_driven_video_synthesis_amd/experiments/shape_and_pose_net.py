@@ -122,7 +122,9 @@ class ShapePoseNet:
         # ---- hipGraph replay of the whole step (opt-in: ``training.hip_graph`` / VUNET_HIP_GRAPH=1 / the keyword)
         self._dev_sched = False
         self._graphs = {}
-        self._pack_overlap = os.environ.get("VUNET_PACK_OVERLAP", "1") != "0"   # weight folds beside the VGG target pass
+        # weight folds beside the VGG target pass: measured -0.4 % (tools/ab_step.py pack_overlap), inside box-to-box noise,
+        # at the price of two concurrent streams in the part of the step the per-kernel roofline is read from: off
+        self._pack_overlap = os.environ.get("VUNET_PACK_OVERLAP", "0") == "1"
         if hip_graph is None:
             hip_graph = bool(tr.get("hip_graph", os.environ.get("VUNET_HIP_GRAPH", "0") == "1"))
         if hip_graph:
