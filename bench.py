@@ -308,7 +308,9 @@ def render_row(vunet, device, size, frames=50, chunk=50, iters=5):
                 pmc = json.load(open(os.path.join(ROOT, rel)))
             except (OSError, ValueError):
                 continue
-            ents = [v for k, v in pmc.get("kernels", {}).items() if k.startswith("conv_blk_tiled_kernel")]
+            # (both forms of the tiled kernel: the wave-specialised one runs the 128-channel layers)
+            ents = [v for k, v in pmc.get("kernels", {}).items()
+                    if k.startswith("conv_blk_tiled_kernel") or k.startswith("conv_blk_ws_kernel")]
             if ents:   # every instantiation of the kernel, weighted by its launches
                 nl = sum(e["launches_sampled"] for e in ents)
                 row["roofline"]["traffic"] = sum(e["hbm_bytes_per_launch"] * e["launches_sampled"] for e in ents) / nl
