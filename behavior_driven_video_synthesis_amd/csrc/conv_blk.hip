@@ -177,9 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a)
     for (int i = 0; i < NX; ++i) {
       if (tid + 256 * i < XU) {
         uint4 v = xv[i];
-#ifndef BLK_ABL_NOELU   // timing ablations (tools/ab_build.sh): results are wrong, only the clock is read
         if (PRO != 0) v = bk_elu8(v);
-#endif
         buf[lds_x[i]] = ((vbits >> i) & 1u) ? v : make_uint4(0, 0, 0, 0);
       }
     }
@@ -198,13 +196,11 @@ __global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a)
       for (int mt = 0; mt < MT; ++mt) av[mt].u = wL[tap * MB + mt * 32];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bv[nt].u = xL[(dr + nt) * IW + dc];
-#ifndef BLK_ABL_NOMFMA
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt].b, bv[nt].b, acc[mt][nt], 0, 0, 0);
-#endif
     }
   };
 
