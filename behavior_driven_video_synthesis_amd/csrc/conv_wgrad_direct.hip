@@ -51,19 +51,27 @@ __device__ __forceinline__ h2_f16x8 wd_frag(uint32_t a, uint32_t b, uint32_t c, 
   return __builtin_bit_cast(h2_f16x8, u);
 }
 
-// S: stride (1, 2).  W4: output maps 4 wide (an octet is two output rows of 4).  T: 9 (3x3, pad 1) or 1 (1x1, S = 1).
+// S: stride (1, 2).  W4: output maps 4 wide (an octet is two output rows of 4).  T: 9 (3x3, pad 1) or 1 (1x1, S = 1), or
+// 3: the three taps of ONE kernel row -- a wave then owns (co tile, kernel row kh): it loads one input row per octet instead
+// of three and keeps three accumulators instead of nine (~110 VGPRs instead of 243), so four waves per SIMD cover the
+// load -> MFMA dependency that bounds the nine-tap form on the large stride-2 maps (r03: 53 TFLOP/s, two waves per SIMD
+// waiting on 17 uncoalesced loads per 27 MFMAs).
 template <int S, bool W4, int T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDirectArgs a_in) {
   WgradDirectArgs a = a_in;
   inact_resolve(a.in1);
   inact_resolve(a.in2);
   // rows / loaded columns of the input one octet touches
-  constexpr int R = T == 1 ? 1 : (W4 ? S + 3 : 3);
+  static_assert(T != 3 || !W4, "the kernel-row split is for maps >= 8 wide");
+  constexpr int R = (T == 1 || T == 3) ? 1 : (W4 ? S + 3 : 3);
   constexpr int L = T == 1 ? 8 : (W4 ? 4 * S + 2 : 8 * S + 2);   // L - 1 used at S = 2 (no right halo)
   const vunet_wgrad_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int unit = blockIdx.x * 4 + wave;          // (split, co tile), co tile fastest: the waves of a workgroup share x
+  // (split, co tile[, kernel row]), fastest last: the waves of a workgroup share x (and, row-split, dy)
+  const int unit0 = blockIdx.x * 4 + wave;
+  const int krow = T == 3 ? unit0 % 3 : 0;
+  const int unit = T == 3 ? unit0 / 3 : unit0;
   const int cot = unit % a.ncot, split = unit / a.ncot;
   const int ci0 = blockIdx.y * 32;
   const int H = d.Hs, W = d.Ws, HW = H * W, HoWo = d.Ho * d.Wo;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
       const float* xp = xs + cbase;
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) {
-        const int ih = T == 1 ? 0 : S * r0 - 1 + rr;
+        const int ih = T == 1 ? 0 : S * r0 - 1 + rr + krow;
         const bool rok = ov && ci_ok && (T == 1 || (unsigned)ih < (unsigned)H);
         const int ihc = rok ? ih : 0;
         if (T == 1) {
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
     // ---- nine taps: fragment = 8 elements selected from the rows, split, three products
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int kh = t / 3, kw = t % 3;
+      const int kh = T == 3 ? 0 : t / 3, kw = t % 3;   // (row-split: the one staged row IS kernel row krow)
       float f[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -197,18 +205,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
   }
 
   // ---- partial slab of this split:  [split][Coutp][T * Ctot], k order (tap, ci)
-  const size_t KT = (size_t)T * a.Ctot;
+  const size_t KT = (size_t)(T == 3 ? 9 : T) * a.Ctot;
   float* slab = a.slabs + (size_t)split * a.Coutp * KT;
   if (ci_ok) {
     auto store = [&](auto tc) {
       constexpr int t = decltype(tc)::value;
+      const int tap = T == 3 ? krow * 3 + t : t;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cr = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (cr < d.Cout) slab[(size_t)cr * KT + (size_t)t * a.Ctot + ci] = acc[t][r] * descale * descale2;
+        if (cr < d.Cout) slab[(size_t)cr * KT + (size_t)tap * a.Ctot + ci] = acc[t][r] * descale * descale2;
       }
     };
     store(std::integral_constant<int, 0>{});
+    if constexpr (T == 3) {
+      store(std::integral_constant<int, 1>{});
+      store(std::integral_constant<int, 2>{});
+    }
     if constexpr (T == 9) {
       store(std::integral_constant<int, 1>{});
       store(std::integral_constant<int, 2>{});
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
       store(std::integral_constant<int, 8>{});
     }
   }
-  if (blockIdx.y == 0) {
+  if (blockIdx.y == 0 && krow == 0) {
     const float tot = dsum + __shfl_xor(dsum, 32, 64);
     if (h == 0 && co < a.Coutp) a.dshift[(size_t)split * a.Coutp + co] = co_ok ? tot : 0.f;
   }
@@ -259,11 +272,19 @@ static void direct_geometry(const vunet_wgrad_desc* d, WgradDirectArgs& a) {
 
 // Pixel splits: about 2048 waves in all (eight per CU), every wave at least four K steps (eight octets) where the
 // problem has them; few splits for the tiny maps (a slab is written per split).
+// kernel-row split (three waves per (split, co tile), one kernel row each): the stride-2 layers on maps >= 8 wide by
+// default; VUNET_TUNE_WGRAD_ROWSPLIT 1 = never, 2 = the stride-1 direct layers as well (A/B, tests)
+static bool direct_rowsplit(int cls) {
+  const int knob = g_vunet_tune[VUNET_TUNE_WGRAD_ROWSPLIT];
+  if (knob == 1) return false;
+  return cls == 5 || (knob == 2 && cls == 4);
+}
+
 int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d) {
   WgradDirectArgs a;
   direct_geometry(d, a);
   const int ncit = (a.Ctot + 31) / 32;
-  int S = 2048 / (a.ncot * ncit);
+  int S = 2048 / (a.ncot * ncit * (direct_rowsplit(direct_class(d)) ? 3 : 1));
   const int by_work = (a.noct + 7) / 8;
   if (S > by_work) S = by_work;
   if (S < 1) S = 1;
@@ -274,7 +295,7 @@ int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d) {
 
 int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len) {
   const int cls = direct_class(d);
-  const int S = (cls == 3 || cls == 5) ? 2 : 1, W4 = (cls == 2 || cls == 3), T = cls == 1 ? 1 : 9;
+  const int S = (cls == 3 || cls == 5) ? 2 : 1, W4 = (cls == 2 || cls == 3), T = cls == 1 ? 1 : (direct_rowsplit(cls) ? 3 : 9);
   return snprintf(name, len, "conv_wgrad_direct_kernel<%d, %s, %d>", S, W4 ? "true" : "false", T);
 }
 
@@ -290,8 +311,14 @@ int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const 
   a.ops = (a.ops + 1) & ~1;   // whole K steps of two octets
   a.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
   a.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
-  const int units = d->nsplit * a.ncot;
+  const bool rs = direct_rowsplit(cls);
+  const int units = d->nsplit * a.ncot * (rs ? 3 : 1);
   dim3 grid((unsigned)((units + 3) / 4), (unsigned)((a.Ctot + 31) / 32)), block(256);
+  if (rs) {
+    if (cls == 5) VUNET_LAUNCH((conv_wgrad_direct_kernel<2, false, 3>), grid, block, 0, st, a);
+    else VUNET_LAUNCH((conv_wgrad_direct_kernel<1, false, 3>), grid, block, 0, st, a);
+    return vunet_check_launch();
+  }
   switch (cls) {
     case 1: VUNET_LAUNCH((conv_wgrad_direct_kernel<1, false, 1>), grid, block, 0, st, a); break;
     case 2: VUNET_LAUNCH((conv_wgrad_direct_kernel<1, true, 9>), grid, block, 0, st, a); break;

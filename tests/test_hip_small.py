@@ -202,9 +202,13 @@ WGRAD = [
 ]
 
 
+@pytest.mark.parametrize("rowsplit", [0, 1, 2], ids=["rowsplit_auto", "rowsplit_off", "rowsplit_all"])
 @pytest.mark.parametrize("case", WGRAD)
-def test_direct_weight_gradient_vs_fp64(case):
+def test_direct_weight_gradient_vs_fp64(case, rowsplit):
+    """(rowsplit: the kernel-row split of the direct kernel -- one kernel row per wave -- by default on the stride-2
+    layers of maps >= 8 wide, switched off / widened to the stride-1 direct layers by the tuning knob)"""
     ops = _ops()
+    ops.set_tuning("wgrad_rowsplit", rowsplit)
     n, c1, c2, cout, hs, ws, k, stride, in_act, drop = case
     pad = 1 if k == 3 else 0
     ho, wo = (hs + 2 * pad - k) // stride + 1, (ws + 2 * pad - k) // stride + 1

@@ -28,6 +28,10 @@ def switch(on):
         ops.enable_grad_passthrough(on)
     elif what == "wn_batch":
         ops.enable_wn_batching(on)
+    elif what == "wgrad_rowsplit":
+        ops.set_tuning("wgrad_rowsplit", 0 if on else 1)
+    elif what == "wgrad_rowsplit_all":
+        ops.set_tuning("wgrad_rowsplit", 2 if on else 0)
     elif what == "l1_pool":
         ops.l1_pool_fusion["on"] = on
     elif what == "pack_overlap":
