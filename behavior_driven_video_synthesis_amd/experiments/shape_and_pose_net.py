@@ -122,6 +122,10 @@ class ShapePoseNet:
         # ---- hipGraph replay of the whole step (opt-in: ``training.hip_graph`` / VUNET_HIP_GRAPH=1 / the keyword)
         self._dev_sched = False
         self._graphs = {}
+        # VGG target pass beside the small-map part of the generator's forward (tools/ab_step.py target_overlap)
+        # (on wherever the trainer runs on several streams; measured -1.4 % .. -2.5 % step time)
+        self._target_overlap = os.environ.get("VUNET_TARGET_OVERLAP", "1") != "0"
+        self._target_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # weight folds beside the VGG target pass: measured -0.4 % (tools/ab_step.py pack_overlap), inside box-to-box noise,
         # at the price of two concurrent streams in the part of the step the per-kernel roofline is read from: off
         self._pack_overlap = os.environ.get("VUNET_PACK_OVERLAP", "0") == "1"
@@ -270,7 +274,27 @@ class ShapePoseNet:
         target_img = batch["pose_img"]
         shape_img = batch["stickman"]
         pose_img = batch.get("pose_img_inplane", target_img)
-        out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
+        tstream = self._target_stream if (target_features is None and self._target_overlap and target_img.is_cuda
+                                            and self.vunet._side_stream is not None
+                                            and not torch.cuda.is_current_stream_capturing()) else None
+        if tstream is not None:
+            # The frozen VGG19's pass over the TARGET image needs nothing from the generator.  It is issued on a stream of
+            # its own once the appearance pyramid is through, so that its chip-filling kernels run beside the bottleneck
+            # and the decoder's 4x4 .. 32x32 levels -- ~50 launches of a few microseconds each that leave the GPU idle.
+            main = torch.cuda.current_stream()
+            box = {}
+
+            def start_target_pass():
+                tstream.wait_stream(main)
+                with torch.cuda.stream(tstream), torch.no_grad():
+                    box["f"] = self.custom_vgg(target_img)
+            out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps, after_encoder=start_target_pass)
+            main.wait_stream(tstream)
+            target_features = box["f"]
+            for t_ in target_features.values():
+                t_.record_stream(main)
+        else:
+            out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
         ld = vgg_loss(self.custom_vgg, target_img, out_img, target_features=target_features)
         likelihoods = torch.stack([ld[k] for k in ld], dim=0)
         likelihood_loss = tr["ll_weight"] * torch.sum(likelihoods)

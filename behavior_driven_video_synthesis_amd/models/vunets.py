@@ -358,9 +358,14 @@ class VunetAlter(_VunetBase):
     bottleneck_cls = EncDownAlter
     decoder_cls = DecDownAlter
 
-    def forward(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None):
+    def forward(self, x, c, eps: Optional[Sequence[torch.Tensor]] = None, after_encoder=None):
+        """``after_encoder``: optional callable invoked once the appearance pyramid has been issued and before the
+        bottleneck -- the trainer's hook for work that should run beside the latency-bound small-map layers that follow
+        (the reference's call is ``forward(x, c)``)."""
         gs = self._fork_pose_encoder(c)      # du(c) shares nothing with eu / ed until dd: issued first, side stream
         hs = self.eu(x)
+        if after_encoder is not None:
+            after_encoder()
         _, means, logstds, zs = self.ed(hs, eps)
         imgs = self.dd(self._join_pose_encoder(gs), zs, training=True)
         return imgs, means, logstds, (hs, means, logstds)

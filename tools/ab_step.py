@@ -34,6 +34,8 @@ def switch(on):
         ops.set_tuning("wgrad_rowsplit", 2 if on else 0)
     elif what == "l1_pool":
         ops.l1_pool_fusion["on"] = on
+    elif what == "target_overlap":
+        tr._target_overlap = on
     elif what == "pack_overlap":
         tr._pack_overlap = on
     elif what == "relu_premask":
