@@ -9,6 +9,10 @@ int vunet_conv_h2_launch_mt1(const GatherArgs& ga, const void* wx, int mtiles_pa
                              hipStream_t st);
 int vunet_conv_h2_launch_mt2(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int NT,
                              hipStream_t st);
+// conv_h2_s2.hip: forward of the stride-2 layers (fp16 scheme)
+bool vunet_conv_h2_s2_ok(const vunet_conv_desc* d, int pro);
+int vunet_conv_h2_s2_name(const vunet_conv_desc* d, char* name, int len);
+int vunet_conv_h2_s2_launch(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, hipStream_t st);
 int vunet_conv_h2_launch_par(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, hipStream_t st);
 int vunet_conv_h2_launch_w16(const GatherArgs& ga, const void* wx, int mtiles_pad, const float* amax, int pro, int MT,
                              hipStream_t st);
@@ -101,6 +105,12 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
                      const float* res, const float* aux, const float* mask, float* y, const float* amax, float* amax_out,
                      long min_blocks, void* stream) {
   const int pro = x6_prologue_code(d, mask != nullptr);
+  if (amax && !mask && !aux && !res && !g_vunet_tune[VUNET_TUNE_S2_FWD_F32] && vunet_conv_h2_s2_ok(d, pro)) {
+    GatherArgs gs;   // stride-2 forward: its own kernel (parity-plane staging)
+    fill_args(gs, d, x1, x2, nullptr, shift, res, aux, mask, y);
+    gs.amax_out = amax_out;
+    return vunet_conv_h2_s2_launch(gs, wx, vunet_x6_mtiles(d->Mpad), amax, (hipStream_t)stream);
+  }
   int MT = 0;
   int NT = x6_geometry_ok(d, pro, amax != nullptr) ? x6_pick(d, &MT, min_blocks, amax != nullptr) : 0;
   if (g_vunet_tune[VUNET_TUNE_FORCE_SMALL] && amax && !mask && vunet_conv_h2_small_ok(d, pro)) NT = 0;   // tests
@@ -130,6 +140,8 @@ static bool x6_wanted(const vunet_conv_desc* d, bool has_wx, bool has_aux, bool 
   if (!has_wx || !x6_enabled()) return false;
   const int pro = x6_prologue_code(d, has_mask);
   if (vunet_conv_thin_kind(d, pro == 4 ? 0 : pro, has_aux, has_res) != 0) return false;
+  if (h2 && !has_mask && !has_aux && !has_res && !g_vunet_tune[VUNET_TUNE_S2_FWD_F32] && vunet_conv_h2_s2_ok(d, pro))
+    return true;   // stride-2 forward (conv_h2_s2.hip)
   int MT;
   if (x6_geometry_ok(d, pro, h2) && x6_pick(d, &MT, 128, h2) > 0) return true;
   return h2 && !has_mask && vunet_conv_h2_small_wanted(d, pro);   // the small-map form (conv_h2_small.hip)
@@ -137,6 +149,7 @@ static bool x6_wanted(const vunet_conv_desc* d, bool has_wx, bool has_aux, bool 
 
 static bool x6_uses_small(const vunet_conv_desc* d, bool has_mask, bool h2) {
   const int pro = x6_prologue_code(d, has_mask);
+  if (h2 && !has_mask && !g_vunet_tune[VUNET_TUNE_S2_FWD_F32] && vunet_conv_h2_s2_ok(d, pro)) return false;
   int MT;
   return h2 && !has_mask && !(x6_geometry_ok(d, pro, h2) && x6_pick(d, &MT, 128, h2) > 0);
 }
@@ -191,6 +204,11 @@ extern "C" int vunet_conv2d_variant(const vunet_conv_desc* d, int32_t has_aux, i
                                     char* name, int32_t len) {
   if (!d || !name || len < 8) return VUNET_ERR_ARG;
   if (x6_wanted(d, has_wx != 0, has_aux != 0, false, has_mask != 0, has_wx == 2)) {
+    if (has_wx == 2 && !has_mask && !has_aux && !g_vunet_tune[VUNET_TUNE_S2_FWD_F32] &&
+        vunet_conv_h2_s2_ok(d, x6_prologue_code(d, false))) {
+      vunet_conv_h2_s2_name(d, name, len);
+      return VUNET_OK;
+    }
     if (x6_uses_small(d, has_mask != 0, has_wx == 2))
       return vunet_conv_h2_small_name(d, x6_prologue_code(d, has_mask != 0), name, len);
     int MT;

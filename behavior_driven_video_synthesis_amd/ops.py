@@ -191,7 +191,7 @@ def _scheme() -> int:
 
 
 _wants_split_cache = {}
-_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2, "blk_force_nt": 3, "parity_launches": 4, "blk_ws": 5, "wgrad_rowsplit": 6}
+_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2, "blk_force_nt": 3, "parity_launches": 4, "blk_ws": 5, "wgrad_rowsplit": 6, "s2_fwd_f32": 7}
 
 
 def set_tuning(key: str, value: int):

@@ -360,6 +360,8 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *   VUNET_TUNE_BLK_FORCE_NT    tile height (rows per wave: 1 or 2) of the LDS-tiled blocked-bf16 kernel (vunet_conv2d_blk)
  *   VUNET_TUNE_BLK_WS          the LDS-tiled blocked-bf16 kernel: 1 = always its uniform form (every wave stages and multiplies),
  *                              2 = always the wave-specialised form (four staging + four matrix waves); 0 = by layer width
+ *   VUNET_TUNE_S2_FWD_F32      1: the stride-2 forward layers on the fp32-input MFMA kernel instead of the fp16 scheme's
+ *                              parity-plane kernel (A/B timing, tests)
  *   VUNET_TUNE_WGRAD_ROWSPLIT  the direct weight-gradient kernel's kernel-row split (one kernel row per wave): 1 = never, 2 = also
  *                              for the stride-1 direct layers; 0 = the stride-2 layers on maps >= 8 wide
  *   VUNET_TUNE_PARITY_LAUNCHES 1: the stride-2 data gradient of the fp16 scheme as four launches, one per output parity,
@@ -372,6 +374,7 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
 #define VUNET_TUNE_PARITY_LAUNCHES 4
 #define VUNET_TUNE_BLK_WS 5
 #define VUNET_TUNE_WGRAD_ROWSPLIT 6
+#define VUNET_TUNE_S2_FWD_F32 7
 int vunet_set_tuning(int32_t key, int32_t value);
 
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */

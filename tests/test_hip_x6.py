@@ -492,3 +492,47 @@ def test_h2_scale_handles_extreme_magnitudes(mag, scheme):
         yn, _, _, _ = _run_forward(ops, xn, None, v, g, bias, gamma, beta, 0, 0.0, 0, 0, None, False, True, 2)
         assert torch.isnan(yn[0, :, 3:6, 4:7]).all() and torch.isfinite(yn[1]).all()
         assert torch.isfinite(yn[0, :, :, 16:]).all()
+
+
+@pytest.mark.parametrize("n,cin,cout,ho,wo,relu", [(2, 32, 64, 32, 64, False), (4, 64, 128, 16, 32, False),
+                                                     (33, 16, 32, 8, 32, True), (2, 128, 128, 32, 32, False)])
+def test_h2_stride2_forward_vs_fp64(n, cin, cout, ho, wo, relu):
+    """Forward of the stride-2 Downsample conv (lib/modules.py:148-161) on the fp16 scheme's parity-plane kernel
+    (csrc/conv_h2_s2.hip): input [2 ho, 2 wo] -> output [ho, wo], against an fp64 convolution; the same problem on the
+    fp32-input MFMA kernel it replaces (tuning knob) must agree to fp32 accuracy; published maxima = those of y."""
+    ops = _ops()
+    if ops.conv_precision() != "h2":
+        pytest.skip("fp16 scheme only")
+    g_ = torch.Generator().manual_seed(cin + cout + ho)
+    v, g, bias, gamma, beta = _params(cout, cin, 5)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, cin, 0, 0, False)
+    x = torch.randn(n, cin, 2 * ho, 2 * wo, generator=g_).cuda()
+    d = ops.ConvDesc(N=n, C1=cin, C2=0, Hs=2 * ho, Ws=2 * wo, M=cout, m_off=0, Mpad=wt_f.shape[1], Ho=ho, Wo=wo, KH=3, KW=3,
+                     stride=2, pad=1, mode=0, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0,
+                     out_act=ops.ACT_RELU if relu else 0, d2s=0)
+    assert ops._lib.lib().vunet_conv2d_wants_split(ctypes.byref(d), 0, 0, 0, 2) == 1
+    buf = ctypes.create_string_buffer(96)
+    ops._call("vunet_conv2d_variant", ctypes.byref(d), 0, 2, 0, buf, 96)
+    assert buf.value.decode().startswith("conv_h2_s2_kernel<"), buf.value
+    y = torch.full((n, cout, ho, wo), float("nan"), device="cuda")
+    amax_out = torch.zeros(1024, device="cuda")
+    ops._call("vunet_conv2d", ctypes.byref(d), ops._p(x), None, ops._p(wt_f), ops._p(wx_f), ops._p(shift), None, None,
+              ops._p(y), _amax(ops, x), ops._p(amax_out), ops._stream())
+    w64 = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
+    ref = F.conv2d(x.double().cpu(), w64, None, stride=2, padding=1) + shift.double().cpu().view(1, -1, 1, 1)
+    if relu:
+        ref = torch.relu(ref)
+    s_ = max(float(ref.abs().max()), 1.0)
+    assert torch.isfinite(y).all()
+    assert float((y.double().cpu() - ref).abs().max()) <= 3e-6 * s_
+    assert float(amax_out.max()) == float(y.abs().max())
+    ops.set_tuning("s2_fwd_f32", 1)
+    try:
+        ops._call("vunet_conv2d_variant", ctypes.byref(d), 0, 2, 0, buf, 96)
+        assert not buf.value.decode().startswith("conv_h2_s2_kernel"), buf.value
+        y32 = torch.empty_like(y)
+        ops._call("vunet_conv2d", ctypes.byref(d), ops._p(x), None, ops._p(wt_f), ops._p(wx_f), ops._p(shift), None, None,
+                  ops._p(y32), None, None, ops._stream())
+    finally:
+        ops.set_tuning("s2_fwd_f32", 0)
+    assert_close(y, y32, rtol=2e-5, atol=2e-5 * s_, name="h2 stride-2 forward vs the fp32 MFMA kernel")

@@ -34,6 +34,8 @@ def switch(on):
         ops.set_tuning("wgrad_rowsplit", 2 if on else 0)
     elif what == "l1_pool":
         ops.l1_pool_fusion["on"] = on
+    elif what == "s2_fwd_h2":
+        ops.set_tuning("s2_fwd_f32", 0 if on else 1)
     elif what == "target_overlap":
         tr._target_overlap = on
     elif what == "pack_overlap":
