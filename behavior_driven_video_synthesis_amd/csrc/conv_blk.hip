@@ -469,6 +469,106 @@ __global__ __launch_bounds__(256) void conv_blk_direct_kernel(const BlkArgs a) {
   }
 }
 
+// ---- the KS = 1 form with the WEIGHTS THROUGH LDS.  Read as A fragments straight from global memory they pass through
+// the L1 once per wave: 2 KB per wave and chunk for the two MFMAs of a 1x1 layer, 18 KB for the eighteen of a 3x3 one --
+// twice what the L1 delivers in the time those MFMAs take (the same finding as in conv_h2_s2.hip).  Here the four waves of
+// a workgroup share them: a 1x1 layer copies ALL its chunks once (one barrier), a 3x3 layer one chunk at a time.
+template <int MT, int T, int PRO>
+__global__ __launch_bounds__(256) void conv_blk_direct_lds_kernel(const BlkArgs a) {
+  constexpr int MB = 32 * MT;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  uint4* const wL = smem4;   // T == 1: [chunk][k half][MB]   T == 9: [k half][tap][MB] of the current chunk
+  const vunet_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int mblocks = (d.M + MB - 1) / MB;
+  const int mb = blockIdx.x % mblocks, pb = blockIdx.x / mblocks;
+  const int m0 = mb * MB;
+  const int ptile = pb * 4 + wave;
+  const bool active = ptile * 32 < a.NP;   // (wave-uniform; idle waves still copy weights and meet the barriers)
+  const int P = ptile * 32 + j;
+  const bool valid = P < a.NP;
+  const int Pc = valid ? P : 0;
+  const int HoWo = d.Ho * d.Wo;
+  const int n = Pc / HoWo, rem = Pc - n * HoWo;
+  const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+  const int H = d.Hs, W = d.Ws, HW = H * W;
+  int toff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int ih = oh * d.stride - d.pad + (T == 1 ? 0 : t / 3), iw = ow * d.stride - d.pad + (T == 1 ? 0 : t % 3);
+    const bool ok = valid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    toff[t] = ok ? ih * W + iw : -1;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+  const int nch1 = d.C1 / 16, nch = nch1 + d.C2 / 16;
+
+  auto copy_w = [&](int row0, int nrows) {   // rows of the packed image [chunk][k half][tap] -> wL, MB units each
+    for (int u = tid; u < nrows * MB; u += 256) {
+      const int r = u / MB, m = u - r * MB;
+      const bool ok = d.m_off + m0 + m < d.Mpad;
+      const uint4 v = a.wb[ok ? (size_t)(row0 + r) * d.Mpad + d.m_off + m0 + m : 0];
+      wL[u] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto load_b = [&](int ch, uint4 (&B)[T]) {
+    const bool second = ch >= nch1;
+    const int cb = second ? (ch - nch1) * 2 : ch * 2;
+    const int C8 = (second ? d.C2 : d.C1) >> 3;
+    const uint4* __restrict__ xs = (second ? a.x2 : a.x1) + (size_t)(n * C8 + cb + h) * HW;
+#pragma unroll
+    for (int t = 0; t < T; ++t) B[t] = xs[toff[t] >= 0 ? toff[t] : 0];
+  };
+  auto mma = [&](const uint4* wrow, uint4 (&B)[T]) {   // wrow: this lane's k-half of the chunk, + t * MB + mt * 32 + j
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      BkUnit bv;
+      bv.u = toff[t] >= 0 ? (PRO != 0 ? bk_elu8(B[t]) : B[t]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        BkUnit av;
+        av.u = wrow[t * MB + mt * 32 + j];
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.b, bv.b, acc[mt], 0, 0, 0);
+      }
+    }
+  };
+
+  if (T == 1) {
+    uint4 B0[T], B1[T];
+    if (active) load_b(0, B0);
+    copy_w(0, nch * 2);
+    __syncthreads();
+    if (active) {
+      for (int ch = 0; ch < nch; ch += 2) {
+        const bool more = ch + 1 < nch;
+        if (more) load_b(ch + 1, B1);
+        mma(wL + (ch * 2 + h) * MB, B0);
+        if (more) {
+          if (ch + 2 < nch) load_b(ch + 2, B0);
+          mma(wL + ((ch + 1) * 2 + h) * MB, B1);
+        }
+      }
+    }
+  } else {
+    uint4 B0[T];
+    for (int ch = 0; ch < nch; ++ch) {
+      if (active) load_b(ch, B0);
+      __syncthreads();   // the previous chunk's fragment reads are done
+      copy_w(ch * 2 * T, 2 * T);
+      __syncthreads();
+      if (active) mma(wL + h * T * MB, B0);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bk_store_tile(a, n, oh, ow, valid, m0 + mt * 32, h, acc[mt]);
+  }
+}
+
 // ---- converters and the first layer
 __global__ void nchw_to_blk_kernel(const float* __restrict__ x, uint4* __restrict__ y, int C8, int HW, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one unit: (n, c8, pixel)
@@ -640,6 +740,22 @@ extern "C" int vunet_conv2d_blk(const vunet_conv_desc* d, const void* x1, const 
     else if (MT == 1) { if (pro) BLK_DIRECT(1, T_, 1, 1); else BLK_DIRECT(1, T_, 0, 1); } \
     else { if (pro) BLK_DIRECT(2, T_, 1, 1); else BLK_DIRECT(2, T_, 0, 1); }   \
   } while (0)
+  // weights through LDS (conv_blk_direct_lds_kernel) for the KS = 1 launches whose image fits; VUNET_TUNE_BLK_WS == 3 keeps
+  // the all-global form (A/B, tests)
+  const int nch = (d->C1 + d->C2) / 16, MBd = 32 * MTd;
+  const size_t wlds = (size_t)(d->KH == 1 ? nch * 2 : 18) * MBd * sizeof(uint4);
+  if (!ksplit && wlds <= 64 * 1024 && g_vunet_tune[VUNET_TUNE_BLK_WS] != 3) {
+#define BLK_DLDS(MT_, T_, PRO_) VUNET_LAUNCH((conv_blk_direct_lds_kernel<MT_, T_, PRO_>), dim3(blocks), dim3(256), wlds, st, a)
+    if (d->KH == 1) {
+      if (MT == 1) { if (pro) BLK_DLDS(1, 1, 1); else BLK_DLDS(1, 1, 0); }
+      else { if (pro) BLK_DLDS(2, 1, 1); else BLK_DLDS(2, 1, 0); }
+    } else {
+      if (MT == 1) { if (pro) BLK_DLDS(1, 9, 1); else BLK_DLDS(1, 9, 0); }
+      else { if (pro) BLK_DLDS(2, 9, 1); else BLK_DLDS(2, 9, 0); }
+    }
+#undef BLK_DLDS
+    return vunet_check_launch();
+  }
   if (d->KH == 1) BLK_DIRECT_T(1);
   else BLK_DIRECT_T(9);
 #undef BLK_DIRECT_T

@@ -359,7 +359,8 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *   VUNET_TUNE_FORCE_SMALL     1: vunet_conv2d_x6 takes the small-map K-split kernel wherever it covers the geometry
  *   VUNET_TUNE_BLK_FORCE_NT    tile height (rows per wave: 1 or 2) of the LDS-tiled blocked-bf16 kernel (vunet_conv2d_blk)
  *   VUNET_TUNE_BLK_WS          the LDS-tiled blocked-bf16 kernel: 1 = always its uniform form (every wave stages and multiplies),
- *                              2 = always the wave-specialised form (four staging + four matrix waves); 0 = by layer width
+ *                              2 = always the wave-specialised form (four staging + four matrix waves); 0 = by layer width;
+ *                              3 = the direct kernel with its weights from global memory instead of through LDS
  *   VUNET_TUNE_S2_FWD_F32      1: the stride-2 forward layers on the fp32-input MFMA kernel instead of the fp16 scheme's
  *                              parity-plane kernel (A/B timing, tests)
  *   VUNET_TUNE_WGRAD_ROWSPLIT  the direct weight-gradient kernel's kernel-row split (one kernel row per wave): 1 = never, 2 = also

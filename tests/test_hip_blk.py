@@ -104,6 +104,16 @@ def test_conv2d_blk_matches_bf16_operand_convolution(case):
             finally:
                 ops.set_tuning("blk_ws", 0)
             assert torch.equal(y2, y)
+    else:
+        # the direct kernel reads its weights through LDS where the image fits (default) or from global memory (knob 3)
+        y2 = torch.full_like(y, float("nan")) if nchw else torch.empty_like(y)
+        ops.set_tuning("blk_ws", 3)
+        try:
+            ops._call("vunet_conv2d_blk", ctypes.byref(d), ops._p(b1), ops._p(b2), ops._p(wb), ops._p(shift), ops._p(br),
+                      ops._p(y2), int(nchw), ops._stream())
+        finally:
+            ops.set_tuning("blk_ws", 0)
+        assert torch.equal(y2, y)
 
     x = x1 if x2 is None else torch.cat([x1, x2], 1)
     if elu:

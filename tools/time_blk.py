@@ -21,6 +21,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--frames", type=int, default=25)
 ap.add_argument("--uniform", action="store_true", help="the uniform form of the tiled kernel everywhere (blk_ws = 1)")
 ap.add_argument("--ws", action="store_true", help="the wave-specialised form everywhere (blk_ws = 2)")
+ap.add_argument("--global-weights", action="store_true", help="the direct kernel with weights from global memory (blk_ws = 3)")
 ap.add_argument("--tiled-only", action="store_true", help="only the layers the LDS-tiled kernel runs (A/B builds)")
 a = ap.parse_args()
 N = a.frames
@@ -60,7 +61,7 @@ def run(layer, nt):
                      mode=0, in_act=ops.ACT_ELU if elu else ops.ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0,
                      out_act=ops.ACT_NONE, d2s=d2s)
     ops.set_tuning("blk_force_nt", nt)
-    ops.set_tuning("blk_ws", 1 if a.uniform else (2 if a.ws else 0))
+    ops.set_tuning("blk_ws", 1 if a.uniform else (2 if a.ws else (3 if a.global_weights else 0)))
 
     def call():
         ops._call("vunet_conv2d_blk", ctypes.byref(d), ops._p(x1), ops._p(x2), ops._p(wb), ops._p(shift), ops._p(r), ops._p(y),
