@@ -201,8 +201,14 @@ bool vunet_conv_h2_s2_ok(const vunet_conv_desc* d, int pro) {
          (long)d->N * (d->Ho / 4) * (d->Wo / 32) * (d->M / 32) >= 64;   // (smaller launches: the fp32 / small-map kernels)
 }
 
+// two m-tiles per workgroup where that still leaves two workgroups per CU; else one (twice the workgroups, the input tile
+// staged by both: the 128 -> 128 layer at 64 -> 32 has 256 workgroups with two m-tiles)
+static int s2_mt(const vunet_conv_desc* d) {
+  return (d->M % 64 == 0 && (long)d->N * (d->Ho / 4) * (d->Wo / 32) * (d->M / 64) >= 512) ? 2 : 1;
+}
+
 int vunet_conv_h2_s2_name(const vunet_conv_desc* d, char* name, int len) {
-  return snprintf(name, len, "conv_h2_s2_kernel<%d>", d->M % 64 == 0 ? 2 : 1);
+  return snprintf(name, len, "conv_h2_s2_kernel<%d>", s2_mt(d));
 }
 
 int vunet_conv_h2_s2_launch(const GatherArgs& ga_in, const void* wx, int mtiles_pad, const float* amax, hipStream_t st) {
@@ -210,7 +216,7 @@ int vunet_conv_h2_s2_launch(const GatherArgs& ga_in, const void* wx, int mtiles_
   const vunet_conv_desc& d = ga.d;
   const uintptr_t al = reinterpret_cast<uintptr_t>(ga.y) | reinterpret_cast<uintptr_t>(ga.res);
   ga.wide = (al & 15) == 0 && d.Wo % 4 == 0;   // (fill_args ties `wide` to stride 1: the OUTPUT map is what the stores walk)
-  const int MT = d.M % 64 == 0 ? 2 : 1;
+  const int MT = s2_mt(&d);
   const int blocks = d.N * (d.Ho / 4) * (d.Wo / 32) * (d.M / (32 * MT));
   const size_t lds = (size_t)(2 * 2 * 4 * 5 * 33 + 3 * MT * H2_SLAB) * 16;
   if (MT == 2) {
