@@ -11,6 +11,7 @@ gamma controller.  There is no CPU fallback: CPU tensors raise.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from dataclasses import dataclass
@@ -378,6 +379,7 @@ def pack_weights(v, g, bias, gamma, beta, c1: int, c2: int, kind: int, need_dgra
 # optional per-launch timing of the conv kernel families (bench.py roofline): HIP events on the launch stream
 # ------------------------------------------------------------------------------------------------
 _prof = {"on": False, "recs": []}
+_NO_TIMER = contextlib.nullcontext()   # (the timer's key tuple -- a dozen ctypes field reads -- is built only when profiling)
 
 
 def profile_start():
@@ -445,8 +447,8 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=N
         buf = ctypes.create_string_buffer(96)
         _call("vunet_conv2d_variant", ctypes.byref(desc), 0 if aux is None else 1, 0 if wx is None else scheme, 0, buf, 96)
         kname = buf.value.decode()
-    with _Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act, kname),
-                flop):
+    with (_Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act, kname),
+                flop) if _prof["on"] else _NO_TIMER):
         _call("vunet_conv2d", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), _p(aux), _p(y),
               _p(amax), _p(amax_out), _stream())
     if amax_out is not None:
@@ -620,6 +622,21 @@ def enable_wgrad_streams(on: bool = True):
     nodes).  Only layers whose parameter gradients are written in place into flat buckets take part; the caller
     must call ``join_wgrad_streams()`` after ``backward()`` and before reading those gradients."""
     _wgrad_streams["on"] = bool(on)
+
+
+_stream_objs = {}
+
+
+def _current_stream_obj():
+    """torch.cuda.current_stream() builds a Stream object per call (2.7 us); the objects are cached by raw handle."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream()
+    idx = torch.cuda.current_device()
+    key = (idx, _raw_stream(idx))
+    st = _stream_objs.get(key)
+    if st is None:
+        st = _stream_objs[key] = torch.cuda.current_stream()
+    return st
 
 
 def _wgrad_stream_for(cur):
@@ -923,8 +940,8 @@ class FusedConv(torch.autograd.Function):
             # render path (models/vunets.py:508-515 under no_grad): bf16 operands, fp32 accumulate
             wb = torch.empty((c1 + c2) * 9 * wt_f.shape[1], device=x1.device, dtype=torch.bfloat16)
             _call("vunet_pack_bf16", _p(wt_f), _p(wb), c1, c2, wt_f.shape[1], _stream())
-            with _Timed(("conv_bf16_fwd", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, "conv_bf16_kernel"),
-                        2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
+            with (_Timed(("conv_bf16_fwd", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, "conv_bf16_kernel"),
+                        2.0 * n * ho * wo * cout * (c1 + c2) * k * k) if _prof["on"] else _NO_TIMER):
                 _call("vunet_conv2d_bf16", ctypes.byref(d), _p(x1), _p(x2), _p(wb), _p(shift), _p(res), _p(y), _stream())
         else:
             ctx.amax_x = _conv_gather(d, x1, x2, wt_f, shift, res, None, y, wx_f)   # reused by the weight gradient
@@ -992,8 +1009,8 @@ class FusedConv(torch.autograd.Function):
                 kname = buf.value.decode()
                 if kname.startswith("conv_tiled"):
                     kname = kname.replace(", 1, 0, ", ", 1, 4, ")
-            with _Timed(("conv_gather_dgrad", n, cout, 0, ho, wo, c1, k, cfg.stride, 0, kname),
-                        2.0 * n * ho * wo * cout * c1 * k * k):
+            with (_Timed(("conv_gather_dgrad", n, cout, 0, ho, wo, c1, k, cfg.stride, 0, kname),
+                        2.0 * n * ho * wo * cout * c1 * k * k) if _prof["on"] else _NO_TIMER):
                 rc = -3
                 if wx_d is not None and _wants_split(d, False, cfg.res_is_x1, True):
                     amax = _amax_for(dy) if _scheme() == 2 else None
@@ -1056,8 +1073,8 @@ class FusedConv(torch.autograd.Function):
                 buf = ctypes.create_string_buffer(96)
                 _call("vunet_conv2d_wgrad_variant", ctypes.byref(wd), buf, 96)
                 kname = buf.value.decode()
-            with _Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, kname),
-                        2.0 * n * ho * wo * cout * (c1 + c2) * k * k):
+            with (_Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, kname),
+                        2.0 * n * ho * wo * cout * (c1 + c2) * k * k) if _prof["on"] else _NO_TIMER):
                 _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
                       _p(wg_amax[0]), _p(wg_amax[1]), _stream())
             ni = ctx.needs_input_grad
@@ -1112,14 +1129,20 @@ class FusedConv(torch.autograd.Function):
                 # weight gradients are off the critical path of backward (only the data gradient feeds the next
                 # layer): run wgrad + slab reduce + weight-norm backward on a companion stream; the results land in
                 # the flat gradient buckets, ordered before the optimiser by ops.join_wgrad_streams()
-                cur = torch.cuda.current_stream()
+                cur = _current_stream_obj()
                 wstream = _wgrad_stream_for(cur)
                 wstream.wait_stream(cur)
-                for t_ in (x1, x2, dconv, v, g, bias, gamma, invnorm, wg_amax[0], wg_amax[1]):
+                # tensors the caching allocator may hand out again before the companion stream has read them: the
+                # activations and dy (freed as backward moves on), the |x| maxima if they are not arena slices, invnorm if
+                # it is not part of the model's persistent pack set (the parameters themselves outlive the step)
+                for t_ in (x1, x2, dconv, wg_amax[0], wg_amax[1], None if ctx.prepacked else invnorm):
                     if t_ is not None:
                         t_.record_stream(wstream)
-                with torch.cuda.stream(wstream):
+                torch.cuda.set_stream(wstream)   # (the context-manager form costs 6 us per layer, this pair 0.8)
+                try:
                     weight_gradients(defer_ok)
+                finally:
+                    torch.cuda.set_stream(cur)
             else:
                 dv, dg, dbias, dgamma, dbeta = weight_gradients(defer_ok)
         dx1 = dx2 = None

@@ -118,9 +118,9 @@ class BlockedTransfer:
                      stride=L.stride, pad=L.pad, mode=0, in_act=in_act, in_slope=0.0, drop_p=0.0, drop_seed=0,
                      out_act=ACT_NONE, d2s=int(d2s))
         tiled = _lib.lib().vunet_conv2d_blk_tiled(ctypes.byref(d)) == 1
-        with ops._Timed(("conv_blk_fwd", n, c1, c2, hs, ws, L.cout, L.k, L.stride, int(res is not None), int(out_nchw),
-                         "conv_blk_tiled_kernel" if tiled else "conv_blk_direct_kernel"),
-                        2.0 * n * ho * wo * L.cout * (c1 + c2) * L.k * L.k):
+        with (ops._Timed(("conv_blk_fwd", n, c1, c2, hs, ws, L.cout, L.k, L.stride, int(res is not None), int(out_nchw),
+                          "conv_blk_tiled_kernel" if tiled else "conv_blk_direct_kernel"),
+                         2.0 * n * ho * wo * L.cout * (c1 + c2) * L.k * L.k) if ops._prof["on"] else ops._NO_TIMER):
             _call("vunet_conv2d_blk", ctypes.byref(d), _p(x1), _p(x2), _p(L.wb), _p(L.shift), _p(res), _p(y),
                   int(out_nchw), _stream())
         return y
