@@ -905,10 +905,11 @@ class FusedConv(torch.autograd.Function):
         frozen = not any(t is not None and t.requires_grad for t in (v, g, bias, gamma, beta))
         # frozen feature extractor (VGG19): pack once, reuse for every pass.  The packed buffers hang off the weight
         # tensor itself (they die with it) and are stamped with every operand's storage address and version counter.
-        sub = (c1, c2, cfg.kind, bool(need_x), _scheme())
-        stamp = tuple(None if t is None else (t.data_ptr(), t._version) for t in (v, g, bias, gamma, beta))
-        hit = getattr(v, "_vunet_frozen_pack", {}).get(sub) if frozen else None
-        pre = None
+        sub = stamp = hit = pre = None
+        if frozen:
+            sub = (c1, c2, cfg.kind, bool(need_x), _scheme())
+            stamp = tuple(None if t is None else (t.data_ptr(), t._version) for t in (v, g, bias, gamma, beta))
+            hit = getattr(v, "_vunet_frozen_pack", {}).get(sub)
         if cfg.owner is not None and not frozen:
             old = cfg.owner.__dict__.get("_last_split")
             new = (c1, c2, bool(need_x) or (old is not None and old[2]))
