@@ -166,6 +166,40 @@ extern "C" int vunet_l1_mean_fwd(const float* a, const float* b, float* partial,
                      weight / (float)n);
   return vunet_check_launch();
 }
+// L1 tap + the 2x2 max-pool of the same tensor, forward in ONE pass: partial sums of |a - b| (as l1_partial_kernel) and
+// y = maxpool2(b); one thread per pool window (b is read once instead of by two kernels)
+__global__ __launch_bounds__(256) void l1_pool_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ partial, float* __restrict__ y, int H, int W,
+                                                          int64_t n) {
+  __shared__ float red[4];
+  const int Ho = H >> 1, Wo = W >> 1;
+  float s = 0.f;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(o % Wo);
+    const int64_t t = o / Wo;
+    const int oh = (int)(t % Ho);
+    const int64_t nc = t / Ho;
+    const int64_t i0 = (nc * H + 2 * oh) * W + 2 * ow;
+    const float2 b0 = *reinterpret_cast<const float2*>(b + i0), b1 = *reinterpret_cast<const float2*>(b + i0 + W);
+    const float2 a0 = *reinterpret_cast<const float2*>(a + i0), a1 = *reinterpret_cast<const float2*>(a + i0 + W);
+    s += (fabsf(a0.x - b0.x) + fabsf(a0.y - b0.y)) + (fabsf(a1.x - b1.x) + fabsf(a1.y - b1.y));
+    y[o] = fmaxf(fmaxf(b0.x, b0.y), fmaxf(b1.x, b1.y));
+  }
+  const float tsum = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tsum;
+}
+extern "C" int vunet_l1_pool_fwd(const float* a, const float* b, float* partial, float* out, float* y, float weight,
+                                 int32_t NC, int32_t H, int32_t W, void* st) {
+  if (!a || !b || !partial || !out || !y || (H & 1) || (W & 1)) return VUNET_ERR_ARG;
+  const int64_t n = (int64_t)NC * (H / 2) * (W / 2);
+  int64_t nb = (n + 1023) / 1024;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  VUNET_LAUNCH(l1_pool_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)st, a, b, partial, y, H, W, n);
+  VUNET_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, partial, (int)nb, out,
+               weight / (float)(4 * n));
+  return vunet_check_launch();
+}
 __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ add,
                               float* __restrict__ db, float gs, const float* __restrict__ gout, int64_t n,
                               float* __restrict__ amax_out, int relu_mask) {

@@ -1371,9 +1371,8 @@ class L1ThroughPool(torch.autograd.Function):
         n, c, h, w = pred.shape
         out = torch.zeros(1, device=pred.device, dtype=torch.float32)
         partial = torch.empty(1024, device=pred.device, dtype=torch.float32)
-        _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
         y = torch.empty(n, c, h // 2, w // 2, device=pred.device, dtype=pred.dtype)
-        _call("vunet_maxpool2_fwd", _p(pred), _p(y), n * c, h, w, _stream())
+        _call("vunet_l1_pool_fwd", _p(target), _p(pred), _p(partial), _p(out), _p(y), float(weight), n * c, h, w, _stream())
         tag = _tagged_amax(pred)
         if tag is not None:
             _tag_amax(y, tag)   # |max-pool(x)| <= max|x|

@@ -320,6 +320,10 @@ int vunet_maxpool2_fwd(const float* x, float* y, int32_t NC, int32_t H, int32_t 
  * (models/imagenet_pretrained.py: relu1_2 / relu2_2 feed a loss term AND the next pool):
  *   db = route(dy_pool) + gscale * gout[0] * sign(b - a)   (dy_pool [NC, H/2, W/2] or NULL; routing as vunet_maxpool2_bwd),
  * zeroed where b <= 0 if relu_mask, |db| maxima to amax_out (optional) -- as vunet_l1_mean_bwd_amax */
+/* forward of the same pair in one pass: out[0] += weight * mean|a - b| (partial: >= 1024 floats of workspace) and
+ * y = maxpool2(b) [NC, H/2, W/2] */
+int vunet_l1_pool_fwd(const float* a, const float* b, float* partial, float* out, float* y, float weight, int32_t NC,
+                      int32_t H, int32_t W, void* stream);
 int vunet_l1_pool_bwd(const float* a, const float* b, const float* dy_pool, float* db, float gscale, const float* gout,
                       int32_t NC, int32_t H, int32_t W, float* amax_out, int32_t relu_mask, void* stream);
 /* (vunet_maxpool2_bwd_relu: x is a ReLU output -- dx additionally zeroed where x <= 0, as for vunet_l1_mean_bwd_amax) */

@@ -471,3 +471,25 @@ def test_l1_tap_and_pool_backward_in_one_pass():
               None, 0, ops._stream())
     nz = (pred != target).cpu()       # (sign(0) is 0 here and in ATen alike; ties of the max go to the first element in both)
     assert torch.allclose(got.cpu()[nz], p_.grad[nz], rtol=1e-6, atol=1e-7)
+
+
+def test_l1_tap_and_pool_forward_in_one_pass():
+    """vunet_l1_pool_fwd == vunet_l1_mean_fwd + vunet_maxpool2_fwd (the pooled tensor bit for bit, the loss to the rounding of
+    a different summation order)."""
+    from behavior_driven_video_synthesis_amd import ops
+    g = torch.Generator().manual_seed(22)
+    n, c, h, w = 3, 7, 20, 14
+    pred = torch.randn(n, c, h, w, generator=g).cuda()
+    target = torch.randn(n, c, h, w, generator=g).cuda()
+    partial = torch.empty(1024, device="cuda")
+    want_l = torch.zeros(1, device="cuda")
+    ops._call("vunet_l1_mean_fwd", ops._p(target), ops._p(pred), ops._p(partial), ops._p(want_l), 1.5, pred.numel(), ops._stream())
+    want_y = torch.empty(n, c, h // 2, w // 2, device="cuda")
+    ops._call("vunet_maxpool2_fwd", ops._p(pred), ops._p(want_y), n * c, h, w, ops._stream())
+    got_l = torch.zeros(1, device="cuda")
+    got_y = torch.full_like(want_y, float("nan"))
+    ops._call("vunet_l1_pool_fwd", ops._p(target), ops._p(pred), ops._p(partial), ops._p(got_l), ops._p(got_y), 1.5, n * c, h, w,
+              ops._stream())
+    assert torch.equal(got_y, want_y)
+    assert abs(float(got_l) - float(want_l)) <= 2e-6 * abs(float(want_l))
+    assert abs(float(got_l) - 1.5 * float((target - pred).abs().double().mean())) <= 2e-6 * abs(float(want_l))
