@@ -192,13 +192,15 @@ __device__ __forceinline__ void quad_transpose(float& r0, float& r1, float& r2, 
   r3 = hi ? r3 : u1;
 }
 
+__device__ __forceinline__ float plain_out(float t, bool relu) { return (relu && !(t > 0.f)) ? 0.f : t; }
+
 struct TileSide4 {
   float4 aux[4], res[4];
   float sh[4];
 };
 
 // g: the pixel of THIS lane (as for store_tile_side); the group's four pixels start at g.ow - (lane & 3)
-template <int MODE>
+template <int MODE, int FORM = 0>   // FORM: see store_tile_side4 (1: there is no aux tensor)
 __device__ __forceinline__ void load_tile_side4(const GatherArgs& a, const PixGeo& g, int m_tile0, int h, int k, TileSide4& s) {
   const vunet_conv_desc& d = a.d;
   const size_t pix0 = (size_t)g.oh * d.Wo + (g.ow - k);
@@ -207,18 +209,72 @@ __device__ __forceinline__ void load_tile_side4(const GatherArgs& a, const PixGe
     const int ch = m_tile0 + 8 * q4 + 4 * h + k;
     const bool ok = ch < d.M;
     const size_t o = ok ? (size_t)(g.n * d.M + ch) * a.HoWo + pix0 : 0;
-    if (MODE == 1 && a.aux) s.aux[q4] = *reinterpret_cast<const float4*>(a.aux + o);
+    if (MODE == 1 && FORM != 1 && a.aux) s.aux[q4] = *reinterpret_cast<const float4*>(a.aux + o);
     if (a.res) s.res[q4] = *reinterpret_cast<const float4*>(a.res + o);
     if (MODE == 0 && a.shift) s.sh[q4] = a.shift[ok ? ch : 0];
   }
 }
 
+// FORM: the caller picks it once for all its tiles with side4_form() (a wave-uniform branch around the whole epilogue):
+//   0 general; 1 forward with no / ReLU output activation, data gradient without an activation derivative;
+//   2 data gradient * ELU'(aux); 3 the same with the dropout mask of the forward pass
 template <int MODE>
+__device__ __forceinline__ int side4_form(const GatherArgs& a) {
+#ifdef H2_EPI_GENERIC   // (A/B baseline for tools/ab_build.sh: always the general form)
+  return 0;
+#endif
+  if (MODE == 0) return (a.d.out_act == ACT_NONE || a.d.out_act == ACT_RELU) ? 1 : 0;
+  if (a.aux == nullptr) return 1;
+  if (a.auxa.act == ACT_ELU) return a.auxa.thresh ? 3 : 2;
+  return 0;
+}
+template <int MODE, int FORM = 0>
 __device__ __forceinline__ float store_tile_side4(const GatherArgs& a, const PixGeo& g, int m_tile0, int h, int k, f32x16 acc,
                                                   const TileSide4& s) {   // -> max |stored value| of this lane
   float vmax = 0.f;
   const vunet_conv_desc& d = a.d;
   const size_t pix0 = (size_t)g.oh * d.Wo + (g.ow - k);
+  // The common cases as straight-line code (r03, tools/h2_timeline.py: the general form below spends 7 - 8 us per workgroup
+  // tile in per-element scalar branches on the activation code -- as long as 1.5 K-chunks of the matrix loop):
+  //   forward with no / ReLU output activation (every NormConv2d of the VUnet, every VGG19 layer); data gradient without
+  //   an activation derivative (the layers whose input is not pre-activated, and the ReLU-masked VGG19 chain).
+  if constexpr (FORM != 0) {
+    const bool relu = MODE == 0 && d.out_act == ACT_RELU;
+    const bool has_sh = MODE == 0 && a.shift != nullptr, has_res = a.res != nullptr;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      float v[4] = {acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+#ifndef H2_ABL_EPI_NOTRANSPOSE
+      quad_transpose(v[0], v[1], v[2], v[3], k);
+#endif
+      const int ch = m_tile0 + 8 * q4 + 4 * h + k;
+      const size_t o = (size_t)(g.n * d.M + ch) * a.HoWo + pix0;
+      const float4 rs = has_res ? s.res[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float resv[4] = {rs.x, rs.y, rs.z, rs.w};
+      if constexpr (FORM == 1) {
+        const float sh = has_sh ? s.sh[q4] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = plain_out(v[e] + sh, relu) + resv[e];
+      } else {
+        const float auxv[4] = {s.aux[q4].x, s.aux[q4].y, s.aux[q4].z, s.aux[q4].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float gr = elu_grad_f(auxv[e]);
+          if constexpr (FORM == 3)   // (a.auxa was resolved at kernel entry: the seed is a register)
+            gr = (vunet_hash_u32((uint32_t)(o + e) + a.auxa.seed) >= a.auxa.thresh) ? gr * a.auxa.keep_scale : 0.f;
+          v[e] = v[e] * gr + resv[e];
+        }
+      }
+      if (ch < d.M) {
+#ifdef H2_ABL_EPI_NOSTORE
+        if (v[0] == 12345.f)
+#endif
+        *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
+    }
+    return vmax;
+  }
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
     float v[4] = {acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};

@@ -75,6 +75,21 @@ static inline bool h2_launch_allowed() {
   return ok;
 }
 
+// (diagnostic, tools/ab_build.sh -DH2_TSTAMP=<export name>: wave 0 of every workgroup records the 100 MHz wall clock at its
+// phase boundaries; tools/h2_timeline.py reads them back through the exported function.  Results are unchanged.)
+#ifdef H2_TSTAMP
+static __device__ unsigned long long h2_ts[8192 * 8];
+#define H2_STAMP(k_)                                                                                              \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) h2_ts[blockIdx.x * 8 + (k_)] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+extern "C" int H2_TSTAMP(unsigned long long* out, int nblocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(h2_ts), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
+}
+#else
+#define H2_STAMP(k_)
+#endif
+
 // MODE 0 forward, 1 data gradient (taps mirrored).  PRO 0 none, 1 ELU, 2 ELU + dropout, 4 ReLU mask (MODE 1).
 // PHW >= 0 (MODE 1 only): data gradient of the STRIDE-2 convolution (Downsample, lib/modules.py:152-158) for the output
 // parity (ph, pw) = (PHW >> 1, PHW & 1): dx[2a+ph][2b+pw] = sum over the taps kh = ph+1 (mod 2), kw = pw+1 (mod 2) of
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
                                                                              const uint4* __restrict__ wx, int mtiles_pad,
                                                                              const float* __restrict__ amax) {
   GatherArgs a = a_in;
+  H2_STAMP(0);
   inact_resolve(a.in1);
   inact_resolve(a.in2);
   inact_resolve(a.auxa);
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     sx = h2_pow2(ex);
     h2_pow2_pair(-(ex + ew), descale, descale2);
   }
+  H2_STAMP(1);
 
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
@@ -302,6 +319,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   }
   h2_dma_wait();
   __syncthreads();
+  H2_STAMP(2);
 
   const uint4* const xB0 = xL + h * PIX + (wave * NT * RPQ + jr) * IW + jc;  // + buffer*4*PIX + plane*2*PIX + (q*RPQ + dr)*IW + dc
   const uint4* const wA = wL + h * 32 + j;                       // + buf*WUS + g*WU + ((mt*3 + kw)*2 + plane)*64
@@ -425,8 +443,14 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
       }
     }
   };
-  for (int ch = 0; ch + 1 < nch; ++ch) chunk(ch, std::false_type{});
+  for (int ch = 0; ch + 1 < nch; ++ch) {
+    chunk(ch, std::false_type{});
+#ifdef H2_TSTAMP
+    if (ch == 0) H2_STAMP(6);
+#endif
+  }
   chunk(nch - 1, std::true_type{});
+  H2_STAMP(3);
 
   // What the output store costs (r02, tools/time_conv.py with -DH2_ABL_NOSTORE): without it every layer runs at ~305
   // TFLOP/s whatever its K; with 4-byte stores (lane = pixel, one store instruction per accumulator register) the
@@ -439,6 +463,16 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   // the epilogue; 512-thread workgroups with whole-chunk weight stages; starting the first round of workgroups in eight
   // phases spread over a tile period; non-temporal stores; s_setprio 1 around every tap's MFMA cluster (-DH2_SETPRIO, r03:
   // within +-3 % on every layer shape of tools/time_conv.py).
+  // r03, tools/h2_timeline.py (wall-clock stamps per workgroup): a tile of the 64 x 8 form spends 2.5 us reducing the maxima
+  // behind its first loads, ~1 us converting them, 5.3 - 5.6 us per 16-channel chunk and 7 - 8 us in the epilogue below --
+  // VALU-bound on per-element scalar branches over the activation code, not on the stores (removing the stores or the
+  // lane transposes changed nothing).  Straight-line forms of the common cases (store_tile_side4's FORM) took it to ~5 us:
+  // 64-channel layers -5 %, the others -1 .. 3 %.  A tile-WALKING form (one workgroup per residency slot, the next tile's
+  // first chunk staged behind this tile's last; bit-identical) was built for the 32-channel layers, whose tiles wait 4.5 of
+  // their 11.5 us for the first loads -- and ran 20 - 30 % SLOWER (105 -> 126 - 140 us): every chunk then stages, and a
+  // staging chunk takes 5.4 us against 1.4 for one that does not; requesting all of a chunk's rounds at its start instead
+  // of one per kernel row did not change either form.  These layers move 268 - 400 MB at 2.7 - 2.8 TB/s whatever the
+  // schedule.  Removed.
   // ---- epilogue (arithmetic shared with the fp32 kernels): lane j = pixel (row0 + wave*NT + q, col0 + j).  The MT * NT
   // tiles are named at compile time (a runtime index would put the accumulators in scratch) and software-pipelined: the
   // residual / aux / shift loads of tile t+1 are issued before the stores of tile t (conv_common.h: load_tile_side).
@@ -494,30 +528,45 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   if (PHW < 0 && a.wide) {   // 16-byte epilogue: four lanes transpose their 4 pixels x 4 channels blocks (conv_common.h)
     const int k = lane & 3;
     TileSide4 side[2];
-    load_tile_side4<MODE>(a, geo(0), m0, h, k, side[0]);
-    auto tile = [&](auto tc) {
-      constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT;
+    auto tile = [&](auto tc, auto form_c) {
+      constexpr int t = decltype(tc)::value, q = t / MT, mt = t % MT, FORM = decltype(form_c)::value;
+      if constexpr (t == 0) load_tile_side4<MODE, FORM>(a, geo(0), m0, h, k, side[0]);
       if constexpr (t + 1 < MT * NT)
-        load_tile_side4<MODE>(a, geo((t + 1) / MT), m0 + 32 * ((t + 1) % MT), h, k, side[(t + 1) & 1]);
+        load_tile_side4<MODE, FORM>(a, geo((t + 1) / MT), m0 + 32 * ((t + 1) % MT), h, k, side[(t + 1) & 1]);
 #ifdef H2_ABL_NOSTORE   // timing ablation (tools/ab_build.sh): the output is not written
       if (descale == 12345.f)
 #endif
-      ymax = fmaxf(ymax, store_tile_side4<MODE>(a, geo(q), m0 + 32 * mt, h, k, combined(tc), side[t & 1]));
+      ymax = fmaxf(ymax, store_tile_side4<MODE, FORM>(a, geo(q), m0 + 32 * mt, h, k, combined(tc), side[t & 1]));
     };
-    tile(std::integral_constant<int, 0>{});
-    if constexpr (MT * NT > 1) tile(std::integral_constant<int, 1>{});
-    if constexpr (MT * NT > 2) {
-      tile(std::integral_constant<int, 2>{});
-      tile(std::integral_constant<int, 3>{});
-    }
-    if constexpr (MT * NT > 4) {
-      tile(std::integral_constant<int, 4>{});
-      tile(std::integral_constant<int, 5>{});
-      tile(std::integral_constant<int, 6>{});
-      tile(std::integral_constant<int, 7>{});
-    }
+    auto tiles = [&](auto form_c) {
+      tile(std::integral_constant<int, 0>{}, form_c);
+      if constexpr (MT * NT > 1) tile(std::integral_constant<int, 1>{}, form_c);
+      if constexpr (MT * NT > 2) {
+        tile(std::integral_constant<int, 2>{}, form_c);
+        tile(std::integral_constant<int, 3>{}, form_c);
+      }
+      if constexpr (MT * NT > 4) {
+        tile(std::integral_constant<int, 4>{}, form_c);
+        tile(std::integral_constant<int, 5>{}, form_c);
+        tile(std::integral_constant<int, 6>{}, form_c);
+        tile(std::integral_constant<int, 7>{}, form_c);
+      }
+    };
+    // ONE wave-uniform branch around the whole epilogue: the common cases run straight-line code (conv_common.h:
+    // store_tile_side4's FORM).  The side loads of the first tile sit behind the branch -- issued before it, their
+    // registers were live across all four forms and the data-gradient kernels spilled 264 bytes in the epilogue.
+    const int form = side4_form<MODE>(a);
+    if (form == 1) tiles(std::integral_constant<int, 1>{});
+    else if (MODE == 1 && form == 2) tiles(std::integral_constant<int, MODE == 1 ? 2 : 0>{});
+    else if (MODE == 1 && form == 3) tiles(std::integral_constant<int, MODE == 1 ? 3 : 0>{});
+    else tiles(std::integral_constant<int, 0>{});
     static_assert(MT * NT <= 8, "epilogue tiles are named at compile time");
     publish();
+#ifdef H2_TSTAMP
+    H2_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    H2_STAMP(5);
+#endif
     return;
   }
   TileSide side[2];

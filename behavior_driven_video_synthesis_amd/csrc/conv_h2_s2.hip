@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2_s2_kernel(const GatherArgs a, 
     if (a.wide) {
       TileSide4 side;
       load_tile_side4<0>(a, g, m0 + 32 * mt, h, k4, side);
-      ymax = fmaxf(ymax, store_tile_side4<0>(a, g, m0 + 32 * mt, h, k4, c, side));
+      if (side4_form<0>(a) == 1) ymax = fmaxf(ymax, store_tile_side4<0, 1>(a, g, m0 + 32 * mt, h, k4, c, side));
+      else ymax = fmaxf(ymax, store_tile_side4<0>(a, g, m0 + 32 * mt, h, k4, c, side));
     } else {
       TileSide side;
       load_tile_side(a, g, m0 + 32 * mt, h, side);

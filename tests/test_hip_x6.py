@@ -200,6 +200,38 @@ def test_x6_data_gradient_vs_fp64(cout, cin, h, w, nt, masked, scheme):
     assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * max(float(ref.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("cout,cin,h,w,nt", [(64, 64, 8, 32, 2), (64, 32, 4, 32, 1), (64, 64, 16, 16, 1)])
+def test_h2_data_gradient_with_the_forward_dropout_mask(cout, cin, h, w, nt):
+    """mode 1 with the layer's input dropout: dx = conv_transpose(dy, w_eff) * ELU'(aux) * keep(idx) / (1 - p) + res -- the
+    16-byte epilogue's straight-line form for it (conv_common.h: store_tile_side4, FORM 3) against fp64."""
+    ops = _ops()
+    ops.set_conv_precision("h2")
+    n, p_, seed = 2, 0.1, 77
+    g_ = torch.Generator().manual_seed(cout * 5 + cin)
+    v, g, bias, gamma, beta = _params(cout, cin, 9)
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, g, bias, gamma, beta, cin, 0, 0, True)
+    dy = torch.randn(n, cout, h, w, generator=g_).cuda()
+    aux = torch.randn(n, cin, h, w, generator=g_).cuda()
+    res = torch.randn(n, cin, h, w, generator=g_).cuda()
+    d = ops.ConvDesc(N=n, C1=cout, C2=0, Hs=h, Ws=w, M=cin, m_off=0, Mpad=wt_d.shape[1], Ho=h, Wo=w, KH=3, KW=3,
+                     stride=1, pad=1, mode=1, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
+                     aux_act=ops.ACT_ELU, aux_slope=0.0, aux_drop_p=p_, aux_drop_seed=seed)
+    dx = torch.empty(n, cin, h, w, device="cuda")
+    ops.set_tuning("split_force_nt", nt)
+    try:
+        ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(dy), None, ops._p(wx_d), None, ops._p(res), ops._p(aux), None,
+                  ops._p(dx), _amax(ops, dy), None, ops._stream())
+    finally:
+        ops.set_tuning("split_force_nt", 0)
+    wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
+    ref = F.conv_transpose2d(dy.double().cpu(), wd, padding=1)
+    a = aux.double().cpu()
+    keep = dropout_keep_mask((n, cin, h, w), p_, seed).double() * float(torch.tensor(1.0 / (1.0 - p_), dtype=torch.float32))
+    ref = ref * torch.where(a > 0, torch.ones_like(a), a.exp()) * keep + res.double().cpu()
+    assert float((dx.double().cpu() - ref).abs().max()) <= 3e-6 * max(float(ref.abs().max()), 1.0)
+    assert float((keep == 0).double().mean()) > 0.03   # the mask really dropped something
+
+
 def test_x6_second_source_gradient_uses_column_offset():
     """The data gradient of the second source of a two-source layer reads the weight image at m_off = C1."""
     ops = _ops()

@@ -32,7 +32,11 @@ SHAPES = [
     ("vgg conv2_2 dgrad+relu", 16, 128, 128, 128, 128, 1, 0, True),
     ("vunet rnb 64ch fwd elu", 16, 64, 64, 128, 128, 0, 1, False),
     ("vunet 32ch 256^2 fwd elu", 16, 32, 32, 256, 256, 0, 1, False),
+    ("vunet 32ch 256^2 dgrad", 16, 32, 32, 256, 256, 1, 0, False),
+    ("vunet 32ch 256^2 dgrad elu' drop", 16, 32, 32, 256, 256, 1, 0, "elu+drop"),
     ("vunet 128ch 64^2 dgrad", 16, 128, 128, 64, 64, 1, 0, False),
+    ("vunet 64ch 128^2 dgrad elu'", 16, 64, 64, 128, 128, 1, 0, "elu"),
+    ("vunet 64ch 128^2 dgrad elu' drop", 16, 64, 64, 128, 128, 1, 0, "elu+drop"),
     ("vgg conv4_x fwd", 16, 512, 512, 32, 32, 0, 0, False),
     ("vgg conv2_2 fwd, N = 32", 32, 128, 128, 128, 128, 0, 0, False),
     ("K = 4608, 64^2", 16, 512, 128, 64, 64, 0, 0, False),
@@ -43,7 +47,10 @@ for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(n, cin, h, w, generator=g).cuda()
     v = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    auxk = masked if isinstance(masked, str) else ""   # data gradient * ELU'(aux) (+ the forward pass's dropout mask)
+    masked = bool(masked) and not auxk
     m = torch.randn(n, cin, h, w, generator=g).cuda() if masked else None
+    aux = torch.randn(n, cin, h, w, generator=g).cuda() if auxk else None
     line = [f"{name:28s}"]
     for sch in args.modes.split(","):
         ops.set_conv_precision(sch)
@@ -52,7 +59,8 @@ for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
         y = torch.empty(n, mo, h, w, device="cuda")
         d = ops.ConvDesc(N=n, C1=cin if mode == 0 else cout, C2=0, Hs=h, Ws=w, M=mo, m_off=0,
                          Mpad=(wt_f if mode == 0 else wt_d).shape[1], Ho=h, Wo=w, KH=3, KW=3, stride=1, pad=1, mode=mode,
-                         in_act=in_act, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0)
+                         in_act=in_act, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
+                         aux_act=1 if auxk else 0, aux_slope=0.0, aux_drop_p=0.05 if "drop" in auxk else 0.0, aux_drop_seed=7)
         wx = wx_f if mode == 0 else wx_d
         amax = ops.absmax_partials(x) if sch == "h2" else None
 
@@ -61,7 +69,7 @@ for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
             continue
 
         def launch():
-            ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x), None, ops._p(wx), None, None, None, ops._p(m), ops._p(y),
+            ops._call("vunet_conv2d_x6", ctypes.byref(d), ops._p(x), None, ops._p(wx), None, None, ops._p(aux), ops._p(m), ops._p(y),
                       ops._p(amax), None, ops._stream())
         for _ in range(3):
             launch()
