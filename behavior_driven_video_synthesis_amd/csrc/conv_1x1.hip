@@ -13,6 +13,8 @@
 //   * loads of chunk c+1 (activations and weights) are issued before the MFMAs of chunk c.
 // The data gradient of a 1x1 convolution is the same product with the transposed weights (wt_d) and the
 // epilogue  y = acc * act'(aux) + res  (store_out, shared with the other kernels).
+#include <type_traits>
+
 #include "conv_common.h"
 
 template <int MT, int MODE, int PRO>
@@ -105,6 +107,28 @@ __global__ __launch_bounds__(256, 3) void conv_1x1_kernel(const GatherArgs a_in,
   g.oh = pix / d.Wo;
   g.ow = pix - g.oh * d.Wo;
   g.valid = true;
+  if (a.wide) {
+    // 16-byte stores after a lane-quad transpose, the common cases as straight-line code (conv_common.h): the general
+    // per-element form below cost the split-fp16 kernel 7 - 8 us per tile in scalar branches (tools/h2_timeline.py)
+    const int k = lane & 3;
+    float ymax = 0.f;
+    auto tiles = [&](auto form_c) {
+      constexpr int FORM = decltype(form_c)::value;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        TileSide4 side;
+        load_tile_side4<MODE, FORM>(a, g, m0 + mt * 32, h, k, side);
+        ymax = fmaxf(ymax, store_tile_side4<MODE, FORM>(a, g, m0 + mt * 32, h, k, acc[mt], side));
+      }
+    };
+    const int form = side4_form<MODE>(a);
+    if (form == 1) tiles(std::integral_constant<int, 1>{});
+    else if (MODE == 1 && form == 2) tiles(std::integral_constant<int, MODE == 1 ? 2 : 0>{});
+    else if (MODE == 1 && form == 3) tiles(std::integral_constant<int, MODE == 1 ? 3 : 0>{});
+    else tiles(std::integral_constant<int, 0>{});
+    if (a.amax_out) publish_amax(a, ymax);
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) store_tile16(a, g, m0 + mt * 32, h, acc[mt]);
 }

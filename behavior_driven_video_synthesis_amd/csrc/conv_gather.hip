@@ -483,7 +483,15 @@ int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const fl
     return vunet_conv_thin_launch(ga, thin, st);
   }
   if (!d->d2s) ga.amax_out = amax_out;   // read by the two kernels below only
-  if (use_1x1(d, pro)) return vunet_conv_1x1_launch(ga, pro, st);
+  if (use_1x1(d, pro)) {
+    // 16-byte epilogue (conv_common.h: store_tile_side4): a 32-pixel tile is 8 aligned groups of 4 consecutive pixels
+    const uintptr_t al = reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(aux);
+    ga.wide = (al & 15) == 0 && !d->d2s && (d->Ho * d->Wo) % 32 == 0;
+#ifdef VUNET_AB_NO_WIDE_1X1   // (A/B baseline, tools/ab_build.sh)
+    ga.wide = 0;
+#endif
+    return vunet_conv_1x1_launch(ga, pro, st);
+  }
   if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);
   float* const amax_keep = ga.amax_out;
   ga.amax_out = nullptr;

@@ -493,3 +493,51 @@ def test_l1_tap_and_pool_forward_in_one_pass():
     assert torch.equal(got_y, want_y)
     assert abs(float(got_l) - float(want_l)) <= 2e-6 * abs(float(want_l))
     assert abs(float(got_l) - 1.5 * float((target - pred).abs().double().mean())) <= 2e-6 * abs(float(want_l))
+
+
+@pytest.mark.parametrize("mode,act,drop,with_res,c,cout", [
+    (0, "none", 0.0, True, 32, 32),      # forward, no output activation, residual
+    (0, "relu", 0.0, False, 64, 128),    # forward + ReLU, two m-tiles ... four
+    (1, "none", 0.0, True, 32, 32),      # data gradient, no activation derivative
+    (1, "elu", 0.0, True, 64, 64),       # data gradient * ELU'(aux) + res
+    (1, "elu", 0.1, True, 32, 64),       # ... with the forward pass's dropout mask
+    (0, "sigmoid", 0.0, False, 32, 32),  # the general form stays reachable
+])
+@pytest.mark.gpu
+def test_1x1_kernel_16_byte_epilogue_forms(mode, act, drop, with_res, c, cout):
+    """The streaming 1x1 kernel's 16-byte epilogue (conv_common.h: store_tile_side4, FORM 0..3) against fp64:
+    forward y = act(W x + shift) + res, data gradient dx = W^T dy * ELU'(aux) * keep / (1 - p) + res."""
+    import ctypes
+    import torch.nn.functional as F
+    from behavior_driven_video_synthesis_amd import ops
+    n, h, w, seed = 2, 8, 64, 123
+    g = torch.Generator().manual_seed(c + cout + mode)
+    v = (torch.randn(cout, c, 1, 1, generator=g) * 0.2).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    wt_f, wt_d, scale, shift, invnorm, wx_f, wx_d = ops.pack_weights(v, None, bias, None, None, c, 0, 1, True)
+    cin_k, mo = (c, cout) if mode == 0 else (cout, c)          # channels read / written by this launch
+    x = torch.randn(n, cin_k, h, w, generator=g).cuda()
+    res = torch.randn(n, mo, h, w, generator=g).cuda() if with_res else None
+    aux = torch.randn(n, mo, h, w, generator=g).cuda() if (mode == 1 and act == "elu") else None
+    out_act = {"none": 0, "relu": ops.ACT_RELU, "sigmoid": ops.ACT_SIGMOID, "elu": 0}[act] if mode == 0 else 0
+    d = ops.ConvDesc(N=n, C1=cin_k, C2=0, Hs=h, Ws=w, M=mo, m_off=0, Mpad=(wt_f if mode == 0 else wt_d).shape[1], Ho=h, Wo=w,
+                     KH=1, KW=1, stride=1, pad=0, mode=mode, in_act=0, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=out_act,
+                     d2s=0, aux_act=ops.ACT_ELU if aux is not None else 0, aux_slope=0.0, aux_drop_p=drop, aux_drop_seed=seed)
+    y = torch.full((n, mo, h, w), float("nan"), device="cuda")
+    ops._call("vunet_conv2d_gather", ctypes.byref(d), ops._p(x), None, ops._p(wt_f if mode == 0 else wt_d),
+              ops._p(shift) if mode == 0 else None, ops._p(res), ops._p(aux), ops._p(y), ops._stream())
+    wd = v.double().cpu() * scale.double().cpu().view(-1, 1, 1, 1)
+    if mode == 0:
+        ref = F.conv2d(x.double().cpu(), wd) + shift.double().cpu().view(1, -1, 1, 1)
+        ref = {"none": ref, "relu": ref.clamp_min(0), "sigmoid": torch.sigmoid(ref)}[act]
+    else:
+        ref = F.conv_transpose2d(x.double().cpu(), wd)
+        if aux is not None:
+            a = aux.double().cpu()
+            ref = ref * torch.where(a > 0, torch.ones_like(a), a.exp())
+            if drop > 0:
+                ref = ref * dropout_keep_mask((n, mo, h, w), drop, seed).double() * float(torch.tensor(1.0 / (1.0 - drop),
+                                                                                                      dtype=torch.float32))
+    if res is not None:
+        ref = ref + res.double().cpu()
+    assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
