@@ -64,6 +64,80 @@ __global__ __launch_bounds__(256) void conv_thin_m_kernel(const GatherArgs a) {
     if (m < d.M) store_out(a, g, m, acc[m]);
 }
 
+// ---- conv_thin_m_kernel with R vertically adjacent output pixels per lane: the (R + 2) x 3 input window of a channel is
+//      loaded once for the R pixels (R = 4: 4.5 L1 loads per pixel and channel instead of 9) and the next channel's window
+//      is requested before this channel's FMAs.  Same fmaf chain per output as the one-pixel form: bit-identical results.
+template <int MODE, int R>
+__global__ __launch_bounds__(256) void conv_thin_mv_kernel(const GatherArgs a) {
+  const vunet_conv_desc& d = a.d;
+  const int H = d.Hs, W = d.Ws, HW = a.HsWs;
+  const int tiles_w = (W + 31) / 32, tiles_h = (H + 8 * R - 1) / (8 * R);
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_w;
+  const int ty = (bid / tiles_w) % tiles_h;
+  const int n = bid / (tiles_w * tiles_h);
+  const int ow = tx * 32 + (threadIdx.x & 31), oh0 = ty * 8 * R + (threadIdx.x >> 5) * R;
+  int off[R + 2][3];
+  uint32_t ok = 0;
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ih = oh0 - 1 + r, iw = ow - 1 + k;
+      const bool v = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      off[r][k] = v ? ih * W + iw : 0;
+      ok |= (v ? 1u : 0u) << (r * 3 + k);
+    }
+  float acc[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[r][m] = 0.f;
+  const int C = d.C1, Cp = (C + 1) & ~1;
+  const float* __restrict__ xs = a.x1 + (size_t)n * C * HW;
+  const float* __restrict__ wt = a.wt + d.m_off;
+  float xn[R + 2][3];
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xn[r][k] = xs[off[r][k]];
+  for (int c = 0; c < C; ++c) {
+    float xv[R + 2][3];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xv[r][k] = ((ok >> (r * 3 + k)) & 1u) ? xn[r][k] : 0.f;
+    const int cn = c + 1 < C ? c + 1 : c;   // (the last iteration re-reads its own window: unconditional loads)
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xn[r][k] = xs[(size_t)cn * HW + off[r][k]];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int tap = MODE == 0 ? t : 8 - t;   // data gradient: the taps mirrored
+      const float* __restrict__ w = wt + (size_t)(tap * Cp + c) * d.Mpad;   // wave-uniform: scalar loads
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[r][m] = fmaf(w[m], xv[r + t / 3][t % 3], acc[r][m]);
+    }
+  }
+  if (ow >= W) return;
+  PixGeo g;
+  g.n = n;
+  g.ow = ow;
+  g.valid = true;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    g.oh = oh0 + r;
+    if (g.oh < H) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (m < d.M) store_out(a, g, m, acc[r][m]);
+    }
+  }
+}
+
 // ---- CI (= 3: RGB) input channels, 3x3 pad 1 (KS 3) or 1x1 (KS 1), stride 1; forward, or (3x3) the data gradient of
 //      a layer with 3 OUTPUT channels (dd.out_conv, models/vunets.py:281: dy has 3 channels) with the taps mirrored ------
 template <int KS, int CI>
@@ -144,6 +218,106 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const
   if (a.amax_out) publish_amax(a, ymax);   // (whole waves reach this point: `inside` only guards the stores)
 }
 
+// ---- the 3x3 form of conv_thin_k_kernel with R vertically adjacent output pixels per lane --------------------------------
+// conv_thin_k_kernel is bound by the LDS return path, not by its FMAs: a broadcast ds_read_b128 still delivers 1 KiB to the
+// wave, and a lane needs 54 of them per 8 output channels for 216 FMAs -- at bs 16, 256^2, 64 output channels that is 92 us
+// of LDS time per CU against 46 us of fp32 FMA time (130 us measured, r03).  Here a lane owns a column strip of R pixels:
+// one weight read feeds R FMAs per output channel (54 reads : 216 R FMAs), and the (R + 2) x 3 input window per channel is
+// loaded once for the R pixels (R = 4: 54 loads instead of 108).  Same arithmetic order per pixel as the one-pixel form
+// (taps outer, channels inner, one fmaf chain per output): bit-identical results.
+template <int CI, int R>
+__global__ __launch_bounds__(256, 2) void conv_thin_kv_kernel(const GatherArgs a) {
+  constexpr int T = 9;
+  const vunet_conv_desc& d = a.d;
+  const int H = d.Hs, W = d.Ws, HW = a.HsWs;
+  const int tiles_w = (W + 31) / 32, tiles_h = (H + 8 * R - 1) / (8 * R);
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_w;
+  const int ty = (bid / tiles_w) % tiles_h;
+  const int n = bid / (tiles_w * tiles_h);
+  const int ow = tx * 32 + (threadIdx.x & 31), oh0 = ty * 8 * R + (threadIdx.x >> 5) * R;
+  constexpr int C = CI, Cp = (C + 1) & ~1;
+  float xv[CI][R + 2][3];
+  const float* __restrict__ xs = a.x1 + (size_t)n * C * HW;
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ih = oh0 - 1 + r, iw = ow - 1 + k;
+      const bool v = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      const int off = v ? ih * W + iw : 0;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const float x = xs[c * HW + off];
+        xv[c][r][k] = v ? x : 0.f;
+      }
+    }
+  const bool relu = d.mode == 0 && d.out_act == ACT_RELU;
+  __shared__ __attribute__((aligned(16))) float wL[T * CI * 128];
+  const int Mr = (d.M + 7) & ~7;
+  for (int e = threadIdx.x; e < T * CI * Mr; e += 256) {
+    const int m = e % Mr, r = e / Mr;           // r = t*CI + c
+    const int t = r / CI, c = r - t * CI;
+    const int tw = d.mode == 0 ? t : T - 1 - t;   // data gradient: the weight of tap t is stored under the mirrored tap
+    wL[r * Mr + m] = m < d.M ? a.wt[(size_t)(tw * Cp + c) * d.Mpad + d.m_off + m] : 0.f;
+  }
+  __syncthreads();
+  constexpr int MBK = 8;                   // outputs per pass
+  float ymax = 0.f;
+#pragma unroll 1
+  for (int m0 = 0; m0 < d.M; m0 += MBK) {
+    float acc[R][MBK];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MBK; ++m) acc[r][m] = 0.f;
+    int woff = m0 / 4;   // in 16-byte units
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const float4 w0 = reinterpret_cast<const float4*>(wL)[(t * CI + c) * (Mr / 4) + woff];
+        const float4 w1 = reinterpret_cast<const float4*>(wL)[(t * CI + c) * (Mr / 4) + woff + 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float x = xv[c][r + t / 3][t % 3];
+          acc[r][0] = fmaf(w0.x, x, acc[r][0]);
+          acc[r][1] = fmaf(w0.y, x, acc[r][1]);
+          acc[r][2] = fmaf(w0.z, x, acc[r][2]);
+          acc[r][3] = fmaf(w0.w, x, acc[r][3]);
+          acc[r][4] = fmaf(w1.x, x, acc[r][4]);
+          acc[r][5] = fmaf(w1.y, x, acc[r][5]);
+          acc[r][6] = fmaf(w1.z, x, acc[r][6]);
+          acc[r][7] = fmaf(w1.w, x, acc[r][7]);
+        }
+      }
+      // one tap's weight reads in flight: hipcc otherwise hoists all 54 reads of a pass above the FMAs and spills them.
+      // The next tap's LDS offset is made to depend on this tap's last FMA of every accumulator chain.
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        asm volatile("" : "+v"(woff), "+v"(acc[r][0]), "+v"(acc[r][1]), "+v"(acc[r][2]), "+v"(acc[r][3]), "+v"(acc[r][4]),
+                          "+v"(acc[r][5]), "+v"(acc[r][6]), "+v"(acc[r][7]));
+    }
+    if (ow < W) {   // lean epilogue (this kernel is only chosen for: + shift, optional ReLU, no residual)
+#pragma unroll
+      for (int m = 0; m < MBK; ++m)
+        if (m0 + m < d.M) {
+          const float sh = a.shift ? a.shift[m0 + m] : 0.f;
+          float* __restrict__ yp = a.y + (size_t)(n * d.M + m0 + m) * HW + oh0 * W + ow;
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (oh0 + r < H) {
+              float v = acc[r][m] + sh;
+              if (relu) v = fmaxf(v, 0.f);
+              yp[r * W] = v;
+              ymax = fmaxf(ymax, fabsf(v));
+            }
+        }
+    }
+  }
+  if (a.amax_out) publish_amax(a, ymax);   // (whole waves reach this point)
+}
+
 // which thin kernel (if any) takes this problem: 1 = thin_m, 2 = thin_k, 0 = none
 VUNET_ENV_FLAG(env_no_thin, "VUNET_NO_THIN")
 int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool has_res) {
@@ -159,19 +333,31 @@ int vunet_conv_thin_kind(const vunet_conv_desc* d, int pro, bool has_aux, bool h
   return 0;
 }
 
+VUNET_ENV_FLAG(env_no_thin_kv, "VUNET_NO_THIN_KV")   // (A/B timing: the one-pixel-per-lane form everywhere)
+static bool thin_kv(const vunet_conv_desc& d) { return d.KH == 3 && d.Hs >= 32 && !env_no_thin_kv(); }   // the column-strip form
+
 int vunet_conv_thin_name(const vunet_conv_desc* d, int kind, char* name, int len) {
+  if (kind == 1 && thin_kv(*d)) return snprintf(name, len, "conv_thin_mv_kernel<%d, 4>", d->mode);
   if (kind == 1) return snprintf(name, len, "conv_thin_m_kernel<%d>", d->mode);
+  if (thin_kv(*d)) return snprintf(name, len, "conv_thin_kv_kernel<3, 4>");
   return snprintf(name, len, "conv_thin_k_kernel<%d, 3>", d->KH);
 }
 
 int vunet_conv_thin_launch(const GatherArgs& ga, int kind, hipStream_t st) {
   const vunet_conv_desc& d = ga.d;
   dim3 grid((unsigned)(d.N * ((d.Hs + 7) / 8) * ((d.Ws + 31) / 32))), block(256);
-  if (kind == 1) {
+  if (kind == 1 && thin_kv(d)) {
+    dim3 gv((unsigned)(d.N * ((d.Hs + 31) / 32) * ((d.Ws + 31) / 32)));
+    if (d.mode == 0) VUNET_LAUNCH((conv_thin_mv_kernel<0, 4>), gv, block, 0, st, ga);
+    else VUNET_LAUNCH((conv_thin_mv_kernel<1, 4>), gv, block, 0, st, ga);
+  } else if (kind == 1) {
     if (d.mode == 0) VUNET_LAUNCH((conv_thin_m_kernel<0>), grid, block, 0, st, ga);
     else VUNET_LAUNCH((conv_thin_m_kernel<1>), grid, block, 0, st, ga);
   } else {
-    if (d.KH == 3) VUNET_LAUNCH((conv_thin_k_kernel<3, 3>), grid, block, 0, st, ga);
+    if (thin_kv(d)) {
+      dim3 gv((unsigned)(d.N * ((d.Hs + 31) / 32) * ((d.Ws + 31) / 32)));
+      VUNET_LAUNCH((conv_thin_kv_kernel<3, 4>), gv, block, 0, st, ga);
+    } else if (d.KH == 3) VUNET_LAUNCH((conv_thin_k_kernel<3, 3>), grid, block, 0, st, ga);
     else VUNET_LAUNCH((conv_thin_k_kernel<1, 3>), grid, block, 0, st, ga);
   }
   return vunet_check_launch();

@@ -184,9 +184,9 @@ def test_kernel_selection_of_the_gather_entry_point():
     assert variant(C1=128, M=128, Mpad=128, Hs=8, Ws=8, Ho=8, Wo=8) == "conv_gather_splitk_kernel<16, 0, 3>"
     assert variant(mode=1, stride=2, C1=128, M=64, Hs=64, Ws=64, Ho=128, Wo=128) == "conv_gather_kernel<phase x4>"
     # three channels on one side: VALU kernels
-    assert variant(C1=32, M=3, Mpad=32, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_m_kernel<0>"
+    assert variant(C1=32, M=3, Mpad=32, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_mv_kernel<0, 4>"
     assert variant(C1=3, M=32, Mpad=32, KH=1, KW=1, pad=0, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_k_kernel<1, 3>"
-    assert variant(C1=3, M=64, Mpad=64, Hs=256, Ws=256, Ho=256, Wo=256, out_act=ops.ACT_RELU) == "conv_thin_k_kernel<3, 3>"
+    assert variant(C1=3, M=64, Mpad=64, Hs=256, Ws=256, Ho=256, Wo=256, out_act=ops.ACT_RELU) == "conv_thin_kv_kernel<3, 4>"
 
 
 def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):

@@ -130,4 +130,4 @@ def test_three_channel_side_kernels_vs_oracle(case):
     if case[3] <= 4 and case[4] % 8 == 0 and case[5] % 32 == 0:
         assert any(k.startswith("conv_wgrad_thin_kernel") for k in kernels), kernels
     if case[3] == 3 and case[6] == 3:
-        assert any(k.startswith("conv_thin_k_kernel<3") for k in kernels), kernels     # the 3 -> C data gradient
+        assert any(k.startswith("conv_thin_kv_kernel<3") for k in kernels), kernels     # the 3 -> C data gradient
