@@ -127,7 +127,33 @@ __device__ __forceinline__ float store_tile_side(const GatherArgs& a, const PixG
                                                  const f32x16& acc, const TileSide& s) {
   const vunet_conv_desc& d = a.d;
   float vmax = 0.f;
-  if (d.d2s) {  // sub-pixel store: rare (up-convs), scattered addresses
+  if (d.d2s) {  // sub-pixel store (up-convs, lib/modules.py: Upsample + DepthToSpace): scattered addresses
+    const int Cq = d.M >> 2;
+#ifdef VUNET_AB_NO_D2S_FAST   // (A/B baseline, tools/ab_build.sh)
+    if (false) {
+#else
+    if ((Cq & 31) == 0 && m_tile0 + 32 <= d.M && g.valid && (d.out_act == ACT_NONE || d.out_act == ACT_RELU)) {
+#endif
+      // a 32-channel m-tile lies inside ONE sub-pixel block: (dy, dx) and the first output channel are tile-uniform,
+      // so the per-element work is an add and a store (store_out divides by the runtime Cq for every element: the
+      // up-conv layers ran 20 - 25 % below their stride-1 neighbours, r03 profiles/r03_layers_1stream.txt)
+      const int blk = m_tile0 / Cq, c0 = m_tile0 - blk * Cq + 4 * h;
+      const size_t rs = (size_t)(2 * d.Ho) * (2 * d.Wo);   // output channel stride
+      const size_t o0 = ((size_t)(g.n * Cq + c0) * (2 * d.Ho) + (2 * g.oh + (blk >> 1))) * (2 * d.Wo) + 2 * g.ow + (blk & 1);
+      const bool relu = d.out_act == ACT_RELU;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cr = (r & 3) + 8 * (r >> 2);
+        const size_t o = o0 + cr * rs;
+        float v = acc[r];
+        if (a.shift) v += a.shift[m_tile0 + 4 * h + cr];
+        v = (relu && !(v > 0.f)) ? 0.f : v;
+        if (a.res) v += a.res[o];
+        a.y[o] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+      return vmax;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m_tile0 + (r & 3) + 8 * (r >> 2) + 4 * h;

@@ -32,6 +32,8 @@ SHAPES = [
     ("vgg conv2_2 dgrad+relu", 16, 128, 128, 128, 128, 1, 0, True),
     ("vunet rnb 64ch fwd elu", 16, 64, 64, 128, 128, 0, 1, False),
     ("vunet 32ch 256^2 fwd elu", 16, 32, 32, 256, 256, 0, 1, False),
+    ("vunet up 64->128 d2s 128^2", 16, 64, 128, 128, 128, 0, 1, "d2s"),
+    ("vunet up 128->256 d2s 64^2", 16, 128, 256, 64, 64, 0, 1, "d2s"),
     ("vunet 32ch 256^2 dgrad", 16, 32, 32, 256, 256, 1, 0, False),
     ("vunet 32ch 256^2 dgrad elu' drop", 16, 32, 32, 256, 256, 1, 0, "elu+drop"),
     ("vunet 128ch 64^2 dgrad", 16, 128, 128, 64, 64, 1, 0, False),
@@ -47,6 +49,8 @@ for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(n, cin, h, w, generator=g).cuda()
     v = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    d2s = masked == "d2s"                              # the up-convolution's sub-pixel store
+    masked = False if d2s else masked
     auxk = masked if isinstance(masked, str) else ""   # data gradient * ELU'(aux) (+ the forward pass's dropout mask)
     masked = bool(masked) and not auxk
     m = torch.randn(n, cin, h, w, generator=g).cuda() if masked else None
@@ -59,7 +63,7 @@ for name, n, cin, cout, h, w, mode, in_act, masked in SHAPES:
         y = torch.empty(n, mo, h, w, device="cuda")
         d = ops.ConvDesc(N=n, C1=cin if mode == 0 else cout, C2=0, Hs=h, Ws=w, M=mo, m_off=0,
                          Mpad=(wt_f if mode == 0 else wt_d).shape[1], Ho=h, Wo=w, KH=3, KW=3, stride=1, pad=1, mode=mode,
-                         in_act=in_act, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=0,
+                         in_act=in_act, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=0, d2s=int(d2s),
                          aux_act=1 if auxk else 0, aux_slope=0.0, aux_drop_p=0.05 if "drop" in auxk else 0.0, aux_drop_seed=7)
         wx = wx_f if mode == 0 else wx_d
         amax = ops.absmax_partials(x) if sch == "h2" else None
