@@ -140,7 +140,17 @@ bool vunet_conv_1x1_applicable(const vunet_conv_desc* d, int pro) {
          pro != 3 && (d->mode == 0 || pro == 0);
 }
 
-static int mt_of(const vunet_conv_desc* d) { return d->M <= 32 ? 1 : d->M <= 64 ? 2 : 4; }
+// m-tiles per workgroup: all of M (x is then read once) unless that leaves the chip short of workgroups -- the 128-channel
+// layers of the 32^2 / 64^2 levels are 128 / 512 workgroups of four chunk-serial steps each (56 us for 0.5 GFLOP at 32^2,
+// r03); with fewer m-tiles per workgroup x is re-read from L2, which at these sizes costs nothing
+static int mt_of(const vunet_conv_desc* d) {
+  int MT = d->M <= 32 ? 1 : d->M <= 64 ? 2 : 4;
+#ifndef VUNET_AB_1X1_MT_BY_M   // (A/B baseline, tools/ab_build.sh)
+  const long groups = ((long)d->N * d->Hs * d->Ws / 32 + 3) / 4;
+  while (MT > 1 && groups * ((d->M + 32 * MT - 1) / (32 * MT)) < 1024) MT >>= 1;
+#endif
+  return MT;
+}
 
 int vunet_conv_1x1_name(const vunet_conv_desc* d, int pro, char* name, int len) {
   return snprintf(name, len, "conv_1x1_kernel<%d, %d, %d>", mt_of(d), d->mode, d->mode == 1 ? 0 : pro);

@@ -12,7 +12,9 @@ from behavior_driven_video_synthesis_amd import ops  # noqa: E402
 # (name, n, c, h, w, mode, in_act / aux_act)
 SHAPES = [("32ch 256^2 fwd elu", 16, 32, 256, 256, 0, 1), ("32ch 256^2 dgrad elu'", 16, 32, 256, 256, 1, 1),
           ("64ch 128^2 fwd elu", 16, 64, 128, 128, 0, 1), ("64ch 128^2 dgrad elu'", 16, 64, 128, 128, 1, 1),
-          ("128ch 64^2 fwd elu", 16, 128, 64, 64, 0, 1), ("128ch 64^2 dgrad elu'", 16, 128, 64, 64, 1, 1)]
+          ("128ch 64^2 fwd elu", 16, 128, 64, 64, 0, 1), ("128ch 64^2 dgrad elu'", 16, 128, 64, 64, 1, 1),
+          ("128ch 32^2 fwd elu", 16, 128, 32, 32, 0, 1), ("128ch 32^2 dgrad elu'", 16, 128, 32, 32, 1, 1),
+          ("128ch 16^2 fwd elu", 16, 128, 16, 16, 0, 1)]
 # the 3-channel layers (VGG19 conv1_1, the pyramids' first convolutions, the output layer's data gradient): fp32 FMA kernel
 for name, n, cin, cout, h, w, mode in [("3 -> 64 3x3 256^2 fwd + relu", 16, 3, 64, 256, 256, 0),
                                       ("3 -> 32 3x3 256^2 fwd", 16, 3, 32, 256, 256, 0),
