@@ -39,6 +39,8 @@ SHAPES = [
     ("vunet 128ch 64^2 dgrad", 16, 128, 128, 64, 64, 1, 0, False),
     ("vunet 64ch 128^2 dgrad elu'", 16, 64, 64, 128, 128, 1, 0, "elu"),
     ("vunet 64ch 128^2 dgrad elu' drop", 16, 64, 64, 128, 128, 1, 0, "elu+drop"),
+    ("vunet 128ch 32^2 fwd elu", 16, 128, 128, 32, 32, 0, 1, False),
+    ("vunet 128ch 32^2 dgrad elu'", 16, 128, 128, 32, 32, 1, 0, "elu"),
     ("vgg conv4_x fwd", 16, 512, 512, 32, 32, 0, 0, False),
     ("vgg conv2_2 fwd, N = 32", 32, 128, 128, 128, 128, 0, 0, False),
     ("K = 4608, 64^2", 16, 512, 128, 64, 64, 0, 0, False),
