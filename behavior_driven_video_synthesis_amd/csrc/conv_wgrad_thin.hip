@@ -4,9 +4,9 @@
 // A 32-row MFMA tile would multiply >= 87 % zeros here, and the kernels that did so spent their time on the operand
 // gathers, not the matrix pipe (conv_wgrad_tiled_kernel<1,4,3,1>: 470 us for 1.8 GFLOP at bs 16).  This is a plain fp32
 // FMA kernel instead: a workgroup stages an (8 + 2) x (32 + 2) pixel tile of all input channels (prologue applied once
-// per element) and the matching dy tile in LDS, every thread owns (tap, ci) items and runs over the tile's 256 pixels --
-// one LDS read of f(x) per pixel (lanes = consecutive ci: the channel pitch is odd, conflict-free), one broadcast read of
-// the 4 dy values, Cout FMAs -- and accumulates over the tiles of its split.  Partial sums go to the slabs
+// per element) and the matching dy tile in LDS, every thread owns a (kernel row, ci) item and slides along the tile's rows
+// -- one LDS read of f(x) per pixel (lanes = consecutive ci: the channel pitch is odd, conflict-free), one broadcast read
+// of the 4 dy values, 3 taps x Cout FMAs -- and accumulates over the tiles of its split.  Partial sums go to the slabs
 // vunet_weightnorm_bwd* reduces ([split][Coutp][T * Ctot], k order (tap, ci)); the per-channel sums of dy ride along.
 #include "common.h"
 
@@ -20,7 +20,12 @@ struct WgradThinArgs {
   InAct in1;
 };
 
-template <int MAXI>   // (tap, ci) items per thread: ceil(9 * C1 / 256)
+// Work items (r03 rewrite).  The first form gave a thread (tap, ci) items and, per pixel, one LDS read of f(x), one
+// broadcast float4 of dy and 4 FMAs -- bound by the LDS return path (a broadcast read still delivers 1 KiB to the wave),
+// 193 us at bs 16.  Now a thread owns (kernel ROW kh, ci): it slides along the tile's rows keeping the last two f(x) values,
+// so one new f(x) read and one dy read feed the THREE taps of the row -- 12 FMAs per pixel.  3 C items use at most 192
+// threads; G = 256 / (3 C) (a power of two, <= 8) groups of threads split the tile's 8 rows and are summed through LDS at
+// the end (fixed order).
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradThinArgs a_in) {
   WgradThinArgs a = a_in;
   inact_resolve(a.in1);
@@ -32,23 +37,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradThinArg
   float* const xT = smem;                                      // [C][IH][IW] (+1 per channel)
   float4* const dyT = reinterpret_cast<float4*>(smem + ((C * CP + 3) & ~3));   // [TH*TW] (co 0..3)
   const int tid = threadIdx.x;
-  const int nitems = 9 * C;
+  const int nitems = 3 * C;                                    // (kh, ci)
+  int G = 1;
+  while (G < 8 && 2 * G * nitems <= 256) G *= 2;               // thread groups; each takes TH / G rows of every tile
+  const int RG = TH / G;
+  const int grp = tid / nitems, it = tid - grp * nitems;       // consecutive lanes: consecutive ci
+  const bool worker = grp < G;
+  const int kh = it / C, ci = it - kh * C;
 
-  float acc[MAXI][4];
+  float acc[3][4];
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i)
+  for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
+    for (int c = 0; c < 4; ++c) acc[kw][c] = 0.f;
   float dpart[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's share of sum_px dy[co]
   const int sg = tid / (TW + 2), scol = tid - sg * (TW + 2);   // staging group (0..6 used) and halo-tile column
-
-  int it_tap[MAXI], it_ci[MAXI];
-#pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int it = tid + 256 * i;
-    it_ci[i] = it % C;            // consecutive lanes: consecutive ci
-    it_tap[i] = it / C;
-  }
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int n = tile / a.tiles_per_img, tr = tile - n * a.tiles_per_img;
@@ -96,42 +99,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradThinArg
       for (int co = 0; co < 4; ++co) dpart[co] += v[co];
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-      if (tid + 256 * i < nitems) {
-        const int kh = it_tap[i] / 3, kw = it_tap[i] - 3 * kh;
-        const float* xp = xT + it_ci[i] * CP + kh * IW + kw;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int r = 0; r < TH; ++r) {
+    if (worker) {
+      for (int rr = 0; rr < RG; ++rr) {
+        const int r = grp * RG + rr;
+        const float* xp = xT + ci * CP + (r + kh) * IW;   // halo-tile row r + kh, columns 0 .. 33 <-> taps kw = 0 .. 2
+        float x0 = xp[0], x1 = xp[1];
 #pragma unroll 8
-          for (int col = 0; col < TW; ++col) {
-            const float x = xp[r * IW + col];
-            const float4 g = dyT[r * TW + col];   // the same address in every lane: a broadcast read
-            a0 = fmaf(g.x, x, a0);
-            a1 = fmaf(g.y, x, a1);
-            a2 = fmaf(g.z, x, a2);
-            a3 = fmaf(g.w, x, a3);
-          }
+        for (int col = 0; col < TW; ++col) {
+          const float x2 = xp[col + 2];
+          const float4 g = dyT[r * TW + col];   // the same address in every lane of a group: a broadcast read
+          acc[0][0] = fmaf(g.x, x0, acc[0][0]);
+          acc[0][1] = fmaf(g.y, x0, acc[0][1]);
+          acc[0][2] = fmaf(g.z, x0, acc[0][2]);
+          acc[0][3] = fmaf(g.w, x0, acc[0][3]);
+          acc[1][0] = fmaf(g.x, x1, acc[1][0]);
+          acc[1][1] = fmaf(g.y, x1, acc[1][1]);
+          acc[1][2] = fmaf(g.z, x1, acc[1][2]);
+          acc[1][3] = fmaf(g.w, x1, acc[1][3]);
+          acc[2][0] = fmaf(g.x, x2, acc[2][0]);
+          acc[2][1] = fmaf(g.y, x2, acc[2][1]);
+          acc[2][2] = fmaf(g.z, x2, acc[2][2]);
+          acc[2][3] = fmaf(g.w, x2, acc[2][3]);
+          x0 = x1;
+          x1 = x2;
         }
-        acc[i][0] += a0;
-        acc[i][1] += a1;
-        acc[i][2] += a2;
-        acc[i][3] += a3;
       }
     }
   }
 
-  // ---- slab of this split
+  // ---- sum the G groups (fixed order) and write the slab of this split
+  __syncthreads();
+  float* const part = smem;   // [G][nitems][12]
+  if (worker) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) part[(grp * nitems + it) * 12 + kw * 4 + c] = acc[kw][c];
+  }
+  __syncthreads();
   const size_t K = (size_t)9 * C;
   float* slab = a.slabs + (size_t)blockIdx.x * a.Coutp * K;
+  if (tid < nitems) {   // group 0's threads: item `it` = tid
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int it = tid + 256 * i;
-    if (it < nitems) {
+    for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-      for (int co = 0; co < 4; ++co)
-        if (co < d.Cout) slab[(size_t)co * K + (size_t)it_tap[i] * C + it_ci[i]] = acc[i][co];
-    }
+      for (int co = 0; co < 4; ++co) {
+        float t = 0.f;
+        for (int g = 0; g < G; ++g) t += part[(g * nitems + tid) * 12 + kw * 4 + co];
+        if (co < d.Cout) slab[(size_t)co * K + (size_t)(kh * 3 + kw) * C + ci] = t;
+      }
   }
   // ---- per-channel sums of dy of this split: wave sums, then four waves through LDS
   __syncthreads();
@@ -162,7 +178,7 @@ int vunet_wgrad_thin_nslabs(const vunet_wgrad_desc* d) {
 }
 
 int vunet_wgrad_thin_name(const vunet_wgrad_desc* d, char* name, int len) {
-  return snprintf(name, len, "conv_wgrad_thin_kernel<%d>", (9 * d->C1 + 255) / 256);
+  return snprintf(name, len, "conv_wgrad_thin_kernel");
 }
 
 int vunet_wgrad_thin_launch(const vunet_wgrad_desc* d, const float* x1, const float* dy, float* slabs, float* dshift,
@@ -178,17 +194,9 @@ int vunet_wgrad_thin_launch(const vunet_wgrad_desc* d, const float* x1, const fl
   if (d->nsplit != vunet_wgrad_thin_nslabs(d)) return VUNET_ERR_ARG;
   const int CP = 10 * 35 + 1;
   const size_t lds = ((size_t)((d->C1 * CP + 3) & ~3) + 4 * 256) * sizeof(float);
-  const int maxi = (9 * d->C1 + 255) / 256;
-#define THIN_LAUNCH(M_)                                                                                              \
-  do {                                                                                                               \
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_wgrad_thin_kernel<M_>,                               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
-      return VUNET_ERR_LAUNCH;                                                                                       \
-    VUNET_LAUNCH((conv_wgrad_thin_kernel<M_>), dim3(d->nsplit), dim3(256), lds, st, a);                              \
-  } while (0)
-  if (maxi == 1) THIN_LAUNCH(1);
-  else if (maxi == 2) THIN_LAUNCH(2);
-  else THIN_LAUNCH(3);
-#undef THIN_LAUNCH
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_wgrad_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds) != hipSuccess)
+    return VUNET_ERR_LAUNCH;
+  VUNET_LAUNCH(conv_wgrad_thin_kernel, dim3(d->nsplit), dim3(256), lds, st, a);
   return vunet_check_launch();
 }

@@ -4,7 +4,8 @@ import ctypes, os, sys, torch
 sys.path.insert(0, "/root/repo")
 from behavior_driven_video_synthesis_amd import ops
 ops.set_conv_precision("h2")
-for name, n, c1, cout, h, w in [("128ch 128^2", 16, 128, 128, 128, 128), ("64ch 256^2", 16, 64, 64, 256, 256), ("256ch 64^2", 16, 256, 256, 64, 64), ("32ch 256^2", 16, 32, 32, 256, 256), ("64+64->64 128^2", 16, 128, 64, 128, 128)]:
+for name, n, c1, cout, h, w in [("128ch 128^2", 16, 128, 128, 128, 128), ("64ch 256^2", 16, 64, 64, 256, 256), ("256ch 64^2", 16, 256, 256, 64, 64), ("32ch 256^2", 16, 32, 32, 256, 256), ("64+64->64 128^2", 16, 128, 64, 128, 128),
+                               ("32->3 out_conv 256^2 (fp32 FMA kernel)", 16, 32, 3, 256, 256)]:
     x = torch.randn(n, c1, h, w, device="cuda"); dy = torch.randn(n, cout, h, w, device="cuda")
     wd = ops.WgradDesc(N=n, C1=c1, C2=0, Hs=h, Ws=w, Cout=cout, Ho=h, Wo=w, KH=3, KW=3, stride=1, pad=1, in_act=1, in_slope=0.0, drop_p=0.0, drop_seed=0, nsplit=1, flags=2)
     ns = ops._lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd)); wd.nsplit = ns
