@@ -128,6 +128,17 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   constexpr bool ALLP = PHW == 4;         // every output parity in this launch
   static_assert(!ALLP || (NT == 1 && TW == 32 && NWV == 4 && PRO == 0), "fused parities: one dy row per wave");
   constexpr int NQ = ALLP ? 4 : NT;       // accumulator tiles per m-tile: pixel-row tiles, or the four parities
+  // PIPE (16-wide maps): the fragment reads of tap kw + 1 are issued before the MFMAs of tap kw.  VGG19 conv5_x at bs 16 is
+  // 256 workgroups -- one wave per SIMD, no partner whose MFMAs cover this wave's LDS latency -- and the compiler's schedule
+  // is read -> wait -> MFMA: 93 -> 82 us forward, 113 -> 103 us data gradient (r03).  With two waves per SIMD (every other
+  // form) the same pipelining was 3 - 6 % SLOWER (r02, r03: -DH2_PIPE), so it is tied to the tile width.  Requesting all
+  // staging rounds at the start of a chunk, dropping the weight-DMA wait (timing only) and one m-tile per workgroup (512
+  // workgroups) each changed nothing here: the chunk time of this form is its fragment-read latency.
+#ifdef H2_PIPE
+  constexpr bool PIPE = PHW < 0;
+#else
+  constexpr bool PIPE = TW == 16 && PHW < 0;
+#endif
   constexpr int PH = (PHW >= 0 && !ALLP) ? (PHW >> 1) : 0, PW = (PHW >= 0 && !ALLP) ? (PHW & 1) : 0;
   constexpr int NKH = (PHW < 0 || ALLP) ? 3 : (PH ? 2 : 1);   // kernel rows visited per chunk
   constexpr int NTHR = 64 * NWV;
@@ -348,9 +359,8 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
 #endif
       // row / column of the staged tile (origin row0-1, col0-1) that tap (kh, kw) reads for output row q, column j
       const int dr = PHW >= 0 ? (ph_t + 1 - kh) / 2 + 1 : (MODE == 0 ? kh : 2 - kh);
-#if defined(H2_PIPE)
-      // (experiment) fragment reads software-pipelined inside the phase: tap kw + 1 is read while tap kw multiplies
-      if constexpr (PHW < 0) {
+      // fragment reads software-pipelined inside the phase: tap kw + 1 is read while tap kw multiplies (PIPE above)
+      if constexpr (PIPE) {
         H2Unit fa[2][2][MT], fb[2][2][NT];
         auto rd = [&](int kw, H2Unit (&av)[2][MT], H2Unit (&bv)[2][NT]) {
           const int dc = MODE == 0 ? kw : 2 - kw;
@@ -372,15 +382,22 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
+#ifdef H2_SINGLE
               f32x16 cx = acc[mt][q];
               cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][1][mt].b, fb[kw & 1][0][q].b, cx, 0, 0, 0);
               cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][0][mt].b, fb[kw & 1][1][q].b, cx, 0, 0, 0);
               cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][0][mt].b, fb[kw & 1][0][q].b, cx, 0, 0, 0);
               acc[mt][q] = cx;
+#else
+              f32x16 cx = acx[mt][q];   // same products, same order and same accumulators as the plain loop below
+              cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][1][mt].b, fb[kw & 1][0][q].b, cx, 0, 0, 0);
+              cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][0][mt].b, fb[kw & 1][1][q].b, cx, 0, 0, 0);
+              acx[mt][q] = cx;
+              acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kw & 1][0][mt].b, fb[kw & 1][0][q].b, acc[mt][q], 0, 0, 0);
+#endif
             }
         }
       } else
-#endif
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         if (PHW >= 0 && !ALLP && ((kw + PW) & 1) == 0) continue;   // this parity's taps only: kw = pw + 1 (mod 2)
