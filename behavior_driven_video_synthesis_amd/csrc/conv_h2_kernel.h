@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   // PIPE (16-wide maps): the fragment reads of tap kw + 1 are issued before the MFMAs of tap kw.  VGG19 conv5_x at bs 16 is
   // 256 workgroups -- one wave per SIMD, no partner whose MFMAs cover this wave's LDS latency -- and the compiler's schedule
   // is read -> wait -> MFMA: 93 -> 82 us forward, 113 -> 103 us data gradient (r03).  With two waves per SIMD (every other
-  // form) the same pipelining was 3 - 6 % SLOWER (r02, r03: -DH2_PIPE), so it is tied to the tile width.  Requesting all
+  // form) the same pipelining was 3 - 16 % SLOWER (r02, r03: -DH2_PIPE; conv3_x 242 -> 278 us), so it is tied to the tile width
+  // (the 128-channel 32^2 layers, 256 workgroups of the 8-row tile, would gain 8 % -- 2 us on 14 launches: not instantiated).  Requesting all
   // staging rounds at the start of a chunk, dropping the weight-DMA wait (timing only) and one m-tile per workgroup (512
   // workgroups) each changed nothing here: the chunk time of this form is its fragment-read latency.
 #ifdef H2_PIPE
