@@ -9,10 +9,18 @@ gradient to the VUnet), VGG19 weights are seeded-synthetic (no network for the p
 stickman input is drawn by the GPU rasteriser from synthetic 17-joint skeletons.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # N > 1: bench.py starts the N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # ... or is started as one rank of N
 
 Rank 0 prints ONE JSON line.
+  --gpus N      replaces nn.DataParallel (experiments/shape_and_pose_net.py:213-214,223-224,230-233): one process per GPU,
+                gradient buckets all-reduced over RCCL while backward runs.  Called WITHOUT a torchrun environment and
+                with N > 1, bench.py starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>`
+                as a fresh CHILD process before anything touches the GPU (never an exec of this process), relays rank
+                0's JSON line and the child's exit code, and fails non-zero if fewer than N GPUs are visible or the line's
+                `n_gpus` / `rccl_world_size` is not N.  `VUNET_DP_FORCE=1 python bench.py --gpus 1` takes the same route
+                with one rank (launcher + one-rank RCCL communicator on a 1-GPU box).
   roofline      measured live with HIP events around every conv-family launch in an extra instrumented region
                 after the timed one (so the events do not perturb `value`); `traffic` comes from the committed
                 rocprofv3 PMC summary profiles/<round>_pmc_traffic.json (tools/profile.sh), named in
@@ -334,11 +342,58 @@ def timed_steps(trainer, batch, warmup, steps, sync_all):
     return time.perf_counter() - t0, out
 
 
+def launch_ranks(args):
+    """``bench.py --gpus N`` outside a torchrun environment: start the N ranks as a fresh child process tree, relay rank
+    0's JSON line.  Nothing in THIS process has touched the GPU (``torch.cuda.device_count()`` does not initialise HIP)
+    and nothing will: the parent only waits.  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py --gpus {n}: only {have} GPU(s) visible", file=sys.stderr)
+        return 3
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env["VUNET_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)   # stderr passes through
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)              # anything else the ranks wrote to stdout is not the result
+    if p.returncode != 0:
+        print(f"bench.py --gpus {n}: the rank processes exited with code {p.returncode}", file=sys.stderr)
+        return p.returncode
+    if line is None:
+        print(f"bench.py --gpus {n}: rank 0 printed no JSON line", file=sys.stderr)
+        return 4
+    res = json.loads(line)
+    if res.get("n_gpus") != n or res.get("config", {}).get("rccl_world_size") != n:
+        print(f"bench.py --gpus {n}: the line reports n_gpus={res.get('n_gpus')}, "
+              f"rccl_world_size={res.get('config', {}).get('rccl_world_size')}", file=sys.stderr)
+        return 5
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     args = parse()
     if args.cpu_child:
         return cpu_baseline_child(args.cpu_child)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("VUNET_DP_FORCE") == "1"):
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started as one rank of {world}: the two must agree")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # stdout carries ONE JSON line.  Native libraries write there too (RCCL prints a version banner through C stdio when
@@ -412,6 +467,8 @@ def main():
                    # share of the all-reduce time that ran while backward was still computing (HIP events)
                    "allreduce_overlap_frac": trainer.averager.overlap_fraction()},
     }
+    if result["config"]["rccl_world_size"] != args.gpus:
+        raise SystemExit(f"rank {rank}: RCCL communicator spans {result['config']['rccl_world_size']} rank(s), --gpus {args.gpus}")
     if dist.is_initialized():
         # self-validation of the data-parallel run: after the timed steps every rank must hold bit-identical parameters
         # (bucket checksums all-gathered and compared); a number from diverged replicas is not a result

@@ -327,3 +327,24 @@ def test_checkpoint_round_trip_keeps_the_regressor_file(tmp_path):
     for x, y in zip(a.optimizer_regressor.buckets, b_.optimizer_regressor.buckets):
         assert y.step == 2 and torch.equal(x.exp_avg, y.exp_avg) and torch.equal(x.exp_avg_sq, y.exp_avg_sq)
     assert not restore(str(tmp_path / "empty"), b_)
+
+
+def test_bench_gpus_n_starts_ranks_or_fails_loudly():
+    """bench.py --gpus N (the driver's call, no torchrun environment): with fewer than N GPUs visible it must exit
+    non-zero without printing a result line -- never fall back to one rank (here: no GPU at all).  And started as one
+    rank of a world whose size is not N it refuses as well."""
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VUNET_DP_FORCE")}
+    need = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(2, need)), "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "must agree" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())

@@ -24,6 +24,24 @@ def test_bench_under_torchrun_with_forced_dp_path():
     assert out["config"]["rccl_world_size"] == 1 and out["config"]["allreduce_ms_per_step"] > 0   # events on the comm stream
 
 
+def test_bench_entry_point_starts_its_own_ranks():
+    """``VUNET_DP_FORCE=1 python bench.py --gpus 1`` with NO torchrun environment: bench.py itself starts the rank
+    process tree (a fresh child, before this parent touches the GPU), relays rank 0's ONE JSON line on stdout and its
+    exit code -- the route `python bench.py --gpus N` takes for N > 1, exercised on the 1-GPU pool."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VUNET_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2",
+           "--size", "64", "--no-cpu-baseline", "--no-roofline", "--no-render", "--no-config1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                       # stdout carries the result line and nothing else
+    out = json.loads(lines[0])
+    assert "torch.distributed.run" in r.stderr                     # ... and it came from the rank tree bench.py started
+    assert out["n_gpus"] == 1 and out["config"]["rccl_world_size"] == 1 and out["config"]["dp_consistent"] is True
+    assert out["config"]["allreduce_ms_per_step"] > 0 and out["value"] > 0
+
+
 def test_forced_one_rank_rccl_run_equals_the_plain_run(tmp_path):
     """tools/dp_check.py with one rank under torchrun (hooks, communication stream, RCCL all-reduce of every bucket, the
     averaged KL scalar) against the same steps without a process group: a one-rank SUM / 1 changes nothing, so the
