@@ -686,4 +686,30 @@ extern "C" int vunet_upsample_bilinear2x_bwd(const float* dy, float* dx, int64_t
   return vunet_check_launch();
 }
 
-extern "C" int vunet_abi_version(void) { return 5; }
+extern "C" int vunet_abi_version(void) { return 6; }
+
+// ------------------------------------------------------------------ window crop with a device-resident corner
+__global__ void crop_window_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int H, int W, int P,
+                                   const int32_t* __restrict__ off, int bwd) {
+  const int oy = off[0], ox = off[1];
+  const int64_t n = (int64_t)planes * P * P;
+  EW_LOOP(i, n) {
+    const int j = (int)(i % P), r = (int)((i / P) % P);
+    const int64_t pl = i / ((int64_t)P * P);
+    const int64_t src = (pl * H + (oy + r)) * W + (ox + j);
+    if (bwd) y[src] = x[i];     // (x = dy, y = dx)
+    else y[i] = x[src];
+  }
+}
+extern "C" int vunet_crop_window(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t P, const int32_t* off,
+                                 void* st) {
+  if (!x || !y || !off || planes < 1 || P < 1 || P > H || P > W) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(crop_window_kernel, ew_grid((int64_t)planes * P * P), dim3(256), 0, (hipStream_t)st, x, y, planes, H, W, P, off, 0);
+  return vunet_check_launch();
+}
+extern "C" int vunet_crop_window_bwd(const float* dy, float* dx, int32_t planes, int32_t H, int32_t W, int32_t P,
+                                     const int32_t* off, void* st) {
+  if (!dy || !dx || !off || planes < 1 || P < 1 || P > H || P > W) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(crop_window_kernel, ew_grid((int64_t)planes * P * P), dim3(256), 0, (hipStream_t)st, dy, dx, planes, H, W, P, off, 1);
+  return vunet_check_launch();
+}

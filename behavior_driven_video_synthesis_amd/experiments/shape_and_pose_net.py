@@ -100,6 +100,7 @@ class ShapePoseNet:
             self.gan_weight = float(gan.get("weight", 1.0))
             self.gan_patch = data["spatial_size"] // 4 + 2   # PartDiscriminator opens with a valid 3x3 conv (:87)
             self._gan_rng = torch.Generator().manual_seed(config["general"].get("seed", 42) + 7919)
+            self._gan_off = torch.zeros(2, dtype=torch.int32, device=self.device)   # this step's window corner (oy, ox)
         # ---- data parallel (replaces nn.DataParallel, :213-214)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         broadcast_parameters(self.optimizer.buckets, 0, process_group)
@@ -126,6 +127,7 @@ class ShapePoseNet:
         # (on wherever the trainer runs on several streams; measured -1.4 % .. -2.5 % step time)
         self._target_overlap = os.environ.get("VUNET_TARGET_OVERLAP", "1") != "0"
         self._target_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._capture_forks = os.environ.get("VUNET_CAPTURE_FORKS", "1") != "0"   # (A/B switch: the capture keeps the fork)
         # weight folds beside the VGG target pass: measured -0.4 % (tools/ab_step.py pack_overlap), inside box-to-box noise,
         # at the price of two concurrent streams in the part of the step the per-kernel roofline is read from: off
         self._pack_overlap = os.environ.get("VUNET_PACK_OVERLAP", "0") == "1"
@@ -165,9 +167,13 @@ class ShapePoseNet:
         """``capture=False`` keeps the device-resident schedule but launches eagerly (the parity baseline of the test)."""
         if self.device.type != "cuda":
             raise RuntimeError("hipGraph mode needs the GPU")
-        if self.gan is not None or self.averager.active:
-            raise RuntimeError("hipGraph mode covers the single-GPU reference step (no adversarial term, no RCCL "
-                               "all-reduce inside the capture); run those configurations eagerly")
+        if self.gan is not None and self.gan.use_gp:
+            raise RuntimeError("hipGraph mode does not cover the R1 penalty (a double backward assembled from ATen ops per "
+                               "step); run that configuration eagerly")
+        if self.averager.active and not self.averager.native:
+            raise RuntimeError("hipGraph mode with data parallelism needs the gradient all-reduce on the C-ABI RCCL "
+                               "communicator (vunet_dp_allreduce_bucket: an ordinary stream operation, capturable); this "
+                               "averager runs on torch.distributed collectives -- run eagerly")
         if not self._dev_sched:
             self._lr_dev = torch.full((1,), self.lr, dtype=torch.float64, device=self.device)
             self._imax_dev = torch.full((), self.imax, dtype=torch.float32, device=self.device)
@@ -175,6 +181,8 @@ class ShapePoseNet:
             self.optimizer.use_device_schedule(self._lr_dev)
             if self.train_regressor:
                 self.optimizer_regressor.use_device_schedule()
+            if self.gan is not None:
+                self.gan.opt.use_device_schedule()
             ops.set_dropout_step(self._drop_step)
             self._graph_stream = torch.cuda.Stream()
             self._dev_sched = True
@@ -192,7 +200,20 @@ class ShapePoseNet:
         return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v)))
 
     def _train_fn_graph(self, batch, it, eps, reg_eps):
-        # host-side schedule values of THIS step -> device (two tiny launches outside the graph)
+        # Every device-schedule step -- the eager ones before the capture, the capture itself and the replays -- runs on
+        # ONE dedicated stream: the per-stream state the step builds lazily (weight-gradient companion streams, slab arenas
+        # and the item tables of the batched weight-norm backward, which hold arena addresses and are uploaded from host
+        # memory on first use) then already exists, with the same addresses, when the step is recorded.
+        caller = torch.cuda.current_stream()
+        gs = self._graph_stream
+        gs.wait_stream(caller)
+        with torch.cuda.stream(gs):
+            out = self._train_fn_graph_on_stream(batch, it, eps, reg_eps)
+        caller.wait_stream(gs)
+        return out
+
+    def _train_fn_graph_on_stream(self, batch, it, eps, reg_eps):
+        # host-side schedule values of THIS step -> device (three tiny launches outside the graph)
         self._lr_dev.fill_(self.lr)
         self._imax_dev.fill_(self.imax)
         self._drop_step.fill_(it & 0x7FFFFFFF)
@@ -226,6 +247,8 @@ class ShapePoseNet:
             self.optimizer.note_replayed_steps(1)
             if self.train_regressor and "reg_imgs" in batch:
                 self.optimizer_regressor.note_replayed_steps(batch["reg_imgs"].shape[1])
+            if self.gan is not None:
+                self.gan.opt.note_replayed_steps(1)
         rec["graph"].replay()
         return dict(rec["out"])   # tensors are the graph's static outputs: valid until the next train_fn call
 
@@ -238,6 +261,12 @@ class ShapePoseNet:
         self.iteration += 1
         it = self.iteration
         self.averager.start_step()
+        if self.gan is not None:
+            # one (patch x patch) window per step, the same for the real and the generated batch: drawn on the host, handed
+            # to the step through device memory (ops.CropWindow), so that the step's launch arguments never change
+            P, S = self.gan_patch, batch["pose_img"].shape[-1]
+            off = torch.randint(0, S - P + 1, (2,), generator=self._gan_rng).to(torch.int32)
+            self._gan_off.copy_(off, non_blocking=True)
         if self._dev_sched:
             out = self._train_fn_graph(batch, it, eps, reg_eps)
         else:
@@ -274,9 +303,11 @@ class ShapePoseNet:
         target_img = batch["pose_img"]
         shape_img = batch["stickman"]
         pose_img = batch.get("pose_img_inplane", target_img)
+        # (inside a hipGraph capture too: ``wait_stream`` on a capturing stream forks the target stream into the capture, the
+        # wait on it below joins it back -- the recorded graph keeps the branch)
         tstream = self._target_stream if (target_features is None and self._target_overlap and target_img.is_cuda
                                             and self.vunet._side_stream is not None
-                                            and not torch.cuda.is_current_stream_capturing()) else None
+                                            and (self._capture_forks or not torch.cuda.is_current_stream_capturing())) else None
         if tstream is not None:
             # The frozen VGG19's pass over the TARGET image needs nothing from the generator.  It is issued on a stream of
             # its own once the appearance pyramid is through, so that its chip-filling kernels run beside the bottleneck
@@ -311,11 +342,9 @@ class ShapePoseNet:
             out["loss_reg"] = loss_regressor.detach()
         patches = None
         if self.gan is not None:
-            # one (patch x patch) window per step, the same for the real and the generated batch
-            P, S = self.gan_patch, target_img.shape[-1]
-            oy, ox = (int(v) for v in torch.randint(0, S - P + 1, (2,), generator=self._gan_rng))
-            fake_patch = out_img[:, :, oy:oy + P, ox:ox + P].contiguous()
-            real_patch = target_img[:, :, oy:oy + P, ox:ox + P].contiguous()
+            P = self.gan_patch
+            fake_patch = ops.CropWindow.apply(out_img, self._gan_off, P)
+            real_patch = ops.CropWindow.apply(target_img, self._gan_off, P)
             gen_loss, w = self.gan.get_genloss(fake_patch, likelihood_loss, self.vunet.dd.out_conv.conv.weight_v)
             loss = loss + self.gan_weight * w * gen_loss
             out["gen_loss"] = gen_loss.detach()
@@ -328,7 +357,7 @@ class ShapePoseNet:
         kl_avg = self.averager.finish(kl.detach().clone().reshape(1))
         self.optimizer.step()
         if patches is not None:
-            out.update(self.gan.train_disc(*patches))
+            out.update(self.gan.train_disc(*patches, as_tensors=True))   # device scalars: no host synchronisation
         # gamma controller on the device (:82-85,442); with DP every rank sees the averaged KL
         if self._dev_sched:   # in place, information_max from device memory: nothing here is a per-step launch argument
             self.gamma.copy_(torch.clamp(self.gamma - tr["gamma_step"] * (self._imax_dev - kl_avg.reshape(())), min=0.0))

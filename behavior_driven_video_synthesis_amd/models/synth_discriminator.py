@@ -107,7 +107,9 @@ class DiscTrainer(object):
         toggle_grad(self.disc, train_disc)
         toggle_grad(self.generator, not train_disc)
 
-    def train_disc(self, real_x, fake_x, retain_graph=False):
+    def train_disc(self, real_x, fake_x, retain_graph=False, as_tensors=False):
+        """``as_tensors``: return the losses as device scalars instead of python floats (the reference's ``.item()`` calls
+        are three host synchronisations per step, and cannot be part of a captured hipGraph)."""
         self._only(True)
         self.disc.train()
         if self.averager is not None:
@@ -129,10 +131,10 @@ class DiscTrainer(object):
             self.averager.finish()
         self.opt.step()
         self._only(False)
-        out = {"dloss": (real_loss + fake_loss).item(), "dloss_r": real_loss.item(), "dloss_f": fake_loss.item()}
+        out = {"dloss": (real_loss + fake_loss).detach(), "dloss_r": real_loss.detach(), "dloss_f": fake_loss.detach()}
         if reg is not None:
-            out["gp"] = reg.item()
-        return out
+            out["gp"] = reg.detach()
+        return out if as_tensors else {k: v.item() for k, v in out.items()}
 
     def get_genloss(self, x_fake, pre_loss, last_layer_weight):
         self._only(False)

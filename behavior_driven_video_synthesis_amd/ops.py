@@ -805,7 +805,7 @@ class prepacked:
 _WN_GROUP = 16                  # layers per batched launch pair, at most
 _WN_ARENA_FLOATS = 48 << 20     # 192 MB of slabs per stream between two flushes: they stay in the 256 MB Infinity Cache
 _wn_batch = {"on": os.environ.get("VUNET_WN_BATCH", "1") != "0", "pending": {}, "arena": {}, "tables": {},
-             "callback_queued": False}
+             "callback_queued": False, "capture": os.environ.get("VUNET_WN_BATCH_CAPTURE", "1") != "0"}
 
 
 def enable_wn_batching(on: bool = True):
@@ -843,6 +843,10 @@ def _wn_flush_stream(stream_key):
     sig = tuple(it[0] for it in items)
     tab = _wn_batch["tables"].get(sig)
     if tab is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("batched weight-norm backward: this group's item table has not been built yet and cannot be "
+                               "uploaded while a hipGraph is being captured -- run an eager step of the same geometry on "
+                               "the capture stream first (ShapePoseNet does)")
         arr = (WnBwdItem * len(items))()
         max_cout = max_blocks = 1
         for i, (fields, _params, _keep) in enumerate(items):
@@ -1122,10 +1126,11 @@ class FusedConv(torch.autograd.Function):
         if ctx.need_w:
             ni_ = ctx.needs_input_grad
             all_direct = all((not ni_[3 + i]) or p_ is None or _has_direct_grad(p_) for i, p_ in enumerate(ctx.param_refs))
-            # batched weight-norm backward: not while a hipGraph is being captured (its item tables are uploaded from host
-            # memory on first use; a captured step keeps the per-layer launches -- same arithmetic, bit for bit)
+            # batched weight-norm backward.  While a hipGraph is being captured its item tables must already exist (they are
+            # uploaded from host memory on first use): the trainer runs its eager steps on the capture stream first, so
+            # that arenas, companion streams and tables are the captured step's own (_wn_flush_stream raises otherwise)
             defer_ok = (_wn_batch["on"] and ctx.prepacked and all_direct and dy.is_cuda
-                        and not torch.cuda.is_current_stream_capturing())
+                        and (_wn_batch["capture"] or not torch.cuda.is_current_stream_capturing()))
             if _wgrad_streams["on"] and all_direct and dy.is_cuda:
                 # weight gradients are off the critical path of backward (only the data gradient feeds the next
                 # layer): run wgrad + slab reduce + weight-norm backward on a companion stream; the results land in
@@ -1246,6 +1251,29 @@ class SpaceToDepth(torch.autograd.Function):
         dx = torch.empty(n, c // 4, 2 * h, 2 * w, device=dy.device, dtype=dy.dtype)
         _call("vunet_depth_to_space", _p(dy), _p(dx), n, c, h, w, _stream())
         return dx
+
+
+class CropWindow(torch.autograd.Function):
+    """y = x[:, :, oy:oy+P, ox:ox+P] with (oy, ox) read from DEVICE memory (``off``: int32[2] on the GPU): the launch
+    arguments are the same every step, so the adversarial term's random patch can be part of a captured hipGraph
+    (vunet_crop_window; the backward scatters into a zeroed tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, off, size):
+        _dev(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty(n, c, size, size, device=x.device, dtype=x.dtype)
+        _call("vunet_crop_window", _p(x), _p(y), n * c, h, w, size, _p(off), _stream())
+        ctx.off, ctx.geo = off, (n, c, h, w, size)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w, size = ctx.geo
+        dx = torch.zeros(n, c, h, w, device=dy.device, dtype=dy.dtype)
+        _call("vunet_crop_window_bwd", _p(_c(dy)), _p(dx), n * c, h, w, size, _p(ctx.off), _stream())
+        return dx, None, None
 
 
 class UpsampleBilinear2x(torch.autograd.Function):

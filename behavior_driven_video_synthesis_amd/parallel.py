@@ -7,6 +7,13 @@ gradient average -- an all-reduce per flat parameter bucket (optim.FlatBucket: d
 launched asynchronously as soon as the last gradient of the bucket has been written, so it overlaps
 with the rest of the backward pass.  ``backend="nccl"`` is RCCL on ROCm; the same code runs on gloo
 for the CPU tests.
+
+On the GPU the bucket all-reduces of a step go through the C-ABI library's own RCCL communicator
+(``vunet_dp_init`` / ``vunet_dp_allreduce_bucket``, csrc/dp_rccl.hip): torch.distributed remains the
+bootstrap -- rendezvous, the one-time parameter broadcast, the 128-byte unique id, the end-of-run consistency
+check -- while the data path of every step is an ordinary operation on the communication stream, which also makes
+it capturable in a hipGraph.  ``VUNET_DP_BACKEND=torch`` keeps the step's collectives on torch.distributed; if
+the native communicator cannot be brought up the averager says so on stderr and does the same.
 """
 from __future__ import annotations
 
@@ -43,6 +50,14 @@ class BucketedGradAverager:
         self._ready = [False] * len(self.buckets)
         self._last_fire_seq = [1 << 60] * len(self.buckets)
         self._seq = 0
+        self.native = False               # bucket all-reduces through the C-ABI RCCL communicator (GPU only)
+        self.backend = "none"
+        if self.active:
+            self.backend = "torch.distributed"
+            if self.buckets[0].grad.is_cuda and os.environ.get("VUNET_DP_BACKEND", "native") != "torch":
+                self.native = _init_native_comm(process_group)
+                if self.native:
+                    self.backend = "rccl-cabi"
         if self.active:
             from . import ops
             self._bucket_of = {}
@@ -101,13 +116,20 @@ class BucketedGradAverager:
         cur = torch.cuda.current_stream()
         ops.join_wgrad_streams()   # cur now waits for the companion streams' in-place gradient writes
         self._comm_stream.wait_stream(cur)
+        timed = not torch.cuda.is_current_stream_capturing()   # (timing events cannot be read back from a captured graph)
         with torch.cuda.stream(self._comm_stream):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            work.wait()            # stream-level: the communication stream waits for RCCL's stream, the host does not block
-            e1.record()
-        if self._events:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if self.native:
+                t.record_stream(self._comm_stream)
+                ops._call("vunet_dp_allreduce_bucket", ops._p(t), t.numel(), 0, ops._stream())
+            else:
+                work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                work.wait()        # stream-level: the communication stream waits for RCCL's stream, the host does not block
+            if timed:
+                e1.record()
+        if timed and self._events:
             self._events[-1].append((e0, e1))
 
     def start_step(self):
@@ -124,7 +146,8 @@ class BucketedGradAverager:
     def mark_backward_end(self):
         """Called by the training step right after ``loss.backward()``: a HIP event on the current stream that marks where
         backward ended, against which ``overlap_fraction`` places the collectives."""
-        if self.active and self._bwd_end and torch.cuda.is_available() and self.buckets[0].grad.is_cuda:
+        if (self.active and self._bwd_end and torch.cuda.is_available() and self.buckets[0].grad.is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self._bwd_end[-1] = ev
@@ -210,6 +233,51 @@ class BucketedGradAverager:
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=self.pg)
         return all(bool(torch.equal(g, gathered[0])) for g in gathered)
+
+
+_native_comm = {"world": 0}
+
+
+def _init_native_comm(process_group=None) -> bool:
+    """Bring up the C-ABI library's RCCL communicator over the ranks of ``process_group`` (once per process; a second
+    averager of the same world size -- the discriminator's -- shares it).  The unique id travels through torch.distributed."""
+    from . import _lib
+    lib = _lib.lib()
+    world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+    if _native_comm["world"] == world and lib.vunet_dp_world() == world:
+        return True
+    if lib.vunet_dp_world() != 0:
+        return False                      # a communicator of another shape exists already: stay on torch.distributed
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.vunet_dp_unique_id(buf) if rank == 0 else 0
+    box = [bytes(buf.raw) if rc == 0 else None]
+    src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=process_group)
+    if box[0] is None:
+        rc = -3
+    else:
+        rc = lib.vunet_dp_init(world, rank, ctypes.c_char_p(box[0]))
+    ok = torch.tensor([1 if rc == 0 else 0], device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)    # all ranks or none
+    if int(ok.item()) != 1:
+        if rc == 0:
+            lib.vunet_dp_finalize()
+        import sys
+        print(f"[vunet dp] rank {rank}: native RCCL communicator not available (code {rc}); the step's all-reduces stay on "
+              "torch.distributed", file=sys.stderr)
+        return False
+    _native_comm["world"] = world
+    return True
+
+
+def shutdown_native_comm():
+    """Destroy the C-ABI RCCL communicator (end of the run, before the process group goes away)."""
+    if _native_comm["world"]:
+        from . import _lib
+        torch.cuda.synchronize()
+        _lib.lib().vunet_dp_finalize()
+        _native_comm["world"] = 0
 
 
 def _scale_(t: torch.Tensor, a: float):

@@ -416,6 +416,32 @@ int vunet_u8_to_unit(const uint8_t* in, float* out, int64_t n, void* stream);
 int vunet_ssim_partial(const float* x, const float* y, int32_t planes, int32_t H, int32_t W, float data_range,
                        const float* window11, float* partial, void* stream);
 
+/* ---- data parallelism over RCCL.  Replaces nn.DataParallel of experiments/shape_and_pose_net.py:213-214,
+ * 223-224,230-233: one process per GPU holds a persistent replica; the only exchange of a step is the SUM of the flat
+ * gradient buckets.  RCCL is bound at run time (dlopen of librccl.so.1 -- the instance PyTorch mapped, if any); without it
+ * these return VUNET_ERR_UNSUPPORTED.  Bootstrap: rank 0 calls vunet_dp_unique_id and hands the 128 bytes to every rank
+ * through any side channel (the host mirror uses the torch.distributed store it was launched with); every rank then calls
+ * vunet_dp_init(world, rank, id) with its GPU current (collective: returns when all ranks have joined).
+ *   vunet_dp_allreduce_bucket  in-place ncclAllReduce(ncclFloat, ncclSum or ncclAvg) of n floats on `stream`: asynchronous,
+ *                              ordered like a kernel launch on that stream, capturable in a hipGraph; every rank must issue
+ *                              its buckets in the same order.
+ *   vunet_dp_world             ranks of the communicator, 0 before init / after finalize.
+ *   vunet_dp_finalize          destroys the communicator (idempotent). */
+int vunet_dp_unique_id(void* id128);
+int vunet_dp_init(int32_t world, int32_t rank, const void* id128);
+int vunet_dp_world(void);
+int vunet_dp_allreduce_bucket(float* buf, int64_t n, int32_t average, void* stream);
+int vunet_dp_finalize(void);
+
+/* Square window of a batch of maps with its corner read from DEVICE memory (the adversarial term's patch: one random
+ * (P x P) window per step, experiments' gan option): y[n][c][i][j] = x[n][c][off[0] + i][off[1] + j], off = int32[2] on the
+ * device -- the launch arguments do not change from step to step, so the crop can sit in a captured hipGraph.
+ * vunet_crop_window_bwd scatters dy back into a ZEROED dx of x's shape (it writes the window only). */
+int vunet_crop_window(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t P, const int32_t* off,
+                      void* stream);
+int vunet_crop_window_bwd(const float* dy, float* dx, int32_t planes, int32_t H, int32_t W, int32_t P, const int32_t* off,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ def test_bench_under_torchrun_with_forced_dp_path():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
     assert out["config"]["rccl_world_size"] == 1 and out["config"]["allreduce_ms_per_step"] > 0   # events on the comm stream
+    assert out["config"]["dp_backend"] == "rccl-cabi"      # the step's all-reduces went through vunet_dp_allreduce_bucket
 
 
 def test_bench_entry_point_starts_its_own_ranks():
@@ -62,5 +63,28 @@ def test_forced_one_rank_rccl_run_equals_the_plain_run(tmp_path):
     a, b = torch.load(os.path.join(out, "rank0.pt")), torch.load(os.path.join(out, "single.pt"))
     assert a["allreduce_ms"] is not None and b["allreduce_ms"] is None
     assert a["losses"] == b["losses"] and a["gamma"] == b["gamma"]
+    for x, y in zip(a["flat"], b["flat"]):
+        assert torch.equal(x, y)
+
+
+def test_captured_step_with_rccl_allreduces_equals_the_eager_one(tmp_path):
+    """The data-parallel step replayed from ONE hipGraph -- bucket all-reduces on the C-ABI RCCL communicator, communication
+    stream forked and joined inside the capture -- against the same device-resident schedule launched eagerly: parameters,
+    losses and gamma bit-identical after 9 steps (the capture happens at step 4, five replays follow)."""
+    import torch
+    env = dict(os.environ, VUNET_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = os.path.join(ROOT, "tools", "dp_check.py")
+    res = {}
+    for mode, port in (("capture", "29523"), ("eager", "29525")):
+        out = str(tmp_path / mode)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                            "--master-addr", "127.0.0.1", "--master-port", port, script, "--out", out, "--steps", "9",
+                            "--graph", mode], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = torch.load(os.path.join(out, "rank0.pt"))
+    a, b = res["capture"], res["eager"]
+    assert a["backend"] == b["backend"] == "rccl-cabi" and a["graphs"] == 1 and b["graphs"] == 0
+    assert a["losses"] == b["losses"] and a["gamma"] == b["gamma"]
+    assert len(set(a["losses"])) == len(a["losses"])
     for x, y in zip(a["flat"], b["flat"]):
         assert torch.equal(x, y)

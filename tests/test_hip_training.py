@@ -275,13 +275,15 @@ def test_shape_pose_net_l2_conv_variant_initialises_and_trains():
     assert float(outs[-1]["likelihood_loss"]) < float(out1["likelihood_loss"]) * 1.5
 
 
-def _graph_run(capture, steps, with_regressor=False, dropout=0.05, seed=4321):
+def _graph_run(capture, steps, with_regressor=False, dropout=0.05, seed=4321, gan=False):
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
                                                                                      synthetic_batch)
     ops.set_dropout_seed(seed)
     cfg = _tiny(DEFAULT_CONFIG, lr=2e-3, n_init_batches=1, gamma_step=1e-3, information_max=5.0,
                 train_regressor=with_regressor, dropout_prob=dropout, imax_scaling="ascend")
+    if gan:
+        cfg["training"]["gan"] = dict(enabled=True, weight=1.0, pd_scales=2, lr=2e-3)
     tr = ShapePoseNet(cfg, device="cuda:0", vgg_width_div=8, total_steps=50, vgg_synthetic=True, hip_graph=False)
     if capture is not None:
         tr.enable_hip_graph(capture=capture)
@@ -295,7 +297,7 @@ def _graph_run(capture, steps, with_regressor=False, dropout=0.05, seed=4321):
             batch["reg_targets"] = torch.rand(4, 2, 17, 2, generator=g).cuda()
         o = tr.train_fn(batch)
         outs.append({k: float(v) for k, v in o.items() if k in ("loss", "kl_loss", "gamma", "learning_rate", "imax",
-                                                                 "loss_reg")})
+                                                                 "loss_reg", "gen_loss", "dloss", "dloss_r", "dloss_f")})
     torch.cuda.synchronize()
     ops.set_dropout_step(None)
     return tr, outs
@@ -324,6 +326,23 @@ def test_hip_graph_replay_is_bit_identical_to_eager(with_regressor):
         for (k, p), (_, q) in zip(a.regressor.state_dict().items(), b.regressor.state_dict().items()):
             assert torch.equal(p, q), k
         assert float(sa["regressor"]["optimizer"]["state"][0]["step"]) == 14.0
+
+
+def test_hip_graph_replay_with_the_adversarial_term():
+    """the step WITH the adversarial term -- generator loss through the PartDiscriminator on a random window
+    whose corner is read from device memory (ops.CropWindow), one discriminator step with its own fused Adam -- replayed
+    from the captured multi-stream graph against the same schedule launched eagerly: bit-identical losses, generator and
+    discriminator parameters after 7 steps (4 replays, a fresh window and batch per step)."""
+    a, oa = _graph_run(True, 7, gan=True)
+    assert len(a._graphs) == 1
+    b, ob = _graph_run(False, 7, gan=True)
+    assert oa == ob, (oa, ob)
+    assert all("dloss" in o and "gen_loss" in o for o in oa) and len({o["dloss"] for o in oa}) == len(oa)
+    for (k, p), (_, q) in zip(a.vunet.state_dict().items(), b.vunet.state_dict().items()):
+        assert torch.equal(p, q), k
+    for (k, p), (_, q) in zip(a.gan.disc.state_dict().items(), b.gan.disc.state_dict().items()):
+        assert torch.equal(p, q), k
+    assert float(a.state_dict()["discriminator"]["opt"]["state"][0]["step"]) == 7.0
 
 
 def test_device_schedule_matches_the_host_schedule():

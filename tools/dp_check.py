@@ -28,6 +28,9 @@ ap.add_argument("--world", type=int, default=0, help="--single: the world size w
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch", type=int, default=2, help="per-rank batch")
 ap.add_argument("--size", type=int, default=64)
+ap.add_argument("--graph", choices=["off", "capture", "eager"], default="off",
+                help="device-resident schedule: the step replayed from a captured hipGraph (all-reduces inside) / the same "
+                     "schedule launched eagerly; posterior noise then comes from torch's generator (seeded per run)")
 a = ap.parse_args()
 
 world = a.world if a.single else int(os.environ["WORLD_SIZE"])
@@ -47,6 +50,9 @@ cfg["training"].update(dropout_prob=0.0, train_regressor=False, n_init_batches=1
                        information_max=5.0)
 with contextlib.redirect_stdout(sys.stderr):
     tr = ShapePoseNet(cfg, device=dev, vgg_width_div=8, total_steps=100, vgg_synthetic=True)   # same seed on every rank
+if a.graph != "off":
+    tr.enable_hip_graph(capture=(a.graph == "capture"))
+    torch.manual_seed(4242 + rank)
 nlat = cfg["architecture"]["n_latent_scales"]
 lat = [(32, a.size // 2 ** (tr.vunet.n_scales - 1 - i)) for i in range(nlat)]   # (channels, width) of the latent scales
 
@@ -64,16 +70,19 @@ losses = []
 for step in range(a.steps):
     x, c, eps = global_batch(step)
     sl = slice(0, world * a.batch) if a.single else slice(rank * a.batch, (rank + 1) * a.batch)
-    out = tr.train_fn({"pose_img": x[sl].to(dev), "stickman": c[sl].to(dev)}, [e[sl].to(dev) for e in eps])
+    out = tr.train_fn({"pose_img": x[sl].to(dev), "stickman": c[sl].to(dev)},
+                      None if a.graph != "off" else [e[sl].to(dev) for e in eps])
     losses.append(float(out["loss"]))
 torch.cuda.synchronize()
 sd = tr.vunet.state_dict()
 res = {"losses": losses, "gamma": float(tr.gamma),
        "sums": {k: float(v.double().sum()) for k, v in sd.items()},
        "tensor": sd["dd.out_conv.conv.weight_v"].cpu(), "flat": [b.flat.cpu() for b in tr.optimizer.buckets],
-       "allreduce_ms": tr.averager.mean_allreduce_ms()}
+       "allreduce_ms": tr.averager.mean_allreduce_ms(), "backend": tr.averager.backend, "graphs": len(tr._graphs)}
 os.makedirs(a.out, exist_ok=True)
 torch.save(res, os.path.join(a.out, "single.pt" if a.single else f"rank{rank}.pt"))
 if dist.is_initialized():
+    from behavior_driven_video_synthesis_amd.parallel import shutdown_native_comm
     dist.barrier()
+    shutdown_native_comm()
     dist.destroy_process_group()
