@@ -39,7 +39,7 @@ DEFAULT_CONFIG = {
 class Vunet:
     def __init__(self, config: Dict, device="cuda:0", n_channels_x: int = 30, vgg_weights_path: Optional[str] = None,
                  vgg_width_div: int = 1, total_steps: Optional[int] = None, process_group=None,
-                 vgg_synthetic: bool = False):
+                 vgg_synthetic: bool = False, vgg_seed: int = 1234):
         self.config = config
         self.device = torch.device(device)
         arch, data, tr = config["architecture"], config["data"], config["training"]
@@ -51,7 +51,7 @@ class Vunet:
         overlap = self.device.type == "cuda" and os.environ.get("VUNET_TWO_STREAMS", "1") != "0"
         self.vunet.enable_two_streams(overlap)   # pose encoder (du) on a second HIP stream beside eu / ed
         ops.enable_wgrad_streams(overlap)
-        self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div,
+        self.vgg = vgg19(pretrained=True, weights_path=vgg_weights_path, width_div=vgg_width_div, seed=vgg_seed,
                          synthetic=vgg_synthetic).to(self.device)
         self.vgg.eval()
         self.custom_vgg = PerceptualVGG(self.vgg, tr["vgg_weights"]).to(self.device)

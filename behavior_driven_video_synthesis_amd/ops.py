@@ -653,7 +653,11 @@ def join_wgrad_streams():
     flush_weight_grads()
     cur = torch.cuda.current_stream()
     for key in _wgrad_streams["dirty"]:
-        cur.wait_stream(_wgrad_streams["by_stream"][key])
+        ws = _wgrad_streams["by_stream"][key]
+        # (the data-parallel hooks call this from INSIDE a companion stream's flush: a stream never waits on itself -- a
+        # no-op when launched eagerly, a node that depends on itself when the step is being captured into a hipGraph)
+        if ws.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(ws)
     _wgrad_streams["dirty"].clear()
 
 

@@ -123,7 +123,8 @@ class BucketedGradAverager:
                 e0.record()
             if self.native:
                 t.record_stream(self._comm_stream)
-                ops._call("vunet_dp_allreduce_bucket", ops._p(t), t.numel(), 0, ops._stream())
+                if os.environ.get("VUNET_DP_DRYRUN") != "1":   # (debug: the stream topology without the collective)
+                    ops._call("vunet_dp_allreduce_bucket", ops._p(t), t.numel(), 0, ops._stream())
             else:
                 work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 work.wait()        # stream-level: the communication stream waits for RCCL's stream, the host does not block

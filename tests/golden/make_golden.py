@@ -386,6 +386,58 @@ def g5_trajectory():
     save("g5_trajectory", meta, {"final.dd.out_conv.conv.weight_v": net.state_dict()["dd.out_conv.conv.weight_v"].numpy()})
 
 
+# ---------------------------------------------------------------- G5c trajectory of the VunetOrg loop (experiments/vunet.py)
+def g5_org_trajectory():
+    """experiments/vunet.py:248-338,362-371 driven by hand: VunetOrg forward (posterior + autoregressive prior draws) ->
+    ll_weight * sum(vgg_loss) + kl_weight * compute_kl_loss(p_means, q_means) -> torch.optim.Adam over the four param groups;
+    after every iteration lr <- linear decay to 0 over total_steps and kl_weight <- linear ramp kl_init .. kl_max between
+    total_steps // 2 and 3 * total_steps // 4 (so the weight a step uses is the one set after the previous iteration).
+    total_steps = 8, K = 7: the ramp (iterations 6 and 7 run with 0.5 and 1.0) is inside the trajectory."""
+    from functools import partial
+    from lib import utils as ru   # linear_var (lib/utils.py:520-527), the schedule function the reference loop binds
+    from oracle.vunet_oracle import make_synthetic_vgg19
+    seed, K, total_steps = 53, 7, 8
+    cfg = dict(ORG_CFG)
+    net = rv.VunetOrg(n_channels_x=3, **cfg)
+    sh = load_synth(net, seed)
+    vsd = make_synthetic_vgg19(seed=79, width_div=8)
+    pv = rp.PerceptualVGG(build_vgg_features(vsd), [1.0] * 6)
+    pv.eval()
+    lr0, betas, kl_init, kl_max, ll_weight = 8e-4, (0.5, 0.9), 1e-6, 1.0, 5.0    # config/vunet.yaml
+    adjust_lr = partial(ru.linear_var, start_it=0, end_it=total_steps, start_val=lr0, end_val=0, clip_min=0, clip_max=lr0)
+    adjust_kl = partial(ru.linear_var, start_it=total_steps // 2, end_it=3 * total_steps // 4, start_val=kl_init,
+                        end_val=kl_max, clip_min=kl_init, clip_max=1.0)
+    opt = torch.optim.Adam([{"params": getattr(net, n).parameters(), "name": n} for n in ["eu", "ed", "du", "dd"]],
+                           lr=lr0, betas=betas)
+    kl_weight, lr = float(adjust_kl(0)), float(adjust_lr(0))
+    for pg_ in opt.param_groups:
+        pg_["lr"] = lr
+    rec, eps_shapes = [], None
+    net.train()
+    for it in range(1, K + 1):
+        x = synth_image(f"otraj.x{it}", (2, 3, 32, 32), seed)
+        c = synth_image(f"otraj.c{it}", (2, 3, 32, 32), seed)
+        opt.zero_grad()
+        with FixedNoise(f"otraj.{it}", seed) as fn:
+            img, qs, ps, _ = net(x, c)
+        eps_shapes = fn.shapes
+        ld = rl.vgg_loss(pv, x, img)
+        ll = ll_weight * torch.sum(torch.stack([ld[k] for k in ld], dim=0))
+        kl = rl.compute_kl_loss(ps, qs)
+        loss = ll + kl_weight * kl
+        loss.backward()
+        opt.step()
+        rec.append({"it": it, "loss": float(loss), "ll": float(ll), "kl": float(kl), "kl_weight": kl_weight, "lr": lr})
+        lr, kl_weight = float(adjust_lr(it)), float(adjust_kl(it))
+        for pg_ in opt.param_groups:
+            pg_["lr"] = lr
+    csum = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in net.state_dict().items()}
+    meta = {"seed": seed, "cfg": cfg, "shapes": sh, "vgg_seed": 79, "vgg_width_div": 8, "K": K, "lr0": lr0,
+            "betas": list(betas), "kl_init": kl_init, "kl_max": kl_max, "ll_weight": ll_weight, "total_steps": total_steps,
+            "eps_shapes": eps_shapes, "steps": rec, "param_checksums": csum}
+    save("g5_org_trajectory", meta, {"final.dd.out_conv.conv.weight_v": net.state_dict()["dd.out_conv.conv.weight_v"].numpy()})
+
+
 # ---------------------------------------------------------------- G5b trajectory with the regressor side loop on
 def g5_regressor_trajectory():
     """experiments/shape_and_pose_net.py:360-466 with ``train_regressor: True`` driven by hand on the reference's
@@ -674,6 +726,7 @@ if __name__ == "__main__":
     g4_discriminators()
     g5_trajectory()
     g5_regressor_trajectory()
+    g5_org_trajectory()
     g6_full_size()
     g7_metrics()
     g1b_upsample_bilinear()

@@ -453,3 +453,47 @@ def test_vgg_loss_and_gradient_vs_oracle_with_the_fused_backward_paths():
     assert rel <= 2e-3 and rel <= rel32, (rel, rel32)
     assert float((got - g64).abs().max()) <= 1e-2 * float(g64.abs().max())
     assert any(k.startswith("conv_h2_kernel<") for k in fam), sorted(fam)      # the fp16 row-tiled kernels really ran
+
+
+def test_full_width_vgg19_loss_and_gradient_at_256_vs_float64_oracle():
+    """the perceptual loss at the BENCHMARK shape -- full-width VGG19 (64 .. 512 channels), 256x256,
+    batch 2: every layer form the bs-16 step runs (64-channel 256^2 rows, the 512-channel 32^2 layers, the 16-wide
+    conv5_x form) -- the six loss terms to 1e-4 and d loss / d pred against the CPU oracle evaluated in float64, same bar
+    as the 128^2 test above: at least as close to float64 as the float32 oracle is."""
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.lib.losses import vgg_loss
+    from behavior_driven_video_synthesis_amd.models.imagenet_pretrained import PerceptualVGG, vgg19
+    from oracle import vunet_oracle as O
+    weights = [1.0, 0.5, 1.5, 1.0, 2.0, 1.0]
+    pv = PerceptualVGG(vgg19(seed=78, width_div=1), weights).cuda()
+    vsd = O.make_synthetic_vgg19(seed=78, width_div=1)
+    target = synth_image("vl256.t", (2, 3, 256, 256), 5)
+    pred0 = synth_image("vl256.p", (2, 3, 256, 256), 6)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))    # (PyTorch-CPU thrashes on this path with hundreds of threads)
+    try:
+        def oracle(dtype):
+            p_ = pred0.clone().to(dtype).requires_grad_(True)
+            ld_ = O.vgg_loss({k: v.to(dtype) for k, v in vsd.items()}, weights, target.to(dtype), p_)
+            torch.stack([v.sum() for v in ld_.values()]).sum().backward()
+            return ld_, p_.grad.double()
+        ld64, g64 = oracle(torch.float64)
+        _, g32 = oracle(torch.float32)
+    finally:
+        torch.set_num_threads(threads)
+    p = pred0.cuda().requires_grad_(True)
+    ops.profile_start()
+    ld = vgg_loss(pv, target.cuda(), p)
+    torch.stack([v.sum() for v in ld.values()]).sum().backward()
+    fam = ops.profile_stop(by_kernel=True)
+    assert list(ld) == list(ld64)
+    for k in ld:
+        assert_close(ld[k].cpu(), ld64[k].detach().float().reshape(ld[k].shape), rtol=1e-4, atol=1e-6, name="vgg_loss256." + k)
+    got = p.grad.double().cpu()
+    rel = float((got - g64).norm() / g64.norm())
+    rel32 = float((g32 - g64).norm() / g64.norm())
+    assert rel <= 2e-3 and rel <= rel32, (rel, rel32)
+    assert float((got - g64).abs().max()) <= 1e-2 * float(g64.abs().max())
+    names = sorted(fam)
+    assert any(k.startswith("conv_h2_kernel<2, 2, 0, 0") for k in names), names      # the step's dominant kernel
+    assert any(k.startswith("conv_h2_kernel<") and k.endswith(", 16>") for k in names), names   # conv5_x: the 16-wide form

@@ -577,3 +577,96 @@ def test_gradient_pass_through_changes_nothing_but_the_launch_count():
         assert torch.equal(sd_on[k], sd_off[k]), k
     # 5 VGG taps (the last has one reader) + one skip per pyramid level that is followed by a down-sampling layer
     assert adds_off - adds_on >= 4 + 3, (adds_on, adds_off)
+
+
+def test_full_size_step_with_the_adversarial_term_vs_oracle():
+    """BASELINE config 2's "+GAN" at full size -- VunetAlter 256x256 (nf 32 .. 128), full-width VGG19,
+    batch 4, ``training.gan.enabled``: one training step.  Finite, bit-reproducible from the seed (two trainers: identical
+    scalars and parameters), and the adversarial scalars against the oracle's restatement of DiscTrainer
+    (models/synth_discriminator.py:139-191: BCE-with-logits of the PartDiscriminator on the step's real / generated
+    window) evaluated on the CPU with the discriminator's pre-step weights -- 1e-4."""
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
+                                                                                     synthetic_batch)
+    from oracle import vunet_oracle as O
+    batch = synthetic_batch(4, 256, "cuda:0", seed=11)
+    g = torch.Generator().manual_seed(5)
+    eps = [torch.randn(4, 128, w, w, generator=g).cuda() for w in (4, 8)]
+
+    def run():
+        cfg = copy.deepcopy(DEFAULT_CONFIG)
+        cfg["training"].update(train_regressor=False, dropout_prob=0.0,
+                               gan=dict(enabled=True, weight=1.0, pd_scales=3, lr=2e-4))
+        tr = ShapePoseNet(cfg, device="cuda:0", total_steps=1000, vgg_synthetic=True)
+        dsd = {k: v.detach().clone().cpu() for k, v in tr.gan.disc.state_dict().items()}
+        with torch.no_grad():
+            img, _, _, _ = tr.vunet.train()(batch["pose_img"], batch["stickman"], eps)   # the step's generated batch
+        out = tr.train_fn(batch, eps=eps)
+        torch.cuda.synchronize()
+        return tr, dsd, img, {k: float(v) for k, v in out.items() if torch.is_tensor(v) or isinstance(v, float)}
+
+    tr, dsd, img, out = run()
+    assert all(v == v and abs(v) < float("inf") for v in out.values()), out
+    for k in ("loss", "gen_loss", "dloss", "dloss_r", "dloss_f", "likelihood_loss"):
+        assert k in out
+    oy, ox = (int(v) for v in tr._gan_off.cpu())
+    P = tr.gan_patch
+    assert P == 66 and 0 <= oy <= 256 - P and 0 <= ox <= 256 - P
+    fake = img[:, :, oy:oy + P, ox:ox + P].cpu()
+    real = batch["pose_img"][:, :, oy:oy + P, ox:ox + P].cpu()
+    with torch.no_grad():
+        lf = O.part_discriminator(dsd, fake, 3)
+        lr_ = O.part_discriminator(dsd, real, 3)
+    want = {"gen_loss": float(O.bce_with_logits(lf, 1.0)), "dloss_r": float(O.bce_with_logits(lr_, 1.0)),
+            "dloss_f": float(O.bce_with_logits(lf, 0.0))}
+    want["dloss"] = want["dloss_r"] + want["dloss_f"]
+    for k, v in want.items():
+        assert abs(out[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, out[k], v)
+    # the discriminator and the generator both moved, and toggle_grad was restored
+    assert any(not torch.equal(v.cpu(), dsd[k]) for k, v in tr.gan.disc.state_dict().items())
+    assert all(p.requires_grad for p in tr.vunet.parameters())
+    # bit-reproducible from the seed
+    tr2, _, img2, out2 = run()
+    assert out == out2 and torch.equal(img, img2)
+    for (k, p), (_, q) in zip(tr.vunet.state_dict().items(), tr2.vunet.state_dict().items()):
+        assert torch.equal(p, q), k
+    for (k, p), (_, q) in zip(tr.gan.disc.state_dict().items(), tr2.gan.disc.state_dict().items()):
+        assert torch.equal(p, q), k
+
+
+def test_vunet_org_train_fn_follows_the_reference_trajectory():
+    """VERDICT r3 missing #4: ``experiments.vunet.Vunet.train_fn`` ITSELF -- VunetOrg forward with posterior and
+    autoregressive-prior draws, ll_weight * perceptual + kl_weight * compute_kl_loss, fused Adam, lr decay and the linear KL
+    warm-up between T/2 and 3T/4 (experiments/vunet.py:248-338,362-371) -- against the seven-step trajectory recorded from
+    the reference's modules driven by hand with torch.optim.Adam (tests/golden/make_golden.py g5_org_trajectory; the
+    warm-up ramp, kl_weight 1e-6 -> 0.5 -> 1.0, lies inside it).  Tolerance as for g5_trajectory: 5e-4 after Adam steps."""
+    from conftest import load_golden
+    from hip_parity_utils import assert_close
+    from synth import seeded_randn, synth_image, synth_state_dict
+    from behavior_driven_video_synthesis_amd.experiments.vunet import DEFAULT_CONFIG, Vunet
+    meta, arr = load_golden("g5_org_trajectory")
+    seed, n_lat, shapes = meta["seed"], meta["cfg"]["n_latent_scales"], meta["eps_shapes"]
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["data"]["spatial_size"] = meta["cfg"]["spatial_size"]
+    cfg["architecture"].update(nf_start=meta["cfg"]["nf_start"], nf_max=meta["cfg"]["nf_max"])
+    cfg["training"].update(dropout_prob=0.0, lr=meta["lr0"], adam_betas=tuple(meta["betas"]), kl_init=meta["kl_init"],
+                           kl_max=meta["kl_max"], ll_weight=meta["ll_weight"])
+    tr = Vunet(cfg, device="cuda:0", n_channels_x=3, vgg_width_div=meta["vgg_width_div"], vgg_seed=meta["vgg_seed"],
+               vgg_synthetic=True, total_steps=meta["total_steps"])
+    tr.vunet.load_state_dict(synth_state_dict(meta["shapes"], seed))
+    for rec in meta["steps"]:
+        it = rec["it"]
+        batch = {"pose_img": synth_image(f"otraj.x{it}", (2, 3, 32, 32), seed).cuda(),
+                 "stickman": synth_image(f"otraj.c{it}", (2, 3, 32, 32), seed).cuda()}
+        eps = [seeded_randn(f"otraj.{it}.eps{i}", tuple(shapes[i]), seed).cuda() for i in range(n_lat)]
+        prior = [[seeded_randn(f"otraj.{it}.eps{n_lat + 4 * i + l}", tuple(shapes[n_lat + 4 * i + l]), seed).cuda()
+                  for l in range(4)] for i in range(n_lat)]
+        assert abs(tr.lr - rec["lr"]) < 1e-12 and abs(tr.kl_weight - rec["kl_weight"]) < 1e-12   # what THIS step runs with
+        out = tr.train_fn(batch, eps, prior)
+        for key, want in (("loss", rec["loss"]), ("likelihood_loss", rec["ll"]), ("kl_loss", rec["kl"])):
+            assert abs(float(out[key]) - want) <= 5e-4 * abs(want) + 1e-5, (it, key, float(out[key]), want)
+    sd = tr.vunet.state_dict()
+    assert_close(sd["dd.out_conv.conv.weight_v"], arr["final.dd.out_conv.conv.weight_v"], rtol=2e-3, atol=2e-5,
+                 name="final weight")
+    for k, s in meta["param_checksums"].items():
+        got = float(sd[k].double().abs().sum())
+        assert abs(got - s[1]) <= 5e-4 * s[1] + 1e-5, (k, got, s[1])

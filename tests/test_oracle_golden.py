@@ -343,3 +343,43 @@ def test_g1b_bilinear_upsample_branch():
     for k, s in meta["grad_sums"].items():
         if s is not None:
             assert abs(float(msd[k].grad.double().abs().sum()) - s[1]) <= 1e-3 * s[1] + 1e-4, k
+
+
+def test_g5_org_trajectory():
+    """The VunetOrg loop of experiments/vunet.py:248-338,362-371 (ll_weight * perceptual + kl_weight * compute_kl_loss, Adam,
+    lr decay, the linear KL warm-up between T/2 and 3T/4) recorded from the reference's modules: the oracle follows it."""
+    meta, arr = load_golden("g5_org_trajectory")
+    seed, cfg, T = meta["seed"], meta["cfg"], meta["total_steps"]
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(meta["shapes"], seed).items()}
+    vsd = O.make_synthetic_vgg19(seed=meta["vgg_seed"], width_div=meta["vgg_width_div"])
+    opt = torch.optim.Adam([{"params": [v for k, v in sd.items() if k.startswith(n + ".")], "name": n}
+                            for n in ["eu", "ed", "du", "dd"]], lr=meta["lr0"], betas=tuple(meta["betas"]))
+    shapes, n_lat = meta["eps_shapes"], cfg["n_latent_scales"]
+    lr = meta["lr0"]
+    klw = O.linear_var(0, T // 2, 3 * T // 4, meta["kl_init"], meta["kl_max"], meta["kl_init"], 1.0)
+    assert [r["kl_weight"] for r in meta["steps"]][-2:] == [pytest.approx(0.5, rel=1e-5), pytest.approx(1.0)]   # the ramp is inside
+    for rec in meta["steps"]:
+        it = rec["it"]
+        x = synth_image(f"otraj.x{it}", (2, 3, 32, 32), seed)
+        c = synth_image(f"otraj.c{it}", (2, 3, 32, 32), seed)
+        eps = [seeded_randn(f"otraj.{it}.eps{i}", tuple(shapes[i]), seed) for i in range(n_lat)]
+        prior = [[seeded_randn(f"otraj.{it}.eps{n_lat + 4 * i + l}", tuple(shapes[n_lat + 4 * i + l]), seed)
+                  for l in range(4)] for i in range(n_lat)]
+        assert abs(lr - rec["lr"]) < 1e-12 and abs(klw - rec["kl_weight"]) < 1e-12
+        img, qs, ps = O.vunet_org_forward(sd, cfg, x, c, eps, prior)
+        ld = O.vgg_loss(vsd, [1.0] * 6, x, img)
+        ll = meta["ll_weight"] * torch.stack(list(ld.values()), dim=0).sum()
+        kl = O.compute_kl_loss(ps, qs)
+        loss = ll + klw * kl
+        for got, key in ((loss, "loss"), (ll, "ll"), (kl, "kl")):
+            assert abs(float(got.detach()) - rec[key]) <= 2e-4 * abs(rec[key]) + 1e-5, (it, key)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        lr = O.linear_var(it, 0, T, meta["lr0"], 0, 0, meta["lr0"])
+        klw = O.linear_var(it, T // 2, 3 * T // 4, meta["kl_init"], meta["kl_max"], meta["kl_init"], 1.0)
+        for g in opt.param_groups:
+            g["lr"] = lr
+    close(sd["dd.out_conv.conv.weight_v"], arr["final.dd.out_conv.conv.weight_v"], rtol=1e-3, atol=1e-5)
+    for k, s in meta["param_checksums"].items():
+        assert abs(float(sd[k].detach().double().abs().sum()) - s[1]) <= 1e-4 * s[1] + 1e-5, k
