@@ -364,7 +364,9 @@ int vunet_wgrad_x6_nslabs(const vunet_wgrad_desc* d) {
   // 512 workgroups = exactly the two resident per CU, one round: measured best with the fp16 kernel (r02: 1024 -> 512:
   // conv_wgrad_h2_kernel<2> 2.08 -> 1.87 ms per step, half the slab volume for the reduce; 768 and 256 are worse)
   static const int target = [] { const char* e = getenv("VUNET_WGRAD_SPLIT_WGS"); return e ? atoi(e) : 512; }();   // tuning
-  int S = target / (ciblocks * coblocks);
+  // (fp16 scheme, round 4: a workgroup is 512 threads -- two groups in antiphase, conv_wgrad_h2.hip -- so ONE workgroup per
+  // CU is resident: half the workgroups, each walking twice the tiles, half the slab volume again)
+  int S = ((d->flags & 2) ? target / 2 : target) / (ciblocks * coblocks);
   if (S > ntiles / 2) S = ntiles / 2;
   if (S < 1) S = 1;
   if (S > 512) S = 512;
