@@ -59,6 +59,25 @@ __device__ __forceinline__ float apply_in_act(const InAct& a, float v, uint32_t 
   return v;
 }
 
+// The same prologue as STRAIGHT-LINE code for the forms the models use (FORM: 0 none, 1 ELU, 2 ELU + dropout, 3 whatever the
+// descriptor says = apply_in_act).  apply_in_act branches on the activation code and the dropout threshold per ELEMENT; a
+// staging loop that calls it is dominated by scalar branches (conv_wgrad_h2.hip, round 4: 358 of them, 3.0 - 3.4 us per
+// tile against 2.6 us for the tile's MFMAs).  Kernels pick the form once per launch (in_act_form_of, wave-uniform) and
+// instantiate their staging code per form behind that one branch.  The argument must have been resolved (inact_resolve).
+template <int FORM>
+__device__ __forceinline__ float in_act_form(const InAct& a, float v, uint32_t idx) {
+  if constexpr (FORM == 0) return v;
+  else if constexpr (FORM == 1) return elu_f(v);
+  else if constexpr (FORM == 2) {
+    v = elu_f(v);
+    return (vunet_hash_u32(idx + a.seed) >= a.thresh) ? v * a.keep_scale : 0.f;
+  } else return apply_in_act(a, v, idx);
+}
+__device__ __forceinline__ int in_act_form_of(const InAct& a) {
+  if (a.thresh) return a.act == ACT_ELU ? 2 : 3;
+  return a.act == ACT_NONE ? 0 : (a.act == ACT_ELU ? 1 : 3);
+}
+
 // d/dv of apply_in_act evaluated at the pre-activation value v
 __device__ __forceinline__ float in_act_grad(const InAct& a, float v, uint32_t idx) {
   float g = 1.f;

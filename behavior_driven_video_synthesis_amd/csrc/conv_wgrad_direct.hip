@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float dsum = 0.f;
 
+  const int pro_form = in_act_form_of(a.in1);   // (wave-uniform; the two sources differ in the dropout seed only)
   const int o_begin = split * a.ops, o_end = min(o_begin + a.ops, a.noct);
   // (1x1: four K steps unrolled, so that their loads -- the whole cost of this HBM-bound case -- are in flight together)
 #pragma unroll(T == 1 ? 4 : 1)
@@ -143,9 +144,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
     }
 
     // ---- B source: R input rows x L columns of channel ci, prologue applied, scaled; seg[rr][0] is input column
-    //      S * c0 - 1 (the left halo), rows start at S * r0 - 1
+    //      S * c0 - 1 (the left halo), rows start at S * r0 - 1.  The prologue as straight-line code, one instantiation per
+    //      form behind a wave-uniform branch (common.h: in_act_form; out-of-range elements are zeroed BEFORE it and scaled
+    //      by 0 -- "ok ? f(v) * sx : 0" puts every element's prologue in an exec-mask block of its own).
     float seg[R][L];
-    {
+    auto stage = [&](auto pro_c) {
+      constexpr int PRO = decltype(pro_c)::value;
       const uint32_t cbase = (uint32_t)(n * Cs + cl) * (uint32_t)HW;
       const float* xp = xs + cbase;
 #pragma unroll
@@ -153,13 +157,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
         const int ih = T == 1 ? 0 : S * r0 - 1 + rr + krow;
         const bool rok = ov && ci_ok && (T == 1 || (unsigned)ih < (unsigned)H);
         const int ihc = rok ? ih : 0;
+        const float sxr = rok ? sx : 0.f;
         if (T == 1) {
           const uint32_t off = (uint32_t)c0;
           const wd_f32x4 v0 = *reinterpret_cast<const wd_f32x4*>(xp + off), v1 = *reinterpret_cast<const wd_f32x4*>(xp + off + 4);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float t_ = e < 4 ? v0[e] : v1[e - 4];
-            seg[rr][e] = rok ? apply_in_act(ia, t_, cbase + off + e) * sx : 0.f;
+            seg[rr][e] = in_act_form<PRO>(ia, rok ? t_ : 0.f, cbase + off + e) * sxr;
           }
         } else {
           constexpr int NV = (L - 2) / 4;      // aligned 16-byte loads per row: columns S*c0 .. S*c0 + 4*NV - 1
@@ -170,14 +175,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
           const bool lok = rok && c0 > 0, hok = rok && S == 1 && S * c0 + 4 * NV < W;
           const float lv = xp[lok ? off - 1 : off];
           const float hv = xp[hok ? off + 4 * NV : off];
-          seg[rr][0] = lok ? apply_in_act(ia, lv, cbase + off - 1) * sx : 0.f;
+          seg[rr][0] = in_act_form<PRO>(ia, lok ? lv : 0.f, cbase + off - 1) * (lok ? sx : 0.f);
 #pragma unroll
           for (int e = 0; e < 4 * NV; ++e)
-            seg[rr][1 + e] = rok ? apply_in_act(ia, v[e >> 2][e & 3], cbase + off + e) * sx : 0.f;
-          seg[rr][L - 1] = hok ? apply_in_act(ia, hv, cbase + off + 4 * NV) * sx : 0.f;
+            seg[rr][1 + e] = in_act_form<PRO>(ia, rok ? v[e >> 2][e & 3] : 0.f, cbase + off + e) * sxr;
+          seg[rr][L - 1] = in_act_form<PRO>(ia, hok ? hv : 0.f, cbase + off + 4 * NV) * (hok ? sx : 0.f);
         }
       }
-    }
+    };
+    if (pro_form == 2) stage(std::integral_constant<int, 2>{});
+    else if (pro_form == 1) stage(std::integral_constant<int, 1>{});
+    else if (pro_form == 0) stage(std::integral_constant<int, 0>{});
+    else stage(std::integral_constant<int, 3>{});
 
     // ---- nine taps: fragment = 8 elements selected from the rows, split, three products
 #pragma unroll

@@ -94,20 +94,10 @@ __device__ __forceinline__ void wg_dma4(const void* gsrc, uint32_t lds_addr) {
                : "memory");
 }
 
-// Prologue f(x) as straight-line code (PRO: 0 none, 1 ELU, 2 ELU + dropout, 3 whatever the descriptor says).  The generic
-// form branches on the activation code and the dropout threshold PER ELEMENT -- 358 scalar branches in the round-3 kernel,
-// whose conversion of one tile took 3.0 - 3.4 us against 2.6 us for the tile's 108 MFMAs (tools/wgrad_timeline.py,
-// profiles/r04_wgrad_timeline.txt); the staging code is now instantiated per form behind ONE wave-uniform branch per tile.
-template <int PRO>
-__device__ __forceinline__ float wg_prologue(const InAct& a, float v, uint32_t idx) {
-  if constexpr (PRO == 0) return v;
-  else if constexpr (PRO == 1) return elu_f(v);
-  else if constexpr (PRO == 2) {
-    v = elu_f(v);
-    return (vunet_hash_u32(idx + a.seed) >= a.thresh) ? v * a.keep_scale : 0.f;   // (a.seed: resolved at kernel entry)
-  } else return apply_in_act(a, v, idx);
-}
-
+// The prologue f(x) runs as straight-line code (common.h: in_act_form): the generic form branches on the activation code and
+// the dropout threshold PER ELEMENT -- 358 scalar branches in the round-3 kernel, whose conversion of one tile took 3.0 - 3.4 us
+// against 2.6 us for the tile's 108 MFMAs (tools/wgrad_timeline.py, profiles/r04_wgrad_timeline.txt); the staging code is
+// instantiated per form behind ONE wave-uniform branch per tile.
 struct WgradH2Args {
   vunet_wgrad_desc d;
   const float* x1;
@@ -337,7 +327,7 @@ __global__ __launch_bounds__(256 * WG_GROUPS, WG_GROUPS == 2 ? 1 : 2) void conv_
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float t = e < 4 ? xv[i][0][e] : xv[i][1][e - 4];
-        f[e] = wg_prologue<PRO>(ia, ok ? t : 0.f, gidx[i] + e) * sxk;
+        f[e] = in_act_form<PRO>(ia, ok ? t : 0.f, gidx[i] + e) * sxk;
       }
       uint32_t ph[4], pl[4];
       wg_split2(f[0], f[1], ph[0], pl[0]);
@@ -362,8 +352,8 @@ __global__ __launch_bounds__(256 * WG_GROUPS, WG_GROUPS == 2 ? 1 : 2) void conv_
     if constexpr (FROM_LDS) fetch_halo();
     if (tid < ENT) {
       const bool okl = okbits & 16u, okr = okbits & 32u;
-      const float fl = wg_prologue<PRO>(ia, okl ? hv[0] : 0.f, hidx - 1) * (okl ? sx : 0.f);
-      const float fr = wg_prologue<PRO>(ia, okr ? hv[1] : 0.f, hidx + 32) * (okr ? sx : 0.f);
+      const float fl = in_act_form<PRO>(ia, okl ? hv[0] : 0.f, hidx - 1) * (okl ? sx : 0.f);
+      const float fr = in_act_form<PRO>(ia, okr ? hv[1] : 0.f, hidx + 32) * (okr ? sx : 0.f);
       uint32_t ph, pl;
       wg_split2(fr, fl, ph, pl);   // low half = right halo, high = left
       unsigned short* const eb = reinterpret_cast<unsigned short*>(eL);
@@ -375,7 +365,7 @@ __global__ __launch_bounds__(256 * WG_GROUPS, WG_GROUPS == 2 ? 1 : 2) void conv_
     }
   };
   // the form of this layer's prologue (wave-uniform, the same for every tile)
-  const int pro_form = ia.thresh ? (ia.act == ACT_ELU ? 2 : 3) : (ia.act == ACT_NONE ? 0 : (ia.act == ACT_ELU ? 1 : 3));
+  const int pro_form = in_act_form_of(ia);
   auto write_x = [&]() {
     constexpr std::integral_constant<bool, DMA> from_lds{};
     if (pro_form == 2) write_x_as(std::integral_constant<int, 2>{}, from_lds);
