@@ -1,48 +1,59 @@
 #!/usr/bin/env python3
-"""GPU timeline of the timed bench steps from a rocprofv3 kernel trace: how much of the wall time has NO kernel running
-(host-bound / dependency gaps), how much has exactly one, and the per-queue busy time.
+"""GPU timeline of the training steps from a rocprofv3 kernel trace: per STEP (the interval between two launches of the
+step's first kernel, the batched weight fold) how much of the time has no kernel running (dependency / launch gaps), one,
+two, three or more; per-queue busy time; the largest idle gaps with the kernels around them.
 
-    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-config1
-    python tools/timeline.py gpurun_out/tl/*/*_kernel_trace.csv
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render
+    python tools/timeline.py gpurun_out/tl/*/*_kernel_trace.csv [marker kernel substring, default wn_scale_multi_kernel]
 """
 import csv
+import statistics
 import sys
 from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
+marker = sys.argv[2] if len(sys.argv) > 2 else "wn_scale_multi_kernel"
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"]) for r in rows))
-t_end = ev[-1][1]
-# last ~60 % of the trace = steady-state steps
-t0 = ev[0][0] + int(0.4 * (t_end - ev[0][0]))
-ev = [e for e in ev if e[0] >= t0]
-span = ev[-1][1] - ev[0][0]
-pts = []
-for s, e, q, k in ev:
-    pts.append((s, 1))
-    pts.append((e, -1))
-pts.sort()
-depth, last, hist = 0, pts[0][0], defaultdict(int)
-for t, d in pts:
-    hist[min(depth, 3)] += t - last
-    depth += d
-    last = t
-print(f"window {span / 1e6:.1f} ms, kernels {len(ev)}")
-for k in sorted(hist):
-    print(f"  {k}{'+' if k == 3 else ' '} kernels running: {hist[k] / 1e6:8.2f} ms ({100.0 * hist[k] / span:5.1f} %)")
-busy = defaultdict(int)
-for s, e, q, k in ev:
-    busy[q] += e - s
-for q, b in sorted(busy.items(), key=lambda kv: -kv[1]):
-    print(f"  queue {q}: busy {b / 1e6:8.2f} ms ({100.0 * b / span:5.1f} %)")
-# the largest idle gaps and what follows them
+starts = [s for s, e, q, k in ev if marker in k]
+if len(starts) < 3:
+    raise SystemExit(f"marker kernel {marker!r} found {len(starts)} times")
+iv = [(a, b) for a, b in zip(starts, starts[1:])]
+med = statistics.median(b - a for a, b in iv)
+steps = [(a, b) for a, b in iv if 0.7 * med <= b - a <= 1.3 * med]       # the back-to-back steps (not the ones around a sync)
+print(f"{len(iv)} step intervals, median {med / 1e6:.3f} ms; {len(steps)} within 30 % of it are analysed")
+hist, busy, span, nk = defaultdict(int), defaultdict(int), 0, 0
 gaps = []
-cur_end = ev[0][1]
-for s, e, q, k in ev[1:]:
-    if s > cur_end:
-        gaps.append((s - cur_end, k))
-    cur_end = max(cur_end, e)
+for a, b in steps:
+    inside = [(max(s, a), min(e, b), q, k) for s, e, q, k in ev if e > a and s < b]
+    nk += sum(1 for s, e, q, k in ev if a <= s < b)
+    pts = sorted([(s, 1, k) for s, e, q, k in inside] + [(e, -1, k) for s, e, q, k in inside])
+    depth, last, last_end_name = 0, a, "(step start)"
+    for t, dlt, k in pts:
+        hist[min(depth, 3)] += t - last
+        if depth == 0 and t - last > 0 and dlt == 1:
+            gaps.append((t - last, last_end_name, k))
+        depth += dlt
+        if dlt == -1 and depth == 0:
+            last_end_name = k
+        last = t
+    hist[min(depth, 3)] += b - last
+    for s, e, q, k in inside:
+        busy[q] += e - s
+    span += b - a
+n = len(steps)
+print(f"per step: {span / n / 1e6:.3f} ms, {nk / n:.0f} kernels")
+for d in sorted(hist):
+    print(f"  {d}{'+' if d == 3 else ' '} kernels running: {hist[d] / n / 1e6:7.3f} ms ({100.0 * hist[d] / span:5.1f} %)")
+for q, v in sorted(busy.items(), key=lambda kv: -kv[1]):
+    print(f"  queue {q}: busy {v / n / 1e6:7.3f} ms per step ({100.0 * v / span:5.1f} %)")
 gaps.sort(reverse=True)
-print("largest idle gaps (us) and the kernel that ends them:")
-for g, k in gaps[:12]:
-    print(f"  {g / 1e3:8.1f}  {k[:90]}")
-print(f"  total idle in gaps > 5 us: {sum(g for g, _ in gaps if g > 5000) / 1e6:.2f} ms over {sum(1 for g, _ in gaps if g > 5000)} gaps")
+print(f"idle gaps: {len(gaps) / n:.0f} per step, {sum(g for g, _, _ in gaps) / n / 1e6:.3f} ms per step; > 5 us: "
+      f"{sum(1 for g, _, _ in gaps if g > 5000) / n:.0f} per step, {sum(g for g, _, _ in gaps if g > 5000) / n / 1e6:.3f} ms")
+agg = defaultdict(lambda: [0, 0])
+for g, ka, kb in gaps:
+    key = (ka.split("(")[0][:60], kb.split("(")[0][:60])
+    agg[key][0] += g
+    agg[key][1] += 1
+print("idle time by (kernel that ended before the gap -> kernel that ended it), us per step:")
+for (ka, kb), (g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
+    print(f"  {g / n / 1e3:8.1f} us  x{c / n:5.1f}  {ka}  ->  {kb}")
