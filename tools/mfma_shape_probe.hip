@@ -27,7 +27,7 @@ union Unit {
 
 constexpr int LDS_UNITS = 4352;   // 68 KB of 16-byte units
 
-template <int SHAPE, int READS>
+template <int SHAPE, int READS, int ORDER = 0>
 __global__ __launch_bounds__(256, 2) void probe(const uint4* __restrict__ src, float* __restrict__ out, int iters,
                                                unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) uint4 L[];
@@ -64,16 +64,53 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* __restrict__ src, f
           for (int q = 0; q < 2; ++q)
             if (READS || it == 0) bv[p][q].u = xB[p * 680 + q * 34 + kw + rot];
         }
+        if constexpr (ORDER == 0) {          // the kernel's order: per output tile, the two cross terms then the leading one
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              f32x16 cx = acx[mt][q];
+              cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, cx, 0, 0, 0);
+              cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, cx, 0, 0, 0);
+              acx[mt][q] = cx;
+              acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+            }
+        } else if constexpr (ORDER == 1) {   // by product type: consecutive MFMAs never share an accumulator
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acx[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, acx[mt][q], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acx[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, acx[mt][q], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+        } else if constexpr (ORDER == 2) {   // A-stationary: the A operand changes every 2 - 4 MFMAs
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+              acx[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, acx[mt][q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acx[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, acx[mt][q], 0, 0, 0);
+          }
+        } else {                              // B-stationary
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            f32x16 cx = acx[mt][q];
-            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, cx, 0, 0, 0);
-            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, cx, 0, 0, 0);
-            acx[mt][q] = cx;
-            acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+              acx[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][mt].b, bv[0][q].b, acx[mt][q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acx[mt][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][mt].b, bv[1][q].b, acx[mt][q], 0, 0, 0);
           }
+        }
       }
     }
     float s = 0.f;
@@ -146,9 +183,9 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* __restrict__ src, f
     }                                                                          \
   } while (0)
 
-template <int SHAPE, int READS>
+template <int SHAPE, int READS, int ORDER = 0>
 static void run(const char* name, const uint4* src, float* out, unsigned long long* stamps, int blocks, int iters) {
-  auto k = probe<SHAPE, READS>;
+  auto k = probe<SHAPE, READS, ORDER>;
   const size_t lds = LDS_UNITS * 16;
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1;
@@ -177,10 +214,10 @@ static void run(const char* name, const uint4* src, float* out, unsigned long lo
   const double flops = 2.0 * mac_it * iters * 4.0 * blocks * reps;
   const double tf = flops / (ms * 1e-3) / 1e12;
   const double mfma_per_wave = (SHAPE == 0 ? 36.0 : 144.0) * iters;
-  printf("{\"loop\": \"%s\", \"mfma\": \"%s\", \"lds_reads\": %d, \"issued_tflops\": %.1f, \"algorithmic_tflops_3_products\": %.1f, "
+  printf("{\"loop\": \"%s\", \"mfma\": \"%s\", \"order\": %d, \"lds_reads\": %d, \"issued_tflops\": %.1f, \"algorithmic_tflops_3_products\": %.1f, "
          "\"frac_of_2500\": %.3f, \"us_per_launch\": %.1f, \"inkernel_clock_ghz_median\": %.3f, "
          "\"s_memtime_ticks_per_mfma_per_wave_median\": %.2f}\n",
-         name, SHAPE == 0 ? "32x32x16_f16" : "16x16x32_f16", READS, tf, tf / 3, tf / 2500.0, 1e3 * ms / reps,
+         name, SHAPE == 0 ? "32x32x16_f16" : "16x16x32_f16", ORDER, READS, tf, tf / 3, tf / 2500.0, 1e3 * ms / reps,
          clk[blocks / 2] / 1e9, cyc[blocks / 2] / mfma_per_wave);
   fflush(stdout);
 }
@@ -204,6 +241,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     const char* tag = zero ? "zeros" : "random";
     run<0, 1>(tag, src, out, stamps, blocks, iters);
+    if (!zero) {   // issue orders of the same twelve MFMAs per tap (order 0 is the kernel's)
+      run<0, 1, 1>(tag, src, out, stamps, blocks, iters);
+      run<0, 1, 2>(tag, src, out, stamps, blocks, iters);
+      run<0, 1, 3>(tag, src, out, stamps, blocks, iters);
+    }
     run<1, 1>(tag, src, out, stamps, blocks, iters);
     run<0, 0>(tag, src, out, stamps, blocks, iters);
     run<1, 0>(tag, src, out, stamps, blocks, iters);
