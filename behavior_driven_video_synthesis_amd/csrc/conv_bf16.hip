@@ -219,6 +219,9 @@ extern "C" int vunet_conv2d_bf16(const vunet_conv_desc* d, const float* x1, cons
   if (!vunet_conv2d_bf16_supported(d)) return VUNET_ERR_UNSUPPORTED;
   GatherArgs ga;
   ga.wide = 0;
+  ga.res2 = nullptr;
+  ga.amax2 = nullptr;
+  ga.amax_out = nullptr;
   ga.amax_out = nullptr;
   ga.d = *d;
   ga.x1 = x1;

@@ -27,6 +27,13 @@ struct GatherArgs {
   // internal: data gradient through a ReLU epilogue -- x1 (= dy) is multiplied by [mask > 0] while it is staged
   // (prologue code 4; mask = the forward output, shaped like x1).  nullptr: off.
   const float* mask;
+  // internal (fp16 scheme): the second source's 512 partial |x| maxima when they live in a buffer of their own (the kernel's
+  // `amax` argument then holds only the first source's); nullptr: `amax` holds all 1024.
+  const float* amax2;
+  // internal (data gradient): a SECOND tensor added in the epilogue, shaped like y -- the gradient that reaches the layer's
+  // input through another reader (ops.py: pass-through alias) when the one residual slot is taken by dy itself (a
+  // VunetRNB's x is both the convolution's source and the residual).  nullptr: off.  Mode 1 only.
+  const float* res2;
 };
 
 struct PixGeo {
@@ -80,6 +87,7 @@ __device__ __forceinline__ float store_out(const GatherArgs& a, const PixGeo& g,
     const size_t o = (size_t)(g.n * d.M + m) * a.HoWo + pix;
     if (a.aux) v *= in_act_grad(a.auxa, a.aux[o], (uint32_t)o);
     if (a.res) v += a.res[o];
+    if (a.res2) v += a.res2[o];
     a.y[o] = v;
   }
   return v;
@@ -181,6 +189,7 @@ __device__ __forceinline__ float store_tile_side(const GatherArgs& a, const PixG
       v *= in_act_grad(a.auxa, s.aux[r], (uint32_t)o);
     }
     if (a.res) v += s.res[r];
+    if (d.mode == 1 && a.res2 && ok) v += a.res2[o];
     if (ok) {
       a.y[o] = v;
       vmax = fmaxf(vmax, fabsf(v));
@@ -264,6 +273,17 @@ __device__ __forceinline__ float store_tile_side4(const GatherArgs& a, const Pix
   // tile in per-element scalar branches on the activation code -- as long as 1.5 K-chunks of the matrix loop):
   //   forward with no / ReLU output activation (every NormConv2d of the VUnet, every VGG19 layer); data gradient without
   //   an activation derivative (the layers whose input is not pre-activated, and the ReLU-masked VGG19 chain).
+  // second residual (data gradient only): requested here, added below -- the lane transposes cover most of its latency, and
+  // it needs no second prefetched register set in the kernels' software-pipelined epilogues
+  float4 r2[4];
+  const bool has_r2 = MODE == 1 && a.res2 != nullptr;
+  if (has_r2) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int ch = m_tile0 + 8 * q4 + 4 * h + k;
+      r2[q4] = *reinterpret_cast<const float4*>(a.res2 + (ch < d.M ? (size_t)(g.n * d.M + ch) * a.HoWo + pix0 : 0));
+    }
+  }
   if constexpr (FORM != 0) {
     const bool relu = MODE == 0 && d.out_act == ACT_RELU;
     const bool has_sh = MODE == 0 && a.shift != nullptr, has_res = a.res != nullptr;
@@ -290,6 +310,9 @@ __device__ __forceinline__ float store_tile_side4(const GatherArgs& a, const Pix
             gr = (vunet_hash_u32((uint32_t)(o + e) + a.auxa.seed) >= a.auxa.thresh) ? gr * a.auxa.keep_scale : 0.f;
           v[e] = v[e] * gr + resv[e];
         }
+      }
+      if (has_r2) {
+        v[0] += r2[q4].x; v[1] += r2[q4].y; v[2] += r2[q4].z; v[3] += r2[q4].w;
       }
       if (ch < d.M) {
 #ifdef H2_ABL_EPI_NOSTORE
@@ -324,6 +347,9 @@ __device__ __forceinline__ float store_tile_side4(const GatherArgs& a, const Pix
       if (a.res) t += resv[e];
       v[e] = t;
     }
+    if (has_r2) {
+      v[0] += r2[q4].x; v[1] += r2[q4].y; v[2] += r2[q4].z; v[3] += r2[q4].w;
+    }
     if (ch < d.M) {
       *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
       vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -353,6 +379,11 @@ __device__ __forceinline__ float store_tile_pair(const GatherArgs& a, int n, int
       }
       if (a.res) {
         const float2 x = *reinterpret_cast<const float2*>(a.res + o);
+        v0 += x.x;
+        v1 += x.y;
+      }
+      if (a.res2) {
+        const float2 x = *reinterpret_cast<const float2*>(a.res2 + o);
         v0 += x.x;
         v1 += x.y;
       }

@@ -447,6 +447,8 @@ int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const fl
   GatherArgs ga;
   ga.wide = 0;
   ga.amax_out = nullptr;
+  ga.res2 = nullptr;
+  ga.amax2 = nullptr;
   ga.d = *d;
   ga.x1 = x1; ga.x2 = x2; ga.wt = wt; ga.shift = shift; ga.res = res; ga.aux = aux; ga.y = y;
   ga.NP = d->N * d->Ho * d->Wo;
@@ -495,6 +497,8 @@ int vunet_conv2d_gather_amax(const vunet_conv_desc* d, const float* x1, const fl
   if (use_tiled(d, pro)) return vunet_conv_tiled_launch(ga, pro, st);
   float* const amax_keep = ga.amax_out;
   ga.amax_out = nullptr;
+  ga.res2 = nullptr;
+  ga.amax2 = nullptr;
   if (d->KH == 3 && d->KW == 3) return dispatch_gather<3>(ga, pro, st, amax_keep);
   if (d->KH == 1 && d->KW == 1) return dispatch_gather<1>(ga, pro, st, amax_keep);
   return dispatch_gather<0>(ga, pro, st, amax_keep);
@@ -513,6 +517,8 @@ extern "C" int vunet_conv2d_dgrad_relu(const vunet_conv_desc* d, const float* dy
   GatherArgs ga;
   ga.wide = 0;
   ga.amax_out = nullptr;
+  ga.res2 = nullptr;
+  ga.amax2 = nullptr;
   ga.d = *d;
   ga.x1 = dy; ga.x2 = nullptr; ga.wt = wt; ga.shift = nullptr; ga.res = res; ga.aux = nullptr; ga.y = dx;
   ga.NP = d->N * d->Ho * d->Wo;

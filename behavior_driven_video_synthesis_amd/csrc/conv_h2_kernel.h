@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
   // ---- scales: x by 2^ex from the tensor maximum (1024 partial maxima, reduced here, behind the loads issued above),
   //      w by the exponent in the image header
   {
-    const float4 pm = reinterpret_cast<const float4*>(amax)[tid & 255];
+    const float4 pm = h2_amax4(amax, a.amax2, tid & 255);
     float m_ = fmaxf(fmaxf(pm.x, pm.y), fmaxf(pm.z, pm.w));
     m_ = wave_max(m_);
     float* const redm = reinterpret_cast<float*>(smem4);

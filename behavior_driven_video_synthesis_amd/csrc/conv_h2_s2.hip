@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_s2_kernel(const GatherArgs a, 
   // ---- scales: x by 2^ex from the tensor maximum (1024 partial maxima), w by the exponent in the image header
   float sx, descale, descale2;
   {
-    const float4 pm = reinterpret_cast<const float4*>(amax)[tid];
+    const float4 pm = h2_amax4(amax, a.amax2, tid);
     float m_ = wave_max(fmaxf(fmaxf(pm.x, pm.y), fmaxf(pm.z, pm.w)));
     float* const redm = reinterpret_cast<float*>(smem4);
     if (lane == 0) redm[wave] = m_;

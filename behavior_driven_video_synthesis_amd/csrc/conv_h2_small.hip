@@ -247,10 +247,10 @@ __global__ __launch_bounds__(64 * NWV) void conv_h2_small_kernel(const GatherArg
   {
     float m_;   // the 1024 partial maxima: 512 threads x 2 or 256 x 4
     if constexpr (NWV == 8) {
-      const float2 pm = reinterpret_cast<const float2*>(amax)[tid];
+      const float2 pm = h2_amax2(amax, a.amax2, tid);
       m_ = fmaxf(pm.x, pm.y);
     } else {
-      const float4 pm = reinterpret_cast<const float4*>(amax)[tid];
+      const float4 pm = h2_amax4(amax, a.amax2, tid);
       m_ = fmaxf(fmaxf(pm.x, pm.y), fmaxf(pm.z, pm.w));
     }
     m_ = wave_max(m_);

@@ -164,14 +164,14 @@ int vunet_wgrad_x6_launch(const vunet_wgrad_desc* d, const float* x1, const floa
 // conv_wgrad_h2.hip: the same layers with two scaled fp16 terms / three products (d->flags bit 1)
 int vunet_wgrad_h2_name(const vunet_wgrad_desc* d, char* name, int len);
 int vunet_wgrad_h2_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
-                          float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st);
+                          float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy, hipStream_t st);
 
 // conv_wgrad_direct.hip: small maps, stride 2, 1x1 on the fp16 matrix cores (d->flags bit 1), operands straight from global
 bool vunet_wgrad_direct_applicable(const vunet_wgrad_desc* d);
 int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d);
 int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len);
 int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
-                              float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st);
+                              float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy, hipStream_t st);
 
 extern "C" int vunet_conv2d_wgrad_wants_split(const vunet_wgrad_desc* d) {
   return d && (vunet_wgrad_x6_applicable(d) || vunet_wgrad_direct_applicable(d)) ? 1 : 0;
@@ -234,8 +234,16 @@ static int launch_wgrad(const WgradArgs& wa, hipStream_t st) {
   return vunet_check_launch();
 }
 
+extern "C" int vunet_conv2d_wgrad_a2(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
+                                     float* slabs, float* dshift, const float* amax_x, const float* amax_x2,
+                                     const float* amax_dy, void* stream);
 extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
                                   float* slabs, float* dshift, const float* amax_x, const float* amax_dy, void* stream) {
+  return vunet_conv2d_wgrad_a2(d, x1, x2, dy, slabs, dshift, amax_x, nullptr, amax_dy, stream);
+}
+extern "C" int vunet_conv2d_wgrad_a2(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
+                                     float* slabs, float* dshift, const float* amax_x, const float* amax_x2,
+                                     const float* amax_dy, void* stream) {
   if (!d || !x1 || !dy || !slabs || !dshift) return VUNET_ERR_ARG;
   if (d->C2 > 0 && !x2) return VUNET_ERR_ARG;
   if (d->nsplit < 1 || d->KH < 1 || d->KW < 1) return VUNET_ERR_ARG;
@@ -245,13 +253,13 @@ extern "C" int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, co
   if (vunet_wgrad_x6_applicable(d)) {
     if (d->flags & 2) {
       if (!amax_x || !amax_dy) return VUNET_ERR_ARG;
-      return vunet_wgrad_h2_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_dy, (hipStream_t)stream);
+      return vunet_wgrad_h2_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_x2, amax_dy, (hipStream_t)stream);
     }
     return vunet_wgrad_x6_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);
   }
   if (vunet_wgrad_direct_applicable(d)) {
     if (!amax_x || !amax_dy) return VUNET_ERR_ARG;
-    return vunet_wgrad_direct_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_dy, (hipStream_t)stream);
+    return vunet_wgrad_direct_launch(d, x1, x2, dy, slabs, dshift, amax_x, amax_x2, amax_dy, (hipStream_t)stream);
   }
   if (vunet_wgrad_thin_applicable(d)) return vunet_wgrad_thin_launch(d, x1, dy, slabs, dshift, (hipStream_t)stream);
   if (vunet_wgrad_tiled_applicable(d)) return vunet_wgrad_tiled_launch(d, x1, x2, dy, slabs, dshift, (hipStream_t)stream);

@@ -27,6 +27,7 @@ struct WgradDirectArgs {
   float* slabs;
   float* dshift;
   const float* amax_x;
+  const float* amax_x2;   // the second source's 512 partial maxima in a buffer of their own, or nullptr (split_h2.h: h2_amax4)
   const float* amax_dy;
   int Ctot, Coutp, ncot, noct, ops;   // co tiles; pixel octets in all; octets per split (even)
   int opr, opi;                       // octets per output row / per image
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
   float sx, sdy, descale, descale2;
   {
     __shared__ float redm[8];
-    const float4 px = reinterpret_cast<const float4*>(a.amax_x)[tid], pd = reinterpret_cast<const float4*>(a.amax_dy)[tid];
+    const float4 px = h2_amax4(a.amax_x, a.amax_x2, tid), pd = reinterpret_cast<const float4*>(a.amax_dy)[tid];
     float mx = wave_max(fmaxf(fmaxf(px.x, px.y), fmaxf(px.z, px.w)));
     float md = wave_max(fmaxf(fmaxf(pd.x, pd.y), fmaxf(pd.z, pd.w)));
     if (lane == 0) { redm[wave] = mx; redm[4 + wave] = md; }
@@ -309,12 +310,12 @@ int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len) {
 }
 
 int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
-                              float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st) {
+                              float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy, hipStream_t st) {
   const int cls = direct_class(d);
   if (!cls) return VUNET_ERR_UNSUPPORTED;
   WgradDirectArgs a;
   a.d = *d;
-  a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift; a.amax_x = amax_x; a.amax_dy = amax_dy;
+  a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift; a.amax_x = amax_x; a.amax_x2 = amax_x2; a.amax_dy = amax_dy;
   direct_geometry(d, a);
   a.ops = (a.noct + d->nsplit - 1) / d->nsplit;
   a.ops = (a.ops + 1) & ~1;   // whole K steps of two octets

@@ -108,6 +108,7 @@ struct WgradH2Args {
   int Ctot, Coutp, tiles_per_img_w, tiles_per_img, ntiles, tps;
   InAct in1, in2;
   const float* amax_x;    // 1024 partial maxima of |x1|, |x2|
+  const float* amax_x2;   // or: the second source's 512 in a buffer of their own (split_h2.h: h2_amax4)
   const float* amax_dy;   // 1024 partial maxima of |dy| (second half zeros)
 };
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256 * WG_GROUPS, WG_GROUPS == 2 ? 1 : 2) void conv_
   float sx, sdy, descale, descale2;
   {
     // (every group reduces all 1024 + 1024 partial maxima: the same values in both)
-    const float4 px = reinterpret_cast<const float4*>(a.amax_x)[tid], pd = reinterpret_cast<const float4*>(a.amax_dy)[tid];
+    const float4 px = h2_amax4(a.amax_x, a.amax_x2, tid), pd = reinterpret_cast<const float4*>(a.amax_dy)[tid];
     float mx = wave_max(fmaxf(fmaxf(px.x, px.y), fmaxf(px.z, px.w)));
     float md = wave_max(fmaxf(fmaxf(pd.x, pd.y), fmaxf(pd.z, pd.w)));
     float* const redm = reinterpret_cast<float*>(smem4) + grp * 8;
@@ -596,11 +597,11 @@ int vunet_wgrad_h2_name(const vunet_wgrad_desc* d, char* name, int len) {
 
 // same applicability and split count as the three-term kernel (vunet_wgrad_x6_applicable / _nslabs)
 int vunet_wgrad_h2_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
-                          float* dshift, const float* amax_x, const float* amax_dy, hipStream_t st) {
+                          float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy, hipStream_t st) {
   WgradH2Args a;
   a.d = *d;
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift;
-  a.amax_x = amax_x; a.amax_dy = amax_dy;
+  a.amax_x = amax_x; a.amax_x2 = amax_x2; a.amax_dy = amax_dy;
   int MTW, ciblocks, coblocks;
   h2_geometry(d, MTW, a.ntiles, ciblocks, coblocks);
   a.Ctot = d->C1 + d->C2;

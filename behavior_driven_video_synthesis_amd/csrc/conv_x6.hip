@@ -104,16 +104,20 @@ static void fill_args(GatherArgs& ga, const vunet_conv_desc* d, const float* x1,
   const uintptr_t al = reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(aux);
   ga.wide = (al & 15) == 0 && !d->d2s && d->stride == 1 && d->Wo % 4 == 0;
   ga.amax_out = nullptr;
+  ga.amax2 = nullptr;
+  ga.res2 = nullptr;
 }
 
 static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
                      const float* res, const float* aux, const float* mask, float* y, const float* amax, float* amax_out,
-                     long min_blocks, void* stream) {
+                     long min_blocks, void* stream, const float* amax2 = nullptr, const float* res2 = nullptr) {
   const int pro = x6_prologue_code(d, mask != nullptr);
+  if (res2 && (d->mode != 1 || !amax)) return VUNET_ERR_UNSUPPORTED;   // (second residual: the fp16 scheme's data gradients)
   if (amax && !mask && !aux && !res && !g_vunet_tune[VUNET_TUNE_S2_FWD_F32] && vunet_conv_h2_s2_ok(d, pro)) {
     GatherArgs gs;   // stride-2 forward: its own kernel (parity-plane staging)
     fill_args(gs, d, x1, x2, nullptr, shift, res, aux, mask, y);
     gs.amax_out = amax_out;
+    gs.amax2 = amax2;
     return vunet_conv_h2_s2_launch(gs, wx, vunet_x6_mtiles(d->Mpad), amax, (hipStream_t)stream);
   }
   int MT = 0;
@@ -121,6 +125,8 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
   if (g_vunet_tune[VUNET_TUNE_FORCE_SMALL] && amax && !mask && vunet_conv_h2_small_ok(d, pro)) NT = 0;   // tests
   GatherArgs ga;
   fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
+  ga.amax2 = amax2;
+  ga.res2 = res2;
   if (amax) ga.amax_out = amax_out;   // only the fp16 kernels publish |y| maxima
   if (NT == 0) {
     if (amax) ga.amax_out = amax_out;   // (the small-map kernel publishes through every store, depth-to-space included)   // the row-tiled kernels do not cover / cannot fill the chip with this problem: the small-map form (fp16 scheme)
@@ -177,15 +183,24 @@ extern "C" int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const 
   return x6_launch(d, x1, x2, wx, shift, res, aux, mask, y, amax, amax_out, 1, stream);
 }
 
+extern "C" int vunet_conv2d_a2(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
+                               const float* shift, const float* res, const float* res2, const float* aux, float* y,
+                               const float* amax, const float* amax2, float* amax_out, void* stream) {
+  if (!d) return VUNET_ERR_ARG;
+  if (amax2 && (!amax || d->C2 <= 0)) return VUNET_ERR_ARG;
+  if (res2 && (!res || d->mode != 1)) return VUNET_ERR_ARG;
+  if (x6_wanted(d, wx != nullptr, aux != nullptr, res != nullptr, false, amax != nullptr)) {
+    if (!x1 || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
+    return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, amax, amax_out, 128, stream, amax2, res2);
+  }
+  if (res2) return VUNET_ERR_UNSUPPORTED;   // (the fp32 kernels take one residual: the caller adds the second itself)
+  return vunet_conv2d_gather_amax(d, x1, x2, wt, shift, res, aux, y, amax_out, stream);
+}
+
 extern "C" int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
                             const float* shift, const float* res, const float* aux, float* y, const float* amax,
                             float* amax_out, void* stream) {
-  if (!d) return VUNET_ERR_ARG;
-  if (x6_wanted(d, wx != nullptr, aux != nullptr, res != nullptr, false, amax != nullptr)) {
-    if (!x1 || !y || (d->C2 > 0 && !x2) || d->Mpad % 32 != 0) return VUNET_ERR_ARG;
-    return x6_launch(d, x1, x2, wx, shift, res, aux, nullptr, y, amax, amax_out, 128, stream);
-  }
-  return vunet_conv2d_gather_amax(d, x1, x2, wt, shift, res, aux, y, amax_out, stream);
+  return vunet_conv2d_a2(d, x1, x2, wt, wx, shift, res, nullptr, aux, y, amax, nullptr, amax_out, stream);
 }
 
 extern "C" int vunet_conv2d_publishes_amax(const vunet_conv_desc* d, int32_t has_aux, int32_t has_res, int32_t split) {

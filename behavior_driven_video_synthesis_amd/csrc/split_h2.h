@@ -44,3 +44,15 @@ __device__ __forceinline__ void h2_split2(float a, float b, uint32_t& h, uint32_
   h = __builtin_bit_cast(uint32_t, ph);
   l = __builtin_bit_cast(uint32_t, pl);
 }
+
+// The 1024 partial |x| maxima of a convolution's input as ONE buffer [x1: 512 | x2: 512] -- or, when the two sources'
+// maxima live in different buffers (producer-side tags, ops.py), as two: `amax` holds source 1's 512, `amax2` source 2's
+// (no concatenation launch).  i indexes float4s (0..255) / float2s (0..511).
+__device__ __forceinline__ float4 h2_amax4(const float* __restrict__ amax, const float* __restrict__ amax2, int i) {
+  const float* p = (amax2 != nullptr && i >= 128) ? amax2 - 512 : amax;
+  return reinterpret_cast<const float4*>(p)[i];
+}
+__device__ __forceinline__ float2 h2_amax2(const float* __restrict__ amax, const float* __restrict__ amax2, int i) {
+  const float* p = (amax2 != nullptr && i >= 256) ? amax2 - 512 : amax;
+  return reinterpret_cast<const float2*>(p)[i];
+}

@@ -308,11 +308,20 @@ class VunetRNB(nn.Module):
         self.conv = conv_layer(in_channels=in_c, out_channels=channels, kernel_size=kernel_size,
                                padding=kernel_size // 2)
 
-    def forward(self, x, a: Optional[TensorOrPair] = None):
+    def forward(self, x, a: Optional[TensorOrPair] = None, passthrough: bool = False):
+        """``passthrough`` (weight-normalised convolutions): -> (out, x_alias).  Whoever else reads ``x`` (a skip connection)
+        should read the alias: its gradient then reaches this block's data-gradient kernel and is added in its epilogue --
+        beside ``dy``, which the residual ``+ x`` puts there already (``ops.ConvCfg.passthrough``, the second residual slot
+        of ``vunet_conv2d_a2``) -- instead of by an autograd add over the tensor."""
         act, slope = _act_code(self.act_fn)
         p = self.dout.p if self.training else 0.0
+        kw = {"passthrough": True} if (passthrough and isinstance(self.conv, NormConv2d)) else {}
         if a is not None:
             assert self.residual
             a = self.nin.fused(a, in_act=act, in_slope=slope)
-            return self.conv.fused((x, a), res=x, in_act=act, in_slope=slope, drop_p=p)
-        return self.conv.fused(x, res=x, in_act=act, in_slope=slope, drop_p=p)
+            out = self.conv.fused((x, a), res=x, in_act=act, in_slope=slope, drop_p=p, **kw)
+        else:
+            out = self.conv.fused(x, res=x, in_act=act, in_slope=slope, drop_p=p, **kw)
+        if passthrough and not kw:
+            return out, x
+        return out

@@ -77,8 +77,13 @@ class _Pyramid(nn.Module):
         feats, h = [], self.nin(image)
         blocks = iter(self.blocks)
         for level in range(self.n_scales):
-            for _ in range(RNB_PER_SCALE):
-                h = next(blocks)(h)
+            for i in range(RNB_PER_SCALE):
+                if i == 0:
+                    h = next(blocks)(h)
+                else:
+                    # the previous block's output has two readers, this block and the skip connection: the skip reads the
+                    # alias this block hands back, so both gradients meet in this block's data-gradient epilogue
+                    h, feats[-1] = next(blocks)(h, passthrough=True)
                 feats.append(h)
             if level < self.n_scales - 1:
                 # the skip connection reads the alias the down-sampling layer hands back: one gradient chain, the skip's

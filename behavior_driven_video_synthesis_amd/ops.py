@@ -298,9 +298,14 @@ def _amax_for(x1, x2=None):
     t2 = _tagged_amax(x2)
     if t1 is None and t2 is None:
         return absmax_partials(x1, x2)
-    h1 = t1[:512] if t1 is not None else absmax_partials(x1)[:512]
-    h2 = t2[:512] if t2 is not None else absmax_partials(x2)[:512]
-    return torch.cat([h1, h2])
+    # the two sources' maxima live in buffers of their own (a producer's tag / a pass over one source): handed to the
+    # kernels as a PAIR (vunet_conv2d_a2 / vunet_conv2d_wgrad_a2) -- no launch to concatenate them
+    return (t1 if t1 is not None else absmax_partials(x1), t2 if t2 is not None else absmax_partials(x2))
+
+
+def _amax_pair(amax):
+    """-> (amax, amax2) pointers' tensors for the *_a2 entry points."""
+    return amax if isinstance(amax, tuple) else (amax, None)
 
 
 def _publishes_amax(desc, has_aux: bool, has_res: bool, has_wx: bool) -> bool:
@@ -421,7 +426,7 @@ class _Timed:
             _prof["recs"].append((self.name, self.flop, self.e0, self.e1))
 
 
-def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=None):
+def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=None, res2=None):
     """``amax``: the |x| partial maxima if the caller already has them (h2 scheme), else taken from the producer's tag or
     computed here when needed.  Returns the maxima the launch used (None if it did not need any).  When the fp16 kernel
     runs (and does not store through depth-to-space) y is tagged with the maxima of what it wrote."""
@@ -449,8 +454,18 @@ def _conv_gather(desc: ConvDesc, x1, x2, wt, shift, res, aux, y, wx=None, amax=N
         kname = buf.value.decode()
     with (_Timed((name, desc.N, desc.C1, desc.C2, desc.Hs, desc.Ws, desc.M, desc.KH, desc.stride, desc.in_act, kname),
                 flop) if _prof["on"] else _NO_TIMER):
-        _call("vunet_conv2d", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), _p(aux), _p(y),
-              _p(amax), _p(amax_out), _stream())
+        a1, a2 = _amax_pair(amax)
+        rc = _lib.lib().vunet_conv2d_a2(ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), _p(res2),
+                                        _p(aux), _p(y), _p(a1), _p(a2), _p(amax_out), _stream())
+        if rc == -3 and res2 is not None:
+            # a kernel without the second residual slot (nothing was launched): one residual in the epilogue, the other by
+            # an add over the result -- whose maxima are then not what the epilogue published
+            _call("vunet_conv2d_a2", ctypes.byref(desc), _p(x1), _p(x2), _p(wt), _p(wx), _p(shift), _p(res), None, _p(aux),
+                  _p(y), _p(a1), _p(a2), None, _stream())
+            y.add_(res2)
+            amax_out = None
+        elif rc != 0:
+            raise RuntimeError(f"vunet_conv2d_a2 failed with code {rc}")
     if amax_out is not None:
         _tag_amax(y, amax_out)
     return amax
@@ -1084,8 +1099,9 @@ class FusedConv(torch.autograd.Function):
                 kname = buf.value.decode()
             with (_Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, kname),
                         2.0 * n * ho * wo * cout * (c1 + c2) * k * k) if _prof["on"] else _NO_TIMER):
-                _call("vunet_conv2d_wgrad", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
-                      _p(wg_amax[0]), _p(wg_amax[1]), _stream())
+                ax1, ax2 = _amax_pair(wg_amax[0])
+                _call("vunet_conv2d_wgrad_a2", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
+                      _p(ax1), _p(ax2), _p(wg_amax[1]), _stream())
             ni = ctx.needs_input_grad
             if defer:   # every needed gradient is a view of a flat bucket: hand the layer to the batched backward
                 outs = [p_.grad if (p_ is not None and need) else None for p_, need in zip(ctx.param_refs, ni[3:8])]
@@ -1145,7 +1161,7 @@ class FusedConv(torch.autograd.Function):
                 # tensors the caching allocator may hand out again before the companion stream has read them: the
                 # activations and dy (freed as backward moves on), the |x| maxima if they are not arena slices, invnorm if
                 # it is not part of the model's persistent pack set (the parameters themselves outlive the step)
-                for t_ in (x1, x2, dconv, wg_amax[0], wg_amax[1], None if ctx.prepacked else invnorm):
+                for t_ in (x1, x2, dconv, *_amax_pair(wg_amax[0]), wg_amax[1], None if ctx.prepacked else invnorm):
                     if t_ is not None:
                         t_.record_stream(wstream)
                 torch.cuda.set_stream(wstream)   # (the context-manager form costs 6 us per layer, this pair 0.8)
@@ -1157,7 +1173,7 @@ class FusedConv(torch.autograd.Function):
                 dv, dg, dbias, dgamma, dbeta = weight_gradients(defer_ok)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
-            def dgrad(x, cs, m_off, seed, add, mask_by_x=False):
+            def dgrad(x, cs, m_off, seed, add, mask_by_x=False, add2=None):
                 dx = torch.empty_like(x)
                 has_aux = cfg.in_act != ACT_NONE or cfg.drop_p > 0
                 # x is a ReLU output and this layer has no prologue of its own: the epilogue's act'(aux) slot applies
@@ -1172,14 +1188,14 @@ class FusedConv(torch.autograd.Function):
                 amax = None
                 if wx_d is not None and _scheme() == 2 and _wants_split(d, has_aux, add is not None):
                     amax = get_dy_amax()
-                _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d, amax)
+                _conv_gather(d, dconv, None, wt_d, None, add, x if has_aux else None, dx, wx_d, amax, res2=add2)
                 if mask_by_x:
                     _tag_masked(dx, x)
                 return dx
             if ctx.needs_input_grad[0]:
-                dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else g_alias, ctx.x1_relu_out)
-                if cfg.res_is_x1 and g_alias is not None:   # (the epilogue adds one tensor)
-                    dx1.add_(g_alias)
+                # (x is the residual AND has another reader: dy in the epilogue's first slot, that reader's gradient in its second)
+                dx1 = dgrad(x1, c1, 0, cfg.drop_seed, dy if cfg.res_is_x1 else g_alias, ctx.x1_relu_out,
+                            add2=g_alias if cfg.res_is_x1 else None)
                 g_alias = None
             if x2 is not None and ctx.needs_input_grad[1]:
                 dx2 = dgrad(x2, c2, c1, (cfg.drop_seed + SEED2_OFFSET) & 0xFFFFFFFF, None)

@@ -113,6 +113,15 @@ int vunet_conv2d_gather_variant(const vunet_conv_desc* d, int32_t has_aux, char*
 int vunet_conv2d(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
                  const float* shift, const float* res, const float* aux, float* y, const float* amax, float* amax_out,
                  void* stream);
+/* The same with the two sources' maxima in buffers of their own (each the 512-slot |y| maxima its producer published through
+ * amax_out): amax = source 1's, amax2 = source 2's (>= 512 floats each); amax2 NULL = vunet_conv2d.  Saves the caller the
+ * launch that would concatenate them. */
+/* res2 (data gradient, mode 1, with res): a second tensor shaped like y added in the epilogue -- the gradient that reaches the
+ * layer's input through its other reader when `res` is taken by dy itself (VunetRNB: x is the convolution's source AND the
+ * residual, lib/modules.py:221-233); the fp16-scheme kernels only, VUNET_ERR_UNSUPPORTED (nothing launched) elsewhere. */
+int vunet_conv2d_a2(const vunet_conv_desc* d, const float* x1, const float* x2, const float* wt, const void* wx,
+                    const float* shift, const float* res, const float* res2, const float* aux, float* y, const float* amax,
+                    const float* amax2, float* amax_out, void* stream);
 int vunet_conv2d_x6(const vunet_conv_desc* d, const float* x1, const float* x2, const void* wx, const float* shift,
                     const float* res, const float* aux, const float* mask, float* y, const float* amax, float* amax_out,
                     void* stream);
@@ -193,6 +202,11 @@ typedef struct vunet_wgrad_desc {
  * and vunet_conv2d_wgrad_wants_split(d) == 1, else may be NULL */
 int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
                        float* slabs, float* dshift, const float* amax_x, const float* amax_dy, void* stream);
+/* (amax_x2: the second source's 512 partial maxima in a buffer of their own, amax_x then holding the first source's; NULL:
+ * amax_x holds all 1024 -- as vunet_conv2d_a2) */
+int vunet_conv2d_wgrad_a2(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
+                          float* slabs, float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy,
+                          void* stream);
 int vunet_conv2d_wgrad_wants_split(const vunet_wgrad_desc* d);
 int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len);
 /* number of pixel splits the library wants for this problem (caller sizes the slabs from it) */
