@@ -40,7 +40,9 @@
 // and step, the 64 lanes (ci, octet half) on 64 consecutive dwords.  Staging writes the two halves as 16-bit stores when it
 // writes the unit they belong to (a unit's first pixel is the right neighbour of the octet before it, its last the left
 // neighbour of the octet behind it; the tile's halo columns fill octets 0 / 3).  Timing: +-2 % (the conflicts were never
-// what bounded the kernel); the counter is 0.
+// what bounded the kernel).  SQ_LDS_BANK_CONFLICT per launch 9.2e6 -> 4.2e6 (<1>) and 6.4e6 -> 1.7e6 (<2>) cycles
+// (profiles/r04_pmc_sq.json): the fragment reads are conflict-free; what is left are the staging WRITES (the 16-bit edge
+// stores, 2-way, and the 16-byte unit stores across the 5-unit entry stride), a ninth as frequent as the reads.
 #include <type_traits>
 
 #include "common.h"

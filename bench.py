@@ -50,8 +50,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
 X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
 FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
-PMC_TRAFFIC_RENDER = ["profiles/r03_pmc_traffic_render.json"]
-PMC_TRAFFIC = ["profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"]
+PMC_TRAFFIC_RENDER = ["profiles/r04_pmc_traffic_render.json", "profiles/r03_pmc_traffic_render.json"]
+PMC_TRAFFIC = ["profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json",
+               "profiles/r01_pmc_traffic.json"]
 
 
 def parse():
