@@ -57,14 +57,16 @@ __device__ __forceinline__ void wn_pack_x6_body(const WnArgs& a, size_t start, s
     const int nch = img == 0 ? nch1 + a.d.C2 / 16 : nch1;
     const int Mdim = img == 0 ? a.d.Cout : a.Ctot;
     const int mtp = x6_mtiles(Mdim);
-    const size_t total = (size_t)nch * 3 * mtp * 3 * 64;
-    for (size_t i = start; i < total; i += stride) {
-      const int j = (int)(i & 31), half = (int)((i >> 5) & 1);
-      size_t q = i >> 6;
-      const int kw = (int)(q % 3); q /= 3;
-      const int mt = (int)(q % mtp); q /= mtp;
-      const int kh = (int)(q % 3);
-      const int ch = (int)(q / 3);
+    // (32-bit index arithmetic: a layer's image has < 2^31 units, and a 64-bit division by a run-time value costs ~100
+    // instructions -- five of them per unit were most of this kernel's 300 us per step in round 3)
+    const uint32_t total = (uint32_t)nch * 3u * (uint32_t)mtp * 3u * 64u;
+    for (uint32_t i = (uint32_t)start; i < total; i += (uint32_t)stride) {
+      const int j = (int)(i & 31u), half = (int)((i >> 5) & 1u);
+      uint32_t q = i >> 6;
+      const int kw = (int)(q % 3u); q /= 3u;
+      const int mt = (int)(q % (uint32_t)mtp); q /= (uint32_t)mtp;
+      const int kh = (int)(q % 3u);
+      const int ch = (int)(q / 3u);
       const int tap = kh * 3 + kw, m = mt * 32 + j;
       float w[8];
 #pragma unroll
@@ -126,14 +128,16 @@ __device__ __forceinline__ void wn_pack_h2_body(const WnArgs& a, size_t start, s
     const int nch = img == 0 ? nch1 + a.d.C2 / 16 : nch1;
     const int Mdim = img == 0 ? a.d.Cout : a.Ctot;
     const int mtp = x6_mtiles(Mdim);
-    const size_t total = (size_t)nch * 3 * mtp * 3 * 64;
-    for (size_t i = start; i < total; i += stride) {
-      const int j = (int)(i & 31), half = (int)((i >> 5) & 1);
-      size_t q = i >> 6;
-      const int kw = (int)(q % 3); q /= 3;
-      const int mt = (int)(q % mtp); q /= mtp;
-      const int kh = (int)(q % 3);
-      const int ch = (int)(q / 3);
+    // (32-bit index arithmetic: a layer's image has < 2^31 units, and a 64-bit division by a run-time value costs ~100
+    // instructions -- five of them per unit were most of this kernel's 300 us per step in round 3)
+    const uint32_t total = (uint32_t)nch * 3u * (uint32_t)mtp * 3u * 64u;
+    for (uint32_t i = (uint32_t)start; i < total; i += (uint32_t)stride) {
+      const int j = (int)(i & 31u), half = (int)((i >> 5) & 1u);
+      uint32_t q = i >> 6;
+      const int kw = (int)(q % 3u); q /= 3u;
+      const int mt = (int)(q % (uint32_t)mtp); q /= (uint32_t)mtp;
+      const int kh = (int)(q % 3u);
+      const int ch = (int)(q / 3u);
       const int tap = kh * 3 + kw, m = mt * 32 + j;
       float w[8];
 #pragma unroll
@@ -327,12 +331,12 @@ __device__ __forceinline__ void wn_scale_body(const WnArgs& a, int co, int lane)
 }
 
 __device__ __forceinline__ void wn_pack_body(const WnArgs& a, size_t start, size_t stride) {
-  const size_t nf = (size_t)a.Kf * a.Mpad_f;
-  const size_t nd = a.wt_d ? (size_t)a.Kd * a.Mpad_d : 0;
+  const uint32_t nf = (uint32_t)a.Kf * (uint32_t)a.Mpad_f;
+  const uint32_t nd = a.wt_d ? (uint32_t)a.Kd * (uint32_t)a.Mpad_d : 0u;
   const int T = a.T;
-  for (size_t i = start; i < nf + nd; i += stride) {
+  for (uint32_t i = (uint32_t)start; i < nf + nd; i += (uint32_t)stride) {   // (32-bit index arithmetic, as above)
     if (i < nf) {
-      const int krow = (int)(i / a.Mpad_f), m = (int)(i - (size_t)krow * a.Mpad_f);
+      const int krow = (int)(i / (uint32_t)a.Mpad_f), m = (int)(i - (uint32_t)krow * (uint32_t)a.Mpad_f);
       int tap, c, cg;
       bool ok;
       const int k1 = T * a.C1p;
@@ -342,8 +346,8 @@ __device__ __forceinline__ void wn_pack_body(const WnArgs& a, size_t start, size
       if (ok && m < a.d.Cout) w = a.scale[m] * a.v[((size_t)m * a.Ctot + cg) * T + tap];
       a.wt_f[i] = w;
     } else {
-      const size_t e = i - nf;
-      const int row = (int)(e / a.Mpad_d), ci = (int)(e - (size_t)row * a.Mpad_d);
+      const uint32_t e = i - nf;
+      const int row = (int)(e / (uint32_t)a.Mpad_d), ci = (int)(e - (uint32_t)row * (uint32_t)a.Mpad_d);
       const int tap = row / a.Coutp2, co = row - tap * a.Coutp2;
       float w = 0.f;
       if (co < a.d.Cout && ci < a.Ctot) w = a.scale[co] * a.v[((size_t)co * a.Ctot + ci) * T + tap];
@@ -358,10 +362,19 @@ __global__ __launch_bounds__(64) void wn_scale_multi_kernel(const WnItemDev* __r
   wn_scale_body(item_args(it), blockIdx.x, threadIdx.x);
 }
 
+// One grid row per layer, gridDim.x workgroups wide; a layer uses as many of its row's workgroups as it has work for (one
+// per 1024 matrix elements) and the rest leave at once.  Round 3 gave every layer 64: the launch took 300 us at the top of
+// every step, nothing beside it, waiting for the few 256 -> 128 layers' 64 workgroups on a quarter of the chip while the
+// 32-channel layers' had left long ago (profiles/r04_timeline_graph.txt).
 __global__ __launch_bounds__(256) void wn_pack_multi_kernel(const WnItemDev* __restrict__ items) {
   const WnArgs a = item_args(items[blockIdx.y]);
-  wn_pack_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
-  wn_pack_split_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+  const size_t n = (size_t)a.Kf * a.Mpad_f + (a.wt_d ? (size_t)a.Kd * a.Mpad_d : 0);
+  size_t nb = (n + 1023) / 1024;
+  if (nb > gridDim.x) nb = gridDim.x;
+  if (nb < 1) nb = 1;
+  if (blockIdx.x >= nb) return;
+  wn_pack_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, nb * 256);
+  wn_pack_split_body(a, (size_t)blockIdx.x * 256 + threadIdx.x, nb * 256);
 }
 
 extern "C" int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_t n_items, int32_t max_cout,
@@ -371,7 +384,7 @@ extern "C" int vunet_weightnorm_fwd_multi(const vunet_wn_item* items_dev, int32_
   const WnItemDev* items = reinterpret_cast<const WnItemDev*>(items_dev);
   hipStream_t st = (hipStream_t)stream;
   VUNET_LAUNCH(wn_scale_multi_kernel, dim3((unsigned)max_cout, (unsigned)n_items), dim3(64), 0, st, items);
-  VUNET_LAUNCH(wn_pack_multi_kernel, dim3(64, (unsigned)n_items), dim3(256), 0, st, items);
+  VUNET_LAUNCH(wn_pack_multi_kernel, dim3(512, (unsigned)n_items), dim3(256), 0, st, items);
   return vunet_check_launch();
 }
 
