@@ -541,3 +541,17 @@ def test_1x1_kernel_16_byte_epilogue_forms(mode, act, drop, with_res, c, cout):
     if res is not None:
         ref = ref + res.double().cpu()
     assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (1, 5, 6, 24), (2, 4, 4, 12), (3, 32, 64, 64), (1, 2, 2, 2)])
+def test_space_to_depth_kernel_forms(shape):
+    """vunet_space_to_depth in both kernel forms (16-byte vectors for W % 8 == 0, per element otherwise) against the
+    index formula of lib/modules.py:11-21: y[n, (2i + j) C + c, h, w] = x[n, c, 2h + i, 2w + j] -- a permutation, bit-exact;
+    and depth-to-space inverts it."""
+    from behavior_driven_video_synthesis_amd import ops
+    n, c, h, w = shape
+    x = torch.randn(n, c, h, w, device="cuda")
+    y = ops.SpaceToDepth.apply(x)
+    ref = x.view(n, c, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(n, 4 * c, h // 2, w // 2)
+    assert torch.equal(y, ref)
+    assert torch.equal(ops.DepthToSpace.apply(y), x)
