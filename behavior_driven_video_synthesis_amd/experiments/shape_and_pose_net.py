@@ -234,10 +234,25 @@ class ShapePoseNet:
             static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=self._graph_stream):
+            steps_before = [b.step for b in self.optimizer.buckets]
+            try:
+                with torch.cuda.graph(graph, stream=self._graph_stream):
+                    self.optimizer.zero_grad()
+                    with ops.prepacked(self.vunet):
+                        out = self._step(static, it, None, None)
+            except Exception as e:   # noqa: BLE001 -- a runtime that cannot record this step: say so and issue eagerly from here on
+                import sys
+                print(f"[vunet] hipGraph capture of the training step failed ({type(e).__name__}: {e}); the step is issued "
+                      "eagerly (device-resident schedule) from here on", file=sys.stderr)
+                self._capture = False
+                self._graphs.clear()
+                for b, n in zip(self.optimizer.buckets, steps_before):   # the aborted pass advanced the host-side counts
+                    b.step = n
+                ops.flush_weight_grads()
+                torch.cuda.synchronize()
                 self.optimizer.zero_grad()
                 with ops.prepacked(self.vunet):
-                    out = self._step(static, it, None, None)
+                    return self._step(batch, it, eps, reg_eps)
             rec = self._graphs[key] = {"graph": graph, "static": static, "out": out}
         else:
             for k, v in batch.items():
