@@ -362,12 +362,116 @@ __global__ __launch_bounds__(64) void wn_scale_multi_kernel(const WnItemDev* __r
   wn_scale_body(item_args(it), blockIdx.x, threadIdx.x);
 }
 
-// One grid row per layer, gridDim.x workgroups wide; a layer uses as many of its row's workgroups as it has work for (one
-// per 1024 matrix elements) and the rest leave at once.  Round 3 gave every layer 64: the launch took 300 us at the top of
-// every step, nothing beside it, waiting for the few 256 -> 128 layers' 64 workgroups on a quarter of the chip while the
-// 32-channel layers' had left long ago (profiles/r04_timeline_graph.txt).
+// ---- batched pack, one grid row per layer.
+// Round 3 gave every layer 64 workgroups that each GATHERED their outputs from v (one float per output element, neighbouring
+// lanes K floats apart: 64 cache lines per load instruction, every line of v fetched again for each of its nine taps and for each
+// of the four images): 300 us at the top of every step with nothing beside it (profiles/r04_timeline_graph.txt).  A 3x3 layer of
+// the fp16 scheme is now packed by TILES: one workgroup = 32 output channels x one 16-channel chunk x 9 taps of v, read once,
+// coalesced (32 rows of 576 contiguous bytes), scaled, parked in LDS (row stride 145 floats: conflict-free along either axis),
+// and written out four times -- the two fp32 K-major matrices and the two split images -- each in its own coalesced order.
+// Regions no tile owns (padding m-tiles of the images, columns past Ctot of wt_d) are never touched: the host allocates these
+// buffers zero-filled (ops.py).  Other layers (1x1, ragged channel counts, the bf16 scheme) keep the gathering loop, with
+// workgroups per layer by its size.
+constexpr int WN_TILE_LD = 145;
+
+__device__ __forceinline__ bool wn_tiled_ok(const WnArgs& a) {
+  return a.T == 9 && a.d.split == 2 && a.wx_f != nullptr && a.d.C1 % 16 == 0 && a.d.C2 % 16 == 0;
+}
+
+__device__ __forceinline__ void wn_pack_tile(const WnArgs& a, int mtile, int ch, float* tile) {
+  const int tid = threadIdx.x;
+  const int nch1 = a.d.C1 / 16;
+  const bool second = ch >= nch1;
+  const int cg0 = second ? a.d.C1 + (ch - nch1) * 16 : ch * 16;   // first channel of the chunk among all input channels
+  const int m0 = mtile * 32;
+  const int ew = wn_layer_exp(a);                                 // (cooperative: every thread of the workgroup)
+  const float sw = h2_pow2(ew);
+  // ---- v tile -> LDS, scaled: tile[co][ci * 9 + tap]
+  for (int e = tid; e < 32 * 144; e += 256) {
+    const int r = e / 144, k = e - r * 144;
+    const int co = m0 + r;
+    tile[r * WN_TILE_LD + k] = co < a.d.Cout ? a.scale[co] * a.v[((size_t)co * a.Ctot + cg0) * 9 + k] : 0.f;
+  }
+  __syncthreads();
+  // ---- wt_f: rows (source, tap, channel), columns m -- 32 consecutive floats per row
+  {
+    const int cl0 = second ? (ch - nch1) * 16 : ch * 16;          // first channel of the chunk inside its source
+    const int krow0 = second ? 9 * a.C1p : 0, Cp = second ? a.C2p : a.C1p;
+    for (int e = tid; e < 32 * 144; e += 256) {
+      const int m = e & 31, q = e >> 5;
+      const int ci = q & 15, tap = q >> 4;
+      a.wt_f[(size_t)(krow0 + tap * Cp + cl0 + ci) * a.Mpad_f + m0 + m] = tile[m * WN_TILE_LD + ci * 9 + tap];
+    }
+  }
+  // ---- wt_d: rows (tap, co), columns input channel -- 16 consecutive floats per row
+  if (a.wt_d) {
+    for (int e = tid; e < 32 * 144; e += 256) {
+      const int ci = e & 15, q = e >> 4;
+      const int r = q & 31, tap = q >> 5;
+      const int co = m0 + r;
+      if (co < a.Coutp2) a.wt_d[(size_t)(tap * a.Coutp2 + co) * a.Mpad_d + cg0 + ci] = tile[r * WN_TILE_LD + ci * 9 + tap];
+    }
+  }
+  // ---- forward image: K chunk `ch`, m-tile `mtile`: units (tap, plane, half, j): 32 consecutive units per (tap, plane, half)
+  {
+    uint4* const out = a.wx_f + 1;
+    const int mtp = x6_mtiles(a.d.Cout);
+    if (mtile == 0 && ch == 0 && tid == 0) a.wx_f[0] = make_uint4((uint32_t)ew, 0u, 0u, 0u);
+    for (int e = tid; e < 9 * 2 * 32; e += 256) {
+      const int j = e & 31, half = (e >> 5) & 1, tap = e >> 6;
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      float w[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[c] = tile[j * WN_TILE_LD + (half * 8 + c) * 9 + tap] * sw;
+      uint4 ph, pl;
+      h2_split2(w[0], w[1], ph.x, pl.x);
+      h2_split2(w[2], w[3], ph.y, pl.y);
+      h2_split2(w[4], w[5], ph.z, pl.z);
+      h2_split2(w[6], w[7], ph.w, pl.w);
+      const size_t base = ((((size_t)(ch * 3 + kh) * mtp + mtile) * 3 + kw) * 2) * 64 + half * 32 + j;
+      out[base] = ph;
+      out[base + 64] = pl;
+    }
+  }
+  // ---- data-gradient image: K = output channels (this tile: chunks 2 mtile, 2 mtile + 1), M = input channels
+  if (a.wx_d) {
+    uint4* const out = a.wx_d + 1;
+    const int mtp = x6_mtiles(a.Ctot);
+    if (mtile == 0 && ch == 0 && tid == 0) a.wx_d[0] = make_uint4((uint32_t)ew, 0u, 0u, 0u);
+    for (int e = tid; e < 2 * 9 * 2 * 16; e += 256) {
+      const int ci = e & 15, half = (e >> 4) & 1;
+      const int q = e >> 5;
+      const int tap = q % 9, chl = q / 9;
+      const int chd = 2 * mtile + chl;
+      if (chd * 16 >= a.d.Cout) continue;
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      float w[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[c] = tile[(chl * 16 + half * 8 + c) * WN_TILE_LD + ci * 9 + tap] * sw;
+      uint4 ph, pl;
+      h2_split2(w[0], w[1], ph.x, pl.x);
+      h2_split2(w[2], w[3], ph.y, pl.y);
+      h2_split2(w[4], w[5], ph.z, pl.z);
+      h2_split2(w[6], w[7], ph.w, pl.w);
+      const int cgt = cg0 + ci;
+      const size_t base = ((((size_t)(chd * 3 + kh) * mtp + (cgt >> 5)) * 3 + kw) * 2) * 64 + half * 32 + (cgt & 31);
+      out[base] = ph;
+      out[base + 64] = pl;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wn_pack_multi_kernel(const WnItemDev* __restrict__ items) {
+  __shared__ float tile[32 * WN_TILE_LD];
   const WnArgs a = item_args(items[blockIdx.y]);
+  if (wn_tiled_ok(a)) {
+    const int ntm = (a.d.Cout + 31) / 32, nch = a.Ctot / 16;
+    for (int t = blockIdx.x; t < ntm * nch; t += gridDim.x) {   // (wave-uniform trip count)
+      wn_pack_tile(a, t % ntm, t / ntm, tile);
+      __syncthreads();                                          // the tile is rewritten by the next round
+    }
+    return;
+  }
   const size_t n = (size_t)a.Kf * a.Mpad_f + (a.wt_d ? (size_t)a.Kd * a.Mpad_d : 0);
   size_t nb = (n + 1023) / 1024;
   if (nb > gridDim.x) nb = gridDim.x;

@@ -360,7 +360,8 @@ def _alloc_x6(cout, c1, c2, k, dgrad, dev):
     if _scheme() == 0:
         return None
     n = x6_image_units(cout, c1, c2, k, dgrad, _scheme())
-    return torch.empty(n * 4, device=dev, dtype=torch.int32) if n else None
+    # (zero-filled ONCE: the tiled pack never touches the padding m-tiles of an image, vunet_weightnorm_fwd_multi)
+    return torch.zeros(n * 4, device=dev, dtype=torch.int32) if n else None
 
 
 def pack_weights(v, g, bias, gamma, beta, c1: int, c2: int, kind: int, need_dgrad: bool):
@@ -765,8 +766,9 @@ def _build_prepack_set(model):
         c1, c2, need_x = m._last_split
         cout, ctot, kh, kw = v.shape
         t = kh * kw
-        wt_f = torch.empty(t * (_r2(c1) + _r2(c2)), _r32(cout), device=dev, dtype=torch.float32)
-        wt_d = torch.empty(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_x else None
+        # (zero-filled once: the tiled pack writes what its tiles own -- columns past Ctot of wt_d stay as allocated)
+        wt_f = torch.zeros(t * (_r2(c1) + _r2(c2)), _r32(cout), device=dev, dtype=torch.float32)
+        wt_d = torch.zeros(t * _r2(cout), _r32(ctot), device=dev, dtype=torch.float32) if need_x else None
         wx_f = _alloc_x6(cout, c1, c2, kh, False, dev) if kh == kw else None
         wx_d = _alloc_x6(cout, c1, c2, kh, True, dev) if (need_x and kh == kw) else None
         small = torch.empty(4, cout, device=dev, dtype=torch.float32)

@@ -38,6 +38,11 @@ def step_side():
     cur.wait_stream(side)
 
 
+def step_side_nowait():
+    with torch.cuda.stream(side):
+        tr.train_fn(batch)
+
+
 def block(fn, n=10):
     for _ in range(3):
         fn()
@@ -54,6 +59,8 @@ for _ in range(6):
     tr.train_fn(batch)
 res["1 eager host schedule, default stream"] = [round(block(step_plain), 2) for _ in range(3)]
 res["2 eager host schedule, side stream + waits"] = [round(block(step_side), 2) for _ in range(3)]
+res["2b eager host schedule, side stream, no waits"] = [round(block(step_side_nowait), 2) for _ in range(3)]
+res["1 again"] = [round(block(step_plain), 2) for _ in range(3)]
 tr.enable_hip_graph(capture=False)
 res["3 eager device schedule (on its stream)"] = [round(block(step_plain), 2) for _ in range(3)]
 orig = ops.set_dropout_step
