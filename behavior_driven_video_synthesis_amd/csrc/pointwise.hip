@@ -716,7 +716,7 @@ extern "C" int vunet_upsample_bilinear2x_bwd(const float* dy, float* dx, int64_t
   return vunet_check_launch();
 }
 
-extern "C" int vunet_abi_version(void) { return 7; }
+extern "C" int vunet_abi_version(void) { return 8; }
 
 // ------------------------------------------------------------------ window crop with a device-resident corner
 __global__ void crop_window_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int H, int W, int P,
@@ -741,5 +741,63 @@ extern "C" int vunet_crop_window_bwd(const float* dy, float* dx, int32_t planes,
                                      const int32_t* off, void* st) {
   if (!dy || !dx || !off || planes < 1 || P < 1 || P > H || P > W) return VUNET_ERR_ARG;
   VUNET_LAUNCH(crop_window_kernel, ew_grid((int64_t)planes * P * P), dim3(256), 0, (hipStream_t)st, dy, dx, planes, H, W, P, off, 1);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ the step's scalar glue as single launches
+// loss = ll_weight * sum_i term[i] (+ gamma * kl) -- experiments/shape_and_pose_net.py:391-405 -- and its gradient.  One
+// thread: six to eight scalars.  The sum runs in double and is rounded once (any fp32 summation order is within 1 ulp of it).
+struct LossTermPtrs {
+  const float* t[VUNET_LOSS_MAX_TERMS];
+};
+__global__ void total_loss_kernel(LossTermPtrs a, int n, const float* __restrict__ kl, const float* __restrict__ gamma,
+                                  float gamma_const, float ll_weight, int use_kl, float* __restrict__ loss,
+                                  float* __restrict__ llo) {
+  if (threadIdx.x | blockIdx.x) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += (double)a.t[i][0];
+  const float ll = __fmul_rn(ll_weight, (float)s);
+  llo[0] = ll;
+  const float g = gamma ? gamma[0] : gamma_const;
+  loss[0] = use_kl ? __fadd_rn(ll, __fmul_rn(g, kl[0])) : ll;   // (separately rounded, as the reference's mul / add)
+}
+__global__ void total_loss_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ g_ll, int n,
+                                      const float* __restrict__ gamma, float gamma_const, float ll_weight, int use_kl,
+                                      float* __restrict__ d) {
+  const int i = threadIdx.x;
+  if (blockIdx.x || i > n) return;
+  const float gl = g_loss ? g_loss[0] : 0.f, gll = g_ll ? g_ll[0] : 0.f;
+  if (i < n) d[i] = __fmul_rn(ll_weight, __fadd_rn(gl, gll));
+  else d[n] = use_kl ? gl * (gamma ? gamma[0] : gamma_const) : 0.f;
+}
+extern "C" int vunet_total_loss(const float* const* terms, int32_t n, const float* kl, const float* gamma, float gamma_const,
+                                float ll_weight, int32_t use_kl, float* loss, float* ll, void* st) {
+  if (!terms || n < 1 || n > VUNET_LOSS_MAX_TERMS || !loss || !ll || (use_kl && !kl)) return VUNET_ERR_ARG;
+  LossTermPtrs a;
+  for (int i = 0; i < VUNET_LOSS_MAX_TERMS; ++i) a.t[i] = i < n ? terms[i] : nullptr;
+  for (int i = 0; i < n; ++i)
+    if (!a.t[i]) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(total_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, a, n, kl, gamma, gamma_const, ll_weight, use_kl, loss,
+               ll);
+  return vunet_check_launch();
+}
+extern "C" int vunet_total_loss_bwd(const float* g_loss, const float* g_ll, int32_t n, const float* gamma, float gamma_const,
+                                    float ll_weight, int32_t use_kl, float* d, void* st) {
+  if (n < 1 || n > VUNET_LOSS_MAX_TERMS || !d) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(total_loss_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, g_loss, g_ll, n, gamma, gamma_const, ll_weight,
+               use_kl, d);
+  return vunet_check_launch();
+}
+
+// gamma <- max(gamma - gamma_step * (information_max - avg_kl), 0), in place (experiments/shape_and_pose_net.py:82-85, 442)
+__global__ void gamma_update_kernel(float* __restrict__ gamma, const float* __restrict__ imax, const float* __restrict__ kl,
+                                    float gamma_step) {
+  if (threadIdx.x | blockIdx.x) return;
+  const float g = __fsub_rn(gamma[0], __fmul_rn(gamma_step, __fsub_rn(imax[0], kl[0])));   // no fma: the reference's rounding
+  gamma[0] = g > 0.f ? g : (g != g ? g : 0.f);     // torch.clamp(min=0) passes NaN through
+}
+extern "C" int vunet_gamma_update(float* gamma, const float* imax, const float* avg_kl, float gamma_step, void* st) {
+  if (!gamma || !imax || !avg_kl) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(gamma_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, gamma, imax, avg_kl, gamma_step);
   return vunet_check_launch();
 }

@@ -342,13 +342,11 @@ class ShapePoseNet:
         else:
             out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps)
         ld = vgg_loss(self.custom_vgg, target_img, out_img, target_features=target_features)
-        likelihoods = torch.stack([ld[k] for k in ld], dim=0)
-        likelihood_loss = tr["ll_weight"] * torch.sum(likelihoods)
         kl = compute_kl_with_prior(means, logstds)
-        loss = likelihood_loss
-        if it > tr["n_init_batches"]:
-            tuning = 1.0 if self.config["architecture"].get("cvae", False) else self.gamma
-            loss = loss + tuning * kl
+        # :391-405 -- likelihood_loss = ll_weight * sum(terms); loss = likelihood_loss (+ tuning * kl after the init batches)
+        tuning = 1.0 if self.config["architecture"].get("cvae", False) else self.gamma
+        loss, likelihood_loss = ops.TotalLoss.apply(kl, tuning, tr["ll_weight"], it > tr["n_init_batches"],
+                                                    *[ld[k] for k in ld])
         out = {}
         if self.train_regressor and "reg_imgs" in batch:
             loss_regressor = self._regressor_steps(batch, reg_eps)
@@ -369,13 +367,13 @@ class ShapePoseNet:
         ops.flush_weight_grads()   # (normally already done by the end-of-backward callback) before the streams are joined
         self.vunet.join_streams()
         ops.join_wgrad_streams()
-        kl_avg = self.averager.finish(kl.detach().clone().reshape(1))
+        kl_avg = self.averager.finish(kl.detach().clone().reshape(1)) if self.averager.active else kl.detach()
         self.optimizer.step()
         if patches is not None:
             out.update(self.gan.train_disc(*patches, as_tensors=True))   # device scalars: no host synchronisation
         # gamma controller on the device (:82-85,442); with DP every rank sees the averaged KL
         if self._dev_sched:   # in place, information_max from device memory: nothing here is a per-step launch argument
-            self.gamma.copy_(torch.clamp(self.gamma - tr["gamma_step"] * (self._imax_dev - kl_avg.reshape(())), min=0.0))
+            ops.gamma_update_(self.gamma, self._imax_dev, kl_avg, tr["gamma_step"])
         else:
             self.gamma = torch.clamp(self.gamma - tr["gamma_step"] * (self.imax - kl_avg.reshape(())), min=0.0)
         out.update({"loss": loss.detach(), "likelihood_loss": likelihood_loss.detach(), "kl_loss": kl.detach()})

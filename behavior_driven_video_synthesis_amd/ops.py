@@ -226,6 +226,19 @@ def _new_amax_out(dev):
     return a[0][a[1] - 1]
 
 
+def _zero_scalar(dev, shape=(1,)):
+    """A zeroed fp32 accumulator for a loss kernel (they add their workgroups' partial sums into it): a slice of this
+    step's zeroed arena -- no fill launch of its own.  Each accumulator gets 64 bytes of a row."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, _raw_stream(idx) if _raw_stream is not None else 0)
+    z = _zero_rows.get(key)
+    if z is None or z[1] + 16 > z[0].numel():
+        z = _zero_rows[key] = [_new_amax_out(dev), 0]
+    z[1] += 16
+    return z[0][z[1] - 16:z[1] - 15].view(shape)
+
+
+_zero_rows = {}
 _amax_retired = []
 
 
@@ -237,6 +250,7 @@ def _reset_amax_arena():
     of grace is enough (and costs no record_stream call per launch)."""
     _amax_retired[:] = [list(_amax_arena.values())]
     _amax_arena.clear()
+    _zero_rows.clear()
 
 
 def _tag_amax(t, buf):
@@ -1340,6 +1354,44 @@ class Reparam(torch.autograd.Function):
         return dmu, dls, None
 
 
+class TotalLoss(torch.autograd.Function):
+    """(loss, likelihood_loss) of the training step from its scalar terms, ONE launch each way (vunet_total_loss / _bwd):
+    likelihood_loss = ll_weight * sum(terms), loss = likelihood_loss + gamma * kl once the KL term is on -- the reference's
+    torch.stack / sum / mul / add chain (experiments/shape_and_pose_net.py:391-405) and its five backward nodes.  ``gamma``: a
+    device scalar (the controller's state, no gradient) or a Python float."""
+
+    @staticmethod
+    def forward(ctx, kl, gamma, ll_weight: float, use_kl: bool, *terms):
+        _dev(kl, *terms)
+        n = len(terms)
+        g_t = gamma if torch.is_tensor(gamma) else None
+        g_c = 0.0 if g_t is not None else float(gamma)
+        loss = torch.empty((), device=kl.device, dtype=torch.float32)
+        ll = torch.empty((), device=kl.device, dtype=torch.float32)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+        _call("vunet_total_loss", ptrs, n, _p(kl), _p(g_t), g_c, float(ll_weight), int(bool(use_kl)), _p(loss), _p(ll), _stream())
+        ctx.cfg = (n, g_t, g_c, float(ll_weight), int(bool(use_kl)), [t.shape for t in terms], kl.shape)
+        return loss, ll
+
+    @staticmethod
+    def backward(ctx, g_loss, g_ll):
+        n, g_t, g_c, llw, use_kl, shapes, kl_shape = ctx.cfg
+        ref = g_loss if g_loss is not None else g_ll
+        d = torch.empty(n + 1, device=ref.device, dtype=torch.float32)
+        _call("vunet_total_loss_bwd", _p(None if g_loss is None else _c(g_loss)), _p(None if g_ll is None else _c(g_ll)), n,
+              _p(g_t), g_c, llw, use_kl, _p(d), _stream())
+        return (d[n:n + 1].view(kl_shape) if use_kl else None, None, None, None,
+                *[d[i:i + 1].view(sh) for i, sh in enumerate(shapes)])
+
+
+def gamma_update_(gamma, imax, avg_kl, gamma_step: float):
+    """gamma <- max(gamma - gamma_step * (information_max - avg_kl), 0) in place, all three device scalars: one launch
+    (vunet_gamma_update; experiments/shape_and_pose_net.py:82-85, 442)."""
+    _dev(gamma, imax, avg_kl)
+    _call("vunet_gamma_update", _p(gamma), _p(imax), _p(avg_kl), float(gamma_step), _stream())
+    return gamma
+
+
 class L1Mean(torch.autograd.Function):
     """weight * mean|target - pred|, shape [1]; gradient flows to pred only (lib/losses.py:98-102)."""
 
@@ -1347,7 +1399,7 @@ class L1Mean(torch.autograd.Function):
     def forward(ctx, target, pred, weight: float):
         _dev(target, pred)
         target, pred = _c(target), _c(pred)
-        out = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        out = _zero_scalar(pred.device)
         partial = torch.empty(1024, device=pred.device, dtype=torch.float32)
         _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
         ctx.save_for_backward(target, pred)
@@ -1388,7 +1440,7 @@ class L1MeanThrough(torch.autograd.Function):
         _dev(target, pred)
         assert pred.is_contiguous()
         target = _c(target)
-        out = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        out = _zero_scalar(pred.device)
         partial = torch.empty(1024, device=pred.device, dtype=torch.float32)
         _call("vunet_l1_mean_fwd", _p(target), _p(pred), _p(partial), _p(out), float(weight), pred.numel(), _stream())
         ctx.save_for_backward(target, pred)
@@ -1419,7 +1471,7 @@ class L1ThroughPool(torch.autograd.Function):
         _dev(target, pred)
         target, pred = _c(target), _c(pred)
         n, c, h, w = pred.shape
-        out = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        out = _zero_scalar(pred.device)
         partial = torch.empty(1024, device=pred.device, dtype=torch.float32)
         y = torch.empty(n, c, h // 2, w // 2, device=pred.device, dtype=pred.dtype)
         _call("vunet_l1_pool_fwd", _p(target), _p(pred), _p(partial), _p(out), _p(y), float(weight), n * c, h, w, _stream())
@@ -1457,7 +1509,7 @@ class KLPrior(torch.autograd.Function):
         mu, logstd = _c(mu), _c(logstd)
         n = mu.shape[0]
         d = mu.numel() // n
-        out = torch.zeros((), device=mu.device, dtype=torch.float32)
+        out = _zero_scalar(mu.device, ())
         partial = torch.empty(256, device=mu.device, dtype=torch.float32)
         _call("vunet_kl_fwd", _p(mu), _p(logstd), _p(partial), _p(out), float(weight), n, d, _stream())
         ctx.save_for_backward(mu, logstd)
@@ -1480,7 +1532,7 @@ class SqDiff(torch.autograd.Function):
         _dev(p, q)
         p, q = _c(p), _c(q)
         n = p.shape[0]
-        out = torch.zeros((), device=p.device, dtype=torch.float32)
+        out = _zero_scalar(p.device, ())
         partial = torch.empty(256, device=p.device, dtype=torch.float32)
         _call("vunet_sqdiff_fwd", _p(p), _p(q), _p(partial), _p(out), float(weight), n, p.numel() // n, _stream())
         ctx.save_for_backward(p, q)

@@ -20,14 +20,18 @@ from . import ops
 class FlatBucket:
     """One contiguous fp32 buffer holding a list of parameters (and one holding their gradients)."""
 
-    def __init__(self, params: List[torch.nn.Parameter], name: str = ""):
+    def __init__(self, params: List[torch.nn.Parameter], name: str = "", flat: torch.Tensor = None,
+                 grad: torch.Tensor = None):
+        """``flat`` / ``grad``: slices of an arena shared by all buckets of an optimiser (FusedAdam), so that zeroing the
+        gradients and the Adam update are ONE launch each over the arena; None: buffers of the bucket's own."""
         self.name = name
         self.params = [p for p in params]
         assert self.params, "empty parameter group"
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.flat = flat if flat is not None else torch.empty(self.numel, device=dev, dtype=torch.float32)
+        self.grad = grad if grad is not None else torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        assert self.flat.numel() == self.numel and self.grad.numel() == self.numel
         self.offsets = []
         off = 0
         with torch.no_grad():
@@ -40,8 +44,9 @@ class FlatBucket:
                 self.offsets.append(off)
                 off += n
 
-    def zero_grad(self):
-        self.grad.zero_()
+    def zero_grad(self, fill: bool = True):
+        if fill:
+            self.grad.zero_()
         for p, off in zip(self.params, self.offsets):  # re-attach in case autograd replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
@@ -62,18 +67,46 @@ class FusedAdam:
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False)
         self.param_groups: List[Dict] = []
         self.buckets: List[FlatBucket] = []
+        groups = [dict(g) for g in groups]
         for g in groups:
-            g = dict(g)
             g["params"] = list(g["params"])
             for k, v in self.defaults.items():
                 g.setdefault(k, v)
-            b = FlatBucket(g["params"], g.get("name", ""))
-            b.exp_avg = torch.zeros_like(b.flat)
-            b.exp_avg_sq = torch.zeros_like(b.flat)
+        # ONE arena for the parameters, gradients and moments of all groups (each bucket a 256-byte-aligned slice): zeroing
+        # the gradients and -- while the groups share their hyper-parameters, as the reference's do (:237-246, one lr
+        # schedule for all four) -- the Adam update are one launch each instead of one per group.  The padding between
+        # slices holds zeros and stays zero (g = 0, m = v = 0: the update is 0).
+        dev = groups[0]["params"][0].device if groups and groups[0]["params"] else None
+        sizes = [sum(p.numel() for p in g["params"]) for g in groups]
+        starts, total = [], 0
+        for n in sizes:
+            starts.append(total)
+            total += (n + 63) // 64 * 64
+        self._arena = None
+        if dev is not None and len(groups) > 1:
+            self._arena = {k: torch.zeros(total, device=dev, dtype=torch.float32) for k in ("flat", "grad", "m", "v")}
+        for g, n, st in zip(groups, sizes, starts):
+            if self._arena is not None:
+                b = FlatBucket(g["params"], g.get("name", ""), self._arena["flat"][st:st + n], self._arena["grad"][st:st + n])
+                b.exp_avg, b.exp_avg_sq = self._arena["m"][st:st + n], self._arena["v"][st:st + n]
+            else:
+                b = FlatBucket(g["params"], g.get("name", ""))
+                b.exp_avg = torch.zeros_like(b.flat)
+                b.exp_avg_sq = torch.zeros_like(b.flat)
             b.step = 0
             self.buckets.append(b)
             self.param_groups.append(g)
         self.lr_dev = self.step_dev = None
+
+    def _uniform(self):
+        """The hyper-parameters all groups share, or None (then every bucket gets its own launch)."""
+        if self._arena is None:
+            return None
+        keys = ("lr", "betas", "eps", "weight_decay")
+        first = tuple(self.param_groups[0][k] for k in keys)
+        if all(tuple(g[k] for k in keys) == first for g in self.param_groups) and len({b.step for b in self.buckets}) == 1:
+            return first
+        return None
 
     def use_device_schedule(self, lr_dev: torch.Tensor = None):
         """Keep the step count (int64) and the learning rate (float64, ``lr_dev`` or a tensor of its own) on the device:
@@ -95,8 +128,10 @@ class FusedAdam:
             b.step += n
 
     def zero_grad(self, set_to_none: bool = False):
+        if self._arena is not None:
+            self._arena["grad"].zero_()
         for b in self.buckets:
-            b.zero_grad()
+            b.zero_grad(fill=self._arena is None)
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
@@ -113,15 +148,29 @@ class FusedAdam:
                     self.lr_dev.fill_(lr)
                     self._lr_mirrored = lr
             self.step_dev.add_(1)
-            for g, b in zip(self.param_groups, self.buckets):
+            uni = self._uniform()
+            for b in self.buckets:
                 b.gather_foreign_grads()
                 b.step += 1
+            if uni is not None:
+                ar = self._arena
+                ops.adam_step_flat_dev(ar["flat"], ar["grad"], ar["m"], ar["v"], self.lr_dev, uni[1][0], uni[1][1], uni[2],
+                                       uni[3], self.step_dev, grad_scale)
+                return
+            for g, b in zip(self.param_groups, self.buckets):
                 ops.adam_step_flat_dev(b.flat, b.grad, b.exp_avg, b.exp_avg_sq, self.lr_dev, g["betas"][0], g["betas"][1],
                                        g["eps"], g["weight_decay"], self.step_dev, grad_scale)
             return
-        for g, b in zip(self.param_groups, self.buckets):
+        uni = self._uniform()
+        for b in self.buckets:
             b.gather_foreign_grads()
             b.step += 1
+        if uni is not None:
+            ar = self._arena
+            ops.adam_step_flat(ar["flat"], ar["grad"], ar["m"], ar["v"], uni[0], uni[1][0], uni[1][1], uni[2], uni[3],
+                               self.buckets[0].step, grad_scale)
+            return
+        for g, b in zip(self.param_groups, self.buckets):
             ops.adam_step_flat(b.flat, b.grad, b.exp_avg, b.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
                                g["eps"], g["weight_decay"], b.step, grad_scale)
 

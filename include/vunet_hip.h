@@ -456,6 +456,21 @@ int vunet_crop_window(const float* x, float* y, int32_t planes, int32_t H, int32
 int vunet_crop_window_bwd(const float* dy, float* dx, int32_t planes, int32_t H, int32_t W, int32_t P, const int32_t* off,
                           void* stream);
 
+/* The training step's scalar glue, one launch each (every operand a device scalar: nothing here changes between steps, so
+ * the launches sit in the captured hipGraph).
+ * vunet_total_loss: *ll = likelihood_loss = ll_weight * sum_i terms[i][0]  (n <= VUNET_LOSS_MAX_TERMS perceptual terms; terms is
+ *   a HOST array of n device pointers), *loss = likelihood_loss + g * kl[0] when use_kl, else likelihood_loss; g = gamma[0] (device) or gamma_const when
+ *   gamma is NULL  (reference experiments/shape_and_pose_net.py:391-405: torch.stack / sum / ll_weight * / + tuning * kl).
+ * vunet_total_loss_bwd: d[i] = ll_weight * (g_loss + g_ll) for the n terms, d[n] = g_loss * g (0 without use_kl); g_loss /
+ *   g_ll may be NULL (= 0).
+ * vunet_gamma_update: gamma[0] <- max(gamma[0] - gamma_step * (imax[0] - avg_kl[0]), 0)   (:82-85, :442). */
+#define VUNET_LOSS_MAX_TERMS 8
+int vunet_total_loss(const float* const* terms, int32_t n, const float* kl, const float* gamma, float gamma_const,
+                     float ll_weight, int32_t use_kl, float* loss, float* ll, void* stream);
+int vunet_total_loss_bwd(const float* g_loss, const float* g_ll, int32_t n, const float* gamma, float gamma_const,
+                         float ll_weight, int32_t use_kl, float* d, void* stream);
+int vunet_gamma_update(float* gamma, const float* imax, const float* avg_kl, float gamma_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

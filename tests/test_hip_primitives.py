@@ -555,3 +555,38 @@ def test_space_to_depth_kernel_forms(shape):
     ref = x.view(n, c, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(n, 4 * c, h // 2, w // 2)
     assert torch.equal(y, ref)
     assert torch.equal(ops.DepthToSpace.apply(y), x)
+
+
+@pytest.mark.parametrize("use_kl,gamma", [(True, "dev"), (True, 1.0), (False, "dev")])
+def test_total_loss_and_gamma_controller_vs_the_reference_expressions(use_kl, gamma):
+    """ops.TotalLoss / ops.gamma_update_ (one launch each) against the reference's expression chains
+    (experiments/shape_and_pose_net.py:391-405 and :82-85): values to 1 ulp of fp32, gradients exactly."""
+    from behavior_driven_video_synthesis_amd import ops
+    g = torch.Generator().manual_seed(5)
+    vals = (torch.rand(6, generator=g) * 40).tolist()
+    terms = [torch.tensor([v], device="cuda", requires_grad=True) for v in vals]
+    kl = torch.tensor(3.25, device="cuda", requires_grad=True)
+    gam = torch.tensor(0.37, device="cuda") if gamma == "dev" else gamma
+    loss, ll = ops.TotalLoss.apply(kl, gam, 0.7, use_kl, *terms)
+    t2 = [t.detach().clone().requires_grad_(True) for t in terms]
+    kl2 = kl.detach().clone().requires_grad_(True)
+    ll_ref = 0.7 * torch.sum(torch.stack(t2, dim=0))
+    loss_ref = ll_ref + gam * kl2 if use_kl else ll_ref
+    assert loss.shape == loss_ref.shape == () and ll.shape == ()
+    assert abs(float(ll) - float(ll_ref)) <= 2e-7 * abs(float(ll_ref))
+    assert abs(float(loss) - float(loss_ref)) <= 2e-7 * abs(float(loss_ref))
+    # both outputs carry gradient (the adversarial term's adaptive weight differentiates likelihood_loss on its own)
+    (2.0 * loss + 0.5 * ll).backward()
+    (2.0 * loss_ref + 0.5 * ll_ref).backward()
+    for a, b in zip(terms, t2):
+        assert a.grad.shape == b.grad.shape and torch.equal(a.grad, b.grad)
+    if use_kl:
+        assert torch.equal(kl.grad, kl2.grad)
+    else:
+        assert kl.grad is None and kl2.grad is None
+    for g0, imax, klv in ((0.5, 2.0, 3.0), (0.001, 9.0, 1.0), (0.0, 1.0, 1.0)):
+        gd = torch.tensor(g0, device="cuda")
+        im, kv = torch.tensor(imax, device="cuda"), torch.tensor([klv], device="cuda")
+        want = torch.clamp(gd - 0.01 * (im - kv.reshape(())), min=0.0)
+        ops.gamma_update_(gd, im, kv, 0.01)
+        assert torch.equal(gd, want)
