@@ -71,7 +71,7 @@ def declared_symbols() -> list:
 
 
 _CTYPE = {"int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "int64_t": ctypes.c_int64,
-          "float": ctypes.c_float, "int": ctypes.c_int}
+          "float": ctypes.c_float, "double": ctypes.c_double, "int": ctypes.c_int}
 
 
 def declared_prototypes() -> dict:

@@ -75,7 +75,7 @@ static int x6_pick(const vunet_conv_desc* d, int* MT, long min_blocks, bool h2 =
   // layers' load / store phases (32 channels at 256^2: 120 -> 112 us, r02)
   const int top = h2 ? (*MT == 1 ? 1 : 2) : (*MT == 1 ? 4 : 2);
   if (int NT = g_vunet_tune[VUNET_TUNE_SPLIT_FORCE_NT]) {  // tests / tuning (vunet_set_tuning)
-    if (NT > top) NT = top;
+    if (NT > top) NT = (h2 && *MT == 1 && NT == 2) ? 2 : top;   // (h2, one m-tile: the 8-row form is built, for A/B runs)
     if ((NT == 1 || NT == 2 || NT == 4) && x6_blocks(d, *MT, NT) > 0) return NT;
   }
   // (r03: one m-tile per workgroup for the 16-wide maps -- VGG19 conv5_x at bs 16 is 256 workgroups of two m-tiles, half of

@@ -801,3 +801,40 @@ extern "C" int vunet_gamma_update(float* gamma, const float* imax, const float* 
   VUNET_LAUNCH(gamma_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, gamma, imax, avg_kl, gamma_step);
   return vunet_check_launch();
 }
+
+// ------------------------------------------------------------------ unit-variance latent sample with in-kernel noise
+// z = mu + eps, eps ~ N(0, 1) drawn here (models/vunets.py:151-156: `p + torch.randn_like(p)`): Box-Muller on two 32-bit hashes of
+// (element index, seed, step) -- the step read from the device counter of vunet_set_dropout_step when one is set, so the launch
+// arguments stay constant from step to step (captured hipGraph) while every replay draws fresh noise.  One launch instead of
+// a zero-fill, a generator launch and the reparametrisation kernel; the backward is the identity.
+__global__ void unit_sample_kernel(const float* __restrict__ mu, float* __restrict__ z, float* __restrict__ eps_out, int64_t n,
+                                   uint32_t seed, const uint32_t* __restrict__ step) {
+  if (step) seed += step[0] * VUNET_DROP_STEP_MUL;
+  EW_LOOP(i, n) {
+    const uint32_t a = vunet_hash_u32((uint32_t)(2 * i) + seed), b = vunet_hash_u32((uint32_t)(2 * i + 1) + (seed ^ 0x68E31DA4u));
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);    // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);             // [0, 1)
+    const float e = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958648f * u2);
+    if (eps_out) eps_out[i] = e;
+    z[i] = mu[i] + e;
+  }
+}
+extern "C" int vunet_unit_sample(const float* mu, float* z, float* eps_out, int64_t n, uint32_t seed, void* st) {
+  if (!mu || !z || n < 0) return VUNET_ERR_ARG;
+  if (n == 0) return VUNET_OK;
+  VUNET_LAUNCH(unit_sample_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, z, eps_out, n, seed, g_vunet_drop_step);
+  return vunet_check_launch();
+}
+
+// ------------------------------------------------------------------ this step's schedule values -> device, one launch
+__global__ void set_schedule_kernel(double* lr, double lr_v, float* imax, float imax_v, int32_t* step, int32_t step_v) {
+  if (threadIdx.x | blockIdx.x) return;
+  if (lr) lr[0] = lr_v;
+  if (imax) imax[0] = imax_v;
+  if (step) step[0] = step_v;
+}
+extern "C" int vunet_set_schedule(double* lr_dev, double lr, float* imax_dev, float imax, int32_t* step_dev, int32_t step,
+                                  void* st) {
+  VUNET_LAUNCH(set_schedule_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, lr_dev, lr, imax_dev, imax, step_dev, step);
+  return vunet_check_launch();
+}

@@ -120,6 +120,7 @@ class ShapePoseNet:
         for pg in self.optimizer.param_groups:
             pg["lr"] = self.lr
         self.gamma = torch.zeros((), device=self.device, dtype=torch.float32)  # device-resident controller state
+        self._one = torch.ones((), device=self.device, dtype=torch.float32)    # seed of every backward pass
         # ---- hipGraph replay of the whole step (opt-in: ``training.hip_graph`` / VUNET_HIP_GRAPH=1 / the keyword)
         self._dev_sched = False
         self._graphs = {}
@@ -213,10 +214,8 @@ class ShapePoseNet:
         return out
 
     def _train_fn_graph_on_stream(self, batch, it, eps, reg_eps):
-        # host-side schedule values of THIS step -> device (three tiny launches outside the graph)
-        self._lr_dev.fill_(self.lr)
-        self._imax_dev.fill_(self.imax)
-        self._drop_step.fill_(it & 0x7FFFFFFF)
+        # host-side schedule values of THIS step -> device (one tiny launch outside the graph)
+        ops.set_schedule_(self._lr_dev, self.lr, self._imax_dev, self.imax, self._drop_step, it & 0x7FFFFFFF)
         # the library keeps ONE process-wide counter pointer: another graph-mode trainer (or set_dropout_step(None)) may
         # have replaced it since this trainer's last step -- re-assert ours (host-only, no launch) before anything draws
         ops.set_dropout_step(self._drop_step)
@@ -362,7 +361,7 @@ class ShapePoseNet:
             loss = loss + self.gan_weight * w * gen_loss
             out["gen_loss"] = gen_loss.detach()
             patches = (real_patch.detach(), fake_patch.detach())
-        loss.backward()
+        loss.backward(gradient=self._one)   # (a resident 1.0: no ones_like launch per step)
         self.averager.mark_backward_end()
         ops.flush_weight_grads()   # (normally already done by the end-of-backward callback) before the streams are joined
         self.vunet.join_streams()

@@ -104,6 +104,8 @@ class DecUp(_Pyramid):
 
 def latent_sample(p, eps: Optional[torch.Tensor] = None):
     """:151-156 -- unit-variance sample around ``p``."""
+    if eps is None and p.is_cuda:
+        return ops.UnitSample.apply(p)   # noise drawn inside the kernel: one launch, identity backward
     return ops.Reparam.apply(p, torch.zeros_like(p), _noise_like(p, eps))
 
 

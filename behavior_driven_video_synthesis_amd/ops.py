@@ -1354,6 +1354,30 @@ class Reparam(torch.autograd.Function):
         return dmu, dls, None
 
 
+class UnitSample(torch.autograd.Function):
+    """z = mu + eps with eps ~ N(0, 1) drawn inside the kernel (vunet_unit_sample; models/vunets.py:151-156): one launch
+    instead of zeros_like + randn_like + the reparametrisation kernel, and no backward launch (dz/dmu = 1).  The seed
+    follows the dropout seeds' sequence (next_dropout_seed), the step-to-step variation under a captured graph comes
+    from the device step counter (set_dropout_step)."""
+
+    @staticmethod
+    def forward(ctx, mu):
+        _dev(mu)
+        mu = _c(mu)
+        z = torch.empty_like(mu)
+        _call("vunet_unit_sample", _p(mu), _p(z), None, mu.numel(), next_dropout_seed(), _stream())
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        return dz
+
+
+def set_schedule_(lr_dev, lr: float, imax_dev, imax: float, step_dev, step: int):
+    """This step's learning rate / information_max / dropout step into their device scalars: one launch (vunet_set_schedule)."""
+    _call("vunet_set_schedule", _p(lr_dev), float(lr), _p(imax_dev), float(imax), _p(step_dev), int(step), _stream())
+
+
 class TotalLoss(torch.autograd.Function):
     """(loss, likelihood_loss) of the training step from its scalar terms, ONE launch each way (vunet_total_loss / _bwd):
     likelihood_loss = ll_weight * sum(terms), loss = likelihood_loss + gamma * kl once the KL term is on -- the reference's

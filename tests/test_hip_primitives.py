@@ -590,3 +590,43 @@ def test_total_loss_and_gamma_controller_vs_the_reference_expressions(use_kl, ga
         want = torch.clamp(gd - 0.01 * (im - kv.reshape(())), min=0.0)
         ops.gamma_update_(gd, im, kv, 0.01)
         assert torch.equal(gd, want)
+
+
+def test_unit_sample_draws_standard_normal_noise_and_passes_the_gradient_through():
+    """ops.UnitSample (vunet_unit_sample): z - mu is N(0, 1) noise -- moments, tail mass and lag-1 correlation of 2^20 draws
+    within a few standard errors -- reproducible from the seed sequence, fresh per call and per device step; dz/dmu = 1."""
+    from behavior_driven_video_synthesis_amd import ops
+    n = 1 << 20
+    mu = seeded_randn("us.mu", (4, 64, 64, 64), 3).cuda().requires_grad_(True)
+    ops.set_dropout_seed(1234)
+    z1 = ops.UnitSample.apply(mu)
+    z2 = ops.UnitSample.apply(mu)
+    ops.set_dropout_seed(1234)
+    z1b = ops.UnitSample.apply(mu)
+    assert torch.equal(z1, z1b) and not torch.equal(z1, z2)
+    e = (z1 - mu).detach().double().flatten()
+    assert abs(float(e.mean())) < 5 / n ** 0.5
+    assert abs(float(e.var()) - 1.0) < 5 * (2.0 / n) ** 0.5
+    assert abs(float((e ** 3).mean())) < 5 * (15.0 / n) ** 0.5
+    assert abs(float((e ** 4).mean()) - 3.0) < 5 * (96.0 / n) ** 0.5
+    assert abs(float((e.abs() > 2.0).double().mean()) - 0.0455003) < 5 * (0.0455 / n) ** 0.5
+    assert abs(float((e[1:] * e[:-1]).mean())) < 5 / n ** 0.5
+    assert abs(float((e * (z2 - mu).detach().double().flatten()).mean())) < 5 / n ** 0.5
+    g = seeded_randn("us.g", tuple(mu.shape), 4).cuda()
+    z1.backward(g)
+    assert torch.equal(mu.grad, g)
+    # the device step counter moves the noise without changing a launch argument
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.set_dropout_step(ctr)
+    try:
+        ops.set_dropout_seed(99)
+        a = ops.UnitSample.apply(mu.detach())
+        ctr.fill_(1)
+        ops.set_dropout_seed(99)
+        b = ops.UnitSample.apply(mu.detach())
+        ctr.fill_(0)
+        ops.set_dropout_seed(99)
+        a2 = ops.UnitSample.apply(mu.detach())
+    finally:
+        ops.set_dropout_step(None)
+    assert torch.equal(a, a2) and not torch.equal(a, b)

@@ -18,6 +18,7 @@ sys.argv = sys.argv[:1]
 args = parse()
 with contextlib.redirect_stdout(sys.stderr):
     tr = ShapePoseNet(make_config(args), device="cuda:0", total_steps=150000, vgg_synthetic=True)
+tr.enable_hip_graph(capture=False)   # the device-resident schedule of the captured step, issued eagerly so the profiler sees it
 batch = synthetic_batch(16, 256, "cuda:0", seed=42)
 for _ in range(3):
     tr.train_fn(batch)
@@ -33,3 +34,17 @@ for e in rows[:40]:
     for fr in e.stack[:5]:
         if "behavior_driven" in fr or "bench" in fr:
             print("            ", fr)
+
+# ---- who calls them: top-level ATen calls with device time, by the nearest frame of this package
+import collections  # noqa: E402
+cnt = collections.Counter()
+for e in prof.events():
+    if not e.name.startswith("aten::") or e.device_time_total <= 0:
+        continue
+    if e.cpu_parent is not None and e.cpu_parent.name.startswith("aten::"):
+        continue
+    frames = [f for f in (e.stack or []) if "behavior_driven" in f or "bench" in f]
+    cnt[(e.name, frames[0].strip()[-110:] if frames else "?")] += 1
+print()
+for (name, where), n in cnt.most_common(40):
+    print(f"{n / 3:6.1f}/step  {name:18s} {where}")
