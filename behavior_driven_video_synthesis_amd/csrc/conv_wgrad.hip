@@ -173,6 +173,36 @@ int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len);
 int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
                               float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy, hipStream_t st);
 
+int vunet_wgrad_direct_form(const vunet_wgrad_desc* d);
+int vunet_wgrad_direct_launch_multi(const vunet_wgrad_item* items, const int* idx, int cnt, hipStream_t st);
+
+// layers whose weight gradient runs on the direct kernel and is a short launch: batched (vunet_conv2d_wgrad_multi)
+extern "C" int vunet_conv2d_wgrad_batchable(const vunet_wgrad_desc* d) {
+  if (!d || vunet_wgrad_x6_applicable(d) || !vunet_wgrad_direct_applicable(d)) return 0;
+  return (int64_t)d->N * d->Ho * d->Wo <= 16384 ? 1 : 0;
+}
+
+extern "C" int vunet_conv2d_wgrad_multi(const vunet_wgrad_item* items, int32_t n, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return VUNET_ERR_ARG;
+  constexpr int MAXN = 256;
+  if (n > MAXN) return VUNET_ERR_ARG;
+  int form[MAXN], idx[MAXN];
+  for (int i = 0; i < n; ++i) {
+    if (!vunet_conv2d_wgrad_batchable(&items[i].d) || items[i].d.nsplit < 1) return VUNET_ERR_UNSUPPORTED;
+    form[i] = vunet_wgrad_direct_form(&items[i].d);
+  }
+  for (int i = 0; i < n; ++i) {
+    if (form[i] < 0) continue;           // already launched with an earlier item of its form
+    int cnt = 0;
+    const int f = form[i];
+    for (int k = i; k < n; ++k)
+      if (form[k] == f) { idx[cnt++] = k; form[k] = -1; }
+    const int rc = vunet_wgrad_direct_launch_multi(items, idx, cnt, (hipStream_t)stream);
+    if (rc != VUNET_OK) return rc;
+  }
+  return VUNET_OK;
+}
+
 extern "C" int vunet_conv2d_wgrad_wants_split(const vunet_wgrad_desc* d) {
   return d && (vunet_wgrad_x6_applicable(d) || vunet_wgrad_direct_applicable(d)) ? 1 : 0;
 }

@@ -57,9 +57,9 @@ __device__ __forceinline__ h2_f16x8 wd_frag(uint32_t a, uint32_t b, uint32_t c, 
 // of three and keeps three accumulators instead of nine (~110 VGPRs instead of 243), so four waves per SIMD cover the
 // load -> MFMA dependency that bounds the nine-tap form on the large stride-2 maps (r03: 53 TFLOP/s, two waves per SIMD
 // waiting on 17 uncoalesced loads per 27 MFMAs).
+// (bx, by): the workgroup's place in THIS layer's grid -- blockIdx for a launch of its own, a slice of the grid for a batched one
 template <int S, bool W4, int T>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDirectArgs a_in) {
-  WgradDirectArgs a = a_in;
+__device__ __forceinline__ void wgrad_direct_body(WgradDirectArgs& a, const int bx, const int by) {
   inact_resolve(a.in1);
   inact_resolve(a.in2);
   // rows / loaded columns of the input one octet touches
@@ -70,11 +70,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   // (split, co tile[, kernel row]), fastest last: the waves of a workgroup share x (and, row-split, dy)
-  const int unit0 = blockIdx.x * 4 + wave;
+  const int unit0 = bx * 4 + wave;
   const int krow = T == 3 ? unit0 % 3 : 0;
   const int unit = T == 3 ? unit0 / 3 : unit0;
   const int cot = unit % a.ncot, split = unit / a.ncot;
-  const int ci0 = blockIdx.y * 32;
+  const int ci0 = by * 32;
   const int H = d.Hs, W = d.Ws, HW = H * W, HoWo = d.Ho * d.Wo;
 
   // ---- operand scales
@@ -243,10 +243,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
       store(std::integral_constant<int, 8>{});
     }
   }
-  if (blockIdx.y == 0 && krow == 0) {
+  if (by == 0 && krow == 0) {
     const float tot = dsum + __shfl_xor(dsum, 32, 64);
     if (h == 0 && co < a.Coutp) a.dshift[(size_t)split * a.Coutp + co] = co_ok ? tot : 0.f;
   }
+}
+
+template <int S, bool W4, int T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDirectArgs a_in) {
+  WgradDirectArgs a = a_in;
+  wgrad_direct_body<S, W4, T>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Several layers of one form in ONE launch (vunet_conv2d_wgrad_multi): the small-map layers' weight gradients are 20 - 30 us
+// launches of ~2000 short waves each -- latency, not work -- and 60 of them per step interleaved with the data-gradient chain
+// cost more than they overlap.  The layers' argument blocks travel by value (kernel arguments: the pointers change from step to
+// step when the step is issued eagerly); a workgroup finds its layer by a scalar scan of the grid prefix sums.
+constexpr int WD_MULTI = 12;
+struct WgradDirectBatch {
+  WgradDirectArgs it[WD_MULTI];
+  int start[WD_MULTI + 1];   // first workgroup of layer i (start[n] = grid size)
+  int gx[WD_MULTI];          // layer i's grid is gx[i] x gy[i], flattened x-fastest
+  int n;
+};
+static_assert(sizeof(WgradDirectBatch) <= 4096, "kernel arguments: 4 KB");
+template <int S, bool W4, int T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_direct_multi_kernel(const WgradDirectBatch b) {
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.start[i + 1]) ++i;
+  WgradDirectArgs a = b.it[i];
+  const int local = (int)blockIdx.x - b.start[i];
+  wgrad_direct_body<S, W4, T>(a, local % b.gx[i], local / b.gx[i]);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -309,11 +336,9 @@ int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len) {
   return snprintf(name, len, "conv_wgrad_direct_kernel<%d, %s, %d>", S, W4 ? "true" : "false", T);
 }
 
-int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
-                              float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy, hipStream_t st) {
-  const int cls = direct_class(d);
-  if (!cls) return VUNET_ERR_UNSUPPORTED;
-  WgradDirectArgs a;
+// the kernel's argument block and grid of one layer
+static void direct_fill(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs, float* dshift,
+                        const float* amax_x, const float* amax_x2, const float* amax_dy, WgradDirectArgs& a, int& gx, int& gy) {
   a.d = *d;
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.slabs = slabs; a.dshift = dshift; a.amax_x = amax_x; a.amax_x2 = amax_x2; a.amax_dy = amax_dy;
   direct_geometry(d, a);
@@ -321,9 +346,68 @@ int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const 
   a.ops = (a.ops + 1) & ~1;   // whole K steps of two octets
   a.in1 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed);
   a.in2 = make_inact(d->in_act, d->in_slope, d->drop_p, d->drop_seed + 0x9E3779B9u);
+  const int units = d->nsplit * a.ncot * (direct_rowsplit(direct_class(d)) ? 3 : 1);
+  gx = (units + 3) / 4;
+  gy = (a.Ctot + 31) / 32;
+}
+
+// form of a layer's kernel: class * 2 + (kernel-row split)
+static int direct_form(const vunet_wgrad_desc* d) {
+  const int cls = direct_class(d);
+  return cls ? cls * 2 + (direct_rowsplit(cls) ? 1 : 0) : 0;
+}
+
+template <int S, bool W4, int T>
+static void direct_launch_batch(const WgradDirectBatch& b, hipStream_t st) {
+  VUNET_LAUNCH((conv_wgrad_direct_multi_kernel<S, W4, T>), dim3((unsigned)b.start[b.n]), dim3(256), 0, st, b);
+}
+
+// items[i] for i in idx[0..cnt): all of one form
+int vunet_wgrad_direct_launch_multi(const vunet_wgrad_item* items, const int* idx, int cnt, hipStream_t st) {
+  if (cnt < 1) return VUNET_OK;
+  const int form = direct_form(&items[idx[0]].d);
+  if (!form) return VUNET_ERR_UNSUPPORTED;
+  for (int at = 0; at < cnt; at += WD_MULTI) {
+    WgradDirectBatch b;
+    b.n = cnt - at < WD_MULTI ? cnt - at : WD_MULTI;
+    b.start[0] = 0;
+    for (int k = 0; k < b.n; ++k) {
+      const vunet_wgrad_item& it = items[idx[at + k]];
+      if (direct_form(&it.d) != form) return VUNET_ERR_ARG;
+      if (!it.x1 || !it.dy || !it.slabs || !it.dshift || !it.amax_x || !it.amax_dy || (it.d.C2 > 0 && !it.x2)) return VUNET_ERR_ARG;
+      int gx, gy;
+      direct_fill(&it.d, it.x1, it.x2, it.dy, it.slabs, it.dshift, it.amax_x, it.amax_x2, it.amax_dy, b.it[k], gx, gy);
+      b.gx[k] = gx;
+      b.start[k + 1] = b.start[k] + gx * gy;
+    }
+    for (int k = b.n; k < WD_MULTI; ++k) { b.it[k] = b.it[0]; b.gx[k] = 1; b.start[k + 1] = b.start[b.n]; }
+    switch (form) {
+      case 2: direct_launch_batch<1, false, 1>(b, st); break;
+      case 4: direct_launch_batch<1, true, 9>(b, st); break;
+      case 6: direct_launch_batch<2, true, 9>(b, st); break;
+      case 8: direct_launch_batch<1, false, 9>(b, st); break;
+      case 9: direct_launch_batch<1, false, 3>(b, st); break;
+      case 10: direct_launch_batch<2, false, 9>(b, st); break;
+      case 11: direct_launch_batch<2, false, 3>(b, st); break;
+      default: return VUNET_ERR_UNSUPPORTED;
+    }
+    const int rc = vunet_check_launch();
+    if (rc != VUNET_OK) return rc;
+  }
+  return VUNET_OK;
+}
+
+int vunet_wgrad_direct_form(const vunet_wgrad_desc* d) { return direct_form(d); }
+
+int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy, float* slabs,
+                              float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy, hipStream_t st) {
+  const int cls = direct_class(d);
+  if (!cls) return VUNET_ERR_UNSUPPORTED;
+  WgradDirectArgs a;
+  int gx, gy;
+  direct_fill(d, x1, x2, dy, slabs, dshift, amax_x, amax_x2, amax_dy, a, gx, gy);
   const bool rs = direct_rowsplit(cls);
-  const int units = d->nsplit * a.ncot * (rs ? 3 : 1);
-  dim3 grid((unsigned)((units + 3) / 4), (unsigned)((a.Ctot + 31) / 32)), block(256);
+  dim3 grid((unsigned)gx, (unsigned)gy), block(256);
   if (rs) {
     if (cls == 5) VUNET_LAUNCH((conv_wgrad_direct_kernel<2, false, 3>), grid, block, 0, st, a);
     else VUNET_LAUNCH((conv_wgrad_direct_kernel<1, false, 3>), grid, block, 0, st, a);

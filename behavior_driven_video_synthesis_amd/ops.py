@@ -44,6 +44,11 @@ class WgradDesc(ctypes.Structure):
                 ("drop_seed", ctypes.c_uint32), ("nsplit", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
+class WgradItem(ctypes.Structure):   # vunet_wgrad_item: one layer of a batched weight-gradient launch
+    _fields_ = [("d", WgradDesc)] + [(n, ctypes.c_void_p) for n in ("x1", "x2", "dy", "slabs", "dshift", "amax_x", "amax_x2",
+                                                                   "amax_dy")]
+
+
 class WnDesc(ctypes.Structure):
     _fields_ = [("Cout", ctypes.c_int32), ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("KH", ctypes.c_int32),
                 ("KW", ctypes.c_int32), ("kind", ctypes.c_int32), ("split", ctypes.c_int32)]
@@ -837,10 +842,20 @@ class prepacked:
 # ``flush_weight_grads`` / ``join_wgrad_streams`` is called.  Slabs and workspaces are per-layer persistent buffers, so
 # the device-side item table of a group is identical from step to step and is uploaded once.
 # ------------------------------------------------------------------------------------------------
-_WN_GROUP = 16                  # layers per batched launch pair, at most
+_WN_GROUP = int(os.environ.get("VUNET_WN_GROUP", "32"))   # layers per batched launch pair, at most
 _WN_ARENA_FLOATS = 48 << 20     # 192 MB of slabs per stream between two flushes: they stay in the 256 MB Infinity Cache
 _wn_batch = {"on": os.environ.get("VUNET_WN_BATCH", "1") != "0", "pending": {}, "arena": {}, "tables": {},
-             "callback_queued": False, "capture": os.environ.get("VUNET_WN_BATCH_CAPTURE", "1") != "0"}
+             "callback_queued": False, "capture": os.environ.get("VUNET_WN_BATCH_CAPTURE", "1") != "0",
+             "wgrad": os.environ.get("VUNET_WGRAD_BATCH", "1") != "0"}   # (A/B: the short weight-gradient launches batched too)
+_wgrad_batchable_cache = {}
+
+
+def _wgrad_batchable(wd) -> bool:
+    key = bytes(wd)
+    r = _wgrad_batchable_cache.get(key)
+    if r is None:
+        r = _wgrad_batchable_cache[key] = _lib.lib().vunet_conv2d_wgrad_batchable(ctypes.byref(wd)) == 1
+    return r
 
 
 def enable_wn_batching(on: bool = True):
@@ -884,7 +899,8 @@ def _wn_flush_stream(stream_key):
                                "the capture stream first (ShapePoseNet does)")
         arr = (WnBwdItem * len(items))()
         max_cout = max_blocks = 1
-        for i, (fields, _params, _keep) in enumerate(items):
+        for i, item in enumerate(items):
+            fields = item[0]
             (slabs, dshift, v, g, bias, gamma, invnorm, dv, dg, dbias, dgamma, dbeta, work, dsc, ns) = fields
             it = arr[i]
             it.slabs, it.dshift, it.v, it.g, it.bias, it.gamma, it.invnorm = slabs, dshift, v, g, bias, gamma, invnorm
@@ -897,9 +913,19 @@ def _wn_flush_stream(stream_key):
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(torch.device("cuda", dev_idx))
         tab = _wn_batch["tables"][sig] = (table, len(items), max_cout, max_blocks)
     table, n, max_cout, max_blocks = tab
+    # layers whose weight-gradient LAUNCH was deferred too (short launches on small maps): all of them now, grouped by
+    # kernel form -- a handful of launches instead of one per layer, ordered before the reduction that reads their slabs
+    wg = [it[3] for it in items if len(it) > 3 and it[3] is not None]
+    if wg:
+        arr = (WgradItem * len(wg))()
+        for i, (wd_bytes, ptrs) in enumerate(wg):
+            ctypes.memmove(ctypes.addressof(arr[i].d), wd_bytes, ctypes.sizeof(WgradDesc))
+            (arr[i].x1, arr[i].x2, arr[i].dy, arr[i].slabs, arr[i].dshift, arr[i].amax_x, arr[i].amax_x2,
+             arr[i].amax_dy) = ptrs
+        _call("vunet_conv2d_wgrad_multi", arr, len(wg), ctypes.c_void_p(raw))
     _call("vunet_weightnorm_bwd_multi", _p(table), n, max_cout, max_blocks, ctypes.c_void_p(raw))
-    for _fields, params, _keep in items:
-        for p_ in params:
+    for it in items:
+        for p_ in it[1]:
             for hook in _grad_hooks:
                 hook(p_)
 
@@ -911,12 +937,13 @@ def flush_weight_grads():
     _wn_batch["callback_queued"] = False
 
 
-def _wn_defer(fields, params, keep):
-    """``keep``: tensors the item points at that nothing else is guaranteed to hold until the flush."""
+def _wn_defer(fields, params, keep, wgrad=None):
+    """``keep``: tensors the item points at that nothing else is guaranteed to hold until the flush.  ``wgrad``: (descriptor
+    bytes, pointers) of the layer's weight-gradient launch when that is deferred to the flush as well."""
     idx = torch.cuda.current_device()
     key = (idx, _raw_stream(idx))
     lst = _wn_batch["pending"].setdefault(key, [])
-    lst.append((fields, params, keep))
+    lst.append((fields, params, keep, wgrad))
     if len(lst) >= _WN_GROUP:
         _wn_flush_stream(key)
     elif not _wn_batch["callback_queued"]:
@@ -1113,18 +1140,28 @@ class FusedConv(torch.autograd.Function):
                 buf = ctypes.create_string_buffer(96)
                 _call("vunet_conv2d_wgrad_variant", ctypes.byref(wd), buf, 96)
                 kname = buf.value.decode()
-            with (_Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, kname),
-                        2.0 * n * ho * wo * cout * (c1 + c2) * k * k) if _prof["on"] else _NO_TIMER):
-                ax1, ax2 = _amax_pair(wg_amax[0])
-                _call("vunet_conv2d_wgrad_a2", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
-                      _p(ax1), _p(ax2), _p(wg_amax[1]), _stream())
+            ax1, ax2 = _amax_pair(wg_amax[0])
+            # short launches (small maps, 1x1, the small stride-2 layers): the launch itself waits for the flush, where the
+            # layers of one kernel form share a launch (vunet_conv2d_wgrad_multi); per-launch timing runs keep them apart
+            late = (defer and _wn_batch["wgrad"] and not _prof["on"]
+                    and _wgrad_batchable(wd))
+            if not late:
+                with (_Timed(("conv_wgrad", n, c1, c2, hs, ws, cout, k, cfg.stride, cfg.in_act, kname),
+                            2.0 * n * ho * wo * cout * (c1 + c2) * k * k) if _prof["on"] else _NO_TIMER):
+                    _call("vunet_conv2d_wgrad_a2", ctypes.byref(wd), _p(x1), _p(x2), _p(dconv), _p(slabs), _p(dshift),
+                          _p(ax1), _p(ax2), _p(wg_amax[1]), _stream())
             ni = ctx.needs_input_grad
             if defer:   # every needed gradient is a view of a flat bucket: hand the layer to the batched backward
                 outs = [p_.grad if (p_ is not None and need) else None for p_, need in zip(ctx.param_refs, ni[3:8])]
                 ptrs = tuple(None if t is None else t.data_ptr() for t in
                              (slabs, dshift, v, g, bias, gamma, invnorm, outs[0], outs[1], outs[2], outs[3], outs[4], work))
+                wg_item, keep = None, (invnorm,)
+                if late:
+                    wg_item = (bytes(wd), tuple(None if t is None else t.data_ptr() for t in
+                                                (x1, x2, dconv, slabs, dshift, ax1, ax2, wg_amax[1])))
+                    keep = (invnorm, x1, x2, dconv, ax1, ax2, wg_amax[1])
                 _wn_defer(ptrs + ((cout, c1, c2, k, k, cfg.kind), ns),
-                          [p_ for p_, o in zip(ctx.param_refs, outs) if o is not None], (invnorm,))
+                          [p_ for p_, o in zip(ctx.param_refs, outs) if o is not None], keep, wg_item)
                 return None, None, None, None, None
             params = (v, g, bias, gamma, gamma)  # beta has gamma's shape
             outs, direct = [], []

@@ -207,6 +207,24 @@ int vunet_conv2d_wgrad(const vunet_wgrad_desc* d, const float* x1, const float* 
 int vunet_conv2d_wgrad_a2(const vunet_wgrad_desc* d, const float* x1, const float* x2, const float* dy,
                           float* slabs, float* dshift, const float* amax_x, const float* amax_x2, const float* amax_dy,
                           void* stream);
+/* The weight gradients of SEVERAL layers in as few launches as their kernel forms allow (items of one form share a launch,
+ * up to 12 per launch; argument blocks travel by value).  For the layers vunet_conv2d_wgrad_batchable(d) == 1 accepts: the
+ * small-map / 1x1 / stride-2 layers of the fp16 scheme whose own launch is latency, not work (N * Ho * Wo <= 16384) -- about 60
+ * per training step of the reference's VunetAlter at 256^2, each the weight-gradient half of a NormConv2d backward
+ * (lib/modules.py:120-145).  Every item as vunet_conv2d_wgrad_a2's arguments; results identical to one call per item. */
+typedef struct vunet_wgrad_item {
+  vunet_wgrad_desc d;
+  const float* x1;
+  const float* x2;
+  const float* dy;
+  float* slabs;
+  float* dshift;
+  const float* amax_x;
+  const float* amax_x2;
+  const float* amax_dy;
+} vunet_wgrad_item;
+int vunet_conv2d_wgrad_multi(const vunet_wgrad_item* items, int32_t n, void* stream);
+int vunet_conv2d_wgrad_batchable(const vunet_wgrad_desc* d);
 int vunet_conv2d_wgrad_wants_split(const vunet_wgrad_desc* d);
 int vunet_conv2d_wgrad_variant(const vunet_wgrad_desc* d, char* name, int32_t len);
 /* number of pixel splits the library wants for this problem (caller sizes the slabs from it) */

@@ -270,3 +270,62 @@ def test_direct_weight_gradient_vs_fp64(case, rowsplit):
     assert eh <= 5.0 * e3 + 4e-7 * sc, (eh, e3, sc)
     refb = dy.double().cpu().sum(dim=(0, 2, 3))
     assert float((dbh.double().cpu() - refb).abs().max()) <= 1e-5 * max(float(refb.abs().max()), 1.0)
+
+
+def test_batched_weight_gradient_launch_equals_one_launch_per_layer():
+    """vunet_conv2d_wgrad_multi: the layers of WGRAD the library calls batchable, all in one call (several kernel forms, more
+    items of one form than a launch holds), write the same slabs bit for bit as vunet_conv2d_wgrad_a2 per layer; layers the
+    call does not take are refused, not silently skipped."""
+    ops = _ops()
+    ops.set_tuning("wgrad_rowsplit", 0)
+    lib = ops._lib.lib()
+    items, singles, keep = [], [], []
+    cases = [c for c in WGRAD] + [WGRAD[0], WGRAD[1], WGRAD[8]] * 5   # 27 items: the 3x3 / 4-wide form 6x, the 1x1 form 8x ...
+    refused = 0
+    for ci, case in enumerate(cases):
+        n, c1, c2, cout, hs, ws, k, stride, in_act, drop = case
+        pad = 1 if k == 3 else 0
+        ho, wo = (hs + 2 * pad - k) // stride + 1, (ws + 2 * pad - k) // stride + 1
+        g_ = torch.Generator().manual_seed(1000 + ci)
+        x1 = torch.randn(n, c1, hs, ws, generator=g_).cuda()
+        x2 = torch.randn(n, c2, hs, ws, generator=g_).cuda() if c2 else None
+        dy = torch.randn(n, cout, ho, wo, generator=g_).cuda()
+        wd = ops.WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=stride, pad=pad,
+                           in_act=in_act, in_slope=0.0, drop_p=drop, drop_seed=0xBEEF + ci, nsplit=1, flags=2)
+        wd.nsplit = lib.vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
+        if lib.vunet_conv2d_wgrad_batchable(ctypes.byref(wd)) != 1:
+            refused += 1
+            one = (ops.WgradItem * 1)()
+            one[0].d = wd
+            assert lib.vunet_conv2d_wgrad_multi(one, 1, ops._stream()) == -3
+            continue
+        ktot, cp = k * k * (c1 + c2), ops._r32(cout)
+        size = wd.nsplit * cp * ktot + wd.nsplit * cp
+        a, b = (torch.full((size,), float("nan"), device="cuda") for _ in range(2))
+        amx, amd = ops.absmax_partials(x1, x2), ops.absmax_partials(dy)
+        ops._call("vunet_conv2d_wgrad_a2", ctypes.byref(wd), ops._p(x1), ops._p(x2), ops._p(dy), ops._p(a),
+                  ops._p(a[wd.nsplit * cp * ktot:]), ops._p(amx), None, ops._p(amd), ops._stream())
+        items.append((wd, x1, x2, dy, b, b[wd.nsplit * cp * ktot:], amx, amd))
+        singles.append(a)
+        keep.append((x1, x2, dy, amx, amd))
+    assert len(items) >= 20
+    # a layer of the row-tiled weight-gradient kernel (3x3 / stride 1 on a 32-wide map) and a long direct launch (1x1 at 256^2)
+    for shape in ((2, 32, 32, 32, 32, 3, 1), (16, 32, 32, 256, 256, 1, 0)):
+        n, c, cout, hs, ws, k, pad = shape
+        wd = ops.WgradDesc(N=n, C1=c, C2=0, Hs=hs, Ws=ws, Cout=cout, Ho=hs, Wo=ws, KH=k, KW=k, stride=1, pad=pad, in_act=0,
+                           in_slope=0.0, drop_p=0.0, drop_seed=0, nsplit=1, flags=2)
+        wd.nsplit = lib.vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
+        assert lib.vunet_conv2d_wgrad_batchable(ctypes.byref(wd)) == 0
+        one = (ops.WgradItem * 1)()
+        one[0].d = wd
+        assert lib.vunet_conv2d_wgrad_multi(one, 1, ops._stream()) == -3
+    arr = (ops.WgradItem * len(items))()
+    for i, (wd, x1, x2, dy, b, bsh, amx, amd) in enumerate(items):
+        arr[i].d = wd
+        arr[i].x1, arr[i].x2, arr[i].dy = x1.data_ptr(), None if x2 is None else x2.data_ptr(), dy.data_ptr()
+        arr[i].slabs, arr[i].dshift = b.data_ptr(), bsh.data_ptr()
+        arr[i].amax_x, arr[i].amax_x2, arr[i].amax_dy = amx.data_ptr(), None, amd.data_ptr()
+    ops._call("vunet_conv2d_wgrad_multi", arr, len(items), ops._stream())
+    torch.cuda.synchronize()
+    for i, (a, it) in enumerate(zip(singles, items)):
+        assert torch.equal(a.view(torch.int32), it[4].view(torch.int32)), f"item {i}: {cases[i]}"
