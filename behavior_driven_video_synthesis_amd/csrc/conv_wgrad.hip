@@ -179,7 +179,9 @@ int vunet_wgrad_direct_launch_multi(const vunet_wgrad_item* items, const int* id
 // layers whose weight gradient runs on the direct kernel and is a short launch: batched (vunet_conv2d_wgrad_multi)
 extern "C" int vunet_conv2d_wgrad_batchable(const vunet_wgrad_desc* d) {
   if (!d || vunet_wgrad_x6_applicable(d) || !vunet_wgrad_direct_applicable(d)) return 0;
-  return (int64_t)d->N * d->Ho * d->Wo <= 16384 ? 1 : 0;
+  // (A/B: VUNET_WGRAD_BATCH_PIX moves the bound between "latency" and "work")
+  static const int64_t bound = [] { const char* e = getenv("VUNET_WGRAD_BATCH_PIX"); return e ? atoll(e) : 16384ll; }();
+  return (int64_t)d->N * d->Ho * d->Wo <= bound ? 1 : 0;
 }
 
 extern "C" int vunet_conv2d_wgrad_multi(const vunet_wgrad_item* items, int32_t n, void* stream) {

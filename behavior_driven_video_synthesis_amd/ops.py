@@ -842,7 +842,7 @@ class prepacked:
 # ``flush_weight_grads`` / ``join_wgrad_streams`` is called.  Slabs and workspaces are per-layer persistent buffers, so
 # the device-side item table of a group is identical from step to step and is uploaded once.
 # ------------------------------------------------------------------------------------------------
-_WN_GROUP = int(os.environ.get("VUNET_WN_GROUP", "32"))   # layers per batched launch pair, at most
+_WN_GROUP = int(os.environ.get("VUNET_WN_GROUP", "64"))   # layers per batched launch pair, at most
 _WN_ARENA_FLOATS = 48 << 20     # 192 MB of slabs per stream between two flushes: they stay in the 256 MB Infinity Cache
 _wn_batch = {"on": os.environ.get("VUNET_WN_BATCH", "1") != "0", "pending": {}, "arena": {}, "tables": {},
              "callback_queued": False, "capture": os.environ.get("VUNET_WN_BATCH_CAPTURE", "1") != "0",
