@@ -807,8 +807,8 @@ extern "C" int vunet_gamma_update(float* gamma, const float* imax, const float* 
 // (element index, seed, step) -- the step read from the device counter of vunet_set_dropout_step when one is set, so the launch
 // arguments stay constant from step to step (captured hipGraph) while every replay draws fresh noise.  One launch instead of
 // a zero-fill, a generator launch and the reparametrisation kernel; the backward is the identity.
-__global__ void unit_sample_kernel(const float* __restrict__ mu, float* __restrict__ z, float* __restrict__ eps_out, int64_t n,
-                                   uint32_t seed, const uint32_t* __restrict__ step) {
+__global__ void unit_sample_kernel(const float* __restrict__ mu, const float* __restrict__ ls, float* __restrict__ z,
+                                   float* __restrict__ eps_out, int64_t n, uint32_t seed, const uint32_t* __restrict__ step) {
   if (step) seed += step[0] * VUNET_DROP_STEP_MUL;
   EW_LOOP(i, n) {
     const uint32_t a = vunet_hash_u32((uint32_t)(2 * i) + seed), b = vunet_hash_u32((uint32_t)(2 * i + 1) + (seed ^ 0x68E31DA4u));
@@ -816,13 +816,14 @@ __global__ void unit_sample_kernel(const float* __restrict__ mu, float* __restri
     const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);             // [0, 1)
     const float e = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958648f * u2);
     if (eps_out) eps_out[i] = e;
-    z[i] = mu[i] + e;
+    z[i] = ls ? e * __expf(ls[i]) + mu[i] : mu[i] + e;     // (with a log-std: vunet_reparam_fwd's expression)
   }
 }
-extern "C" int vunet_unit_sample(const float* mu, float* z, float* eps_out, int64_t n, uint32_t seed, void* st) {
+extern "C" int vunet_unit_sample(const float* mu, const float* logstd, float* z, float* eps_out, int64_t n, uint32_t seed,
+                                 void* st) {
   if (!mu || !z || n < 0) return VUNET_ERR_ARG;
   if (n == 0) return VUNET_OK;
-  VUNET_LAUNCH(unit_sample_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, z, eps_out, n, seed, g_vunet_drop_step);
+  VUNET_LAUNCH(unit_sample_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)st, mu, logstd, z, eps_out, n, seed, g_vunet_drop_step);
   return vunet_check_launch();
 }
 

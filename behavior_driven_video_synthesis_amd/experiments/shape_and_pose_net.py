@@ -219,6 +219,7 @@ class ShapePoseNet:
         # the library keeps ONE process-wide counter pointer: another graph-mode trainer (or set_dropout_step(None)) may
         # have replaced it since this trainer's last step -- re-assert ours (host-only, no launch) before anything draws
         ops.set_dropout_step(self._drop_step)
+        ops.set_dropout_host_step(0)            # (the device counter carries the step)
         ops.reset_dropout_counter()
         key = self._graph_key(batch, it) if (self._capture and eps is None and reg_eps is None) else None
         if key is None:
@@ -281,11 +282,19 @@ class ShapePoseNet:
             P, S = self.gan_patch, batch["pose_img"].shape[-1]
             off = torch.randint(0, S - P + 1, (2,), generator=self._gan_rng).to(torch.int32)
             self._gan_off.copy_(off, non_blocking=True)
+        with ops.kernel_noise():   # posterior noise from the sampling kernels themselves (ops.kernel_noise)
+            return self._train_fn(batch, it, eps, reg_eps)
+
+    def _train_fn(self, batch, it, eps, reg_eps):
         if self._dev_sched:
             out = self._train_fn_graph(batch, it, eps, reg_eps)
         else:
             if ops.dropout_step_counter() is not None:   # left behind by a graph-mode trainer of this process
                 ops.set_dropout_step(None)
+            # the seed sequence restarts every step and carries the step number as a host-side offset: the same dropout
+            # masks and posterior noise as the device-schedule / captured step of this number draws
+            ops.reset_dropout_counter()
+            ops.set_dropout_host_step(it & 0x7FFFFFFF)
             self.optimizer.zero_grad()
             target_features = None
             side = self.vunet._side_stream

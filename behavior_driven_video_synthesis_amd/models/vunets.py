@@ -104,7 +104,7 @@ class DecUp(_Pyramid):
 
 def latent_sample(p, eps: Optional[torch.Tensor] = None):
     """:151-156 -- unit-variance sample around ``p``."""
-    if eps is None and p.is_cuda:
+    if eps is None and p.is_cuda and ops.kernel_noise_enabled():
         return ops.UnitSample.apply(p)   # noise drawn inside the kernel: one launch, identity backward
     return ops.Reparam.apply(p, torch.zeros_like(p), _noise_like(p, eps))
 
@@ -177,6 +177,8 @@ class EncDownAlter(_Bottleneck):
 
     def reparametrize(self, mu, logstd, eps: Optional[torch.Tensor] = None):
         """:594-597 -- eps * exp(logstd) + mu."""
+        if eps is None and mu.is_cuda and ops.kernel_noise_enabled():
+            return ops.Reparam.apply(mu, logstd, None)   # noise drawn inside the kernel
         return ops.Reparam.apply(mu, logstd, _noise_like(logstd, eps))
 
 

@@ -104,12 +104,20 @@ def _r32(x: int) -> int:
 # ------------------------------------------------------------------------------------------------
 # dropout seeds: one fresh 32-bit seed per fused conv call, derived from torch's seed
 # ------------------------------------------------------------------------------------------------
-_drop_state = {"base": None, "ctr": 0, "step": None}
+_drop_state = {"base": None, "ctr": 0, "step": None, "host_step": 0}
 
 
 def set_dropout_seed(seed: int):
     _drop_state["base"] = int(seed) & 0xFFFFFFFF
     _drop_state["ctr"] = 0
+
+
+def set_dropout_host_step(step: int):
+    """The step's number as a HOST value: every seed handed out afterwards is offset by ``step * 0x9E3779B1`` -- what the
+    kernels add themselves from the device counter of ``set_dropout_step``.  A trainer that restarts the seed sequence
+    every step (``reset_dropout_counter``) and sets this draws the same masks and the same posterior noise as the
+    device-schedule / captured step of the same number (0: no offset)."""
+    _drop_state["host_step"] = int(step) & 0xFFFFFFFF
 
 
 def reset_dropout_counter():
@@ -141,7 +149,7 @@ def next_dropout_seed() -> int:
     _drop_state["ctr"] += 1
     x = (_drop_state["base"] * 0x9E3779B1 + _drop_state["ctr"] * 0x85EBCA77) & 0xFFFFFFFF
     x ^= x >> 15
-    return (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    return ((x * 0x2C1B3C6D) + _drop_state["host_step"] * 0x9E3779B1) & 0xFFFFFFFF
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1378,7 +1386,11 @@ class Reparam(torch.autograd.Function):
         _dev(mu, logstd, eps)
         mu, logstd, eps = _c(mu), _c(logstd), _c(eps)
         z = torch.empty_like(mu)
-        _call("vunet_reparam_fwd", _p(mu), _p(logstd), _p(eps), _p(z), mu.numel(), _stream())
+        if eps is None:   # the noise is drawn inside the kernel (vunet_unit_sample) and kept for the backward
+            eps = torch.empty_like(mu)
+            _call("vunet_unit_sample", _p(mu), _p(logstd), _p(z), _p(eps), mu.numel(), next_dropout_seed(), _stream())
+        else:
+            _call("vunet_reparam_fwd", _p(mu), _p(logstd), _p(eps), _p(z), mu.numel(), _stream())
         ctx.save_for_backward(logstd, eps)
         return z
 
@@ -1389,6 +1401,30 @@ class Reparam(torch.autograd.Function):
         dmu, dls = torch.empty_like(dz), torch.empty_like(dz)
         _call("vunet_reparam_bwd", _p(dz), _p(logstd), _p(eps), _p(dmu), _p(dls), dz.numel(), _stream())
         return dmu, dls, None
+
+
+# Posterior / prior noise drawn INSIDE the sampling kernel (UnitSample, Reparam with eps=None) instead of by torch.randn_like.
+# Off by default: the reference's modules draw through torch.randn_like, and code written against them may rely on that
+# (torch.manual_seed streams, a patched randn_like that replays recorded draws -- tests/test_hip_training.py does).  The
+# trainers of this package switch it on around their own steps: one launch per draw, constant launch arguments.
+_kernel_noise = {"on": False}
+
+
+def kernel_noise_enabled() -> bool:
+    return _kernel_noise["on"]
+
+
+class kernel_noise:
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _kernel_noise["on"] = _kernel_noise["on"], self.on
+        return self
+
+    def __exit__(self, *exc):
+        _kernel_noise["on"] = self.prev
+        return False
 
 
 class UnitSample(torch.autograd.Function):
@@ -1402,7 +1438,7 @@ class UnitSample(torch.autograd.Function):
         _dev(mu)
         mu = _c(mu)
         z = torch.empty_like(mu)
-        _call("vunet_unit_sample", _p(mu), _p(z), None, mu.numel(), next_dropout_seed(), _stream())
+        _call("vunet_unit_sample", _p(mu), None, _p(z), None, mu.numel(), next_dropout_seed(), _stream())
         return z
 
     @staticmethod

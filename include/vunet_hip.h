@@ -489,10 +489,11 @@ int vunet_total_loss_bwd(const float* g_loss, const float* g_ll, int32_t n, cons
                          float ll_weight, int32_t use_kl, float* d, void* stream);
 int vunet_gamma_update(float* gamma, const float* imax, const float* avg_kl, float gamma_step, void* stream);
 
-/* z = mu + eps, eps ~ N(0, 1) drawn inside the kernel (reference models/vunets.py:151-156, latent_sample: p + randn_like(p)):
- * Box-Muller on two hashes of (element, seed, step), the step taken from the device counter of vunet_set_dropout_step when one
- * is set.  eps_out (may be NULL) receives the noise.  The gradient w.r.t. mu is the identity. */
-int vunet_unit_sample(const float* mu, float* z, float* eps_out, int64_t n, uint32_t seed, void* stream);
+/* z = mu + eps (logstd NULL; reference models/vunets.py:151-156, latent_sample: p + randn_like(p)) or z = eps * exp(logstd) + mu
+ * (:594-597, reparametrize) with eps ~ N(0, 1) drawn inside the kernel: Box-Muller on two hashes of (element, seed, step), the
+ * step taken from the device counter of vunet_set_dropout_step when one is set.  eps_out (may be NULL) receives the noise
+ * (vunet_reparam_bwd needs it).  Without logstd the gradient w.r.t. mu is the identity. */
+int vunet_unit_sample(const float* mu, const float* logstd, float* z, float* eps_out, int64_t n, uint32_t seed, void* stream);
 
 /* The host-side schedule values of a step (learning rate as double, information_max, dropout step) written to their device
  * scalars by ONE launch; the values travel as kernel arguments, so the host may run any number of steps ahead.  NULL

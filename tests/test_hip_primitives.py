@@ -615,6 +615,16 @@ def test_unit_sample_draws_standard_normal_noise_and_passes_the_gradient_through
     g = seeded_randn("us.g", tuple(mu.shape), 4).cuda()
     z1.backward(g)
     assert torch.equal(mu.grad, g)
+    # with a log-std (reparametrize): z = eps * exp(logstd) + mu, eps kept for the backward, gradients as vunet_reparam_bwd
+    ls = (0.3 * seeded_randn("us.ls", tuple(mu.shape), 5)).cuda().requires_grad_(True)
+    mu2 = mu.detach().clone().requires_grad_(True)
+    ops.set_dropout_seed(77)
+    zr = ops.Reparam.apply(mu2, ls, None)
+    er = ((zr - mu2) / ls.exp()).detach().double().flatten()
+    assert abs(float(er.mean())) < 5 / n ** 0.5 and abs(float(er.var()) - 1.0) < 5 * (2.0 / n) ** 0.5
+    zr.backward(g)
+    assert torch.equal(mu2.grad, g)
+    assert_close(ls.grad, g * (zr - mu2).detach(), 1e-5, 1e-6, "dlogstd")
     # the device step counter moves the noise without changing a launch argument
     ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
     ops.set_dropout_step(ctr)
