@@ -256,13 +256,23 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 || MT * NT >= 8) ? 1 : 2) void 
     ia.seed = second ? a.in2.seed : a.in1.seed;
     const int gbase = (n * C + cs) * HW;
     const bool ok = (vbits >> i) & 1u;
+    // (a unit outside the image: its INPUT is zeroed -- every prologue maps 0 to 0 -- instead of selecting the result: written
+    //  as "ok ? f(x) * sx : 0" the compiler sinks each element's prologue into an exec-mask block of its own, eight
+    //  saveexec / branch / restore sequences per unit around ~16 VALU instructions each)
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+#ifdef H2_SELECT_AFTER   // (A/B, tools/ab_build.sh: the form before round 4 -- same values)
       float t_ = xv[i][k];
       if constexpr (PRO == 4) t_ = mk[0][k] > 0.f ? t_ : 0.f;
       else if constexpr (PRO != 0) t_ = prologue<PRO>(ia, t_, (uint32_t)gbase + rel[i] + (uint32_t)(k * HW));
       v[k] = ok ? t_ * sx : 0.f;
+#else
+      float t_ = ok ? xv[i][k] : 0.f;
+      if constexpr (PRO == 4) t_ = mk[0][k] > 0.f ? t_ : 0.f;
+      else if constexpr (PRO != 0) t_ = prologue<PRO>(ia, t_, (uint32_t)gbase + rel[i] + (uint32_t)(k * HW));
+      v[k] = t_ * sx;
+#endif
     }
     uint4 ph, pl;
     h2_split2(v[0], v[1], ph.x, pl.x);
