@@ -839,3 +839,39 @@ extern "C" int vunet_set_schedule(double* lr_dev, double lr, float* imax_dev, fl
   VUNET_LAUNCH(set_schedule_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, lr_dev, lr, imax_dev, imax, step_dev, step);
   return vunet_check_launch();
 }
+
+// ------------------------------------------------------------------ a fan-out's gradients summed in one launch, maxima included
+// out = ((g0 + g1) + g2) + g3 over up to four tensors of one shape, in that order (the autograd engine's accumulation order
+// is the caller's to reproduce), with the partial |out| maxima the split-fp16 kernels scale by published like a convolution's
+// (amax_out: 512 zero-initialised floats, atomic max on the bit patterns; may be NULL): replaces the engine's aten::add_
+// launches and the vunet_absmax_partials pass of the next data gradient on the small maps of the bottleneck.
+struct SumSrcs {
+  const float* s[4];
+};
+__global__ __launch_bounds__(256) void sum_amax_kernel(SumSrcs a, int n, float* __restrict__ out, float* __restrict__ amax_out,
+                                                       int64_t numel) {
+  float m = 0.f;
+  EW_LOOP(i, numel) {
+    float v = a.s[0][i] + a.s[1][i];
+    if (n > 2) v += a.s[2][i];
+    if (n > 3) v += a.s[3][i];
+    out[i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  if (amax_out) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(reinterpret_cast<unsigned*>(amax_out) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 511u), __float_as_uint(m));
+  }
+}
+extern "C" int vunet_sum_amax(const float* const* srcs, int32_t n, float* out, float* amax_out, int64_t numel, void* st) {
+  if (!srcs || n < 2 || n > 4 || !out || numel < 0) return VUNET_ERR_ARG;
+  SumSrcs a;
+  for (int i = 0; i < 4; ++i) {
+    a.s[i] = i < n ? srcs[i] : nullptr;
+    if (i < n && !a.s[i]) return VUNET_ERR_ARG;
+  }
+  if (numel == 0) return VUNET_OK;
+  VUNET_LAUNCH(sum_amax_kernel, ew_grid(numel), dim3(256), 0, (hipStream_t)st, a, n, out, amax_out, numel);
+  return vunet_check_launch();
+}

@@ -144,17 +144,24 @@ class _Bottleneck(nn.Module):
         for s in range(self.n_scales):
             h = self.blocks[2 * s](h, skips.pop())
             hidden.append(h)
-            loc = self.make_latent_params[s](h)
-            locs.append(loc)
+            # h feeds the posterior's parameter layer(s) AND the next block, the parameters feed the sample AND the KL term:
+            # each reader gets a handle of its own, so that the gradients meet in one launch (ops.fan_out) instead of
+            # being summed by the engine one aten::add_ at a time -- on 4 x 4 / 8 x 8 maps every launch is latency
+            if self.learn_std:
+                h_mu, h_sd, h_next = ops.fan_out(h, 3)
+            else:
+                (h_mu, h_next), h_sd = ops.fan_out(h, 2), None
+            loc_kl, loc = ops.fan_out(self.make_latent_params[s](h_mu), 2)
+            locs.append(loc_kl)
             noise = None if eps is None else eps[s]
             if self.learn_std:
-                log_sd = self.make_logstds[s].fused(h, out_act=ops.ACT_SIGMOID)   # conv + squash, :574-575
-                scales.append(log_sd)
+                log_sd_kl, log_sd = ops.fan_out(self.make_logstds[s].fused(h_sd, out_act=ops.ACT_SIGMOID), 2)   # conv + squash, :574-575
+                scales.append(log_sd_kl)
                 z = self.reparametrize(loc, log_sd, noise)
             else:
                 z = latent_sample(loc, noise)
             samples.append(z)
-            h = self.blocks[2 * s + 1](h, (skips.pop(), z))   # cat([g, z]) read as two sources, :210 / :583
+            h = self.blocks[2 * s + 1](h_next, (skips.pop(), z))   # cat([g, z]) read as two sources, :210 / :583
             hidden.append(h)
             h = self.ups[s](h)
         hidden.append(self.fin_block(h, skips.pop()))

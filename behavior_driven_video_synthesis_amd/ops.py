@@ -1427,6 +1427,49 @@ class kernel_noise:
         return False
 
 
+class FanOut(torch.autograd.Function):
+    """``n`` aliases of ``x`` for ``n`` readers: their gradients meet in THIS node's backward and are summed by one launch
+    that also publishes the sum's |.| maxima (vunet_sum_amax) -- instead of n - 1 ``aten::add_`` launches of the autograd
+    engine and a maxima pass in front of the next data gradient.  For the small maps of the bottleneck, where every launch is
+    latency.  The sum runs over the gradients in REVERSE reader order -- the order in which the engine, which runs later-created
+    nodes first, would have accumulated them (same bits as the plain graph)."""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_c(g) for g in reversed(gs) if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        _dev(*gs)
+        out = torch.empty_like(gs[0])
+        amax_out = _new_amax_out(out.device) if _scheme() == 2 else None
+        ptrs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        _call("vunet_sum_amax", ptrs, len(gs), _p(out), _p(amax_out), out.numel(), _stream())
+        if amax_out is not None:
+            _tag_amax(out, amax_out)
+        return out, None
+
+
+_FAN_OUT = os.environ.get("VUNET_FAN_OUT", "1") != "0"   # (A/B switch)
+
+
+def fan_out(x, n: int):
+    """``n`` handles on ``x`` whose gradients are summed in one launch (FanOut) when the graph is recording on the GPU and
+    gradient pass-through is on; otherwise ``x`` itself ``n`` times."""
+    if n < 2 or not (_grad_passthrough and _FAN_OUT and x.is_cuda and torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    outs = FanOut.apply(x, n)
+    for o in outs:
+        carry_amax_tag(x, o)
+    return outs
+
+
 class UnitSample(torch.autograd.Function):
     """z = mu + eps with eps ~ N(0, 1) drawn inside the kernel (vunet_unit_sample; models/vunets.py:151-156): one launch
     instead of zeros_like + randn_like + the reparametrisation kernel, and no backward launch (dz/dmu = 1).  The seed

@@ -500,6 +500,12 @@ int vunet_unit_sample(const float* mu, const float* logstd, float* z, float* eps
  * pointers are skipped. */
 int vunet_set_schedule(double* lr_dev, double lr, float* imax_dev, float imax, int32_t* step_dev, int32_t step, void* stream);
 
+/* out = ((g0 + g1) + g2) + g3 over n = 2..4 tensors of numel floats each (srcs: HOST array of device pointers), in that order,
+ * and -- amax_out non-NULL: 512 zero-initialised floats -- the partial maxima of |out| (as vunet_conv2d's amax_out).  One launch for
+ * what autograd does with n - 1 aten::add_ launches plus the next layer's vunet_absmax_partials pass: the gradients of a tensor
+ * with several readers (the bottleneck's hidden state feeds mu, log-sigma and the next block: reference models/vunets.py:560-590). */
+int vunet_sum_amax(const float* const* srcs, int32_t n, float* out, float* amax_out, int64_t numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

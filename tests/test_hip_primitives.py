@@ -3,6 +3,8 @@
 Tolerance: fp32 MFMA is a k-ordered fmaf chain (exact fp32), the CPU reference sums in a different
 order -> atol/rtol 1e-4 on outputs, 1e-3 on weight gradients (long reductions)  (SURVEY 8c).
 """
+import ctypes
+
 import pytest
 import torch
 
@@ -640,3 +642,32 @@ def test_unit_sample_draws_standard_normal_noise_and_passes_the_gradient_through
     finally:
         ops.set_dropout_step(None)
     assert torch.equal(a, a2) and not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_fan_out_sums_its_readers_gradients_in_one_launch(n):
+    """ops.fan_out / vunet_sum_amax: the gradient of a tensor with n readers equals the autograd engine's sum bit for bit
+    (the engine accumulates later-created readers first), and the sum carries its |.| maxima as a tag."""
+    from behavior_driven_video_synthesis_amd import ops
+    x = seeded_randn("fo.x", (3, 16, 8, 8), 11).cuda().requires_grad_(True)
+    ws = [seeded_randn(f"fo.w{i}", (3, 16, 8, 8), 12 + i).cuda() * (10.0 ** (i - 1)) for i in range(n)]
+    hs = ops.fan_out(x * 1.0, n)
+    assert len(hs) == n and all(h.data_ptr() == hs[0].data_ptr() for h in hs)
+    seen = {}
+    hs[0].grad_fn.next_functions   # (the aliases share ONE backward node)
+    y = sum((h * w).sum() for h, w in zip(hs, ws))
+    mid = hs[0]._base if hs[0]._base is not None else hs[0]
+    mid.register_hook(lambda g: seen.setdefault("g", g))
+    y.backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    h2 = x2 * 1.0
+    sum((h2 * w).sum() for w in ws).backward()
+    assert torch.equal(x.grad, x2.grad)
+    g = seen["g"]
+    tag = ops._tagged_amax(g)
+    assert tag is not None and float(tag.max()) == float(g.abs().max())
+    # the raw entry point: argument checks
+    lib = ops._lib.lib()
+    out = torch.empty_like(ws[0])
+    ptrs = (ctypes.c_void_p * 1)(ws[0].data_ptr())
+    assert lib.vunet_sum_amax(ptrs, 1, ops._p(out), None, out.numel(), ops._stream()) < 0
