@@ -160,7 +160,8 @@ class _Bottleneck(nn.Module):
                 z = self.reparametrize(loc, log_sd, noise)
             else:
                 z = latent_sample(loc, noise)
-            samples.append(z)
+            z_out, z = ops.fan_out(z, 2)   # (the decoder reads the sample too)
+            samples.append(z_out)
             h = self.blocks[2 * s + 1](h_next, (skips.pop(), z))   # cat([g, z]) read as two sources, :210 / :583
             hidden.append(h)
             h = self.ups[s](h)
