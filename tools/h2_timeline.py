@@ -25,6 +25,8 @@ SHAPES = [
     ("vgg conv3_x fwd", 16, 256, 256, 64, 64, 0, 0),
     ("128ch 64^2 dgrad", 16, 128, 128, 64, 64, 1, 0),
 ]
+if len(sys.argv) > 1 and sys.argv[1] == "fill":   # conv1_2 at 1 / 2 / 4 / 16 images: 256 workgroups = ONE per CU, 512 = one round, ...
+    SHAPES = [(f"vgg conv1_2 fwd, N = {n_}", n_, 64, 64, 256, 256, 0, 0) for n_ in (1, 2, 4, 16)]
 if len(sys.argv) > 1 and sys.argv[1] == "mt1":   # the one-m-tile kernel (conv_h2_mt1.hip built with -DH2_TSTAMP instead)
     SHAPES = [("32ch 256^2 fwd elu", 16, 32, 32, 256, 256, 0, 1), ("32ch 256^2 dgrad", 16, 32, 32, 256, 256, 1, 0)]
 lib = ops._lib.lib()
