@@ -127,6 +127,9 @@ static int x6_launch(const vunet_conv_desc* d, const float* x1, const float* x2,
   fill_args(ga, d, x1, x2, nullptr, shift, res, aux, mask, y);
   ga.amax2 = amax2;
   ga.res2 = res2;
+  // the 16-byte epilogue reads res2 with float4 loads too: an offset view that is contiguous but not 16-byte aligned
+  // takes the scalar epilogue
+  ga.wide = ga.wide && (reinterpret_cast<uintptr_t>(res2) & 15) == 0;
   if (amax) ga.amax_out = amax_out;   // only the fp16 kernels publish |y| maxima
   if (NT == 0) {
     if (amax) ga.amax_out = amax_out;   // (the small-map kernel publishes through every store, depth-to-space included)   // the row-tiled kernels do not cover / cannot fill the chip with this problem: the small-map form (fp16 scheme)

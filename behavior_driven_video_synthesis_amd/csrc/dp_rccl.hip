@@ -62,6 +62,11 @@ bool bind() {
 
 }  // namespace
 
+// 1 if RCCL can be bound in this process (librccl found, every entry point resolved), else 0.  Touches no GPU and no
+// communicator: ranks exchange this flag BEFORE anyone enters the blocking ncclCommInitRank (a rank that cannot bind would
+// otherwise leave the others waiting inside it forever).
+extern "C" int vunet_dp_available(void) { return bind() ? 1 : 0; }
+
 extern "C" int vunet_dp_unique_id(void* id128) {
   if (!id128) return VUNET_ERR_ARG;
   if (!bind()) return VUNET_ERR_UNSUPPORTED;

@@ -103,6 +103,10 @@ class ShapePoseNet:
             self._gan_off = torch.zeros(2, dtype=torch.int32, device=self.device)   # this step's window corner (oy, ox)
         # ---- data parallel (replaces nn.DataParallel, :213-214)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if self.world > 1:
+            # every rank seeds torch alike (same initial weights), but the ranks are different SAMPLES of the global batch:
+            # their dropout masks and posterior noise (both hashed from this base) must differ
+            ops.set_dropout_seed((config["general"].get("seed", 42) + 0x632BE5AB * dist.get_rank(process_group)) & 0xFFFFFFFF)
         broadcast_parameters(self.optimizer.buckets, 0, process_group)
         # backward finishes dd first, then ed/du, then eu: launch in that order
         self.averager = BucketedGradAverager(self.optimizer.buckets, process_group)
@@ -213,6 +217,14 @@ class ShapePoseNet:
         caller.wait_stream(gs)
         return out
 
+    def _capture_agreed(self, ok_here: bool) -> bool:
+        """True iff EVERY rank recorded the step (single process: this one did)."""
+        if not (self.averager.active and dist.is_initialized() and self.world > 1):
+            return ok_here
+        flag = torch.tensor([1 if ok_here else 0], device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
     def _train_fn_graph_on_stream(self, batch, it, eps, reg_eps):
         # host-side schedule values of THIS step -> device (one tiny launch outside the graph)
         ops.set_schedule_(self._lr_dev, self.lr, self._imax_dev, self.imax, self._drop_step, it & 0x7FFFFFFF)
@@ -234,22 +246,37 @@ class ShapePoseNet:
             static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            steps_before = [b.step for b in self.optimizer.buckets]
+            # every optimiser whose step() runs inside the step keeps a host-side count the aborted pass would leave advanced
+            opts = [self.optimizer] + ([self.optimizer_regressor] if self.train_regressor else []) + \
+                   ([self.gan.opt] if self.gan is not None else [])
+            steps_before = [[b.step for b in o.buckets] for o in opts]
+            err = out = None
             try:
                 with torch.cuda.graph(graph, stream=self._graph_stream):
                     self.optimizer.zero_grad()
                     with ops.prepacked(self.vunet):
                         out = self._step(static, it, None, None)
             except Exception as e:   # noqa: BLE001 -- a runtime that cannot record this step: say so and issue eagerly from here on
+                err = e
+            # Data parallel: the ranks must stay in the same mode -- a rank that replays its recorded all-reduces while
+            # another issues them eagerly after an aborted pass would pair collectives that do not belong together (or
+            # wait for ones that never come).  One MIN over "my capture succeeded", outside the capture.
+            if not self._capture_agreed(err is None):
                 import sys
-                print(f"[vunet] hipGraph capture of the training step failed ({type(e).__name__}: {e}); the step is issued "
+                why = f"{type(err).__name__}: {err}" if err is not None else "another rank could not record it"
+                print(f"[vunet] hipGraph capture of the training step failed ({why}); the step is issued "
                       "eagerly (device-resident schedule) from here on", file=sys.stderr)
                 self._capture = False
                 self._graphs.clear()
-                for b, n in zip(self.optimizer.buckets, steps_before):   # the aborted pass advanced the host-side counts
-                    b.step = n
+                del graph
+                for o, ns in zip(opts, steps_before):   # the aborted / discarded pass advanced the host-side counts
+                    for b, n in zip(o.buckets, ns):
+                        b.step = n
                 ops.flush_weight_grads()
                 torch.cuda.synchronize()
+                # the recording pass ran the averager's hooks: its per-step state says "every bucket launched" -- start over,
+                # or the eager pass would issue no all-reduce at all and finish() would refuse the step
+                self.averager.start_step()
                 self.optimizer.zero_grad()
                 with ops.prepacked(self.vunet):
                     return self._step(batch, it, eps, reg_eps)
@@ -384,8 +411,13 @@ class ShapePoseNet:
             ops.gamma_update_(self.gamma, self._imax_dev, kl_avg, tr["gamma_step"])
         else:
             self.gamma = torch.clamp(self.gamma - tr["gamma_step"] * (self.imax - kl_avg.reshape(())), min=0.0)
-        out.update({"loss": loss.detach(), "likelihood_loss": likelihood_loss.detach(), "kl_loss": kl.detach()})
-        out.update({k: v.detach() for k, v in ld.items()})
+        # The scalars that LEAVE the step are gathered into one small tensor of their own (one launch): the loss kernels'
+        # outputs are 4-byte views into the step's 512 KB accumulator arena (ops._zero_scalar), and a caller that keeps the
+        # returned values -- a logging list -- would otherwise keep one arena alive per step.
+        names = ["loss", "likelihood_loss", "kl_loss"] + list(ld)
+        terms = [loss, likelihood_loss, kl] + [ld[k] for k in ld]
+        packed = torch.cat([t.detach().reshape(1) for t in terms])
+        out.update({k: packed[i].view(t.shape) for i, (k, t) in enumerate(zip(names, terms))})
         return out
 
     def _regressor_steps(self, batch, reg_eps=None):

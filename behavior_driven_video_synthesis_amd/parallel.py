@@ -250,21 +250,36 @@ def _init_native_comm(process_group=None) -> bool:
     if lib.vunet_dp_world() != 0:
         return False                      # a communicator of another shape exists already: stay on torch.distributed
     import ctypes
+    import sys
+    flag_dev = "cuda" if dist.get_backend(process_group) == "nccl" else "cpu"
+
+    def all_agree(ok_here: bool) -> bool:
+        ok = torch.tensor([1 if ok_here else 0], device=flag_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
+        return int(ok.item()) == 1
+
+    # Handshake in two rounds.  ncclCommInitRank blocks until EVERY rank has entered it, so a rank that cannot even bind
+    # RCCL (dlopen / dlsym fails there) must be found out before anyone calls it: first every rank says whether the
+    # library binds (vunet_dp_available: no GPU call, no communicator) and the flags are MIN-reduced over torch.distributed;
+    # only if all can does rank 0 draw the unique id and everyone joins.  The second MIN (after init) catches a failed join.
+    can_bind = lib.vunet_dp_available() == 1
+    if not all_agree(can_bind):
+        print(f"[vunet dp] rank {rank}: RCCL cannot be bound on every rank (here: {'yes' if can_bind else 'no'}); the step's "
+              "all-reduces stay on torch.distributed", file=sys.stderr)
+        return False
     buf = ctypes.create_string_buffer(128)
     rc = lib.vunet_dp_unique_id(buf) if rank == 0 else 0
     box = [bytes(buf.raw) if rc == 0 else None]
     src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
     dist.broadcast_object_list(box, src=src, group=process_group)
-    if box[0] is None:
-        rc = -3
-    else:
-        rc = lib.vunet_dp_init(world, rank, ctypes.c_char_p(box[0]))
-    ok = torch.tensor([1 if rc == 0 else 0], device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)    # all ranks or none
-    if int(ok.item()) != 1:
+    if box[0] is None:          # rank 0 could not draw an id: every rank sees None and nobody enters the init
+        print(f"[vunet dp] rank {rank}: no RCCL unique id from rank 0; the step's all-reduces stay on torch.distributed",
+              file=sys.stderr)
+        return False
+    rc = lib.vunet_dp_init(world, rank, ctypes.c_char_p(box[0]))
+    if not all_agree(rc == 0):      # all ranks or none
         if rc == 0:
             lib.vunet_dp_finalize()
-        import sys
         print(f"[vunet dp] rank {rank}: native RCCL communicator not available (code {rc}); the step's all-reduces stay on "
               "torch.distributed", file=sys.stderr)
         return False

@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the config-1 (Market 128^2, bs 2) plumbing rows")
     ap.add_argument("--no-render", action="store_true", help="skip the config-5 render-loop row")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the `variants` rows (the step with the regressor side loop / the adversarial term / both, and the "
+                         "fp32-input-MFMA precision, 10 replayed steps each on this box)")
     ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of CPU work allowed for the bs-16 baseline")
     ap.add_argument("--cpu-threads", type=int, default=64, help="cap on the CPU baseline's threads")
     ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)
@@ -331,6 +334,47 @@ def render_row(vunet, device, size, frames=50, chunk=50, iters=5):
     return row
 
 
+def variant_rows(args, device, steps=10, warmup=3):
+    """The optional terms of BASELINE config 2 and the pure-fp32 arithmetic, timed on THIS box beside the headline (same
+    batch, same size, the step replayed from a captured hipGraph where the configuration can be recorded):
+      regressor       the regressor side loop as the reference config runs it (experiments/shape_and_pose_net.py:407-425)
+      gan             the PartDiscriminator adversarial term + one discriminator step (models/synth_discriminator.py:140-242;
+                      the reference ships it but its loop never constructs it -- SURVEY F2)
+      regressor+gan   both
+      precision_f32   the headline step with every convolution on the fp32-input MFMA kernels (no operand split)."""
+    import argparse
+    import contextlib
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
+    rows = {}
+    for name, kw in (("regressor", {"regressor": True}), ("gan", {"gan": True}), ("regressor+gan", {"regressor": True, "gan": True}),
+                     ("precision_f32", {"precision": "f32"})):
+        a = argparse.Namespace(**{**vars(args), **kw})
+        try:
+            ops.set_conv_precision(a.precision)
+            with contextlib.redirect_stdout(sys.stderr):
+                tr = ShapePoseNet(make_config(a), device=device, total_steps=150000, vgg_synthetic=True, hip_graph=False)
+                try:
+                    tr.enable_hip_graph()
+                except RuntimeError as e:
+                    print(f"bench.py: variant {name}: hipGraph mode not available ({e}); issuing eagerly", file=sys.stderr)
+            batch = synthetic_batch(a.batch, a.size, device, seed=42, with_regressor=a.regressor)
+            settle = 0
+            while tr._dev_sched and tr._capture and not tr._graphs and settle < 12:
+                tr.train_fn(batch)
+                settle += 1
+            el, out = timed_steps(tr, batch, warmup, steps, torch.cuda.synchronize)
+            rows[name] = {"value": a.batch * steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+                          "warmup": warmup, "hip_graph": bool(tr._graphs), "conv_precision": a.precision,
+                          "final_loss": float(out["loss"])}
+            del tr, batch
+        finally:
+            ops.set_conv_precision(args.precision)
+            ops.set_dropout_step(None)
+    torch.cuda.empty_cache()
+    return rows
+
+
 def timed_steps(trainer, batch, warmup, steps, sync_all):
     for _ in range(warmup):
         trainer.train_fn(batch)
@@ -417,10 +461,11 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # the constructors print like the reference does; stdout is for the JSON line
         trainer = ShapePoseNet(cfg, device=device, total_steps=150000, vgg_synthetic=True, hip_graph=False)
-        # auto: replay wherever the configuration can be captured; with several ranks the step is issued eagerly unless
-        # asked for (the RCCL all-reduces are capturable -- C-ABI communicator -- but an N > 1 capture has not run on
-        # hardware yet, and a first multi-GPU number should not depend on it)
-        if args.hip_graph == "on" or (args.hip_graph == "auto" and not trainer.averager.active):
+        # auto: replay wherever the configuration can be captured.  With several ranks that needs the step's all-reduces on
+        # the C-ABI RCCL communicator (ordinary stream operations: capturable); an eagerly issued step is 12-22 ms of
+        # Python on a slow-host box, exactly what a scaling figure is sensitive to.  A capture that fails on ANY rank sends
+        # every rank back to eager issue together (ShapePoseNet._capture_agreed; said on stderr, `config.hip_graph` false).
+        if args.hip_graph == "on" or (args.hip_graph == "auto" and (not trainer.averager.active or trainer.averager.native)):
             try:
                 trainer.enable_hip_graph()
             except RuntimeError as e:      # a configuration the capture does not cover (stated by the trainer)
@@ -527,6 +572,9 @@ def main():
     elif not args.no_roofline:
         ops.profile_stop()
 
+    if (rank == 0 and world == 1 and not dist.is_initialized() and not args.no_variants
+            and not (args.regressor or args.gan) and args.precision == "h2"):
+        result["variants"] = variant_rows(args, device)
     if rank == 0 and world == 1 and not args.no_render and args.size % 32 == 0:
         result["render"] = render_row(trainer.vunet, device, args.size)
     # BASELINE config 1 (Market 128^2, bs 2, 30-channel 64x64 appearance input): plumbing rows, GPU and CPU

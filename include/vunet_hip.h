@@ -255,7 +255,12 @@ int vunet_weightnorm_fwd(const vunet_wn_desc* d, const float* v, const float* g,
                          float* scale, float* shift, float* invnorm, float* wmax, void* stream);
 
 /* Batched form: the weights of every layer of a model in two launches.  items_dev: DEVICE array of n_items
- * entries (the pointers are device pointers; entries with kind/NULL rules as above); max_cout = max over items. */
+ * entries (the pointers are device pointers; entries with kind/NULL rules as above); max_cout = max over items.
+ * PRECONDITION (ABI 8 on): wt_f, wt_d, wx_f and wx_d of every item must be ZERO-FILLED once by the caller before the first
+ * call (hipMemset; repeated calls on the same buffers need no refill).  The batched pack is LDS-tiled and writes only what
+ * its tiles own: the padding m-tiles of wx_f / wx_d, the lanes past Ctot and the columns past Ctot of wt_d are never
+ * written, and the split kernels multiply whatever those positions hold (uninitialised memory -> garbage / NaN in the
+ * padding rows).  The per-layer vunet_weightnorm_fwd writes every position itself and has no such precondition. */
 typedef struct vunet_wn_item {
   const float *v, *g, *bias, *gamma, *beta;
   float *wt_f, *wt_d, *scale, *shift, *invnorm;
@@ -459,6 +464,7 @@ int vunet_ssim_partial(const float* x, const float* y, int32_t planes, int32_t H
  *                              its buckets in the same order.
  *   vunet_dp_world             ranks of the communicator, 0 before init / after finalize.
  *   vunet_dp_finalize          destroys the communicator (idempotent). */
+int vunet_dp_available(void);   /* 1 / 0: librccl binds in this process (no GPU call, no communicator): exchange it first */
 int vunet_dp_unique_id(void* id128);
 int vunet_dp_init(int32_t world, int32_t rank, const void* id128);
 int vunet_dp_world(void);

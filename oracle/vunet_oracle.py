@@ -152,12 +152,17 @@ def dropout_apply(x: Tensor, mask: Optional[Tensor], p: float) -> Tensor:
 
 
 def rnb(sd: SD, p: str, x: Tensor, a: Optional[Tensor] = None,
-        drop_mask: Optional[Tensor] = None, drop_p: float = 0.0) -> Tensor:
-    """VunetRNB.forward (lib/modules.py:221-233), ELU activation, 3x3 conv."""
+        drop_mask: Optional[Tensor] = None, drop_p: float = 0.0, drop=None) -> Tensor:
+    """VunetRNB.forward (lib/modules.py:221-233), ELU activation, 3x3 conv.
+
+    ``drop`` (whole-model parity tests): ``drop(p, x_shape, a_shape) -> (keep-mask over cat(x, nin(a)), prob)`` for the
+    block named ``p`` -- the keep-mask nn.Dropout would have drawn at :229, injected."""
     r = x
     if a is not None:
         a = _conv_any(sd, p + ".nin", F.elu(a))
         r = torch.cat([r, a], dim=1)
+    if drop is not None:
+        drop_mask, drop_p = drop(p, tuple(x.shape), None if a is None else tuple(a.shape))
     r = dropout_apply(F.elu(r), drop_mask, drop_p)
     r = _conv_any(sd, p + ".conv", r, padding=1)
     return x + r
@@ -174,13 +179,13 @@ def vunet_dims(cfg: dict, n_channels_x: int = 3) -> dict:
                 n_latent_scales=cfg["n_latent_scales"])
 
 
-def enc_up(sd: SD, p: str, x: Tensor, n_scales: int) -> List[Tensor]:
+def enc_up(sd: SD, p: str, x: Tensor, n_scales: int, drop=None) -> List[Tensor]:
     """EncUp.forward / DecUp.forward (models/vunets.py:133-148, 246-261)."""
     hs = []
     h = _conv_any(sd, p + ".nin", x)
     for i in range(n_scales):
         for n in range(2):
-            h = rnb(sd, f"{p}.blocks.{2 * i + n}", h)
+            h = rnb(sd, f"{p}.blocks.{2 * i + n}", h, drop=drop)
             hs.append(h)
         if i + 1 < n_scales:
             h = downsample(sd, f"{p}.downs.{i}", h)
@@ -188,7 +193,7 @@ def enc_up(sd: SD, p: str, x: Tensor, n_scales: int) -> List[Tensor]:
 
 
 def enc_down_alter(sd: SD, p: str, gs: Sequence[Tensor], n_latent: int,
-                   eps: Optional[Sequence[Tensor]] = None):
+                   eps: Optional[Sequence[Tensor]] = None, drop=None):
     """EncDownAlter.forward (models/vunets.py:558-597).
 
     ``eps`` replaces torch.randn_like at :596 (one tensor per latent scale).
@@ -198,7 +203,7 @@ def enc_down_alter(sd: SD, p: str, gs: Sequence[Tensor], n_latent: int,
     hs, means, logstds, zs = [], [], [], []
     h = _conv_any(sd, p + ".nin", gs[-1])
     for i in range(n_latent):
-        h = rnb(sd, f"{p}.blocks.{2 * i}", h, gs.pop())
+        h = rnb(sd, f"{p}.blocks.{2 * i}", h, gs.pop(), drop=drop)
         hs.append(h)
         mu = _conv_any(sd, f"{p}.make_latent_params.{i}", h, padding=1)
         ls = torch.sigmoid(_conv_any(sd, f"{p}.make_logstds.{i}", h, padding=1))
@@ -208,31 +213,31 @@ def enc_down_alter(sd: SD, p: str, gs: Sequence[Tensor], n_latent: int,
         z = e * torch.exp(ls) + mu
         zs.append(z)
         gz = torch.cat([gs.pop(), z], dim=1)
-        h = rnb(sd, f"{p}.blocks.{2 * i + 1}", h, gz)
+        h = rnb(sd, f"{p}.blocks.{2 * i + 1}", h, gz, drop=drop)
         hs.append(h)
         h = upsample(sd, f"{p}.ups.{i}", h)
-    h = rnb(sd, p + ".fin_block", h, gs.pop())
+    h = rnb(sd, p + ".fin_block", h, gs.pop(), drop=drop)
     hs.append(h)
     return hs, means, logstds, zs
 
 
 def dec_down_alter(sd: SD, p: str, gs: Sequence[Tensor], zs: Sequence[Tensor], n_scales: int,
                    n_latent: int, training: bool = True,
-                   prior_eps: Optional[Sequence[Tensor]] = None, subpixel: bool = True) -> Tensor:
+                   prior_eps: Optional[Sequence[Tensor]] = None, subpixel: bool = True, drop=None) -> Tensor:
     """DecDownAlter.forward (models/vunets.py:332-414).  ``subpixel`` False (``subpixel_upsampling: False``): the levels
     past the latent scales up-sample bilinearly (models/vunets.py:325-329)."""
     gs = list(gs)
     zs = list(zs)
     h = _conv_any(sd, p + ".nin", gs[-1])
     for i in range(n_scales):
-        h = rnb(sd, f"{p}.blocks.{2 * i}", h, gs.pop())
+        h = rnb(sd, f"{p}.blocks.{2 * i}", h, gs.pop(), drop=drop)
         if i < n_latent:
             if training:
                 z = zs.pop(0)
             else:
                 z = prior_eps[i] if prior_eps is not None else torch.randn_like(h)
-            h = rnb(sd, f"{p}.auto_blocks.{i}", h, z)
-        h = rnb(sd, f"{p}.blocks.{2 * i + 1}", h, gs.pop())
+            h = rnb(sd, f"{p}.auto_blocks.{i}", h, z, drop=drop)
+        h = rnb(sd, f"{p}.blocks.{2 * i + 1}", h, gs.pop(), drop=drop)
         if i + 1 < n_scales:
             h = upsample(sd, f"{p}.ups.{i}", h) if (subpixel or i < n_latent) else upsample_bilinear(sd, f"{p}.ups.{i}", h)
     assert not gs
@@ -240,14 +245,14 @@ def dec_down_alter(sd: SD, p: str, gs: Sequence[Tensor], zs: Sequence[Tensor], n
 
 
 def vunet_alter_forward(sd: SD, cfg: dict, x: Tensor, c: Tensor,
-                        eps: Optional[Sequence[Tensor]] = None, n_channels_x: int = 3):
-    """VunetAlter.forward (models/vunets.py:490-500) -> (img, means, logstds, hs)."""
+                        eps: Optional[Sequence[Tensor]] = None, n_channels_x: int = 3, drop=None):
+    """VunetAlter.forward (models/vunets.py:490-500) -> (img, means, logstds, hs).  ``drop``: see ``rnb``."""
     d = vunet_dims(cfg, n_channels_x)
-    hs = enc_up(sd, "eu", x, d["n_scales_x"])
-    _, means, logstds, zs = enc_down_alter(sd, "ed", hs, d["n_latent_scales"], eps)
-    gs = enc_up(sd, "du", c, d["n_scales"])
+    hs = enc_up(sd, "eu", x, d["n_scales_x"], drop=drop)
+    _, means, logstds, zs = enc_down_alter(sd, "ed", hs, d["n_latent_scales"], eps, drop=drop)
+    gs = enc_up(sd, "du", c, d["n_scales"], drop=drop)
     img = dec_down_alter(sd, "dd", gs, zs, d["n_scales"], d["n_latent_scales"], True,
-                         subpixel=bool(cfg.get("subpixel_upsampling", True)))
+                         subpixel=bool(cfg.get("subpixel_upsampling", True)), drop=drop)
     return img, means, logstds, hs
 
 
@@ -506,9 +511,9 @@ def update_gamma(gamma: float, gamma_step: float, imax: float, kl: float) -> flo
 
 
 def train_step_losses(sd: SD, cfg: dict, vgg_sd: SD, vgg_weights, x: Tensor, c: Tensor, target: Tensor,
-                      eps, gamma: float, iteration: int, n_init_batches: int, ll_weight: float = 1.0):
+                      eps, gamma: float, iteration: int, n_init_batches: int, ll_weight: float = 1.0, drop=None):
     """Loss assembly of train_fn (experiments/shape_and_pose_net.py:382-405), regressor path off."""
-    img, means, logstds, _ = vunet_alter_forward(sd, cfg, x, c, eps)
+    img, means, logstds, _ = vunet_alter_forward(sd, cfg, x, c, eps, drop=drop)
     ld = vgg_loss(vgg_sd, vgg_weights, target, img)
     ll = ll_weight * torch.stack(list(ld.values()), dim=0).sum()
     kl = compute_kl_with_prior(means, logstds)

@@ -165,6 +165,83 @@ def test_four_ranks_with_uneven_completion_order_launch_in_one_agreed_order():
     assert len({tuple(r[4]) for r in res}) == 1
 
 
+def _worker_capture_fallback(rank, world, port, q):
+    """The protocol of a failed hipGraph capture under data parallelism (ShapePoseNet._train_fn_graph_on_stream), on gloo:
+    (i) the ranks agree on "everybody recorded the step" with one MIN -- a rank whose own capture succeeded goes eager too
+    when another's failed; (ii) the aborted recording pass leaves the averager saying "every bucket launched": re-running the
+    step without ``start_step()`` issues no all-reduce and ``finish()`` refuses it; with it the step is a normal one and the
+    replicas stay bit-identical (what bench.py's ``dp_consistent`` checks at the end of a run)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet
+    from behavior_driven_video_synthesis_amd.optim import FlatBucket
+    from behavior_driven_video_synthesis_amd.parallel import BucketedGradAverager, broadcast_parameters
+
+    torch.manual_seed(5 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3))
+    buckets = [FlatBucket(list(net[2].parameters()), "late"), FlatBucket(list(net[0].parameters()), "early")]
+    broadcast_parameters(buckets, 0)
+    avg = BucketedGradAverager(buckets)
+    fake = types.SimpleNamespace(averager=avg, world=world, device=torch.device("cpu"))
+    agreed = [ShapePoseNet._capture_agreed(fake, True),            # everybody recorded it
+              ShapePoseNet._capture_agreed(fake, rank != 1),       # rank 1 could not: nobody replays
+              ShapePoseNet._capture_agreed(fake, False)]
+    g = torch.Generator().manual_seed(11)
+    x_all, y_all = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    per = 8 // world
+    xs, ys = x_all[rank * per:(rank + 1) * per], y_all[rank * per:(rank + 1) * per]
+
+    def step(restart):
+        if restart:
+            avg.start_step()
+        for b in buckets:
+            b.zero_grad()
+        ((net(xs) - ys) ** 2).mean().backward()
+        avg.finish()
+        with torch.no_grad():
+            for b in buckets:
+                b.flat.add_(b.grad, alpha=-0.1)
+    step(True)
+    step(True)
+    # the state an aborted recording pass leaves behind: hooks fired and every bucket "launched", nothing exchanged
+    avg.start_step()
+    avg._fired = list(avg._expected)
+    avg._launched = [True] * len(buckets)
+    avg._fired_at_launch = list(avg._expected)
+    avg._next_pos = len(buckets)
+    try:
+        step(False)
+        refused = False
+    except RuntimeError:
+        refused = True
+    step(True)                      # what the trainer does: start the step over, then issue it eagerly
+    step(True)
+    q.put((rank, agreed, refused, avg.replicas_consistent(), [float(b.flat.double().sum()) for b in buckets]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_failed_capture_protocol_keeps_the_ranks_in_one_mode_and_the_replicas_consistent():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_capture_fallback, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, agreed, refused, consistent, sums in res:
+        assert agreed == [True, False, False], (rank, agreed)     # the same answer on both ranks, whoever failed
+        assert refused                                            # without start_step() the re-run is refused, not half-averaged
+        assert consistent is True
+    assert res[0][4] == res[1][4]
+
+
 def test_flat_bucket_views_and_adam_state_dict_layout():
     sys.path.insert(0, ROOT)
     from behavior_driven_video_synthesis_amd.optim import FlatBucket

@@ -88,3 +88,29 @@ def test_captured_step_with_rccl_allreduces_equals_the_eager_one(tmp_path):
     assert len(set(a["losses"])) == len(a["losses"])
     for x, y in zip(a["flat"], b["flat"]):
         assert torch.equal(x, y)
+
+
+def test_failed_capture_with_an_active_averager_falls_back_to_the_eager_step(tmp_path):
+    """a capture that fails AFTER the recording pass has run the averager's hooks and advanced the optimisers'
+    host-side step counts.  The trainer must restart the averager's step state before it re-runs the step eagerly (or no
+    all-reduce is issued and ``finish()`` refuses the step) and restore the counts: the run then equals the eager
+    device-schedule run bit for bit, with no graph kept."""
+    import torch
+    env = dict(os.environ, VUNET_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = os.path.join(ROOT, "tools", "dp_check.py")
+    res = {}
+    for mode, port in (("capture-fail", "29527"), ("eager", "29529")):
+        out = str(tmp_path / mode)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                            "--master-addr", "127.0.0.1", "--master-port", port, script, "--out", out, "--steps", "7",
+                            "--graph", mode], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        if mode == "capture-fail":
+            assert "injected capture failure" in r.stderr and "issued eagerly" in r.stderr.replace("\n", " ")
+        res[mode] = torch.load(os.path.join(out, "rank0.pt"))
+    a, b = res["capture-fail"], res["eager"]
+    assert a["backend"] == b["backend"] == "rccl-cabi" and a["graphs"] == b["graphs"] == 0
+    assert a["losses"] == b["losses"] and a["gamma"] == b["gamma"]
+    assert a["adam_steps"] == b["adam_steps"] == [7, 7, 7, 7]
+    for x, y in zip(a["flat"], b["flat"]):
+        assert torch.equal(x, y)

@@ -28,9 +28,12 @@ ap.add_argument("--world", type=int, default=0, help="--single: the world size w
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch", type=int, default=2, help="per-rank batch")
 ap.add_argument("--size", type=int, default=64)
-ap.add_argument("--graph", choices=["off", "capture", "eager"], default="off",
+ap.add_argument("--graph", choices=["off", "capture", "eager", "capture-fail"], default="off",
                 help="device-resident schedule: the step replayed from a captured hipGraph (all-reduces inside) / the same "
-                     "schedule launched eagerly; posterior noise then comes from torch's generator (seeded per run)")
+                     "schedule launched eagerly / a capture that is made to fail after the whole step has been recorded (the "
+                     "trainer must fall back to eager issue with the averager's state intact).  The posterior noise is then "
+                     "drawn inside the sampling kernels from the dropout seed base (ops.set_dropout_seed: the config seed, "
+                     "offset per rank by the trainer), not from torch's generator")
 a = ap.parse_args()
 
 world = a.world if a.single else int(os.environ["WORLD_SIZE"])
@@ -51,8 +54,16 @@ cfg["training"].update(dropout_prob=0.0, train_regressor=False, n_init_batches=1
 with contextlib.redirect_stdout(sys.stderr):
     tr = ShapePoseNet(cfg, device=dev, vgg_width_div=8, total_steps=100, vgg_synthetic=True)   # same seed on every rank
 if a.graph != "off":
-    tr.enable_hip_graph(capture=(a.graph == "capture"))
-    torch.manual_seed(4242 + rank)
+    tr.enable_hip_graph(capture=(a.graph != "eager"))
+    if a.graph == "capture-fail":
+        real_step = tr._step
+
+        def step_that_fails_while_recording(*args, **kw):
+            out_ = real_step(*args, **kw)   # the whole step is recorded first: hooks fired, host-side step counts advanced
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected capture failure (tools/dp_check.py --graph capture-fail)")
+            return out_
+        tr._step = step_that_fails_while_recording
 nlat = cfg["architecture"]["n_latent_scales"]
 lat = [(32, a.size // 2 ** (tr.vunet.n_scales - 1 - i)) for i in range(nlat)]   # (channels, width) of the latent scales
 
@@ -78,7 +89,7 @@ sd = tr.vunet.state_dict()
 res = {"losses": losses, "gamma": float(tr.gamma),
        "sums": {k: float(v.double().sum()) for k, v in sd.items()},
        "tensor": sd["dd.out_conv.conv.weight_v"].cpu(), "flat": [b.flat.cpu() for b in tr.optimizer.buckets],
-       "allreduce_ms": tr.averager.mean_allreduce_ms(), "backend": tr.averager.backend, "graphs": len(tr._graphs)}
+       "adam_steps": [int(b.step) for b in tr.optimizer.buckets], "allreduce_ms": tr.averager.mean_allreduce_ms(), "backend": tr.averager.backend, "graphs": len(tr._graphs)}
 os.makedirs(a.out, exist_ok=True)
 torch.save(res, os.path.join(a.out, "single.pt" if a.single else f"rank{rank}.pt"))
 if dist.is_initialized():

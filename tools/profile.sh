@@ -18,10 +18,10 @@ mkdir -p $OUT
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 # (PMC passes and the one-stream trace issue the step eagerly: the same kernels, one dispatch per launch for the counters)
-BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-config1 --no-render --hip-graph off"
+BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-config1 --no-render --no-variants --hip-graph off"
 
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render --no-variants > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 cp $(ls $OUT/${TAG}_trace/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
 # per-step GPU timeline of the replayed graph (idle / 1 / 2 / 3+ kernels running, idle gaps by neighbouring kernels)
 python3 tools/timeline.py $(ls $OUT/${TAG}_trace/*/*_kernel_trace.csv | head -1) > $OUT/${TAG}_timeline_graph.txt 2>&1
@@ -29,7 +29,7 @@ python3 tools/timeline.py $(ls $OUT/${TAG}_trace/*/*_kernel_trace.csv | head -1)
 # (what bench.py's `roofline` region measures with HIP events; compare its avg_launch_us with the AverageNs here)
 export VUNET_TWO_STREAMS=0
 rm -rf $OUT/${TAG}_trace1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render --hip-graph off > $OUT/${TAG}_trace1_bench.json 2> $OUT/${TAG}_trace1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render --no-variants --hip-graph off > $OUT/${TAG}_trace1_bench.json 2> $OUT/${TAG}_trace1.err
 cp $(ls $OUT/${TAG}_trace1/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats_1stream.csv 2>/dev/null
 rm -rf $OUT/${TAG}_trace1
 unset VUNET_TWO_STREAMS

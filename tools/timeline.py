@@ -3,7 +3,7 @@
 step's first kernel, the batched weight fold) how much of the time has no kernel running (dependency / launch gaps), one,
 two, three or more; per-queue busy time; the largest idle gaps with the kernels around them.
 
-    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-config1 --no-render --no-variants
     python tools/timeline.py gpurun_out/tl/*/*_kernel_trace.csv [marker kernel substring, default wn_scale_multi_kernel]
 """
 import csv
