@@ -277,6 +277,7 @@ class ShapePoseNet:
                 # the recording pass ran the averager's hooks: its per-step state says "every bucket launched" -- start over,
                 # or the eager pass would issue no all-reduce at all and finish() would refuse the step
                 self.averager.start_step()
+                ops.reset_dropout_counter()   # the recording pass drew this step's seeds: the eager pass draws the same ones
                 self.optimizer.zero_grad()
                 with ops.prepacked(self.vunet):
                     return self._step(batch, it, eps, reg_eps)

@@ -137,8 +137,11 @@ class BucketedGradAverager:
         self._fired = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._works = []
-        self._events.append([])
-        self._bwd_end.append(None)
+        # (a step replayed from a captured hipGraph issues nothing from Python and records no events: its empty record is
+        #  reused, so the measurements of the eagerly issued steps before the capture stay in the window)
+        if not self._events or self._events[-1]:
+            self._events.append([])
+            self._bwd_end.append(None)
         self._next_pos = 0
         self._ready = [False] * len(self.buckets)
         self._seq = 0

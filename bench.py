@@ -530,7 +530,11 @@ def main():
                    "dp_backend": trainer.averager.backend,
                    "allreduce_ms_per_step": trainer.averager.mean_allreduce_ms(),
                    # share of the all-reduce time that ran while backward was still computing (HIP events)
-                   "allreduce_overlap_frac": trainer.averager.overlap_fraction()},
+                   "allreduce_overlap_frac": trainer.averager.overlap_fraction(),
+                   # (HIP events cannot be read back from a captured graph: under replay the two figures above are those of the
+                   #  eagerly issued steps before the capture -- same kernels, same streams)
+                   "allreduce_timed_on": ("eager steps before the capture" if trainer._graphs else "timed steps")
+                                         if trainer.averager.active else None},
     }
     if result["config"]["rccl_world_size"] != args.gpus:
         raise SystemExit(f"rank {rank}: RCCL communicator spans {result['config']['rccl_world_size']} rank(s), --gpus {args.gpus}")

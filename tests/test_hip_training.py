@@ -306,9 +306,9 @@ def test_benchmark_size_step_vs_oracle():
 
     Bars: the six perceptual terms, the KL term and the loss to 1e-4 relative.  The four gradient buckets by relative L2:
     the gradient of an L1 loss on ReLU / max-pool features is discontinuous in the features, so two float32 evaluations of
-    d loss / d image already differ by ~3e-3 (profiles/r04_vgg_grad_cmp_256.txt: float32 oracle 2.6e-3 and this path 3.3e-3
-    from the float64 oracle) and every generator gradient inherits that: the bar is 1e-2, the measured distances are
-    printed."""
+    d loss / d image can differ by ~3e-3 on adversarial inputs (profiles/r04_vgg_grad_cmp_256.txt: float32 oracle 2.6e-3 and
+    this path 3.3e-3 from the float64 oracle on random images) and every generator gradient inherits that: the bar is 2e-3.
+    Measured on this step (profiles/r05_bench_size_parity.txt): eu 3.9e-7, ed 3.1e-7, du 2.2e-5, dd 2.1e-5."""
     import copy
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
@@ -385,7 +385,7 @@ def test_benchmark_size_step_vs_oracle():
                          .reshape(-1) for k, _ in get_member(tr.vunet, n).named_parameters()])
         rel = float((got[n].double() - ref.double()).norm() / ref.double().norm())
         print(f"bucket {n}: relative L2 distance to the oracle {rel:.2e}")
-        assert rel <= 1e-2, (n, rel)
+        assert rel <= 2e-3, (n, rel)
 
 
 def test_shape_pose_net_l2_conv_variant_initialises_and_trains():
