@@ -137,7 +137,7 @@ static inline InAct make_inact(int act, float slope, float p, uint32_t seed) {
   }
 
 // process-wide tuning knobs (vunet_set_tuning, pointwise.hip): plain loads on the launch path
-extern int g_vunet_tune[8];
+extern int g_vunet_tune[16];
 
 static inline int vunet_check_launch() {
   hipError_t e = hipGetLastError();

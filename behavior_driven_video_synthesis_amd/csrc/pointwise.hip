@@ -523,10 +523,10 @@ extern "C" int vunet_set_dropout_step(const uint32_t* step_dev) {
 }
 
 // ------------------------------------------------------------------ tuning knobs (tests / kernel tuning)
-int g_vunet_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int g_vunet_tune[16] = {0};
 
 extern "C" int vunet_set_tuning(int32_t key, int32_t value) {
-  if (key < 0 || key >= 8) return VUNET_ERR_ARG;
+  if (key < 0 || key >= VUNET_TUNE_COUNT) return VUNET_ERR_ARG;
   g_vunet_tune[key] = value;
   return VUNET_OK;
 }

@@ -337,7 +337,7 @@ class ShapePoseNet:
                     packed.__enter__()
                 try:
                     with torch.no_grad():
-                        target_features = self.custom_vgg(batch["pose_img"])
+                        target_features = self.custom_vgg.features_for_loss(batch["pose_img"])
                     main.wait_stream(side)
                     out = self._step(batch, it, eps, reg_eps, target_features)
                 finally:
@@ -369,7 +369,7 @@ class ShapePoseNet:
             def start_target_pass():
                 tstream.wait_stream(main)
                 with torch.cuda.stream(tstream), torch.no_grad():
-                    box["f"] = self.custom_vgg(target_img)
+                    box["f"] = self.custom_vgg.features_for_loss(target_img)
             out_img, means, logstds, _ = self.vunet(pose_img, shape_img, eps, after_encoder=start_target_pass)
             main.wait_stream(tstream)
             target_features = box["f"]

@@ -57,11 +57,17 @@ def vgg_loss(custom_vgg, target, pred, weights=None, target_features=None):
     builds both (it never disables ``requires_grad`` on VGG), which changes neither the loss nor the
     gradient reaching the generator.
     """
+    fast = (weights is None and ops._grad_passthrough and torch.is_grad_enabled() and pred.requires_grad
+            and hasattr(custom_vgg, "loss_terms"))
     if target_features is None:
         with torch.no_grad():
-            target_features = custom_vgg(target)
-    if (weights is None and ops._grad_passthrough and torch.is_grad_enabled() and pred.requires_grad
-            and hasattr(custom_vgg, "loss_terms")):
+            # (on the tap-by-tap route the target's features may stay in the stack's internal layout)
+            target_features = (custom_vgg.features_for_loss(target) if (fast and hasattr(custom_vgg, "features_for_loss"))
+                               else custom_vgg(target))
+    planes = type(target_features).__name__ == "_P2Target"   # (features_for_loss: the taps in the stack's internal layout)
+    if planes and weights is not None:
+        raise RuntimeError("vgg_loss(weights=...) needs fp32 target features: pass custom_vgg(target), not features_for_loss(target)")
+    if fast or planes:
         return custom_vgg.loss_terms(pred, target_features)   # the same terms, formed tap by tap during the pass
     wanted = VGGOutput(**target_features)
     got = VGGOutput(**custom_vgg(pred))

@@ -104,6 +104,231 @@ def _adopt_features(features: nn.Sequential) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+# ------------------------------------------------------------------------------------------------
+# The stack on PRE-SPLIT activations ("p2", csrc/conv_p2.hip / planes.hip).  From relu1_1 on, every activation of the pass
+# lives in HBM as two fp16 planes that ARE the matrix-core operand of the next layer (converted once, by the kernel that
+# produces them); L1 taps, max-pools and the whole backward chain work on the planes directly.  Same arithmetic as the
+# fp32-tensor path (two scaled fp16 terms per operand, three products, fp32 accumulation): tests/test_hip_p2.py.
+# ------------------------------------------------------------------------------------------------
+_p2_switch = {"on": __import__("os").environ.get("VUNET_VGG_P2", "1") != "0"}
+
+
+def enable_p2(on: bool = True):
+    """The perceptual loss's VGG19 pass on pre-split planes (default) or on fp32 NCHW tensors (the path every other layer uses)."""
+    _p2_switch["on"] = bool(on)
+
+
+class _P2Target(dict):
+    """``PerceptualVGG.features_for_loss(target)`` on the p2 path: tap name -> the tap's planes BUFFER (a tensor, so that
+    callers can ``record_stream`` the values), "input" -> the preprocessed image (fp32); ``planes``: name -> ops.Planes.
+    Valid until the next target pass of the same PerceptualVGG (the buffers are persistent and reused)."""
+
+    planes = None
+    generation = 0
+
+
+class _P2Engine:
+    """Persistent state of the p2 pass of one PerceptualVGG and one input geometry: per role ("t": target pass, "p":
+    prediction pass) the planes of every activation from relu1_1 to the last tap, for the prediction role also the
+    gradient planes, and one meta arena per role that is zeroed by ONE fill at the start of a pass."""
+
+    def __init__(self, program, n, h, w, device):
+        self.program, self.geo, self.device = program, (n, h, w), device
+        self.roles = {}
+        self.generation = 0
+
+    @staticmethod
+    def build_program(mods, last, taps):
+        """mods: the (index, module) list of ``features``.  -> (first conv, [step...]) with step = ("conv", module, tap name
+        or None) | ("pool",), or None if the stack is not conv+relu / pool shaped."""
+        steps, first, i = [], None, 0
+        while i < len(mods):
+            name, m = mods[i]
+            if int(name) > last:
+                break
+            if isinstance(m, Conv2d):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if nxt is None or not (isinstance(nxt[1], _Marker) and nxt[1].kind == "relu"):
+                    return None
+                tap = taps.get(nxt[0])
+                if first is None:
+                    if tap is not None:
+                        return None
+                    first = m
+                else:
+                    steps.append(("conv", m, tap))
+                i += 2
+            elif isinstance(m, _Marker) and m.kind == "pool":
+                if first is None:
+                    return None
+                steps.append(("pool",))
+                i += 1
+            else:
+                return None
+        if first is None or not steps or steps[-1][0] != "conv" or steps[-1][2] is None:
+            return None
+        return first, steps
+
+    def shapes(self):
+        """(C, H, W) of A[0] .. A[L]; None if a layer is outside what vunet_p2_conv covers."""
+        first, steps = self.program
+        n, h, w = self.geo
+        c = first.weight.shape[0]
+        out = [(c, h, w)]
+        for st in steps:
+            if st[0] == "pool":
+                if h % 2 or w % 2:
+                    return None
+                h, w = h // 2, w // 2
+            else:
+                m = st[1]
+                if m.weight.shape[1] != c or tuple(m.weight.shape[2:]) != (3, 3) or not ops.p2_conv_supported(n, c, h, w, m.weight.shape[0]):
+                    return None
+                # the data gradient of the same layer
+                if not ops.p2_conv_supported(n, m.weight.shape[0], h, w, c):
+                    return None
+                c = m.weight.shape[0]
+            out.append((c, h, w))
+        return out
+
+    def _role(self, role):
+        st = self.roles.get(role)
+        if st is None:
+            shp = self.shapes()
+            n = self.geo[0]
+            L = len(shp)
+            metas = torch.zeros(3 * L, ops.P2_META_INTS, device=self.device, dtype=torch.int32)
+            acts = [ops.Planes((n, c, h, w), self.device, meta=metas[k]) for k, (c, h, w) in enumerate(shp)]
+            st = self.roles[role] = {"metas": metas, "A": acts, "G": [None] * L, "U": [None] * L, "shp": shp}
+        return st
+
+    def _grad_buf(self, st, kind, k):
+        lst = st[kind]
+        if lst[k] is None:
+            c, h, w = st["shp"][k]
+            L = len(st["shp"])
+            lst[k] = ops.Planes((self.geo[0], c, h, w), self.device, meta=st["metas"][(1 if kind == "G" else 2) * L + k])
+        return lst[k]
+
+    @staticmethod
+    def _weights(m):
+        w = m.__dict__.get("_p2w")
+        if w is None or w.weight is not m.weight:
+            w = ops.P2Weights(m.weight, m.bias)
+            object.__setattr__(m, "_p2w", w)
+        return w
+
+    def forward(self, role, y0, targets=None, tap_weights=None):
+        """y0: relu1_1 as an fp32 tensor (conv1_1 runs on the 3-channel VALU kernel).  -> ({tap: Planes}, {tap: loss [1]})."""
+        st = self._role(role)
+        st["metas"].zero_()
+        A = st["A"]
+        ops.p2_from_nchw(y0, out=A[0], zero_meta=False)
+        taps, losses = {}, {}
+        steps = self.program[1]
+        for k, step in enumerate(steps, start=1):
+            if step[0] == "conv":
+                ops.p2_conv(A[k - 1], self._weights(step[1]), A[k], relu=True)
+                tap = step[2]
+                if tap is not None:
+                    taps[tap] = A[k]
+                    pool_next = k < len(steps) and steps[k][0] == "pool"
+                    if targets is not None and not pool_next:
+                        losses[tap] = ops.p2_l1_fwd(targets[tap], A[k], tap_weights[tap])
+            else:
+                prev = steps[k - 2] if k >= 2 else None
+                tap = prev[2] if (prev is not None and prev[0] == "conv") else None
+                if targets is not None and tap is not None:
+                    losses[tap] = ops.p2_pool_fwd(A[k - 1], A[k], t=targets[tap], weight=tap_weights[tap])
+                else:
+                    ops.p2_pool_fwd(A[k - 1], A[k])
+        return taps, losses
+
+    def backward(self, targets, tap_weights, gouts):
+        """The data-gradient chain of the prediction pass, top tap down to relu1_1.  gouts: {tap: upstream gradient of the tap's
+        loss term (device tensor [1]) or None}.  -> d loss / d relu1_1-output, ALREADY multiplied by [relu1_1 > 0], fp32."""
+        st = self.roles["p"]
+        A, steps = st["A"], self.program[1]
+        L = len(steps)
+
+        def tap_scale(tap, k):
+            c, h, w = st["shp"][k]
+            return float(tap_weights[tap]) / (self.geo[0] * c * h * w)
+
+        def has(tap):
+            return tap is not None and gouts.get(tap) is not None
+        # D = gradient w.r.t. the convolution output under A[k] (i.e. after the ReLU backward), kept in G[k]
+        k = L
+        top = steps[L - 1][2]
+        D = None
+        if has(top):
+            D = ops.p2_l1_bwd(targets[top], A[L], None, self._grad_buf(st, "G", L), tap_scale(top, L), gouts[top])
+        while k >= 1:
+            step = steps[k - 1]
+            if step[0] == "pool":
+                # D holds the gradient w.r.t. the pool OUTPUT A[k]; A[k-1] is a ReLU output, possibly a tap
+                prev = steps[k - 2]
+                tap = prev[2] if has(prev[2]) else None
+                if D is None and tap is None:
+                    k -= 1
+                    continue
+                if D is None:   # nothing from above: the tap's own step only
+                    D = ops.p2_l1_bwd(targets[tap], A[k - 1], None, self._grad_buf(st, "G", k - 1), tap_scale(tap, k - 1), gouts[tap])
+                else:
+                    D = ops.p2_pool_bwd(A[k - 1], D, self._grad_buf(st, "G", k - 1), t=None if tap is None else targets[tap],
+                                        gscale=0.0 if tap is None else tap_scale(tap, k - 1), gout=None if tap is None else gouts[tap])
+                k -= 1
+                continue
+            # conv step k: A[k] = relu(conv(A[k-1])), D = gradient w.r.t. the conv output
+            below = steps[k - 2] if k >= 2 else None          # what produced A[k-1]
+            if D is None:
+                tap = below[2] if (below is not None and below[0] == "conv" and has(below[2])) else None
+                if tap is not None:
+                    D = ops.p2_l1_bwd(targets[tap], A[k - 1], None, self._grad_buf(st, "G", k - 1), tap_scale(tap, k - 1), gouts[tap])
+                k -= 1
+                continue
+            wts = self._weights(step[1])
+            if below is None:                                   # A[0] = relu1_1: mask and leave the planes
+                D = ops.p2_conv(D, wts, self._grad_buf(st, "G", 0), dgrad=True, mask=A[0])
+            elif below[0] == "pool":                            # gradient w.r.t. a pool output: no ReLU of its own
+                D = ops.p2_conv(D, wts, self._grad_buf(st, "G", k - 1), dgrad=True)
+            elif has(below[2]):                                 # A[k-1] is a tap read by this layer too: add the tap's step, then mask
+                up = ops.p2_conv(D, wts, self._grad_buf(st, "U", k - 1), dgrad=True)
+                D = ops.p2_l1_bwd(targets[below[2]], A[k - 1], up, self._grad_buf(st, "G", k - 1), tap_scale(below[2], k - 1),
+                                  gouts[below[2]])
+            else:
+                D = ops.p2_conv(D, wts, self._grad_buf(st, "G", k - 1), dgrad=True, mask=A[k - 1])
+            k -= 1
+        if D is None:
+            return None
+        return D.to_nchw()
+
+
+class P2VggLoss(torch.autograd.Function):
+    """The prediction pass of the perceptual loss from relu1_1 up, on pre-split planes: (relu1_1 output, engine, target) ->
+    one loss term per tap.  ONE autograd node: the backward walks the data-gradient chain itself (conv / tap / pool kernels
+    on planes) and hands back d loss / d relu1_1-output already multiplied by the ReLU mask."""
+
+    @staticmethod
+    def forward(ctx, y0, engine, target, tap_weights, names):
+        _, losses = engine.forward("p", y0, target.planes, tap_weights)
+        ctx.engine, ctx.target, ctx.tap_weights, ctx.names = engine, target, tap_weights, names
+        ctx.y0 = y0
+        ctx.generation = target.generation
+        return tuple(losses[n] for n in names)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        if ctx.target.generation != ctx.generation:
+            raise RuntimeError("P2VggLoss.backward: the target features were overwritten by a later target pass of the same "
+                               "PerceptualVGG (its planes buffers are persistent): run forward + backward per target")
+        g = ctx.engine.backward(ctx.target.planes, ctx.tap_weights,
+                                {n: (None if go is None else go.contiguous()) for n, go in zip(ctx.names, gouts)})
+        if g is not None:
+            ops._tag_masked(g, ctx.y0)
+        return g, None, None, None, None
+
+
 class PerceptualVGG(nn.Module):
     """models/imagenet_pretrained.py:8-61: dict ``input, relu1_2, relu2_2, relu3_2, relu4_2, relu5_2``."""
 
@@ -160,6 +385,45 @@ class PerceptualVGG(nn.Module):
         self._walk(x, keep)
         return out
 
+    # ---- the pass on pre-split planes (see _P2Engine)
+    def _p2_engine(self, x):
+        """The engine for inputs shaped like ``x``, or None where the p2 kernels do not cover the stack / geometry."""
+        if not (_p2_switch["on"] and x.is_cuda and x.dim() == 4 and ops.conv_precision() == "h2"):
+            return None
+        cache = self.__dict__.setdefault("_p2_engines", {})
+        key = (tuple(x.shape), x.device.index)
+        if key not in cache:
+            eng = None
+            prog = _P2Engine.build_program(list(self.vgg_layers._modules.items()), max(int(k) for k in self.target_layers),
+                                           self.target_layers)
+            if prog is not None and not any(p.requires_grad for p in self.vgg_layers.parameters()):
+                eng = _P2Engine(prog, x.shape[0], x.shape[2], x.shape[3], x.device)
+                if eng.shapes() is None:
+                    eng = None
+            cache[key] = eng
+        return cache[key]
+
+    def _tap_weights(self):
+        names = ["input"] + [self.target_layers[k] for k in sorted(self.target_layers, key=int)]
+        return dict(zip(names, (float(w) for w in self.loss_weights)))
+
+    def features_for_loss(self, x):
+        """What ``loss_terms`` / ``lib.losses.vgg_loss`` need of a TARGET image: on the p2 path the taps' planes (a
+        ``_P2Target``; valid until the next call on this module), else ``forward(x)``."""
+        eng = self._p2_engine(x)
+        if eng is None or torch.is_grad_enabled():
+            return self.forward(x)
+        xp = ops.VggPreprocess.apply(x)
+        y0 = eng.program[0].fused(xp, out_act=ops.ACT_RELU)
+        taps, _ = eng.forward("t", y0)
+        out = _P2Target({"input": xp})
+        out.update({k: v.buf for k, v in taps.items()})
+        out.planes = taps
+        eng.generation += 1
+        out.generation = eng.generation
+        out.engine = eng
+        return out
+
     def loss_terms(self, pred, target_features):
         """``{tap: w_tap * mean|target_tap - pred_tap|}`` of lib/losses.py:81-119 in ONE pass over ``pred``: each term is
         formed when its tap is computed and the next layer reads the alias ``ops.L1MeanThrough`` hands back, so a tap's
@@ -168,6 +432,18 @@ class PerceptualVGG(nn.Module):
         weights = dict(zip(["input"] + [self.target_layers[k] for k in sorted(self.target_layers, key=int)],
                            self.loss_weights))
         losses = {}
+        if isinstance(target_features, _P2Target):
+            eng = target_features.engine
+            if target_features.generation != eng.generation:
+                raise RuntimeError("loss_terms: these target features were overwritten by a later features_for_loss() call")
+            xp = ops.VggPreprocess.apply(pred)
+            losses["input"], xp_alias = ops.L1MeanThrough.apply(target_features["input"], xp, float(weights["input"]))
+            ops.carry_amax_tag(xp, xp_alias)
+            y0 = eng.program[0].fused(xp_alias, out_act=ops.ACT_RELU)
+            names = tuple(st[2] for st in eng.program[1] if st[0] == "conv" and st[2] is not None)
+            terms = P2VggLoss.apply(y0, eng, target_features, self._tap_weights(), names)
+            losses.update(dict(zip(names, terms)))
+            return losses
 
         def term(name, t):
             losses[name], alias = ops.L1MeanThrough.apply(target_features[name], t, float(weights[name]))

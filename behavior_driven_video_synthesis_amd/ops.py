@@ -205,7 +205,7 @@ def _scheme() -> int:
 
 
 _wants_split_cache = {}
-_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2, "blk_force_nt": 3, "parity_launches": 4, "blk_ws": 5, "wgrad_rowsplit": 6, "s2_fwd_f32": 7}
+_TUNING_KEYS = {"split_force_nt": 0, "tiled_force_nt": 1, "force_small": 2, "blk_force_nt": 3, "parity_launches": 4, "blk_ws": 5, "wgrad_rowsplit": 6, "s2_fwd_f32": 7, "p2_form": 8}
 
 
 def set_tuning(key: str, value: int):
@@ -1802,3 +1802,136 @@ def adam_step_flat_dev(param, grad, exp_avg, exp_avg_sq, lr_dev, beta1, beta2, e
         raise RuntimeError("adam_step_flat_dev: lr as a float64 and step as an int64 device tensor")
     _call("vunet_adam_step_dev", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(lr_dev),
           float(beta1), float(beta2), float(eps), float(weight_decay), _p(step_dev), float(grad_scale), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# "p2": pre-split activations (csrc/conv_p2.hip).  A planes tensor of logical shape [N, C, H, W] is an fp16 tensor
+# [2, N, C / 8, H + 2, W + 2, 8] (hi / lo planes, channel blocks of 8, one-pixel zero border) plus 128 int32 of meta
+# (scale exponent, slots for the maximum).  The buffers are zero-filled ONCE and reused: no kernel writes the border.
+# ------------------------------------------------------------------------------------------------
+P2_META_INTS = 128
+
+
+class P2Desc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("N", "C", "H", "W", "M", "relu")]
+
+
+class Planes:
+    """A planes tensor: ``buf`` (fp16, zero border), ``meta`` (int32[128]), the logical ``shape`` (N, C, H, W)."""
+
+    __slots__ = ("buf", "meta", "shape")
+
+    def __init__(self, shape, device, meta=None):
+        n, c, h, w = shape
+        assert c % 8 == 0
+        self.shape = (int(n), int(c), int(h), int(w))
+        self.buf = torch.zeros(2, n, c // 8, h + 2, w + 2, 8, device=device, dtype=torch.float16)
+        self.meta = meta if meta is not None else torch.zeros(P2_META_INTS, device=device, dtype=torch.int32)
+
+    def to_nchw(self):
+        n, c, h, w = self.shape
+        y = torch.empty(n, c, h, w, device=self.buf.device, dtype=torch.float32)
+        _call("vunet_p2_to_nchw", _p(self.buf), _p(self.meta), _p(y), n, c, h, w, _stream())
+        return y
+
+
+def p2_from_nchw(x, out: Planes = None, relu: bool = False, amax=None, zero_meta: bool = True) -> Planes:
+    """fp32 NCHW -> planes (the scale from the tensor's true maximum: its amax tag, or a pass over it).  ``zero_meta`` False:
+    the caller has zeroed ``out.meta`` already (one fill for all the metas of a pass)."""
+    _dev(x)
+    x = _c(x)
+    if out is None:
+        out = Planes(tuple(x.shape), x.device)
+    if amax is None:
+        amax = _tagged_amax(x)
+    if amax is None:
+        amax = absmax_partials(x)
+    n, c, h, w = x.shape
+    if zero_meta:
+        out.meta.zero_()
+    _call("vunet_p2_from_nchw", _p(x), _p(amax), min(int(amax.numel()), 512), int(relu), _p(out.buf), _p(out.meta), n, c, h, w,
+          _stream())
+    return out
+
+
+class P2Weights:
+    """Weight image + constants of one frozen 3x3 layer for vunet_p2_conv (forward and, on demand, data gradient)."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+        self.cout, self.cin = int(weight.shape[0]), int(weight.shape[1])
+        self._img = {}
+
+    def image(self, dgrad: bool):
+        rec = self._img.get(dgrad)
+        stamp = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else self.bias._version)
+        if rec is None or rec[0] != stamp:
+            nbytes = _lib.lib().vunet_p2_weight_image_bytes(self.cout, self.cin, int(dgrad))
+            if nbytes <= 0:
+                raise RuntimeError("p2 weight image: geometry not covered")
+            dev = self.weight.device
+            img = torch.empty(nbytes // 2, device=dev, dtype=torch.float16)
+            wk = torch.empty(4, device=dev, dtype=torch.float32)
+            work = torch.empty(2 * max(self.cout, self.cin), device=dev, dtype=torch.float32)
+            _call("vunet_p2_pack_weights", _p(_c(self.weight.detach())), _p(None if self.bias is None else _c(self.bias.detach())),
+                  self.cout, self.cin, int(dgrad), _p(img), _p(wk), _p(work), _stream())
+            rec = self._img[dgrad] = (stamp, img, wk)
+        return rec[1], rec[2]
+
+
+def p2_conv_supported(n, c, h, w, m) -> bool:
+    d = P2Desc(n, c, h, w, m, 0)
+    return _lib.lib().vunet_p2_conv_supported(ctypes.byref(d)) == 1
+
+
+def p2_conv(x: Planes, wts: P2Weights, out: Planes, relu: bool = True, dgrad: bool = False, mask: Planes = None):
+    """out = relu(conv(x) + bias) (forward) or conv^T(x) [* (mask != 0)] (data gradient).  ``out.meta``'s maximum slots
+    must be zero (the caller zeroes the metas of a pass in one fill)."""
+    n, c, h, w = x.shape
+    m = wts.cin if dgrad else wts.cout
+    assert c == (wts.cout if dgrad else wts.cin) and out.shape == (n, m, h, w)
+    img, wk = wts.image(dgrad)
+    d = P2Desc(n, c, h, w, m, int(relu and not dgrad))
+    _call("vunet_p2_conv", ctypes.byref(d), _p(x.buf), _p(x.meta), _p(img), _p(wk),
+          _p(None if dgrad or wts.bias is None else wts.bias), _p(None if mask is None else mask.buf), _p(out.buf), _p(out.meta),
+          _stream())
+    return out
+
+
+def p2_l1_fwd(t: Planes, p: Planes, weight: float):
+    """weight * mean |t - p| of two planes tensors -> fp32 [1] (vunet_p2_l1_fwd)."""
+    n, c, h, w = p.shape
+    assert t.shape == p.shape
+    out = _zero_scalar(p.buf.device)
+    partial = torch.empty(1024, device=p.buf.device, dtype=torch.float32)
+    _call("vunet_p2_l1_fwd", _p(t.buf), _p(t.meta), _p(p.buf), _p(p.meta), _p(partial), _p(out), float(weight), n, c, h, w, _stream())
+    return out
+
+
+def p2_pool_fwd(p: Planes, out: Planes, t: Planes = None, weight: float = 0.0):
+    """out = maxpool2x2(p); with ``t`` also the L1 term weight * mean |t - p| from the same pass -> fp32 [1] (else None)."""
+    n, c, h, w = p.shape
+    assert out.shape == (n, c, h // 2, w // 2)
+    loss = partial = None
+    if t is not None:
+        loss = _zero_scalar(p.buf.device)
+        partial = torch.empty(1024, device=p.buf.device, dtype=torch.float32)
+    _call("vunet_p2_pool_fwd", _p(None if t is None else t.buf), _p(None if t is None else t.meta), _p(p.buf), _p(p.meta), _p(partial),
+          _p(loss), float(weight), _p(out.buf), _p(out.meta), n, c, h, w, _stream())
+    return loss
+
+
+def p2_l1_bwd(t: Planes, p: Planes, add, g: Planes, gscale: float, gout):
+    """g = [add] + gscale * gout[0] * sign(p - t), zeroed where p == 0 (vunet_p2_l1_bwd)."""
+    n, c, h, w = p.shape
+    _call("vunet_p2_l1_bwd", _p(t.buf), _p(t.meta), _p(p.buf), _p(p.meta), _p(None if add is None else add.buf),
+          _p(None if add is None else add.meta), _p(g.buf), _p(g.meta), float(gscale), _p(gout), n, c, h, w, _stream())
+    return g
+
+
+def p2_pool_bwd(p: Planes, dy: Planes, g: Planes, t: Planes = None, gscale: float = 0.0, gout=None):
+    """g = route(dy) [+ gscale * gout[0] * sign(p - t)], zeroed where p == 0 (vunet_p2_pool_bwd)."""
+    n, c, h, w = p.shape
+    _call("vunet_p2_pool_bwd", _p(None if t is None else t.buf), _p(None if t is None else t.meta), _p(p.buf), _p(p.meta), _p(dy.buf),
+          _p(dy.meta), _p(g.buf), _p(g.meta), float(gscale), _p(gout), n, c, h, w, _stream())
+    return g

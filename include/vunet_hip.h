@@ -408,6 +408,8 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *                              for the stride-1 direct layers; 0 = the stride-2 layers on maps >= 8 wide
  *   VUNET_TUNE_PARITY_LAUNCHES 1: the stride-2 data gradient of the fp16 scheme as four launches, one per output parity,
  *                              instead of the fused kernel (A/B timing, tests)
+ *   VUNET_TUNE_P2_FORM         vunet_p2_conv: 1 = always the four-wave / 64-channel workgroup, 2 = the eight-wave / 128-channel
+ *                              one wherever the channel count allows; 0 = by how many workgroups the problem has
  * Returns VUNET_ERR_ARG for an unknown key. */
 #define VUNET_TUNE_SPLIT_FORCE_NT 0
 #define VUNET_TUNE_TILED_FORCE_NT 1
@@ -417,6 +419,8 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
 #define VUNET_TUNE_BLK_WS 5
 #define VUNET_TUNE_WGRAD_ROWSPLIT 6
 #define VUNET_TUNE_S2_FWD_F32 7
+#define VUNET_TUNE_P2_FORM 8
+#define VUNET_TUNE_COUNT 9
 int vunet_set_tuning(int32_t key, int32_t value);
 
 /* Dropout keep-mask of the conv prologue, materialised (parity tests / debugging only) */
@@ -511,6 +515,62 @@ int vunet_set_schedule(double* lr_dev, double lr, float* imax_dev, float imax, i
  * what autograd does with n - 1 aten::add_ launches plus the next layer's vunet_absmax_partials pass: the gradients of a tensor
  * with several readers (the bottleneck's hidden state feeds mu, log-sigma and the next block: reference models/vunets.py:560-590). */
 int vunet_sum_amax(const float* const* srcs, int32_t n, float* out, float* amax_out, int64_t numel, void* stream);
+
+/* ---- "p2": the frozen VGG19 stack of the perceptual loss on PRE-SPLIT activations (ABI 9; csrc/conv_p2.hip).  Replaces, for
+ * models/imagenet_pretrained.py:42-61 run twice per step by lib/losses.py:81-119, the per-workgroup operand conversion of
+ * vunet_conv2d's fp16 scheme by ONE conversion per tensor, done by the kernel that produces it.
+ *
+ * A planes tensor ("P2") of logical shape [N][C][H][W], C % 8 == 0:
+ *     fp16  [2 planes][N][C / 8][H + 2][W + 2][8]     plane 0 = hi, plane 1 = lo:  2^e x = hi + lo / 2^11
+ *     int32 meta[128]:  [0] e;  [16 .. 79] 64 slots, the largest hold an upper bound of max |x| (fp32 bit patterns)
+ * PRECONDITIONS (the caller's): the buffer is zero-filled once -- no kernel writes the one-pixel border, every consumer
+ * reads it as the convolution's zero padding; meta[16 .. 79] of an OUTPUT are zero before its producer is launched
+ * (the producers atomicMax into them).  Buffers and metas may be reused from step to step.
+ * The scale of an output is derived in its producer from a bound (max row sum of |w| x the input's maximum + max |shift|),
+ * see csrc/conv_p2.hip for why a loose bound costs no accuracy. */
+typedef struct vunet_p2_desc {
+  int32_t N, C, H, W;   /* input planes: C % 32 == 0; H % 8 == 0; W == 16 or W % 32 == 0 */
+  int32_t M;            /* output channels, M % 64 == 0; the output planes are [N][M][H][W] */
+  int32_t relu;         /* 1: ReLU on the output (the forward layers of the stack) */
+} vunet_p2_desc;
+int vunet_p2_conv_supported(const vunet_p2_desc* d);   /* 1 / 0 */
+/* y = [relu]( conv3x3_pad1(x; image) + shift ), or with `mask` (planes shaped like y: the forward activation that feeds the
+ * layer below) the data-gradient form  y = conv3x3(x; dgrad image) * [mask != 0].  image / wk from vunet_p2_pack_weights. */
+int vunet_p2_conv(const vunet_p2_desc* d, const void* x, const int32_t* xmeta, const void* w_image, const float* wk,
+                  const float* shift, const void* mask, void* y, int32_t* ymeta, void* stream);
+/* Weight image of a 3x3 layer, w [Cout][Cin][3][3] fp32.  dgrad = 0: rows Cout, sums over Cin (Cout % 16 == 0, Cin % 32 == 0);
+ * dgrad = 1: rows Cin, sums over Cout, taps mirrored.  wk[4]: max row sum of |w| (x 1 + 1e-6), max |shift| (dgrad: 0), the
+ * weights' scale exponent, max |w|.  workspace: 2 * rows floats.  vunet_p2_weight_image_bytes: bytes of the image, 0 if the
+ * geometry is not covered. */
+int vunet_p2_weight_image_bytes(int32_t Cout, int32_t Cin, int32_t dgrad);
+int vunet_p2_pack_weights(const float* w, const float* shift, int32_t Cout, int32_t Cin, int32_t dgrad, void* image, float* wk,
+                          float* workspace, void* stream);
+/* fp32 NCHW <-> planes.  from_nchw: amax = n_amax partial maxima of |x| (vunet_absmax_partials / a producer's amax_out): the
+ * scale comes from the true maximum; relu = 1 applies max(x, 0) on the way. */
+int vunet_p2_from_nchw(const float* x, const float* amax, int32_t n_amax, int32_t relu, void* y, int32_t* ymeta, int32_t N,
+                       int32_t C, int32_t H, int32_t W, void* stream);
+int vunet_p2_to_nchw(const void* x, const int32_t* xmeta, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+
+/* Pointwise kernels of the p2 pass (csrc/planes.hip), all on planes tensors [N][C][H][W] with their metas:
+ *   vunet_p2_l1_fwd    out[0] += weight * mean |t - p|  (lib/losses.py:98-102); partial: 1024 floats of workspace
+ *   vunet_p2_pool_fwd  y = maxpool2x2(p) (planes [N][C][H/2][W/2]; inherits p's scale and maximum); with t != NULL also the L1
+ *                      term of the tap that feeds the pool (relu1_2, relu2_2), from the same pass over p
+ *   vunet_p2_l1_bwd    g = [add] + c sign(p - t), zeroed where p == 0 (p is a ReLU output): the gradient w.r.t. the convolution
+ *                      output under the tap; c = gscale * gout[0] (gout: the loss term's upstream gradient, a device scalar, or
+ *                      NULL for 1); add (optional): the gradient arriving from the layer above, planes shaped like p
+ *   vunet_p2_pool_bwd  g = route(dy) [+ c sign(p - t) with t != NULL], zeroed where p == 0: backward of the pool (first maximum in
+ *                      scan order, as ATen) fused with the ReLU backward and, for relu1_2 / relu2_2, the tap's step
+ * Output metas: maximum slots zeroed by the caller beforehand; the scale is derived from max|add| (max|dy|) + |c|. */
+int vunet_p2_l1_fwd(const void* t, const int32_t* tmeta, const void* p, const int32_t* pmeta, float* partial, float* out,
+                    float weight, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int vunet_p2_pool_fwd(const void* t, const int32_t* tmeta, const void* p, const int32_t* pmeta, float* partial, float* out,
+                      float weight, void* y, int32_t* ymeta, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int vunet_p2_l1_bwd(const void* t, const int32_t* tmeta, const void* p, const int32_t* pmeta, const void* add,
+                    const int32_t* addmeta, void* g, int32_t* gmeta, float gscale, const float* gout, int32_t N, int32_t C,
+                    int32_t H, int32_t W, void* stream);
+int vunet_p2_pool_bwd(const void* t, const int32_t* tmeta, const void* p, const int32_t* pmeta, const void* dy,
+                      const int32_t* dymeta, void* g, int32_t* gmeta, float gscale, const float* gout, int32_t N, int32_t C,
+                      int32_t H, int32_t W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,112 @@
+"""-m gpu: the pre-split ("p2") convolution path of the VGG19 stack (csrc/conv_p2.hip) through the C ABI against float64:
+the planes round trip, the forward and data-gradient kernels in both workgroup forms and both tile widths, the ReLU mask of
+the data gradient, and the claim that a scale derived from a LOOSE bound costs no accuracy."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from behavior_driven_video_synthesis_amd import ops
+    return ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def test_planes_round_trip_and_zero_border():
+    ops = _ops()
+    x = _rand((2, 16, 8, 32), 1, 3.0).cuda()
+    p = ops.p2_from_nchw(x)
+    y = p.to_nchw()
+    assert float((y - x).abs().max()) <= 2.0 ** -22 * float(x.abs().max())
+    b = p.buf
+    assert float(b[:, :, :, 0].abs().max()) == 0 and float(b[:, :, :, -1].abs().max()) == 0
+    assert float(b[:, :, :, :, 0].abs().max()) == 0 and float(b[:, :, :, :, -1].abs().max()) == 0
+    # the scale puts the maximum into [2^13, 2^14)
+    hi = b[0].float().abs().max()
+    assert 2.0 ** 13 <= float(hi) < 2.0 ** 14
+    e = int(p.meta[0])
+    assert abs(float(hi) / 2.0 ** e - float(x.abs().max())) <= 2.0 ** -10 * float(x.abs().max())
+    # relu on the way
+    pr = ops.p2_from_nchw(x, relu=True)
+    assert float((pr.to_nchw() - x.clamp_min(0)).abs().max()) <= 2.0 ** -22 * float(x.abs().max())
+
+
+CASES = [  # (N, C, H, W, M, forced workgroup form)
+    (1, 32, 8, 32, 64, 1), (2, 64, 16, 32, 64, 1), (1, 64, 8, 64, 128, 2), (2, 128, 16, 32, 128, 2), (1, 96, 8, 32, 192, 1),
+    (2, 64, 16, 16, 128, 2), (3, 32, 8, 16, 64, 1), (1, 256, 8, 32, 256, 0), (1, 128, 24, 96, 64, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_vs_float64(case):
+    ops = _ops()
+    n, c, h, w, m, form = case
+    x = _rand((n, c, h, w), 11, 2.0).clamp_min(0)          # a ReLU output, like every input of the stack
+    wt = _rand((m, c, 3, 3), 12, (2.0 / (9 * c)) ** 0.5)
+    bias = _rand((m,), 13, 0.1)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1))
+    ops.set_tuning("p2_form", form)
+    px = ops.p2_from_nchw(x.cuda())
+    out = ops.Planes((n, m, h, w), "cuda")
+    ops.p2_conv(px, ops.P2Weights(wt.cuda(), bias.cuda()), out)
+    y = out.to_nchw().double().cpu()
+    scale = float(ref.abs().max())
+    err = float((y - ref).abs().max())
+    assert err <= 3e-6 * scale, (case, err / scale)
+    # the published maximum is an upper bound of what was stored, and the scale exponent keeps every value below 2^14
+    amax = float(out.meta[16:80].view(torch.float32).max())
+    assert amax >= float(y.abs().max()) * (1 - 1e-6) and amax <= scale * (1 + 1e-5)
+    assert float(out.buf[0].float().abs().max()) < 2.0 ** 14
+    assert float(out.buf[:, :, :, 0].abs().max()) == 0 and float(out.buf[:, :, :, :, -1].abs().max()) == 0   # border untouched
+
+
+@pytest.mark.parametrize("case", [(2, 64, 16, 32, 64, 1), (1, 128, 8, 64, 128, 2), (2, 128, 16, 16, 64, 0), (1, 64, 8, 32, 128, 0)])
+def test_data_gradient_with_relu_mask_vs_float64(case):
+    ops = _ops()
+    n, cin, h, w, cout, form = case      # the layer maps cin -> cout; dy has cout channels, dx has cin
+    dy = _rand((n, cout, h, w), 21, 1e-3)
+    wt = _rand((cout, cin, 3, 3), 22, (2.0 / (9 * cin)) ** 0.5)
+    act = _rand((n, cin, h, w), 23).clamp_min(0)           # the forward activation that fed the layer (a ReLU output)
+    ref = torch.nn.functional.conv_transpose2d(dy.double(), wt.double(), padding=1) * (act > 0).double()
+    ops.set_tuning("p2_form", form)
+    pdy, pact = ops.p2_from_nchw(dy.cuda()), ops.p2_from_nchw(act.cuda())
+    out = ops.Planes((n, cin, h, w), "cuda")
+    ops.p2_conv(pdy, ops.P2Weights(wt.cuda(), None), out, dgrad=True, mask=pact)
+    y = out.to_nchw().double().cpu()
+    scale = float(ref.abs().max())
+    assert float((y - ref).abs().max()) <= 3e-6 * scale, case
+    assert float((y[(act == 0)]).abs().max()) == 0.0       # masked entries are exact zeros in both planes
+    # without the mask
+    out2 = ops.Planes((n, cin, h, w), "cuda")
+    ops.p2_conv(pdy, ops.P2Weights(wt.cuda(), None), out2, dgrad=True)
+    ref2 = torch.nn.functional.conv_transpose2d(dy.double(), wt.double(), padding=1)
+    assert float((out2.to_nchw().double().cpu() - ref2).abs().max()) <= 3e-6 * float(ref2.abs().max())
+
+
+def test_a_scale_from_a_loose_bound_costs_no_accuracy():
+    """The producer scales its output by a power of two derived from a BOUND of its maximum.  Here the input planes are
+    written with a scale 2^20 below the one the true maximum would give (their hi plane then peaks near 2^-7 instead of
+    2^13) and chained through two layers: the result stays within the same 3e-6 of the float64 convolution."""
+    ops = _ops()
+    n, c, h, w, m = 1, 64, 8, 32, 64
+    x = _rand((n, c, h, w), 31, 2.0).clamp_min(0)
+    w1, b1 = _rand((m, c, 3, 3), 32, (2.0 / (9 * c)) ** 0.5), _rand((m,), 33, 0.1)
+    w2, b2 = _rand((m, m, 3, 3), 34, (2.0 / (9 * m)) ** 0.5), _rand((m,), 35, 0.1)
+    r1 = torch.relu(torch.nn.functional.conv2d(x.double(), w1.double(), b1.double(), padding=1))
+    r2 = torch.relu(torch.nn.functional.conv2d(r1, w2.double(), b2.double(), padding=1))
+    fake = torch.full((512,), float(x.abs().max()) * 2.0 ** 20, device="cuda")
+    px = ops.p2_from_nchw(x.cuda(), amax=fake)
+    assert float(px.buf[0].float().abs().max()) < 2.0 ** -6
+    assert float((px.to_nchw().cpu() - x).abs().max()) <= 2.0 ** -22 * float(x.abs().max())     # still exact to fp32 resolution
+    o1, o2 = ops.Planes((n, m, h, w), "cuda"), ops.Planes((n, m, h, w), "cuda")
+    ops.p2_conv(px, ops.P2Weights(w1.cuda(), b1.cuda()), o1)
+    ops.p2_conv(o1, ops.P2Weights(w2.cuda(), b2.cuda()), o2)
+    # (the first layer's bound inherits the inflated maximum: its output planes sit 2^20 low as well)
+    assert float(o1.buf[0].float().abs().max()) < 2.0 ** -2
+    assert float((o1.to_nchw().double().cpu() - r1).abs().max()) <= 3e-6 * float(r1.abs().max())
+    assert float((o2.to_nchw().double().cpu() - r2).abs().max()) <= 3e-6 * float(r2.abs().max())
