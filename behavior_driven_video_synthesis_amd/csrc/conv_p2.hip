@@ -38,6 +38,8 @@
 //             halves (v_permlane16_swap) so that a lane holds the 8 channels of one 16-byte unit; data gradient: the unit is
 //             masked by [forward activation != 0] read as two 16-byte units of the forward planes (the ReLU backward of the
 //             layer below); max |y| published into the output's meta
+#include <stdio.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -329,6 +331,242 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_p2_kernel(const
   }
 }
 
+// ---- the eight-wave form with its two wave groups in ANTIPHASE.
+// In conv_p2_kernel every wave of a workgroup reads its fragments right after the tap's barrier and multiplies afterwards:
+// eight waves want 128 KB from the LDS at once (1024 cycles at 128 B / clock), the matrix pipes wait, then the LDS idles
+// while 2 x 768 cycles of MFMAs run -- measured: the phases ADD (0.45 of the fp16 peak: 63 % pipe occupancy at the clock
+// the chip holds).  Here waves 0-3 (one per SIMD) and waves 4-7 (their partners on the same SIMDs) run half a step apart:
+//      group 0:  R(t) | M(t) | R(t+1) | M(t+1) | ...          R = the tap's 16 ds_read_b128 (+ issuing LDS-DMA),
+//      group 1:   -   | R(t) | M(t)   | R(t+1) | ...          M = its 48 MFMAs;  "|" = s_barrier of all eight waves
+// so that in every segment one wave of each SIMD multiplies while its partner reads.  One register set of fragments is
+// enough (a wave's R segment starts after its M segment has ended).  Group 0 copies the weight slabs (slab t+1 at the start
+// of R(t): its buffer was last read by group 1 one segment earlier, reads retired before that barrier), group 1 the next
+// chunk's activation pieces; each group retires its own transfers at the end of its M segment, i.e. a full two segments
+// after issuing them and one barrier before anybody reads them.
+template <int CT>
+__global__ __launch_bounds__(512, 1) void conv_p2a_kernel(const P2Args a) {
+  constexpr int NW = 8, MW = 128;
+  constexpr int RT = 8, IH = RT + 2, CW = CT + 2, XPIX = IH * CW, XU = 8 * XPIX;
+  constexpr int NXI = (XU + 63) / 64, XS = NXI * 64;
+  constexpr int NXG = (NXI + 3) / 4;               // x pieces per wave of group 1 and chunk
+  constexpr int XPT = 2, NXT = (NXG + XPT - 1) / XPT;   // ... XPT per tap over the chunk's first NXT taps
+  constexpr int WU = MW * 8;
+  constexpr int PTR = CT / 16, NPT = 2 * PTR;
+  static_assert(NXT <= 8, "the next chunk's pieces must be visible before its first tap");
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  uint4* const xL = smem;                // [2][XS]
+  uint4* const wL = smem + 2 * XS;       // [2][WU]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mg = wave >> 2, rg = wave & 3;          // mg is also the wave's phase group
+  const int px = lane & 15, cg = lane >> 4;
+  const int Hp = a.H + 2, Wp = a.W + 2, CB = a.C >> 3, MB = a.M >> 3;
+
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblocks = a.M / MW;
+  const int mb = bid % mblocks;
+  int t = bid / mblocks;
+  const int tiles_w = a.W / CT, tiles_h = a.H / RT;
+  const int tx = t % tiles_w;
+  t /= tiles_w;
+  const int ty = t % tiles_h;
+  const int n = t / tiles_h;
+  const int row0 = ty * RT, col0 = tx * CT, m0 = mb * MW;
+
+  uint32_t xoff[NXG];                               // piece rg + 4 i of the tile (group 1; group 0 uses them in the prologue too)
+#pragma unroll
+  for (int i = 0; i < NXG; ++i) {
+    int j = rg + 4 * i;
+    if (j >= NXI) j = NXI - 1;
+    int u = 64 * j + lane;
+    if (u >= XU) u = XU - 1;
+    const int p = u / (4 * XPIX);
+    int rem = u - p * 4 * XPIX;
+    const int kq = rem / XPIX;
+    rem -= kq * XPIX;
+    const int r = rem / CW, c = rem - r * CW;
+    xoff[i] = (uint32_t)((((size_t)p * a.N * CB + kq) * Hp + (row0 + r)) * Wp + col0 + c) * 16u;
+  }
+  const uint32_t xL_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)xL;
+  const uint32_t wL_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)wL;
+  const char* const xsrc0 = reinterpret_cast<const char*>(a.x) + (size_t)n * CB * Hp * Wp * 16;
+  const size_t xchunk = (size_t)4 * Hp * Wp * 16;
+  const char* const wsrc0 = reinterpret_cast<const char*>(a.w) + (size_t)mb * (MW / 16) * 128 * 16;
+  const size_t wslab = (size_t)(a.M / 16) * 128 * 16;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+
+  auto issue_x = [&](int ch, int i) {   // this wave's piece i of chunk ch (waves with the same rg copy the same piece)
+    int j = rg + 4 * i;
+    if (j >= NXI) j = NXI - 1;
+    p2_dma(xoff[i], p2_uniform_ptr(xsrc0 + (size_t)ch * xchunk), xL_addr + (uint32_t)((ch & 1) * XS + 64 * j) * 16u);
+  };
+  auto issue_w = [&](int g, int buf) {  // this wave's quarter of slab g (four wave-instructions)
+    const char* src = wsrc0 + (size_t)g * wslab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int part = rg * 4 + i;
+      p2_dma(lane16, p2_uniform_ptr(src + (size_t)part * 1024), wL_addr + (uint32_t)(buf * WU + part * 64) * 16u);
+    }
+  };
+
+  // ---- prologue: group 0 requests slab 0, group 1 the first chunk's tile; the scales are worked out behind the transfers
+  if (mg == 0) issue_w(0, 0);
+  else {
+#pragma unroll
+    for (int i = 0; i < NXG; ++i) issue_x(0, i);
+  }
+  float descale, descale2, sy;
+  {
+    const int ex = a.xmeta[0];
+    const float amax_x = p2_meta_amax(a.xmeta, lane);
+    const int ew = (int)a.wk[2];
+    h2_pow2_pair(-(ex + ew), descale, descale2);
+    const float bound = a.wk[0] * amax_x + a.wk[1];
+    const int ey = h2_scale_exp(bound);
+    sy = h2_pow2(ey);
+    if (blockIdx.x == 0 && tid == 0) a.ymeta[0] = ey;
+  }
+  f32x4 acc[4][NPT], acx[4][NPT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int q = 0; q < NPT; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][q][r] = acx[mt][q][r] = 0.f;
+  p2_dma_wait<0>();
+  __syncthreads();
+  if (mg == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one segment behind
+
+  const int nch = a.C >> 5;
+  const uint4* const wA0 = wL + (mg * 4) * 128 + lane;
+  const uint4* const xB0 = xL + cg * XPIX + px + (2 * rg) * CW;
+
+  auto chunk = [&](int ch, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
+    const uint4* const xB = xB0 + (ch & 1) * XS;
+    const int wpar = (ch * 9) & 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const int g = ch * 9 + tap;
+      const int buf = wpar ^ (tap & 1);
+      const bool more_w = !(LAST && tap == 8);
+      // ---- R segment: request what the NEXT steps need, then read this tap's fragments
+      if (mg == 0) {
+        if (more_w) issue_w(g + 1, buf ^ 1);
+      } else if (!LAST && tap < NXT) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+          if (tap * XPT + i < NXG) issue_x(ch + 1, tap * XPT + i);
+      }
+      const uint4* const wA = wA0 + buf * WU;
+      P2Unit av[2][4], bv[2][NPT];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) av[p][mt].u = wA[(mt * 2 + p) * 64];
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) bv[p][q].u = xB[p * 4 * XPIX + (q / PTR + kh) * CW + (q % PTR) * 16 + kw];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are retired BEFORE the barrier: the partner group may refill
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M segment
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < NPT; ++q)
+          acx[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[1][mt].b, bv[0][q].b, acx[mt][q], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < NPT; ++q)
+          acx[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[0][mt].b, bv[1][q].b, acx[mt][q], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < NPT; ++q)
+          acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[0][mt].b, bv[0][q].b, acc[mt][q], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      p2_dma_wait<0>();                                     // this wave's transfers of the R segment: landed
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int ch = 0; ch + 1 < nch; ++ch) chunk(ch, std::false_type{});
+  chunk(nch - 1, std::true_type{});
+  if (mg == 0) __builtin_amdgcn_s_barrier();       // (both groups pass the same number of barriers)
+
+  const bool relu = a.relu != 0;
+  const size_t plane = (size_t)a.N * MB * Hp * Wp;
+  float ymax = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int co = m0 + 64 * mg + 16 * mt + 4 * cg;
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.shift) {
+      const float4 s4 = *reinterpret_cast<const float4*>(a.shift + co);
+      sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+    }
+#pragma unroll
+    for (int qp = 0; qp < NPT; qp += 2) {
+      uint32_t hh[2][2], ll[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float c = (acc[mt][qp + s][r] + acx[mt][qp + s][r] * (1.f / 2048.f)) * descale * descale2 + sh[r];
+          c = (relu && !(c > 0.f)) ? 0.f : c;
+          ymax = fmaxf(ymax, fabsf(c));
+          v[r] = c * sy;
+        }
+        h2_split2(v[0], v[1], hh[s][0], ll[s][0]);
+        h2_split2(v[2], v[3], hh[s][1], ll[s][1]);
+      }
+      p2_swap16(hh[0][0], hh[1][0]);
+      p2_swap16(hh[0][1], hh[1][1]);
+      p2_swap16(ll[0][0], ll[1][0]);
+      p2_swap16(ll[0][1], ll[1][1]);
+      uint4 uh = make_uint4(hh[0][0], hh[0][1], hh[1][0], hh[1][1]);
+      uint4 ul = make_uint4(ll[0][0], ll[0][1], ll[1][0], ll[1][1]);
+      const int q = qp + (cg & 1);
+      const int orow = row0 + 2 * rg + q / PTR, ocol = col0 + (q % PTR) * 16 + px;
+      const int cb = ((m0 + 64 * mg + 16 * mt) >> 3) + (cg >> 1);
+      const size_t o = (((size_t)n * MB + cb) * Hp + (orow + 1)) * Wp + (ocol + 1);
+      if (a.mask) {
+        const uint4 mh = a.mask[o], ml = a.mask[plane + o];
+        const uint32_t k0 = p2_nonzero_halves((mh.x | ml.x) & 0x7FFF7FFFu), k1 = p2_nonzero_halves((mh.y | ml.y) & 0x7FFF7FFFu);
+        const uint32_t k2 = p2_nonzero_halves((mh.z | ml.z) & 0x7FFF7FFFu), k3 = p2_nonzero_halves((mh.w | ml.w) & 0x7FFF7FFFu);
+        uh.x &= k0; uh.y &= k1; uh.z &= k2; uh.w &= k3;
+        ul.x &= k0; ul.y &= k1; ul.z &= k2; ul.w &= k3;
+      }
+      a.y[o] = uh;
+      a.y[plane + o] = ul;
+    }
+  }
+  {
+    const float m_ = wave_max(ymax);
+    if (lane == 0)
+      atomicMax(reinterpret_cast<unsigned*>(a.ymeta) + P2_AMAX0 + ((blockIdx.x * NW + wave) & (P2_NSLOT - 1)), __float_as_uint(m_));
+  }
+}
+
+template <int CT>
+int p2a_launch(const P2Args& a, hipStream_t st) {
+  constexpr int XU = 8 * 10 * (CT + 2), XS = (XU + 63) / 64 * 64, WU = 128 * 8;
+  constexpr size_t lds = (size_t)(2 * XS + 2 * WU) * 16;
+  const int blocks = a.N * (a.H / 8) * (a.W / CT) * (a.M / 128);
+  auto kern = conv_p2a_kernel<CT>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VUNET_ERR_LAUNCH;
+  VUNET_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds, st, a);
+  return vunet_check_launch();
+}
+
 template <int NW, int CT, int XBUF>
 int p2_launch(const P2Args& a, hipStream_t st) {
   constexpr int XU = 8 * 10 * (CT + 2), XS = (XU + 63) / 64 * 64, WU = 16 * NW * 8;
@@ -353,6 +591,15 @@ static bool p2_shape_ok(const vunet_p2_desc* d) {
 
 extern "C" int vunet_p2_conv_supported(const vunet_p2_desc* d) { return p2_shape_ok(d) ? 1 : 0; }
 
+// waves per workgroup: eight / 128 channels (x double-buffered, one workgroup per CU) where that still fills the chip;
+// otherwise four / 64 channels (two workgroups per CU, x single-buffered).  VUNET_TUNE_P2_FORM: 1 = four, 2 = eight (tests, A/B)
+static int p2_form(const vunet_p2_desc* d) {
+  const long px_tiles = (long)d->N * (d->H / 8) * (d->W / (d->W == 16 ? 16 : 32));
+  const int force = g_vunet_tune[VUNET_TUNE_P2_FORM];
+  const bool wide = d->M % 128 == 0 && (force == 2 || force == 3 || (force != 1 && px_tiles * (d->M / 128) >= 256));
+  return wide ? 8 : 4;
+}
+
 extern "C" int vunet_p2_conv(const vunet_p2_desc* d, const void* x, const int32_t* xmeta, const void* w_image, const float* wk,
                              const float* shift, const void* mask, void* y, int32_t* ymeta, void* stream) {
   if (!d || !x || !xmeta || !w_image || !wk || !y || !ymeta) return VUNET_ERR_ARG;
@@ -363,13 +610,20 @@ extern "C" int vunet_p2_conv(const vunet_p2_desc* d, const void* x, const int32_
   a.y = (uint4*)y; a.ymeta = ymeta;
   a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.relu = d->relu;
   hipStream_t st = (hipStream_t)stream;
-  const long px_tiles = (long)d->N * (d->H / 8) * (d->W / (d->W == 16 ? 16 : 32));
-  const int force = g_vunet_tune[VUNET_TUNE_P2_FORM];   // tests / A-B: 1 = four waves, 2 = eight waves
-  // eight waves / 128 channels per workgroup (x double-buffered, one workgroup per CU) where that still fills the chip;
-  // otherwise four waves / 64 channels (two workgroups per CU, x single-buffered)
-  const bool wide = force == 2 || (force != 1 && d->M % 128 == 0 && px_tiles * (d->M / 128) >= 256);
-  if (d->W == 16) return wide && d->M % 128 == 0 ? p2_launch<8, 16, 2>(a, st) : p2_launch<4, 16, 1>(a, st);
-  return wide && d->M % 128 == 0 ? p2_launch<8, 32, 2>(a, st) : p2_launch<4, 32, 1>(a, st);
+  const int form = p2_form(d);
+  const bool lockstep = g_vunet_tune[VUNET_TUNE_P2_FORM] == 3;   // (A/B: the eight-wave form without the antiphase)
+  if (d->W == 16) return form == 8 ? (lockstep ? p2_launch<8, 16, 2>(a, st) : p2a_launch<16>(a, st)) : p2_launch<4, 16, 1>(a, st);
+  return form == 8 ? (lockstep ? p2_launch<8, 32, 2>(a, st) : p2a_launch<32>(a, st)) : p2_launch<4, 32, 1>(a, st);
+}
+
+// the kernel instantiation vunet_p2_conv launches for this problem, in rocprofv3's spelling (bench.py's roofline keys)
+extern "C" int vunet_p2_conv_variant(const vunet_p2_desc* d, char* name, int32_t len) {
+  if (!d || !name || len < 32) return VUNET_ERR_ARG;
+  if (!p2_shape_ok(d)) return VUNET_ERR_UNSUPPORTED;
+  const int form = p2_form(d);
+  if (form == 8 && g_vunet_tune[VUNET_TUNE_P2_FORM] != 3) snprintf(name, (size_t)len, "conv_p2a_kernel<%d>", d->W == 16 ? 16 : 32);
+  else snprintf(name, (size_t)len, "conv_p2_kernel<%d, %d, %d>", form, d->W == 16 ? 16 : 32, form == 8 ? 2 : 1);
+  return VUNET_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ weight image

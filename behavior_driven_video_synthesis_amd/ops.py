@@ -1892,9 +1892,16 @@ def p2_conv(x: Planes, wts: P2Weights, out: Planes, relu: bool = True, dgrad: bo
     assert c == (wts.cout if dgrad else wts.cin) and out.shape == (n, m, h, w)
     img, wk = wts.image(dgrad)
     d = P2Desc(n, c, h, w, m, int(relu and not dgrad))
-    _call("vunet_p2_conv", ctypes.byref(d), _p(x.buf), _p(x.meta), _p(img), _p(wk),
-          _p(None if dgrad or wts.bias is None else wts.bias), _p(None if mask is None else mask.buf), _p(out.buf), _p(out.meta),
-          _stream())
+    timer = _NO_TIMER
+    if _prof["on"]:
+        buf = ctypes.create_string_buffer(96)
+        _call("vunet_p2_conv_variant", ctypes.byref(d), buf, 96)
+        timer = _Timed(("conv_gather_dgrad" if dgrad else "conv_gather_fwd", n, c, 0, h, w, m, 3, 1, 0, buf.value.decode()),
+                       2.0 * n * h * w * c * m * 9)
+    with timer:
+        _call("vunet_p2_conv", ctypes.byref(d), _p(x.buf), _p(x.meta), _p(img), _p(wk),
+              _p(None if dgrad or wts.bias is None else wts.bias), _p(None if mask is None else mask.buf), _p(out.buf), _p(out.meta),
+              _stream())
     return out
 
 

@@ -50,8 +50,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
 X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
 FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
-PMC_TRAFFIC_RENDER = ["profiles/r04_pmc_traffic_render.json", "profiles/r03_pmc_traffic_render.json"]
-PMC_TRAFFIC = ["profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json",
+PMC_TRAFFIC_RENDER = ["profiles/r05_pmc_traffic_render.json", "profiles/r04_pmc_traffic_render.json", "profiles/r03_pmc_traffic_render.json"]
+PMC_TRAFFIC = ["profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json",
                "profiles/r01_pmc_traffic.json"]
 
 
@@ -212,13 +212,14 @@ def cpu_baseline(args, cfg, batch, cfg1, batch1):
 
 def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
     is_x6 = "x6" in dom
-    is_h2 = "h2" in dom
+    is_h2 = "h2" in dom or "conv_p2" in dom   # (p2: the same three-product arithmetic on pre-split planes)
     products = 3 if is_h2 else (X6_PRODUCTS if is_x6 else 1)
     peak = BF16_MFMA_PEAK_TFLOPS / products if (is_x6 or is_h2) else FP32_MFMA_PEAK_TFLOPS
     ach = kern[dom]["flop"] / (kern[dom]["ms"] * 1e-3) / 1e12
     r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
          "peak_basis": ("fp32-accurate split-fp16 kernel: dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 MFMAs per algorithmic MAC "
-                        "block (csrc/conv_h2_kernel.h); `achieved` counts ALGORITHMIC fp32 FLOPs" if is_h2 else
+                        "block (csrc/conv_h2_kernel.h; csrc/conv_p2.hip for the VGG19 stack on pre-split planes); `achieved` counts "
+                        "ALGORITHMIC fp32 FLOPs" if is_h2 else
                         "fp32-accurate split-bf16 kernel: dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic MAC "
                         "block (csrc/conv_x6_kernel.h); `achieved` counts ALGORITHMIC fp32 FLOPs" if is_x6 else
                         "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"),

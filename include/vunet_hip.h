@@ -409,7 +409,8 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *   VUNET_TUNE_PARITY_LAUNCHES 1: the stride-2 data gradient of the fp16 scheme as four launches, one per output parity,
  *                              instead of the fused kernel (A/B timing, tests)
  *   VUNET_TUNE_P2_FORM         vunet_p2_conv: 1 = always the four-wave / 64-channel workgroup, 2 = the eight-wave / 128-channel
- *                              one wherever the channel count allows; 0 = by how many workgroups the problem has
+ *                              one (wave groups in antiphase) wherever the channel count allows, 3 = that one with all waves in
+ *                              lockstep (A/B); 0 = by how many workgroups the problem has
  * Returns VUNET_ERR_ARG for an unknown key. */
 #define VUNET_TUNE_SPLIT_FORCE_NT 0
 #define VUNET_TUNE_TILED_FORCE_NT 1
@@ -534,6 +535,7 @@ typedef struct vunet_p2_desc {
   int32_t relu;         /* 1: ReLU on the output (the forward layers of the stack) */
 } vunet_p2_desc;
 int vunet_p2_conv_supported(const vunet_p2_desc* d);   /* 1 / 0 */
+int vunet_p2_conv_variant(const vunet_p2_desc* d, char* name, int32_t len);   /* kernel instantiation, rocprofv3 spelling */
 /* y = [relu]( conv3x3_pad1(x; image) + shift ), or with `mask` (planes shaped like y: the forward activation that feeds the
  * layer below) the data-gradient form  y = conv3x3(x; dgrad image) * [mask != 0].  image / wk from vunet_p2_pack_weights. */
 int vunet_p2_conv(const vunet_p2_desc* d, const void* x, const int32_t* xmeta, const void* w_image, const float* wk,

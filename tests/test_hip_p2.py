@@ -39,6 +39,8 @@ def test_planes_round_trip_and_zero_border():
 CASES = [  # (N, C, H, W, M, forced workgroup form)
     (1, 32, 8, 32, 64, 1), (2, 64, 16, 32, 64, 1), (1, 64, 8, 64, 128, 2), (2, 128, 16, 32, 128, 2), (1, 96, 8, 32, 192, 1),
     (2, 64, 16, 16, 128, 2), (3, 32, 8, 16, 64, 1), (1, 256, 8, 32, 256, 0), (1, 128, 24, 96, 64, 0),
+    # form 2: eight waves, the two wave groups in antiphase (conv_p2a_kernel); 3: the same tile in lockstep (conv_p2_kernel<8>)
+    (1, 64, 8, 64, 128, 3), (2, 96, 16, 16, 128, 3), (2, 288, 8, 32, 256, 2), (4, 32, 8, 32, 128, 2),
 ]
 
 
@@ -65,7 +67,8 @@ def test_forward_vs_float64(case):
     assert float(out.buf[:, :, :, 0].abs().max()) == 0 and float(out.buf[:, :, :, :, -1].abs().max()) == 0   # border untouched
 
 
-@pytest.mark.parametrize("case", [(2, 64, 16, 32, 64, 1), (1, 128, 8, 64, 128, 2), (2, 128, 16, 16, 64, 0), (1, 64, 8, 32, 128, 0)])
+@pytest.mark.parametrize("case", [(2, 64, 16, 32, 64, 1), (1, 128, 8, 64, 128, 2), (2, 128, 16, 16, 64, 0), (1, 64, 8, 32, 128, 0),
+                                  (1, 128, 8, 64, 128, 3), (2, 128, 16, 16, 64, 2)])
 def test_data_gradient_with_relu_mask_vs_float64(case):
     ops = _ops()
     n, cin, h, w, cout, form = case      # the layer maps cin -> cout; dy has cout channels, dx has cin
@@ -110,3 +113,95 @@ def test_a_scale_from_a_loose_bound_costs_no_accuracy():
     assert float(o1.buf[0].float().abs().max()) < 2.0 ** -2
     assert float((o1.to_nchw().double().cpu() - r1).abs().max()) <= 3e-6 * float(r1.abs().max())
     assert float((o2.to_nchw().double().cpu() - r2).abs().max()) <= 3e-6 * float(r2.abs().max())
+
+
+def _planes(ops, t):
+    return ops.p2_from_nchw(t.cuda())
+
+
+def test_l1_tap_and_pool_kernels_vs_torch():
+    """The pointwise kernels on planes (csrc/planes.hip) against torch on the values the planes hold: L1 term, max-pool
+    (+ L1 of the same pass), the tap's backward step with and without an incoming gradient, the pool's backward with and
+    without the tap's step -- ReLU masks included."""
+    ops = _ops()
+    n, c, h, w = 2, 16, 8, 32
+    t = _rand((n, c, h, w), 41).clamp_min(0)
+    p = _rand((n, c, h, w), 42).clamp_min(0)
+    pt, pp = _planes(ops, t), _planes(ops, p)
+    tv, pv = pt.to_nchw().double().cpu(), pp.to_nchw().double().cpu()     # the values the kernels see
+    # L1
+    loss = ops.p2_l1_fwd(pt, pp, 1.5)
+    assert abs(float(loss) - 1.5 * float((tv - pv).abs().mean())) <= 2e-6 * float(loss)
+    # pool (+ L1)
+    pooled = ops.Planes((n, c, h // 2, w // 2), "cuda")
+    loss2 = ops.p2_pool_fwd(pp, pooled, t=pt, weight=0.5)
+    assert abs(float(loss2) - 0.5 * float((tv - pv).abs().mean())) <= 2e-6 * float(loss2)
+    ref_pool = torch.nn.functional.max_pool2d(pv, 2, 2)
+    assert torch.equal(pooled.to_nchw().double().cpu(), ref_pool)        # the maximum's halves are carried over unchanged
+    assert int(pooled.meta[0]) == int(pp.meta[0])
+    pooled2 = ops.Planes((n, c, h // 2, w // 2), "cuda")
+    assert ops.p2_pool_fwd(pp, pooled2) is None and torch.equal(pooled2.buf, pooled.buf)
+    # tap backward: g = add + c sign(p - t), masked by p > 0
+    gout = torch.tensor([0.7], device="cuda")
+    cst = 0.7 * 2.0
+    add = _rand((n, c, h, w), 43, 1e-2)
+    padd = _planes(ops, add)
+    av = padd.to_nchw().double().cpu()
+    for with_add in (False, True):
+        g = ops.Planes((n, c, h, w), "cuda")
+        ops.p2_l1_bwd(pt, pp, padd if with_add else None, g, 2.0, gout)
+        ref = (av if with_add else 0.0) + cst * torch.sign(pv - tv)
+        ref = ref * (pv > 0)
+        got = g.to_nchw().double().cpu()
+        assert float((got - ref).abs().max()) <= 2.0 ** -21 * float(ref.abs().max())
+        assert float(g.meta[16:80].view(torch.float32).max()) >= float(got.abs().max()) * (1 - 1e-6)
+    # pool backward (+ the tap's step)
+    dy = _rand((n, c, h // 2, w // 2), 44, 1e-2)
+    pdy = _planes(ops, dy)
+    dyv = pdy.to_nchw().double().cpu()
+    pvr = pv.clone().requires_grad_(True)
+    torch.nn.functional.max_pool2d(pvr, 2, 2).backward(dyv)
+    routed = pvr.grad
+    for with_tap in (False, True):
+        g = ops.Planes((n, c, h, w), "cuda")
+        ops.p2_pool_bwd(pp, pdy, g, t=pt if with_tap else None, gscale=2.0 if with_tap else 0.0, gout=gout if with_tap else None)
+        ref = (routed + (cst * torch.sign(pv - tv) if with_tap else 0.0)) * (pv > 0)
+        got = g.to_nchw().double().cpu()
+        assert float((got - ref).abs().max()) <= 2.0 ** -21 * float(ref.abs().max()), with_tap
+
+
+def test_vgg_loss_on_planes_equals_the_fp32_tensor_path():
+    """lib.losses.vgg_loss through the p2 engine (planes from relu1_1 up, one autograd node for the whole prediction pass)
+    against the same loss through the per-layer fp32-tensor path: full-width VGG19 at 256^2, batch 2.  Loss terms to 2e-6
+    relative; d loss / d pred by relative L2 -- both are fp32-accurate evaluations of a gradient that is discontinuous in
+    the features (sign(p - t), pool argmax), so they scatter around each other like each does around float64
+    (test_hip_models.py::test_full_width_vgg19_loss_and_gradient_at_256_vs_float64_oracle covers this path against float64)."""
+    ops = _ops()
+    from behavior_driven_video_synthesis_amd.lib.losses import vgg_loss
+    from behavior_driven_video_synthesis_amd.models import imagenet_pretrained as ip
+    weights = [1.0, 0.5, 1.5, 1.0, 2.0, 1.0]
+    pv = ip.PerceptualVGG(ip.vgg19(seed=78, width_div=1, synthetic=True, pretrained=True), weights).cuda()
+    g = torch.Generator().manual_seed(9)
+    target = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    pred0 = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    res = {}
+    for mode in (True, False):
+        ip.enable_p2(mode)
+        try:
+            p = pred0.clone().requires_grad_(True)
+            ops.profile_start()
+            ld = vgg_loss(pv, target, p)
+            torch.stack([v.sum() for v in ld.values()]).sum().backward()
+            fam = ops.profile_stop(by_kernel=True)
+            res[mode] = ({k: float(v) for k, v in ld.items()}, p.grad.double().cpu(), sorted(fam))
+        finally:
+            ip.enable_p2(True)
+    (la, ga, ka), (lb, gb, kb) = res[True], res[False]
+    assert list(la) == list(lb) == ["input", "relu1_2", "relu2_2", "relu3_2", "relu4_2", "relu5_2"]
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-6 * abs(lb[k]), (k, la[k], lb[k])
+    rel = float((ga - gb).norm() / gb.norm())
+    print(f"p2 vs fp32-tensor path: d loss / d pred relative L2 {rel:.2e}")
+    assert rel <= 5e-3, rel
+    # the fp32-tensor run went through the h2 row kernels, the p2 run did not (its convolutions are not profiled per launch)
+    assert any(k.startswith("conv_h2_kernel<2, 2") for k in kb) and not any(k.startswith("conv_h2_kernel<2, 2") for k in ka), (ka, kb)
