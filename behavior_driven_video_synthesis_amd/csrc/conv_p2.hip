@@ -72,9 +72,12 @@ __device__ __forceinline__ void p2_dma(uint32_t voff, const void* sbase, uint32_
                : "memory");
 }
 template <int N>
-__device__ __forceinline__ void p2_dma_wait() {
+__device__ __forceinline__ void p2_dma_wait() {   // all but the N youngest transfers of this wave have landed
+  static_assert(N == 0 || N == 1 || N == 2 || N == 4, "counts in use");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 __device__ __forceinline__ const void* p2_uniform_ptr(const void* p) {
   const uint64_t v = (uint64_t)p;
@@ -342,7 +345,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_p2_kernel(const
 // enough (a wave's R segment starts after its M segment has ended).  Group 0 copies the weight slabs (slab t+1 at the start
 // of R(t): its buffer was last read by group 1 one segment earlier, reads retired before that barrier), group 1 the next
 // chunk's activation pieces; each group retires its own transfers at the end of its M segment, i.e. a full two segments
-// after issuing them and one barrier before anybody reads them.
+// after issuing them and one barrier before anybody reads them.  (Measured and not kept, r05: three slab buffers with the
+// transfers requested two taps ahead and counted waits that leave the newest in flight -- conv4_x 173 us against 168 - 170:
+// the transfers' latency is not what the loop waits for.)
 template <int CT>
 __global__ __launch_bounds__(512, 1) void conv_p2a_kernel(const P2Args a) {
   constexpr int NW = 8, MW = 128;
@@ -738,6 +743,17 @@ extern "C" int vunet_p2_pack_weights(const float* w, const float* shift, int32_t
   if (nb > 2048) nb = 2048;
   VUNET_LAUNCH(p2_wpack_kernel, dim3((unsigned)nb), dim3(256), 0, st, w, (int)Cout, (int)Cin, (int)dgrad, (const float*)wk,
                (uint4*)image);
+  return vunet_check_launch();
+}
+
+// wk alone (no image): the bound constants of a layer the p2 kernels do not run themselves (the 3-channel first layer,
+// csrc/conv_thin.hip: vunet_p2_conv_first).  w [Cout][Cin][3][3]; workspace: 2 * Cout floats.
+extern "C" int vunet_p2_weight_bound(const float* w, const float* shift, int32_t Cout, int32_t Cin, float* wk, float* workspace,
+                                     void* stream) {
+  if (!w || !wk || !workspace || Cout < 1 || Cin < 1) return VUNET_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  VUNET_LAUNCH(p2_wstat_kernel, dim3((unsigned)Cout), dim3(256), 0, st, w, (int)Cout, (int)Cin, 0, workspace);
+  VUNET_LAUNCH(p2_wk_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)Cout, shift, shift ? (int)Cout : 0, wk);
   return vunet_check_launch();
 }
 

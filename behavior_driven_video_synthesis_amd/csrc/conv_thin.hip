@@ -10,7 +10,10 @@
 //   thin_k : 3 input channels, the (<= 27) input values of a pixel stay in registers and M walks the outputs
 //            in blocks of 8 accumulators.
 // Same weight layout (K-major wt_f / wt_d), same epilogue (store_out) as the MFMA kernels.
+#include <string.h>
+
 #include "conv_common.h"
+#include "split_h2.h"
 
 // ---- M <= 4, 3x3 / stride 1 / pad 1, forward (MODE 0) or data gradient (MODE 1: mirrored taps) ----------------
 template <int MODE>
@@ -225,8 +228,18 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 4) void conv_thin_k_kernel(const
 // one weight read feeds R FMAs per output channel (54 reads : 216 R FMAs), and the (R + 2) x 3 input window per channel is
 // loaded once for the R pixels (R = 4: 54 loads instead of 108).  Same arithmetic order per pixel as the one-pixel form
 // (taps outer, channels inner, one fmaf chain per output): bit-identical results.
-template <int CI, int R>
-__global__ __launch_bounds__(256, 2) void conv_thin_kv_kernel(const GatherArgs a) {
+// PL (planes output, csrc/conv_p2.hip): the 8 output channels of a pass are exactly one 16-byte unit of a planes tensor -- the
+// result is scaled by the power of two derived from the bound  wk[0] * max|x| + wk[1], split and stored as (hi, lo) units into
+// the padded planes at a.y (P2Out below), its maximum published into the planes' meta: the first layer of the VGG19 stack
+// hands relu1_1 to conv1_2 without an fp32 round trip through HBM.
+struct P2Out {
+  const float* amax_x;   // partial |x| maxima of the input (n_amax floats)
+  int n_amax;
+  const float* wk;       // [0] max row sum of |w|, [1] max |shift|
+  int* ymeta;
+};
+template <int CI, int R, bool PL = false>
+__global__ __launch_bounds__(256, 2) void conv_thin_kv_kernel(const GatherArgs a, const P2Out po) {
   constexpr int T = 9;
   const vunet_conv_desc& d = a.d;
   const int H = d.Hs, W = d.Ws, HW = a.HsWs;
@@ -264,6 +277,15 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kv_kernel(const GatherArgs a
   __syncthreads();
   constexpr int MBK = 8;                   // outputs per pass
   float ymax = 0.f;
+  float sy = 1.f;
+  if constexpr (PL) {
+    float m_ = 0.f;
+    for (int i = threadIdx.x & 63; i < po.n_amax; i += 64) m_ = fmaxf(m_, po.amax_x[i]);
+    m_ = wave_max(m_);
+    const int ey = h2_scale_exp(po.wk[0] * m_ + po.wk[1]);
+    sy = h2_pow2(ey);
+    if (blockIdx.x == 0 && threadIdx.x == 0) po.ymeta[0] = ey;
+  }
 #pragma unroll 1
   for (int m0 = 0; m0 < d.M; m0 += MBK) {
     float acc[R][MBK];
@@ -298,7 +320,33 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kv_kernel(const GatherArgs a
         asm volatile("" : "+v"(woff), "+v"(acc[r][0]), "+v"(acc[r][1]), "+v"(acc[r][2]), "+v"(acc[r][3]), "+v"(acc[r][4]),
                           "+v"(acc[r][5]), "+v"(acc[r][6]), "+v"(acc[r][7]));
     }
-    if (ow < W) {   // lean epilogue (this kernel is only chosen for: + shift, optional ReLU, no residual)
+    if constexpr (PL) {   // one planes unit per pixel and pass (d.M % 8 == 0, W % 32 == 0, H % (8 R) == 0: checked by the caller)
+      float sh[MBK];
+#pragma unroll
+      for (int m = 0; m < MBK; ++m) sh[m] = a.shift ? a.shift[m0 + m] : 0.f;
+      const int Hp = H + 2, Wp = W + 2, MB8 = d.M >> 3;
+      uint4* const yu = reinterpret_cast<uint4*>(a.y);
+      const size_t plane = (size_t)d.N * MB8 * Hp * Wp;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float v[MBK];
+#pragma unroll
+        for (int m = 0; m < MBK; ++m) {
+          float t = acc[r][m] + sh[m];
+          if (relu) t = fmaxf(t, 0.f);
+          ymax = fmaxf(ymax, fabsf(t));
+          v[m] = t * sy;
+        }
+        uint4 hu, lu;
+        h2_split2(v[0], v[1], hu.x, lu.x);
+        h2_split2(v[2], v[3], hu.y, lu.y);
+        h2_split2(v[4], v[5], hu.z, lu.z);
+        h2_split2(v[6], v[7], hu.w, lu.w);
+        const size_t o = (((size_t)n * MB8 + (m0 >> 3)) * Hp + (oh0 + r + 1)) * Wp + (ow + 1);
+        yu[o] = hu;
+        yu[plane + o] = lu;
+      }
+    } else if (ow < W) {   // lean epilogue (this kernel is only chosen for: + shift, optional ReLU, no residual)
 #pragma unroll
       for (int m = 0; m < MBK; ++m)
         if (m0 + m < d.M) {
@@ -315,7 +363,13 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kv_kernel(const GatherArgs a
         }
     }
   }
-  if (a.amax_out) publish_amax(a, ymax);   // (whole waves reach this point)
+  if constexpr (PL) {
+    const float m_ = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(reinterpret_cast<unsigned*>(po.ymeta) + 16 + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u), __float_as_uint(m_));
+  } else {
+    if (a.amax_out) publish_amax(a, ymax);   // (whole waves reach this point)
+  }
 }
 
 // which thin kernel (if any) takes this problem: 1 = thin_m, 2 = thin_k, 0 = none
@@ -356,9 +410,30 @@ int vunet_conv_thin_launch(const GatherArgs& ga, int kind, hipStream_t st) {
   } else {
     if (thin_kv(d)) {
       dim3 gv((unsigned)(d.N * ((d.Hs + 31) / 32) * ((d.Ws + 31) / 32)));
-      VUNET_LAUNCH((conv_thin_kv_kernel<3, 4>), gv, block, 0, st, ga);
+      VUNET_LAUNCH((conv_thin_kv_kernel<3, 4>), gv, block, 0, st, ga, P2Out{});
     } else if (d.KH == 3) VUNET_LAUNCH((conv_thin_k_kernel<3, 3>), grid, block, 0, st, ga);
     else VUNET_LAUNCH((conv_thin_k_kernel<1, 3>), grid, block, 0, st, ga);
   }
+  return vunet_check_launch();
+}
+
+// The first layer of the p2 VGG19 pass (include/vunet_hip.h: vunet_p2_conv_first): 3 -> M channels, 3x3 / pad 1, + shift, ReLU,
+// fp32 NCHW in, planes out.
+extern "C" int vunet_p2_conv_first(const float* x, const float* amax_x, int32_t n_amax, const float* wt_f, int32_t Mpad,
+                                   const float* shift, const float* wk, void* y, int32_t* ymeta, int32_t N, int32_t H, int32_t W,
+                                   int32_t M, void* stream) {
+  if (!x || !amax_x || n_amax < 1 || !wt_f || !wk || !y || !ymeta) return VUNET_ERR_ARG;
+  if (N < 1 || M < 8 || M % 8 || M > 128 || H % 32 || W % 32 || ((uintptr_t)y & 15)) return VUNET_ERR_UNSUPPORTED;
+  GatherArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  vunet_conv_desc& d = ga.d;
+  d.N = N; d.C1 = 3; d.C2 = 0; d.Hs = H; d.Ws = W; d.M = M; d.m_off = 0; d.Mpad = Mpad; d.Ho = H; d.Wo = W; d.KH = 3; d.KW = 3;
+  d.stride = 1; d.pad = 1; d.mode = 0; d.out_act = ACT_RELU;
+  ga.x1 = x; ga.wt = wt_f; ga.shift = shift; ga.y = reinterpret_cast<float*>(y);
+  ga.NP = N * H * W; ga.HoWo = H * W; ga.HsWs = H * W;
+  ga.ph = ga.pw = -1;
+  P2Out po{amax_x, (int)n_amax, wk, (int*)ymeta};
+  dim3 gv((unsigned)(N * (H / 32) * (W / 32)));
+  VUNET_LAUNCH((conv_thin_kv_kernel<3, 4, true>), gv, dim3(256), 0, (hipStream_t)stream, ga, po);
   return vunet_check_launch();
 }

@@ -218,12 +218,34 @@ class _P2Engine:
             object.__setattr__(m, "_p2w", w)
         return w
 
-    def forward(self, role, y0, targets=None, tap_weights=None):
-        """y0: relu1_1 as an fp32 tensor (conv1_1 runs on the 3-channel VALU kernel).  -> ({tap: Planes}, {tap: loss [1]})."""
+    def _first(self):
+        """conv1_1 (3 input channels: the VALU kernel of csrc/conv_thin.hip, writing planes): its K-major weights for the
+        forward and the data gradient and the bound constants, packed once (the stack is frozen)."""
+        m = self.program[0]
+        stamp = (m.weight.data_ptr(), m.weight._version, m.bias._version)
+        rec = m.__dict__.get("_p2first")
+        if rec is None or rec[0] != stamp:
+            w, b = m.weight.detach().contiguous(), m.bias.detach().contiguous()
+            wt_f, wt_d, _, shift, _, _, wx_d = ops.pack_weights(w, None, b, None, None, 3, 0, 1, True)
+            wk = torch.empty(4, device=w.device, dtype=torch.float32)
+            work = torch.empty(2 * w.shape[0], device=w.device, dtype=torch.float32)
+            ops._call("vunet_p2_weight_bound", ops._p(w), ops._p(b), int(w.shape[0]), 3, ops._p(wk), ops._p(work), ops._stream())
+            rec = (stamp, wt_f, wt_d, shift, wx_d, wk)
+            object.__setattr__(m, "_p2first", rec)
+        return rec
+
+    def forward(self, role, xp, targets=None, tap_weights=None):
+        """xp: the preprocessed image (fp32, 3 channels).  -> ({tap: Planes}, {tap: loss [1]})."""
         st = self._role(role)
         st["metas"].zero_()
         A = st["A"]
-        ops.p2_from_nchw(y0, out=A[0], zero_meta=False)
+        _, wt_f, _, shift, _, wk = self._first()
+        n, _, h, w = xp.shape
+        amax = ops._tagged_amax(xp)
+        if amax is None:
+            amax = ops.absmax_partials(xp)
+        ops._call("vunet_p2_conv_first", ops._p(xp), ops._p(amax), 512, ops._p(wt_f), int(wt_f.shape[1]), ops._p(shift), ops._p(wk),
+                  ops._p(A[0].buf), ops._p(A[0].meta), n, h, w, A[0].shape[1], ops._stream())
         taps, losses = {}, {}
         steps = self.program[1]
         for k, step in enumerate(steps, start=1):
@@ -301,19 +323,27 @@ class _P2Engine:
             k -= 1
         if D is None:
             return None
-        return D.to_nchw()
+        # conv1_1's data gradient (64 -> 3 channels: VALU kernel) on the fp32 form of D
+        _, _, wt_d, _, wx_d, _ = self._first()
+        n, h, w = self.geo
+        c0 = st["shp"][0][0]
+        dconv = D.to_nchw()
+        dx = torch.empty(n, 3, h, w, device=self.device, dtype=torch.float32)
+        d = ops.ConvDesc(N=n, C1=c0, C2=0, Hs=h, Ws=w, M=3, m_off=0, Mpad=wt_d.shape[1], Ho=h, Wo=w, KH=3, KW=3, stride=1, pad=1,
+                         mode=1, in_act=ops.ACT_NONE, in_slope=0.0, drop_p=0.0, drop_seed=0, out_act=ops.ACT_NONE, d2s=0)
+        ops._conv_gather(d, dconv, None, wt_d, None, None, None, dx, wx_d)
+        return dx
 
 
 class P2VggLoss(torch.autograd.Function):
-    """The prediction pass of the perceptual loss from relu1_1 up, on pre-split planes: (relu1_1 output, engine, target) ->
-    one loss term per tap.  ONE autograd node: the backward walks the data-gradient chain itself (conv / tap / pool kernels
-    on planes) and hands back d loss / d relu1_1-output already multiplied by the ReLU mask."""
+    """The prediction pass of the perceptual loss from conv1_1 up, on pre-split planes: (preprocessed image, engine, target)
+    -> one loss term per tap.  ONE autograd node: the backward walks the data-gradient chain itself (conv / tap / pool
+    kernels on planes, conv1_1's 64 -> 3 data gradient last) and hands back d loss / d preprocessed-image."""
 
     @staticmethod
-    def forward(ctx, y0, engine, target, tap_weights, names):
-        _, losses = engine.forward("p", y0, target.planes, tap_weights)
+    def forward(ctx, xp, engine, target, tap_weights, names):
+        _, losses = engine.forward("p", xp, target.planes, tap_weights)
         ctx.engine, ctx.target, ctx.tap_weights, ctx.names = engine, target, tap_weights, names
-        ctx.y0 = y0
         ctx.generation = target.generation
         return tuple(losses[n] for n in names)
 
@@ -324,8 +354,6 @@ class P2VggLoss(torch.autograd.Function):
                                "PerceptualVGG (its planes buffers are persistent): run forward + backward per target")
         g = ctx.engine.backward(ctx.target.planes, ctx.tap_weights,
                                 {n: (None if go is None else go.contiguous()) for n, go in zip(ctx.names, gouts)})
-        if g is not None:
-            ops._tag_masked(g, ctx.y0)
         return g, None, None, None, None
 
 
@@ -398,7 +426,9 @@ class PerceptualVGG(nn.Module):
                                            self.target_layers)
             if prog is not None and not any(p.requires_grad for p in self.vgg_layers.parameters()):
                 eng = _P2Engine(prog, x.shape[0], x.shape[2], x.shape[3], x.device)
-                if eng.shapes() is None:
+                first = prog[0]
+                if (eng.shapes() is None or x.shape[1] != 3 or first.weight.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32
+                        or first.weight.shape[0] % 8 or first.weight.shape[0] > 128):
                     eng = None
             cache[key] = eng
         return cache[key]
@@ -414,8 +444,7 @@ class PerceptualVGG(nn.Module):
         if eng is None or torch.is_grad_enabled():
             return self.forward(x)
         xp = ops.VggPreprocess.apply(x)
-        y0 = eng.program[0].fused(xp, out_act=ops.ACT_RELU)
-        taps, _ = eng.forward("t", y0)
+        taps, _ = eng.forward("t", xp)
         out = _P2Target({"input": xp})
         out.update({k: v.buf for k, v in taps.items()})
         out.planes = taps
@@ -439,9 +468,8 @@ class PerceptualVGG(nn.Module):
             xp = ops.VggPreprocess.apply(pred)
             losses["input"], xp_alias = ops.L1MeanThrough.apply(target_features["input"], xp, float(weights["input"]))
             ops.carry_amax_tag(xp, xp_alias)
-            y0 = eng.program[0].fused(xp_alias, out_act=ops.ACT_RELU)
             names = tuple(st[2] for st in eng.program[1] if st[0] == "conv" and st[2] is not None)
-            terms = P2VggLoss.apply(y0, eng, target_features, self._tap_weights(), names)
+            terms = P2VggLoss.apply(xp_alias, eng, target_features, self._tap_weights(), names)
             losses.update(dict(zip(names, terms)))
             return losses
 

@@ -547,6 +547,13 @@ int vunet_p2_conv(const vunet_p2_desc* d, const void* x, const int32_t* xmeta, c
 int vunet_p2_weight_image_bytes(int32_t Cout, int32_t Cin, int32_t dgrad);
 int vunet_p2_pack_weights(const float* w, const float* shift, int32_t Cout, int32_t Cin, int32_t dgrad, void* image, float* wk,
                           float* workspace, void* stream);
+/* The FIRST layer of the stack (3 input channels: no matrix-core work): conv3x3 + shift + ReLU on the fp32 image, written as
+ * planes (csrc/conv_thin.hip).  wt_f / Mpad / shift: the layer's K-major weights from vunet_weightnorm_fwd; wk from
+ * vunet_p2_weight_bound (max row sum of |w|, max |shift|); amax_x: n_amax partial maxima of |x|.  M % 8 == 0, M <= 128,
+ * H % 32 == 0, W % 32 == 0. */
+int vunet_p2_weight_bound(const float* w, const float* shift, int32_t Cout, int32_t Cin, float* wk, float* workspace, void* stream);
+int vunet_p2_conv_first(const float* x, const float* amax_x, int32_t n_amax, const float* wt_f, int32_t Mpad, const float* shift,
+                        const float* wk, void* y, int32_t* ymeta, int32_t N, int32_t H, int32_t W, int32_t M, void* stream);
 /* fp32 NCHW <-> planes.  from_nchw: amax = n_amax partial maxima of |x| (vunet_absmax_partials / a producer's amax_out): the
  * scale comes from the true maximum; relu = 1 applies max(x, 0) on the way. */
 int vunet_p2_from_nchw(const float* x, const float* amax, int32_t n_amax, int32_t relu, void* y, int32_t* ymeta, int32_t N,

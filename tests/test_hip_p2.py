@@ -205,3 +205,30 @@ def test_vgg_loss_on_planes_equals_the_fp32_tensor_path():
     assert rel <= 5e-3, rel
     # the fp32-tensor run went through the h2 row kernels, the p2 run did not (its convolutions are not profiled per launch)
     assert any(k.startswith("conv_h2_kernel<2, 2") for k in kb) and not any(k.startswith("conv_h2_kernel<2, 2") for k in ka), (ka, kb)
+
+
+def test_first_layer_writes_planes_vs_float64():
+    """conv1_1 of the stack (3 input channels, fp32 FMA kernel) with the planes epilogue: relu(conv + bias) as (hi, lo) units,
+    scale from the bound, maximum published, border untouched."""
+    ops = _ops()
+    n, h, w, m = 2, 32, 64, 64
+    x = _rand((n, 3, h, w), 51, 1.5)
+    wt, b = _rand((m, 3, 3, 3), 52, 0.3), _rand((m,), 53, 0.1)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    wc, bc = wt.cuda(), b.cuda()
+    wt_f, _, _, shift, _, _, _ = ops.pack_weights(wc, None, bc, None, None, 3, 0, 1, False)
+    wk = torch.empty(4, device="cuda")
+    work = torch.empty(2 * m, device="cuda")
+    ops._call("vunet_p2_weight_bound", ops._p(wc), ops._p(bc), m, 3, ops._p(wk), ops._p(work), ops._stream())
+    assert abs(float(wk[0]) - float(wt.abs().sum(dim=(1, 2, 3)).max())) <= 1e-5 * float(wk[0]) and float(wk[1]) == float(b.abs().max())
+    xc = x.cuda()
+    out = ops.Planes((n, m, h, w), "cuda")
+    ops._call("vunet_p2_conv_first", ops._p(xc), ops._p(ops.absmax_partials(xc)), 512, ops._p(wt_f), int(wt_f.shape[1]), ops._p(shift),
+              ops._p(wk), ops._p(out.buf), ops._p(out.meta), n, h, w, m, ops._stream())
+    y = out.to_nchw().double().cpu()
+    scale = float(ref.abs().max())
+    assert float((y - ref).abs().max()) <= 3e-6 * scale
+    amax = float(out.meta[16:80].view(torch.float32).max())
+    assert scale * (1 - 1e-5) <= amax <= scale * (1 + 1e-5)
+    assert float(out.buf[0].float().abs().max()) < 2.0 ** 14
+    assert float(out.buf[:, :, :, 0].abs().max()) == 0 and float(out.buf[:, :, :, :, -1].abs().max()) == 0
