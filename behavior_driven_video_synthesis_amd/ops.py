@@ -859,7 +859,10 @@ _wgrad_batchable_cache = {}
 
 
 def _wgrad_batchable(wd) -> bool:
-    key = bytes(wd)
+    # (everything the C-side predicate looks at; NOT the dropout seed, which changes from step to step when issued eagerly:
+    #  keyed by the whole descriptor the cache grew by one entry per layer and step)
+    key = (wd.N, wd.C1, wd.C2, wd.Hs, wd.Ws, wd.Cout, wd.Ho, wd.Wo, wd.KH, wd.KW, wd.stride, wd.pad, wd.in_act, wd.drop_p > 0,
+           wd.nsplit, wd.flags)
     r = _wgrad_batchable_cache.get(key)
     if r is None:
         r = _wgrad_batchable_cache[key] = _lib.lib().vunet_conv2d_wgrad_batchable(ctypes.byref(wd)) == 1

@@ -38,7 +38,7 @@ def agg(path):
     """kernel -> counter -> [n, sum]"""
     d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].replace("void ", "").split("(")[0]
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         c = d[k][r["Counter_Name"]]
         c[0] += 1
         c[1] += float(r["Counter_Value"])
