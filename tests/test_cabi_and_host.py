@@ -34,7 +34,7 @@ def test_ctypes_structs_match_header_field_order():
     txt = open(os.path.join(ROOT, "include", "vunet_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     for cname, cls in (("vunet_conv_desc", ops.ConvDesc), ("vunet_wgrad_desc", ops.WgradDesc),
-                       ("vunet_wn_desc", ops.WnDesc)):
+                       ("vunet_wn_desc", ops.WnDesc), ("vunet_p2_desc", ops.P2Desc)):
         body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname, txt, flags=re.S).group(1)
         fields = []
         for decl in body.split(";"):
@@ -187,6 +187,45 @@ def test_kernel_selection_of_the_gather_entry_point():
     assert variant(C1=32, M=3, Mpad=32, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_mv_kernel<0, 4>"
     assert variant(C1=3, M=32, Mpad=32, KH=1, KW=1, pad=0, Hs=256, Ws=256, Ho=256, Wo=256) == "conv_thin_k_kernel<1, 3>"
     assert variant(C1=3, M=64, Mpad=64, Hs=256, Ws=256, Ho=256, Wo=256, out_act=ops.ACT_RELU) == "conv_thin_kv_kernel<3, 4>"
+
+
+def test_p2_dispatch_and_the_vgg19_program_are_host_logic():
+    """The pre-split VGG19 path (csrc/conv_p2.hip, models/imagenet_pretrained._P2Engine) without a GPU: which geometries
+    vunet_p2_conv covers and which workgroup form it picks, the weight image's size, and the program the engine derives from
+    the ``features`` stack (first layer, conv / pool steps, taps) -- incl. the stacks it must refuse."""
+    import ctypes
+    import torch
+    from behavior_driven_video_synthesis_amd import _lib, ops
+    from behavior_driven_video_synthesis_amd.models.imagenet_pretrained import PerceptualVGG, _P2Engine, vgg19
+    lib = _lib.lib()
+
+    def variant(n, c, h, w, m):
+        d = ops.P2Desc(n, c, h, w, m, 1)
+        if lib.vunet_p2_conv_supported(ctypes.byref(d)) != 1:
+            return None
+        buf = ctypes.create_string_buffer(96)
+        assert lib.vunet_p2_conv_variant(ctypes.byref(d), buf, 96) == 0
+        return buf.value.decode()
+    # the bs-16 256^2 stack: eight waves in antiphase wherever 128-channel workgroups fill the chip, four waves otherwise
+    assert variant(16, 64, 256, 256, 64) == "conv_p2_kernel<4, 32, 1>"          # conv1_2
+    assert variant(16, 128, 128, 128, 128) == "conv_p2a_kernel<32>"              # conv2_2
+    assert variant(16, 512, 32, 32, 512) == "conv_p2a_kernel<32>"                # conv4_x
+    assert variant(16, 512, 32, 32, 256) == "conv_p2_kernel<4, 32, 1>"           # conv4_1's data gradient: 128 wide workgroups would be 128
+    assert variant(16, 512, 16, 16, 512) == "conv_p2_kernel<4, 16, 1>"           # conv5_x
+    assert variant(2, 48, 32, 32, 64) is None and variant(2, 64, 12, 32, 64) is None and variant(2, 64, 16, 24, 64) is None
+    assert variant(2, 64, 16, 32, 96) is None
+    assert lib.vunet_p2_weight_image_bytes(512, 512, 0) == 512 * 512 * 9 * 4 and lib.vunet_p2_weight_image_bytes(64, 3, 0) == 0
+    assert lib.vunet_p2_weight_image_bytes(64, 128, 1) == 64 * 128 * 9 * 4
+    pv = PerceptualVGG(vgg19(synthetic=True, pretrained=True), [1.0] * 6)
+    first, steps = _P2Engine.build_program(list(pv.vgg_layers._modules.items()), 31, pv.target_layers)
+    assert tuple(first.weight.shape) == (64, 3, 3, 3)
+    assert [s_[0] for s_ in steps] == ["conv", "pool", "conv", "conv", "pool"] + ["conv"] * 4 + ["pool"] + ["conv"] * 4 + ["pool", "conv", "conv"]
+    assert [s_[2] for s_ in steps if s_[0] == "conv" and s_[2]] == ["relu1_2", "relu2_2", "relu3_2", "relu4_2", "relu5_2"]
+    # a stack whose first layer is tapped, or with a bare conv (no ReLU behind it), is not p2-shaped: the fp32-tensor path serves it
+    assert _P2Engine.build_program(list(pv.vgg_layers._modules.items()), 31, {"1": "relu1_1", "31": "relu5_2"}) is None
+    assert _P2Engine.build_program(list(pv.vgg_layers._modules.items())[:1], 31, pv.target_layers) is None
+    # no engine on the CPU (and none for a half-width stack's 32-channel layers): features_for_loss falls back to forward()
+    assert pv._p2_engine(torch.zeros(1, 3, 64, 64)) is None
 
 
 def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
