@@ -135,7 +135,8 @@ class _P2Engine:
     def __init__(self, program, n, h, w, device):
         self.program, self.geo, self.device = program, (n, h, w), device
         self.roles = {}
-        self.generation = 0
+        self.generation = 0        # target passes so far (a _P2Target is valid until the next one)
+        self.pred_generation = 0   # prediction passes so far (their activations live in ONE set of persistent buffers)
 
     @staticmethod
     def build_program(mods, last, taps):
@@ -343,8 +344,9 @@ class P2VggLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xp, engine, target, tap_weights, names):
         _, losses = engine.forward("p", xp, target.planes, tap_weights)
+        engine.pred_generation += 1
         ctx.engine, ctx.target, ctx.tap_weights, ctx.names = engine, target, tap_weights, names
-        ctx.generation = target.generation
+        ctx.generation, ctx.pred_generation = target.generation, engine.pred_generation
         return tuple(losses[n] for n in names)
 
     @staticmethod
@@ -352,6 +354,10 @@ class P2VggLoss(torch.autograd.Function):
         if ctx.target.generation != ctx.generation:
             raise RuntimeError("P2VggLoss.backward: the target features were overwritten by a later target pass of the same "
                                "PerceptualVGG (its planes buffers are persistent): run forward + backward per target")
+        if ctx.engine.pred_generation != ctx.pred_generation:
+            raise RuntimeError("P2VggLoss.backward: a later vgg_loss() of the same PerceptualVGG and input geometry has overwritten "
+                               "this pass's activations (persistent planes buffers): call backward() before the next vgg_loss(), "
+                               "or switch the planes path off (models.imagenet_pretrained.enable_p2(False)) for this use")
         g = ctx.engine.backward(ctx.target.planes, ctx.tap_weights,
                                 {n: (None if go is None else go.contiguous()) for n, go in zip(ctx.names, gouts)})
         return g, None, None, None, None

@@ -232,3 +232,27 @@ def test_first_layer_writes_planes_vs_float64():
     assert scale * (1 - 1e-5) <= amax <= scale * (1 + 1e-5)
     assert float(out.buf[0].float().abs().max()) < 2.0 ** 14
     assert float(out.buf[:, :, :, 0].abs().max()) == 0 and float(out.buf[:, :, :, :, -1].abs().max()) == 0
+
+
+def test_a_second_pass_before_backward_is_refused_not_silently_wrong():
+    """The engine keeps ONE set of activation buffers per role: a second vgg_loss() before the first one's backward() overwrites
+    what that backward would read -- it must raise, and so must a loss against target features of an earlier target pass."""
+    ops = _ops()
+    from behavior_driven_video_synthesis_amd.lib.losses import vgg_loss
+    from behavior_driven_video_synthesis_amd.models import imagenet_pretrained as ip
+    pv = ip.PerceptualVGG(ip.vgg19(seed=5, width_div=1, synthetic=True, pretrained=True), [1.0] * 6).cuda()
+    g = torch.Generator().manual_seed(1)
+    t = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    p1 = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).cuda().requires_grad_(True)
+    p2 = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).cuda().requires_grad_(True)
+    l1 = vgg_loss(pv, t, p1)
+    l2 = vgg_loss(pv, t, p2)
+    sum(v.sum() for v in l2.values()).backward()                  # the latest pass: fine
+    assert p2.grad is not None and torch.isfinite(p2.grad).all()
+    with pytest.raises(RuntimeError, match="overwritten"):
+        sum(v.sum() for v in l1.values()).backward()
+    with torch.no_grad():
+        old = pv.features_for_loss(t)
+        pv.features_for_loss(t)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        pv.loss_terms(p1.detach().requires_grad_(True), old)
