@@ -1,0 +1,210 @@
+"""CPU oracle for the behaviour front half of BASELINE config 5: flow sample -> pose_behavior_rnn decode.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package may import this module: only ``tests/`` and
+``__graft_entry__.smoke()`` use it, and only as the *checker*.
+
+A functional (state-dict driven) restatement in plain PyTorch-CPU fp32 of
+
+* ``UnsupervisedTransformer2`` -> ``UnconditionalFlow2`` -> ``UnconditionalFlatDoubleCouplingFlowBlock2``
+  (``ActNorm`` + ``DoubleVectorCouplingBlock2`` + ``Shuffle``), both directions
+  (models/flow/simple_flow.py:136-176, models/flow/blocks.py:95-128, :276-319, :531-559, :692-704,
+  lib/modules.py:236-257, :260-331);
+* ``ResidualBehaviorNet``: ``BEncoder`` (one-layer LSTM over the sequence + the two 1x1 ``NormConv2d`` heads),
+  ``ResidualRNNDecoder`` (LSTM cell + ``n_out`` + residual) and ``generate_seq``
+  (models/pose_behavior_rnn.py:125-209, :463-534, :538-626).  The decoder's ``rnn_type="gru"`` branch is not
+  restated: the reference defines ``n_out`` only inside the LSTM branch (:473-478), so its GRU decoder cannot run.
+
+Every function cites the reference lines it follows (paths relative to the upstream repository root) and takes a
+flat ``sd`` mapping with the reference's state-dict key names, so the product modules' ``state_dict()`` can be fed
+in unchanged.  Parity pin: ``tests/golden/g9_behavior.npz`` was written by ``tests/golden/make_golden.py`` from the
+imported reference classes; ``tests/test_oracle_golden.py`` holds this restatement to it.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# BasicFullyConnectedNet -- lib/modules.py:236-257
+# --------------------------------------------------------------------------
+def fully_connected_depth(sd: SD, p: str) -> int:
+    """Number of hidden Linear layers: ``main`` holds Linear at 0, 2, ..., 2*(depth+1) with LeakyReLU between."""
+    n = 0
+    while f"{p}.main.{2 * n}.weight" in sd:
+        n += 1
+    return n - 2
+
+
+def fully_connected(sd: SD, p: str, x: Tensor, use_tanh: bool) -> Tensor:
+    """Linear -> LeakyReLU(0.01) -> depth x (Linear -> LeakyReLU) -> Linear [-> Tanh]   (lib/modules.py:240-257)."""
+    depth = fully_connected_depth(sd, p)
+    h = x
+    for i in range(depth + 2):
+        h = F.linear(h, sd[f"{p}.main.{2 * i}.weight"], sd[f"{p}.main.{2 * i}.bias"])
+        if i < depth + 1:
+            h = F.leaky_relu(h, 0.01)
+    return torch.tanh(h) if use_tanh else h
+
+
+# --------------------------------------------------------------------------
+# ActNorm (initialised) -- lib/modules.py:292-331
+# --------------------------------------------------------------------------
+def actnorm_forward(sd: SD, p: str, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """h = scale * (x + loc); logdet = H*W*sum(log|scale|) per sample, H = W = 1 here   (lib/modules.py:307-316)."""
+    scale, loc = sd[f"{p}.scale"].reshape(1, -1), sd[f"{p}.loc"].reshape(1, -1)
+    h = scale * (x + loc)
+    logdet = torch.sum(torch.log(torch.abs(scale))) * torch.ones(x.shape[0])
+    return h, logdet
+
+
+def actnorm_reverse(sd: SD, p: str, y: Tensor) -> Tensor:
+    """h = y / scale - loc   (lib/modules.py:320-331)."""
+    return y / sd[f"{p}.scale"].reshape(1, -1) - sd[f"{p}.loc"].reshape(1, -1)
+
+
+# --------------------------------------------------------------------------
+# DoubleVectorCouplingBlock2 -- models/flow/blocks.py:276-319
+# --------------------------------------------------------------------------
+def _swap_halves(x: Tensor) -> Tensor:
+    return torch.cat(torch.chunk(x, 2, dim=1)[::-1], dim=1)
+
+
+def coupling_forward(sd: SD, p: str, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """Two affine half-couplings; the halves change roles before the second   (models/flow/blocks.py:296-309)."""
+    logdet = torch.zeros(x.shape[0])
+    for i in range(2):
+        if i % 2 != 0:
+            x = _swap_halves(x)
+        xa, xk = torch.chunk(x, 2, dim=1)
+        scale = fully_connected(sd, f"{p}.s.{i}", xa, True)
+        xk = xk * scale.exp() + fully_connected(sd, f"{p}.t.{i}", xa, False)
+        x = torch.cat((xa, xk), dim=1)
+        logdet = logdet + scale.reshape(x.shape[0], -1).sum(dim=1)
+    return x, logdet
+
+
+def coupling_reverse(sd: SD, p: str, x: Tensor) -> Tensor:
+    """models/flow/blocks.py:310-319."""
+    for i in (1, 0):
+        if i % 2 == 0:
+            x = _swap_halves(x)
+        xa, xk = torch.chunk(x, 2, dim=1)
+        xk = (xk - fully_connected(sd, f"{p}.t.{i}", xa, False)) * fully_connected(sd, f"{p}.s.{i}", xa, True).neg().exp()
+        x = torch.cat((xa, xk), dim=1)
+    return x
+
+
+# --------------------------------------------------------------------------
+# UnconditionalFlatDoubleCouplingFlowBlock2 / UnconditionalFlow2 -- models/flow/blocks.py:531-559, :95-128
+# --------------------------------------------------------------------------
+def flow_n_blocks(sd: SD, p: str = "flow") -> int:
+    n = 0
+    while f"{p}.sub_layers.{n}.norm_layer.loc" in sd:
+        n += 1
+    return n
+
+
+def flow_forward(sd: SD, x: Tensor, p: str = "flow") -> Tuple[Tensor, Tensor]:
+    """x [B, C] -> (z [B, C], logdet [B]); ActNorm, coupling, shuffle per block   (models/flow/blocks.py:111-121, :540-551)."""
+    logdet = torch.zeros(x.shape[0])
+    for i in range(flow_n_blocks(sd, p)):
+        q = f"{p}.sub_layers.{i}"
+        x, ld = actnorm_forward(sd, f"{q}.norm_layer", x)
+        logdet = logdet + ld
+        x, ld = coupling_forward(sd, f"{q}.coupling", x)
+        logdet = logdet + ld
+        x = x[:, sd[f"{q}.shuffle.forward_shuffle_idx"].long()]
+    return x, logdet
+
+
+def flow_reverse(sd: SD, z: Tensor, p: str = "flow") -> Tensor:
+    """z [B, C] -> x [B, C]   (models/flow/blocks.py:122-125, :552-557; simple_flow.py:167-170)."""
+    x = z
+    for i in reversed(range(flow_n_blocks(sd, p))):
+        q = f"{p}.sub_layers.{i}"
+        x = x[:, sd[f"{q}.shuffle.backward_shuffle_idx"].long()]
+        x = coupling_reverse(sd, f"{q}.coupling", x)
+        x = actnorm_reverse(sd, f"{q}.norm_layer", x)
+    return x
+
+
+# --------------------------------------------------------------------------
+# recurrent cell -- torch.nn.LSTMCell / one-layer torch.nn.LSTM as the reference instantiates them
+# --------------------------------------------------------------------------
+def lstm_cell(w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor, x: Tensor, h: Tensor, c: Tensor):
+    """Gate order i, f, g, o (torch.nn.LSTMCell): c' = f*c + i*g, h' = o*tanh(c')."""
+    gates = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+    i, f, g, o = gates.chunk(4, dim=1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    return torch.sigmoid(o) * torch.tanh(c2), c2
+
+
+# --------------------------------------------------------------------------
+# ResidualRNNDecoder / generate_seq -- models/pose_behavior_rnn.py:487-506, :603-626
+# --------------------------------------------------------------------------
+def generate_seq(sd: SD, b: Tensor, x_pose: Tensor, length: int, start_frame: int, p: str = "decoder"):
+    """Roll the residual decoder out from ``x_pose[:, start_frame]`` with hidden = cell = ``b``.
+
+    Returns (xs [B, len, n_kps], cs [B, len, n_kps]): cs holds each step's *input* pose, as the reference returns
+    it (``return out + res, res``, :506; "changes are here velocities", :619)."""
+    w_ih, w_hh = sd[f"{p}.rnn.weight_ih"], sd[f"{p}.rnn.weight_hh"]
+    b_ih, b_hh = sd[f"{p}.rnn.bias_ih"], sd[f"{p}.rnn.bias_hh"]
+    x = x_pose[:, start_frame]
+    h, c = b, b
+    xs: List[Tensor] = []
+    cs: List[Tensor] = []
+    for _ in range(length):
+        res = x
+        if f"{p}.n_in.weight" in sd:
+            x = F.linear(x, sd[f"{p}.n_in.weight"], sd[f"{p}.n_in.bias"])
+        h, c = lstm_cell(w_ih, w_hh, b_ih, b_hh, x, h, c)
+        x = F.linear(h, sd[f"{p}.n_out.weight"], sd[f"{p}.n_out.bias"]) + res
+        xs.append(x)
+        cs.append(res)
+    return torch.stack(xs, dim=1), torch.stack(cs, dim=1)
+
+
+# --------------------------------------------------------------------------
+# BEncoder -- models/pose_behavior_rnn.py:175-209
+# --------------------------------------------------------------------------
+def _norm_linear(sd: SD, p: str, x: Tensor) -> Tensor:
+    """``NormConv2d`` with a 1x1 kernel on a 1x1 map: gamma * (g * v/||v|| . x + bias) + beta   (lib/modules.py:135-145)."""
+    v, g = sd[f"{p}.conv.weight_v"], sd[f"{p}.conv.weight_g"]
+    w = (v * (g / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1, 1))).reshape(v.shape[0], -1)
+    y = F.linear(x, w, sd[f"{p}.conv.bias"])
+    return sd[f"{p}.gamma"].reshape(1, -1) * y + sd[f"{p}.beta"].reshape(1, -1)
+
+
+def infer_b(sd: SD, seq: Tensor, eps: Optional[Tensor] = None, sample_noise: Optional[Tensor] = None, p: str = "b_enc"):
+    """One-layer LSTM over ``seq`` [B, T, n_kps] from a zero state; ``pre`` = last hidden.  With the information
+    bottleneck: mu / logstd heads and b = eps*exp(logstd) + mu, or (``sample=True``) pure noise   (:175-209).
+
+    Returns (b, mu, logstd, pre); without the heads in ``sd``: pre alone."""
+    w_ih, w_hh = sd[f"{p}.rnn.weight_ih_l0"], sd[f"{p}.rnn.weight_hh_l0"]
+    b_ih, b_hh = sd[f"{p}.rnn.bias_ih_l0"], sd[f"{p}.rnn.bias_hh_l0"]
+    bsz, hid = seq.shape[0], w_hh.shape[1]
+    h, c = torch.zeros(bsz, hid), torch.zeros(bsz, hid)
+    for t in range(seq.shape[1]):
+        h, c = lstm_cell(w_ih, w_hh, b_ih, b_hh, seq[:, t], h, c)
+    pre = h
+    if f"{p}.mu_fn.gamma" not in sd:
+        return pre
+    mu, logstd = _norm_linear(sd, f"{p}.mu_fn", pre), _norm_linear(sd, f"{p}.std_fn", pre)
+    if sample_noise is not None:
+        return sample_noise, mu, logstd, pre
+    b = (torch.zeros_like(mu) if eps is None else eps) * torch.exp(logstd) + mu
+    return b, mu, logstd, pre
+
+
+def behavior_net_forward(sd: SD, x1: Tensor, x2: Tensor, length: int, start_frame: int = 0,
+                         eps: Optional[Tensor] = None, sample_noise: Optional[Tensor] = None):
+    """``ResidualBehaviorNet.forward`` with the bottleneck: (xs, cs, b, mu, logstd, pre)   (:574-586)."""
+    b, mu, logstd, pre = infer_b(sd, x1, eps, sample_noise)
+    xs, cs = generate_seq(sd, b, x2, length, start_frame)
+    return xs, cs, b, mu, logstd, pre

@@ -26,7 +26,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 REF = os.environ.get("VUNET_REFERENCE", "/root/reference")
 
-from synth import seeded_randn, synth_image, synth_state_dict  # noqa: E402
+from synth import seeded_randn, synth_behavior_state, synth_image, synth_state_dict  # noqa: E402
 
 
 def _install_stubs():
@@ -712,6 +712,73 @@ def g7_metrics():
     save("g7_metrics", meta, arrays)
 
 
+def behavior_state(mod, seed):
+    """Seeded values for every floating tensor of a behaviour / flow module (synth.synth_behavior_state); index buffers
+    (``Shuffle``) keep the permutation the reference drew."""
+    sd = mod.state_dict()
+    stored = {k: v for k, v in sd.items() if not v.dtype.is_floating_point and k.rsplit(".", 1)[-1] != "initialized"}
+    out = synth_behavior_state({k: list(v.shape) for k, v in sd.items()}, seed, stored)
+    mod.load_state_dict(out)
+    return out
+
+
+def g9_behavior():
+    """Behaviour front half of config 5 (experiments/behavior_net.py:1086-1100, :1173-1184): the reference's own
+    ``UnsupervisedTransformer2`` (both directions) and ``ResidualBehaviorNet`` (``infer_b``, ``generate_seq``,
+    ``forward``) at small sizes, one flow with an odd channel count.  The fixture stores the permutations the
+    reference drew, the recipe of every other tensor and the expected outputs."""
+    from models import pose_behavior_rnn as rb
+    from models.flow import simple_flow as rf
+    seed = 91
+    arrays, meta = {}, {"seed": seed, "cases": {}}
+    for tag, (chan, mid, depth, n_flows, bsz) in {"even": (64, 128, 2, 3, 5), "odd": (33, 48, 1, 2, 4)}.items():
+        torch.manual_seed(seed)
+        flow = rf.UnsupervisedTransformer2(flow_in_channels=chan, flow_mid_channels=mid, flow_hidden_depth=depth,
+                                           n_flows=n_flows)
+        sd = behavior_state(flow, seed)
+        flow.eval()
+        x = seeded_randn(f"flow.{tag}.x", (bsz, chan), seed)
+        z = seeded_randn(f"flow.{tag}.z", (bsz, chan), seed)
+        with torch.no_grad():
+            out, logdet = flow(x)
+            rev = flow.reverse(z)
+        meta["cases"][f"flow_{tag}"] = {"kw": dict(flow_in_channels=chan, flow_mid_channels=mid, flow_hidden_depth=depth,
+                                                   n_flows=n_flows), "batch": bsz,
+                                        "shapes": {k: list(v.shape) for k, v in sd.items()}}
+        for k, v in sd.items():
+            if k.endswith("_shuffle_idx"):
+                arrays[f"flow_{tag}.sd.{k}"] = v.numpy()
+        arrays[f"flow_{tag}.forward"] = out.reshape(bsz, chan).numpy()
+        arrays[f"flow_{tag}.logdet"] = logdet.numpy()
+        arrays[f"flow_{tag}.reverse"] = rev.reshape(bsz, chan).numpy()
+    # the behaviour net: information bottleneck on, LSTM decoder, with and without the decoder's input layer
+    n_kps, hid, bsz, t_in, length = 51, 64, 5, 7, 6
+    for tag, nin in {"plain": False, "nin": True}.items():
+        torch.manual_seed(seed)
+        net = rb.ResidualBehaviorNet(n_kps=n_kps, information_bottleneck=True, decoder_arch="lstm",
+                                     linear_in_decoder=nin, dim_hidden_b=hid)
+        sd = behavior_state(net, seed)
+        net.eval()
+        net.b_enc.init_hidden = lambda bs, device: rb.BEncoder.init_hidden(net.b_enc, bs, "cpu")   # get_device() is -1 on CPU
+        x1 = 0.5 * seeded_randn(f"net.{tag}.x1", (bsz, t_in, n_kps), seed)
+        x2 = 0.5 * seeded_randn(f"net.{tag}.x2", (bsz, t_in, n_kps), seed)
+        b_given = seeded_randn(f"net.{tag}.b", (bsz, hid), seed)
+        with torch.no_grad():
+            gen_xs, gen_cs, _, _ = net.generate_seq(b_given, x2, len=length, start_frame=t_in - 1)
+            with FixedNoise(f"net.{tag}", seed) as fn:
+                xs, cs, _, b, mu, logstd, pre = net(x1, x2, length, start_frame=2)
+            with FixedNoise(f"net.{tag}.prior", seed):
+                xs_p, _, _, b_p, *_ = net(x1, x2, length, start_frame=0, sample=True)
+        meta["cases"][f"net_{tag}"] = {"kw": dict(n_kps=n_kps, information_bottleneck=True, decoder_arch="lstm",
+                                                  linear_in_decoder=nin, dim_hidden_b=hid),
+                                       "batch": bsz, "t_in": t_in, "len": length, "noise_shapes": fn.shapes,
+                                       "shapes": {k: list(v.shape) for k, v in sd.items()}}
+        for name, v in dict(gen_xs=gen_xs, gen_cs=gen_cs, xs=xs, cs=cs, b=b, mu=mu, logstd=logstd, pre=pre,
+                            xs_prior=xs_p, b_prior=b_p).items():
+            arrays[f"net_{tag}.{name}"] = v.numpy()
+    save("g9_behavior", meta, arrays)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -732,3 +799,4 @@ if __name__ == "__main__":
     g1b_upsample_bilinear()
     g1c_l2norm_init()
     g8_pretrained_dir()
+    g9_behavior()

@@ -57,3 +57,25 @@ def synth_state_dict(shapes: Dict[str, Sequence[int]], seed: int = 0) -> Dict[st
 def synth_image(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor:
     """Image-like input in [-1, 1]."""
     return seeded_rand(name, shape, seed) * 2.0 - 1.0
+
+
+def synth_behavior_state(shapes: Dict[str, Sequence[int]], seed: int, stored: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """State dict of a flow / behaviour net: ``stored`` holds the tensors the recipe cannot rebuild (the ``Shuffle``
+    permutations the reference drew); ActNorm is marked initialised, with scales away from zero and of both signs;
+    recurrent weights are scaled by fan-in."""
+    out = {}
+    for k, shape in shapes.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if k in stored:
+            out[k] = torch.as_tensor(stored[k]).clone()
+        elif leaf == "initialized":
+            out[k] = torch.tensor(1, dtype=torch.uint8)
+        elif leaf == "scale":
+            r = seeded_randn(k, tuple(shape), seed)
+            sign = torch.where(r > 1.2, -torch.ones_like(r), torch.ones_like(r))
+            out[k] = (0.7 + 0.3 * r.abs()) * sign
+        elif leaf in ("weight_ih", "weight_hh", "weight_ih_l0", "weight_hh_l0"):
+            out[k] = seeded_randn(k, tuple(shape), seed) * (1.0 / shape[1]) ** 0.5
+        else:
+            out[k] = synth_param(k, tuple(shape), seed)
+    return out

@@ -383,3 +383,56 @@ def test_g5_org_trajectory():
     close(sd["dd.out_conv.conv.weight_v"], arr["final.dd.out_conv.conv.weight_v"], rtol=1e-3, atol=1e-5)
     for k, s in meta["param_checksums"].items():
         assert abs(float(sd[k].detach().double().abs().sum()) - s[1]) <= 1e-4 * s[1] + 1e-5, k
+
+
+# ---------------------------------------------------------------- G9 behaviour front half (config 5)
+def _behavior_sd(info, arr, prefix, seed):
+    from synth import synth_behavior_state
+    stored = {k[len(prefix) + 4:]: torch.from_numpy(v) for k, v in arr.items() if k.startswith(prefix + ".sd.")}
+    return synth_behavior_state(info["shapes"], seed, stored)
+
+
+@pytest.mark.parametrize("tag", ["even", "odd"])
+def test_g9_flow_both_directions(tag):
+    """UnsupervisedTransformer2 forward (z, logdet) and reverse vs the reference's own outputs; reverse(forward(x)) = x."""
+    from oracle import behavior_oracle as B
+    meta, arr = load_golden("g9_behavior")
+    seed, info = meta["seed"], meta["cases"][f"flow_{tag}"]
+    sd = _behavior_sd(info, arr, f"flow_{tag}", seed)
+    chan, bsz = info["kw"]["flow_in_channels"], info["batch"]
+    x = seeded_randn(f"flow.{tag}.x", (bsz, chan), seed)
+    z = seeded_randn(f"flow.{tag}.z", (bsz, chan), seed)
+    out, logdet = B.flow_forward(sd, x)
+    close(out, arr[f"flow_{tag}.forward"])
+    close(logdet, arr[f"flow_{tag}.logdet"])
+    close(B.flow_reverse(sd, z), arr[f"flow_{tag}.reverse"])
+    if chan % 2 == 0:
+        # (odd C: torch.chunk splits 17 | 16 both before and after the swap, so the reference's reverse does not undo
+        # its forward's swap (models/flow/blocks.py:301 vs :314); both directions are restated as they are.)
+        close(B.flow_reverse(sd, out), x.numpy(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["plain", "nin"])
+def test_g9_behavior_net(tag):
+    """ResidualBehaviorNet: generate_seq from a given b, forward (posterior sample) and forward(sample=True)."""
+    from oracle import behavior_oracle as B
+    meta, arr = load_golden("g9_behavior")
+    seed, info = meta["seed"], meta["cases"][f"net_{tag}"]
+    sd = _behavior_sd(info, arr, f"net_{tag}", seed)
+    bsz, t_in, length, n_kps = info["batch"], info["t_in"], info["len"], info["kw"]["n_kps"]
+    hid = info["kw"]["dim_hidden_b"]
+    x1 = 0.5 * seeded_randn(f"net.{tag}.x1", (bsz, t_in, n_kps), seed)
+    x2 = 0.5 * seeded_randn(f"net.{tag}.x2", (bsz, t_in, n_kps), seed)
+    b_given = seeded_randn(f"net.{tag}.b", (bsz, hid), seed)
+    xs, cs = B.generate_seq(sd, b_given, x2, length, t_in - 1)
+    close(xs, arr[f"net_{tag}.gen_xs"])
+    close(cs, arr[f"net_{tag}.gen_cs"])
+    assert info["noise_shapes"] == [[bsz, hid]]
+    eps = seeded_randn(f"net.{tag}.eps0", (bsz, hid), seed)
+    xs, cs, b, mu, logstd, pre = B.behavior_net_forward(sd, x1, x2, length, start_frame=2, eps=eps)
+    for name, v in dict(xs=xs, cs=cs, b=b, mu=mu, logstd=logstd, pre=pre).items():
+        close(v, arr[f"net_{tag}.{name}"])
+    noise = seeded_randn(f"net.{tag}.prior.eps0", (bsz, hid), seed)
+    xs, _, b, *_ = B.behavior_net_forward(sd, x1, x2, length, start_frame=0, sample_noise=noise)
+    close(b, arr[f"net_{tag}.b_prior"])
+    close(xs, arr[f"net_{tag}.xs_prior"])
