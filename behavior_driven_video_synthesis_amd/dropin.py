@@ -4,13 +4,14 @@
     python -m behavior_driven_video_synthesis_amd.dropin main.py --config config/shape_and_pose_net.yaml --gpu 0
 
 ``install()`` registers this package's modules in ``sys.modules`` under the names the reference imports them by --
-``lib.modules``, ``lib.losses``, ``models.vunets``, ``models.imagenet_pretrained``, ``models.synth_discriminator`` -- so
+``lib.modules``, ``lib.losses``, ``models.vunets``, ``models.imagenet_pretrained``, ``models.synth_discriminator``,
+``models.pose_behavior_rnn``, ``models.flow.blocks``, ``models.flow.simple_flow`` -- so
 ``experiments/shape_and_pose_net.py``'s ``from models.vunets import VunetAlter`` (:10), ``from lib.losses import vgg_loss``
 and friends resolve to the HIP-backed classes without a single edited line.  Each alias is a HYBRID module: names this
 package defines come from here; every other name (the flow / behaviour-net building blocks of ``lib/modules.py:236-707``,
 the sequence losses of ``lib/losses.py``, ...) falls through to the reference's own file, loaded from the checkout under a
 private name, so the experiments outside the hot path keep working.  ``lib`` / ``models`` stay the checkout's namespace
-packages; only the five hot-path sub-modules are replaced.
+packages; only these sub-modules are replaced.
 
 The reference's loop then drives these modules with its own ``torch.optim.Adam`` (autograd accumulates the gradients the
 usual way; the flat-bucket fast path is ``experiments.shape_and_pose_net.ShapePoseNet`` of this package), and
@@ -32,6 +33,10 @@ ALIASES = {
     "models.vunets": "behavior_driven_video_synthesis_amd.models.vunets",
     "models.imagenet_pretrained": "behavior_driven_video_synthesis_amd.models.imagenet_pretrained",
     "models.synth_discriminator": "behavior_driven_video_synthesis_amd.models.synth_discriminator",
+    # the behaviour front half of config 5 (experiments/behavior_net.py:14-17 imports these)
+    "models.pose_behavior_rnn": "behavior_driven_video_synthesis_amd.models.pose_behavior_rnn",
+    "models.flow.blocks": "behavior_driven_video_synthesis_amd.models.flow.blocks",
+    "models.flow.simple_flow": "behavior_driven_video_synthesis_amd.models.flow.simple_flow",
 }
 
 

@@ -325,3 +325,92 @@ class VunetRNB(nn.Module):
         if passthrough and not kw:
             return out, x
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# building blocks of the behaviour path (flow + recurrent nets): lib/modules.py:236-331
+# ------------------------------------------------------------------------------------------------
+class Linear(nn.Module):
+    """Parameter holder with ``nn.Linear``'s keys (weight [out, in], bias [out]) and default initialisation; the product
+    runs in ``seq.MlpGroup`` (csrc/seq.hip), never through ATen."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        w = torch.empty(out_features, in_features)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))   # nn.Linear.reset_parameters
+        bound = 1.0 / math.sqrt(in_features)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+
+
+class _Marker(nn.Module):
+    """A parameter-free slot of ``BasicFullyConnectedNet.main`` (LeakyReLU / Tanh): keeps the reference's indices, so the
+    Linear layers sit at main.0, main.2, ... in the state dict.  The activation itself is applied inside the kernels."""
+
+    def __init__(self, name: str):
+        super().__init__()
+        self.name = name
+
+    def extra_repr(self):
+        return self.name
+
+
+class BasicFullyConnectedNet(nn.Module):
+    """lib/modules.py:236-257: Linear, LeakyReLU, depth x (Linear, LeakyReLU), Linear [, Tanh]."""
+
+    def __init__(self, dim, depth, hidden_dim=256, use_tanh=False, use_bn=False, out_dim=None):
+        super().__init__()
+        if use_bn:
+            raise NotImplementedError("use_bn: no flow of the reference builds its MLPs with BatchNorm1d (models/flow/blocks.py)")
+        self.use_tanh = use_tanh
+        layers = [Linear(dim, hidden_dim), _Marker("LeakyReLU(0.01)")]
+        for _ in range(depth):
+            layers += [Linear(hidden_dim, hidden_dim), _Marker("LeakyReLU(0.01)")]
+        layers.append(Linear(hidden_dim, dim if out_dim is None else out_dim))
+        if use_tanh:
+            layers.append(_Marker("Tanh"))
+        self.main = nn.Sequential(*layers)
+        self._engine = None
+
+    def linears(self):
+        return [m for m in self.main if isinstance(m, Linear)]
+
+    def forward(self, x):
+        """Stand-alone evaluation ([B, dim] -> [B, out]); inside a coupling block the s and t nets run as one launch per
+        layer instead (``seq.FlowEngine``)."""
+        from .. import seq
+        if self._engine is None:
+            object.__setattr__(self, "_engine", seq.MlpEngine(self))
+        return self._engine(x)
+
+
+class ActNorm(nn.Module):
+    """lib/modules.py:260-331 for flat inputs ([B, C] or [B, C, 1, 1]): h = scale (x + loc), with the data-dependent
+    initialisation on the first forward call (loc = -mean, scale = 1 / (std + 1e-6) over the batch)."""
+
+    def __init__(self, num_features, logdet=False, affine=True):
+        assert affine
+        super().__init__()
+        self.logdet = logdet
+        self.loc = nn.Parameter(torch.zeros(1, num_features, 1, 1))
+        self.scale = nn.Parameter(torch.ones(1, num_features, 1, 1))
+        self.register_buffer("initialized", torch.tensor(0, dtype=torch.uint8))
+
+    def initialize(self, input):
+        from .. import seq
+        seq.actnorm_initialize(self, input)
+
+    def forward(self, input, reverse=False):
+        from .. import seq
+        if reverse:
+            return self.reverse(input)
+        if self.initialized.item() == 0:
+            self.initialize(input)
+            self.initialized.fill_(1)
+        h, logdet = seq.actnorm_apply(self, input, False)
+        return (h, logdet) if self.logdet else h
+
+    def reverse(self, output):
+        from .. import seq
+        return seq.actnorm_apply(self, output, True)[0]

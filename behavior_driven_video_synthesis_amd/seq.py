@@ -1,0 +1,557 @@
+"""Launch plans of the behaviour front half of BASELINE config 5 (csrc/seq.hip): flow sample -> pose_behavior_rnn decode.
+
+The reference runs ``flow.reverse`` and ``net.generate_seq`` as ATen chains (experiments/behavior_net.py:1173-1184):
+about 600 small launches for the 15-block flow of config/behavior_net.yaml and 250 for a 50-step roll-out.  Here an MLP
+is one launch per layer (the s and t nets of a coupling in the same launch), everything between two MLP evaluations of
+the flow is one launch, an LSTM step is two, and a whole pass is recorded once per batch size into a hipGraph and
+replayed.  ``FlowEngine`` / ``BehaviorEngine`` hold the packed weights and the per-batch-size buffers of one module;
+the ``nn.Module`` mirrors (models/flow, models/pose_behavior_rnn.py) own the parameters and call into them.
+
+There is no CPU path: the engines raise without a device tensor and the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes
+import gc
+import os
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .ops import _call, _p, _stream
+
+MAX_ROWS = 64   # batch rows per launch (four 16-row MFMA tiles); larger batches are processed in chunks
+
+
+class SeqLinearDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "ldx", "S_in", "S_out", "act_in", "nets", "shared_in")]
+
+
+class SeqCouplingDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "c1", "ld_in", "ld_out", "S", "Mp", "reverse", "affine_on_src")]
+
+
+class SeqLstmDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "H", "S", "ldx", "hoff", "n", "ldraw")] + [("seq_stride", ctypes.c_int64)]
+
+
+def _up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _need_device(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise RuntimeError("the behaviour path runs on hand-written gfx950 kernels: fp32 device tensors only (no CPU fallback)")
+
+
+def choose_split(m_pad: int, k_pad: int, nets: int) -> int:
+    """K split of a layer: double it until the launch has >= 512 workgroups, keeping >= 128 k per workgroup (one
+    32-wide chunk for each of its four waves) and the split aligned to chunks."""
+    s = 1
+    while s < 16 and (m_pad // 16) * s * nets < 512 and k_pad % (64 * s) == 0 and k_pad // (2 * s) >= 128:
+        s *= 2
+    return s
+
+
+def weight_image(w: torch.Tensor, m_pad: int, k_pad: int, col_off: int = 0, row_scale: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[M, K] weights -> the zero-padded [m_pad, k_pad] image ``vunet_seq_linear`` reads.  Weights whose shape already
+    fits (every layer of the reference configuration) are used in place: no second copy of a 2.5 GB flow."""
+    w2 = w.detach().reshape(w.shape[0], -1)
+    m, k = w2.shape
+    if out is None and row_scale is None and col_off == 0 and (m, k) == (m_pad, k_pad) and w2.is_contiguous():
+        return w2
+    if out is None:
+        out = torch.zeros(m_pad, k_pad, device=w.device, dtype=torch.float32)
+    _call("vunet_seq_pack_rows", _p(w2.contiguous()), m, k, _p(row_scale), _p(out), k_pad, col_off, _stream())
+    return out
+
+
+def padded_vector(b: torch.Tensor, n_pad: int) -> torch.Tensor:
+    b1 = b.detach().reshape(-1)
+    if b1.numel() == n_pad and b1.is_contiguous():
+        return b1
+    out = torch.zeros(n_pad, device=b.device, dtype=torch.float32)
+    _call("vunet_seq_pack_rows", _p(b1.contiguous()), 1, b1.numel(), None, _p(out), n_pad, 0, _stream())
+    return out
+
+
+def linear(desc: SeqLinearDesc, w: Sequence[torch.Tensor], xin: torch.Tensor, bias_in: Sequence[Optional[torch.Tensor]],
+           out: torch.Tensor):
+    _call("vunet_seq_linear", ctypes.byref(desc), _p(w[0]), _p(w[1] if len(w) > 1 else None), _p(xin), _p(bias_in[0]),
+          _p(bias_in[1] if len(bias_in) > 1 else None), _p(out), _stream())
+
+
+class MlpGroup:
+    """One or two ``BasicFullyConnectedNet`` stacks (lib/modules.py:236-257) of equal shape evaluated together.
+
+    ``layers[net]`` = [(weight, bias), ...]; the stacks either share their input (the s and t nets of a coupling) or
+    are single.  ``run`` leaves the LAST layer's partial slabs in a buffer: its bias (and the scale net's tanh) belong
+    to the consumer kernel."""
+
+    def __init__(self, layers: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], k_in_pad: int):
+        self.nets = len(layers)
+        n_layers = len(layers[0])
+        self.dims = []     # per layer: (m_pad, k_pad, split)
+        self.w: List[List[torch.Tensor]] = []
+        self.b: List[List[torch.Tensor]] = []
+        k_pad = k_in_pad
+        for li in range(n_layers):
+            m = layers[0][li][0].shape[0]
+            m_pad = _up(m, 16) if li == n_layers - 1 else _up(m, 32)   # a hidden width is the next layer's K
+            self.w.append([weight_image(net[li][0], m_pad, k_pad) for net in layers])
+            self.b.append([padded_vector(net[li][1], m_pad) for net in layers])
+            self.dims.append((m_pad, k_pad, choose_split(m_pad, k_pad, self.nets)))
+            k_pad = m_pad
+        self.out_pad = self.dims[-1][0]
+        self.out_split = self.dims[-1][2]
+
+    def partial_floats(self, b_pad: int) -> int:
+        return max(self.nets * s * b_pad * m for m, _, s in self.dims)
+
+    def run(self, rows: int, xin: torch.Tensor, ldx: int, bufs: Sequence[torch.Tensor]) -> torch.Tensor:
+        """``xin``: [b_pad, ldx] operand (read from column 0).  Returns the buffer holding [nets][S][b_pad][out_pad]."""
+        src, s_in, bias_in, shared = xin, 1, [None] * self.nets, 1
+        for li, (m_pad, k_pad, split) in enumerate(self.dims):
+            dst = bufs[li % 2]
+            d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, s_in, split, 0 if li == 0 else 1, self.nets, shared)
+            linear(d, self.w[li], src, bias_in, dst)
+            src, s_in, bias_in, shared = dst, split, self.b[li], 0
+        return src
+
+
+class MlpEngine:
+    """A single ``BasicFullyConnectedNet`` on its own: [B, dim] -> [B, out] (rows in chunks of 64)."""
+
+    def __init__(self, net):
+        self._net = weakref.ref(net)
+        self._packed_for = None
+
+    @property
+    def net(self):
+        return self._net()
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        _need_device(x)
+        _lib.lib()
+        lin = self.net.linears()
+        key = _versions([p for l in lin for p in (l.weight, l.bias)])
+        if key != self._packed_for:
+            self.k_pad = _up(lin[0].in_features, 32)
+            self.group = MlpGroup([[(l.weight, l.bias) for l in lin]], self.k_pad)
+            self._packed_for = key
+        g, dev, m_out = self.group, x.device, lin[-1].out_features
+        outs = []
+        for s in range(0, x.shape[0], MAX_ROWS):
+            chunk = x[s:s + MAX_ROWS]
+            rows, b_pad = chunk.shape[0], _up(chunk.shape[0], 16)
+            xin = torch.zeros(b_pad, self.k_pad, device=dev)
+            xin[:rows, :chunk.shape[1]].copy_(chunk)
+            bufs = [torch.zeros(g.partial_floats(b_pad), device=dev) for _ in range(2)]
+            part = g.run(rows, xin, self.k_pad, bufs)
+            res = torch.empty(rows, m_out, device=dev)
+            _call("vunet_seq_finish", _p(part), g.out_split, g.out_pad, _p(g.b[-1][0]), 2 if self.net.use_tanh else 0, _p(res), m_out,
+                  rows, m_out, _stream())
+            outs.append(res)
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+
+def _flat2(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() == 4 and x.shape[2] == 1 and x.shape[3] == 1:
+        return x.reshape(x.shape[0], x.shape[1])
+    if x.dim() != 2:
+        raise ValueError(f"the behaviour path works on [B, C] (or [B, C, 1, 1]) tensors, got {tuple(x.shape)}")
+    return x
+
+
+def actnorm_initialize(mod, x: torch.Tensor):
+    """lib/modules.py:270-290 on the rows of ``x`` [B, C]; writes ``mod.loc`` / ``mod.scale`` in place."""
+    _need_device(x)
+    x2 = _flat2(x).contiguous()
+    b, c = x2.shape
+    _call("vunet_seq_actnorm_init", _p(x2), c, b, c, _p(mod.loc.data), _p(mod.scale.data), _stream())
+
+
+def actnorm_apply(mod, x: torch.Tensor, reverse: bool):
+    """-> (h shaped like x, logdet [B] or None): lib/modules.py:307-316 / :320-331."""
+    _need_device(x)
+    x2 = _flat2(x).contiguous()
+    b, c = x2.shape
+    out = torch.empty_like(x2)
+    logdet = None if reverse else torch.zeros(b, device=x.device)
+    d = SeqCouplingDesc(b, c, c, c, c, 1, c, 1 if reverse else 0, 0)
+    _call("vunet_seq_coupling", ctypes.byref(d), _p(x2), None, None, None, None, _p(mod.scale.detach().reshape(-1)),
+          _p(mod.loc.detach().reshape(-1)), _p(out), _p(logdet), _stream())
+    return out.reshape(x.shape), logdet
+
+
+class _GraphCache:
+    """Record a launch sequence once per key into a hipGraph and replay it (torch.cuda.CUDAGraph is the handle)."""
+
+    def __init__(self):
+        self.graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        self.enabled = os.environ.get("VUNET_SEQ_GRAPH", "1") != "0"
+        self._stream = None
+
+    def run(self, key, issue):
+        if not self.enabled or torch.cuda.is_current_stream_capturing():   # (inside someone else's capture: become part of it)
+            issue()
+            return
+        g = self.graphs.get(key)
+        if g is None:
+            issue()                      # once eagerly: first-launch work (module load, function attributes) stays outside
+            torch.cuda.synchronize()
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            # no collector run while the stream records: a finaliser that frees device memory or destroys another graph
+            # (an engine of a model that went out of scope) is not a recordable operation and aborts the process
+            was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g, stream=self._stream):
+                    issue()
+            finally:
+                if was_on:
+                    gc.enable()
+            self.graphs[key] = g
+        g.replay()
+
+
+def _versions(params) -> tuple:
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+class FlowEngine:
+    """``UnconditionalFlow2`` (models/flow/blocks.py:95-128) in both directions for batches of <= 64 rows."""
+
+    def __init__(self, flow):
+        self._flow = weakref.ref(flow)     # the module owns the engine; no cycle for the collector to find
+        self._packed_for = None
+        self._plans: Dict[int, dict] = {}
+        self.graph = _GraphCache()
+
+    @property
+    def flow(self):
+        return self._flow()
+
+    # ---- weights
+    def _pack(self):
+        params = list(self.flow.parameters()) + list(self.flow.buffers())
+        key = _versions(params)
+        if key == self._packed_for:
+            return
+        blocks = list(self.flow.sub_layers)
+        c = self.flow.in_channels
+        dev = blocks[0].norm_layer.loc.device
+        c1 = c // 2 + c % 2
+        self.C, self.c1, self.ld = c, c1, _up(c, 32)
+        ar = torch.arange(c, device=dev)
+        swap = torch.cat(torch.chunk(ar, 2)[::-1])          # x -> cat(chunk(x, 2)[::-1])  (models/flow/blocks.py:301, :314)
+        self.swap = swap.to(torch.int32)
+        self.blocks = []
+        for blk in blocks:
+            cp = blk.coupling
+            halves = [MlpGroup([[(l.weight, l.bias) for l in cp.s[i].linears()], [(l.weight, l.bias) for l in cp.t[i].linears()]],
+                               _up(c1, 32)) for i in range(2)]
+            self.blocks.append(dict(
+                halves=halves, scale=blk.norm_layer.scale.detach().reshape(-1), loc=blk.norm_layer.loc.detach().reshape(-1),
+                fwd=blk.shuffle.forward_shuffle_idx.to(torch.int32), bwd=blk.shuffle.backward_shuffle_idx.to(torch.int32)))
+        self._packed_for = key
+        self._all_init = False
+        self._plans.clear()
+        self.graph.graphs.clear()
+
+    def _plan(self, rows: int) -> dict:
+        p = self._plans.get(rows)
+        if p is None:
+            dev = self.blocks[0]["scale"].device
+            b_pad = _up(rows, 16)
+            nf = max(h.partial_floats(b_pad) for blk in self.blocks for h in blk["halves"])
+            p = dict(b_pad=b_pad,
+                     state=[torch.zeros(b_pad, self.ld, device=dev) for _ in range(2)],
+                     part=[torch.zeros(nf, device=dev) for _ in range(2)],
+                     x_in=torch.zeros(rows, self.C, device=dev), x_out=torch.zeros(rows, self.C, device=dev),
+                     logdet=torch.zeros(b_pad, device=dev))
+            self._plans[rows] = p
+        return p
+
+    # ---- launches
+    def _step(self, rows, src, ld_in, dst, ld_out, reverse, half=None, map_=None, scale=None, loc=None, on_src=0, st=None,
+              logdet=None):
+        d = SeqCouplingDesc(rows, self.C, self.c1, ld_in, ld_out, half.out_split if half else 1, half.out_pad if half else self.C,
+                            reverse, on_src)
+        _call("vunet_seq_coupling", ctypes.byref(d), _p(src), _p(st), _p(half.b[-1][0] if half else None),
+              _p(half.b[-1][1] if half else None), _p(map_), _p(scale), _p(loc), _p(dst), _p(logdet), _stream())
+
+    def _issue_reverse(self, rows: int, p: dict):
+        """shuffle^-1, half 1, swap + half 0, ActNorm^-1 per block, last block first (models/flow/blocks.py:552-557, :310-319)."""
+        st, cur = p["state"], 0
+        n = len(self.blocks)
+        self._step(rows, p["x_in"], self.C, st[0], self.ld, 1, map_=self.blocks[n - 1]["bwd"])
+        for i in reversed(range(n)):
+            blk = self.blocks[i]
+            h1, h0 = blk["halves"][1], blk["halves"][0]
+            part = h1.run(rows, st[cur], self.ld, p["part"])
+            self._step(rows, st[cur], self.ld, st[1 - cur], self.ld, 1, half=h1, st=part, map_=self.swap)
+            cur = 1 - cur
+            part = h0.run(rows, st[cur], self.ld, p["part"])
+            last = i == 0
+            self._step(rows, st[cur], self.ld, p["x_out"] if last else st[1 - cur], self.C if last else self.ld, 1, half=h0, st=part,
+                       map_=None if last else self.blocks[i - 1]["bwd"], scale=blk["scale"], loc=blk["loc"], on_src=1)
+            cur = 1 - cur
+
+    def _issue_forward(self, rows: int, p: dict):
+        """ActNorm, half 0, swap + half 1, shuffle per block (models/flow/blocks.py:540-551, :296-309)."""
+        st, cur = p["state"], 0
+        n = len(self.blocks)
+        ld_acc = p["logdet"]
+        ld_acc.zero_()
+        self._step(rows, p["x_in"], self.C, st[0], self.ld, 0, scale=self.blocks[0]["scale"], loc=self.blocks[0]["loc"], logdet=ld_acc)
+        for i in range(n):
+            blk = self.blocks[i]
+            h0, h1 = blk["halves"]
+            part = h0.run(rows, st[cur], self.ld, p["part"])
+            self._step(rows, st[cur], self.ld, st[1 - cur], self.ld, 0, half=h0, st=part, map_=self.swap, logdet=ld_acc)
+            cur = 1 - cur
+            part = h1.run(rows, st[cur], self.ld, p["part"])
+            last = i == n - 1
+            nxt = None if last else self.blocks[i + 1]
+            self._step(rows, st[cur], self.ld, p["x_out"] if last else st[1 - cur], self.C if last else self.ld, 0, half=h1, st=part,
+                       map_=blk["fwd"], scale=None if last else nxt["scale"], loc=None if last else nxt["loc"], on_src=0, logdet=ld_acc)
+            cur = 1 - cur
+
+    def _issue_forward_init(self, rows: int, p: dict):
+        """The forward pass of a flow whose ActNorm layers still await their data-dependent initialisation
+        (lib/modules.py:303-305): each block's statistics come from the batch as it reaches that block, so the affine
+        step cannot ride on the previous block's last launch.  Issued eagerly, once."""
+        st, cur = p["state"], 0
+        ld_acc = p["logdet"]
+        ld_acc.zero_()
+        self._step(rows, p["x_in"], self.C, st[0], self.ld, 0)
+        n = len(self.blocks)
+        for i, (blk, mod) in enumerate(zip(self.blocks, self.flow.sub_layers)):
+            norm = mod.norm_layer
+            if norm.initialized.item() == 0:
+                _call("vunet_seq_actnorm_init", _p(st[cur]), self.ld, rows, self.C, _p(norm.loc.data), _p(norm.scale.data), _stream())
+                norm.initialized.fill_(1)
+            self._step(rows, st[cur], self.ld, st[cur], self.ld, 0, scale=blk["scale"], loc=blk["loc"], logdet=ld_acc)
+            h0, h1 = blk["halves"]
+            part = h0.run(rows, st[cur], self.ld, p["part"])
+            self._step(rows, st[cur], self.ld, st[1 - cur], self.ld, 0, half=h0, st=part, map_=self.swap, logdet=ld_acc)
+            cur = 1 - cur
+            part = h1.run(rows, st[cur], self.ld, p["part"])
+            last = i == n - 1
+            self._step(rows, st[cur], self.ld, p["x_out"] if last else st[1 - cur], self.C if last else self.ld, 0, half=h1, st=part,
+                       map_=blk["fwd"], logdet=ld_acc)
+            cur = 1 - cur
+
+    def _run(self, x: torch.Tensor, reverse: bool):
+        _need_device(x)
+        _lib.lib()
+        self._pack()
+        if not reverse and not self._initialised():
+            x2 = x.reshape(x.shape[0], -1)
+            if x2.shape[0] > MAX_ROWS or x2.shape[0] < 2:
+                raise ValueError("ActNorm's data-dependent initialisation needs one batch of 2..64 rows")
+            p = self._plan(x2.shape[0])
+            p["x_in"].copy_(x2)
+            self._issue_forward_init(x2.shape[0], p)
+            return p["x_out"].clone(), p["logdet"][:x2.shape[0]].clone()
+        x2 = x.reshape(x.shape[0], -1)
+        if x2.shape[1] != self.C:
+            raise ValueError(f"flow over {self.C} channels got {tuple(x.shape)}")
+        outs, lds = [], []
+        for s in range(0, x2.shape[0], MAX_ROWS):
+            chunk = x2[s:s + MAX_ROWS]
+            rows = chunk.shape[0]
+            p = self._plan(rows)
+            p["x_in"].copy_(chunk)
+            self.graph.run((rows, reverse), (lambda: self._issue_reverse(rows, p)) if reverse else (lambda: self._issue_forward(rows, p)))
+            outs.append(p["x_out"].clone())
+            if not reverse:
+                lds.append(p["logdet"][:rows].clone())
+        out = outs[0] if len(outs) == 1 else torch.cat(outs)
+        if reverse:
+            return out
+        return out, (lds[0] if len(lds) == 1 else torch.cat(lds))
+
+    def _initialised(self) -> bool:
+        if not getattr(self, "_all_init", False):
+            self._all_init = all(int(b.norm_layer.initialized.item()) != 0 for b in self.flow.sub_layers)
+        return self._all_init
+
+    def reverse(self, z: torch.Tensor) -> torch.Tensor:
+        return self._run(z, True)
+
+    def forward(self, x: torch.Tensor):
+        return self._run(x, False)
+
+
+class BehaviorEngine:
+    """``ResidualBehaviorNet`` (models/pose_behavior_rnn.py:538-626): the behaviour encoder's LSTM + bottleneck heads and the
+    residual decoder's roll-out, for batches of <= 64 rows."""
+
+    def __init__(self, net):
+        self._net = weakref.ref(net)
+        self._packed_for = None
+        self._plans: Dict[int, dict] = {}
+        self.graph = _GraphCache()
+
+    @property
+    def net(self):
+        return self._net()
+
+    def _pack(self):
+        net = self.net
+        key = _versions(list(net.parameters()))
+        if key == self._packed_for:
+            return
+        dec, enc = net.decoder, net.b_enc
+        self.n, self.H = dec.n_in_out, dec.n_hidden
+        if self.H % 32:
+            raise ValueError("dim_hidden_b must be a multiple of 32 on the HIP path")
+        self.hoff = _up(self.n, 32)
+        self.ldx = self.hoff + self.H
+        self.ldraw = _up(self.n, 64)
+        dev = dec.rnn.weight_ih.device
+
+        def gate_image(w_ih, w_hh):
+            img = torch.zeros(4 * self.H, self.ldx, device=dev)
+            weight_image(w_ih, 4 * self.H, self.ldx, 0, out=img)
+            weight_image(w_hh, 4 * self.H, self.ldx, self.hoff, out=img)
+            return img
+        self.dec_w = gate_image(dec.rnn.weight_ih, dec.rnn.weight_hh)
+        self.enc_w = gate_image(enc.rnn.weight_ih_l0, enc.rnn.weight_hh_l0)
+        self.split = choose_split(4 * self.H, self.ldx, 1)
+        self.heads = None
+        if enc.ib:
+            scales, biases = [], []
+            for head in (enc.mu_fn, enc.std_fn):
+                v, g, b, gamma, beta = head._params()
+                rs, be = torch.empty(self.H, device=dev), torch.empty(self.H, device=dev)
+                _call("vunet_seq_normlinear_rows", _p(v.detach().contiguous()), _p(g.detach().contiguous()), _p(b.detach().contiguous()),
+                      _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), self.H, self.H, _p(rs), _p(be), _stream())
+                scales.append(weight_image(v, self.H, self.H, 0, row_scale=rs))
+                biases.append(be)
+            self.heads = (scales, biases, choose_split(self.H, self.H, 2))
+        self._packed_for = key
+        self._plans.clear()
+        self.graph.graphs.clear()
+
+    def _plan(self, rows: int) -> dict:
+        p = self._plans.get(rows)
+        if p is None:
+            dev = self.dec_w.device
+            b_pad = _up(rows, 16)
+            p = dict(b_pad=b_pad, xh=torch.zeros(b_pad, self.ldx, device=dev), c=torch.zeros(b_pad, self.H, device=dev),
+                     xraw=torch.zeros(b_pad, self.ldraw, device=dev), gates=torch.zeros(self.split * b_pad * 4 * self.H, device=dev),
+                     pre=torch.zeros(b_pad, self.H, device=dev), b_in=torch.zeros(rows, self.H, device=dev),
+                     heads=torch.zeros(2 * 16 * b_pad * self.H, device=dev), io={})
+            self._plans[rows] = p
+        return p
+
+    def _gates(self, rows, p, w):
+        d = SeqLinearDesc(rows, 4 * self.H, self.ldx, self.ldx, 1, self.split, 0, 1, 1)
+        linear(d, [w], p["xh"], [None], p["gates"])
+
+    def _issue_decode(self, rows, p, x_pose, t_in, start_frame, length, xs, cs):
+        dec = self.net.decoder
+        n, esz = self.n, 4
+        w_in = dec.n_in.weight.detach() if dec.use_nin else None
+        b_in = dec.n_in.bias.detach() if dec.use_nin else None
+        x0 = ctypes.c_void_p(x_pose.data_ptr() + start_frame * n * esz)
+        _call("vunet_seq_start", x0, t_in * n, _p(p["b_in"]), _p(p["b_in"]), _p(w_in), _p(b_in), _p(p["xraw"]), self.ldraw,
+              _p(p["xh"]), self.ldx, self.hoff, _p(p["c"]), rows, n, self.H, _stream())
+        d = SeqLstmDesc(rows, self.H, self.split, self.ldx, self.hoff, n, self.ldraw, length * n)
+        for t in range(length):
+            self._gates(rows, p, self.dec_w)
+            _call("vunet_seq_lstm_step", ctypes.byref(d), _p(p["gates"]), _p(dec.rnn.bias_ih.detach()), _p(dec.rnn.bias_hh.detach()),
+                  _p(p["c"]), _p(p["xh"]), None, _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()), _p(w_in), _p(b_in),
+                  _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), None,
+                  _stream())
+
+    def generate_seq(self, b: torch.Tensor, x_pose: torch.Tensor, length: int, start_frame: int):
+        """-> (xs [B, len, n], cs [B, len, n]); models/pose_behavior_rnn.py:603-626."""
+        _need_device(b, x_pose)
+        _lib.lib()
+        self._pack()
+        if x_pose.dim() != 3 or x_pose.shape[2] != self.n or b.shape[1] != self.H:
+            raise ValueError(f"generate_seq: poses {tuple(x_pose.shape)}, behaviour {tuple(b.shape)}")
+        start_frame = start_frame % x_pose.shape[1]
+        xs_all, cs_all = [], []
+        for s in range(0, b.shape[0], MAX_ROWS):
+            bc, xc = b[s:s + MAX_ROWS], x_pose[s:s + MAX_ROWS]
+            rows, t_in = bc.shape[0], xc.shape[1]
+            p = self._plan(rows)
+            key = ("dec", rows, t_in, start_frame, length)
+            io = p["io"].get(key)
+            if io is None:
+                dev = b.device
+                io = dict(x=torch.zeros(rows, t_in, self.n, device=dev), xs=torch.zeros(rows, length, self.n, device=dev),
+                          cs=torch.zeros(rows, length, self.n, device=dev))
+                p["io"][key] = io
+            io["x"].copy_(xc)
+            p["b_in"].copy_(bc)
+            self.graph.run(key, lambda: self._issue_decode(rows, p, io["x"], t_in, start_frame, length, io["xs"], io["cs"]))
+            xs_all.append(io["xs"].clone())
+            cs_all.append(io["cs"].clone())
+        if len(xs_all) == 1:
+            return xs_all[0], cs_all[0]
+        return torch.cat(xs_all), torch.cat(cs_all)
+
+    def _issue_encode(self, rows, p, seq, t_in, eps, mu, logstd, b_out):
+        enc = self.net.b_enc
+        n, esz = self.n, 4
+        _call("vunet_seq_start", _p(seq), t_in * n, None, None, None, None, None, 0, _p(p["xh"]), self.ldx, self.hoff, _p(p["c"]),
+              rows, n, self.H, _stream())
+        d = SeqLstmDesc(rows, self.H, self.split, self.ldx, self.hoff, n, self.ldraw, t_in * n)
+        for t in range(t_in):
+            self._gates(rows, p, self.enc_w)
+            nxt = ctypes.c_void_p(seq.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
+            _call("vunet_seq_lstm_step", ctypes.byref(d), _p(p["gates"]), _p(enc.rnn.bias_ih_l0.detach()), _p(enc.rnn.bias_hh_l0.detach()),
+                  _p(p["c"]), _p(p["xh"]), _p(p["pre"]) if t == t_in - 1 else None, None, None, None, None, None, None, None, nxt,
+                  _stream())
+        if self.heads is not None:
+            w, bias, split = self.heads
+            dl = SeqLinearDesc(rows, self.H, self.H, self.H, 1, split, 0, 2, 1)
+            linear(dl, w, p["pre"], [None, None], p["heads"])
+            _call("vunet_seq_bottleneck", _p(p["heads"]), split, self.H, _p(bias[0]), _p(bias[1]), _p(eps), _p(mu), _p(logstd), _p(b_out),
+                  rows, self.H, _stream())
+
+    def infer_b(self, seq: torch.Tensor, eps: Optional[torch.Tensor]):
+        """LSTM over ``seq`` [B, T, n] from a zero state.  -> (b, mu, logstd, pre) with the bottleneck heads (b = eps *
+        exp(logstd) + mu; eps None: b = mu), else pre   (models/pose_behavior_rnn.py:175-201, :587-601)."""
+        _need_device(seq, eps)
+        _lib.lib()
+        self._pack()
+        if seq.dim() != 3 or seq.shape[2] != self.n:
+            raise ValueError(f"infer_b: sequence {tuple(seq.shape)}")
+        res = []
+        for s in range(0, seq.shape[0], MAX_ROWS):
+            sc = seq[s:s + MAX_ROWS]
+            rows, t_in = sc.shape[0], sc.shape[1]
+            p = self._plan(rows)
+            key = ("enc", rows, t_in, eps is not None)
+            io = p["io"].get(key)
+            if io is None:
+                dev = seq.device
+                io = dict(x=torch.zeros(rows, t_in, self.n, device=dev), eps=torch.zeros(rows, self.H, device=dev),
+                          mu=torch.zeros(rows, self.H, device=dev), logstd=torch.zeros(rows, self.H, device=dev),
+                          b=torch.zeros(rows, self.H, device=dev))
+                p["io"][key] = io
+            io["x"].copy_(sc)
+            if eps is not None:
+                io["eps"].copy_(eps[s:s + MAX_ROWS])
+            self.graph.run(key, lambda: self._issue_encode(rows, p, io["x"], t_in, io["eps"] if eps is not None else None, io["mu"],
+                                                           io["logstd"], io["b"]))
+            pre = p["pre"][:rows].clone()
+            res.append((io["b"].clone(), io["mu"].clone(), io["logstd"].clone(), pre) if self.heads is not None else (pre,))
+        if self.heads is None:
+            return res[0][0] if len(res) == 1 else torch.cat([r[0] for r in res])
+        if len(res) == 1:
+            return res[0]
+        return tuple(torch.cat([r[i] for r in res]) for i in range(4))

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.vunet_abi_version() == 9
+    assert lib.vunet_abi_version() == 10
 
 
 def test_header_is_plain_c_abi():
@@ -238,22 +238,29 @@ def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
     co = tmp_path / "checkout"
     (co / "lib").mkdir(parents=True)
     (co / "models").mkdir()
-    (co / "lib" / "modules.py").write_text("class NormConv2d:\n    ORIGIN = 'checkout'\nclass ActNorm:\n    ORIGIN = 'checkout'\n")
+    (co / "lib" / "modules.py").write_text("class NormConv2d:\n    ORIGIN = 'checkout'\nclass GINActNorm:\n    ORIGIN = 'checkout'\n")
     (co / "lib" / "utils.py").write_text("def helper():\n    return 'checkout utils'\n")
     (co / "lib" / "losses.py").write_text("from lib.utils import helper\nclass FlowLoss:\n    ORIGIN = helper()\n")
     (co / "models" / "vunets.py").write_text("class VunetAlter:\n    ORIGIN = 'checkout'\n")
+    (co / "models" / "flow").mkdir()
+    (co / "models" / "flow" / "__init__.py").write_text("")
+    (co / "models" / "flow" / "simple_flow.py").write_text("class UnsupervisedTransformer2:\n    ORIGIN = 'checkout'\nclass SupervisedTransformer:\n    ORIGIN = 'checkout'\n")
+    (co / "models" / "pose_behavior_rnn.py").write_text("class ResidualBehaviorNet:\n    ORIGIN = 'checkout'\nclass MTVAE:\n    ORIGIN = 'checkout'\n")
     (co / "main.py").write_text(
         "from models.vunets import VunetAlter, Regressor\n"
-        "from lib.modules import NormConv2d, ActNorm\n"
+        "from lib.modules import NormConv2d, GINActNorm\n"
         "from lib.losses import vgg_loss, compute_kl_with_prior, FlowLoss\n"
         "from lib.utils import helper\n"
         "from models.imagenet_pretrained import PerceptualVGG\n"
         "from models.synth_discriminator import DiscTrainer\n"
+        "from models.flow.simple_flow import UnsupervisedTransformer2, SupervisedTransformer\n"
+        "from models.pose_behavior_rnn import ResidualBehaviorNet, MTVAE\n"
         "import sys\n"
         "print('ARGS', sys.argv[1:])\n"
+        "print('BEHAVIOR', UnsupervisedTransformer2.__module__, ResidualBehaviorNet.__module__, SupervisedTransformer.ORIGIN, MTVAE.ORIGIN)\n"
         "print('VUNET', VunetAlter.__module__)\n"
         "print('NORMCONV', NormConv2d.__module__)\n"
-        "print('ACTNORM', ActNorm.ORIGIN)\n"
+        "print('ACTNORM', GINActNorm.ORIGIN)\n"
         "print('FLOWLOSS', FlowLoss.ORIGIN)\n"
         "print('UTILS', helper())\n"
         "print('VGGLOSS', vgg_loss.__module__, PerceptualVGG.__module__, DiscTrainer.__module__)\n")
@@ -266,6 +273,7 @@ def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
     assert out["ARGS"] == "['--config', 'x.yaml']"
     assert out["VUNET"] == pkg + ".models.vunets" and out["NORMCONV"] == pkg + ".lib.modules"
     assert out["ACTNORM"] == "checkout" and out["FLOWLOSS"] == "checkout utils" and out["UTILS"] == "checkout utils"
+    assert out["BEHAVIOR"] == f"{pkg}.models.flow.simple_flow {pkg}.models.pose_behavior_rnn checkout checkout"
     assert out["VGGLOSS"] == f"{pkg}.lib.losses {pkg}.models.imagenet_pretrained {pkg}.models.synth_discriminator"
 
 

@@ -1,0 +1,219 @@
+"""Behaviour front half of BASELINE config 5 on the GPU (csrc/seq.hip through the C ABI): the flow in both directions and
+the behaviour net's encoder / decoder against the fixtures the reference's own classes wrote (tests/golden/g9_behavior.npz)
+and against the pinned oracle (oracle/behavior_oracle.py) at sizes up to the reference configuration's."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from synth import seeded_randn, synth_behavior_state
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=2e-4, atol=2e-5)   # fp32 chains of 20 - 60 layers / 50 recurrent steps, different summation order
+FLOW_TOL = dict(rtol=1e-3, atol=1e-4)   # a flow pass multiplies by exp(+-s) and 1/scale 2 x n_flows times: rounding differences
+#                                         of the MLP sums (k order: four waves x S slabs here, one dot product on the CPU) grow
+#                                         with the pass's condition number; measured 3.7e-4 on one element of 320, 1e-6 typical
+
+
+def close(a, b, **kw):
+    tol = dict(TOL)
+    tol.update(kw)
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, **tol)
+
+
+def _sd(info, arr, prefix, seed):
+    stored = {k[len(prefix) + 4:]: torch.from_numpy(v) for k, v in arr.items() if k.startswith(prefix + ".sd.")}
+    return synth_behavior_state(info["shapes"], seed, stored)
+
+
+def _flow(kw, sd):
+    from behavior_driven_video_synthesis_amd.models.flow.simple_flow import UnsupervisedTransformer2
+    flow = UnsupervisedTransformer2(**kw)
+    flow.load_state_dict(sd)          # strict: the key set is the reference's
+    return flow.cuda()
+
+
+def _net(kw, sd):
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    net = ResidualBehaviorNet(**kw)
+    net.load_state_dict(sd)
+    return net.cuda()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("tag", ["even", "odd"])
+def test_flow_vs_reference_fixture(tag, graph):
+    meta, arr = load_golden("g9_behavior")
+    seed, info = meta["seed"], meta["cases"][f"flow_{tag}"]
+    flow = _flow(info["kw"], _sd(info, arr, f"flow_{tag}", seed))
+    flow.flow.engine().graph.enabled = graph
+    chan, bsz = info["kw"]["flow_in_channels"], info["batch"]
+    x = seeded_randn(f"flow.{tag}.x", (bsz, chan), seed).cuda()
+    z = seeded_randn(f"flow.{tag}.z", (bsz, chan), seed).cuda()
+    for _ in range(2):                                   # second call: the replayed graph
+        out, logdet = flow(x)
+        rev = flow.reverse(z)
+        assert out.shape == (bsz, chan, 1, 1) and rev.shape == (bsz, chan, 1, 1)
+        close(out.reshape(bsz, chan), arr[f"flow_{tag}.forward"], **FLOW_TOL)
+        close(logdet, arr[f"flow_{tag}.logdet"], **FLOW_TOL)
+        close(rev.reshape(bsz, chan), arr[f"flow_{tag}.reverse"], **FLOW_TOL)
+    if chan % 2 == 0:
+        close(flow.reverse(out).reshape(bsz, chan), x, rtol=1e-3, atol=1e-4)
+    close(flow.sample((bsz, chan)).shape, (bsz, chan))
+
+
+@pytest.mark.parametrize("tag", ["plain", "nin"])
+def test_behavior_net_vs_reference_fixture(tag):
+    meta, arr = load_golden("g9_behavior")
+    seed, info = meta["seed"], meta["cases"][f"net_{tag}"]
+    net = _net(info["kw"], _sd(info, arr, f"net_{tag}", seed))
+    bsz, t_in, length, n_kps, hid = info["batch"], info["t_in"], info["len"], info["kw"]["n_kps"], info["kw"]["dim_hidden_b"]
+    x1 = (0.5 * seeded_randn(f"net.{tag}.x1", (bsz, t_in, n_kps), seed)).cuda()
+    x2 = (0.5 * seeded_randn(f"net.{tag}.x2", (bsz, t_in, n_kps), seed)).cuda()
+    b_given = seeded_randn(f"net.{tag}.b", (bsz, hid), seed).cuda()
+    for _ in range(2):
+        xs, cs, zs, b_ret = net.generate_seq(b_given, x2, len=length, start_frame=t_in - 1)
+        close(xs, arr[f"net_{tag}.gen_xs"])
+        close(cs, arr[f"net_{tag}.gen_cs"])
+        assert zs == [] and b_ret is b_given
+    eps = seeded_randn(f"net.{tag}.eps0", (bsz, hid), seed).cuda()
+    xs, cs, _, b, mu, logstd, pre = net(x1, x2, length, start_frame=2, eps=eps)
+    for name, v in dict(xs=xs, cs=cs, b=b, mu=mu, logstd=logstd, pre=pre).items():
+        close(v, arr[f"net_{tag}.{name}"])
+    noise = seeded_randn(f"net.{tag}.prior.eps0", (bsz, hid), seed).cuda()
+    xs, _, _, b, *_ = net(x1, x2, length, start_frame=0, sample=True, eps=noise)
+    close(b, arr[f"net_{tag}.b_prior"])
+    close(xs, arr[f"net_{tag}.xs_prior"])
+    # without an injected eps the module draws its own: shapes and finiteness only
+    xs, cs, _, b, mu, logstd, pre = net(x1, x2, length)
+    assert xs.shape == (bsz, length, n_kps) and torch.isfinite(xs).all() and not torch.equal(b, mu)
+
+
+def _random_flow(chan, mid, depth, n_flows, seed, s_gain=1.0):
+    """``s_gain`` < 1 shrinks the scale nets' last layer: with the recipe's O(1) pre-activations every tanh saturates and a
+    pass multiplies by e^(+-1) per half-coupling -- a condition number no trained flow has, and one fp32 cannot carry."""
+    from behavior_driven_video_synthesis_amd.models.flow.simple_flow import UnsupervisedTransformer2
+    torch.manual_seed(seed)
+    flow = UnsupervisedTransformer2(flow_in_channels=chan, flow_mid_channels=mid, flow_hidden_depth=depth, n_flows=n_flows)
+    sd = flow.state_dict()
+    stored = {k: v for k, v in sd.items() if k.endswith("_shuffle_idx")}
+    sd = synth_behavior_state({k: list(v.shape) for k, v in sd.items()}, seed, stored)
+    last = f".main.{2 * (depth + 1)}."
+    for k in sd:
+        if ".coupling.s." in k and last in k:
+            sd[k] = sd[k] * s_gain
+    flow.load_state_dict(sd)
+    return flow.cuda(), sd
+
+
+@pytest.mark.parametrize("bsz", [1, 16, 17, 48, 64, 100])
+def test_flow_vs_oracle_over_batch_sizes(bsz):
+    """Every batch-tile count of the kernel (1..4 tiles of 16 rows) and the chunking above 64 rows."""
+    from oracle import behavior_oracle as B
+    flow, sd = _random_flow(96, 160, 2, 2, 5)
+    x = seeded_randn("bs.x", (bsz, 96), 5)
+    z = seeded_randn("bs.z", (bsz, 96), 5)
+    out, logdet = flow(x.cuda())
+    o_ref, l_ref = B.flow_forward(sd, x)
+    close(out.reshape(bsz, 96), o_ref, **FLOW_TOL)
+    close(logdet, l_ref, **FLOW_TOL)
+    close(flow.reverse(z.cuda()).reshape(bsz, 96), B.flow_reverse(sd, z), **FLOW_TOL)
+
+
+def test_flow_at_the_reference_width_vs_oracle_and_round_trip():
+    """config/behavior_net.yaml: 1024 channels, 2048 hidden, depth 2 (4 of the 15 blocks: 670 MB of weights), 16 rows as
+    experiments/behavior_net.py:1173 samples them; graph replay must equal the eager issue bit for bit."""
+    from oracle import behavior_oracle as B
+    flow, sd = _random_flow(1024, 2048, 2, 4, 9, s_gain=0.1)
+    eng = flow.flow.engine()
+    z = seeded_randn("full.z", (16, 1024), 9)
+    x_ref = B.flow_reverse(sd, z)
+    x_f64 = B.flow_reverse({k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}, z.double())
+    eng.graph.enabled = False
+    x_eager = flow.reverse(z.cuda())
+    eng.graph.enabled = True
+    x_graph = [flow.reverse(z.cuda()) for _ in range(3)][-1]
+    assert torch.equal(x_eager, x_graph)
+    # against the float64 oracle, next to the CPU float32 oracle's own distance from it
+    e_hip = float((x_graph.reshape(16, 1024).cpu().double() - x_f64).abs().max() / x_f64.abs().max())
+    e_cpu = float((x_ref.double() - x_f64).abs().max() / x_f64.abs().max())
+    print(f"flow reverse at 1024 / 2048 x 4 blocks: max err / max|x|  HIP {e_hip:.2e}  CPU fp32 {e_cpu:.2e}")
+    assert e_hip <= max(3.0 * e_cpu, 2e-6), (e_hip, e_cpu)
+    close(x_graph.reshape(16, 1024), x_ref, **FLOW_TOL)
+    back, logdet = flow(x_graph)
+    close(back.reshape(16, 1024), z, rtol=1e-3, atol=2e-4)
+    _, l_ref = B.flow_forward(sd, x_ref)
+    close(logdet, l_ref, rtol=1e-3, atol=1e-2)
+
+
+def test_decoder_roll_out_at_the_reference_size_vs_oracle():
+    """dim_hidden_b 1024, 51 pose dimensions, 50 steps (config/behavior_net.yaml), 16 rows; graph == eager."""
+    from oracle import behavior_oracle as B
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    torch.manual_seed(3)
+    net = ResidualBehaviorNet(51, information_bottleneck=True, decoder_arch="lstm", linear_in_decoder=False, dim_hidden_b=1024)
+    sd = synth_behavior_state({k: list(v.shape) for k, v in net.state_dict().items()}, 3, {})
+    net.load_state_dict(sd)
+    net = net.cuda()
+    b = seeded_randn("dec.b", (16, 1024), 3)
+    seq = 0.5 * seeded_randn("dec.x", (16, 50, 51), 3)
+    xs_ref, cs_ref = B.generate_seq(sd, b, seq, 50, 49)
+    eng = net.engine()
+    eng.graph.enabled = False
+    xs_e, cs_e, _, _ = net.generate_seq(b.cuda(), seq.cuda(), len=50, start_frame=49)
+    eng.graph.enabled = True
+    xs_g = [net.generate_seq(b.cuda(), seq.cuda(), len=50, start_frame=49)[0] for _ in range(3)][-1]
+    assert torch.equal(xs_e, xs_g)
+    close(xs_g, xs_ref, rtol=1e-3, atol=1e-4)
+    close(cs_e, cs_ref, rtol=1e-3, atol=1e-4)
+    eps = seeded_randn("dec.eps", (16, 1024), 3)
+    b2, mu, logstd, pre = net.infer_b(seq.cuda(), False, eps=eps.cuda())
+    rb, rmu, rls, rpre = B.infer_b(sd, seq, eps)
+    for got, ref in ((b2, rb), (mu, rmu), (logstd, rls), (pre, rpre)):
+        close(got, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_actnorm_data_dependent_initialisation():
+    """lib/modules.py:270-290, :303-305: the first forward of a fresh flow sets loc / scale from the batch, block by block."""
+    from behavior_driven_video_synthesis_amd.lib.modules import ActNorm
+    from oracle import behavior_oracle as B
+    x = seeded_randn("an.x", (24, 40), 2) * 3.0 + 1.5
+    an = ActNorm(40, logdet=True).cuda()
+    h, logdet = an(x.cuda())
+    mean, std = x.mean(0), x.std(0)
+    close(an.loc.reshape(-1), -mean, rtol=1e-5, atol=1e-6)
+    close(an.scale.reshape(-1), 1.0 / (std + 1e-6), rtol=1e-5, atol=1e-6)
+    assert int(an.initialized.item()) == 1
+    close(h, (x - mean) / (std + 1e-6) * 1.0, rtol=1e-4, atol=1e-5)
+    close(logdet, torch.log(1.0 / (std + 1e-6)).sum().expand(24), rtol=1e-5, atol=1e-4)
+    close(an.reverse(h), x, rtol=1e-4, atol=1e-5)
+    # a fresh flow: after the first forward every block is initialised and its input statistics were normalised
+    from behavior_driven_video_synthesis_amd.models.flow.simple_flow import UnsupervisedTransformer2
+    torch.manual_seed(4)
+    flow = UnsupervisedTransformer2(flow_in_channels=32, flow_mid_channels=64, flow_hidden_depth=1, n_flows=3).cuda()
+    xb = (seeded_randn("an.flow", (32, 32), 2) * 2.0 - 0.5).cuda()
+    out, logdet = flow(xb)
+    assert all(int(blk.norm_layer.initialized.item()) == 1 for blk in flow.flow.sub_layers)
+    sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+    o_ref, l_ref = B.flow_forward(sd, xb.cpu())          # the oracle with the parameters the init produced
+    close(out.reshape(32, 32), o_ref, **FLOW_TOL)
+    close(logdet, l_ref, rtol=1e-4, atol=1e-3)
+    close(sd["flow.sub_layers.0.norm_layer.loc"].reshape(-1), -xb.cpu().mean(0), rtol=1e-5, atol=1e-6)
+    out2, _ = flow(xb)                                     # second call: the fused, graph-replayed pass
+    close(out2, out, rtol=1e-5, atol=1e-6)
+
+
+def test_stand_alone_mlp_and_the_cpu_refusal():
+    from behavior_driven_video_synthesis_amd.lib.modules import BasicFullyConnectedNet
+    from oracle import behavior_oracle as B
+    for tanh in (False, True):
+        net = BasicFullyConnectedNet(dim=17, depth=2, hidden_dim=48, use_tanh=tanh, out_dim=9)
+        sd = synth_behavior_state({k: list(v.shape) for k, v in net.state_dict().items()}, 6, {})
+        net.load_state_dict(sd)
+        x = seeded_randn("mlp.x", (70, 17), 6)
+        close(net.cuda()(x.cuda()), B.fully_connected({"p." + k: v for k, v in sd.items()}, "p", x, tanh))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(x)
