@@ -1,23 +1,28 @@
 // Behaviour front half of BASELINE config 5: flow sample -> pose_behavior_rnn decode, on pose vectors [B, n_kps] and behaviour
 // codes [B, C] (experiments/behavior_net.py:1086-1100, :1173-1184).
 //
-// Everything here is a chain of skinny matrix products  Y[B, M] = f(X)[B, K] . W[M, K]^T  with B <= 64 rows and weights of
+// Everything here is a chain of skinny matrix products  Y[B, M] = act(X[B, K] . W[M, K]^T + b)  with B <= 64 rows and weights of
 // 0.2 - 17 MB per layer (the flow of config/behavior_net.yaml: 60 MLPs of 512-2048-2048-2048-512, 2.5 GB of fp32 weights per
 // sample pass; the decoder: one [4096, 1075] gate matrix read 50 times).  Each weight is used once per pass, so the bound is
 // the weight stream from HBM, not the matrix cores: the kernels are laid out for that.
 //
-//   * seq_linear_kernel: one wave owns 16 output rows; a K chunk of 32 is 128 contiguous bytes per weight row, two 16-byte
-//     loads per lane, eight v_mfma_f32_16x16x4_f32 (exact fp32: the reference computes in fp32) against the batch tile.  The
-//     four waves of a workgroup and the S_out workgroups of a row tile split K, so that even the 512-row layers put >= 256
-//     workgroups on the chip; a workgroup adds its waves through LDS and stores ONE partial slab, in a fixed order.  Nothing is
-//     reduced with atomics: the consumer adds the S partial slabs, the producing layer's bias and its activation while it loads
-//     its operand ("X = act(sum_s P[s] + bias)"), so an MLP is one launch per layer and bit-reproducible.  The s and t nets of
-//     a coupling (same input, same shapes) and the mu / logstd heads run as one launch (grid z).
+//   * seq_linear_kernel: a workgroup owns a 16-row tile of W (32 where that still fills the chip) over the whole K; a K chunk
+//     of 32 is 128 contiguous bytes per weight row, two 16-byte loads per lane, eight v_mfma_f32_16x16x4_f32 per tile (exact
+//     fp32: the reference computes in fp32) against the batch tile.  The four waves split K by chunks and add through LDS in
+//     wave order; wave 0 adds the bias, applies the activation and stores the layer's output, so the next layer reads a plain
+//     operand.  K is NOT split over workgroups.  Two split forms were built and measured (profiles/r05_seq_time.txt):
+//     (1) partial slabs summed, with bias + LeakyReLU, by the consumer's loads: every 16-row tile of the next layer re-read every
+//     slab of X from L2 -- 100 MB of L1 fills for a 33 MB layer, 17.5 us where the weights stream in 5 (a CU fills its L1 at
+//     <= 70 GB/s from L2; MI355X_MICROARCH.md "Indexed rows"); (2) the last workgroup to arrive at a tile's counter adds the
+//     slabs: behind __threadfence() +10 us per launch (buffer_wbl2 + buffer_inv), behind sc1 stores / loads and an agent
+//     atomic wrong results on partial-line slabs.  Without a split the 2048-row layers still put 256 workgroups on the chip;
+//     the 512-row heads (8 MB) run on 64 CUs and take what the split forms took.  The s and t nets of a coupling (same
+//     input, same shapes) and the mu / logstd heads run as one launch (grid z).
 //   * seq_coupling_kernel: everything between two MLP evaluations of the flow -- the affine coupling itself, the half swap,
 //     ``Shuffle`` and ``ActNorm`` -- as "v = couple(in); out[c] = affine(v[map[c]])" with a host-composed index map.
-//   * seq_lstm_kernel: the gate nonlinearities and state update of one LSTM step from the gate partials, the decoder's output
-//     layer + residual (``ResidualRNNDecoder.forward``), the optional input layer, and the next step's operand row
-//     [x | 0 | h] -- one workgroup per batch row, two launches per time step.
+//   * seq_lstm_{enc,dec}_kernel: the gate nonlinearities and state update of one LSTM step, the decoder's output layer +
+//     residual (``ResidualRNNDecoder.forward``) and the next step's operand row [x | 0 | h]; two launches per time step.  The
+//     decoder's optional input layer is folded into the gate matrix when the weights are packed.
 #include "common.h"
 
 namespace {
@@ -25,114 +30,153 @@ namespace {
 constexpr int SEQ_MAX_NB = 4;   // batch tiles of 16: B <= 64
 
 struct SeqLinearArgs {
-  const float* w[2];        // [M][K] row-major, M % 16 == 0, K % 32 == 0 (zero padded)
-  const float* xin;         // [nets_in][S_in][Bp][ldx]
-  const float* bias_in[2];  // [K] bias of the layer that produced xin's partials (NULL: none)
-  float* out;               // [nets][S_out][Bp][M]
-  int M, K, Bp, ldx, S_in, S_out, act_in, shared_in;
+  const float* w[2];      // [M][K] row-major, M % 16 == 0, K % 32 == 0 (zero padded)
+  const float* x;         // [nets_in][Bp][ldx]
+  const float* bias[2];   // [M] (NULL: none)
+  float* y;               // [nets][Bp][M]
+  int M, K, Bp, ldx, act[2], shared_in;
 };
 
-__device__ __forceinline__ float4 seq_act4(float4 v, int act) {
-  if (act == 1) {   // nn.LeakyReLU() default slope 0.01 (lib/modules.py:244)
-    v.x = v.x > 0.f ? v.x : 0.01f * v.x;
-    v.y = v.y > 0.f ? v.y : 0.01f * v.y;
-    v.z = v.z > 0.f ? v.z : 0.01f * v.z;
-    v.w = v.w > 0.f ? v.w : 0.01f * v.w;
-  }
-  return v;
-}
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// grid (M/16, S_out, nets), 256 threads.  Lane l of a wave: i = l & 15 (weight row / batch row), kq = l >> 4; in a K chunk of 32
-// it holds k = 8 kq .. 8 kq + 7 of its row -- the same k for the A (weights) and B (batch) operand of MFMA step j = 0..7.
-template <int NB>
-__global__ __launch_bounds__(256) void seq_linear_kernel(SeqLinearArgs a) {
-  __shared__ float4 red[3][NB][64];
+__device__ __forceinline__ float seq_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.01f * v);   // nn.LeakyReLU() default slope 0.01 (lib/modules.py:244)
+  if (act == 2) return tanhf(v);              // the scale nets' head (lib/modules.py:252-253)
+  return v;
+}
+
+// The weight stream is the cost and a wave has few chunks (2 - 8), so what matters is bytes in flight: a group of U chunks
+// issues all of its loads (weights of RT tiles, the operand of NB batch tiles) before the first MFMA.  The scheduling barrier
+// keeps it that way: without it the scheduler interleaves loads and uses to save registers and keeps ~7 loads in flight.
+template <int NB, int RT, int U, int WAVES>
+__device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const float* __restrict__ w, const float* __restrict__ x, int c0,
+                                                 f32x4 (&acc)[RT][NB]) {
+  float4 wv[RT][U][2], xv[NB][U][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* wp = w + (size_t)rt * 16 * a.K + 32 * (c0 + WAVES * u);
+      wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
+      wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 4);
+    }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* xp = x + (size_t)nb * 16 * a.ldx + 32 * (c0 + WAVES * u);
+      xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
+      xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 4);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float wa[8] = {wv[rt][u][0].x, wv[rt][u][0].y, wv[rt][u][0].z, wv[rt][u][0].w,
+                           wv[rt][u][1].x, wv[rt][u][1].y, wv[rt][u][1].z, wv[rt][u][1].w};
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float xb[8] = {xv[nb][u][0].x, xv[nb][u][0].y, xv[nb][u][0].z, xv[nb][u][0].w,
+                             xv[nb][u][1].x, xv[nb][u][1].y, xv[nb][u][1].z, xv[nb][u][1].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[rt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[j], acc[rt][nb], 0, 0, 0);
+      }
+    }
+}
+
+// grid (M / (16 RT), 1, nets), 64 WAVES threads.  Lane l of a wave: i = l & 15 (weight row / batch row), kq = l >> 4; in a K chunk
+// of 32 it holds k = 8 kq .. 8 kq + 7 of its row -- the same k for the A (weights) and B (batch) operand of MFMA step j = 0..7.
+// D: lane holds batch row n = l & 15 of its tile, output rows 4 (l >> 4) + r of the weight tile.
+// WAVES = 16 where K has >= 16 chunks: a wave's groups are sequential round trips to HBM (four waves with 16 chunks each took
+// 12 us for a layer whose weights stream in 5); with 16 waves the whole tile's weights are requested at once.
+template <int NB, int RT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a) {
+  __shared__ float4 red[WAVES - 1][RT][NB][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * 16, split = blockIdx.y, net = blockIdx.z;
-  const int kb = a.K / a.S_out, nchunk = kb >> 5;
-  const float* __restrict__ w = a.w[net] + (size_t)(m0 + i) * a.K + (size_t)split * kb + 8 * kq;
-  const size_t slab_in = (size_t)a.Bp * a.ldx;
-  const float* __restrict__ x = a.xin + (a.shared_in ? 0 : (size_t)net * a.S_in * slab_in) + (size_t)i * a.ldx + (size_t)split * kb + 8 * kq;
-  const float* __restrict__ bias = a.bias_in[net] ? a.bias_in[net] + (size_t)split * kb + 8 * kq : nullptr;
-  f32x4 acc[NB];
+  const int m0 = blockIdx.x * 16 * RT, net = blockIdx.z;
+  const int nchunk = a.K >> 5;
+  const float* __restrict__ w = a.w[net] + (size_t)(m0 + i) * a.K + 8 * kq;
+  const float* __restrict__ x = a.x + (a.shared_in ? 0 : (size_t)net * a.Bp * a.ldx) + (size_t)i * a.ldx + 8 * kq;
+  f32x4 acc[RT][NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int c = wave; c < nchunk; c += 4) {
-    const float4 w0 = *reinterpret_cast<const float4*>(w + 32 * c), w1 = *reinterpret_cast<const float4*>(w + 32 * c + 4);
-    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-    if (bias) {
-      b0 = *reinterpret_cast<const float4*>(bias + 32 * c);
-      b1 = *reinterpret_cast<const float4*>(bias + 32 * c + 4);
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this wave's chunks: wave, wave + WAVES, ... (ascending k; the order of the sums is fixed by the geometry alone)
+  int c = wave;
+  // (16 waves share the CU's registers: 128 each)
+  constexpr int UMAX = WAVES == 16 ? (NB == 1 ? 4 : NB == 2 ? 2 : 1) : ((NB + RT <= 3) ? 4 : 2);
+  for (; c + WAVES * (UMAX - 1) < nchunk; c += WAVES * UMAX) seq_linear_group<NB, RT, UMAX, WAVES>(a, w, x, c, acc);
+  if constexpr (UMAX == 4)
+    if (c + WAVES < nchunk) {
+      seq_linear_group<NB, RT, 2, WAVES>(a, w, x, c, acc);
+      c += 2 * WAVES;
     }
-    const float wa[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const float* xp = x + (size_t)nb * 16 * a.ldx + 32 * c;
-      float4 x0 = b0, x1 = b1;
-      for (int s = 0; s < a.S_in; ++s) {
-        x0 = add4(x0, *reinterpret_cast<const float4*>(xp + s * slab_in));
-        x1 = add4(x1, *reinterpret_cast<const float4*>(xp + s * slab_in + 4));
-      }
-      x0 = seq_act4(x0, a.act_in);
-      x1 = seq_act4(x1, a.act_in);
-      const float xb[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[j], acc[nb], 0, 0, 0);
-    }
-  }
-  // waves 1..3 -> LDS; wave 0 adds them in wave order and stores the slab.  D: lane holds batch row n = l & 15 of its tile,
-  // output rows m0 + 4 (l >> 4) + r.
+  if constexpr (UMAX > 1)
+    for (; c < nchunk; c += WAVES) seq_linear_group<NB, RT, 1, WAVES>(a, w, x, c, acc);
+  // waves 1.. -> LDS; wave 0 adds them in wave order
   if (wave) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) red[wave - 1][nb][lane] = make_float4(acc[nb][0], acc[nb][1], acc[nb][2], acc[nb][3]);
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        red[wave - 1][rt][nb][lane] = make_float4(acc[rt][nb][0], acc[rt][nb][1], acc[rt][nb][2], acc[rt][nb][3]);
   }
   __syncthreads();
-  if (wave == 0) {
-    float* out = a.out + ((size_t)net * a.S_out + split) * a.Bp * a.M + m0 + 4 * kq;
+  if (wave) return;
+  float4 v[RT][NB];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      float4 v = make_float4(acc[nb][0], acc[nb][1], acc[nb][2], acc[nb][3]);
+      v[rt][nb] = make_float4(acc[rt][nb][0], acc[rt][nb][1], acc[rt][nb][2], acc[rt][nb][3]);
+#pragma unroll 3
+      for (int q = 0; q < WAVES - 1; ++q) v[rt][nb] = add4(v[rt][nb], red[q][rt][nb][lane]);
+    }
+  const size_t col = (size_t)m0 + 4 * kq;   // + 16 rt; row n = 16 nb + i
+  float* y = a.y + (size_t)net * a.Bp * a.M + col;
+  const float* bias = a.bias[net];
+  const int act = a.act[net];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) v = add4(v, red[q][nb][lane]);
-      *reinterpret_cast<float4*>(out + (size_t)(nb * 16 + i) * a.M) = v;
+  for (int rt = 0; rt < RT; ++rt) {
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + col + 16 * rt);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float4 t = add4(v[rt][nb], bv);
+      t = make_float4(seq_act(t.x, act), seq_act(t.y, act), seq_act(t.z, act), seq_act(t.w, act));
+      *reinterpret_cast<float4*>(y + (size_t)(nb * 16 + i) * a.M + 16 * rt) = t;
     }
   }
 }
 
 struct SeqCouplingArgs {
   const float* in;       // [B..][ld_in]: xa = in[b][0..c1), xk = in[b][c1..C)
-  const float* st;       // [2][S][Bp][Mp] partials of the s net (0) and the t net (1); NULL: no coupling (v = in)
-  const float* bias_s;   // [c2]
-  const float* bias_t;
+  const float* st;       // [2][Bp][Mp]: s = tanh(scale net) (0) and t = translation net (1); NULL: no coupling (v = in)
   const int* map;        // [C] out[c] = v[map[c]]; NULL: identity
   const float* scale;    // [C] ActNorm scale / loc (NULL: none)
   const float* loc;
   float* out;            // [B..][ld_out]
   float* logdet;         // [B] forward only: += sum(s) + sum log|scale|
-  int B, Bp, C, c1, ld_in, ld_out, S, Mp, reverse, affine_on_src;
+  int B, Bp, C, c1, ld_in, ld_out, Mp, reverse, affine_on_src;
 };
 
-// grid B, 256 threads: one batch row per workgroup.
+// grid (B, Y), 256 threads: batch row b, channels blockIdx.y * 256 + t, + 256 Y, ...  With a log-determinant to accumulate Y = 1
+// (one workgroup owns the row's sum: fixed order, no atomics); otherwise the channels spread over the chip.
 __global__ __launch_bounds__(256) void seq_coupling_kernel(SeqCouplingArgs a) {
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float* in = a.in + (size_t)b * a.ld_in;
-  const size_t slab = (size_t)a.Bp * a.Mp;
   float ld_sum = 0.f;
-  for (int c = threadIdx.x; c < a.C; c += 256) {
+  for (int c = blockIdx.y * 256 + threadIdx.x; c < a.C; c += 256 * gridDim.y) {
     const int j = a.map ? a.map[c] : c;
     float v = in[j];
     if (a.st && j >= a.c1) {
       const int q = j - a.c1;
-      float s = a.bias_s[q], t = a.bias_t[q];
-      for (int p = 0; p < a.S; ++p) {
-        s += a.st[p * slab + (size_t)b * a.Mp + q];
-        t += a.st[(a.S + p) * slab + (size_t)b * a.Mp + q];
-      }
-      s = tanhf(s);   // BasicFullyConnectedNet(use_tanh=True) is the scale net (models/flow/blocks.py:283-287)
-      if (a.reverse) v = (v - t) * expf(-s);   // :316
+      const float s = a.st[(size_t)b * a.Mp + q], t = a.st[((size_t)a.Bp + b) * a.Mp + q];
+      if (a.reverse) v = (v - t) * expf(-s);   // models/flow/blocks.py:316
       else {
         v = v * expf(s) + t;                   // :304
         ld_sum += s;                           // :306
@@ -158,100 +202,107 @@ __global__ __launch_bounds__(256) void seq_coupling_kernel(SeqCouplingArgs a) {
 }
 
 struct SeqLstmArgs {
-  const float* gates;   // [S][Bp][4 H] partials of [W_ih | 0 | W_hh] . [x | 0 | h]
+  const float* gates;   // [Bp][4 H]: [W_ih | 0 | W_hh] . [x | 0 | h]
   const float* bias;    // [4 H] b_ih
   const float* bias2;   // [4 H] b_hh
-  float* c;             // [Bp][H] cell state, in place
+  const float* bias3;   // [4 H] W_ih b_in of a folded input layer (NULL: none)
+  const float* c_in;    // [Bp][H] cell state of the previous step
+  float* c_out;         // [Bp][H] (a different buffer: every workgroup of a row reads c_in)
   float* xh;            // [Bp][ldx] operand row of the next step: x at 0, h at hoff
   float* h_out;         // [Bp][H] copy of h (NULL: none) -- the encoder's ``pre``
-  // decoder (w_out != NULL): x' = n_out(h) + x, xs[b] = x', cs[b] = x; the next operand is n_in(x') or x'
+  // decoder (w_out != NULL): x' = n_out(h) + x, xs[b] = x', cs[b] = x; x' is the next operand
   const float* w_out;   // [n][H]
   const float* b_out;
-  const float* w_in;    // [n][n] (NULL: ``linear_in_decoder`` off)
-  const float* b_in;
-  float* xraw;          // [Bp][64-padded n] the step's input pose (the residual), replaced by x'
+  float* xraw;          // [Bp][ldraw] the step's input pose (the residual), replaced by x'
   float* xs;            // row b at xs + b * seq_stride
   float* cs;
   // encoder (w_out == NULL): the next input comes from the sequence
   const float* x_next;  // row b at x_next + b * seq_stride (NULL at the last step)
   long long seq_stride;
-  int B, Bp, H, S, ldx, hoff, n, ldraw;
+  int B, Bp, H, ldx, hoff, n, ldraw;
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-// grid B, 256 threads, dynamic LDS: H + 64-padded n floats
-__global__ __launch_bounds__(256) void seq_lstm_kernel(SeqLstmArgs a) {
-  extern __shared__ float lds[];
-  float* hs = lds;
-  float* xn = lds + a.H;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t slab = (size_t)a.Bp * 4 * a.H;
-  for (int j = threadIdx.x; j < a.H; j += 256) {
-    float g[4];
+// gate order i, f, g, o (torch.nn.LSTMCell, models/pose_behavior_rnn.py:476, :498)
+__device__ __forceinline__ float seq_lstm_cell(const SeqLstmArgs& a, int b, int j, float& c2) {
+  float g[4];
+  const float* gp = a.gates + (size_t)b * 4 * a.H + j;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v = a.bias[q * a.H + j] + a.bias2[q * a.H + j];
-      for (int s = 0; s < a.S; ++s) v += a.gates[s * slab + (size_t)b * 4 * a.H + q * a.H + j];
-      g[q] = v;
-    }
-    // gate order i, f, g, o (torch.nn.LSTMCell, models/pose_behavior_rnn.py:476, :498)
-    const float c2 = sigmoid_f(g[1]) * a.c[(size_t)b * a.H + j] + sigmoid_f(g[0]) * tanhf(g[2]);
-    const float h = sigmoid_f(g[3]) * tanhf(c2);
-    a.c[(size_t)b * a.H + j] = c2;
+  for (int q = 0; q < 4; ++q) {
+    g[q] = a.bias[q * a.H + j] + a.bias2[q * a.H + j];
+    if (a.bias3) g[q] += a.bias3[q * a.H + j];
+    g[q] += gp[q * a.H];
+  }
+  c2 = sigmoid_f(g[1]) * a.c_in[(size_t)b * a.H + j] + sigmoid_f(g[0]) * tanhf(g[2]);
+  return sigmoid_f(g[3]) * tanhf(c2);
+}
+
+// encoder step: grid (B, H / 256): one thread per hidden unit
+__global__ __launch_bounds__(256) void seq_lstm_enc_kernel(SeqLstmArgs a) {
+  const int b = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+  if (j < a.H) {
+    float c2;
+    const float h = seq_lstm_cell(a, b, j, c2);
+    a.c_out[(size_t)b * a.H + j] = c2;
     a.xh[(size_t)b * a.ldx + a.hoff + j] = h;
     if (a.h_out) a.h_out[(size_t)b * a.H + j] = h;
-    hs[j] = h;
   }
-  if (!a.w_out) {
-    if (a.x_next)
-      for (int r = threadIdx.x; r < a.n; r += 256) a.xh[(size_t)b * a.ldx + r] = a.x_next[b * a.seq_stride + r];
-    return;
+  if (a.x_next && j < a.n) a.xh[(size_t)b * a.ldx + j] = a.x_next[b * a.seq_stride + j];
+}
+
+// decoder step: grid (B, ceil(n / 8)), 256 threads, dynamic LDS: H floats.  Every workgroup of a row recomputes the row's h
+// (1024 units: ~80 L2 loads per thread) so that the 51 output rows spread over 7 workgroups instead of queueing in one; wave w
+// of workgroup y owns output rows 8 y + w and 8 y + w + 4.  Workgroup y = 0 publishes c and h.
+__global__ __launch_bounds__(256) void seq_lstm_dec_kernel(SeqLstmArgs a) {
+  extern __shared__ float hs[];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < a.H; j += 256) {
+    float c2;
+    const float h = seq_lstm_cell(a, b, j, c2);
+    hs[j] = h;
+    if (blockIdx.y == 0) {
+      a.c_out[(size_t)b * a.H + j] = c2;
+      a.xh[(size_t)b * a.ldx + a.hoff + j] = h;
+      if (a.h_out) a.h_out[(size_t)b * a.H + j] = h;
+    }
   }
   __syncthreads();
-  for (int r = wave; r < a.n; r += 4) {   // out = n_out(h) + res (:504-506)
-    const float* wr = a.w_out + (size_t)r * a.H;
-    float s = 0.f;
-    for (int j = lane; j < a.H; j += 64) s += wr[j] * hs[j];
-    s = wave_sum(s);
-    if (lane == 0) {
+  const int r0 = blockIdx.y * 8 + wave, r1 = r0 + 4;
+  const bool v0 = r0 < a.n, v1 = r1 < a.n;
+  const float* w0 = a.w_out + (size_t)(v0 ? r0 : 0) * a.H;
+  const float* w1 = a.w_out + (size_t)(v1 ? r1 : 0) * a.H;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+  for (int j = lane; j < a.H; j += 64) {   // out = n_out(h) + res (:504-506)
+    const float h = hs[j];
+    s0 += w0[j] * h;
+    s1 += w1[j] * h;
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = q ? r1 : r0;
+      if (r >= a.n) continue;
       const float res = a.xraw[(size_t)b * a.ldraw + r];
-      const float x2 = (s + a.b_out[r]) + res;
+      const float x2 = ((q ? s1 : s0) + a.b_out[r]) + res;
       a.xs[b * a.seq_stride + r] = x2;
       a.cs[b * a.seq_stride + r] = res;
       a.xraw[(size_t)b * a.ldraw + r] = x2;
-      xn[r] = x2;
+      a.xh[(size_t)b * a.ldx + r] = x2;
     }
-  }
-  __syncthreads();
-  for (int r = threadIdx.x; r < a.n; r += 256) {
-    float v = xn[r];
-    if (a.w_in) {   // x = n_in(x) in front of the cell (:494-495)
-      v = a.b_in[r];
-      for (int q = 0; q < a.n; ++q) v += a.w_in[(size_t)r * a.n + q] * xn[q];
-    }
-    a.xh[(size_t)b * a.ldx + r] = v;
   }
 }
 
-// first operand row [x0 | 0 | h0] and the initial state; grid B, 256 threads, LDS: 64-padded n floats
+// first operand row [x0 | 0 | h0] and the initial state; grid B, 256 threads
 __global__ __launch_bounds__(256) void seq_start_kernel(const float* x0, long long x0_stride, const float* h0, const float* c0,
-                                                        const float* w_in, const float* b_in, float* xraw, int ldraw, float* xh,
-                                                        int ldx, int hoff, float* c, int n, int H) {
-  extern __shared__ float lds[];
+                                                        float* xraw, int ldraw, float* xh, int ldx, int hoff, float* c, int n, int H) {
   const int b = blockIdx.x;
   for (int r = threadIdx.x; r < n; r += 256) {
     const float v = x0[b * x0_stride + r];
-    lds[r] = v;
     if (xraw) xraw[(size_t)b * ldraw + r] = v;
-  }
-  __syncthreads();
-  for (int r = threadIdx.x; r < n; r += 256) {
-    float v = lds[r];
-    if (w_in) {
-      v = b_in[r];
-      for (int q = 0; q < n; ++q) v += w_in[(size_t)r * n + q] * lds[q];
-    }
     xh[(size_t)b * ldx + r] = v;
   }
   for (int j = threadIdx.x; j < H; j += 256) {
@@ -260,35 +311,29 @@ __global__ __launch_bounds__(256) void seq_start_kernel(const float* x0, long lo
   }
 }
 
-// mu = sum_s P0[s] + bias0, logstd = sum_s P1[s] + bias1, b = eps * exp(logstd) + mu  (models/pose_behavior_rnn.py:180-201)
-__global__ __launch_bounds__(256) void seq_bottleneck_kernel(const float* part, int S, int Bp, int Mp, const float* bias_mu,
-                                                             const float* bias_std, const float* eps, float* mu, float* logstd,
-                                                             float* bout, int B, int H) {
+// ``linear_in_decoder``: x = n_in(x) in front of the cell (models/pose_behavior_rnn.py:494-495) folded into the gate matrix:
+// W_ih (W_in x + b_in) = (W_ih W_in) x + W_ih b_in.  One thread per element of the [M][n] product; bias by column n.
+__global__ __launch_bounds__(256) void seq_fold_input_kernel(const float* w_ih, const float* w_in, const float* b_in, int M, int n,
+                                                             float* w_fold, float* bias_fold) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * (n + 1)) return;
+  const int m = idx / (n + 1), q = idx - m * (n + 1);
+  float s = 0.f;
+  for (int r = 0; r < n; ++r) s += w_ih[(size_t)m * n + r] * (q < n ? w_in[(size_t)r * n + q] : b_in[r]);
+  if (q < n) w_fold[(size_t)m * n + q] = s;
+  else bias_fold[m] = s;
+}
+
+// heads: [2][Bp][Mp] = (mu, logstd) from seq_linear_kernel; b = eps * exp(logstd) + mu  (models/pose_behavior_rnn.py:180-201)
+__global__ __launch_bounds__(256) void seq_bottleneck_kernel(const float* heads, int Bp, int Mp, const float* eps, float* mu,
+                                                             float* logstd, float* bout, int B, int H) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= B * H) return;
   const int b = idx / H, j = idx - b * H;
-  const size_t slab = (size_t)Bp * Mp;
-  float m = bias_mu[j], l = bias_std[j];
-  for (int s = 0; s < S; ++s) {
-    m += part[s * slab + (size_t)b * Mp + j];
-    l += part[(S + s) * slab + (size_t)b * Mp + j];
-  }
+  const float m = heads[(size_t)b * Mp + j], l = heads[((size_t)Bp + b) * Mp + j];
   mu[idx] = m;
   logstd[idx] = l;
   if (bout) bout[idx] = eps ? eps[idx] * expf(l) + m : m;
-}
-
-// out[b][j] = act(sum_s part[s][b][j] + bias[j]): the value of a layer whose consumer is not one of the kernels above
-__global__ __launch_bounds__(256) void seq_finish_kernel(const float* part, int S, int Bp, int Mp, const float* bias, int act, float* out,
-                                                         int ld_out, int B, int M) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= B * M) return;
-  const int b = idx / M, j = idx - b * M;
-  float v = bias ? bias[j] : 0.f;
-  for (int s = 0; s < S; ++s) v += part[(size_t)s * Bp * Mp + (size_t)b * Mp + j];
-  if (act == 1) v = v > 0.f ? v : 0.01f * v;
-  else if (act == 2) v = tanhf(v);
-  out[(size_t)b * ld_out + j] = v;
 }
 
 // dst[m][col_off + k] = src[m][k] * (row_scale ? row_scale[m] : 1) for m < M, k < K; dst is a zero-filled padded image
@@ -335,7 +380,50 @@ __global__ __launch_bounds__(256) void seq_actnorm_init_kernel(const float* x, i
   scale[c] = 1.f / (sqrtf(v / (float)(B - 1)) + 1e-6f);
 }
 
+// Decoded pose vectors -> pixel keypoints, what the reference does per frame in numpy (float64, since its camera matrix is):
+// unNormalizeData (data/data_conversions_3d.py:178-211): full[dims_to_use] = x, full = full * std + mean;
+// apply_affine_transform (:588-605): cam = [R | t] . (X, 1); camera_projection (:892-912): (u, v) = (fx X/Z + x0, fy Y/Z + y0);
+// then the joint rescale to the synthesis resolution (:1139-1140).  One thread per (frame, joint).
+__global__ __launch_bounds__(256) void seq_pose_project_kernel(const float* x, int n_use, const int* dims_to_use, const double* mean,
+                                                               const double* stdv, int f32_math, const double* cam, float* kps, int T,
+                                                               int J) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * J) return;
+  const int t = idx / J, j = idx - t * J;
+  double p[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int d = 3 * j + a;
+    // position of dimension d among the used ones (dims_to_use is ascending); unused dimensions hold 0 * std + mean
+    int lo = 0, hi = n_use;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (dims_to_use[mid] < d) lo = mid + 1;
+      else hi = mid;
+    }
+    const float v = (lo < n_use && dims_to_use[lo] == d) ? x[(size_t)t * n_use + lo] : 0.f;
+    // numpy's promotion: float32 arithmetic when the statistics are float32 arrays, float64 when they are float64
+    p[a] = f32_math ? (double)(v * (float)stdv[d] + (float)mean[d]) : (double)v * stdv[d] + mean[d];
+  }
+  // cam: 12 doubles of [R | t] row-major, then fx, x0, fy, y0, then the two rescale factors
+  double c[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) c[r] = ((p[0] * cam[4 * r] + p[1] * cam[4 * r + 1]) + p[2] * cam[4 * r + 2]) + cam[4 * r + 3];
+  const double xn = c[0] / c[2], yn = c[1] / c[2], zn = c[2] / c[2];
+  const double u = (xn * cam[12] + yn * 0.0) + zn * cam[13], w = (xn * 0.0 + yn * cam[14]) + zn * cam[15];
+  kps[2 * (size_t)idx] = (float)(u * cam[16]);
+  kps[2 * (size_t)idx + 1] = (float)(w * cam[17]);
+}
+
 }  // namespace
+
+extern "C" int vunet_seq_pose_project(const float* x, int32_t n_use, const int32_t* dims_to_use, const double* mean, const double* stdv,
+                                      int32_t D, int32_t f32_math, const double* cam, float* kps, int32_t T, int32_t J, void* stream) {
+  if (!x || !dims_to_use || !mean || !stdv || !cam || !kps || n_use < 1 || T < 1 || J < 1 || D < 3 * J) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(seq_pose_project_kernel, dim3((T * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n_use, dims_to_use, mean,
+               stdv, f32_math, cam, kps, T, J);
+  return vunet_check_launch();
+}
 
 extern "C" int vunet_seq_actnorm_init(const float* x, int32_t ld, int32_t B, int32_t C, float* loc, float* scale, void* stream) {
   if (!x || !loc || !scale || B < 2 || C < 1 || ld < C) return VUNET_ERR_ARG;
@@ -343,51 +431,63 @@ extern "C" int vunet_seq_actnorm_init(const float* x, int32_t ld, int32_t B, int
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* xin,
-                                const float* bias_in0, const float* bias_in1, float* out, void* stream) {
-  if (!d || !w0 || !xin || !out) return VUNET_ERR_ARG;
+// rows per workgroup tile: 32 (two MFMA tiles per wave share the operand registers: half the operand traffic per weight byte)
+// where that still leaves 256 workgroups, else 16
+static int seq_row_tiles(const vunet_seq_linear_desc* d) {
+  return (d->M % 32 == 0 && (d->M / 32) * d->nets >= 256) ? 2 : 1;
+}
+
+extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* x, const float* bias0,
+                                const float* bias1, float* y, void* stream) {
+  if (!d || !w0 || !x || !y) return VUNET_ERR_ARG;
   if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
-  if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->M < 16 || d->M % 16 || d->S_in < 1 || d->S_out < 1) return VUNET_ERR_ARG;
-  if (d->K < 32 || d->K % (32 * d->S_out) || d->ldx < d->K || d->ldx % 4) return VUNET_ERR_ARG;
-  if (d->act_in < 0 || d->act_in > 1) return VUNET_ERR_ARG;
+  if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->M < 16 || d->M % 16) return VUNET_ERR_ARG;
+  if (d->K < 32 || d->K % 32 || d->ldx < d->K || d->ldx % 4) return VUNET_ERR_ARG;
+  if (d->act0 < 0 || d->act0 > 2 || d->act1 < 0 || d->act1 > 2) return VUNET_ERR_ARG;
   SeqLinearArgs a;
   a.w[0] = w0;
   a.w[1] = w1;
-  a.xin = xin;
-  a.bias_in[0] = bias_in0;
-  a.bias_in[1] = bias_in1;
-  a.out = out;
+  a.x = x;
+  a.bias[0] = bias0;
+  a.bias[1] = bias1;
+  a.y = y;
   a.M = d->M;
   a.K = d->K;
   a.Bp = (d->B + 15) / 16 * 16;
   a.ldx = d->ldx;
-  a.S_in = d->S_in;
-  a.S_out = d->S_out;
-  a.act_in = d->act_in;
+  a.act[0] = d->act0;
+  a.act[1] = d->act1;
   a.shared_in = d->shared_in;
-  const dim3 grid(d->M / 16, d->S_out, d->nets);
+  const int rt = seq_row_tiles(d);
+  const dim3 grid(d->M / (16 * rt), 1, d->nets);
   hipStream_t st = (hipStream_t)stream;
+  const bool wide = rt == 1 && d->K >= 16 * 32;   // 16 waves: at least one chunk each
+#define SEQ_LINEAR_CASE(NB)                                                                   \
+  case NB:                                                                                    \
+    if (rt == 2) VUNET_LAUNCH((seq_linear_kernel<NB, 2, 4>), grid, dim3(256), 0, st, a);      \
+    else if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16>), grid, dim3(1024), 0, st, a);  \
+    else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4>), grid, dim3(256), 0, st, a);              \
+    break;
   switch (a.Bp / 16) {
-    case 1: VUNET_LAUNCH(seq_linear_kernel<1>, grid, dim3(256), 0, st, a); break;
-    case 2: VUNET_LAUNCH(seq_linear_kernel<2>, grid, dim3(256), 0, st, a); break;
-    case 3: VUNET_LAUNCH(seq_linear_kernel<3>, grid, dim3(256), 0, st, a); break;
-    default: VUNET_LAUNCH(seq_linear_kernel<4>, grid, dim3(256), 0, st, a); break;
+    SEQ_LINEAR_CASE(1)
+    SEQ_LINEAR_CASE(2)
+    SEQ_LINEAR_CASE(3)
+    SEQ_LINEAR_CASE(4)
+    default: return VUNET_ERR_ARG;
   }
+#undef SEQ_LINEAR_CASE
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const float* bias_s,
-                                  const float* bias_t, const int32_t* map, const float* scale, const float* loc, float* out,
-                                  float* logdet, void* stream) {
+extern "C" int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const int32_t* map,
+                                  const float* scale, const float* loc, float* out, float* logdet, void* stream) {
   if (!d || !in || !out || d->B < 1 || d->C < 1 || d->ld_in < d->C || d->ld_out < d->C) return VUNET_ERR_ARG;
-  if (st && (!bias_s || !bias_t || d->S < 1 || d->c1 < 0 || d->c1 > d->C || d->Mp < d->C - d->c1)) return VUNET_ERR_ARG;
+  if (st && (d->c1 < 0 || d->c1 > d->C || d->Mp < d->C - d->c1)) return VUNET_ERR_ARG;
   if ((scale == nullptr) != (loc == nullptr)) return VUNET_ERR_ARG;
   if (in == out && map) return VUNET_ERR_ARG;   // a gather cannot run in place
   SeqCouplingArgs a;
   a.in = in;
   a.st = st;
-  a.bias_s = bias_s;
-  a.bias_t = bias_t;
   a.map = map;
   a.scale = scale;
   a.loc = loc;
@@ -399,45 +499,40 @@ extern "C" int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float*
   a.c1 = d->c1;
   a.ld_in = d->ld_in;
   a.ld_out = d->ld_out;
-  a.S = d->S;
   a.Mp = d->Mp;
   a.reverse = d->reverse;
   a.affine_on_src = d->affine_on_src;
-  VUNET_LAUNCH(seq_coupling_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, a);
+  VUNET_LAUNCH(seq_coupling_kernel, dim3(d->B, a.logdet ? 1 : (d->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_start(const float* x0, int64_t x0_stride, const float* h0, const float* c0, const float* w_in,
-                               const float* b_in, float* xraw, int32_t ldraw, float* xh, int32_t ldx, int32_t hoff, float* c,
-                               int32_t B, int32_t n, int32_t H, void* stream) {
+extern "C" int vunet_seq_start(const float* x0, int64_t x0_stride, const float* h0, const float* c0, float* xraw, int32_t ldraw,
+                               float* xh, int32_t ldx, int32_t hoff, float* c, int32_t B, int32_t n, int32_t H, void* stream) {
   if (!x0 || !xh || !c || B < 1 || n < 1 || H < 1 || hoff < n || ldx < hoff + H) return VUNET_ERR_ARG;
-  if ((w_in == nullptr) != (b_in == nullptr) || (xraw && ldraw < n)) return VUNET_ERR_ARG;
-  const size_t lds = (size_t)((n + 63) / 64 * 64) * sizeof(float);
-  VUNET_LAUNCH(seq_start_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x0, (long long)x0_stride, h0, c0, w_in, b_in, xraw,
-               ldraw, xh, ldx, hoff, c, n, H);
+  if (xraw && ldraw < n) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(seq_start_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x0, (long long)x0_stride, h0, c0, xraw, ldraw, xh, ldx,
+               hoff, c, n, H);
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_lstm_step(const vunet_seq_lstm_desc* d, const float* gates, const float* bias, const float* bias2, float* c,
-                                   float* xh, float* h_out, const float* w_out, const float* b_out, const float* w_in, const float* b_in,
-                                   float* xraw, float* xs, float* cs, const float* x_next, void* stream) {
-  if (!d || !gates || !bias || !bias2 || !c || !xh || d->B < 1 || d->H < 1 || d->S < 1 || d->n < 1) return VUNET_ERR_ARG;
+extern "C" int vunet_seq_lstm_step(const vunet_seq_lstm_desc* d, const float* gates, const float* bias, const float* bias2,
+                                   const float* bias3, const float* c_in, float* c_out, float* xh, float* h_out, const float* w_out,
+                                   const float* b_out, float* xraw, float* xs, float* cs, const float* x_next, void* stream) {
+  if (!d || !gates || !bias || !bias2 || !c_in || !c_out || c_in == c_out || !xh || d->B < 1 || d->H < 1 || d->n < 1)
+    return VUNET_ERR_ARG;
   if (d->hoff < d->n || d->ldx < d->hoff + d->H) return VUNET_ERR_ARG;
   if (w_out && (!b_out || !xraw || !xs || !cs || d->ldraw < d->n)) return VUNET_ERR_ARG;
-  if ((w_in == nullptr) != (b_in == nullptr)) return VUNET_ERR_ARG;
-  const size_t lds = (size_t)(d->H + (d->n + 63) / 64 * 64) * sizeof(float);
-  if (lds > 160 * 1024) return VUNET_ERR_UNSUPPORTED;
   SeqLstmArgs a;
   a.gates = gates;
   a.bias = bias;
   a.bias2 = bias2;
-  a.c = c;
+  a.bias3 = bias3;
+  a.c_in = c_in;
+  a.c_out = c_out;
   a.xh = xh;
   a.h_out = h_out;
   a.w_out = w_out;
   a.b_out = b_out;
-  a.w_in = w_in;
-  a.b_in = b_in;
   a.xraw = xraw;
   a.xs = xs;
   a.cs = cs;
@@ -446,32 +541,36 @@ extern "C" int vunet_seq_lstm_step(const vunet_seq_lstm_desc* d, const float* ga
   a.B = d->B;
   a.Bp = (d->B + 15) / 16 * 16;
   a.H = d->H;
-  a.S = d->S;
   a.ldx = d->ldx;
   a.hoff = d->hoff;
   a.n = d->n;
   a.ldraw = d->ldraw;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  VUNET_LAUNCH(seq_lstm_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (!w_out) {
+    if (d->n > 256) return VUNET_ERR_UNSUPPORTED;
+    VUNET_LAUNCH(seq_lstm_enc_kernel, dim3(d->B, (d->H + 255) / 256), dim3(256), 0, st, a);
+    return vunet_check_launch();
+  }
+  const size_t lds = (size_t)d->H * sizeof(float);
+  if (lds > 64 * 1024) return VUNET_ERR_UNSUPPORTED;
+  VUNET_LAUNCH(seq_lstm_dec_kernel, dim3(d->B, (d->n + 7) / 8), dim3(256), lds, st, a);
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_bottleneck(const float* part, int32_t S, int32_t Mp, const float* bias_mu, const float* bias_std,
-                                    const float* eps, float* mu, float* logstd, float* b_out, int32_t B, int32_t H, void* stream) {
-  if (!part || !bias_mu || !bias_std || !mu || !logstd || S < 1 || B < 1 || H < 1 || Mp < H) return VUNET_ERR_ARG;
-  const int Bp = (B + 15) / 16 * 16;
-  VUNET_LAUNCH(seq_bottleneck_kernel, dim3((B * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, S, Bp, Mp, bias_mu,
-               bias_std, eps, mu, logstd, b_out, B, H);
+extern "C" int vunet_seq_fold_input(const float* w_ih, const float* w_in, const float* b_in, int32_t M, int32_t n, float* w_fold,
+                                    float* bias_fold, void* stream) {
+  if (!w_ih || !w_in || !b_in || !w_fold || !bias_fold || M < 1 || n < 1) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(seq_fold_input_kernel, dim3((M * (n + 1) + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ih, w_in, b_in, M, n,
+               w_fold, bias_fold);
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_finish(const float* part, int32_t S, int32_t Mp, const float* bias, int32_t act, float* out, int32_t ld_out,
-                                int32_t B, int32_t M, void* stream) {
-  if (!part || !out || S < 1 || B < 1 || M < 1 || Mp < M || ld_out < M || act < 0 || act > 2) return VUNET_ERR_ARG;
+extern "C" int vunet_seq_bottleneck(const float* heads, int32_t Mp, const float* eps, float* mu, float* logstd, float* b_out, int32_t B,
+                                    int32_t H, void* stream) {
+  if (!heads || !mu || !logstd || B < 1 || H < 1 || Mp < H) return VUNET_ERR_ARG;
   const int Bp = (B + 15) / 16 * 16;
-  VUNET_LAUNCH(seq_finish_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, S, Bp, Mp, bias, act, out, ld_out,
-               B, M);
+  VUNET_LAUNCH(seq_bottleneck_kernel, dim3((B * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, heads, Bp, Mp, eps, mu, logstd,
+               b_out, B, H);
   return vunet_check_launch();
 }
 

@@ -116,3 +116,65 @@ def render_sequence(vunet, app_img: torch.Tensor, kps2d: torch.Tensor, spatial_s
     if as_uint8:
         rgb = (scale_img(rgb) * 255.0).clamp_(0.0, 255.0).permute(0, 2, 3, 1).to(torch.uint8)
     return rgb, stick
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 5 end to end: flow sample -> pose_behavior_rnn decode -> per-frame VUnet render
+# ------------------------------------------------------------------------------------------------
+class PoseCamera:
+    """What turns decoded pose vectors into pixel keypoints: the dataset's normalisation statistics
+    (``data_mean`` / ``data_std`` / ``dim_to_use``, data/data_conversions_3d.py:361-385), a camera's extrinsics [3, 4] and
+    intrinsics (f_x, x_0, f_y, y_0), the camera's image size (h, w) and the synthesis resolution.  Held on the device."""
+
+    def __init__(self, data_mean, data_std, dim_to_use, extrinsics, intrinsics, image_size, spatial_size, device="cuda"):
+        import numpy as np
+        mean, std = np.asarray(data_mean), np.asarray(data_std)
+        self.f32_math = int(mean.dtype == np.float32 and std.dtype == np.float32)
+        self.mean = torch.as_tensor(mean.astype(np.float64), device=device)
+        self.std = torch.as_tensor(std.astype(np.float64), device=device)
+        use = np.asarray(sorted(int(d) for d in dim_to_use), dtype=np.int32)
+        self.dims = torch.as_tensor(use, device=device)
+        self.n_use, self.dim = int(use.size), int(mean.size)
+        ext = np.asarray(extrinsics, dtype=np.float64).reshape(3, 4)
+        fx, x0, fy, y0 = [float(v) for v in intrinsics]
+        # (joint_scaling = size / image size, applied to (x, y) with image_size given as (s[0], s[1]): :1139-1140)
+        scale = [float(spatial_size) / float(image_size[0]), float(spatial_size) / float(image_size[1])]
+        self.cam = torch.as_tensor(np.concatenate([ext.reshape(-1), [fx, x0, fy, y0], scale]), device=device)
+        self.spatial_size = int(spatial_size)
+
+    def project(self, poses: torch.Tensor) -> torch.Tensor:
+        """[T, n_use] decoded (normalised) pose vectors -> [T, J, 2] pixel keypoints at the synthesis resolution."""
+        ops._dev(poses)
+        x = poses.reshape(-1, poses.shape[-1]).contiguous()
+        if x.shape[1] != self.n_use:
+            raise ValueError(f"pose vectors of {self.n_use} used dimensions expected, got {tuple(poses.shape)}")
+        t, j = x.shape[0], self.dim // 3
+        kps = torch.empty(t, j, 2, device=x.device, dtype=torch.float32)
+        ops._call("vunet_seq_pose_project", ops._p(x), self.n_use, ops._p(self.dims), ops._p(self.mean), ops._p(self.std), self.dim,
+                  self.f32_math, ops._p(self.cam), ops._p(kps), t, j, ops._stream())
+        return kps
+
+
+@torch.no_grad()
+def behavior_video(flow, net, vunet, app_img: torch.Tensor, start_poses: torch.Tensor, length: int, camera: PoseCamera,
+                   z: Optional[torch.Tensor] = None, start_frame: int = -1, joint_model=H36M_JOINT_MODEL, dtype: str = "bf16",
+                   share_appearance: bool = True, chunk: int = 16):
+    """One synthesised sequence per row of ``start_poses`` [B, T, n_kps] (experiments/behavior_net.py:1173-1184 followed by
+    data/data_conversions_3d.py:1130-1185): behaviour codes b = flow.reverse(z) with z ~ N(0, 1) (or the given ``z`` [B, C]),
+    the decoder's roll-out of ``length`` poses from ``start_poses[:, start_frame]``, camera projection, stickman raster and
+    ``VunetAlter.transfer`` of ``app_img`` [1, 3, H, W] for every frame.
+
+    Returns (frames uint8 [B, length, H, W, 3], poses [B, length, n_kps], keypoints [B, length, J, 2])."""
+    bsz = start_poses.shape[0]
+    if z is None:
+        z = torch.randn(bsz, flow.in_channels, device=start_poses.device)
+    b = flow.reverse(z)
+    b = b.reshape(bsz, -1)
+    poses, *_ = net.generate_seq(b, start_poses, len=length, start_frame=start_frame % start_poses.shape[1])
+    kps = camera.project(poses.reshape(bsz * length, -1)).reshape(bsz, length, -1, 2)
+    frames = []
+    for i in range(bsz):
+        rgb, _ = render_sequence(vunet, app_img, kps[i], spatial_size=camera.spatial_size, joint_model=joint_model, chunk=chunk,
+                                 dtype=dtype, share_appearance=share_appearance)
+        frames.append(rgb)
+    return torch.stack(frames), poses, kps

@@ -26,15 +26,15 @@ MAX_ROWS = 64   # batch rows per launch (four 16-row MFMA tiles); larger batches
 
 
 class SeqLinearDesc(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "ldx", "S_in", "S_out", "act_in", "nets", "shared_in")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "ldx", "act0", "act1", "nets", "shared_in")]
 
 
 class SeqCouplingDesc(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "c1", "ld_in", "ld_out", "S", "Mp", "reverse", "affine_on_src")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "c1", "ld_in", "ld_out", "Mp", "reverse", "affine_on_src")]
 
 
 class SeqLstmDesc(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("B", "H", "S", "ldx", "hoff", "n", "ldraw")] + [("seq_stride", ctypes.c_int64)]
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "H", "ldx", "hoff", "n", "ldraw")] + [("seq_stride", ctypes.c_int64)]
 
 
 def _up(x: int, m: int) -> int:
@@ -47,13 +47,7 @@ def _need_device(*ts):
             raise RuntimeError("the behaviour path runs on hand-written gfx950 kernels: fp32 device tensors only (no CPU fallback)")
 
 
-def choose_split(m_pad: int, k_pad: int, nets: int) -> int:
-    """K split of a layer: double it until the launch has >= 512 workgroups, keeping >= 128 k per workgroup (one
-    32-wide chunk for each of its four waves) and the split aligned to chunks."""
-    s = 1
-    while s < 16 and (m_pad // 16) * s * nets < 512 and k_pad % (64 * s) == 0 and k_pad // (2 * s) >= 128:
-        s *= 2
-    return s
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 
 
 def weight_image(w: torch.Tensor, m_pad: int, k_pad: int, col_off: int = 0, row_scale: Optional[torch.Tensor] = None,
@@ -79,47 +73,48 @@ def padded_vector(b: torch.Tensor, n_pad: int) -> torch.Tensor:
     return out
 
 
-def linear(desc: SeqLinearDesc, w: Sequence[torch.Tensor], xin: torch.Tensor, bias_in: Sequence[Optional[torch.Tensor]],
-           out: torch.Tensor):
-    _call("vunet_seq_linear", ctypes.byref(desc), _p(w[0]), _p(w[1] if len(w) > 1 else None), _p(xin), _p(bias_in[0]),
-          _p(bias_in[1] if len(bias_in) > 1 else None), _p(out), _stream())
+def linear(desc: SeqLinearDesc, w: Sequence[torch.Tensor], x: torch.Tensor, bias: Sequence[Optional[torch.Tensor]], y: torch.Tensor):
+    _call("vunet_seq_linear", ctypes.byref(desc), _p(w[0]), _p(w[1] if len(w) > 1 else None), _p(x), _p(bias[0]),
+          _p(bias[1] if len(bias) > 1 else None), _p(y), _stream())
 
 
 class MlpGroup:
-    """One or two ``BasicFullyConnectedNet`` stacks (lib/modules.py:236-257) of equal shape evaluated together.
+    """One or two ``BasicFullyConnectedNet`` stacks (lib/modules.py:236-257) of equal shape evaluated together: one launch per
+    layer, bias and activation in the launch's epilogue (LeakyReLU between layers; ``tanh_head[net]``: Tanh after the last).
 
     ``layers[net]`` = [(weight, bias), ...]; the stacks either share their input (the s and t nets of a coupling) or
-    are single.  ``run`` leaves the LAST layer's partial slabs in a buffer: its bias (and the scale net's tanh) belong
-    to the consumer kernel."""
+    are single."""
 
-    def __init__(self, layers: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], k_in_pad: int):
+    def __init__(self, layers: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], k_in_pad: int, tanh_head: Sequence[bool]):
         self.nets = len(layers)
         n_layers = len(layers[0])
-        self.dims = []     # per layer: (m_pad, k_pad, split)
+        self.dims = []     # per layer: (m_pad, k_pad)
         self.w: List[List[torch.Tensor]] = []
         self.b: List[List[torch.Tensor]] = []
+        self.head_act = [ACT_TANH if t else ACT_NONE for t in tanh_head] + [ACT_NONE] * (2 - self.nets)
         k_pad = k_in_pad
         for li in range(n_layers):
             m = layers[0][li][0].shape[0]
             m_pad = _up(m, 16) if li == n_layers - 1 else _up(m, 32)   # a hidden width is the next layer's K
             self.w.append([weight_image(net[li][0], m_pad, k_pad) for net in layers])
             self.b.append([padded_vector(net[li][1], m_pad) for net in layers])
-            self.dims.append((m_pad, k_pad, choose_split(m_pad, k_pad, self.nets)))
+            self.dims.append((m_pad, k_pad))
             k_pad = m_pad
         self.out_pad = self.dims[-1][0]
-        self.out_split = self.dims[-1][2]
 
-    def partial_floats(self, b_pad: int) -> int:
-        return max(self.nets * s * b_pad * m for m, _, s in self.dims)
+    def act_floats(self, b_pad: int) -> int:
+        return max(self.nets * b_pad * m for m, _ in self.dims)
 
     def run(self, rows: int, xin: torch.Tensor, ldx: int, bufs: Sequence[torch.Tensor]) -> torch.Tensor:
-        """``xin``: [b_pad, ldx] operand (read from column 0).  Returns the buffer holding [nets][S][b_pad][out_pad]."""
-        src, s_in, bias_in, shared = xin, 1, [None] * self.nets, 1
-        for li, (m_pad, k_pad, split) in enumerate(self.dims):
+        """``xin``: [b_pad, ldx] operand (read from column 0).  Returns the buffer holding the heads' [nets][b_pad][out_pad]."""
+        src, shared = xin, 1
+        last = len(self.dims) - 1
+        for li, (m_pad, k_pad) in enumerate(self.dims):
             dst = bufs[li % 2]
-            d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, s_in, split, 0 if li == 0 else 1, self.nets, shared)
-            linear(d, self.w[li], src, bias_in, dst)
-            src, s_in, bias_in, shared = dst, split, self.b[li], 0
+            act = self.head_act if li == last else [ACT_LRELU, ACT_LRELU]
+            d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, act[0], act[1], self.nets, shared)
+            linear(d, self.w[li], src, self.b[li], dst)
+            src, shared = dst, 0
         return src
 
 
@@ -141,7 +136,7 @@ class MlpEngine:
         key = _versions([p for l in lin for p in (l.weight, l.bias)])
         if key != self._packed_for:
             self.k_pad = _up(lin[0].in_features, 32)
-            self.group = MlpGroup([[(l.weight, l.bias) for l in lin]], self.k_pad)
+            self.group = MlpGroup([[(l.weight, l.bias) for l in lin]], self.k_pad, [self.net.use_tanh])
             self._packed_for = key
         g, dev, m_out = self.group, x.device, lin[-1].out_features
         outs = []
@@ -150,12 +145,9 @@ class MlpEngine:
             rows, b_pad = chunk.shape[0], _up(chunk.shape[0], 16)
             xin = torch.zeros(b_pad, self.k_pad, device=dev)
             xin[:rows, :chunk.shape[1]].copy_(chunk)
-            bufs = [torch.zeros(g.partial_floats(b_pad), device=dev) for _ in range(2)]
-            part = g.run(rows, xin, self.k_pad, bufs)
-            res = torch.empty(rows, m_out, device=dev)
-            _call("vunet_seq_finish", _p(part), g.out_split, g.out_pad, _p(g.b[-1][0]), 2 if self.net.use_tanh else 0, _p(res), m_out,
-                  rows, m_out, _stream())
-            outs.append(res)
+            bufs = [torch.zeros(g.act_floats(b_pad), device=dev) for _ in range(2)]
+            y = g.run(rows, xin, self.k_pad, bufs)
+            outs.append(y[:b_pad * g.out_pad].view(b_pad, g.out_pad)[:rows, :m_out].contiguous())
         return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
@@ -182,8 +174,8 @@ def actnorm_apply(mod, x: torch.Tensor, reverse: bool):
     b, c = x2.shape
     out = torch.empty_like(x2)
     logdet = None if reverse else torch.zeros(b, device=x.device)
-    d = SeqCouplingDesc(b, c, c, c, c, 1, c, 1 if reverse else 0, 0)
-    _call("vunet_seq_coupling", ctypes.byref(d), _p(x2), None, None, None, None, _p(mod.scale.detach().reshape(-1)),
+    d = SeqCouplingDesc(b, c, c, c, c, c, 1 if reverse else 0, 0)
+    _call("vunet_seq_coupling", ctypes.byref(d), _p(x2), None, None, _p(mod.scale.detach().reshape(-1)),
           _p(mod.loc.detach().reshape(-1)), _p(out), _p(logdet), _stream())
     return out.reshape(x.shape), logdet
 
@@ -256,7 +248,7 @@ class FlowEngine:
         for blk in blocks:
             cp = blk.coupling
             halves = [MlpGroup([[(l.weight, l.bias) for l in cp.s[i].linears()], [(l.weight, l.bias) for l in cp.t[i].linears()]],
-                               _up(c1, 32)) for i in range(2)]
+                               _up(c1, 32), [True, False]) for i in range(2)]
             self.blocks.append(dict(
                 halves=halves, scale=blk.norm_layer.scale.detach().reshape(-1), loc=blk.norm_layer.loc.detach().reshape(-1),
                 fwd=blk.shuffle.forward_shuffle_idx.to(torch.int32), bwd=blk.shuffle.backward_shuffle_idx.to(torch.int32)))
@@ -270,7 +262,8 @@ class FlowEngine:
         if p is None:
             dev = self.blocks[0]["scale"].device
             b_pad = _up(rows, 16)
-            nf = max(h.partial_floats(b_pad) for blk in self.blocks for h in blk["halves"])
+            halves = [h for blk in self.blocks for h in blk["halves"]]
+            nf = max(h.act_floats(b_pad) for h in halves)
             p = dict(b_pad=b_pad,
                      state=[torch.zeros(b_pad, self.ld, device=dev) for _ in range(2)],
                      part=[torch.zeros(nf, device=dev) for _ in range(2)],
@@ -282,10 +275,8 @@ class FlowEngine:
     # ---- launches
     def _step(self, rows, src, ld_in, dst, ld_out, reverse, half=None, map_=None, scale=None, loc=None, on_src=0, st=None,
               logdet=None):
-        d = SeqCouplingDesc(rows, self.C, self.c1, ld_in, ld_out, half.out_split if half else 1, half.out_pad if half else self.C,
-                            reverse, on_src)
-        _call("vunet_seq_coupling", ctypes.byref(d), _p(src), _p(st), _p(half.b[-1][0] if half else None),
-              _p(half.b[-1][1] if half else None), _p(map_), _p(scale), _p(loc), _p(dst), _p(logdet), _stream())
+        d = SeqCouplingDesc(rows, self.C, self.c1, ld_in, ld_out, half.out_pad if half else self.C, reverse, on_src)
+        _call("vunet_seq_coupling", ctypes.byref(d), _p(src), _p(st), _p(map_), _p(scale), _p(loc), _p(dst), _p(logdet), _stream())
 
     def _issue_reverse(self, rows: int, p: dict):
         """shuffle^-1, half 1, swap + half 0, ActNorm^-1 per block, last block first (models/flow/blocks.py:552-557, :310-319)."""
@@ -424,9 +415,15 @@ class BehaviorEngine:
             weight_image(w_ih, 4 * self.H, self.ldx, 0, out=img)
             weight_image(w_hh, 4 * self.H, self.ldx, self.hoff, out=img)
             return img
-        self.dec_w = gate_image(dec.rnn.weight_ih, dec.rnn.weight_hh)
+        self.dec_fold_bias = None
+        w_ih = dec.rnn.weight_ih
+        if dec.use_nin:   # x = n_in(x) in front of the cell (:494-495): W_ih (W_in x + b_in) = (W_ih W_in) x + W_ih b_in
+            w_fold, self.dec_fold_bias = torch.empty(4 * self.H, self.n, device=dev), torch.empty(4 * self.H, device=dev)
+            _call("vunet_seq_fold_input", _p(w_ih.detach().contiguous()), _p(dec.n_in.weight.detach().contiguous()),
+                  _p(dec.n_in.bias.detach().contiguous()), 4 * self.H, self.n, _p(w_fold), _p(self.dec_fold_bias), _stream())
+            w_ih = w_fold
+        self.dec_w = gate_image(w_ih, dec.rnn.weight_hh)
         self.enc_w = gate_image(enc.rnn.weight_ih_l0, enc.rnn.weight_hh_l0)
-        self.split = choose_split(4 * self.H, self.ldx, 1)
         self.heads = None
         if enc.ib:
             scales, biases = [], []
@@ -437,7 +434,7 @@ class BehaviorEngine:
                       _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), self.H, self.H, _p(rs), _p(be), _stream())
                 scales.append(weight_image(v, self.H, self.H, 0, row_scale=rs))
                 biases.append(be)
-            self.heads = (scales, biases, choose_split(self.H, self.H, 2))
+            self.heads = (scales, biases)
         self._packed_for = key
         self._plans.clear()
         self.graph.graphs.clear()
@@ -447,32 +444,31 @@ class BehaviorEngine:
         if p is None:
             dev = self.dec_w.device
             b_pad = _up(rows, 16)
-            p = dict(b_pad=b_pad, xh=torch.zeros(b_pad, self.ldx, device=dev), c=torch.zeros(b_pad, self.H, device=dev),
-                     xraw=torch.zeros(b_pad, self.ldraw, device=dev), gates=torch.zeros(self.split * b_pad * 4 * self.H, device=dev),
+            p = dict(b_pad=b_pad, xh=torch.zeros(b_pad, self.ldx, device=dev),
+                     c=[torch.zeros(b_pad, self.H, device=dev) for _ in range(2)],
+                     xraw=torch.zeros(b_pad, self.ldraw, device=dev), gates=torch.zeros(b_pad * 4 * self.H, device=dev),
                      pre=torch.zeros(b_pad, self.H, device=dev), b_in=torch.zeros(rows, self.H, device=dev),
-                     heads=torch.zeros(2 * 16 * b_pad * self.H, device=dev), io={})
+                     heads=torch.zeros(2 * b_pad * self.H, device=dev), io={})
             self._plans[rows] = p
         return p
 
     def _gates(self, rows, p, w):
-        d = SeqLinearDesc(rows, 4 * self.H, self.ldx, self.ldx, 1, self.split, 0, 1, 1)
+        d = SeqLinearDesc(rows, 4 * self.H, self.ldx, self.ldx, ACT_NONE, ACT_NONE, 1, 1)
         linear(d, [w], p["xh"], [None], p["gates"])
 
     def _issue_decode(self, rows, p, x_pose, t_in, start_frame, length, xs, cs):
         dec = self.net.decoder
         n, esz = self.n, 4
-        w_in = dec.n_in.weight.detach() if dec.use_nin else None
-        b_in = dec.n_in.bias.detach() if dec.use_nin else None
         x0 = ctypes.c_void_p(x_pose.data_ptr() + start_frame * n * esz)
-        _call("vunet_seq_start", x0, t_in * n, _p(p["b_in"]), _p(p["b_in"]), _p(w_in), _p(b_in), _p(p["xraw"]), self.ldraw,
-              _p(p["xh"]), self.ldx, self.hoff, _p(p["c"]), rows, n, self.H, _stream())
-        d = SeqLstmDesc(rows, self.H, self.split, self.ldx, self.hoff, n, self.ldraw, length * n)
+        _call("vunet_seq_start", x0, t_in * n, _p(p["b_in"]), _p(p["b_in"]), _p(p["xraw"]), self.ldraw, _p(p["xh"]), self.ldx, self.hoff,
+              _p(p["c"][0]), rows, n, self.H, _stream())
+        d = SeqLstmDesc(rows, self.H, self.ldx, self.hoff, n, self.ldraw, length * n)
         for t in range(length):
             self._gates(rows, p, self.dec_w)
             _call("vunet_seq_lstm_step", ctypes.byref(d), _p(p["gates"]), _p(dec.rnn.bias_ih.detach()), _p(dec.rnn.bias_hh.detach()),
-                  _p(p["c"]), _p(p["xh"]), None, _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()), _p(w_in), _p(b_in),
-                  _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), None,
-                  _stream())
+                  _p(self.dec_fold_bias), _p(p["c"][t % 2]), _p(p["c"][1 - t % 2]), _p(p["xh"]), None, _p(dec.n_out.weight.detach()),
+                  _p(dec.n_out.bias.detach()), _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz),
+                  ctypes.c_void_p(cs.data_ptr() + t * n * esz), None, _stream())
 
     def generate_seq(self, b: torch.Tensor, x_pose: torch.Tensor, length: int, start_frame: int):
         """-> (xs [B, len, n], cs [B, len, n]); models/pose_behavior_rnn.py:603-626."""
@@ -506,21 +502,20 @@ class BehaviorEngine:
     def _issue_encode(self, rows, p, seq, t_in, eps, mu, logstd, b_out):
         enc = self.net.b_enc
         n, esz = self.n, 4
-        _call("vunet_seq_start", _p(seq), t_in * n, None, None, None, None, None, 0, _p(p["xh"]), self.ldx, self.hoff, _p(p["c"]),
-              rows, n, self.H, _stream())
-        d = SeqLstmDesc(rows, self.H, self.split, self.ldx, self.hoff, n, self.ldraw, t_in * n)
+        _call("vunet_seq_start", _p(seq), t_in * n, None, None, None, 0, _p(p["xh"]), self.ldx, self.hoff, _p(p["c"][0]), rows, n, self.H,
+              _stream())
+        d = SeqLstmDesc(rows, self.H, self.ldx, self.hoff, n, self.ldraw, t_in * n)
         for t in range(t_in):
             self._gates(rows, p, self.enc_w)
             nxt = ctypes.c_void_p(seq.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
             _call("vunet_seq_lstm_step", ctypes.byref(d), _p(p["gates"]), _p(enc.rnn.bias_ih_l0.detach()), _p(enc.rnn.bias_hh_l0.detach()),
-                  _p(p["c"]), _p(p["xh"]), _p(p["pre"]) if t == t_in - 1 else None, None, None, None, None, None, None, None, nxt,
-                  _stream())
+                  None, _p(p["c"][t % 2]), _p(p["c"][1 - t % 2]), _p(p["xh"]), _p(p["pre"]) if t == t_in - 1 else None, None, None, None,
+                  None, None, nxt, _stream())
         if self.heads is not None:
-            w, bias, split = self.heads
-            dl = SeqLinearDesc(rows, self.H, self.H, self.H, 1, split, 0, 2, 1)
-            linear(dl, w, p["pre"], [None, None], p["heads"])
-            _call("vunet_seq_bottleneck", _p(p["heads"]), split, self.H, _p(bias[0]), _p(bias[1]), _p(eps), _p(mu), _p(logstd), _p(b_out),
-                  rows, self.H, _stream())
+            w, bias = self.heads
+            dl = SeqLinearDesc(rows, self.H, self.H, self.H, ACT_NONE, ACT_NONE, 2, 1)
+            linear(dl, w, p["pre"], bias, p["heads"])
+            _call("vunet_seq_bottleneck", _p(p["heads"]), self.H, _p(eps), _p(mu), _p(logstd), _p(b_out), rows, self.H, _stream())
 
     def infer_b(self, seq: torch.Tensor, eps: Optional[torch.Tensor]):
         """LSTM over ``seq`` [B, T, n] from a zero state.  -> (b, mu, logstd, pre) with the bottleneck heads (b = eps *

@@ -588,60 +588,66 @@ int vunet_p2_pool_bwd(const void* t, const int32_t* tmeta, const void* p, const 
  * All tensors fp32.  "Bp" is B rounded up to 16; every [Bp][..] buffer is allocated zero-filled by the caller (rows >= B are
  * computed but never read back).
  *
- *   vunet_seq_linear      out[net][s][b][m] = sum over k in split s of  w_net[m][k] * X_net[b][k],
- *                         X_net = act_in(sum over S_in slabs of xin + bias_in_net)   (act_in 0: none, 1: LeakyReLU(0.01)).
- *                         w: [M][K] row-major, M % 16 == 0, K % (32 S_out) == 0 (zero-padded images, vunet_seq_pack_rows);
- *                         xin: [nets_in][S_in][Bp][ldx] with nets_in = 1 (shared_in != 0: both nets read the same operand) or nets;
- *                         out: [nets][S_out][Bp][M] partial slabs, summed by the consumer in slab order (no atomics).  B <= 64.
- *                         v_mfma_f32_16x16x4_f32: exact fp32 products and sums, k ascending inside a wave's chunks.
+ *   vunet_seq_linear      y[net][b][m] = act_net(sum_k w_net[m][k] * x_net[b][k] + bias_net[m])   (act 0: none, 1: LeakyReLU(0.01),
+ *                         2: tanh).  w: [M][K] row-major, M % 16 == 0, K % 32 == 0 (zero-padded images, vunet_seq_pack_rows);
+ *                         x: [nets_in][Bp][ldx] with nets_in = 1 (shared_in != 0: both nets read the same operand) or nets;
+ *                         y: [nets][Bp][M].  B <= 64.  v_mfma_f32_16x16x4_f32: exact fp32 products and sums; a wave adds its K
+ *                         chunks in ascending order, the four waves of a workgroup are added in wave order: bit-reproducible.
  *   vunet_seq_coupling    one step between two MLP evaluations of the flow: v = in with the half v[c1..C) replaced by
- *                         (v - t) exp(-s) (reverse) or v exp(s) + t (forward), s = tanh(sum slabs + bias_s), t = sum slabs + bias_t
- *                         (st: [2][S][Bp][Mp], NULL: no coupling); out[b][c] = A(v[map[c]]) with A = v / scale - loc (reverse) or
+ *                         (v - t) exp(-s) (reverse) or v exp(s) + t (forward); st: [2][Bp][Mp] = (s, t) from vunet_seq_linear with
+ *                         act0 = tanh (NULL: no coupling); out[b][c] = A(v[map[c]]) with A = v / scale - loc (reverse) or
  *                         scale (v + loc) (forward), parameters indexed by map[c] (affine_on_src != 0) or by c (scale NULL: none);
  *                         forward adds sum(s) + sum(log|scale|) into logdet[b].  in != out when map != NULL; rows of in / out
  *                         are ld_in / ld_out floats apart.
- *   vunet_seq_start       first operand row of a recurrence: xh[b] = [n_in(x0[b]) or x0[b] | 0 | h0[b]], c = c0 (NULL: zeros),
- *                         xraw[b] = x0[b] (NULL: skip); x0 row b at x0 + b * x0_stride.  hoff >= n, ldx >= hoff + H.
- *   vunet_seq_lstm_step   gates: [S][Bp][4H] partials of [W_ih | 0 | W_hh] . xh (vunet_seq_linear), bias / bias2 = b_ih / b_hh, gate order
- *                         i, f, g, o: c' = sig(f) c + sig(i) tanh(g), h = sig(o) tanh(c'); h -> xh[b][hoff..], c in place, h_out
+ *   vunet_seq_start       first operand row of a recurrence: xh[b] = [x0[b] | 0 | h0[b]], c = c0 (NULL: zeros), xraw[b] = x0[b]
+ *                         (NULL: skip); x0 row b at x0 + b * x0_stride.  hoff >= n, ldx >= hoff + H.
+ *   vunet_seq_lstm_step   gates: [Bp][4H] = [W_ih | 0 | W_hh] . xh (vunet_seq_linear without bias), bias / bias2 / bias3 = b_ih / b_hh /
+ *                         the folded input layer's W_ih b_in (NULL), gate order i, f, g, o: c' = sig(f) c + sig(i) tanh(g),
+ *                         h = sig(o) tanh(c'); h -> xh[b][hoff..], c_in -> c_out (two buffers, swapped by the caller per step), h_out
  *                         (optional copy).  Decoder (w_out != NULL): x' = w_out h + b_out + xraw[b]; xs[b] = x', cs[b] = the old
- *                         xraw[b] (rows at + b * seq_stride); xraw[b] = x'; xh[b][0..n) = w_in x' + b_in (w_in NULL: x').
+ *                         xraw[b] (rows at + b * seq_stride); xraw[b] = x'; xh[b][0..n) = x'.
  *                         Encoder (w_out == NULL): xh[b][0..n) = x_next[b] (row at + b * seq_stride; NULL: left alone).
- *   vunet_seq_bottleneck  mu = sum slabs(net 0) + bias_mu, logstd = sum slabs(net 1) + bias_std, b = eps exp(logstd) + mu (eps NULL:
- *                         mu; b_out NULL: skip).  part: [2][S][Bp][Mp] from vunet_seq_linear with nets = 2.
- *   vunet_seq_finish      out[b][j] = act(sum slabs + bias[j]) for j < M (act 0: none, 1: LeakyReLU(0.01), 2: tanh): the value of a
- *                         layer whose consumer is none of the kernels above (a stand-alone BasicFullyConnectedNet).
+ *   vunet_seq_fold_input  ``linear_in_decoder`` (models/pose_behavior_rnn.py:494-495) folded into the gate matrix:
+ *                         w_fold [M][n] = w_ih [M][n] . w_in [n][n], bias_fold [M] = w_ih . b_in.
+ *   vunet_seq_bottleneck  heads: [2][Bp][Mp] = (mu, logstd) from vunet_seq_linear with nets = 2; copies them out and forms
+ *                         b = eps exp(logstd) + mu (eps NULL: mu; b_out NULL: skip)   (models/pose_behavior_rnn.py:180-201).
  *   vunet_seq_pack_rows   dst[m][col_off + k] = src[m][k] * (row_scale ? row_scale[m] : 1): builds the zero-padded weight images.
  *   vunet_seq_normlinear_rows   NormConv2d 1x1 as a linear layer (lib/modules.py:135-145): row_scale[m] = gamma g / ||v_m||,
  *                         bias_eff[m] = gamma bias + beta.
+ *   vunet_seq_pose_project      decoded pose vectors -> pixel keypoints [T][J][2]: unNormalizeData (data/data_conversions_3d.py:178-211;
+ *                         dims_to_use ascending, the others hold mean), [R | t] (:588-605), pinhole projection (:892-912) and the
+ *                         rescale to the synthesis resolution (:1139-1140), in float64 like the reference's numpy.  cam: 18 DEVICE
+ *                         doubles = [R | t] row-major (12), fx, x0, fy, y0, scale_x, scale_y; mean / stdv: D device doubles, D >= 3 J;
+ *                         f32_math != 0: x * std + mean in float32 (numpy's result when the statistics are float32 arrays).
  *   vunet_seq_actnorm_init      ActNorm's data-dependent initialisation (lib/modules.py:270-290): loc = -mean, scale = 1 / (std + 1e-6)
  *                         per channel over the B rows of x (unbiased std); B >= 2. */
 typedef struct vunet_seq_linear_desc {
-  int32_t B, M, K, ldx, S_in, S_out, act_in, nets, shared_in;
+  int32_t B, M, K, ldx, act0, act1, nets, shared_in;
 } vunet_seq_linear_desc;
 typedef struct vunet_seq_coupling_desc {
-  int32_t B, C, c1, ld_in, ld_out, S, Mp, reverse, affine_on_src;
+  int32_t B, C, c1, ld_in, ld_out, Mp, reverse, affine_on_src;
 } vunet_seq_coupling_desc;
 typedef struct vunet_seq_lstm_desc {
-  int32_t B, H, S, ldx, hoff, n, ldraw;
+  int32_t B, H, ldx, hoff, n, ldraw;
   int64_t seq_stride;
 } vunet_seq_lstm_desc;
-int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* xin, const float* bias_in0,
-                     const float* bias_in1, float* out, void* stream);
-int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const float* bias_s, const float* bias_t,
-                       const int32_t* map, const float* scale, const float* loc, float* out, float* logdet, void* stream);
-int vunet_seq_start(const float* x0, int64_t x0_stride, const float* h0, const float* c0, const float* w_in, const float* b_in,
-                    float* xraw, int32_t ldraw, float* xh, int32_t ldx, int32_t hoff, float* c, int32_t B, int32_t n, int32_t H,
-                    void* stream);
-int vunet_seq_lstm_step(const vunet_seq_lstm_desc* d, const float* gates, const float* bias, const float* bias2, float* c, float* xh,
-                        float* h_out, const float* w_out, const float* b_out, const float* w_in, const float* b_in, float* xraw, float* xs,
-                        float* cs, const float* x_next, void* stream);
-int vunet_seq_bottleneck(const float* part, int32_t S, int32_t Mp, const float* bias_mu, const float* bias_std, const float* eps,
-                         float* mu, float* logstd, float* b_out, int32_t B, int32_t H, void* stream);
-int vunet_seq_finish(const float* part, int32_t S, int32_t Mp, const float* bias, int32_t act, float* out, int32_t ld_out, int32_t B,
-                     int32_t M, void* stream);
+int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* x, const float* bias0,
+                     const float* bias1, float* y, void* stream);
+int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const int32_t* map, const float* scale,
+                       const float* loc, float* out, float* logdet, void* stream);
+int vunet_seq_start(const float* x0, int64_t x0_stride, const float* h0, const float* c0, float* xraw, int32_t ldraw, float* xh,
+                    int32_t ldx, int32_t hoff, float* c, int32_t B, int32_t n, int32_t H, void* stream);
+int vunet_seq_lstm_step(const vunet_seq_lstm_desc* d, const float* gates, const float* bias, const float* bias2, const float* bias3,
+                        const float* c_in, float* c_out, float* xh, float* h_out, const float* w_out, const float* b_out, float* xraw,
+                        float* xs, float* cs, const float* x_next, void* stream);
+int vunet_seq_fold_input(const float* w_ih, const float* w_in, const float* b_in, int32_t M, int32_t n, float* w_fold,
+                         float* bias_fold, void* stream);
+int vunet_seq_bottleneck(const float* heads, int32_t Mp, const float* eps, float* mu, float* logstd, float* b_out, int32_t B,
+                         int32_t H, void* stream);
 int vunet_seq_pack_rows(const float* src, int32_t M, int32_t K, const float* row_scale, float* dst, int32_t ld_dst, int32_t col_off,
                         void* stream);
+int vunet_seq_pose_project(const float* x, int32_t n_use, const int32_t* dims_to_use, const double* mean, const double* stdv, int32_t D,
+                           int32_t f32_math, const double* cam, float* kps, int32_t T, int32_t J, void* stream);
 int vunet_seq_actnorm_init(const float* x, int32_t ld, int32_t B, int32_t C, float* loc, float* scale, void* stream);
 int vunet_seq_normlinear_rows(const float* v, const float* g, const float* bias, const float* gamma, const float* beta, int32_t M,
                               int32_t K, float* row_scale, float* bias_eff, void* stream);

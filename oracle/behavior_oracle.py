@@ -208,3 +208,27 @@ def behavior_net_forward(sd: SD, x1: Tensor, x2: Tensor, length: int, start_fram
     b, mu, logstd, pre = infer_b(sd, x1, eps, sample_noise)
     xs, cs = generate_seq(sd, b, x2, length, start_frame)
     return xs, cs, b, mu, logstd, pre
+
+
+# --------------------------------------------------------------------------
+# decoded pose vectors -> pixel keypoints -- data/data_conversions_3d.py:178-211, :588-605, :892-912, :1139-1140
+# --------------------------------------------------------------------------
+def poses_to_keypoints(x, data_mean, data_std, dim_to_ignore, extrinsics, intrinsics, image_size, spatial_size):
+    """numpy, as the reference computes it per frame: ``unNormalizeData`` (zeros at the ignored dimensions, then * std +
+    mean), ``apply_affine_transform``, ``camera_projection``, joint rescale.  x: [T, n_use] -> [T, J, 2] float64."""
+    import numpy as np
+    x = np.asarray(x)
+    t, d = x.shape[0], data_mean.shape[0]
+    orig = np.zeros((t, d), dtype=np.float32)
+    use = np.array([i for i in range(d) if i not in dim_to_ignore])
+    orig[:, use] = x
+    orig = np.multiply(orig, np.repeat(data_std.reshape((1, d)), t, axis=0)) + np.repeat(data_mean.reshape((1, d)), t, axis=0)
+    out = []
+    size_arr = np.full((1, 2), spatial_size, dtype=float)
+    for p in orig.reshape(t, -1, 3):
+        x_hom = np.concatenate([p, np.ones((p.shape[0], 1), dtype=p.dtype)], axis=-1)
+        pose_c = x_hom @ np.asarray(extrinsics).T
+        cam = np.asarray([[intrinsics[0], 0.0, intrinsics[1]], [0.0, intrinsics[2], intrinsics[3]], [0.0, 0.0, 1.0]])
+        pose_i = ((pose_c / np.expand_dims(pose_c[..., -1], axis=-1)) @ cam.T)[..., :-1]
+        out.append(pose_i * (size_arr / np.expand_dims(np.asarray(image_size, dtype=float), axis=0)))
+    return np.stack(out)
