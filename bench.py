@@ -260,6 +260,65 @@ def roofline_entry(kern, fam, dom, tot_ms, prof_steps, ms_per_step, batch):
     return r
 
 
+def behavior_row(vunet, device, size, frames=50, rows=16, iters=10):
+    """BASELINE config 5, front half and end to end (experiments/behavior_net.py:1173-1184, data/data_conversions_3d.py:
+    1130-1185): behaviour codes from the flow's reverse pass (config/behavior_net.yaml: 1024 channels, 2048 hidden, depth 2,
+    15 blocks = 2.5 GB of fp32 weights streamed once per pass), the decoder's 50-step roll-out, then projection + raster +
+    bf16 VunetAlter.transfer of one sequence.  Random weights (no checkpoint here).  Roofline of the flow pass: HBM, the
+    weight bytes of its MLPs / 8 TB/s (csrc/seq.hip; profiles/r05_seq_time.txt)."""
+    import numpy as np
+    from behavior_driven_video_synthesis_amd.models.flow.simple_flow import UnsupervisedTransformer2
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    from behavior_driven_video_synthesis_amd.render import PoseCamera, behavior_video
+    torch.manual_seed(11)
+    flow = UnsupervisedTransformer2(flow_in_channels=1024, flow_mid_channels=2048, flow_hidden_depth=2, n_flows=15)
+    for blk in flow.flow.sub_layers:
+        blk.norm_layer.initialized.fill_(1)
+        for mlp in blk.coupling.s:     # an untrained scale net saturates its tanh: keep the pass conditioned like a trained one
+            mlp.linears()[-1].weight.data.mul_(0.1)
+    flow = flow.to(device)
+    net = ResidualBehaviorNet(51, information_bottleneck=True, decoder_arch="lstm", linear_in_decoder=False, dim_hidden_b=1024)
+    net.decoder.n_out.weight.data.mul_(0.05)
+    net = net.to(device)
+    z = torch.randn(rows, 1024, device=device)
+    seq = 0.5 * torch.randn(rows, frames, 51, device=device)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+    t_flow = timed(lambda: flow.reverse(z))
+    b = flow.reverse(z).reshape(rows, 1024)
+    t_dec = timed(lambda: net.generate_seq(b, seq, len=frames, start_frame=frames - 1))
+    t_enc = timed(lambda: net.infer_b(seq, False))
+    w_bytes = 4.0 * sum(p.numel() for n, p in flow.named_parameters() if ".main." in n and n.endswith("weight"))
+    rng = np.random.RandomState(3)
+    cam = PoseCamera((rng.randn(51) * 250.0).astype(np.float32), (40.0 + 40.0 * rng.rand(51)).astype(np.float32), list(range(51)),
+                     np.concatenate([np.eye(3), np.array([[0.0], [0.0], [5000.0]])], axis=1), (1145.0, 500.0, 1145.0, 500.0),
+                     (1000, 1000), size, device=device)
+    app = (torch.rand(1, 3, size, size, device=device) * 2 - 1)
+    was = vunet.training
+    vunet.eval()
+    t_e2e = timed(lambda: behavior_video(flow, net, vunet, app, seq[:1], frames, cam, z=z[:1], dtype="bf16", chunk=frames))
+    vunet.train(was)
+    ach = w_bytes / t_flow / 1e9
+    return {"workload": f"flow reverse ({rows} rows, 15 blocks, 1024 / 2048) + decoder roll-out ({frames} steps, 1024 hidden) + "
+                        f"projection, raster and bf16 transfer of one {frames}-frame sequence at {size}x{size} (BASELINE configs[4])",
+            "data": "synthetic, random weights",
+            "flow_reverse_ms": 1e3 * t_flow, "decode_ms": 1e3 * t_dec, "encode_ms": 1e3 * t_enc, "rows": rows,
+            "sequences_per_s_front_half": rows / (t_flow + t_dec),
+            "end_to_end_ms_per_sequence": 1e3 * t_e2e, "end_to_end_frames_per_s": frames / t_e2e,
+            "roofline": {"bound": "hbm", "kernel": "seq_linear_kernel (the flow's 120 MLP-layer launches)", "achieved": ach,
+                         "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_pass": w_bytes,
+                         "note": "whole reverse pass incl. its 31 coupling launches; per-CU L1 fill bound, see profiles/r05_seq_time.txt"}}
+
+
 def render_row(vunet, device, size, frames=50, chunk=50, iters=5):
     """BASELINE config 5 (the render half): a 50-frame pose sequence -> one raster launch -> batched VunetAlter.transfer
     (reference: per-frame cv2 raster + batch-1 transfer, data/data_conversions_3d.py:1130-1185).  Modes: fp32-accurate
@@ -582,6 +641,7 @@ def main():
         result["variants"] = variant_rows(args, device)
     if rank == 0 and world == 1 and not args.no_render and args.size % 32 == 0:
         result["render"] = render_row(trainer.vunet, device, args.size)
+        result["behavior"] = behavior_row(trainer.vunet, device, args.size)
     # BASELINE config 1 (Market 128^2, bs 2, 30-channel 64x64 appearance input): plumbing rows, GPU and CPU
     cfg1 = batch1 = None
     if rank == 0 and world == 1 and not args.no_config1:

@@ -30,11 +30,13 @@ def test_header_is_plain_c_abi():
 
 
 def test_ctypes_structs_match_header_field_order():
-    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd import ops, seq
     txt = open(os.path.join(ROOT, "include", "vunet_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     for cname, cls in (("vunet_conv_desc", ops.ConvDesc), ("vunet_wgrad_desc", ops.WgradDesc),
-                       ("vunet_wn_desc", ops.WnDesc), ("vunet_p2_desc", ops.P2Desc)):
+                       ("vunet_wn_desc", ops.WnDesc), ("vunet_p2_desc", ops.P2Desc),
+                       ("vunet_seq_linear_desc", seq.SeqLinearDesc), ("vunet_seq_coupling_desc", seq.SeqCouplingDesc),
+                       ("vunet_seq_lstm_desc", seq.SeqLstmDesc)):
         body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname, txt, flags=re.S).group(1)
         fields = []
         for decl in body.split(";"):
@@ -43,9 +45,41 @@ def test_ctypes_structs_match_header_field_order():
                 typ, names = decl.split(None, 1)
                 fields += [(n.strip(), typ) for n in names.split(",")]
         assert [f[0] for f in cls._fields_] == [f[0] for f in fields], cname
-        cmap = {"int32_t": "c_int", "uint32_t": "c_uint", "float": "c_float"}
+        cmap = {"int32_t": "c_int", "uint32_t": "c_uint", "float": "c_float", "int64_t": "c_long"}
         for (n, ct), (_, typ) in zip(cls._fields_, fields):
             assert ct.__name__.startswith(cmap[typ]), (cname, n)
+
+
+def test_behavior_modules_keep_the_reference_state_dict_layout_and_refuse_the_cpu():
+    """The flow / behaviour-net mirrors (BASELINE config 5's front half): key names, order and shapes of the reference's
+    ``UnsupervisedTransformer2`` / ``ResidualBehaviorNet`` as the g9 fixture recorded them; no CPU path."""
+    import pytest
+    import torch
+    from behavior_driven_video_synthesis_amd.models.flow.simple_flow import UnsupervisedTransformer2
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    meta, _ = load_golden("g9_behavior")
+    for tag in ("flow_even", "flow_odd"):
+        info = meta["cases"][tag]
+        flow = UnsupervisedTransformer2(**info["kw"])
+        sd = flow.state_dict()
+        assert list(sd.keys()) == list(info["shapes"].keys())
+        assert {k: list(v.shape) for k, v in sd.items()} == info["shapes"]
+        assert sd["flow.sub_layers.0.shuffle.forward_shuffle_idx"].dtype == torch.int64
+        perm = sd["flow.sub_layers.0.shuffle.forward_shuffle_idx"]
+        assert torch.equal(perm[sd["flow.sub_layers.0.shuffle.backward_shuffle_idx"]], torch.arange(perm.numel()))
+        assert flow.get_last_layer() is flow.flow.sub_layers[-1].coupling.t[-1].linears()[-1].weight
+    for tag in ("net_plain", "net_nin"):
+        info = meta["cases"][tag]
+        net = ResidualBehaviorNet(**info["kw"])
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(info["shapes"].keys())
+        assert {k: list(v.shape) for k, v in sd.items()} == info["shapes"]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        flow.reverse(torch.zeros(2, flow.in_channels))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.generate_seq(torch.zeros(2, 64), torch.zeros(2, 3, 51), len=2, start_frame=0)
+    with pytest.raises(NotImplementedError):
+        ResidualBehaviorNet(51, decoder_arch="gru", dim_hidden_b=64)     # (the reference's GRU decoder cannot run either)
 
 
 def test_state_dict_layout_matches_reference():
