@@ -431,12 +431,6 @@ extern "C" int vunet_seq_actnorm_init(const float* x, int32_t ld, int32_t B, int
   return vunet_check_launch();
 }
 
-// rows per workgroup tile: 32 (two MFMA tiles per wave share the operand registers: half the operand traffic per weight byte)
-// where that still leaves 256 workgroups, else 16
-static int seq_row_tiles(const vunet_seq_linear_desc* d) {
-  return (d->M % 32 == 0 && (d->M / 32) * d->nets >= 256) ? 2 : 1;
-}
-
 extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* x, const float* bias0,
                                 const float* bias1, float* y, void* stream) {
   if (!d || !w0 || !x || !y) return VUNET_ERR_ARG;
@@ -458,15 +452,15 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   a.act[0] = d->act0;
   a.act[1] = d->act1;
   a.shared_in = d->shared_in;
-  const int rt = seq_row_tiles(d);
-  const dim3 grid(d->M / (16 * rt), 1, d->nets);
+  // (RT = 2, a 32-row tile per workgroup, halves the operand traffic per weight byte but leaves half the CUs without a workgroup
+  // at every layer size of the reference configuration: not instantiated)
+  const dim3 grid(d->M / 16, 1, d->nets);
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = rt == 1 && d->K >= 16 * 32;   // 16 waves: at least one chunk each
-#define SEQ_LINEAR_CASE(NB)                                                                   \
-  case NB:                                                                                    \
-    if (rt == 2) VUNET_LAUNCH((seq_linear_kernel<NB, 2, 4>), grid, dim3(256), 0, st, a);      \
-    else if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16>), grid, dim3(1024), 0, st, a);  \
-    else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4>), grid, dim3(256), 0, st, a);              \
+  const bool wide = d->K >= 16 * 32;   // 16 waves: at least one chunk each
+#define SEQ_LINEAR_CASE(NB)                                                              \
+  case NB:                                                                               \
+    if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16>), grid, dim3(1024), 0, st, a);  \
+    else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4>), grid, dim3(256), 0, st, a);         \
     break;
   switch (a.Bp / 16) {
     SEQ_LINEAR_CASE(1)
