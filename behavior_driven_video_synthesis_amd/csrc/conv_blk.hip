@@ -225,6 +225,186 @@ __global__ __launch_bounds__(256, 2) void conv_blk_tiled_kernel(const BlkArgs a)
     for (int nt = 0; nt < NT; ++nt) bk_store_tile(a, n, row0 + wave * NT + nt, col0 + j, true, m0 + mt * 32, h, acc[mt][nt]);
 }
 
+// ---- a whole residual block with a skip input in ONE launch (lib/modules.py:221-233, eval mode):
+//        y = x + conv3x3(elu(cat(x, nin(elu(a)))))
+// The 1x1 `nin` of the skip tensor is computed on the tile's halo region in a pre-phase -- ELU(a) staged once for all of its
+// channels, one small MFMA product per 32 halo pixels, + shift, rounded to bf16 exactly where the separate launch rounds it
+// when it stores, zeroed outside the image (the 3x3 pads ITS input) -- and left in LDS as the second source's image, already
+// through the 3x3's ELU.  The main loop is conv_blk_tiled_kernel's; the second source's chunks stage weights only.  Saves the
+// store and the re-load of nin(elu(a)): 4 of the block's ~10 bytes per pixel and channel.  C1 = C2 = M in {32, 64}.
+struct BlkRnbArgs {
+  BlkArgs b;           // the 3x3: x1 = x, x2 = a (the RAW skip tensor), wb / shift of the 3x3, res, y
+  const uint4* wb_nin; // [chunk of 16][k half][Mpad_nin][8] bf16 (vunet_pack_bf16_taps, taps = 1)
+  const float* shift_nin;
+  int Mpad_nin;
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_blk_rnb_kernel(const BlkRnbArgs ar) {
+  constexpr int TW = 32, TH = 4 * NT, IH = TH + 2, IW = TW + 2, MB = 32 * MT, PIX = IH * IW;
+  constexpr int XU = PIX * 2, WU = 9 * MB * 2;
+  constexpr int NX = (XU + 255) / 256, NW = (WU + 255) / 256;
+  constexpr int BUF = XU + WU;
+  constexpr int C2 = 32 * MT, AU = (C2 / 8) * PIX;   // the skip tensor's tile: all channels
+  constexpr int NPT = (PIX + 31) / 32;
+  static_assert(AU <= 2 * BUF, "the staged skip tile aliases the two chunk buffers");
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  uint4* const aT = smem4 + 2 * BUF;   // nin(elu(a)) after the 3x3's ELU, [channel block][halo pixel]
+
+  const BlkArgs& a = ar.b;
+  const vunet_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int H = d.Hs, W = d.Ws;
+
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  int t = bid;
+  const int tiles_w = W / TW, tiles_h = H / TH;
+  const int tx = t % tiles_w;
+  t /= tiles_w;
+  const int ty = t % tiles_h;
+  const int n = t / tiles_h;
+  const int row0 = ty * TH, col0 = tx * TW;
+
+  // ---- pre-phase 1: ELU(a) of the halo tile, all channels, into the (not yet used) chunk buffers; every load issued first
+  {
+    const uint4* __restrict__ as = a.x2 + (size_t)n * (C2 / 8) * H * W;
+    constexpr int NA = (AU + 255) / 256;
+    uint4 av[NA];
+    bool aok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int u = tid + 256 * i;
+      const int c8 = u / PIX, rem = u - c8 * PIX;
+      const int r = rem / IW, col = rem - r * IW;
+      const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+      aok[i] = u < AU && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      av[i] = as[aok[i] ? ((size_t)c8 * H + ih) * W + iw : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (tid + 256 * i < AU) smem4[tid + 256 * i] = aok[i] ? bk_elu8(av[i]) : make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  // ---- pre-phase 2: the 1x1 product per 32 halo pixels; wave w takes pixel tiles w, w + 4, ...
+  for (int pt = wave; pt < NPT; pt += 4) {
+    const int px = pt * 32 + j, pxc = px < PIX ? px : PIX - 1;
+    const int r = pxc / IW, col = pxc - r * IW;
+    const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+    const bool inside = px < PIX && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < C2 / 16; ++kc) {
+        BkUnit av, bv;
+        av.u = ar.wb_nin[(size_t)(kc * 2 + h) * ar.Mpad_nin + mt * 32 + j];
+        bv.u = smem4[(kc * 2 + h) * PIX + pxc];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.b, bv.b, acc, 0, 0, 0);
+      }
+      if (px < PIX) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int cb = mt * 32 + 8 * q4 + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[4 * q4 + e] + (ar.shift_nin ? ar.shift_nin[cb + e] : 0.f);
+          // the separate launch stores bf16(v); the 3x3 then stages bf16(elu(that)) -- the same two roundings here
+          uint2 o = make_uint2(bk_elu2(bk_pack(v[0], v[1])), bk_elu2(bk_pack(v[2], v[3])));
+          if (!inside) o = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(reinterpret_cast<char*>(aT) + ((size_t)(cb >> 3) * PIX + px) * 16 + (cb & 7) * 2) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();   // the chunk buffers are free again; aT is complete
+
+  // ---- the 3x3 itself: conv_blk_tiled_kernel's loop; chunks of the second source read aT and stage weights only
+  const int m0 = 0;
+  int rel[NX], lds_x[NX];
+  uint32_t vbits = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int u = tid + 256 * i;
+    const int c8 = u / PIX;
+    const int rem = u - c8 * PIX;
+    const int r = rem / IW, col = rem - r * IW;
+    const int ih = row0 - 1 + r, iw = col0 - 1 + col;
+    const bool ok = u < XU && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    rel[i] = ok ? (c8 * H + ih) * W + iw : 0;
+    lds_x[i] = c8 * PIX + rem;
+    vbits |= (ok ? 1u : 0u) << i;
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  constexpr int nch1 = C2 / 16, nch = 2 * nch1;
+  auto issue_loads = [&](int ch, uint4 (&xv)[NX], uint4 (&wv)[NW]) {
+    if (ch < nch1) {
+      const uint4* __restrict__ xs = a.x1 + (size_t)(n * (C2 / 8) + ch * 2) * H * W;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xv[i] = xs[rel[i]];
+    }
+    const uint4* __restrict__ wp = a.wb + (size_t)ch * 18 * d.Mpad + m0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int w = tid + 256 * i;
+      const int ht = w / MB, m = w - ht * MB;
+      const bool ok = w < WU && m0 + m < d.Mpad;
+      const uint4 v = wp[ok ? (size_t)ht * d.Mpad + m : 0];
+      wv[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto write_lds = [&](int ch, uint4* buf, const uint4 (&xv)[NX], const uint4 (&wv)[NW]) {
+    if (ch < nch1) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (tid + 256 * i < XU) buf[lds_x[i]] = ((vbits >> i) & 1u) ? bk_elu8(xv[i]) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (tid + 256 * i < WU) buf[XU + tid + 256 * i] = wv[i];
+  };
+  auto multiply = [&](int ch, const uint4* buf) {
+    const uint4* wL = buf + XU + h * (9 * MB) + j;
+    const uint4* xL = (ch < nch1 ? buf + h * PIX : aT + ((ch - nch1) * 2 + h) * PIX) + wave * NT * IW + j;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dr = tap / 3, dc = tap % 3;
+      BkUnit av[MT], bv[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt].u = wL[tap * MB + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt].u = xL[(dr + nt) * IW + dc];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt].b, bv[nt].b, acc[mt][nt], 0, 0, 0);
+    }
+  };
+  uint4 xv[NX], wv[NW];
+  issue_loads(0, xv, wv);
+  write_lds(0, smem4, xv, wv);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) issue_loads(ch + 1, xv, wv);
+    multiply(ch, smem4 + (ch & 1) * BUF);
+    if (ch + 1 < nch) write_lds(ch + 1, smem4 + ((ch + 1) & 1) * BUF, xv, wv);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bk_store_tile(a, n, row0 + wave * NT + nt, col0 + j, true, m0 + mt * 32, h, acc[mt][nt]);
+}
+
 // ---- the same tile, WAVE-SPECIALISED: 512 threads = four matrix waves (w = 0..3: the taps of chunk c from LDS buffer c & 1,
 // rows w*NT .. as above) beside four staging waves (loads two chunks ahead through two register sets, ELU, the LDS writes
 // of chunk c + 1 into the other buffer), one barrier per chunk for all eight.  In the uniform kernel above every wave does
@@ -675,6 +855,41 @@ static bool blk_tiled_ok(const vunet_conv_desc* d) {
 }
 
 extern "C" int vunet_conv2d_blk_tiled(const vunet_conv_desc* d) { return d && blk_tiled_ok(d) ? 1 : 0; }
+
+static bool blk_rnb_ok(const vunet_conv_desc* d) {
+  return blk_tiled_ok(d) && d->mode == 0 && (d->C1 == 32 || d->C1 == 64) && d->C2 == d->C1 && d->M == d->C1 && d->m_off == 0 &&
+         d->Mpad % 32 == 0 && d->in_act == ACT_ELU && d->drop_p == 0.f && d->out_act == ACT_NONE && !d->d2s;
+}
+
+extern "C" int vunet_conv2d_blk_rnb_supported(const vunet_conv_desc* d) { return d && blk_rnb_ok(d) ? 1 : 0; }
+
+extern "C" int vunet_conv2d_blk_rnb(const vunet_conv_desc* d, const void* x, const void* skip, const void* wb_nin, const float* shift_nin,
+                                    int32_t Mpad_nin, const void* wb, const float* shift, const void* res, void* y, void* stream) {
+  if (!d || !x || !skip || !wb_nin || !wb || !y || Mpad_nin < d->C2 || Mpad_nin % 32) return VUNET_ERR_ARG;
+  if (!blk_rnb_ok(d)) return VUNET_ERR_UNSUPPORTED;
+  BlkRnbArgs ar;
+  BlkArgs& a = ar.b;
+  a.d = *d;
+  a.x1 = (const uint4*)x; a.x2 = (const uint4*)skip; a.wb = (const uint4*)wb; a.shift = shift; a.res = res; a.y = y;
+  a.y_nchw = 0;
+  a.NP = d->N * d->Ho * d->Wo;
+  ar.wb_nin = (const uint4*)wb_nin;
+  ar.shift_nin = shift_nin;
+  ar.Mpad_nin = Mpad_nin;
+  hipStream_t st = (hipStream_t)stream;
+  const int MT = d->M / 32;
+  int NT = (MT == 1 && d->Hs % 8 == 0) ? 2 : 1;   // the tile heights conv_blk_tiled_kernel measured best per channel count
+  if (NT == 2 && (size_t)d->N * (d->Hs / 8) * (d->Ws / 32) < 1024) NT = 1;
+  if (g_vunet_tune[VUNET_TUNE_BLK_FORCE_NT] == 1 || (g_vunet_tune[VUNET_TUNE_BLK_FORCE_NT] == 2 && MT == 1 && d->Hs % 8 == 0))
+    NT = g_vunet_tune[VUNET_TUNE_BLK_FORCE_NT];
+  const int blocks = d->N * (d->Hs / (4 * NT)) * (d->Ws / 32);
+  const int pix = (4 * NT + 2) * 34;
+  const size_t lds = (2 * (size_t)(pix * 2 + 9 * 32 * MT * 2) + (size_t)(4 * MT) * pix) * sizeof(uint4);
+  if (MT == 1 && NT == 1) VUNET_LAUNCH((conv_blk_rnb_kernel<1, 1>), dim3(blocks), dim3(256), lds, st, ar);
+  else if (MT == 1) VUNET_LAUNCH((conv_blk_rnb_kernel<1, 2>), dim3(blocks), dim3(256), lds, st, ar);
+  else VUNET_LAUNCH((conv_blk_rnb_kernel<2, 1>), dim3(blocks), dim3(256), lds, st, ar);
+  return vunet_check_launch();
+}
 
 extern "C" int vunet_conv2d_blk(const vunet_conv_desc* d, const void* x1, const void* x2, const void* wb, const float* shift,
                                 const void* res, void* y, int32_t y_fp32_nchw, void* stream) {

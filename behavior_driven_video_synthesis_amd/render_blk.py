@@ -14,6 +14,7 @@ per parameter version; nothing here runs without the HIP library.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -57,6 +58,11 @@ class BlockedTransfer:
             raise ValueError("this model is outside the blocked render path (see BlockedTransfer.supported)")
         self.vunet = vunet
         self._packs = {}
+        # residual blocks with a skip input as ONE launch (vunet_conv2d_blk_rnb): built for VERDICT r4 #8, bit-identical, and
+        # 6 % SLOWER than the 1x1 + 3x3 pair on both render shapes although it moves a third fewer bytes
+        # (profiles/r05_rnb_fused_ab.txt: the tiled kernel is not HBM-bound, and the halo product is serial work per tile):
+        # off unless VUNET_BLK_FUSE_RNB=1
+        self.fuse_rnb = os.environ.get("VUNET_BLK_FUSE_RNB", "0") == "1"
 
     @staticmethod
     def supported(vunet) -> bool:
@@ -134,9 +140,32 @@ class BlockedTransfer:
         _call("vunet_conv1x1_few_to_blk", _p(image), _p(L.wt_f), _p(L.shift), _p(y), n, c, h, w, L.cout, L.mpad, _stream())
         return y
 
+    def _rnb_fused(self, blk, x, a):
+        """The whole block in one launch (``vunet_conv2d_blk_rnb``: the 1x1 ``nin`` of the skip tensor computed on the tile's
+        halo in LDS), or None where the geometry is not covered."""
+        if not self.fuse_rnb or a.shape != x.shape:
+            return None
+        n, c8, hs, ws, _ = x.shape
+        c = c8 * 8
+        L, Ln = self._pack(blk.conv, c, c), self._pack(blk.nin, c)
+        d = ConvDesc(N=n, C1=c, C2=c, Hs=hs, Ws=ws, M=L.cout, m_off=0, Mpad=L.mpad, Ho=hs, Wo=ws, KH=L.k, KW=L.k,
+                     stride=L.stride, pad=L.pad, mode=0, in_act=ACT_ELU, in_slope=0.0, drop_p=0.0, drop_seed=0,
+                     out_act=ACT_NONE, d2s=0)
+        if Ln.k != 1 or Ln.cout != c or _lib.lib().vunet_conv2d_blk_rnb_supported(ctypes.byref(d)) != 1:
+            return None
+        y = blk_empty(n, L.cout, hs, ws, x.device)
+        with (ops._Timed(("conv_blk_fwd", n, c, c, hs, ws, L.cout, L.k, L.stride, 1, 0, "conv_blk_rnb_kernel"),
+                         2.0 * n * hs * ws * L.cout * (2 * c * 9 + c)) if ops._prof["on"] else ops._NO_TIMER):
+            _call("vunet_conv2d_blk_rnb", ctypes.byref(d), _p(x), _p(a), _p(Ln.wb), _p(Ln.shift), Ln.mpad, _p(L.wb), _p(L.shift),
+                  _p(x), _p(y), _stream())
+        return y
+
     def _rnb(self, blk, x, a=None):
         # lib/modules.py:185-233 with the model in eval mode (no dropout): x + conv3x3(elu(cat(x, nin(elu(a)))))
         if a is not None:
+            y = self._rnb_fused(blk, x, a)
+            if y is not None:
+                return y
             a = self._conv(blk.nin, a, in_act=ACT_ELU)
             return self._conv(blk.conv, x, a, res=x, in_act=ACT_ELU)
         return self._conv(blk.conv, x, res=x, in_act=ACT_ELU)

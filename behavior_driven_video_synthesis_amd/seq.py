@@ -355,6 +355,8 @@ class FlowEngine:
         x2 = x.reshape(x.shape[0], -1)
         if x2.shape[1] != self.C:
             raise ValueError(f"flow over {self.C} channels got {tuple(x.shape)}")
+        if x2.shape[0] == 0:
+            return x2.clone() if reverse else (x2.clone(), x2.new_zeros(0))
         outs, lds = [], []
         for s in range(0, x2.shape[0], MAX_ROWS):
             chunk = x2[s:s + MAX_ROWS]

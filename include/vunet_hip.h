@@ -171,6 +171,13 @@ int vunet_conv2d_bf16(const vunet_conv_desc* d, const float* x1, const float* x2
  *                            input channel) in fp32, stored as blk -- the first layer of the pose encoder */
 int vunet_conv2d_blk(const vunet_conv_desc* d, const void* x1, const void* x2, const void* wb, const float* shift,
                      const void* res, void* y, int32_t y_fp32_nchw, void* stream);
+/* A residual block with a skip input in one launch (lib/modules.py:221-233, eval mode): y = res + conv3x3(elu(cat(x, nin(elu(skip))))),
+ * the 1x1 `nin` computed on the tile's halo in LDS instead of stored and re-loaded; bit-identical to vunet_conv2d_blk(nin) followed by
+ * vunet_conv2d_blk(3x3).  d: the 3x3 (C1 = C2 = M in {32, 64}, ELU prologue, Ws % 32 = 0, Hs % 4 = 0); wb_nin / shift_nin: the nin
+ * layer's vunet_pack_bf16_taps image (taps = 1, row pitch Mpad_nin) and shift.  _supported: 1 / 0. */
+int vunet_conv2d_blk_rnb_supported(const vunet_conv_desc* d);
+int vunet_conv2d_blk_rnb(const vunet_conv_desc* d, const void* x, const void* skip, const void* wb_nin, const float* shift_nin,
+                         int32_t Mpad_nin, const void* wb, const float* shift, const void* res, void* y, void* stream);
 /* 1: vunet_conv2d_blk runs the LDS-tiled kernel for this problem (conv_blk_tiled_kernel), 0: the direct one */
 int vunet_conv2d_blk_tiled(const vunet_conv_desc* d);
 int vunet_pack_bf16_taps(const float* wt_f, void* wb, int32_t C1, int32_t C2, int32_t Mpad, int32_t taps, void* stream);

@@ -241,6 +241,38 @@ def test_render_sequence_layouts_agree():
     assert u8.dtype == torch.uint8 and int((u8.int() - ref8.int()).abs().max()) <= 8
 
 
+@pytest.mark.parametrize("c,n,h,w,nt", [(32, 3, 64, 64, 2), (32, 3, 40, 96, 1), (32, 3, 36, 32, 0), (64, 8, 128, 128, 0),
+                                        (64, 3, 12, 32, 0)])
+def test_fused_residual_block_is_bit_identical_to_its_two_launches(c, n, h, w, nt):
+    """vunet_conv2d_blk_rnb (1x1 nin of the skip tensor on the tile's halo in LDS + 3x3 + residual) vs vunet_conv2d_blk twice:
+    image borders on every side, tile heights 4 and 8, both channel counts.  Bit-identical wherever the separate 1x1 launch
+    sums K in one piece (it splits K over its four waves on small launches of >= 64 channels: there a bf16 ulp may move)."""
+    from behavior_driven_video_synthesis_amd import ops
+    from behavior_driven_video_synthesis_amd.lib.modules import VunetRNB
+    from behavior_driven_video_synthesis_amd.render_blk import BlockedTransfer, to_blk, from_blk
+
+    class _Net:   # the two methods of the executor under test need no model
+        pass
+    blk = VunetRNB(channels=c, a_channels=c, residual=True, dropout_prob=0.0)
+    blk.load_state_dict(synth_state_dict({k: list(v.shape) for k, v in blk.state_dict().items()}, 21))
+    blk = blk.cuda().eval()
+    eng = BlockedTransfer.__new__(BlockedTransfer)
+    eng.vunet, eng._packs, eng.fuse_rnb = _Net(), {}, True
+    x = to_blk(synth_image("rnb.x", (n, c, h, w), 21).cuda() * 2.0)
+    a = to_blk(synth_image("rnb.a", (n, c, h, w), 22).cuda() * 2.0)
+    if nt:
+        ops.set_tuning("blk_force_nt", nt)
+    fused = eng._rnb(blk, x, a)
+    eng.fuse_rnb = False
+    two = eng._rnb(blk, x, a)
+    if c == 64 and n * h * w < 131072:
+        f, t2 = from_blk(fused), from_blk(two)
+        assert float((f - t2).abs().max()) <= 2.0 ** -6 * float(t2.abs().max())     # two bf16 ulps of the largest value
+    else:
+        assert torch.equal(fused, two)
+    assert float(from_blk(fused).abs().max()) > 0.1
+
+
 def test_models_outside_the_blocked_path_fall_back_to_nchw_kernels():
     from behavior_driven_video_synthesis_amd.models.vunets import VunetAlter
     from behavior_driven_video_synthesis_amd.render_blk import BlockedTransfer
@@ -266,14 +298,25 @@ def test_blocked_transfer_at_the_benchmark_widths():
     app = synth_image("app256", (1, 3, size, size), 9).cuda()
     c = synth_image("stick256", (3, 3, size, size), 4).cuda()
     eng = engine_for(net)
+    n_convs = sum(1 for m in list(net.du.modules()) + list(net.dd.modules()) if hasattr(m, "_params"))
+    outs = {}
     with torch.no_grad():
         code = net.appearance_code(app)
         want = net.transfer_code(code, c)
-        ops.profile_start()
-        got = eng.transfer_code(eng.encode_code(code), c)
-        fam = ops.profile_stop()
-    n_convs = sum(1 for m in list(net.du.modules()) + list(net.dd.modules()) if hasattr(m, "_params"))
-    assert fam["conv_blk_fwd"]["n"] == n_convs - 1            # all but the 3-channel first layer (its own kernel)
+        for fuse in (False, True):
+            eng.fuse_rnb = fuse
+            ops.profile_start()
+            outs[fuse] = eng.transfer_code(eng.encode_code(code), c)
+            fam = ops.profile_stop(by_kernel=True)
+            n_blk = sum(v["n"] for k, v in fam.items() if k.startswith("conv_blk_"))
+            n_fused = fam.get("conv_blk_rnb_kernel", {"n": 0})["n"]
+            # all but the 3-channel first layer (its own kernel); a fused block is one launch for two layers
+            assert n_blk == n_convs - 1 - n_fused
+            assert n_fused == (4 if fuse else 0)      # the skip blocks of the 256^2 (32 channels) and 128^2 (64) levels
+    # the fused block rounds where the two launches round; at three frames the separate 64-channel 1x1 launches split K over
+    # their waves, so a bf16 ulp may move there (bit-identity: test_fused_residual_block_is_bit_identical_to_its_two_launches)
+    assert psnr(outs[True], outs[False], peak=2 * float(want.abs().max())) >= 75.0
+    got = outs[True]
     scale = float(want.abs().max())
     db = psnr(got, want, peak=2 * scale)
     assert db >= 60.0, db
