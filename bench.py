@@ -51,6 +51,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
 X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
 FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
 PMC_TRAFFIC_RENDER = ["profiles/r05_pmc_traffic_render.json", "profiles/r04_pmc_traffic_render.json", "profiles/r03_pmc_traffic_render.json"]
+PMC_TRAFFIC_SEQ = ["profiles/r05_pmc_traffic_seq.json"]
 PMC_TRAFFIC = ["profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json",
                "profiles/r01_pmc_traffic.json"]
 
@@ -307,6 +308,20 @@ def behavior_row(vunet, device, size, frames=50, rows=16, iters=10):
     t_e2e = timed(lambda: behavior_video(flow, net, vunet, app, seq[:1], frames, cam, z=z[:1], dtype="bf16", chunk=frames))
     vunet.train(was)
     ach = w_bytes / t_flow / 1e9
+    # HBM bytes of one reverse pass: rocprofv3 PMC passes of tools/time_seq.py --only reverse (tools/profile.sh step 5), committed
+    traffic = traffic_src = None
+    for rel in PMC_TRAFFIC_SEQ:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        kern = {k: v for k, v in pmc.get("kernels", {}).items() if k.startswith("seq_")}
+        coup = [v for k, v in kern.items() if k.startswith("seq_coupling_kernel")]
+        if coup:
+            passes = sum(v["launches_sampled"] for v in coup) / 31.0      # 31 coupling launches per 15-block reverse pass
+            traffic = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in kern.values()) / passes
+            traffic_src = {"file": rel, "collected_at_commit": pmc.get("head", ""), "correction": pmc.get("correction", "")}
+            break
     return {"workload": f"flow reverse ({rows} rows, 15 blocks, 1024 / 2048) + decoder roll-out ({frames} steps, 1024 hidden) + "
                         f"projection, raster and bf16 transfer of one {frames}-frame sequence at {size}x{size} (BASELINE configs[4])",
             "data": "synthetic, random weights",
@@ -314,7 +329,7 @@ def behavior_row(vunet, device, size, frames=50, rows=16, iters=10):
             "sequences_per_s_front_half": rows / (t_flow + t_dec),
             "end_to_end_ms_per_sequence": 1e3 * t_e2e, "end_to_end_frames_per_s": frames / t_e2e,
             "roofline": {"bound": "hbm", "kernel": "seq_linear_kernel (the flow's 120 MLP-layer launches)", "achieved": ach,
-                         "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_pass": w_bytes,
                          "note": "whole reverse pass incl. its 31 coupling launches; per-CU L1 fill bound, see profiles/r05_seq_time.txt"}}
 

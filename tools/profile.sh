@@ -46,6 +46,15 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rfe
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_rwrite -- python3 tools/bench_render.py --iters 1 --chunk 50 --no-ref --only "bf16 blocked+shared_appearance" > /dev/null 2> $OUT/${TAG}_rwrite.err
 python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_rfetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_rwrite/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic_render.json
 rm -rf $OUT/${TAG}_rfetch $OUT/${TAG}_rwrite
+# 5. the behaviour front half (BASELINE config 5): per-kernel times of tools/time_seq.py and the HBM bytes of the flow's reverse
+#    pass (eager issue, one dispatch per launch for the counters; 3 warm-up + 4 timed passes = 7 passes of 31 coupling launches)
+rm -rf $OUT/${TAG}_seq $OUT/${TAG}_sfetch $OUT/${TAG}_swrite
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_seq -- python3 tools/time_seq.py --rows 16 --reps 10 > $OUT/${TAG}_seq_time.json 2> $OUT/${TAG}_seq.err
+cp $(ls $OUT/${TAG}_seq/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_seq_kernel_stats.csv 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_sfetch -- python3 tools/time_seq.py --rows 16 --reps 4 --eager --only reverse > /dev/null 2> $OUT/${TAG}_sfetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_swrite -- python3 tools/time_seq.py --rows 16 --reps 4 --eager --only reverse > /dev/null 2> $OUT/${TAG}_swrite.err
+python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_sfetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_swrite/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic_seq.json
+rm -rf $OUT/${TAG}_seq $OUT/${TAG}_sfetch $OUT/${TAG}_swrite
 # the raw per-dispatch tables are large: keep the summaries only
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
 ls -la $OUT/${TAG}_*

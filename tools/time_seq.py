@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--flows", type=int, default=15)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--only", default=None, choices=[None, "reverse"], help="time the flow's reverse pass only (counter runs)")
     args = ap.parse_args()
     from behavior_driven_video_synthesis_amd.models.flow.simple_flow import UnsupervisedTransformer2
     from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
@@ -56,6 +57,9 @@ def main():
     res["flow_reverse_ms"] = round(t, 4)
     res["flow_weight_GB"] = round(w_bytes / 1e9, 3)
     res["flow_weight_stream_GBps"] = round(w_bytes / t / 1e6, 1)
+    if args.only == "reverse":
+        print(json.dumps(res))
+        return
     t = timed(lambda: flow.flow.engine()._run(z, False), args.reps)
     res["flow_forward_ms"] = round(t, 4)
     b = flow.reverse(z).reshape(args.rows, 1024)
