@@ -183,10 +183,13 @@ def actnorm_apply(mod, x: torch.Tensor, reverse: bool):
 class _GraphCache:
     """Record a launch sequence once per key into a hipGraph and replay it (torch.cuda.CUDAGraph is the handle)."""
 
+    MAX_GRAPHS = 16   # per engine; a caller that keeps changing lengths / start frames does not accumulate recordings
+
     def __init__(self):
         self.graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.enabled = os.environ.get("VUNET_SEQ_GRAPH", "1") != "0"
         self._stream = None
+        self.on_evict = None    # weakref.WeakMethod called with the key of a recording that is dropped (its buffers go too)
 
     def run(self, key, issue):
         if not self.enabled or torch.cuda.is_current_stream_capturing():   # (inside someone else's capture: become part of it)
@@ -209,8 +212,17 @@ class _GraphCache:
             finally:
                 if was_on:
                     gc.enable()
+            if len(self.graphs) >= self.MAX_GRAPHS:
+                self.drop(next(iter(self.graphs)))      # the oldest recording
             self.graphs[key] = g
         g.replay()
+
+
+    def drop(self, key):
+        if self.graphs.pop(key, None) is not None and self.on_evict is not None:
+            cb = self.on_evict()
+            if cb is not None:
+                cb(key)
 
 
 def _versions(params) -> tuple:
@@ -393,6 +405,22 @@ class BehaviorEngine:
         self._packed_for = None
         self._plans: Dict[int, dict] = {}
         self.graph = _GraphCache()
+        self.graph.on_evict = weakref.WeakMethod(self._drop_io)   # (no cycle: the engine's recordings are freed by refcount)
+
+    def _drop_io(self, key):
+        """A recording and the input / output buffers its launches point at live and die together."""
+        for p in self._plans.values():
+            p["io"].pop(key, None)
+
+    def _io(self, p: dict, key, make):
+        io = p["io"].get(key)
+        if io is None:
+            if len(p["io"]) >= _GraphCache.MAX_GRAPHS:
+                old = next(iter(p["io"]))
+                self.graph.drop(old)
+                p["io"].pop(old, None)
+            io = p["io"][key] = make()
+        return io
 
     @property
     def net(self):
@@ -486,12 +514,10 @@ class BehaviorEngine:
             rows, t_in = bc.shape[0], xc.shape[1]
             p = self._plan(rows)
             key = ("dec", rows, t_in, start_frame, length)
-            io = p["io"].get(key)
-            if io is None:
-                dev = b.device
-                io = dict(x=torch.zeros(rows, t_in, self.n, device=dev), xs=torch.zeros(rows, length, self.n, device=dev),
-                          cs=torch.zeros(rows, length, self.n, device=dev))
-                p["io"][key] = io
+            dev = b.device
+            io = self._io(p, key, lambda: dict(x=torch.zeros(rows, t_in, self.n, device=dev),
+                                               xs=torch.zeros(rows, length, self.n, device=dev),
+                                               cs=torch.zeros(rows, length, self.n, device=dev)))
             io["x"].copy_(xc)
             p["b_in"].copy_(bc)
             self.graph.run(key, lambda: self._issue_decode(rows, p, io["x"], t_in, start_frame, length, io["xs"], io["cs"]))
@@ -533,13 +559,10 @@ class BehaviorEngine:
             rows, t_in = sc.shape[0], sc.shape[1]
             p = self._plan(rows)
             key = ("enc", rows, t_in, eps is not None)
-            io = p["io"].get(key)
-            if io is None:
-                dev = seq.device
-                io = dict(x=torch.zeros(rows, t_in, self.n, device=dev), eps=torch.zeros(rows, self.H, device=dev),
-                          mu=torch.zeros(rows, self.H, device=dev), logstd=torch.zeros(rows, self.H, device=dev),
-                          b=torch.zeros(rows, self.H, device=dev))
-                p["io"][key] = io
+            dev = seq.device
+            io = self._io(p, key, lambda: dict(x=torch.zeros(rows, t_in, self.n, device=dev), eps=torch.zeros(rows, self.H, device=dev),
+                                               mu=torch.zeros(rows, self.H, device=dev), logstd=torch.zeros(rows, self.H, device=dev),
+                                               b=torch.zeros(rows, self.H, device=dev)))
             io["x"].copy_(sc)
             if eps is not None:
                 io["eps"].copy_(eps[s:s + MAX_ROWS])

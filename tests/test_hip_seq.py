@@ -294,3 +294,24 @@ def test_behavior_video_end_to_end_vs_the_pieces():
         same = (rgb.int() - frames[i].int()).abs() <= 1
         assert float(same.float().mean()) > 0.995
         assert float(stick.abs().sum()) > 0   # something was drawn
+
+
+def test_recordings_and_their_buffers_are_capped_together():
+    """A caller that keeps changing the roll-out length does not accumulate hipGraphs; an evicted recording takes its input /
+    output buffers with it and a later call with the same key records afresh (same results)."""
+    from behavior_driven_video_synthesis_amd import seq as seq_mod
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    torch.manual_seed(8)
+    net = ResidualBehaviorNet(51, information_bottleneck=True, decoder_arch="lstm", dim_hidden_b=64).cuda()
+    eng = net.engine()
+    b = torch.randn(3, 64, device="cuda")
+    x = 0.5 * torch.randn(3, 4, 51, device="cuda")
+    first = net.generate_seq(b, x, len=2, start_frame=0)[0].clone()
+    cap = seq_mod._GraphCache.MAX_GRAPHS
+    for length in range(3, 3 + cap + 4):
+        net.generate_seq(b, x, len=length, start_frame=0)
+    assert len(eng.graph.graphs) <= cap
+    assert all(len(p["io"]) <= cap for p in eng._plans.values())
+    assert all(k in eng.graph.graphs for p in eng._plans.values() for k in p["io"])
+    again = net.generate_seq(b, x, len=2, start_frame=0)[0]
+    assert torch.equal(first, again)
