@@ -133,6 +133,7 @@ class MlpEngine:
         _need_device(x)
         _lib.lib()
         lin = self.net.linears()
+        _inference_only([p for l in lin for p in (l.weight, l.bias)])
         key = _versions([p for l in lin for p in (l.weight, l.bias)])
         if key != self._packed_for:
             self.k_pad = _up(lin[0].in_features, 32)
@@ -170,6 +171,7 @@ def actnorm_initialize(mod, x: torch.Tensor):
 def actnorm_apply(mod, x: torch.Tensor, reverse: bool):
     """-> (h shaped like x, logdet [B] or None): lib/modules.py:307-316 / :320-331."""
     _need_device(x)
+    _inference_only([mod.loc, mod.scale])
     x2 = _flat2(x).contiguous()
     b, c = x2.shape
     out = torch.empty_like(x2)
@@ -223,6 +225,15 @@ class _GraphCache:
             cb = self.on_evict()
             if cb is not None:
                 cb(key)
+
+
+def _inference_only(params):
+    """The behaviour path has no backward (the training of BASELINE config 4 is not built): a call that autograd would
+    record must fail loudly instead of returning tensors without a graph -- the reference's own inference runs under
+    ``torch.no_grad()`` (experiments/behavior_net.py:1135)."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        raise RuntimeError("the flow / behaviour-net kernels are inference only (no backward is built): call under "
+                           "torch.no_grad() or freeze the parameters")
 
 
 def _versions(params) -> tuple:
@@ -354,6 +365,7 @@ class FlowEngine:
 
     def _run(self, x: torch.Tensor, reverse: bool):
         _need_device(x)
+        _inference_only(self.flow.parameters())
         _lib.lib()
         self._pack()
         if not reverse and not self._initialised():
@@ -503,6 +515,7 @@ class BehaviorEngine:
     def generate_seq(self, b: torch.Tensor, x_pose: torch.Tensor, length: int, start_frame: int):
         """-> (xs [B, len, n], cs [B, len, n]); models/pose_behavior_rnn.py:603-626."""
         _need_device(b, x_pose)
+        _inference_only(self.net.parameters())
         _lib.lib()
         self._pack()
         if x_pose.dim() != 3 or x_pose.shape[2] != self.n or b.shape[1] != self.H:
@@ -549,6 +562,7 @@ class BehaviorEngine:
         """LSTM over ``seq`` [B, T, n] from a zero state.  -> (b, mu, logstd, pre) with the bottleneck heads (b = eps *
         exp(logstd) + mu; eps None: b = mu), else pre   (models/pose_behavior_rnn.py:175-201, :587-601)."""
         _need_device(seq, eps)
+        _inference_only(self.net.parameters())
         _lib.lib()
         self._pack()
         if seq.dim() != 3 or seq.shape[2] != self.n:

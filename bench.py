@@ -293,10 +293,11 @@ def behavior_row(vunet, device, size, frames=50, rows=16, iters=10):
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters
-    t_flow = timed(lambda: flow.reverse(z))
-    b = flow.reverse(z).reshape(rows, 1024)
-    t_dec = timed(lambda: net.generate_seq(b, seq, len=frames, start_frame=frames - 1))
-    t_enc = timed(lambda: net.infer_b(seq, False))
+    with torch.no_grad():
+        t_flow = timed(lambda: flow.reverse(z))
+        b = flow.reverse(z).reshape(rows, 1024)
+        t_dec = timed(lambda: net.generate_seq(b, seq, len=frames, start_frame=frames - 1))
+        t_enc = timed(lambda: net.infer_b(seq, False))
     w_bytes = 4.0 * sum(p.numel() for n, p in flow.named_parameters() if ".main." in n and n.endswith("weight"))
     rng = np.random.RandomState(3)
     cam = PoseCamera((rng.randn(51) * 250.0).astype(np.float32), (40.0 + 40.0 * rng.rand(51)).astype(np.float32), list(range(51)),

@@ -10,6 +10,13 @@ from synth import seeded_randn, synth_behavior_state
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    """The behaviour path is inference only and says so when autograd is recording (last test of this file)."""
+    with torch.no_grad():
+        yield
+
 TOL = dict(rtol=2e-4, atol=2e-5)   # fp32 chains of 20 - 60 layers / 50 recurrent steps, different summation order
 FLOW_TOL = dict(rtol=1e-3, atol=1e-4)   # a flow pass multiplies by exp(+-s) and 1/scale 2 x n_flows times: rounding differences
 #                                         of the MLP sums (k order: four waves x S slabs here, one dot product on the CPU) grow
@@ -315,3 +322,23 @@ def test_recordings_and_their_buffers_are_capped_together():
     assert all(k in eng.graph.graphs for p in eng._plans.values() for k in p["io"])
     again = net.generate_seq(b, x, len=2, start_frame=0)[0]
     assert torch.equal(first, again)
+
+
+def test_a_recorded_call_is_refused():
+    """No backward is built for the behaviour path: with autograd recording and trainable parameters the modules raise instead
+    of handing back tensors without a graph (a reference training loop driven through the drop-in must not train on nothing)."""
+    from behavior_driven_video_synthesis_amd.lib.modules import ActNorm, BasicFullyConnectedNet
+    flow, _ = _random_flow(32, 48, 1, 1, 3)
+    z = torch.randn(2, 32, device="cuda")
+    with torch.enable_grad():
+        with pytest.raises(RuntimeError, match="inference only"):
+            flow.reverse(z)
+        with pytest.raises(RuntimeError, match="inference only"):
+            flow(z)
+        with pytest.raises(RuntimeError, match="inference only"):
+            BasicFullyConnectedNet(dim=16, depth=1, hidden_dim=32).cuda()(z[:, :16])
+        with pytest.raises(RuntimeError, match="inference only"):
+            ActNorm(32).cuda().reverse(z)
+        for p in flow.parameters():
+            p.requires_grad_(False)
+        assert flow.reverse(z).shape == (2, 32, 1, 1)     # frozen parameters: nothing to record
