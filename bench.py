@@ -178,7 +178,55 @@ def cpu_baseline_child(path):
         out["config1"] = {"value": job["batch1"]["pose_img"].shape[0] / statistics.median(t), "unit": "frames/s",
                           "sample": f"BASELINE config 1 (Market 128x128, batch 2, x = 30x64x64): median of {len(t)} timed "
                                     "step(s) after 2 warm-ups, same oracle / threads"}
+    try:
+        out["behavior"] = _cpu_behavior(cores)
+    except Exception as e:   # noqa: BLE001 -- the headline baseline must not depend on this extra row
+        out["behavior"] = {"error": f"{type(e).__name__}: {e}"}
     print("CPU_BASELINE " + json.dumps(out))
+
+
+def _cpu_behavior(cores, rows=16, blocks=3, frames=50):
+    """The behaviour front half of config 5 on the oracle (PyTorch-CPU fp32), bounded: ``blocks`` of the flow's 15 blocks at the
+    reference width (the pass is 15 identical blocks in sequence: time x 5), and the full 50-step decoder roll-out."""
+    from oracle import behavior_oracle as B
+    g = torch.Generator().manual_seed(3)
+    c, mid, c1 = 1024, 2048, 512
+    sd = {}
+    for i in range(blocks):
+        q = f"flow.sub_layers.{i}"
+        sd[f"{q}.norm_layer.loc"] = 0.1 * torch.randn(1, c, 1, 1, generator=g)
+        sd[f"{q}.norm_layer.scale"] = 0.7 + 0.3 * torch.rand(1, c, 1, 1, generator=g)
+        perm = torch.randperm(c, generator=g)
+        sd[f"{q}.shuffle.forward_shuffle_idx"], sd[f"{q}.shuffle.backward_shuffle_idx"] = perm, torch.argsort(perm)
+        for kind in ("s", "t"):
+            for j in range(2):
+                dims = [(mid, c1), (mid, mid), (mid, mid), (c1, mid)]
+                for li, (o, k) in enumerate(dims):
+                    gain = 0.1 if (kind == "s" and li == 3) else 1.0
+                    sd[f"{q}.coupling.{kind}.{j}.main.{2 * li}.weight"] = gain * torch.randn(o, k, generator=g) * (1.5 / k) ** 0.5
+                    sd[f"{q}.coupling.{kind}.{j}.main.{2 * li}.bias"] = 0.1 * torch.randn(o, generator=g)
+    z = torch.randn(rows, c, generator=g)
+    hid, n = 1024, 51
+    dec = {"decoder.rnn.weight_ih": torch.randn(4 * hid, n, generator=g) / hid ** 0.5,
+           "decoder.rnn.weight_hh": torch.randn(4 * hid, hid, generator=g) / hid ** 0.5,
+           "decoder.rnn.bias_ih": 0.1 * torch.randn(4 * hid, generator=g), "decoder.rnn.bias_hh": 0.1 * torch.randn(4 * hid, generator=g),
+           "decoder.n_out.weight": 0.05 * torch.randn(n, hid, generator=g) / hid ** 0.5, "decoder.n_out.bias": 0.1 * torch.randn(n, generator=g)}
+    b, x = torch.randn(rows, hid, generator=g), 0.5 * torch.randn(rows, frames, n, generator=g)
+
+    def med(fn, reps=5):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+    with torch.no_grad():
+        t_flow = med(lambda: B.flow_reverse(sd, z)) * (15.0 / blocks)
+        t_dec = med(lambda: B.generate_seq(dec, b, x, frames, frames - 1))
+    return {"flow_reverse_ms": 1e3 * t_flow, "decode_ms": 1e3 * t_dec, "rows": rows, "cores": cores, "kind": "port",
+            "sample": f"oracle/behavior_oracle.py: flow reverse of {blocks} of the 15 blocks at 1024 / 2048 (x {15 // blocks}: the pass is "
+                      f"15 such blocks in sequence) and the full {frames}-step decoder roll-out at 1024 hidden, {rows} rows, median of 5"}
 
 
 def cpu_baseline(args, cfg, batch, cfg1, batch1):
