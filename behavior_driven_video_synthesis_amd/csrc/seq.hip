@@ -20,9 +20,11 @@
 //     input, same shapes) and the mu / logstd heads run as one launch (grid z).
 //   * seq_coupling_kernel: everything between two MLP evaluations of the flow -- the affine coupling itself, the half swap,
 //     ``Shuffle`` and ``ActNorm`` -- as "v = couple(in); out[c] = affine(v[map[c]])" with a host-composed index map.
-//   * seq_lstm_{enc,dec}_kernel: the gate nonlinearities and state update of one LSTM step, the decoder's output layer +
-//     residual (``ResidualRNNDecoder.forward``) and the next step's operand row [x | 0 | h]; two launches per time step.  The
-//     decoder's optional input layer is folded into the gate matrix when the weights are packed.
+//   * an LSTM step is seq_linear_kernel over the gate matrix [W_ih | 0 | W_hh] with its rows GATE-INTERLEAVED (row 4 j + q =
+//     gate q of unit j): the lane that holds four consecutive output rows of a batch row holds the four gates of one unit and
+//     finishes the cell in its registers -- c', h, the next operand row's h -- so the encoder is ONE launch per time step.  The
+//     decoder adds seq_dec_out_kernel: the output layer + residual (``ResidualRNNDecoder.forward``), which writes the step's pose
+//     and the next operand's x.  The decoder's optional input layer is folded into the gate matrix when the weights are packed.
 #include "common.h"
 
 namespace {
@@ -35,6 +37,15 @@ struct SeqLinearArgs {
   const float* bias[2];   // [M] (NULL: none)
   float* y;               // [nets][Bp][M]
   int M, K, Bp, ldx, act[2], shared_in;
+  // LSTM form (template flag): the rows are gate-interleaved -- row 4 j + q is gate q (i, f, g, o) of hidden unit j -- so the
+  // lane that holds rows 4 kq .. 4 kq + 3 of batch row n holds all four gates of one unit and finishes the cell in registers
+  const float* c_in;      // [Bp][H]
+  float* c_out;           // [Bp][H] (another buffer)
+  float* xh_next;         // [Bp][ldx] the NEXT step's operand rows (another buffer than x): h at hoff
+  float* h_out;           // [Bp][H] or NULL
+  const float* x_next;    // encoder: the next input pose, row b at + b * seq_stride (NULL: the decoder's second launch writes x)
+  long long seq_stride;
+  int H, hoff, n, B;
 };
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -90,9 +101,11 @@ __device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const f
 // D: lane holds batch row n = l & 15 of its tile, output rows 4 (l >> 4) + r of the weight tile.
 // WAVES = 16 where K has >= 16 chunks: a wave's groups are sequential round trips to HBM (four waves with 16 chunks each took
 // 12 us for a layer whose weights stream in 5); with 16 waves the whole tile's weights are requested at once.
-template <int NB, int RT, int WAVES>
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int NB, int RT, int WAVES, bool LSTM = false>
 __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a) {
-  __shared__ float4 red[WAVES - 1][RT][NB][64];
+  __shared__ float4 red[WAVES][RT][NB][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16 * RT, net = blockIdx.z;
@@ -116,26 +129,44 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
     }
   if constexpr (UMAX > 1)
     for (; c < nchunk; c += WAVES) seq_linear_group<NB, RT, 1, WAVES>(a, w, x, c, acc);
-  // waves 1.. -> LDS; wave 0 adds them in wave order
-  if (wave) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        red[wave - 1][rt][nb][lane] = make_float4(acc[rt][nb][0], acc[rt][nb][1], acc[rt][nb][2], acc[rt][nb][3]);
-  }
-  __syncthreads();
-  if (wave) return;
-  float4 v[RT][NB];
+  // every wave's partial -> LDS; wave w < NB adds them in wave order for batch tile w and finishes that tile (the epilogues run
+  // side by side: with tanh / the LSTM cell in them, one wave finishing four tiles was a 4 us tail)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      v[rt][nb] = make_float4(acc[rt][nb][0], acc[rt][nb][1], acc[rt][nb][2], acc[rt][nb][3]);
+    for (int nb = 0; nb < NB; ++nb)
+      red[wave][rt][nb][lane] = make_float4(acc[rt][nb][0], acc[rt][nb][1], acc[rt][nb][2], acc[rt][nb][3]);
+  __syncthreads();
+  if (wave >= NB) return;
+  const int nb = wave;
+  float4 v[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    v[rt] = red[0][rt][nb][lane];
 #pragma unroll 3
-      for (int q = 0; q < WAVES - 1; ++q) v[rt][nb] = add4(v[rt][nb], red[q][rt][nb][lane]);
-    }
+    for (int q = 1; q < WAVES; ++q) v[rt] = add4(v[rt], red[q][rt][nb][lane]);
+  }
   const size_t col = (size_t)m0 + 4 * kq;   // + 16 rt; row n = 16 nb + i
+  if constexpr (LSTM) {
+    // gate order i, f, g, o (torch.nn.LSTMCell, models/pose_behavior_rnn.py:476, :498): c' = sig(f) c + sig(i) tanh(g),
+    // h = sig(o) tanh(c')
+    const int j = (int)(col >> 2);
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias[0] + col);
+    {
+      const int nrow = nb * 16 + i;
+      const float4 g = add4(v[0], bv);
+      const float c2 = sigmoid_f(g.y) * a.c_in[(size_t)nrow * a.H + j] + sigmoid_f(g.x) * tanhf(g.z);
+      const float h = sigmoid_f(g.w) * tanhf(c2);
+      a.c_out[(size_t)nrow * a.H + j] = c2;
+      a.xh_next[(size_t)nrow * a.ldx + a.hoff + j] = h;
+      if (a.h_out) a.h_out[(size_t)nrow * a.H + j] = h;
+    }
+    // the encoder's next input rows: workgroup g copies rows g, g + gridDim.x, ...
+    if (a.x_next && wave == 0)
+      for (int b = blockIdx.x; b < a.B; b += gridDim.x)
+        for (int r = lane; r < a.n; r += 64) a.xh_next[(size_t)b * a.ldx + r] = a.x_next[b * a.seq_stride + r];
+    return;
+  }
   float* y = a.y + (size_t)net * a.Bp * a.M + col;
   const float* bias = a.bias[net];
   const int act = a.act[net];
@@ -143,12 +174,9 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
   for (int rt = 0; rt < RT; ++rt) {
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = *reinterpret_cast<const float4*>(bias + col + 16 * rt);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      float4 t = add4(v[rt][nb], bv);
-      t = make_float4(seq_act(t.x, act), seq_act(t.y, act), seq_act(t.z, act), seq_act(t.w, act));
-      *reinterpret_cast<float4*>(y + (size_t)(nb * 16 + i) * a.M + 16 * rt) = t;
-    }
+    float4 t = add4(v[rt], bv);
+    t = make_float4(seq_act(t.x, act), seq_act(t.y, act), seq_act(t.z, act), seq_act(t.w, act));
+    *reinterpret_cast<float4*>(y + (size_t)(nb * 16 + i) * a.M + 16 * rt) = t;
   }
 }
 
@@ -201,72 +229,25 @@ __global__ __launch_bounds__(256) void seq_coupling_kernel(SeqCouplingArgs a) {
   }
 }
 
-struct SeqLstmArgs {
-  const float* gates;   // [Bp][4 H]: [W_ih | 0 | W_hh] . [x | 0 | h]
-  const float* bias;    // [4 H] b_ih
-  const float* bias2;   // [4 H] b_hh
-  const float* bias3;   // [4 H] W_ih b_in of a folded input layer (NULL: none)
-  const float* c_in;    // [Bp][H] cell state of the previous step
-  float* c_out;         // [Bp][H] (a different buffer: every workgroup of a row reads c_in)
-  float* xh;            // [Bp][ldx] operand row of the next step: x at 0, h at hoff
-  float* h_out;         // [Bp][H] copy of h (NULL: none) -- the encoder's ``pre``
-  // decoder (w_out != NULL): x' = n_out(h) + x, xs[b] = x', cs[b] = x; x' is the next operand
+struct SeqDecOutArgs {
+  const float* xh;      // [Bp][ldx] the operand rows the fused gate launch just wrote: h at hoff
+  float* xh_w;          // the same buffer: x' goes to columns 0 .. n
   const float* w_out;   // [n][H]
   const float* b_out;
   float* xraw;          // [Bp][ldraw] the step's input pose (the residual), replaced by x'
   float* xs;            // row b at xs + b * seq_stride
   float* cs;
-  // encoder (w_out == NULL): the next input comes from the sequence
-  const float* x_next;  // row b at x_next + b * seq_stride (NULL at the last step)
   long long seq_stride;
-  int B, Bp, H, ldx, hoff, n, ldraw;
+  int B, H, ldx, hoff, n, ldraw;
 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
-
-// gate order i, f, g, o (torch.nn.LSTMCell, models/pose_behavior_rnn.py:476, :498)
-__device__ __forceinline__ float seq_lstm_cell(const SeqLstmArgs& a, int b, int j, float& c2) {
-  float g[4];
-  const float* gp = a.gates + (size_t)b * 4 * a.H + j;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    g[q] = a.bias[q * a.H + j] + a.bias2[q * a.H + j];
-    if (a.bias3) g[q] += a.bias3[q * a.H + j];
-    g[q] += gp[q * a.H];
-  }
-  c2 = sigmoid_f(g[1]) * a.c_in[(size_t)b * a.H + j] + sigmoid_f(g[0]) * tanhf(g[2]);
-  return sigmoid_f(g[3]) * tanhf(c2);
-}
-
-// encoder step: grid (B, H / 256): one thread per hidden unit
-__global__ __launch_bounds__(256) void seq_lstm_enc_kernel(SeqLstmArgs a) {
-  const int b = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
-  if (j < a.H) {
-    float c2;
-    const float h = seq_lstm_cell(a, b, j, c2);
-    a.c_out[(size_t)b * a.H + j] = c2;
-    a.xh[(size_t)b * a.ldx + a.hoff + j] = h;
-    if (a.h_out) a.h_out[(size_t)b * a.H + j] = h;
-  }
-  if (a.x_next && j < a.n) a.xh[(size_t)b * a.ldx + j] = a.x_next[b * a.seq_stride + j];
-}
-
-// decoder step: grid (B, ceil(n / 8)), 256 threads, dynamic LDS: H floats.  Every workgroup of a row recomputes the row's h
-// (1024 units: ~80 L2 loads per thread) so that the 51 output rows spread over 7 workgroups instead of queueing in one; wave w
-// of workgroup y owns output rows 8 y + w and 8 y + w + 4.  Workgroup y = 0 publishes c and h.
-__global__ __launch_bounds__(256) void seq_lstm_dec_kernel(SeqLstmArgs a) {
+// The decoder's second launch of a step (models/pose_behavior_rnn.py:504-506): x' = n_out(h) + x, xs[b] = x', cs[b] = x, and x'
+// becomes the next operand.  grid (B, ceil(n / 8)), 256 threads, dynamic LDS: H floats; wave w of workgroup y owns output rows
+// 8 y + w and 8 y + w + 4.
+__global__ __launch_bounds__(256) void seq_dec_out_kernel(SeqDecOutArgs a) {
   extern __shared__ float hs[];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = threadIdx.x; j < a.H; j += 256) {
-    float c2;
-    const float h = seq_lstm_cell(a, b, j, c2);
-    hs[j] = h;
-    if (blockIdx.y == 0) {
-      a.c_out[(size_t)b * a.H + j] = c2;
-      a.xh[(size_t)b * a.ldx + a.hoff + j] = h;
-      if (a.h_out) a.h_out[(size_t)b * a.H + j] = h;
-    }
-  }
+  for (int j = threadIdx.x; j < a.H; j += 256) hs[j] = a.xh[(size_t)b * a.ldx + a.hoff + j];
   __syncthreads();
   const int r0 = blockIdx.y * 8 + wave, r1 = r0 + 4;
   const bool v0 = r0 < a.n, v1 = r1 < a.n;
@@ -274,7 +255,7 @@ __global__ __launch_bounds__(256) void seq_lstm_dec_kernel(SeqLstmArgs a) {
   const float* w1 = a.w_out + (size_t)(v1 ? r1 : 0) * a.H;
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll 8
-  for (int j = lane; j < a.H; j += 64) {   // out = n_out(h) + res (:504-506)
+  for (int j = lane; j < a.H; j += 64) {
     const float h = hs[j];
     s0 += w0[j] * h;
     s1 += w1[j] * h;
@@ -291,9 +272,19 @@ __global__ __launch_bounds__(256) void seq_lstm_dec_kernel(SeqLstmArgs a) {
       a.xs[b * a.seq_stride + r] = x2;
       a.cs[b * a.seq_stride + r] = res;
       a.xraw[(size_t)b * a.ldraw + r] = x2;
-      a.xh[(size_t)b * a.ldx + r] = x2;
+      a.xh_w[(size_t)b * a.ldx + r] = x2;
     }
   }
+}
+
+// bias_perm[4 j + q] = b_ih[q H + j] + b_hh[q H + j] (+ fold[q H + j]): the gate-interleaved row order of the fused launch
+__global__ __launch_bounds__(256) void seq_lstm_bias_kernel(const float* b_ih, const float* b_hh, const float* fold, int H, float* out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4 * H) return;
+  const int j = idx >> 2, q = idx & 3;
+  float v = b_ih[q * H + j] + b_hh[q * H + j];
+  if (fold) v += fold[q * H + j];
+  out[idx] = v;
 }
 
 // first operand row [x0 | 0 | h0] and the initial state; grid B, 256 threads
@@ -336,13 +327,14 @@ __global__ __launch_bounds__(256) void seq_bottleneck_kernel(const float* heads,
   if (bout) bout[idx] = eps ? eps[idx] * expf(l) + m : m;
 }
 
-// dst[m][col_off + k] = src[m][k] * (row_scale ? row_scale[m] : 1) for m < M, k < K; dst is a zero-filled padded image
+// dst[row_off + row_mul m][col_off + k] = src[m][k] * (row_scale ? row_scale[m] : 1) for m < M, k < K; dst is a zero-filled
+// padded image (row_mul = 4, row_off = q: gate q of an LSTM into the gate-interleaved row order)
 __global__ __launch_bounds__(256) void seq_pack_rows_kernel(const float* src, int M, int K, const float* row_scale, float* dst,
-                                                            int ld_dst, int col_off) {
+                                                            int ld_dst, int col_off, int row_off, int row_mul) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)M * K) return;
   const int m = (int)(idx / K), k = (int)(idx - (size_t)m * K);
-  dst[(size_t)m * ld_dst + col_off + k] = src[idx] * (row_scale ? row_scale[m] : 1.f);
+  dst[(size_t)(row_off + row_mul * m) * ld_dst + col_off + k] = src[idx] * (row_scale ? row_scale[m] : 1.f);
 }
 
 // NormConv2d with a 1x1 kernel as a linear layer (lib/modules.py:135-145): row_scale[m] = gamma g / ||v_m||,
@@ -452,6 +444,8 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   a.act[0] = d->act0;
   a.act[1] = d->act1;
   a.shared_in = d->shared_in;
+  a.c_in = nullptr; a.c_out = nullptr; a.xh_next = nullptr; a.h_out = nullptr; a.x_next = nullptr;
+  a.seq_stride = 0; a.H = a.hoff = a.n = a.B = 0;
   // (RT = 2, a 32-row tile per workgroup, halves the operand traffic per weight byte but leaves half the CUs without a workgroup
   // at every layer size of the reference configuration: not instantiated)
   const dim3 grid(d->M / 16, 1, d->nets);
@@ -509,45 +503,81 @@ extern "C" int vunet_seq_start(const float* x0, int64_t x0_stride, const float* 
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_lstm_step(const vunet_seq_lstm_desc* d, const float* gates, const float* bias, const float* bias2,
-                                   const float* bias3, const float* c_in, float* c_out, float* xh, float* h_out, const float* w_out,
-                                   const float* b_out, float* xraw, float* xs, float* cs, const float* x_next, void* stream) {
-  if (!d || !gates || !bias || !bias2 || !c_in || !c_out || c_in == c_out || !xh || d->B < 1 || d->H < 1 || d->n < 1)
-    return VUNET_ERR_ARG;
-  if (d->hoff < d->n || d->ldx < d->hoff + d->H) return VUNET_ERR_ARG;
-  if (w_out && (!b_out || !xraw || !xs || !cs || d->ldraw < d->n)) return VUNET_ERR_ARG;
-  SeqLstmArgs a;
-  a.gates = gates;
-  a.bias = bias;
-  a.bias2 = bias2;
-  a.bias3 = bias3;
+extern "C" int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
+                                    const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, void* stream) {
+  if (!d || !w_perm || !xh || !bias_perm || !c_in || !c_out || c_in == c_out || !xh_next || xh_next == xh) return VUNET_ERR_ARG;
+  if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->H < 4 || d->H % 4 || d->n < 1 || d->hoff < d->n || d->ldx < d->hoff + d->H) return VUNET_ERR_ARG;
+  if (d->ldx % 32) return VUNET_ERR_ARG;
+  SeqLinearArgs a;
+  a.w[0] = w_perm;
+  a.w[1] = nullptr;
+  a.x = xh;
+  a.bias[0] = bias_perm;
+  a.bias[1] = nullptr;
+  a.y = nullptr;
+  a.M = 4 * d->H;
+  a.K = d->ldx;
+  a.Bp = (d->B + 15) / 16 * 16;
+  a.ldx = d->ldx;
+  a.act[0] = a.act[1] = 0;
+  a.shared_in = 1;
   a.c_in = c_in;
   a.c_out = c_out;
-  a.xh = xh;
+  a.xh_next = xh_next;
   a.h_out = h_out;
+  a.x_next = x_next;
+  a.seq_stride = d->seq_stride;
+  a.H = d->H;
+  a.hoff = d->hoff;
+  a.n = d->n;
+  a.B = d->B;
+  const dim3 grid(a.M / 16, 1, 1);
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = a.K >= 16 * 32;
+#define SEQ_LSTM_CASE(NB)                                                                      \
+  case NB:                                                                                     \
+    if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16, true>), grid, dim3(1024), 0, st, a);  \
+    else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4, true>), grid, dim3(256), 0, st, a);         \
+    break;
+  switch (a.Bp / 16) {
+    SEQ_LSTM_CASE(1)
+    SEQ_LSTM_CASE(2)
+    SEQ_LSTM_CASE(3)
+    SEQ_LSTM_CASE(4)
+    default: return VUNET_ERR_ARG;
+  }
+#undef SEQ_LSTM_CASE
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_decoder_out(const vunet_seq_lstm_desc* d, float* xh, const float* w_out, const float* b_out, float* xraw, float* xs,
+                                     float* cs, void* stream) {
+  if (!d || !xh || !w_out || !b_out || !xraw || !xs || !cs || d->B < 1 || d->H < 1 || d->n < 1) return VUNET_ERR_ARG;
+  if (d->hoff < d->n || d->ldx < d->hoff + d->H || d->ldraw < d->n) return VUNET_ERR_ARG;
+  const size_t lds = (size_t)d->H * sizeof(float);
+  if (lds > 64 * 1024) return VUNET_ERR_UNSUPPORTED;
+  SeqDecOutArgs a;
+  a.xh = xh;
+  a.xh_w = xh;
   a.w_out = w_out;
   a.b_out = b_out;
   a.xraw = xraw;
   a.xs = xs;
   a.cs = cs;
-  a.x_next = x_next;
   a.seq_stride = d->seq_stride;
   a.B = d->B;
-  a.Bp = (d->B + 15) / 16 * 16;
   a.H = d->H;
   a.ldx = d->ldx;
   a.hoff = d->hoff;
   a.n = d->n;
   a.ldraw = d->ldraw;
-  hipStream_t st = (hipStream_t)stream;
-  if (!w_out) {
-    if (d->n > 256) return VUNET_ERR_UNSUPPORTED;
-    VUNET_LAUNCH(seq_lstm_enc_kernel, dim3(d->B, (d->H + 255) / 256), dim3(256), 0, st, a);
-    return vunet_check_launch();
-  }
-  const size_t lds = (size_t)d->H * sizeof(float);
-  if (lds > 64 * 1024) return VUNET_ERR_UNSUPPORTED;
-  VUNET_LAUNCH(seq_lstm_dec_kernel, dim3(d->B, (d->n + 7) / 8), dim3(256), lds, st, a);
+  VUNET_LAUNCH(seq_dec_out_kernel, dim3(d->B, (d->n + 7) / 8), dim3(256), lds, (hipStream_t)stream, a);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_lstm_bias(const float* b_ih, const float* b_hh, const float* fold, int32_t H, float* bias_perm, void* stream) {
+  if (!b_ih || !b_hh || !bias_perm || H < 1) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(seq_lstm_bias_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, b_ih, b_hh, fold, H, bias_perm);
   return vunet_check_launch();
 }
 
@@ -569,11 +599,11 @@ extern "C" int vunet_seq_bottleneck(const float* heads, int32_t Mp, const float*
 }
 
 extern "C" int vunet_seq_pack_rows(const float* src, int32_t M, int32_t K, const float* row_scale, float* dst, int32_t ld_dst,
-                                   int32_t col_off, void* stream) {
-  if (!src || !dst || M < 1 || K < 1 || col_off < 0 || ld_dst < col_off + K) return VUNET_ERR_ARG;
+                                   int32_t col_off, int32_t row_off, int32_t row_mul, void* stream) {
+  if (!src || !dst || M < 1 || K < 1 || col_off < 0 || ld_dst < col_off + K || row_off < 0 || row_mul < 1) return VUNET_ERR_ARG;
   const size_t n = (size_t)M * K;
   VUNET_LAUNCH(seq_pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, M, K, row_scale, dst,
-               ld_dst, col_off);
+               ld_dst, col_off, row_off, row_mul);
   return vunet_check_launch();
 }
 

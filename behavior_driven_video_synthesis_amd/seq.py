@@ -60,7 +60,7 @@ def weight_image(w: torch.Tensor, m_pad: int, k_pad: int, col_off: int = 0, row_
         return w2
     if out is None:
         out = torch.zeros(m_pad, k_pad, device=w.device, dtype=torch.float32)
-    _call("vunet_seq_pack_rows", _p(w2.contiguous()), m, k, _p(row_scale), _p(out), k_pad, col_off, _stream())
+    _call("vunet_seq_pack_rows", _p(w2.contiguous()), m, k, _p(row_scale), _p(out), k_pad, col_off, 0, 1, _stream())
     return out
 
 
@@ -69,7 +69,7 @@ def padded_vector(b: torch.Tensor, n_pad: int) -> torch.Tensor:
     if b1.numel() == n_pad and b1.is_contiguous():
         return b1
     out = torch.zeros(n_pad, device=b.device, dtype=torch.float32)
-    _call("vunet_seq_pack_rows", _p(b1.contiguous()), 1, b1.numel(), None, _p(out), n_pad, 0, _stream())
+    _call("vunet_seq_pack_rows", _p(b1.contiguous()), 1, b1.numel(), None, _p(out), n_pad, 0, 0, 1, _stream())
     return out
 
 
@@ -453,10 +453,19 @@ class BehaviorEngine:
         dev = dec.rnn.weight_ih.device
 
         def gate_image(w_ih, w_hh):
+            """[W_ih | 0 | W_hh] with gate-interleaved rows: row 4 j + q = gate q (i, f, g, o) of hidden unit j."""
             img = torch.zeros(4 * self.H, self.ldx, device=dev)
-            weight_image(w_ih, 4 * self.H, self.ldx, 0, out=img)
-            weight_image(w_hh, 4 * self.H, self.ldx, self.hoff, out=img)
+            for src, off in ((w_ih.detach().contiguous(), 0), (w_hh.detach().contiguous(), self.hoff)):
+                for q in range(4):
+                    part = src[q * self.H:(q + 1) * self.H]
+                    _call("vunet_seq_pack_rows", _p(part), self.H, part.shape[1], None, _p(img), self.ldx, off, q, 4, _stream())
             return img
+
+        def gate_bias(b_ih, b_hh, fold):
+            out = torch.empty(4 * self.H, device=dev)
+            _call("vunet_seq_lstm_bias", _p(b_ih.detach().contiguous()), _p(b_hh.detach().contiguous()), _p(fold), self.H, _p(out),
+                  _stream())
+            return out
         self.dec_fold_bias = None
         w_ih = dec.rnn.weight_ih
         if dec.use_nin:   # x = n_in(x) in front of the cell (:494-495): W_ih (W_in x + b_in) = (W_ih W_in) x + W_ih b_in
@@ -465,7 +474,9 @@ class BehaviorEngine:
                   _p(dec.n_in.bias.detach().contiguous()), 4 * self.H, self.n, _p(w_fold), _p(self.dec_fold_bias), _stream())
             w_ih = w_fold
         self.dec_w = gate_image(w_ih, dec.rnn.weight_hh)
+        self.dec_b = gate_bias(dec.rnn.bias_ih, dec.rnn.bias_hh, self.dec_fold_bias)
         self.enc_w = gate_image(enc.rnn.weight_ih_l0, enc.rnn.weight_hh_l0)
+        self.enc_b = gate_bias(enc.rnn.bias_ih_l0, enc.rnn.bias_hh_l0, None)
         self.heads = None
         if enc.ib:
             scales, biases = [], []
@@ -486,31 +497,27 @@ class BehaviorEngine:
         if p is None:
             dev = self.dec_w.device
             b_pad = _up(rows, 16)
-            p = dict(b_pad=b_pad, xh=torch.zeros(b_pad, self.ldx, device=dev),
+            p = dict(b_pad=b_pad, xh=[torch.zeros(b_pad, self.ldx, device=dev) for _ in range(2)],
                      c=[torch.zeros(b_pad, self.H, device=dev) for _ in range(2)],
-                     xraw=torch.zeros(b_pad, self.ldraw, device=dev), gates=torch.zeros(b_pad * 4 * self.H, device=dev),
+                     xraw=torch.zeros(b_pad, self.ldraw, device=dev),
                      pre=torch.zeros(b_pad, self.H, device=dev), b_in=torch.zeros(rows, self.H, device=dev),
                      heads=torch.zeros(2 * b_pad * self.H, device=dev), io={})
             self._plans[rows] = p
         return p
 
-    def _gates(self, rows, p, w):
-        d = SeqLinearDesc(rows, 4 * self.H, self.ldx, self.ldx, ACT_NONE, ACT_NONE, 1, 1)
-        linear(d, [w], p["xh"], [None], p["gates"])
-
     def _issue_decode(self, rows, p, x_pose, t_in, start_frame, length, xs, cs):
         dec = self.net.decoder
         n, esz = self.n, 4
         x0 = ctypes.c_void_p(x_pose.data_ptr() + start_frame * n * esz)
-        _call("vunet_seq_start", x0, t_in * n, _p(p["b_in"]), _p(p["b_in"]), _p(p["xraw"]), self.ldraw, _p(p["xh"]), self.ldx, self.hoff,
-              _p(p["c"][0]), rows, n, self.H, _stream())
+        _call("vunet_seq_start", x0, t_in * n, _p(p["b_in"]), _p(p["b_in"]), _p(p["xraw"]), self.ldraw, _p(p["xh"][0]), self.ldx,
+              self.hoff, _p(p["c"][0]), rows, n, self.H, _stream())
         d = SeqLstmDesc(rows, self.H, self.ldx, self.hoff, n, self.ldraw, length * n)
         for t in range(length):
-            self._gates(rows, p, self.dec_w)
-            _call("vunet_seq_lstm_step", ctypes.byref(d), _p(p["gates"]), _p(dec.rnn.bias_ih.detach()), _p(dec.rnn.bias_hh.detach()),
-                  _p(self.dec_fold_bias), _p(p["c"][t % 2]), _p(p["c"][1 - t % 2]), _p(p["xh"]), None, _p(dec.n_out.weight.detach()),
-                  _p(dec.n_out.bias.detach()), _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz),
-                  ctypes.c_void_p(cs.data_ptr() + t * n * esz), None, _stream())
+            cur, nxt = t % 2, 1 - t % 2
+            _call("vunet_seq_lstm_gates", ctypes.byref(d), _p(self.dec_w), _p(p["xh"][cur]), _p(self.dec_b), _p(p["c"][cur]),
+                  _p(p["c"][nxt]), _p(p["xh"][nxt]), None, None, _stream())
+            _call("vunet_seq_decoder_out", ctypes.byref(d), _p(p["xh"][nxt]), _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()),
+                  _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), _stream())
 
     def generate_seq(self, b: torch.Tensor, x_pose: torch.Tensor, length: int, start_frame: int):
         """-> (xs [B, len, n], cs [B, len, n]); models/pose_behavior_rnn.py:603-626."""
@@ -541,17 +548,15 @@ class BehaviorEngine:
         return torch.cat(xs_all), torch.cat(cs_all)
 
     def _issue_encode(self, rows, p, seq, t_in, eps, mu, logstd, b_out):
-        enc = self.net.b_enc
         n, esz = self.n, 4
-        _call("vunet_seq_start", _p(seq), t_in * n, None, None, None, 0, _p(p["xh"]), self.ldx, self.hoff, _p(p["c"][0]), rows, n, self.H,
-              _stream())
+        _call("vunet_seq_start", _p(seq), t_in * n, None, None, None, 0, _p(p["xh"][0]), self.ldx, self.hoff, _p(p["c"][0]), rows, n,
+              self.H, _stream())
         d = SeqLstmDesc(rows, self.H, self.ldx, self.hoff, n, self.ldraw, t_in * n)
-        for t in range(t_in):
-            self._gates(rows, p, self.enc_w)
-            nxt = ctypes.c_void_p(seq.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
-            _call("vunet_seq_lstm_step", ctypes.byref(d), _p(p["gates"]), _p(enc.rnn.bias_ih_l0.detach()), _p(enc.rnn.bias_hh_l0.detach()),
-                  None, _p(p["c"][t % 2]), _p(p["c"][1 - t % 2]), _p(p["xh"]), _p(p["pre"]) if t == t_in - 1 else None, None, None, None,
-                  None, None, nxt, _stream())
+        for t in range(t_in):   # one launch per time step: gate product, cell update and the next input row
+            cur, nxt = t % 2, 1 - t % 2
+            x_next = ctypes.c_void_p(seq.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
+            _call("vunet_seq_lstm_gates", ctypes.byref(d), _p(self.enc_w), _p(p["xh"][cur]), _p(self.enc_b), _p(p["c"][cur]),
+                  _p(p["c"][nxt]), _p(p["xh"][nxt]), _p(p["pre"]) if t == t_in - 1 else None, x_next, _stream())
         if self.heads is not None:
             w, bias = self.heads
             dl = SeqLinearDesc(rows, self.H, self.H, self.H, ACT_NONE, ACT_NONE, 2, 1)

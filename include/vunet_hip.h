@@ -608,17 +608,21 @@ int vunet_p2_pool_bwd(const void* t, const int32_t* tmeta, const void* p, const 
  *                         are ld_in / ld_out floats apart.
  *   vunet_seq_start       first operand row of a recurrence: xh[b] = [x0[b] | 0 | h0[b]], c = c0 (NULL: zeros), xraw[b] = x0[b]
  *                         (NULL: skip); x0 row b at x0 + b * x0_stride.  hoff >= n, ldx >= hoff + H.
- *   vunet_seq_lstm_step   gates: [Bp][4H] = [W_ih | 0 | W_hh] . xh (vunet_seq_linear without bias), bias / bias2 / bias3 = b_ih / b_hh /
- *                         the folded input layer's W_ih b_in (NULL), gate order i, f, g, o: c' = sig(f) c + sig(i) tanh(g),
- *                         h = sig(o) tanh(c'); h -> xh[b][hoff..], c_in -> c_out (two buffers, swapped by the caller per step), h_out
- *                         (optional copy).  Decoder (w_out != NULL): x' = w_out h + b_out + xraw[b]; xs[b] = x', cs[b] = the old
- *                         xraw[b] (rows at + b * seq_stride); xraw[b] = x'; xh[b][0..n) = x'.
- *                         Encoder (w_out == NULL): xh[b][0..n) = x_next[b] (row at + b * seq_stride; NULL: left alone).
+ *   vunet_seq_lstm_gates  one LSTM step's gate product AND cell update: w_perm = [W_ih | 0 | W_hh] with GATE-INTERLEAVED rows (row
+ *                         4 j + q = gate q of hidden unit j, q = i, f, g, o; vunet_seq_pack_rows with row_mul = 4, row_off = q),
+ *                         bias_perm likewise (vunet_seq_lstm_bias); xh: this step's operand rows [Bp][ldx] = [x | 0 | h];
+ *                         c' = sig(f) c_in + sig(i) tanh(g) -> c_out, h = sig(o) tanh(c') -> xh_next[b][hoff..] (and h_out, optional):
+ *                         xh_next and c_out are OTHER buffers than xh and c_in (every workgroup reads those), swapped by the caller
+ *                         per step.  x_next != NULL (the encoder): xh_next[b][0..n) = x_next[b] (row at + b * seq_stride).
+ *   vunet_seq_decoder_out the decoder's second launch of a step: x' = w_out h + b_out + xraw[b] with h = xh[b][hoff..]; xs[b] = x',
+ *                         cs[b] = the old xraw[b] (rows at + b * seq_stride); xraw[b] = x'; xh[b][0..n) = x'.
+ *   vunet_seq_lstm_bias   bias_perm[4 j + q] = b_ih[q H + j] + b_hh[q H + j] (+ fold[q H + j], the folded input layer's W_ih b_in).
  *   vunet_seq_fold_input  ``linear_in_decoder`` (models/pose_behavior_rnn.py:494-495) folded into the gate matrix:
  *                         w_fold [M][n] = w_ih [M][n] . w_in [n][n], bias_fold [M] = w_ih . b_in.
  *   vunet_seq_bottleneck  heads: [2][Bp][Mp] = (mu, logstd) from vunet_seq_linear with nets = 2; copies them out and forms
  *                         b = eps exp(logstd) + mu (eps NULL: mu; b_out NULL: skip)   (models/pose_behavior_rnn.py:180-201).
- *   vunet_seq_pack_rows   dst[m][col_off + k] = src[m][k] * (row_scale ? row_scale[m] : 1): builds the zero-padded weight images.
+ *   vunet_seq_pack_rows   dst[row_off + row_mul m][col_off + k] = src[m][k] * (row_scale ? row_scale[m] : 1): builds the zero-padded
+ *                         weight images (row_off 0, row_mul 1: plain).
  *   vunet_seq_normlinear_rows   NormConv2d 1x1 as a linear layer (lib/modules.py:135-145): row_scale[m] = gamma g / ||v_m||,
  *                         bias_eff[m] = gamma bias + beta.
  *   vunet_seq_pose_project      decoded pose vectors -> pixel keypoints [T][J][2]: unNormalizeData (data/data_conversions_3d.py:178-211;
@@ -644,15 +648,17 @@ int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const 
                        const float* loc, float* out, float* logdet, void* stream);
 int vunet_seq_start(const float* x0, int64_t x0_stride, const float* h0, const float* c0, float* xraw, int32_t ldraw, float* xh,
                     int32_t ldx, int32_t hoff, float* c, int32_t B, int32_t n, int32_t H, void* stream);
-int vunet_seq_lstm_step(const vunet_seq_lstm_desc* d, const float* gates, const float* bias, const float* bias2, const float* bias3,
-                        const float* c_in, float* c_out, float* xh, float* h_out, const float* w_out, const float* b_out, float* xraw,
-                        float* xs, float* cs, const float* x_next, void* stream);
+int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm, const float* c_in,
+                         float* c_out, float* xh_next, float* h_out, const float* x_next, void* stream);
+int vunet_seq_decoder_out(const vunet_seq_lstm_desc* d, float* xh, const float* w_out, const float* b_out, float* xraw, float* xs,
+                          float* cs, void* stream);
+int vunet_seq_lstm_bias(const float* b_ih, const float* b_hh, const float* fold, int32_t H, float* bias_perm, void* stream);
 int vunet_seq_fold_input(const float* w_ih, const float* w_in, const float* b_in, int32_t M, int32_t n, float* w_fold,
                          float* bias_fold, void* stream);
 int vunet_seq_bottleneck(const float* heads, int32_t Mp, const float* eps, float* mu, float* logstd, float* b_out, int32_t B,
                          int32_t H, void* stream);
 int vunet_seq_pack_rows(const float* src, int32_t M, int32_t K, const float* row_scale, float* dst, int32_t ld_dst, int32_t col_off,
-                        void* stream);
+                        int32_t row_off, int32_t row_mul, void* stream);
 int vunet_seq_pose_project(const float* x, int32_t n_use, const int32_t* dims_to_use, const double* mean, const double* stdv, int32_t D,
                            int32_t f32_math, const double* cam, float* kps, int32_t T, int32_t J, void* stream);
 int vunet_seq_actnorm_init(const float* x, int32_t ld, int32_t B, int32_t C, float* loc, float* scale, void* stream);
