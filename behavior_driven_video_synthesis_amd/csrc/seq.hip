@@ -37,6 +37,7 @@ struct SeqLinearArgs {
   const float* bias[2];   // [M] (NULL: none)
   float* y;               // [nets][Bp][M]
   int M, K, Bp, ldx, act[2], shared_in;
+  int S;                  // > 1: K split over grid.y workgroups, y = [nets][S][Bp][M] RAW partial slabs (no bias, no activation)
   // LSTM form (template flag): the rows are gate-interleaved -- row 4 j + q is gate q (i, f, g, o) of hidden unit j -- so the
   // lane that holds rows 4 kq .. 4 kq + 3 of batch row n holds all four gates of one unit and finishes the cell in registers
   const float* c_in;      // [Bp][H]
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16 * RT, net = blockIdx.z;
-  const int nchunk = a.K >> 5;
-  const float* __restrict__ w = a.w[net] + (size_t)(m0 + i) * a.K + 8 * kq;
-  const float* __restrict__ x = a.x + (a.shared_in ? 0 : (size_t)net * a.Bp * a.ldx) + (size_t)i * a.ldx + 8 * kq;
+  const int kb = a.K / a.S, nchunk = kb >> 5;   // (S = 1 everywhere but the flow's 512-row head layers)
+  const float* __restrict__ w = a.w[net] + (size_t)(m0 + i) * a.K + (size_t)blockIdx.y * kb + 8 * kq;
+  const float* __restrict__ x = a.x + (a.shared_in ? 0 : (size_t)net * a.Bp * a.ldx) + (size_t)i * a.ldx + (size_t)blockIdx.y * kb + 8 * kq;
   f32x4 acc[RT][NB];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -167,6 +168,12 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
         for (int r = lane; r < a.n; r += 64) a.xh_next[(size_t)b * a.ldx + r] = a.x_next[b * a.seq_stride + r];
     return;
   }
+  if (a.S > 1) {   // a raw partial slab: the consumer (seq_coupling_kernel) adds the slabs in slab order, the bias and the tanh
+    float* ys = a.y + ((size_t)net * a.S + blockIdx.y) * a.Bp * a.M + col;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float4*>(ys + (size_t)(nb * 16 + i) * a.M + 16 * rt) = v[rt];
+    return;
+  }
   float* y = a.y + (size_t)net * a.Bp * a.M + col;
   const float* bias = a.bias[net];
   const int act = a.act[net];
@@ -182,13 +189,16 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
 
 struct SeqCouplingArgs {
   const float* in;       // [B..][ld_in]: xa = in[b][0..c1), xk = in[b][c1..C)
-  const float* st;       // [2][Bp][Mp]: s = tanh(scale net) (0) and t = translation net (1); NULL: no coupling (v = in)
+  const float* st;       // [2][S][Bp][Mp]: the scale net's (0) and the translation net's (1) head; NULL: no coupling (v = in).
+                         // S = 1: finished values (s already through tanh); S > 1: raw partial slabs, bias_s / bias_t apply
+  const float* bias_s;
+  const float* bias_t;
   const int* map;        // [C] out[c] = v[map[c]]; NULL: identity
   const float* scale;    // [C] ActNorm scale / loc (NULL: none)
   const float* loc;
   float* out;            // [B..][ld_out]
   float* logdet;         // [B] forward only: += sum(s) + sum log|scale|
-  int B, Bp, C, c1, ld_in, ld_out, Mp, reverse, affine_on_src;
+  int B, Bp, C, c1, ld_in, ld_out, Mp, reverse, affine_on_src, S;
 };
 
 // grid (B, Y), 256 threads: batch row b, channels blockIdx.y * 256 + t, + 256 Y, ...  With a log-determinant to accumulate Y = 1
@@ -203,7 +213,31 @@ __global__ __launch_bounds__(256) void seq_coupling_kernel(SeqCouplingArgs a) {
     float v = in[j];
     if (a.st && j >= a.c1) {
       const int q = j - a.c1;
-      const float s = a.st[(size_t)b * a.Mp + q], t = a.st[((size_t)a.Bp + b) * a.Mp + q];
+      float s, t;
+      if (a.S == 1) {
+        s = a.st[(size_t)b * a.Mp + q];
+        t = a.st[((size_t)a.Bp + b) * a.Mp + q];
+      } else {   // (S <= 8) all slab loads in flight, added in slab order; then bias, and tanh for the scale net
+        const size_t slab = (size_t)a.Bp * a.Mp;
+        const float* ps = a.st + (size_t)b * a.Mp + q;
+        const float* pt = ps + a.S * slab;
+        float vs[8], vt[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          vs[p] = p < a.S ? ps[p * slab] : 0.f;
+          vt[p] = p < a.S ? pt[p * slab] : 0.f;
+        }
+        s = vs[0];
+        t = vt[0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p)
+          if (p < a.S) {
+            s += vs[p];
+            t += vt[p];
+          }
+        s = tanhf(s + a.bias_s[q]);
+        t += a.bias_t[q];
+      }
       if (a.reverse) v = (v - t) * expf(-s);   // models/flow/blocks.py:316
       else {
         v = v * expf(s) + t;                   // :304
@@ -428,7 +462,7 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   if (!d || !w0 || !x || !y) return VUNET_ERR_ARG;
   if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->M < 16 || d->M % 16) return VUNET_ERR_ARG;
-  if (d->K < 32 || d->K % 32 || d->ldx < d->K || d->ldx % 4) return VUNET_ERR_ARG;
+  if (d->S < 1 || d->S > 8 || d->K < 32 || d->K % (32 * d->S) || d->ldx < d->K || d->ldx % 4) return VUNET_ERR_ARG;
   if (d->act0 < 0 || d->act0 > 2 || d->act1 < 0 || d->act1 > 2) return VUNET_ERR_ARG;
   SeqLinearArgs a;
   a.w[0] = w0;
@@ -444,13 +478,14 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   a.act[0] = d->act0;
   a.act[1] = d->act1;
   a.shared_in = d->shared_in;
+  a.S = d->S;
   a.c_in = nullptr; a.c_out = nullptr; a.xh_next = nullptr; a.h_out = nullptr; a.x_next = nullptr;
   a.seq_stride = 0; a.H = a.hoff = a.n = a.B = 0;
   // (RT = 2, a 32-row tile per workgroup, halves the operand traffic per weight byte but leaves half the CUs without a workgroup
   // at every layer size of the reference configuration: not instantiated)
-  const dim3 grid(d->M / 16, 1, d->nets);
+  const dim3 grid(d->M / 16, d->S, d->nets);
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = d->K >= 16 * 32;   // 16 waves: at least one chunk each
+  const bool wide = d->K / d->S >= 16 * 32;   // 16 waves: at least one chunk each
 #define SEQ_LINEAR_CASE(NB)                                                              \
   case NB:                                                                               \
     if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16>), grid, dim3(1024), 0, st, a);  \
@@ -467,15 +502,20 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const int32_t* map,
-                                  const float* scale, const float* loc, float* out, float* logdet, void* stream) {
+extern "C" int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const float* bias_s,
+                                  const float* bias_t, const int32_t* map, const float* scale, const float* loc, float* out,
+                                  float* logdet, void* stream) {
   if (!d || !in || !out || d->B < 1 || d->C < 1 || d->ld_in < d->C || d->ld_out < d->C) return VUNET_ERR_ARG;
-  if (st && (d->c1 < 0 || d->c1 > d->C || d->Mp < d->C - d->c1)) return VUNET_ERR_ARG;
+  if (st && (d->c1 < 0 || d->c1 > d->C || d->Mp < d->C - d->c1 || d->S < 1 || d->S > 8)) return VUNET_ERR_ARG;
+  if (st && d->S > 1 && (!bias_s || !bias_t)) return VUNET_ERR_ARG;
   if ((scale == nullptr) != (loc == nullptr)) return VUNET_ERR_ARG;
   if (in == out && map) return VUNET_ERR_ARG;   // a gather cannot run in place
   SeqCouplingArgs a;
   a.in = in;
   a.st = st;
+  a.bias_s = bias_s;
+  a.bias_t = bias_t;
+  a.S = st ? d->S : 1;
   a.map = map;
   a.scale = scale;
   a.loc = loc;
@@ -521,6 +561,7 @@ extern "C" int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w
   a.ldx = d->ldx;
   a.act[0] = a.act[1] = 0;
   a.shared_in = 1;
+  a.S = 1;
   a.c_in = c_in;
   a.c_out = c_out;
   a.xh_next = xh_next;

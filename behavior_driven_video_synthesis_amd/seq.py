@@ -26,11 +26,11 @@ MAX_ROWS = 64   # batch rows per launch (four 16-row MFMA tiles); larger batches
 
 
 class SeqLinearDesc(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "ldx", "act0", "act1", "nets", "shared_in")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "ldx", "act0", "act1", "nets", "shared_in", "S")]
 
 
 class SeqCouplingDesc(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "c1", "ld_in", "ld_out", "Mp", "reverse", "affine_on_src")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "c1", "ld_in", "ld_out", "Mp", "reverse", "affine_on_src", "S")]
 
 
 class SeqLstmDesc(ctypes.Structure):
@@ -85,7 +85,8 @@ class MlpGroup:
     ``layers[net]`` = [(weight, bias), ...]; the stacks either share their input (the s and t nets of a coupling) or
     are single."""
 
-    def __init__(self, layers: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], k_in_pad: int, tanh_head: Sequence[bool]):
+    def __init__(self, layers: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], k_in_pad: int, tanh_head: Sequence[bool],
+                 split_head: bool = False):
         self.nets = len(layers)
         n_layers = len(layers[0])
         self.dims = []     # per layer: (m_pad, k_pad)
@@ -101,9 +102,17 @@ class MlpGroup:
             self.dims.append((m_pad, k_pad))
             k_pad = m_pad
         self.out_pad = self.dims[-1][0]
+        # the head layer as raw partial slabs for seq_coupling_kernel to add (``split_head``: the consumer is that kernel): a
+        # 512-row head would otherwise run on 32 workgroups per net; K is split until the launch has 256
+        self.head_split = 1
+        if split_head:
+            m_pad, k_pad = self.dims[-1]
+            while (self.head_split < 8 and (m_pad // 16) * self.nets * self.head_split < 256
+                   and k_pad % (64 * self.head_split) == 0 and k_pad // (2 * self.head_split) >= 512):
+                self.head_split *= 2
 
     def act_floats(self, b_pad: int) -> int:
-        return max(self.nets * b_pad * m for m, _ in self.dims)
+        return max(self.nets * b_pad * m * (self.head_split if li == len(self.dims) - 1 else 1) for li, (m, _) in enumerate(self.dims))
 
     def run(self, rows: int, xin: torch.Tensor, ldx: int, bufs: Sequence[torch.Tensor]) -> torch.Tensor:
         """``xin``: [b_pad, ldx] operand (read from column 0).  Returns the buffer holding the heads' [nets][b_pad][out_pad]."""
@@ -112,7 +121,8 @@ class MlpGroup:
         for li, (m_pad, k_pad) in enumerate(self.dims):
             dst = bufs[li % 2]
             act = self.head_act if li == last else [ACT_LRELU, ACT_LRELU]
-            d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, act[0], act[1], self.nets, shared)
+            d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, act[0], act[1], self.nets, shared,
+                              self.head_split if li == last else 1)
             linear(d, self.w[li], src, self.b[li], dst)
             src, shared = dst, 0
         return src
@@ -176,8 +186,8 @@ def actnorm_apply(mod, x: torch.Tensor, reverse: bool):
     b, c = x2.shape
     out = torch.empty_like(x2)
     logdet = None if reverse else torch.zeros(b, device=x.device)
-    d = SeqCouplingDesc(b, c, c, c, c, c, 1 if reverse else 0, 0)
-    _call("vunet_seq_coupling", ctypes.byref(d), _p(x2), None, None, _p(mod.scale.detach().reshape(-1)),
+    d = SeqCouplingDesc(b, c, c, c, c, c, 1 if reverse else 0, 0, 1)
+    _call("vunet_seq_coupling", ctypes.byref(d), _p(x2), None, None, None, None, _p(mod.scale.detach().reshape(-1)),
           _p(mod.loc.detach().reshape(-1)), _p(out), _p(logdet), _stream())
     return out.reshape(x.shape), logdet
 
@@ -271,7 +281,7 @@ class FlowEngine:
         for blk in blocks:
             cp = blk.coupling
             halves = [MlpGroup([[(l.weight, l.bias) for l in cp.s[i].linears()], [(l.weight, l.bias) for l in cp.t[i].linears()]],
-                               _up(c1, 32), [True, False]) for i in range(2)]
+                               _up(c1, 32), [True, False], split_head=True) for i in range(2)]
             self.blocks.append(dict(
                 halves=halves, scale=blk.norm_layer.scale.detach().reshape(-1), loc=blk.norm_layer.loc.detach().reshape(-1),
                 fwd=blk.shuffle.forward_shuffle_idx.to(torch.int32), bwd=blk.shuffle.backward_shuffle_idx.to(torch.int32)))
@@ -298,8 +308,10 @@ class FlowEngine:
     # ---- launches
     def _step(self, rows, src, ld_in, dst, ld_out, reverse, half=None, map_=None, scale=None, loc=None, on_src=0, st=None,
               logdet=None):
-        d = SeqCouplingDesc(rows, self.C, self.c1, ld_in, ld_out, half.out_pad if half else self.C, reverse, on_src)
-        _call("vunet_seq_coupling", ctypes.byref(d), _p(src), _p(st), _p(map_), _p(scale), _p(loc), _p(dst), _p(logdet), _stream())
+        d = SeqCouplingDesc(rows, self.C, self.c1, ld_in, ld_out, half.out_pad if half else self.C, reverse, on_src,
+                            half.head_split if half else 1)
+        _call("vunet_seq_coupling", ctypes.byref(d), _p(src), _p(st), _p(half.b[-1][0] if half else None),
+              _p(half.b[-1][1] if half else None), _p(map_), _p(scale), _p(loc), _p(dst), _p(logdet), _stream())
 
     def _issue_reverse(self, rows: int, p: dict):
         """shuffle^-1, half 1, swap + half 0, ActNorm^-1 per block, last block first (models/flow/blocks.py:552-557, :310-319)."""
@@ -559,7 +571,7 @@ class BehaviorEngine:
                   _p(p["c"][nxt]), _p(p["xh"][nxt]), _p(p["pre"]) if t == t_in - 1 else None, x_next, _stream())
         if self.heads is not None:
             w, bias = self.heads
-            dl = SeqLinearDesc(rows, self.H, self.H, self.H, ACT_NONE, ACT_NONE, 2, 1)
+            dl = SeqLinearDesc(rows, self.H, self.H, self.H, ACT_NONE, ACT_NONE, 2, 1, 1)
             linear(dl, w, p["pre"], bias, p["heads"])
             _call("vunet_seq_bottleneck", _p(p["heads"]), self.H, _p(eps), _p(mu), _p(logstd), _p(b_out), rows, self.H, _stream())
 

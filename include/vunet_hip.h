@@ -598,11 +598,14 @@ int vunet_p2_pool_bwd(const void* t, const int32_t* tmeta, const void* p, const 
  *   vunet_seq_linear      y[net][b][m] = act_net(sum_k w_net[m][k] * x_net[b][k] + bias_net[m])   (act 0: none, 1: LeakyReLU(0.01),
  *                         2: tanh).  w: [M][K] row-major, M % 16 == 0, K % 32 == 0 (zero-padded images, vunet_seq_pack_rows);
  *                         x: [nets_in][Bp][ldx] with nets_in = 1 (shared_in != 0: both nets read the same operand) or nets;
- *                         y: [nets][Bp][M].  B <= 64.  v_mfma_f32_16x16x4_f32: exact fp32 products and sums; a wave adds its K
+ *                         y: [nets][Bp][M].  S > 1 (the flow's 512-row head layers, which would otherwise run on 32 workgroups per
+ *                         net): K split over S workgroups per row tile, y = [nets][S][Bp][M] RAW partial slabs -- no bias, no
+ *                         activation; vunet_seq_coupling adds them.  K % (32 S) == 0, S <= 8.  B <= 64.  v_mfma_f32_16x16x4_f32: exact fp32 products and sums; a wave adds its K
  *                         chunks in ascending order, the four waves of a workgroup are added in wave order: bit-reproducible.
  *   vunet_seq_coupling    one step between two MLP evaluations of the flow: v = in with the half v[c1..C) replaced by
- *                         (v - t) exp(-s) (reverse) or v exp(s) + t (forward); st: [2][Bp][Mp] = (s, t) from vunet_seq_linear with
- *                         act0 = tanh (NULL: no coupling); out[b][c] = A(v[map[c]]) with A = v / scale - loc (reverse) or
+ *                         (v - t) exp(-s) (reverse) or v exp(s) + t (forward); st: [2][S][Bp][Mp] from vunet_seq_linear (NULL: no
+ *                         coupling): S = 1 finished values (act0 = tanh), S > 1 raw slabs added here in slab order, then + bias_s /
+ *                         bias_t and tanh for s; out[b][c] = A(v[map[c]]) with A = v / scale - loc (reverse) or
  *                         scale (v + loc) (forward), parameters indexed by map[c] (affine_on_src != 0) or by c (scale NULL: none);
  *                         forward adds sum(s) + sum(log|scale|) into logdet[b].  in != out when map != NULL; rows of in / out
  *                         are ld_in / ld_out floats apart.
@@ -633,10 +636,10 @@ int vunet_p2_pool_bwd(const void* t, const int32_t* tmeta, const void* p, const 
  *   vunet_seq_actnorm_init      ActNorm's data-dependent initialisation (lib/modules.py:270-290): loc = -mean, scale = 1 / (std + 1e-6)
  *                         per channel over the B rows of x (unbiased std); B >= 2. */
 typedef struct vunet_seq_linear_desc {
-  int32_t B, M, K, ldx, act0, act1, nets, shared_in;
+  int32_t B, M, K, ldx, act0, act1, nets, shared_in, S;
 } vunet_seq_linear_desc;
 typedef struct vunet_seq_coupling_desc {
-  int32_t B, C, c1, ld_in, ld_out, Mp, reverse, affine_on_src;
+  int32_t B, C, c1, ld_in, ld_out, Mp, reverse, affine_on_src, S;
 } vunet_seq_coupling_desc;
 typedef struct vunet_seq_lstm_desc {
   int32_t B, H, ldx, hoff, n, ldraw;
@@ -644,8 +647,8 @@ typedef struct vunet_seq_lstm_desc {
 } vunet_seq_lstm_desc;
 int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* x, const float* bias0,
                      const float* bias1, float* y, void* stream);
-int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const int32_t* map, const float* scale,
-                       const float* loc, float* out, float* logdet, void* stream);
+int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const float* bias_s, const float* bias_t,
+                       const int32_t* map, const float* scale, const float* loc, float* out, float* logdet, void* stream);
 int vunet_seq_start(const float* x0, int64_t x0_stride, const float* h0, const float* c0, float* xraw, int32_t ldraw, float* xh,
                     int32_t ldx, int32_t hoff, float* c, int32_t B, int32_t n, int32_t H, void* stream);
 int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm, const float* c_in,
