@@ -422,7 +422,7 @@ def render_row(vunet, device, size, frames=50, chunk=50, iters=5):
     fam = ops.profile_stop(detail=True)
     # dominant kernel of the bf16 render: the LDS-tiled convolution on channel-blocked bf16 activations (csrc/conv_blk.hip).
     # Algorithmic bytes per launch: bf16 sources + output (+ residual); the fp32 output layer writes 4 B per value.
-    ms = nbytes = n_l = 0.0
+    ms = nbytes = n_l = flop = 0.0
     for key, v in fam.items():
         if key[0] != "conv_blk_fwd" or key[-1] != "conv_blk_tiled_kernel":
             continue
@@ -432,12 +432,16 @@ def render_row(vunet, device, size, frames=50, chunk=50, iters=5):
         ms += v["ms"]
         nbytes += per * v["n"]
         n_l += v["n"]
+        flop += 2.0 * n * ho * wo * m * (c1 + c2) * k * k * v["n"]
     if ms > 0:
         ach = nbytes / (ms * 1e-3) / 1e9
         row["roofline"] = {"bound": "hbm", "kernel": "conv_blk_tiled_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                            "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nbytes / n_l,
                            "avg_launch_us": 1e3 * ms / n_l,
-                           "share_of_conv_time": ms / sum(v["ms"] for v in fam.values())}
+                           "share_of_conv_time": ms / sum(v["ms"] for v in fam.values()),
+                           # the same launches against the OTHER roof: these layers sit between the two
+                           "mfma_achieved_tflops": flop / (ms * 1e-3) / 1e12,
+                           "mfma_frac_of_bf16_peak": flop / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
         # mean HBM bytes per launch of that kernel over the sequence: rocprofv3 PMC passes of tools/bench_render.py
         # (tools/profile.sh step 4), committed summary
         for rel in PMC_TRAFFIC_RENDER:
