@@ -6,17 +6,19 @@
 // sample pass; the decoder: one [4096, 1075] gate matrix read 50 times).  Each weight is used once per pass, so the bound is
 // the weight stream from HBM, not the matrix cores: the kernels are laid out for that.
 //
-//   * seq_linear_kernel: a workgroup owns a 16-row tile of W (32 where that still fills the chip) over the whole K; a K chunk
-//     of 32 is 128 contiguous bytes per weight row, two 16-byte loads per lane, eight v_mfma_f32_16x16x4_f32 per tile (exact
-//     fp32: the reference computes in fp32) against the batch tile.  The four waves split K by chunks and add through LDS in
-//     wave order; wave 0 adds the bias, applies the activation and stores the layer's output, so the next layer reads a plain
-//     operand.  K is NOT split over workgroups.  Two split forms were built and measured (profiles/r05_seq_time.txt):
-//     (1) partial slabs summed, with bias + LeakyReLU, by the consumer's loads: every 16-row tile of the next layer re-read every
-//     slab of X from L2 -- 100 MB of L1 fills for a 33 MB layer, 17.5 us where the weights stream in 5 (a CU fills its L1 at
-//     <= 70 GB/s from L2; MI355X_MICROARCH.md "Indexed rows"); (2) the last workgroup to arrive at a tile's counter adds the
-//     slabs: behind __threadfence() +10 us per launch (buffer_wbl2 + buffer_inv), behind sc1 stores / loads and an agent
-//     atomic wrong results on partial-line slabs.  Without a split the 2048-row layers still put 256 workgroups on the chip;
-//     the 512-row heads (8 MB) run on 64 CUs and take what the split forms took.  The s and t nets of a coupling (same
+//   * seq_linear_kernel: a workgroup owns a 16-row tile of W over the whole K; a K chunk of 32 is 128 contiguous bytes per weight
+//     row, two 16-byte loads per lane, eight v_mfma_f32_16x16x4_f32 per tile (exact fp32: the reference computes in fp32)
+//     against each 16-row batch tile.  Its 16 waves (4 where K is short) split K by chunks and add through LDS in wave order;
+//     wave w then finishes batch tile w -- bias, activation, store -- so the next layer reads a plain operand.  K is NOT split
+//     over workgroups, with one exception (below).  Two general split forms were built and measured
+//     (profiles/r05_seq_time.txt): (1) partial slabs summed, with bias + LeakyReLU, by the consumer's loads: every 16-row tile of
+//     the next layer re-read every slab of X from L2 -- 100 MB of L1 fills for a 33 MB layer, 17.5 us where the weights stream
+//     in 5 (a CU fills its L1 at <= 70 GB/s from L2; MI355X_MICROARCH.md "Indexed rows"); (2) the last workgroup to arrive at
+//     a tile's counter adds the slabs: behind __threadfence() +10 us per launch (buffer_wbl2 + buffer_inv), behind sc1 stores /
+//     loads and an agent atomic wrong results on partial-line slabs.  Without a split the 2048-row layers still put 256
+//     workgroups on the chip.  The exception: the flow's 512-row head layers, whose one consumer (seq_coupling_kernel) reads
+//     every value exactly once -- there K is split four ways into RAW slabs and that kernel adds them in slab order, with the
+//     bias and the scale net's tanh (64 CUs and 10.7 us -> 256 workgroups and 5.1 us).  The s and t nets of a coupling (same
 //     input, same shapes) and the mu / logstd heads run as one launch (grid z).
 //   * seq_coupling_kernel: everything between two MLP evaluations of the flow -- the affine coupling itself, the half swap,
 //     ``Shuffle`` and ``ActNorm`` -- as "v = couple(in); out[c] = affine(v[map[c]])" with a host-composed index map.
@@ -97,13 +99,16 @@ __device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const f
     }
 }
 
-// grid (M / (16 RT), 1, nets), 64 WAVES threads.  Lane l of a wave: i = l & 15 (weight row / batch row), kq = l >> 4; in a K chunk
-// of 32 it holds k = 8 kq .. 8 kq + 7 of its row -- the same k for the A (weights) and B (batch) operand of MFMA step j = 0..7.
-// D: lane holds batch row n = l & 15 of its tile, output rows 4 (l >> 4) + r of the weight tile.
-// WAVES = 16 where K has >= 16 chunks: a wave's groups are sequential round trips to HBM (four waves with 16 chunks each took
-// 12 us for a layer whose weights stream in 5); with 16 waves the whole tile's weights are requested at once.
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
+// grid (M / 16, S, nets), 64 WAVES threads.  Lane l of a wave: i = l & 15 (weight row / batch row), kq = l >> 4; in a K chunk of 32
+// it holds k = 8 kq .. 8 kq + 7 of its row -- the same k for the A (weights) and B (batch) operand of MFMA step j = 0..7.
+// D: lane holds batch row n = l & 15 of its tile, output rows 4 (l >> 4) + r of the weight tile.
+// RT (16-row weight tiles per wave): only 1 is instantiated -- 32-row tiles halve the operand traffic per weight byte but leave
+// half the CUs without a workgroup at every layer size of the reference configuration.
+// WAVES = 16 where K has >= 16 chunks, else 4.  Four waves with 16 chunks each and sixteen with 4 measured the same on the
+// 2048 x 2048 layers (12 us: the bound is what a CU pulls through its L1, not the number of round trips); sixteen are kept
+// because the batch tiles' epilogues then run on separate waves and the short layers request all their weights at once.
 template <int NB, int RT, int WAVES, bool LSTM = false>
 __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a) {
   __shared__ float4 red[WAVES][RT][NB][64];

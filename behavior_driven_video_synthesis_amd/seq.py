@@ -2,9 +2,10 @@
 
 The reference runs ``flow.reverse`` and ``net.generate_seq`` as ATen chains (experiments/behavior_net.py:1173-1184):
 about 600 small launches for the 15-block flow of config/behavior_net.yaml and 250 for a 50-step roll-out.  Here an MLP
-is one launch per layer (the s and t nets of a coupling in the same launch), everything between two MLP evaluations of
-the flow is one launch, an LSTM step is two, and a whole pass is recorded once per batch size into a hipGraph and
-replayed.  ``FlowEngine`` / ``BehaviorEngine`` hold the packed weights and the per-batch-size buffers of one module;
+is one launch per layer with bias and activation in its epilogue (the s and t nets of a coupling in the same launch),
+everything between two MLP evaluations of the flow is one launch, an LSTM step is one launch (the cell update rides in
+the gate product's epilogue) plus one for the decoder's output layer, and a whole pass is recorded once per batch size
+into a hipGraph and replayed.  ``FlowEngine`` / ``BehaviorEngine`` hold the packed weights and the per-batch-size buffers of one module;
 the ``nn.Module`` mirrors (models/flow, models/pose_behavior_rnn.py) own the parameters and call into them.
 
 There is no CPU path: the engines raise without a device tensor and the HIP library.
