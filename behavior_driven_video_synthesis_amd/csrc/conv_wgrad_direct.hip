@@ -255,6 +255,334 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(const WgradDi
   wgrad_direct_body<S, W4, T>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// ---- stride-2 3x3 on the large maps, BOTH operands staged through LDS (round 5) -------------------------------
+// The direct form above reads x as 64-byte pieces of 64 different cache lines per wave instruction (lane = input channel), once
+// per output-channel tile and per kernel row: 366 MB per launch against 201 MB of algorithmic bytes at the 256^2 level, 58 % of
+// the wave cycles waiting (profiles/r04_pmc_sq.json).  Here a workgroup owns (pixel split, 32-channel tile); a step is 16 output
+// pixels of one output row.  Per step the three input rows it touches are loaded ONCE with coalesced 16-byte loads along the row,
+// the prologue (ELU, dropout) + operand scale + two-term split applied once per element, and written to LDS as COLUMN-PARITY
+// planes: E[c] = x[2c], O[c] = x[2c - 1] (17 entries) -- a tap's eight stride-2 elements are then eight consecutive fp16, one
+// aligned ds_read_b128 (kw = 0: O, kw = 1: E, kw = 2: O shifted by one entry with v_alignbit).  dy likewise.  Waves =
+// (output-channel tile, kernel row); planes are [row][plane][channel][48 B]: 16 lanes x 16 B on 64 distinct banks.
+struct S2Lds {
+  static constexpr int PITCH = 48;                       // bytes per (plane, channel) row: 17 fp16 + padding
+  static constexpr int XPLANE = 32 * PITCH;              // one plane of one input row
+  static constexpr int XBYTES = 3 * 4 * XPLANE;          // rows x (E hi, E lo, O hi, O lo)
+  static constexpr int DYCOT = 2 * 32 * PITCH;           // (hi, lo) x 32 channels of one co tile
+};
+
+// Loads of the ring as inline assembly: the compiler's own wait insertion loses the order of loads across the loop's back edge
+// and waits for (nearly) all of them at the first use -- the ring then hides nothing.  The asm loads are invisible to it; the
+// kernel waits itself, with a count (s2_wait): "all but the N newest".  Every thread issues the same number of loads per step.
+__device__ __forceinline__ wd_f32x4 s2_load4(const float* p) {
+  wd_f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ float s2_load1(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void s2_wait() {
+  static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NWAVE, int NU, int NCOT>
+__global__ __launch_bounds__(64 * NWAVE) void conv_wgrad_s2_kernel(const WgradDirectArgs a_in) {
+  WgradDirectArgs a = a_in;
+  inact_resolve(a.in1);
+  inact_resolve(a.in2);
+  constexpr int NTHR = 64 * NWAVE;
+  constexpr int NX = (3 * 32 * 8 + NTHR - 1) / NTHR;     // float4 loads of x per thread and step
+  constexpr int NDY = (NCOT * 32 * 4 + NTHR - 1) / NTHR; // float4 loads of dy per thread and step
+  extern __shared__ __attribute__((aligned(16))) unsigned char s2_lds[];
+  unsigned char* const xL = s2_lds;
+  unsigned char* const dL = s2_lds + S2Lds::XBYTES;
+  const vunet_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int split = blockIdx.x, ci0 = blockIdx.y * 32;
+  const int H = d.Hs, W = d.Ws, HW = H * W, HoWo = d.Ho * d.Wo;
+  const int ppr = d.Wo >> 4, ppi = d.Ho * ppr;            // pixel pairs (16 output pixels) per row / image
+
+  // ---- operand scales (as the direct kernel)
+  float sx, sdy, descale, descale2;
+  {
+    __shared__ float redm[2 * NWAVE];
+    float mx = 0.f, md = 0.f;
+    for (int i = tid; i < 256; i += NTHR) {   // 1024 partial maxima per tensor
+      const float4 px = h2_amax4(a.amax_x, a.amax_x2, i), pd = reinterpret_cast<const float4*>(a.amax_dy)[i];
+      mx = fmaxf(mx, fmaxf(fmaxf(px.x, px.y), fmaxf(px.z, px.w)));
+      md = fmaxf(md, fmaxf(fmaxf(pd.x, pd.y), fmaxf(pd.z, pd.w)));
+    }
+    mx = wave_max(mx);
+    md = wave_max(md);
+    if (lane == 0) { redm[wave] = mx; redm[NWAVE + wave] = md; }
+    __syncthreads();
+    mx = md = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) { mx = fmaxf(mx, redm[w]); md = fmaxf(md, redm[NWAVE + w]); }
+    if (a.in1.thresh) mx *= a.in1.keep_scale;
+    const int ex = h2_scale_exp(mx), ed = h2_scale_exp(md);
+    sx = h2_pow2(ex);
+    sdy = h2_pow2(ed);
+    h2_pow2_pair(-(ex + ed), descale, descale2);
+  }
+  const bool second = ci0 >= d.C1;                        // (C1 % 32 == 0: a channel tile lies in one source)
+  const float* __restrict__ xs = second ? a.x2 : a.x1;
+  const int Cs = second ? d.C2 : d.C1, cl0 = second ? ci0 - d.C1 : ci0;
+  InAct ia = a.in1;
+  ia.seed = second ? a.in2.seed : a.in1.seed;
+  const int pro_form = in_act_form_of(a.in1);
+
+  const int pairs = d.N * ppi, pps = (pairs + d.nsplit - 1) / d.nsplit;
+  const int pb = split * pps, pe = min(pb + pps, pairs);
+
+  // this wave's units: kernel row krow, co tiles cotb and (NU == 2) cotb + 2
+  const int krow = wave % 3, cotb = wave / 3;
+  f32x16 acc[NU][3];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
+
+  // global loads run D steps ahead of their use.  Measured (tools/time_wgrad_s2.py, bs 16): the four-deep ring wins on the
+  // 128-channel layer (two units per wave: 80 -> 74 us) and loses on the 64-channel one (80 -> 101 us: 40 more registers for
+  // a step that is bound by its conversion work, ~200 vector instructions per thread against 9 MFMAs per wave, not by latency)
+  constexpr int D = NCOT == 4 ? 4 : 1;
+  wd_f32x4 xv[D][NX], dv[D][NDY];
+  float xhalo[D];
+  float dsum[NDY];
+#pragma unroll
+  for (int i = 0; i < NDY; ++i) dsum[i] = 0.f;
+
+  // (image, output row, first output column) of a step: divided out once, then advanced step by step -- the loads run D steps
+  // ahead of the conversion, so there are two cursors
+  struct Cursor { int n, r, cb; };
+  auto cursor_at = [&](int p) {
+    Cursor c;
+    c.n = p / ppi;
+    const int rem = p - c.n * ppi;
+    c.r = rem / ppr;
+    c.cb = (rem - c.r * ppr) << 4;
+    return c;
+  };
+  auto advance = [&](Cursor& c) {
+    c.cb += 16;
+    if (c.cb == d.Wo) {
+      c.cb = 0;
+      if (++c.r == d.Ho) { c.r = 0; ++c.n; }
+    }
+  };
+  Cursor cur_load = cursor_at(pb), cur_conv = cur_load;
+  auto prefetch = [&](int p, auto slot_c) {
+    constexpr int K_ = decltype(slot_c)::value;
+    (void)p;
+    const int n = cur_load.n, r = cur_load.r, cb = cur_load.cb;
+    advance(cur_load);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int u = tid + NTHR * i;                      // (row rr, channel ci, quad q), q fastest
+      const int q = u & 7, ci = (u >> 3) & 31, rr = u >> 8;
+      const int ih = 2 * r - 1 + rr;
+      const bool ok = (unsigned)ih < (unsigned)H;          // (u >= 768: rr = 3 reads row 2 r + 2 <= H - 1 or is clamped; unused)
+      const float* xp = xs + ((size_t)(n * Cs + cl0 + ci) * H + (ok ? ih : 0)) * W + 2 * cb + 4 * q;
+      xv[K_][i] = s2_load4(xp);   // (masked when converted)
+    }
+    {                                                     // the left halo column of (row, channel): threads 0 .. 95
+      const int ci = tid & 31, rr = (tid >> 5) % 3;
+      const int ih = 2 * r - 1 + rr;
+      const bool ok = (unsigned)ih < (unsigned)H && cb > 0;
+      xhalo[K_] = s2_load1(xs + ((size_t)(n * Cs + cl0 + ci) * H + (ok ? ih : 0)) * W + (ok ? 2 * cb - 1 : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int u = tid + NTHR * i;                      // (co tile, channel, quad), quad fastest
+      const int q4 = u & 3, co = (u >> 2) & 31, cot = u >> 7;
+      const bool ok = cot < NCOT;
+      const float* dp = a.dy + ((size_t)(n * d.Cout + (ok ? cot * 32 + co : 0)) * d.Ho + r) * d.Wo + cb + 4 * q4;
+      dv[K_][i] = s2_load4(dp);
+    }
+  };
+  auto convert = [&](int p, auto pro_c, auto slot_c) {
+    constexpr int PRO = decltype(pro_c)::value;
+    constexpr int K_ = decltype(slot_c)::value;
+    (void)p;
+    const int n = cur_conv.n, r = cur_conv.r, cb = cur_conv.cb;
+    advance(cur_conv);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int u = tid + NTHR * i;
+      if (u >= 768) continue;
+      const int q = u & 7, ci = (u >> 3) & 31, rr = u >> 8;
+      const int ih = 2 * r - 1 + rr;
+      const bool ok = (unsigned)ih < (unsigned)H;
+      const uint32_t idx = (uint32_t)(n * Cs + cl0 + ci) * (uint32_t)HW + (uint32_t)((ok ? ih : 0) * W + 2 * cb + 4 * q);
+      float f[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[e] = ok ? in_act_form<PRO>(ia, xv[K_][i][e], idx + e) * sx : 0.f;
+      uint32_t eh, el, oh, ol;
+      wd_split2(f[0], f[2], eh, el);                      // even input columns -> E[2q], E[2q + 1]
+      wd_split2(f[1], f[3], oh, ol);                      // odd input columns  -> O[2q + 1], O[2q + 2]
+      unsigned char* base = xL + (size_t)rr * 4 * S2Lds::XPLANE + ci * S2Lds::PITCH;
+      *reinterpret_cast<uint32_t*>(base + 0 * S2Lds::XPLANE + 4 * q) = eh;
+      *reinterpret_cast<uint32_t*>(base + 1 * S2Lds::XPLANE + 4 * q) = el;
+      uint16_t* po_h = reinterpret_cast<uint16_t*>(base + 2 * S2Lds::XPLANE) + 2 * q + 1;
+      uint16_t* po_l = reinterpret_cast<uint16_t*>(base + 3 * S2Lds::XPLANE) + 2 * q + 1;
+      po_h[0] = (uint16_t)(oh & 0xffffu);
+      po_h[1] = (uint16_t)(oh >> 16);
+      po_l[0] = (uint16_t)(ol & 0xffffu);
+      po_l[1] = (uint16_t)(ol >> 16);
+    }
+    if (tid < 96) {
+      const int ci = tid & 31, rr = tid >> 5;
+      const int ih = 2 * r - 1 + rr;
+      const bool ok = (unsigned)ih < (unsigned)H && cb > 0;
+      const uint32_t idx = (uint32_t)(n * Cs + cl0 + ci) * (uint32_t)HW + (uint32_t)((ok ? ih : 0) * W + (ok ? 2 * cb - 1 : 0));
+      const float f0 = ok ? in_act_form<PRO>(ia, xhalo[K_], idx) * sx : 0.f;
+      uint32_t hh, hl;
+      wd_split2(f0, 0.f, hh, hl);
+      unsigned char* base = xL + (size_t)rr * 4 * S2Lds::XPLANE + ci * S2Lds::PITCH;
+      *reinterpret_cast<uint16_t*>(base + 2 * S2Lds::XPLANE) = (uint16_t)(hh & 0xffffu);
+      *reinterpret_cast<uint16_t*>(base + 3 * S2Lds::XPLANE) = (uint16_t)(hl & 0xffffu);
+    }
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int u = tid + NTHR * i;
+      const int q4 = u & 3, co = (u >> 2) & 31, cot = u >> 7;
+      if (cot >= NCOT) continue;
+      dsum[i] += (dv[K_][i][0] + dv[K_][i][1]) + (dv[K_][i][2] + dv[K_][i][3]);
+      uint32_t h0, l0, h1, l1;
+      wd_split2(dv[K_][i][0] * sdy, dv[K_][i][1] * sdy, h0, l0);
+      wd_split2(dv[K_][i][2] * sdy, dv[K_][i][3] * sdy, h1, l1);
+      unsigned char* base = dL + (size_t)cot * S2Lds::DYCOT + co * S2Lds::PITCH + 8 * q4;
+      *reinterpret_cast<uint2*>(base) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(base + 32 * S2Lds::PITCH) = make_uint2(l0, l1);
+    }
+  };
+  auto multiply = [&]() {
+    const unsigned char* xb = xL + (size_t)krow * 4 * S2Lds::XPLANE + j * S2Lds::PITCH + 16 * h;
+    const wd_u32x4 eh = *reinterpret_cast<const wd_u32x4*>(xb), el = *reinterpret_cast<const wd_u32x4*>(xb + S2Lds::XPLANE);
+    const wd_u32x4 oh = *reinterpret_cast<const wd_u32x4*>(xb + 2 * S2Lds::XPLANE), ol = *reinterpret_cast<const wd_u32x4*>(xb + 3 * S2Lds::XPLANE);
+    const uint32_t nh = *reinterpret_cast<const uint16_t*>(xb + 2 * S2Lds::XPLANE + 16), nl = *reinterpret_cast<const uint16_t*>(xb + 3 * S2Lds::XPLANE + 16);
+    // kw = 2: the odd-column plane one entry further
+    const wd_u32x4 sh = {__builtin_amdgcn_alignbit(oh[1], oh[0], 16), __builtin_amdgcn_alignbit(oh[2], oh[1], 16),
+                         __builtin_amdgcn_alignbit(oh[3], oh[2], 16), __builtin_amdgcn_alignbit(nh, oh[3], 16)};
+    const wd_u32x4 sl = {__builtin_amdgcn_alignbit(ol[1], ol[0], 16), __builtin_amdgcn_alignbit(ol[2], ol[1], 16),
+                         __builtin_amdgcn_alignbit(ol[3], ol[2], 16), __builtin_amdgcn_alignbit(nl, ol[3], 16)};
+    const h2_f16x8 Bh[3] = {__builtin_bit_cast(h2_f16x8, oh), __builtin_bit_cast(h2_f16x8, eh), __builtin_bit_cast(h2_f16x8, sh)};
+    const h2_f16x8 Bl[3] = {__builtin_bit_cast(h2_f16x8, ol), __builtin_bit_cast(h2_f16x8, el), __builtin_bit_cast(h2_f16x8, sl)};
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int cot = cotb + 2 * u;
+      if (cot >= NCOT) continue;
+      const unsigned char* db = dL + (size_t)cot * S2Lds::DYCOT + j * S2Lds::PITCH + 16 * h;
+      const h2_f16x8 Ah = *reinterpret_cast<const h2_f16x8*>(db), Al = *reinterpret_cast<const h2_f16x8*>(db + 32 * S2Lds::PITCH);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        f32x16 cc = acc[u][t];
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[t], cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[t], cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[t], cc, 0, 0, 0);
+        acc[u][t] = cc;
+      }
+    }
+  };
+
+  // (not __syncthreads(): its fence waits for vmcnt(0), i.e. for the loads issued D steps ahead -- the whole point of the ring;
+  // LDS traffic is what the two barriers of a step order, so lgkmcnt(0) + s_barrier)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  constexpr int LPS = NX + 1 + NDY;                       // loads per thread and step
+  static_assert((D - 1) * LPS < 64, "ring deeper than vmcnt counts");
+  auto step = [&](int p, auto slot_c) {
+    // this slot's loads have landed when at most the newer slots' are outstanding: D - 1 of them in the steady state, fewer
+    // at the end of the range
+    const int newer = min(D - 1, pe - 1 - p);
+    if (D > 3 && newer == 3) s2_wait<(D > 3 ? 3 : 0) * LPS>();
+    else if (D > 2 && newer == 2) s2_wait<(D > 2 ? 2 : 0) * LPS>();
+    else if (D > 1 && newer == 1) s2_wait<(D > 1 ? 1 : 0) * LPS>();
+    else s2_wait<0>();
+    lds_barrier();                                        // the previous step's fragment reads are done
+    if (pro_form == 2) convert(p, std::integral_constant<int, 2>{}, slot_c);
+    else if (pro_form == 1) convert(p, std::integral_constant<int, 1>{}, slot_c);
+    else if (pro_form == 0) convert(p, std::integral_constant<int, 0>{}, slot_c);
+    else convert(p, std::integral_constant<int, 3>{}, slot_c);
+    lds_barrier();
+    if (p + D < pe) prefetch(p + D, slot_c);              // into the slot just consumed: lands D - 1 steps from now
+    if (cotb < NCOT) multiply();
+  };
+  if (pb + 0 < pe) prefetch(pb + 0, std::integral_constant<int, 0>{});
+  if constexpr (D == 4) {
+    if (pb + 1 < pe) prefetch(pb + 1, std::integral_constant<int, 1>{});
+    if (pb + 2 < pe) prefetch(pb + 2, std::integral_constant<int, 2>{});
+    if (pb + 3 < pe) prefetch(pb + 3, std::integral_constant<int, 3>{});
+  }
+  for (int p0 = pb; p0 < pe; p0 += D) {
+    step(p0, std::integral_constant<int, 0>{});
+    if constexpr (D == 4) {
+      if (p0 + 1 < pe) step(p0 + 1, std::integral_constant<int, 1>{});
+      if (p0 + 2 < pe) step(p0 + 2, std::integral_constant<int, 2>{});
+      if (p0 + 3 < pe) step(p0 + 3, std::integral_constant<int, 3>{});
+    }
+  }
+
+  // ---- partial slab of this split: [split][Coutp][9 * Ctot], k order (tap, ci) -- the direct kernel's layout
+  const size_t KT = (size_t)9 * a.Ctot;
+  float* slab = a.slabs + (size_t)split * a.Coutp * KT;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int cot = cotb + 2 * u;
+    if (cot >= NCOT) continue;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cr = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        slab[(size_t)cr * KT + (size_t)(krow * 3 + t) * a.Ctot + ci0 + j] = acc[u][t][r] * descale * descale2;
+      }
+  }
+  if (blockIdx.y == 0) {
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int u = tid + NTHR * i;
+      const int q4 = u & 3, co = (u >> 2) & 31, cot = u >> 7;
+      float t = dsum[i];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      if (q4 == 0 && cot < NCOT) a.dshift[(size_t)split * a.Coutp + cot * 32 + co] = t;
+    }
+  }
+}
+
+// the LDS-staged form takes the stride-2 layers that are launched on their own (above the batching bound), with whole channel
+// tiles; VUNET_TUNE_WGRAD_ROWSPLIT = 3 keeps them on the direct kernel (A/B, tests)
+static bool s2_staged_ok(const vunet_wgrad_desc* d) {
+  if (g_vunet_tune[VUNET_TUNE_WGRAD_ROWSPLIT] == 3) return false;
+  if (!(d->flags & 2) || (d->flags & 1)) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1) return false;
+  if (d->Ws != 2 * d->Wo || d->Hs != 2 * d->Ho || d->Wo % 16) return false;
+  if (d->C1 % 32 || d->C2 % 32 || d->Cout % 32) return false;
+  const int ncot = d->Cout / 32;
+  if (ncot != 1 && ncot != 2 && ncot != 4) return false;
+  return (int64_t)d->N * d->Ho * d->Wo > 16384;
+}
+
+static int s2_staged_nslabs(const vunet_wgrad_desc* d) {
+  const int ncit = (d->C1 + d->C2) / 32, pairs = d->N * d->Ho * (d->Wo / 16);
+  int S = 512 / ncit;
+  if (S > pairs / 4) S = pairs / 4;
+  return S < 1 ? 1 : S;
+}
+
 // Several layers of one form in ONE launch (vunet_conv2d_wgrad_multi): the small-map layers' weight gradients are 20 - 30 us
 // launches of ~2000 short waves each -- latency, not work -- and 60 of them per step interleaved with the data-gradient chain
 // cost more than they overlap.  The layers' argument blocks travel by value (kernel arguments: the pointers change from step to
@@ -318,6 +646,7 @@ static bool direct_rowsplit(int cls) {
 }
 
 int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d) {
+  if (s2_staged_ok(d)) return s2_staged_nslabs(d);
   WgradDirectArgs a;
   direct_geometry(d, a);
   const int ncit = (a.Ctot + 31) / 32;
@@ -331,6 +660,7 @@ int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d) {
 }
 
 int vunet_wgrad_direct_name(const vunet_wgrad_desc* d, char* name, int len) {
+  if (s2_staged_ok(d)) return snprintf(name, len, "conv_wgrad_s2_kernel");
   const int cls = direct_class(d);
   const int S = (cls == 3 || cls == 5) ? 2 : 1, W4 = (cls == 2 || cls == 3), T = cls == 1 ? 1 : (direct_rowsplit(cls) ? 3 : 9);
   return snprintf(name, len, "conv_wgrad_direct_kernel<%d, %s, %d>", S, W4 ? "true" : "false", T);
@@ -406,6 +736,15 @@ int vunet_wgrad_direct_launch(const vunet_wgrad_desc* d, const float* x1, const 
   WgradDirectArgs a;
   int gx, gy;
   direct_fill(d, x1, x2, dy, slabs, dshift, amax_x, amax_x2, amax_dy, a, gx, gy);
+  if (s2_staged_ok(d)) {
+    const int ncot = d->Cout / 32;
+    dim3 grid((unsigned)d->nsplit, (unsigned)((d->C1 + d->C2) / 32));
+    const size_t lds = (size_t)S2Lds::XBYTES + (size_t)ncot * S2Lds::DYCOT;
+    if (ncot == 1) VUNET_LAUNCH((conv_wgrad_s2_kernel<3, 1, 1>), grid, dim3(192), lds, st, a);
+    else if (ncot == 2) VUNET_LAUNCH((conv_wgrad_s2_kernel<6, 1, 2>), grid, dim3(384), lds, st, a);
+    else VUNET_LAUNCH((conv_wgrad_s2_kernel<6, 2, 4>), grid, dim3(384), lds, st, a);
+    return vunet_check_launch();
+  }
   const bool rs = direct_rowsplit(cls);
   dim3 grid((unsigned)gx, (unsigned)gy), block(256);
   if (rs) {

@@ -272,6 +272,76 @@ def test_direct_weight_gradient_vs_fp64(case, rowsplit):
     assert float((dbh.double().cpu() - refb).abs().max()) <= 1e-5 * max(float(refb.abs().max()), 1.0)
 
 
+# (n, c1, c2, cout, hs, ws, in_act, drop): stride-2 layers above the batching bound (N Ho Wo > 16384) -- conv_wgrad_s2_kernel
+WGRAD_S2 = [
+    (2, 32, 0, 64, 256, 256, 0, 0.0),      # the 256 -> 128 Downsample (two co tiles, six waves)
+    (4, 64, 0, 128, 128, 160, 1, 0.05),    # 128-channel output (four co tiles, two units per wave), ELU + dropout, non-square
+    (2, 32, 32, 32, 192, 256, 1, 0.05),    # two sources (two channel tiles), one co tile (three waves)
+    (9, 32, 0, 64, 96, 96, 0, 0.0),        # splits that end inside a row / an image
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_S2)
+def test_staged_stride2_weight_gradient_vs_fp64_and_the_direct_kernel(case):
+    """csrc/conv_wgrad_direct.hip, conv_wgrad_s2_kernel: x and dy staged once per step through LDS (column-parity planes) instead
+    of read as 64-byte pieces per lane.  Against the float64 reference and against the direct kernel on the same inputs
+    (tuning knob wgrad_rowsplit = 3 keeps these layers there)."""
+    ops = _ops()
+    n, c1, c2, cout, hs, ws, in_act, drop = case
+    k, stride, pad = 3, 2, 1
+    ho, wo = (hs + 2 - 3) // 2 + 1, (ws + 2 - 3) // 2 + 1
+    g_ = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x1 = torch.randn(n, c1, hs, ws, generator=g_).cuda()
+    x2 = torch.randn(n, c2, hs, ws, generator=g_).cuda() if c2 else None
+    dy = torch.randn(n, cout, ho, wo, generator=g_).cuda()
+    seed = 0xFACE
+    ctot, ktot = c1 + c2, 9 * (c1 + c2)
+
+    def run(knob):
+        ops.set_tuning("wgrad_rowsplit", knob)
+        wd = ops.WgradDesc(N=n, C1=c1, C2=c2, Hs=hs, Ws=ws, Cout=cout, Ho=ho, Wo=wo, KH=k, KW=k, stride=stride, pad=pad,
+                           in_act=in_act, in_slope=0.0, drop_p=drop, drop_seed=seed, nsplit=1, flags=2)
+        buf = ctypes.create_string_buffer(96)
+        ops._call("vunet_conv2d_wgrad_variant", ctypes.byref(wd), buf, 96)
+        ns = ops._lib.lib().vunet_conv2d_wgrad_nsplit(ctypes.byref(wd))
+        wd.nsplit = ns
+        cp = ops._r32(cout)
+        slabs = torch.full((ns * cp * ktot + ns * cp,), float("nan"), device="cuda")
+        dshift = slabs[ns * cp * ktot:]
+        ops._call("vunet_conv2d_wgrad", ctypes.byref(wd), ops._p(x1), ops._p(x2), ops._p(dy), ops._p(slabs), ops._p(dshift),
+                  ops._p(ops.absmax_partials(x1, x2)), ops._p(ops.absmax_partials(dy)), ops._stream())
+        dw, db = torch.empty(cout, ctot, k, k, device="cuda"), torch.empty(cout, device="cuda")
+        v, work = torch.zeros(cout, ctot, k, k, device="cuda"), torch.empty(cout * (ktot + 1), device="cuda")
+        wn = ops.WnDesc(cout, c1, c2, k, k, 1, 0)
+        ops._call("vunet_weightnorm_bwd", ctypes.byref(wn), ops._p(slabs), ops._p(dshift), ns, ops._p(v), None, None, None, None,
+                  ops._p(dw), None, ops._p(db), None, None, ops._p(work), 0, ops._stream())
+        torch.cuda.synchronize()
+        return dw, db, buf.value.decode()
+    dws, dbs, name_s = run(0)
+    dwd, dbd, name_d = run(3)
+    assert name_s == "conv_wgrad_s2_kernel" and name_d.startswith("conv_wgrad_direct_kernel<2"), (name_s, name_d)
+    xs = []
+    for i, x in enumerate((x1, x2)):
+        if x is None:
+            continue
+        t = x.double().cpu()
+        if in_act == ops.ACT_ELU:
+            t = F.elu(t)
+        if drop > 0:
+            sd = seed if i == 0 else (seed + ops.SEED2_OFFSET) & 0xFFFFFFFF
+            t = t * dropout_keep_mask(tuple(x.shape), drop, sd).double() * float(torch.tensor(1.0 / (1.0 - drop), dtype=torch.float32))
+        xs.append(t)
+    wz = torch.zeros(cout, ctot, k, k, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(torch.cat(xs, dim=1), wz, stride=2, padding=1) * dy.double().cpu()).sum().backward()
+    ref = wz.grad
+    sc = float(ref.abs().max())
+    es, ed = float((dws.double().cpu() - ref).abs().max()), float((dwd.double().cpu() - ref).abs().max())
+    assert es <= 3e-6 * sc, (es, sc)
+    assert es <= 3.0 * ed + 4e-7 * sc, (es, ed, sc)
+    refb = dy.double().cpu().sum(dim=(0, 2, 3))
+    assert float((dbs.double().cpu() - refb).abs().max()) <= 1e-5 * max(float(refb.abs().max()), 1.0)
+
+
 def test_batched_weight_gradient_launch_equals_one_launch_per_layer():
     """vunet_conv2d_wgrad_multi: the layers of WGRAD the library calls batchable, all in one call (several kernel forms, more
     items of one form than a launch holds), write the same slabs bit for bit as vunet_conv2d_wgrad_a2 per layer; layers the
