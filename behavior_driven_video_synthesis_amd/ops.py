@@ -214,6 +214,15 @@ def set_tuning(key: str, value: int):
     _wants_split_cache.clear()
 
 
+def apply_env_tuning():
+    """``VUNET_TUNING="key=value,key=value"`` (keys of ``_TUNING_KEYS``): dispatcher overrides for A/B runs of whole programs
+    (bench.py calls this once; tests use ``set_tuning``)."""
+    spec = os.environ.get("VUNET_TUNING", "")
+    for kv in filter(None, (t.strip() for t in spec.split(","))):
+        k, _, v = kv.partition("=")
+        set_tuning(k.strip(), int(v))
+
+
 def absmax_partials(x1, x2=None):
     """vunet_absmax_partials: the 1024 partial |x| maxima (512 per source) the split-fp16 kernels scale their input by."""
     out = torch.empty(1024, device=x1.device, dtype=torch.float32)

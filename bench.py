@@ -584,6 +584,7 @@ def main():
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
     ops.set_conv_precision(args.precision)
+    ops.apply_env_tuning()   # VUNET_TUNING=key=value,...: A/B runs of dispatcher choices (none set: the library's own)
 
     cfg = make_config(args)
     import contextlib
