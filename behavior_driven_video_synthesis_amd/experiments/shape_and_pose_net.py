@@ -217,6 +217,12 @@ class ShapePoseNet:
         caller.wait_stream(gs)
         return out
 
+    def _packed_models(self):
+        """The models whose weight-norm folds are done once per step (ops.prepacked): the generator and, with the adversarial
+        term, the discriminator -- it runs three times per step (for the generator's loss, on the real and on the fake patch)
+        and re-folded its 8 layers each time (29 x 4 small launches, ~0.7 ms of the step's kernel time)."""
+        return (self.vunet, self.gan.disc) if self.gan is not None else (self.vunet,)
+
     def _capture_agreed(self, ok_here: bool) -> bool:
         """True iff EVERY rank recorded the step (single process: this one did)."""
         if not (self.averager.active and dist.is_initialized() and self.world > 1):
@@ -238,7 +244,7 @@ class ShapePoseNet:
             if it > self.config["training"]["n_init_batches"]:
                 self._eager_dev_steps += 1
             self.optimizer.zero_grad()
-            with ops.prepacked(self.vunet):
+            with ops.prepacked(*self._packed_models()):
                 return self._step(batch, it, eps, reg_eps)
         rec = self._graphs.get(key)
         fresh = rec is None
@@ -254,7 +260,7 @@ class ShapePoseNet:
             try:
                 with torch.cuda.graph(graph, stream=self._graph_stream):
                     self.optimizer.zero_grad()
-                    with ops.prepacked(self.vunet):
+                    with ops.prepacked(*self._packed_models()):
                         out = self._step(static, it, None, None)
             except Exception as e:   # noqa: BLE001 -- a runtime that cannot record this step: say so and issue eagerly from here on
                 err = e
@@ -279,7 +285,7 @@ class ShapePoseNet:
                 self.averager.start_step()
                 ops.reset_dropout_counter()   # the recording pass drew this step's seeds: the eager pass draws the same ones
                 self.optimizer.zero_grad()
-                with ops.prepacked(self.vunet):
+                with ops.prepacked(*self._packed_models()):
                     return self._step(batch, it, eps, reg_eps)
             rec = self._graphs[key] = {"graph": graph, "static": static, "out": out}
         else:
@@ -333,7 +339,7 @@ class ShapePoseNet:
                 main = torch.cuda.current_stream()
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    packed = ops.prepacked(self.vunet)
+                    packed = ops.prepacked(*self._packed_models())
                     packed.__enter__()
                 try:
                     with torch.no_grad():
@@ -343,7 +349,7 @@ class ShapePoseNet:
                 finally:
                     packed.__exit__(None, None, None)
             else:
-                with ops.prepacked(self.vunet):  # all weight-norm folds of the step in two launches
+                with ops.prepacked(*self._packed_models()):  # all weight-norm folds of the step in two launches
                     out = self._step(batch, it, eps, reg_eps)
         self.adjust_params(it)
         out.update({"learning_rate": self.lr, "gamma": self.gamma, "imax": self.imax})

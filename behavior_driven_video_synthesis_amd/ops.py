@@ -832,19 +832,22 @@ def invalidate_active_prepack(module):
 
 
 class prepacked:
-    """``with ops.prepacked(model):`` -- pack the weights of every already-seen conv layer of ``model`` in two
-    launches and let the fused convs inside the block use them.  The caller guarantees that parameters do not
-    change inside the block (the training step wraps forward + backward, the optimiser steps after it)."""
+    """``with ops.prepacked(model[, model2 ...]):`` -- pack the weights of every already-seen conv layer of the models in two
+    launches per model and let the fused convs inside the block use them.  The caller guarantees that a model's parameters
+    do not change between the block's start and the last use of that model inside it (the training step wraps forward +
+    backward, the optimisers step after the last use: the generator's before the discriminator's own passes, which do not
+    touch the generator; the discriminator's at the very end)."""
 
-    def __init__(self, model):
-        self.model = model
+    def __init__(self, *models):
+        self.models = [m for m in models if m is not None]
 
     def __enter__(self):
         _reset_amax_arena()
-        cur = _build_prepack_set(self.model)
-        if cur is not None:
-            _call("vunet_weightnorm_fwd_multi", _p(cur["table"]), cur["n"], cur["max_cout"], _stream())
-            _active_prepack.update(cur["entries"])
+        for model in self.models:
+            cur = _build_prepack_set(model)
+            if cur is not None:
+                _call("vunet_weightnorm_fwd_multi", _p(cur["table"]), cur["n"], cur["max_cout"], _stream())
+                _active_prepack.update(cur["entries"])
         return self
 
     def __exit__(self, *a):
