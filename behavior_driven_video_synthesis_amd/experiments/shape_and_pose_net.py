@@ -442,6 +442,9 @@ class ShapePoseNet:
         loss_regressor = None
         for i in range(steps):
             means = [m[i * b:(i + 1) * b] for m in means_all]
+            # (the regressor's four plain layers -- two full-window embedders run as 1x1 products of the flattened latent, two
+            # linears -- pack their weights per call: ~0.5 ms of small launches per step that ops.prepacked does not cover, the
+            # embedders' weight view has no owner module whose layout the batched pack knows)
             preds = self.regressor(means)
             tgts = reg_targets[:, i].reshape(reg_targets.shape[0], -1)
             loss_regressor = torch.norm(preds - tgts, dim=1).mean()

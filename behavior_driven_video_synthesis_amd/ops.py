@@ -838,20 +838,34 @@ class prepacked:
     backward, the optimisers step after the last use: the generator's before the discriminator's own passes, which do not
     touch the generator; the discriminator's at the very end)."""
 
+    _depth = 0
+
     def __init__(self, *models):
         self.models = [m for m in models if m is not None]
+        self._keys = []
 
     def __enter__(self):
-        _reset_amax_arena()
+        # (nested blocks -- the regressor's five Adam steps inside the training step each re-fold the regressor -- add their
+        # entries and take only those away again; the per-step arena of |y| maxima is the outermost block's)
+        if prepacked._depth == 0:
+            _reset_amax_arena()
+        prepacked._depth += 1
         for model in self.models:
             cur = _build_prepack_set(model)
             if cur is not None:
                 _call("vunet_weightnorm_fwd_multi", _p(cur["table"]), cur["n"], cur["max_cout"], _stream())
                 _active_prepack.update(cur["entries"])
+                self._keys.extend(cur["entries"].keys())
         return self
 
     def __exit__(self, *a):
-        _active_prepack.clear()
+        prepacked._depth -= 1
+        if prepacked._depth == 0:
+            _active_prepack.clear()
+        else:
+            for k in self._keys:
+                _active_prepack.pop(k, None)
+        self._keys = []
 
 
 # ------------------------------------------------------------------------------------------------
