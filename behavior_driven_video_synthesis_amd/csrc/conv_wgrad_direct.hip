@@ -637,12 +637,15 @@ static void direct_geometry(const vunet_wgrad_desc* d, WgradDirectArgs& a) {
 
 // Pixel splits: about 2048 waves in all (eight per CU), every wave at least four K steps (eight octets) where the
 // problem has them; few splits for the tiny maps (a slab is written per split).
-// kernel-row split (three waves per (split, co tile), one kernel row each): the stride-2 layers on maps >= 8 wide by
-// default; VUNET_TUNE_WGRAD_ROWSPLIT 1 = never, 2 = the stride-1 direct layers as well (A/B, tests)
+// kernel-row split (three waves per (split, co tile), one kernel row each): every 3x3 layer on maps >= 8 wide.  Round 4 split
+// the stride-2 layers only; same-box A/B runs of the whole step at the end of round 5 (profiles/r05_rowsplit_ab.txt: five
+// alternating pairs on two boxes) put the stride-1 direct layers on it too: + 0.4 - 0.7 %.
+// VUNET_TUNE_WGRAD_ROWSPLIT: 1 = never, 2 = (the default, kept as a value for tests), 3 = the large stride-2 layers on the direct
+// kernel instead of the LDS-staged one, 4 = the stride-2 layers only (round 4's choice)
 static bool direct_rowsplit(int cls) {
   const int knob = g_vunet_tune[VUNET_TUNE_WGRAD_ROWSPLIT];
   if (knob == 1) return false;
-  return cls == 5 || (knob == 2 && cls == 4);
+  return cls == 5 || (knob != 4 && cls == 4);
 }
 
 int vunet_wgrad_direct_nslabs(const vunet_wgrad_desc* d) {

@@ -411,8 +411,9 @@ int vunet_set_dropout_step(const uint32_t* step_dev);
  *                              3 = the direct kernel with its weights from global memory instead of through LDS
  *   VUNET_TUNE_S2_FWD_F32      1: the stride-2 forward layers on the fp32-input MFMA kernel instead of the fp16 scheme's
  *                              parity-plane kernel (A/B timing, tests)
- *   VUNET_TUNE_WGRAD_ROWSPLIT  the direct weight-gradient kernel's kernel-row split (one kernel row per wave): 1 = never, 2 = also
- *                              for the stride-1 direct layers; 0 = the stride-2 layers on maps >= 8 wide
+ *   VUNET_TUNE_WGRAD_ROWSPLIT  the direct weight-gradient kernel's kernel-row split (one kernel row per wave): 0 / 2 = every 3x3 layer
+ *                              on maps >= 8 wide, 1 = never, 4 = the stride-2 layers only; 3 = the large stride-2 layers on the
+ *                              direct kernel instead of the LDS-staged conv_wgrad_s2_kernel
  *   VUNET_TUNE_PARITY_LAUNCHES 1: the stride-2 data gradient of the fp16 scheme as four launches, one per output parity,
  *                              instead of the fused kernel (A/B timing, tests)
  *   VUNET_TUNE_P2_FORM         vunet_p2_conv: 1 = always the four-wave / 64-channel workgroup, 2 = the eight-wave / 128-channel

@@ -1,0 +1,8 @@
+#!/bin/bash
+for i in 1 2 3; do
+for t in "" "wgrad_rowsplit=2"; do
+VUNET_TUNING="$t" timeout 600 python bench.py --no-variants --no-config1 --no-render --no-cpu-baseline --no-roofline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('AB', '$t' or 'default', round(d['value'],1), round(d['ms_per_step'],3))"
+done
+done
