@@ -16,8 +16,26 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvunet_hip.so")
-HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "vunet_hip.h")
+INCLUDE_DIR = os.path.join(os.path.dirname(PKG_DIR), "include")
+HEADER = os.path.join(INCLUDE_DIR, "vunet_hip.h")
 ARCH = "gfx950"
+
+
+def headers() -> list:
+    """Every public header of the C ABI (include/*.h): vunet_hip.h and the per-family headers beside it."""
+    return sorted(os.path.join(INCLUDE_DIR, f) for f in os.listdir(INCLUDE_DIR) if f.endswith(".h"))
+
+
+def _deps_of(src: str, seen=None) -> list:
+    """``src`` and the project headers it includes (transitively; ``#include "..."`` resolved beside the includer)."""
+    seen = set() if seen is None else seen
+    if src in seen or not os.path.isfile(src):
+        return []
+    seen.add(src)
+    out = [src]
+    for inc in re.findall(r'^\s*#\s*include\s*"([^"]+)"', open(src).read(), flags=re.M):
+        out += _deps_of(os.path.normpath(os.path.join(os.path.dirname(src), inc)), seen)
+    return out
 
 
 def _sources():
@@ -28,7 +46,7 @@ def _needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = _sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    deps = _sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -43,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        deps = [src, HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        deps = _deps_of(src)   # the source and the headers it actually includes: a new entry point rebuilds its own file only
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
             return obj
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
@@ -63,10 +81,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def _header_text() -> str:
+    txt = "\n".join(open(h).read() for h in headers())
+    return re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+
+
 def declared_symbols() -> list:
-    """Function names declared in include/vunet_hip.h."""
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    """Function names declared in include/*.h."""
+    txt = _header_text()
     return sorted(set(re.findall(r"\bint\s+(vunet_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -75,9 +97,8 @@ _CTYPE = {"int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "int64_t": cty
 
 
 def declared_prototypes() -> dict:
-    """name -> list of ctypes argument types, parsed from include/vunet_hip.h (single source of truth)."""
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    """name -> list of ctypes argument types, parsed from include/*.h (single source of truth)."""
+    txt = _header_text()
     protos = {}
     for m in re.finditer(r"\bint\s+(vunet_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt, flags=re.S):
         name, args = m.group(1), m.group(2).strip()

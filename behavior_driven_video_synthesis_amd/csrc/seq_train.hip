@@ -1,0 +1,519 @@
+// Training of the behaviour path (BASELINE config 4): the flow's maximum-likelihood step, experiments/behavior_net.py:703-714 with
+// the optimiser of :384-395 and the loss of lib/losses.py:294-331.  Interface and data flow: include/vunet_seq_train.h.
+//
+// The flow of config/behavior_net.yaml is 60 MLPs of 512-2048-2048-2048-512: 629 M parameters, 2.5 GB of fp32 weights, trained at 64
+// rows per step.  Per step and parameter the products are 3 x 64 multiply-adds (forward, input gradient, weight gradient) against
+// 28 bytes of unavoidable traffic (W read by the forward pass; W, exp_avg, exp_avg_sq read and written by the update): the step is
+// bound by HBM, 17.6 GB per step, and the matrix work (240 GFLOP of exact fp32, v_mfma_f32_16x16x4_f32) has to hide under it.
+//
+//   * seq_dx_kernel: dX = dZ . W.  The reduction runs over W's ROWS, so a workgroup owns a 64-column stripe of W (256 contiguous
+//     bytes per row; a lane loads 16 of them and feeds one component to each of four matrix instructions whose accumulators hold
+//     the columns 4 i + e) over M / S rows, its waves take 16-row groups round robin and add through LDS in wave order.  S is
+//     chosen so that the launch has >= 256 workgroups; the S partial slabs are raw, and what reads them adds them in slab order:
+//     seq_dz_finish_kernel for a hidden layer (with the LeakyReLU derivative), seq_coupling_bwd_kernel for an MLP's first layer.
+//   * seq_dw_kernel: the weight gradient is never written.  A workgroup forms one 64 x 64 tile of dW = dZ^T . X from LDS-staged
+//     row tiles of dZ and X, turns the accumulator layout into rows through LDS and applies torch.optim.Adam's update to the tile
+//     of W / exp_avg / exp_avg_sq with 16-byte accesses -- one read and one write of each per step.  One launch covers any list of
+//     layers (a device table of descriptors), so the update of a whole coupling half (eight layers) is a single launch of 4 - 20
+//     thousand independent tiles.  hp == NULL: the tile of dW is stored instead (autograd's view of the same kernels).
+//   * seq_coupling_bwd_kernel, seq_actnorm_bwd_kernel, seq_flow_loss_kernel: the pointwise / reduction remainder.
+// Nothing uses float atomics; every sum has a fixed order: a step is bit-reproducible.
+#include "common.h"
+#include "../../include/vunet_seq_train.h"
+
+namespace {
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__device__ __forceinline__ float comp4(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// ------------------------------------------------------------------------------------------------ dX = dZ . W
+struct SeqDxArgs {
+  const float* w[2];   // [M][K]
+  const float* dz;     // [nets][Bp][M]
+  float* raw;          // [nets][S][Bp][K]
+  int M, K, Bp, S;
+};
+
+// grid (K / 64, S, nets), 64 WAVES threads.  Lane l: i = l & 15, q = l >> 4.  In a 16-row group starting at row mb the lane loads
+// W[mb + 4 q + e'][k0 + 4 i .. + 3] (e' = 0..3: four 16-byte loads; a wave instruction covers four rows of 256 bytes) and
+// dZ[16 nb + i][mb + 4 q .. + 3].  MFMA (e', e, nb): A = component e of load e' (row i of A <-> column k0 + 4 i + e), B = component
+// e' of the dZ load (column j of B <-> batch row 16 nb + j), both at reduction slot q <-> W row mb + 4 q + e'.
+// D: lane holds dX[16 nb + (l & 15)][k0 + 4 (4 q + r) + e] in acc[e][nb][r].
+template <int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
+  __shared__ float4 red[WAVES][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.x * 64, s = blockIdx.y, net = blockIdx.z;
+  const int rows = a.M / a.S, ngrp = rows >> 4;
+  const float* __restrict__ w = a.w[net] + (size_t)(s * rows + 4 * q) * a.K + k0 + 4 * i;
+  const float* __restrict__ dz = a.dz + ((size_t)net * a.Bp + i) * a.M + s * rows + 4 * q;
+  f32x4 acc[4][NB];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[e][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int g = wave; g < ngrp; g += WAVES) {
+    float4 wv[4], dv[NB];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) wv[e2] = *reinterpret_cast<const float4*>(w + (size_t)(16 * g + e2) * a.K);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) dv[nb] = *reinterpret_cast<const float4*>(dz + (size_t)16 * nb * a.M + 16 * g);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[e][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(wv[e2], e), comp4(dv[nb], e2), acc[e][nb], 0, 0, 0);
+  }
+  // the waves' partial sums meet in LDS, one batch tile per round; waves 0..3 (thread t: r = t >> 6) add them in wave order
+  float* out = a.raw + ((size_t)net * a.S + s) * a.Bp * a.K;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][r][lane] = make_float4(acc[0][nb][r], acc[1][nb][r], acc[2][nb][r], acc[3][nb][r]);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int r = threadIdx.x >> 6;
+      float4 v = red[0][r][lane];
+#pragma unroll 4
+      for (int p = 1; p < WAVES; ++p) v = add4(v, red[p][r][lane]);
+      *reinterpret_cast<float4*>(out + (size_t)(16 * nb + i) * a.K + k0 + 16 * q + 4 * r) = v;
+    }
+    __syncthreads();
+  }
+}
+
+// dz[n][b][k] = (sum_s raw[n][s][b][k]) * LeakyReLU'(y[n][b][k]); one float4 per thread
+__global__ __launch_bounds__(256) void seq_dz_finish_kernel(const float* __restrict__ raw, const float* __restrict__ y,
+                                                            float* __restrict__ dz, int S, size_t per_net4, float slope) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // float4 index inside one net
+  if (idx >= per_net4) return;
+  const int net = blockIdx.y;
+  const float4* r4 = reinterpret_cast<const float4*>(raw) + (size_t)net * S * per_net4 + idx;
+  float4 v = r4[0];
+  for (int s = 1; s < S; ++s) v = add4(v, r4[(size_t)s * per_net4]);
+  const float4 yv = reinterpret_cast<const float4*>(y)[(size_t)net * per_net4 + idx];
+  v.x *= yv.x > 0.f ? 1.f : slope;
+  v.y *= yv.y > 0.f ? 1.f : slope;
+  v.z *= yv.z > 0.f ? 1.f : slope;
+  v.w *= yv.w > 0.f ? 1.f : slope;
+  reinterpret_cast<float4*>(dz)[(size_t)net * per_net4 + idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ one flow step, backwards
+struct SeqCouplingBwdArgs {
+  const float* gbase;
+  const float* gslabs;
+  const int* inv_map;
+  const float* scale;
+  const float* in;
+  const float* st;
+  const float* bias_s;
+  const float* bias_t;
+  const float* dld;
+  float* gfull;
+  float* gout;
+  float* dzh;
+  int B, Bp, C, c1, ld_g, ld_in, ld_out, ld_full, Mp, S, n_sl, ld_sl, c1s;
+};
+
+// grid (B, ceil(C / 256)), 256 threads: batch row b, coupling index j
+__global__ __launch_bounds__(256) void seq_coupling_bwd_kernel(SeqCouplingBwdArgs a) {
+  const int b = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+  if (j >= a.C) return;
+  const int c = a.inv_map ? a.inv_map[j] : j;
+  float g = a.gbase[(size_t)b * a.ld_g + c];
+  if (a.gslabs && c < a.c1s)
+    for (int n = 0; n < a.n_sl; ++n) g += a.gslabs[((size_t)n * a.Bp + b) * a.ld_sl + c];
+  if (a.gfull) a.gfull[(size_t)b * a.ld_full + c] = g;
+  if (a.scale) g *= a.scale[c];                       // out = scale (u + loc)   (lib/modules.py:307)
+  if (!a.st || j < a.c1) {
+    a.gout[(size_t)b * a.ld_out + j] = g;
+    return;
+  }
+  const int q = j - a.c1;
+  float s;
+  if (a.S == 1) s = a.st[(size_t)b * a.Mp + q];
+  else {   // the forward pass left raw slabs: the same sum in the same order (csrc/seq.hip, seq_coupling_kernel)
+    const size_t slab = (size_t)a.Bp * a.Mp;
+    const float* ps = a.st + (size_t)b * a.Mp + q;
+    s = ps[0];
+    for (int p = 1; p < a.S; ++p) s += ps[p * slab];
+    s = tanhf(s + a.bias_s[q]);
+  }
+  const float xk = a.in[(size_t)b * a.ld_in + j];
+  const float e = expf(s);
+  a.gout[(size_t)b * a.ld_out + j] = g * e;           // x_ = x_k exp(s) + t   (models/flow/blocks.py:304)
+  const float ds = g * xk * e + a.dld[b];             // ... and logdet += sum(s)   (:306)
+  a.dzh[(size_t)b * a.Mp + q] = ds * (1.f - s * s);   // s = tanh(.)   (lib/modules.py:252-253)
+  a.dzh[((size_t)a.Bp + b) * a.Mp + q] = g;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+struct AdamResolved {
+  float step_size, inv_sqrt_bc2, b1, b2, eps, wd;
+};
+
+__device__ __forceinline__ AdamResolved adam_resolve(const vunet_seq_adam_hp& hp) {
+  // bias corrections in double, as torch forms them on the host (torch/optim/adam.py: bias_correction1 / 2, step_size)
+  const double t = (double)*hp.step_dev;
+  const double bc1 = 1.0 - pow((double)hp.beta1, t), bc2 = 1.0 - pow((double)hp.beta2, t);
+  AdamResolved r;
+  r.step_size = (float)(*hp.lr_dev / bc1);
+  r.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  r.b1 = hp.beta1;
+  r.b2 = hp.beta2;
+  r.eps = hp.eps;
+  r.wd = hp.weight_decay;
+  return r;
+}
+
+__device__ __forceinline__ void adam_update(const AdamResolved& h, float g, float& p, float& m, float& v) {
+  if (h.wd != 0.f) g += h.wd * p;
+  m = h.b1 * m + (1.f - h.b1) * g;
+  v = h.b2 * v + (1.f - h.b2) * g * g;
+  p -= h.step_size * (m / (sqrtf(v) * h.inv_sqrt_bc2 + h.eps));
+}
+
+// ------------------------------------------------------------------------------------------------ dW = dZ^T . X (+ Adam)
+constexpr int DW_LD = 80;    // LDS row stride of the staged 64-column tiles: 4 rows q * 80 fall into four disjoint bank groups
+constexpr int DW_LDO = 68;   // ... of the tile of dW on its way from the accumulator layout to rows
+
+// grid: one workgroup per 64 x 64 tile of the launch's flat tile list, 256 threads.  Wave w owns rows 16 w .. 16 w + 15 of the
+// tile: A = dZ^T (row i <-> W row m0 + 16 w + i), B = X (column j <-> W column k0 + 16 blk + j), reduction over the batch rows
+// (step c, slot q <-> row 4 c + q).  D: lane holds dW[m0 + 16 w + 4 q + r][k0 + 16 blk + (l & 15)] in acc[blk][r].
+template <int NB, bool ADAM>
+__global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* __restrict__ tab, int n_layers, int first_tile,
+                                                     vunet_seq_adam_hp hp) {
+  __shared__ float dzs[16 * NB * DW_LD];
+  __shared__ float xs[64 * DW_LD];      // (the tile of dW, [64][DW_LDO], reuses this space)
+  AdamResolved& hsh = *reinterpret_cast<AdamResolved*>(&dzs[64]);   // (in the padding columns of row 0)
+  const int tile = first_tile + blockIdx.x;
+  int lo = 0, hi = n_layers;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid].tile0 <= tile) lo = mid;
+    else hi = mid;
+  }
+  const vunet_seq_dw_layer L = tab[lo];
+  const int t = tile - L.tile0, tm = t / L.tiles_k, tk = t - tm * L.tiles_k;
+  const int m0 = 64 * tm, k0 = 64 * tk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  if (ADAM && tid == 0) hsh = adam_resolve(hp);
+  for (int idx = tid; idx < 16 * NB * 16; idx += 256) {
+    const int b = idx >> 4, c4 = idx & 15;
+    *reinterpret_cast<float4*>(&dzs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(L.dz + (size_t)b * L.ldz + m0 + 4 * c4);
+    *reinterpret_cast<float4*>(&xs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(L.x + (size_t)b * L.ldx + k0 + 4 * c4);
+  }
+  __syncthreads();
+  float av[4 * NB];
+#pragma unroll
+  for (int c = 0; c < 4 * NB; ++c) av[c] = dzs[(4 * c + q) * DW_LD + 16 * wave + i];
+  f32x4 acc[4];
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4 * NB; ++c)
+      acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], xs[(4 * c + q) * DW_LD + 16 * blk + i], acc[blk], 0, 0, 0);
+  }
+  // bias: d b[m] = sum_b dZ[b][m], rows in order (the k = 0 tiles)
+  float bsum = 0.f;
+  if (tk == 0 && tid < 64 && L.bias)
+    for (int b = 0; b < 16 * NB; ++b) bsum += dzs[b * DW_LD + tid];
+  __syncthreads();   // every wave has read its operands: the space of xs becomes the tile of dW, by rows
+  float* dws = xs;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dws[(16 * wave + 4 * q + r) * DW_LDO + 16 * blk + i] = acc[blk][r];
+  __syncthreads();
+  const AdamResolved h = ADAM ? hsh : AdamResolved{};
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
+    float4 g = *reinterpret_cast<const float4*>(&dws[row * DW_LDO + 4 * c4]);
+    if (k0 + 4 * c4 + 3 >= L.kv) {   // (padding columns of the image: only where K is not the layer's own width)
+      const int kc = k0 + 4 * c4;
+      if (kc >= L.kv) g.x = 0.f;
+      if (kc + 1 >= L.kv) g.y = 0.f;
+      if (kc + 2 >= L.kv) g.z = 0.f;
+      g.w = 0.f;
+    }
+    const size_t off = (size_t)(m0 + row) * L.K + k0 + 4 * c4;
+    if constexpr (ADAM) {
+      float4 p = *reinterpret_cast<const float4*>(L.w + off), m = *reinterpret_cast<const float4*>(L.m + off),
+             v = *reinterpret_cast<const float4*>(L.v + off);
+      adam_update(h, g.x, p.x, m.x, v.x);
+      adam_update(h, g.y, p.y, m.y, v.y);
+      adam_update(h, g.z, p.z, m.z, v.z);
+      adam_update(h, g.w, p.w, m.w, v.w);
+      *reinterpret_cast<float4*>(L.w + off) = p;
+      *reinterpret_cast<float4*>(L.m + off) = m;
+      *reinterpret_cast<float4*>(L.v + off) = v;
+    } else {
+      *reinterpret_cast<float4*>(L.g + off) = g;
+    }
+  }
+  if (tk == 0 && tid < 64 && L.bias) {
+    const int m = m0 + tid;
+    if constexpr (ADAM) {
+      float p = L.bias[m], mm = L.bm[m], vv = L.bv[m];
+      adam_update(h, bsum, p, mm, vv);
+      L.bias[m] = p;
+      L.bm[m] = mm;
+      L.bv[m] = vv;
+    } else {
+      L.bg[m] = bsum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ ActNorm loc / scale
+// grid (ceil(C / 64), n_layers), 256 threads: channel bx 64 + (t & 63), row group t >> 6 takes rows rg, rg + 4, ...
+template <bool ADAM>
+__global__ __launch_bounds__(256) void seq_actnorm_bwd_kernel(const vunet_seq_actnorm_layer* __restrict__ tab, int C, int B,
+                                                              const float* __restrict__ dld, vunet_seq_adam_hp hp) {
+  __shared__ float red[2][4][64];
+  const vunet_seq_actnorm_layer L = tab[blockIdx.y];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C)
+    for (int b = rg; b < B; b += 4) {
+      const float g = L.gfull[(size_t)b * L.ld + c];
+      s0 += g;
+      s1 += g * L.out[(size_t)b * L.ld + c];
+    }
+  red[0][rg][cl] = s0;
+  red[1][rg][cl] = s1;
+  __syncthreads();
+  if (rg != 0 || c >= C) return;
+  s0 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  s1 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  float sld = 0.f;
+  for (int b = 0; b < B; ++b) sld += dld[b];
+  const float sc = L.scale[c];
+  // out = sc (u + loc): d sc = sum g (u + loc) = sum g out / sc; logdet = sum_c log|sc| on every row: d sc += sum_b dld / sc
+  const float gsc = (s1 + sld) / sc, glo = sc * s0;
+  if constexpr (ADAM) {
+    const AdamResolved h = adam_resolve(hp);
+    float p = sc, m = L.sm[c], v = L.sv[c];
+    adam_update(h, gsc, p, m, v);
+    L.scale[c] = p;
+    L.sm[c] = m;
+    L.sv[c] = v;
+    p = L.loc[c];
+    m = L.lm[c];
+    v = L.lv[c];
+    adam_update(h, glo, p, m, v);
+    L.loc[c] = p;
+    L.lm[c] = m;
+    L.lv[c] = v;
+  } else {
+    L.gs[c] = gsc;
+    L.gl[c] = glo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ FlowLoss
+// one workgroup of 1024 threads: wave w sums rows w, w + 16, ...; thread 0 adds the row sums in row order
+__global__ __launch_bounds__(1024) void seq_flow_loss_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ logdet,
+                                                             const float* __restrict__ noise, int B, int Bp, int C,
+                                                             float* __restrict__ scalars, float* __restrict__ dz, int ld_dz,
+                                                             float* __restrict__ dld) {
+  __shared__ float rs[2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_b = 1.f / (float)B;
+  for (int b = wave; b < Bp; b += 16) {
+    float s = 0.f, sn = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float v = b < B ? z[(size_t)b * ldz + c] : 0.f;
+      s += v * v;
+      if (dz) dz[(size_t)b * ld_dz + c] = v * inv_b;
+      if (noise && b < B) {
+        const float e = noise[(size_t)b * C + c];
+        sn += e * e;
+      }
+    }
+    s = wave_sum(s);
+    sn = wave_sum(sn);
+    if (lane == 0) {
+      rs[0][b] = 0.5f * s;      // nll (lib/losses.py:330-331)
+      rs[1][b] = 0.5f * sn;
+      if (dld) dld[b] = b < B ? -inv_b : 0.f;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float nll = 0.f, ref = 0.f, ld = 0.f;
+    for (int b = 0; b < B; ++b) {
+      nll += rs[0][b];
+      ref += rs[1][b];
+      ld += logdet[b];
+    }
+    nll *= inv_b;
+    const float nld = -(ld * inv_b);
+    scalars[0] = nll + nld;
+    scalars[1] = ref * inv_b;
+    scalars[2] = nld;
+    scalars[3] = nll;
+  }
+}
+
+__global__ void seq_adam_tick_kernel(int64_t* step) { *step += 1; }
+
+__global__ __launch_bounds__(256) void seq_unpack_rows_kernel(const float* __restrict__ src, int ld_src, int col_off, int row_off,
+                                                              int row_mul, float* __restrict__ dst, int M, int K, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * K) return;
+  const int m = (int)(idx / K), k = (int)(idx - (size_t)m * K);
+  const float v = src[(size_t)(row_off + row_mul * m) * ld_src + col_off + k];
+  dst[idx] = accumulate ? dst[idx] + v : v;
+}
+
+}  // namespace
+
+extern "C" int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw, void* stream) {
+  if (!d || !w0 || !dz || !raw) return VUNET_ERR_ARG;
+  if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
+  if (d->B < 1 || d->B > 64 || d->K < 64 || d->K % 64 || d->S < 1 || d->M < 16 * d->S || d->M % (16 * d->S)) return VUNET_ERR_ARG;
+  SeqDxArgs a;
+  a.w[0] = w0;
+  a.w[1] = w1;
+  a.dz = dz;
+  a.raw = raw;
+  a.M = d->M;
+  a.K = d->K;
+  a.Bp = (d->B + 15) / 16 * 16;
+  a.S = d->S;
+  const dim3 grid(d->K / 64, d->S, d->nets);
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = d->M / d->S >= 16 * 16;   // 16 waves: at least one 16-row group each
+#define SEQ_DX_CASE(NB)                                                          \
+  case NB:                                                                       \
+    if (wide) VUNET_LAUNCH((seq_dx_kernel<NB, 16>), grid, dim3(1024), 0, st, a); \
+    else VUNET_LAUNCH((seq_dx_kernel<NB, 4>), grid, dim3(256), 0, st, a);        \
+    break;
+  switch (a.Bp / 16) {
+    SEQ_DX_CASE(1)
+    SEQ_DX_CASE(2)
+    SEQ_DX_CASE(3)
+    SEQ_DX_CASE(4)
+    default: return VUNET_ERR_ARG;
+  }
+#undef SEQ_DX_CASE
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_dz_finish(const float* raw, const float* y, float* dz, int32_t nets, int32_t S, int32_t Bp, int32_t K,
+                                   float slope, void* stream) {
+  if (!raw || !y || !dz || nets < 1 || nets > 2 || S < 1 || Bp < 16 || Bp % 16 || K < 4 || K % 4) return VUNET_ERR_ARG;
+  const size_t per_net4 = (size_t)Bp * K / 4;
+  VUNET_LAUNCH(seq_dz_finish_kernel, dim3((unsigned)((per_net4 + 255) / 256), nets), dim3(256), 0, (hipStream_t)stream, raw, y, dz, S,
+               per_net4, slope);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_coupling_bwd(const vunet_seq_coupling_bwd_desc* d, const float* gbase, const float* gslabs,
+                                      const int32_t* inv_map, const float* scale, const float* in, const float* st, const float* bias_s,
+                                      const float* bias_t, const float* dld, float* gfull, float* gout, float* dzh, void* stream) {
+  if (!d || !gbase || !gout || d->B < 1 || d->B > 64 || d->C < 1 || d->ld_g < d->C || d->ld_out < d->C) return VUNET_ERR_ARG;
+  if (gslabs && (d->n_sl < 1 || d->ld_sl < d->c1s || d->c1s < 0 || d->c1s > d->C)) return VUNET_ERR_ARG;
+  if (gfull && d->ld_full < d->C) return VUNET_ERR_ARG;
+  if (st && (!in || !dzh || !dld || d->ld_in < d->C || d->c1 < 0 || d->c1 > d->C || d->Mp < d->C - d->c1 || d->S < 1 || d->S > 8))
+    return VUNET_ERR_ARG;
+  if (st && d->S > 1 && (!bias_s || !bias_t)) return VUNET_ERR_ARG;
+  if (gout == gbase && inv_map) return VUNET_ERR_ARG;   // a gather cannot run in place
+  SeqCouplingBwdArgs a;
+  a.gbase = gbase;
+  a.gslabs = gslabs;
+  a.inv_map = inv_map;
+  a.scale = scale;
+  a.in = in;
+  a.st = st;
+  a.bias_s = bias_s;
+  a.bias_t = bias_t;
+  a.dld = dld;
+  a.gfull = gfull;
+  a.gout = gout;
+  a.dzh = dzh;
+  a.B = d->B;
+  a.Bp = (d->B + 15) / 16 * 16;
+  a.C = d->C;
+  a.c1 = d->c1;
+  a.ld_g = d->ld_g;
+  a.ld_in = d->ld_in;
+  a.ld_out = d->ld_out;
+  a.ld_full = d->ld_full;
+  a.Mp = d->Mp;
+  a.S = st ? d->S : 1;
+  a.n_sl = d->n_sl;
+  a.ld_sl = d->ld_sl;
+  a.c1s = d->c1s;
+  VUNET_LAUNCH(seq_coupling_bwd_kernel, dim3(d->B, (d->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  return vunet_check_launch();
+}
+
+static bool adam_hp_ok(const vunet_seq_adam_hp* hp) {
+  return hp->lr_dev && hp->step_dev && hp->beta1 >= 0.f && hp->beta1 < 1.f && hp->beta2 >= 0.f && hp->beta2 < 1.f && hp->eps >= 0.f;
+}
+
+extern "C" int vunet_seq_dw(const vunet_seq_dw_layer* table_dev, int32_t n_layers, int32_t first_tile, int32_t n_tiles, int32_t B,
+                            const vunet_seq_adam_hp* hp, void* stream) {
+  if (!table_dev || n_layers < 1 || first_tile < 0 || n_tiles < 1 || B < 1 || B > 64) return VUNET_ERR_ARG;
+  if (hp && !adam_hp_ok(hp)) return VUNET_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const vunet_seq_adam_hp h = hp ? *hp : vunet_seq_adam_hp{};
+#define SEQ_DW_CASE(NB)                                                                                                  \
+  case NB:                                                                                                               \
+    if (hp) VUNET_LAUNCH((seq_dw_kernel<NB, true>), dim3(n_tiles), dim3(256), 0, st, table_dev, n_layers, first_tile, h); \
+    else VUNET_LAUNCH((seq_dw_kernel<NB, false>), dim3(n_tiles), dim3(256), 0, st, table_dev, n_layers, first_tile, h);   \
+    break;
+  switch ((B + 15) / 16) {
+    SEQ_DW_CASE(1)
+    SEQ_DW_CASE(2)
+    SEQ_DW_CASE(3)
+    SEQ_DW_CASE(4)
+    default: return VUNET_ERR_ARG;
+  }
+#undef SEQ_DW_CASE
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_actnorm_bwd(const vunet_seq_actnorm_layer* table_dev, int32_t n_layers, int32_t C, int32_t B, const float* dld,
+                                     const vunet_seq_adam_hp* hp, void* stream) {
+  if (!table_dev || n_layers < 1 || C < 1 || B < 1 || B > 64 || !dld) return VUNET_ERR_ARG;
+  if (hp && !adam_hp_ok(hp)) return VUNET_ERR_ARG;
+  const dim3 grid((C + 63) / 64, n_layers);
+  if (hp) VUNET_LAUNCH((seq_actnorm_bwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, table_dev, C, B, dld, *hp);
+  else VUNET_LAUNCH((seq_actnorm_bwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, table_dev, C, B, dld, vunet_seq_adam_hp{});
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_flow_loss(const float* z, int32_t ldz, const float* logdet, const float* noise, int32_t B, int32_t C,
+                                   float* scalars, float* dz, int32_t ld_dz, float* dld, void* stream) {
+  if (!z || !logdet || !scalars || B < 1 || B > 64 || C < 1 || ldz < C || (dz && ld_dz < C)) return VUNET_ERR_ARG;
+  const int Bp = (B + 15) / 16 * 16;
+  VUNET_LAUNCH(seq_flow_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, ldz, logdet, noise, B, Bp, C, scalars, dz, ld_dz,
+               dld);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_adam_tick(int64_t* step_dev, void* stream) {
+  if (!step_dev) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(seq_adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_unpack_rows(const float* src, int32_t ld_src, int32_t col_off, int32_t row_off, int32_t row_mul, float* dst,
+                                     int32_t M, int32_t K, int32_t accumulate, void* stream) {
+  if (!src || !dst || M < 1 || K < 1 || col_off < 0 || ld_src < col_off + K || row_off < 0 || row_mul < 1) return VUNET_ERR_ARG;
+  const size_t n = (size_t)M * K;
+  VUNET_LAUNCH(seq_unpack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, col_off,
+               row_off, row_mul, dst, M, K, accumulate);
+  return vunet_check_launch();
+}

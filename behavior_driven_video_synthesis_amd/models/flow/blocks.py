@@ -3,7 +3,9 @@
 
 The modules own the parameters; evaluation happens in ``seq.FlowEngine`` (csrc/seq.hip): one launch per MLP layer with
 the scale and translation nets of a coupling batched, one launch for everything between two MLP evaluations, the whole
-pass replayed from a hipGraph.  A block or a coupling called on its own builds a one-block engine around itself.
+pass replayed from a hipGraph.  Called where autograd records (grad mode on, trainable parameters: the flow stage of
+experiments/behavior_net.py:703-714), the forward direction runs in ``seq_train.FlowTrainEngine`` instead and comes back with
+a graph whose backward is the HIP backward pass (csrc/seq_train.hip).
 """
 from __future__ import annotations
 
@@ -60,6 +62,7 @@ class UnconditionalFlow2(nn.Module):
         self.sub_layers = nn.ModuleList([UnconditionalFlatDoubleCouplingFlowBlock2(in_channels, hidden_dim, hidden_depth)
                                          for _ in range(n_flows)])
         self._engine = None
+        self._train_engine = None
 
     def engine(self):
         if self._engine is None:
@@ -67,9 +70,21 @@ class UnconditionalFlow2(nn.Module):
             object.__setattr__(self, "_engine", seq.FlowEngine(self))
         return self._engine
 
+    def train_engine(self, **adam):
+        """The training plans of this flow (``seq_train.FlowTrainEngine``); ``adam``: the hyper-parameters of its fused
+        optimiser step (used by ``experiments.behavior_net``; autograd callers bring their own optimiser)."""
+        if self._train_engine is None:
+            from ... import seq_train
+            object.__setattr__(self, "_train_engine", seq_train.FlowTrainEngine(self, **adam))
+        return self._train_engine
+
     def forward(self, x, reverse=False):
         if reverse:
             return self.engine().reverse(x)[:, :, None, None]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ... import seq_train
+            out, logdet = seq_train.flow_autograd(self.train_engine(), x)
+            return out[:, :, None, None], logdet
         out, logdet = self.engine().forward(x)
         return out[:, :, None, None], logdet
 

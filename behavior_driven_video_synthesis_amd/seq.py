@@ -87,7 +87,9 @@ class MlpGroup:
     are single."""
 
     def __init__(self, layers: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], k_in_pad: int, tanh_head: Sequence[bool],
-                 split_head: bool = False):
+                 split_head: bool = False, pad_hidden: int = 32, pad_out: int = 16):
+        """``pad_hidden`` / ``pad_out``: the multiples the hidden / head widths are padded to (training pads both to 64: the
+        tiles of ``vunet_seq_dx`` / ``vunet_seq_dw``)."""
         self.nets = len(layers)
         n_layers = len(layers[0])
         self.dims = []     # per layer: (m_pad, k_pad)
@@ -97,7 +99,7 @@ class MlpGroup:
         k_pad = k_in_pad
         for li in range(n_layers):
             m = layers[0][li][0].shape[0]
-            m_pad = _up(m, 16) if li == n_layers - 1 else _up(m, 32)   # a hidden width is the next layer's K
+            m_pad = _up(m, pad_out) if li == n_layers - 1 else _up(m, pad_hidden)   # a hidden width is the next layer's K
             self.w.append([weight_image(net[li][0], m_pad, k_pad) for net in layers])
             self.b.append([padded_vector(net[li][1], m_pad) for net in layers])
             self.dims.append((m_pad, k_pad))
@@ -116,11 +118,12 @@ class MlpGroup:
         return max(self.nets * b_pad * m * (self.head_split if li == len(self.dims) - 1 else 1) for li, (m, _) in enumerate(self.dims))
 
     def run(self, rows: int, xin: torch.Tensor, ldx: int, bufs: Sequence[torch.Tensor]) -> torch.Tensor:
-        """``xin``: [b_pad, ldx] operand (read from column 0).  Returns the buffer holding the heads' [nets][b_pad][out_pad]."""
+        """``xin``: [b_pad, ldx] operand (read from column 0).  Returns the buffer holding the heads' [nets][b_pad][out_pad].
+        ``bufs``: two buffers used alternately, or one per layer (training keeps every layer's output)."""
         src, shared = xin, 1
         last = len(self.dims) - 1
         for li, (m_pad, k_pad) in enumerate(self.dims):
-            dst = bufs[li % 2]
+            dst = bufs[li % len(bufs)]
             act = self.head_act if li == last else [ACT_LRELU, ACT_LRELU]
             d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, act[0], act[1], self.nets, shared,
                               self.head_split if li == last else 1)
@@ -231,6 +234,34 @@ class _GraphCache:
         g.replay()
 
 
+    def run_step(self, key, issue):
+        """``run`` for a launch sequence with side effects (an optimisation step): every call executes it exactly once -- the
+        first call with a key eagerly (first-launch work stays outside a recording), the second records it and replays the
+        recording, later ones replay."""
+        if not self.enabled or torch.cuda.is_current_stream_capturing() or key in self.graphs:
+            return self.run(key, issue)
+        warmed = self.__dict__.setdefault("_warmed", set())
+        if key not in warmed:
+            warmed.add(key)
+            issue()
+            return
+        torch.cuda.synchronize()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, stream=self._stream):
+                issue()
+        finally:
+            if was_on:
+                gc.enable()
+        if len(self.graphs) >= self.MAX_GRAPHS:
+            self.drop(next(iter(self.graphs)))
+        self.graphs[key] = g
+        g.replay()
+
     def drop(self, key):
         if self.graphs.pop(key, None) is not None and self.on_evict is not None:
             cb = self.on_evict()
@@ -254,6 +285,9 @@ def _versions(params) -> tuple:
 class FlowEngine:
     """``UnconditionalFlow2`` (models/flow/blocks.py:95-128) in both directions for batches of <= 64 rows."""
 
+    PAD = 32          # operand row length / MLP input and hidden widths are padded to this multiple
+    PAD_OUT = 16      # ... and the head widths to this one
+
     def __init__(self, flow):
         self._flow = weakref.ref(flow)     # the module owns the engine; no cycle for the collector to find
         self._packed_for = None
@@ -274,7 +308,7 @@ class FlowEngine:
         c = self.flow.in_channels
         dev = blocks[0].norm_layer.loc.device
         c1 = c // 2 + c % 2
-        self.C, self.c1, self.ld = c, c1, _up(c, 32)
+        self.C, self.c1, self.ld = c, c1, _up(c, self.PAD)
         ar = torch.arange(c, device=dev)
         swap = torch.cat(torch.chunk(ar, 2)[::-1])          # x -> cat(chunk(x, 2)[::-1])  (models/flow/blocks.py:301, :314)
         self.swap = swap.to(torch.int32)
@@ -282,14 +316,22 @@ class FlowEngine:
         for blk in blocks:
             cp = blk.coupling
             halves = [MlpGroup([[(l.weight, l.bias) for l in cp.s[i].linears()], [(l.weight, l.bias) for l in cp.t[i].linears()]],
-                               _up(c1, 32), [True, False], split_head=True) for i in range(2)]
+                               _up(c1, self.PAD), [True, False], split_head=True, pad_hidden=self.PAD, pad_out=self.PAD_OUT)
+                      for i in range(2)]
             self.blocks.append(dict(
                 halves=halves, scale=blk.norm_layer.scale.detach().reshape(-1), loc=blk.norm_layer.loc.detach().reshape(-1),
                 fwd=blk.shuffle.forward_shuffle_idx.to(torch.int32), bwd=blk.shuffle.backward_shuffle_idx.to(torch.int32)))
         self._packed_for = key
         self._all_init = False
-        self._plans.clear()
-        self.graph.graphs.clear()
+        # a re-pack that finds every image where it was (parameters used in place, updated by an optimiser: their version
+        # counters moved, their storage did not) keeps the buffers and the recordings, which hold nothing but pointers
+        sig = tuple(t.data_ptr() for blk in self.blocks for h in blk["halves"] for lay in (h.w + h.b) for t in lay) + tuple(
+            blk[k].data_ptr() for blk in self.blocks for k in ("scale", "loc", "fwd", "bwd"))
+        if sig != getattr(self, "_image_sig", None):
+            self._image_sig = sig
+            self._plans.clear()
+            self.graph.graphs.clear()
+            self.graph.__dict__.pop("_warmed", None)
 
     def _plan(self, rows: int) -> dict:
         p = self._plans.get(rows)

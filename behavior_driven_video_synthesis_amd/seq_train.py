@@ -1,0 +1,481 @@
+"""Training plans of the behaviour path (BASELINE config 4; csrc/seq_train.hip, include/vunet_seq_train.h).
+
+The flow stage of ``experiments/behavior_net.py`` (:703-714) is, per step,
+
+    gauss, logdet = latent_flow(bs.detach());  f_loss, log = flow_loss(gauss, logdet)
+    flow_optimizer.zero_grad();  f_loss.backward();  flow_optimizer.step()
+
+with ``Adam(lr = flow_lr * batch_size, betas = (0.5, 0.9), weight_decay)`` (:384-395) and ``FlowLoss`` (lib/losses.py:294-317).
+``FlowTrainEngine`` runs that step on the kernels of csrc/seq.hip (forward, every layer's output kept) and csrc/seq_train.hip
+(loss, input gradients, and the weight gradient fused into Adam's update: dW is never written), recorded once per batch size
+into a hipGraph.  The same backward kernels serve autograd (``flow_autograd``): there the gradients are written out and the
+reference's own ``torch.optim.Adam`` applies them -- what an unchanged ``main.py`` does through ``dropin``.
+
+There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .ops import _call, _p, _stream
+from .seq import ACT_LRELU, FlowEngine, SeqCouplingDesc, _need_device, _up, padded_vector, weight_image  # noqa: F401
+
+LRELU_SLOPE = 0.01   # nn.LeakyReLU() default (lib/modules.py:244)
+
+
+class SeqAdamHp(ctypes.Structure):
+    _fields_ = [("lr_dev", ctypes.c_void_p), ("step_dev", ctypes.c_void_p), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+                ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float)]
+
+
+class SeqDxDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "nets", "S")]
+
+
+class SeqCouplingBwdDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "c1", "ld_g", "ld_in", "ld_out", "ld_full", "Mp", "S", "n_sl", "ld_sl", "c1s")]
+
+
+class SeqDwLayer(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("w", "m", "v", "g", "bias", "bm", "bv", "bg", "dz", "x")]
+                + [(n, ctypes.c_int32) for n in ("M", "K", "ldz", "ldx", "tile0", "tiles_k", "kv", "pad")])
+
+
+class SeqActnormLayer(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("scale", "loc", "sm", "sv", "lm", "lv", "gs", "gl", "gfull", "out")]
+                + [(n, ctypes.c_int32) for n in ("ld", "pad")])
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _table(entries, device) -> torch.Tensor:
+    """A ctypes array of descriptors -> a device byte tensor (the kernels read their descriptors from device memory)."""
+    arr = (type(entries[0]) * len(entries))(*entries)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+class AdamState:
+    """torch.optim.Adam's hyper-parameters with the learning rate (float64) and the step count (int64) on the device."""
+
+    def __init__(self, device, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.lr_dev = torch.full((1,), self.lr, dtype=torch.float64, device=device)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.hp = SeqAdamHp(self.lr_dev.data_ptr(), self.step_dev.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay)
+
+    def set_lr(self, lr: float):
+        if float(lr) != self.lr:
+            self.lr = float(lr)
+            self.lr_dev.fill_(self.lr)
+
+    def tick(self):
+        _call("vunet_seq_adam_tick", _p(self.step_dev), _stream())
+
+    @property
+    def step(self) -> int:
+        return int(self.step_dev.item())
+
+
+class _TrainLayer:
+    """One Linear layer of one MLP: the (possibly padded) weight / bias images the kernels read, and Adam's moments."""
+
+    def __init__(self, name: str, lin, w_img: torch.Tensor, b_img: torch.Tensor):
+        self.name, self.lin, self.w, self.b = name, lin, w_img, b_img
+        self.w_inplace = w_img.data_ptr() == lin.weight.data_ptr()
+        self.b_inplace = b_img.data_ptr() == lin.bias.data_ptr()
+        self.m = self.v = self.bm = self.bv = None
+
+    def moments(self):
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(self.w), torch.zeros_like(self.w)
+            self.bm, self.bv = torch.zeros_like(self.b), torch.zeros_like(self.b)
+
+    def write_back(self):
+        """A padded image is the training master: copy its valid part into the module's parameter."""
+        if not self.w_inplace:
+            m, k = self.lin.weight.shape
+            _call("vunet_seq_unpack_rows", _p(self.w), self.w.shape[1], 0, 0, 1, _p(self.lin.weight.data), m, k, 0, _stream())
+        if not self.b_inplace:
+            n = self.lin.bias.numel()
+            _call("vunet_seq_unpack_rows", _p(self.b), self.b.numel(), 0, 0, 1, _p(self.lin.bias.data), 1, n, 0, _stream())
+
+
+class FlowTrainEngine(FlowEngine):
+    """``UnconditionalFlow2`` forward with every intermediate kept, ``FlowLoss``, the backward pass and Adam, for one batch of
+    <= 64 rows (``config/behavior_net.yaml``: batch_size 64).  Widths are padded to 64 (the tiles of the backward kernels); a
+    parameter whose shape already fits -- every layer of the reference configuration -- is read and updated in place."""
+
+    PAD = 64
+    PAD_OUT = 64
+
+    def __init__(self, flow, lr: float = 1e-3, betas=(0.5, 0.9), eps: float = 1e-8, weight_decay: float = 0.0):
+        super().__init__(flow)
+        self._adam_args = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.adam: Optional[AdamState] = None
+        self._moments: Dict[str, tuple] = {}
+        self._generation = 0
+
+    # ---- weights
+    def _pack(self):
+        before = self._packed_for
+        super()._pack()
+        if self._packed_for == before and getattr(self, "layers", None) is not None:
+            return
+        dev = self.blocks[0]["scale"].device
+        if self.adam is None:
+            self.adam = AdamState(dev, **self._adam_args)
+        self.layers: List[List[List[List[_TrainLayer]]]] = []    # [block][half][net][layer]
+        for bi, (blk, mod) in enumerate(zip(self.blocks, self.flow.sub_layers)):
+            per_half = []
+            for hi, half in enumerate(blk["halves"]):
+                nets = []
+                for ni, kind in enumerate(("s", "t")):
+                    lins = getattr(mod.coupling, kind)[hi].linears()
+                    nets.append([_TrainLayer(f"sub_layers.{bi}.coupling.{kind}.{hi}.main.{2 * li}", lin, half.w[li][ni], half.b[li][ni])
+                                 for li, lin in enumerate(lins)])
+                per_half.append(nets)
+            self.layers.append(per_half)
+        self.inv_swap = torch.argsort(self.swap.long()).to(torch.int32)
+        # Adam's moments survive a re-pack (a load_state_dict between two steps) as long as the shapes do
+        for lay in self._all_layers():
+            old = self._moments.get(lay.name)
+            if old is not None and old[0].shape == lay.w.shape:
+                lay.m, lay.v, lay.bm, lay.bv = old
+        self.norm_moments = getattr(self, "norm_moments", None)
+        if self.norm_moments is None or self.norm_moments[0].device != dev:
+            n = len(self.blocks)
+            self.norm_moments = [torch.zeros(n, 4, self.C, device=dev)]   # per block: scale m, scale v, loc m, loc v
+
+    def _all_layers(self):
+        return [lay for blk in self.layers for half in blk for net in half for lay in net]
+
+    def _ensure_moments(self):
+        for lay in self._all_layers():
+            lay.moments()
+            self._moments[lay.name] = (lay.m, lay.v, lay.bm, lay.bv)
+
+    # ---- buffers
+    def _plan(self, rows: int) -> dict:
+        p = self._plans.get(("train", rows))
+        if p is not None:
+            return p
+        dev = self.blocks[0]["scale"].device
+        b_pad = _up(rows, 16)
+        n = len(self.blocks)
+        z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
+        halves = [h for blk in self.blocks for h in blk["halves"]]
+        h0 = halves[0]
+        n_lay = len(h0.dims)
+        p = dict(b_pad=b_pad, x_in=z(rows, self.C), x_out=z(rows, self.C), logdet=z(b_pad), noise=z(rows, self.C), scalars=z(4),
+                 s0=[z(b_pad, self.ld) for _ in range(n)], s1=[z(b_pad, self.ld) for _ in range(n)],
+                 # per block, half: one output buffer per MLP layer (the heads: raw slabs when the head layer splits K)
+                 y=[[[z(h.nets * b_pad * m * (h.head_split if li == n_lay - 1 else 1)) for li, (m, _) in enumerate(h.dims)]
+                     for h in blk["halves"]] for blk in self.blocks],
+                 dz=[[[z(h.nets * b_pad * m) for (m, _) in h.dims] for h in blk["halves"]] for blk in self.blocks],
+                 dzl=z(b_pad, self.ld), dld=z(b_pad), g0=[z(b_pad, self.ld) for _ in range(2)], g1=z(b_pad, self.ld),
+                 gfull=[z(b_pad, self.ld) for _ in range(n)], dx=z(rows, self.C))
+        # raw input-gradient slabs: S row ranges of W per launch, chosen so that a launch has >= 256 workgroups
+        p["S"] = [self._dx_split(m, k, h0.nets) for (m, k) in h0.dims]
+        p["raw"] = z(max(h0.nets * s * b_pad * k for s, (_, k) in zip(p["S"], h0.dims)))
+        p["raw_in"] = [z(h0.nets * p["S"][0] * b_pad * h0.dims[0][1]) for _ in range(2)]
+        self._plans[("train", rows)] = p
+        return p
+
+    @staticmethod
+    def _dx_split(m: int, k: int, nets: int) -> int:
+        s = 1
+        while (k // 64) * nets * s < 256 and m % (32 * s) == 0 and m // (2 * s) >= 64 and s < 16:
+            s *= 2
+        return s
+
+    # ---- forward, everything kept
+    def _issue_train_forward(self, rows: int, p: dict):
+        """As ``FlowEngine._issue_forward`` (models/flow/blocks.py:540-551, :296-309), into buffers that stay alive."""
+        n = len(self.blocks)
+        ld_acc = p["logdet"]
+        ld_acc.zero_()
+        self._step(rows, p["x_in"], self.C, p["s0"][0], self.ld, 0, scale=self.blocks[0]["scale"], loc=self.blocks[0]["loc"], logdet=ld_acc)
+        for i, blk in enumerate(self.blocks):
+            h0, h1 = blk["halves"]
+            part = h0.run(rows, p["s0"][i], self.ld, p["y"][i][0])
+            self._step(rows, p["s0"][i], self.ld, p["s1"][i], self.ld, 0, half=h0, st=part, map_=self.swap, logdet=ld_acc)
+            part = h1.run(rows, p["s1"][i], self.ld, p["y"][i][1])
+            last = i == n - 1
+            nxt = None if last else self.blocks[i + 1]
+            self._step(rows, p["s1"][i], self.ld, p["x_out"] if last else p["s0"][i + 1], self.C if last else self.ld, 0, half=h1, st=part,
+                       map_=blk["fwd"], scale=None if last else nxt["scale"], loc=None if last else nxt["loc"], on_src=0, logdet=ld_acc)
+
+    # ---- backward
+    def _coupling_bwd(self, rows, p, gbase, ld_g, gslabs, inv_map, scale, in_state, half, heads, gfull, gout, ld_out, dzh):
+        h0 = self.blocks[0]["halves"][0]
+        d = SeqCouplingBwdDesc(rows, self.C, self.c1, ld_g, self.ld, ld_out, self.ld, half.out_pad if half else self.C,
+                               half.head_split if half else 1, (h0.nets * p["S"][0]) if gslabs is not None else 0,
+                               h0.dims[0][1], self.c1)
+        _call("vunet_seq_coupling_bwd", ctypes.byref(d), _p(gbase), _p(gslabs), _p(inv_map), _p(scale), _p(in_state), _p(heads),
+              _p(half.b[-1][0] if half else None), _p(half.b[-1][1] if half else None), _p(p["dld"]), _p(gfull), _p(gout), _p(dzh),
+              _stream())
+
+    def _mlp_bwd(self, rows, p, half, ys, dzs, raw_in):
+        """The input-gradient chain of one coupling half: head -> first layer.  ``dzs[-1]`` holds the heads' dZ."""
+        b_pad = p["b_pad"]
+        for li in range(len(half.dims) - 1, -1, -1):
+            m_pad, k_pad = half.dims[li]
+            s = p["S"][li]
+            raw = raw_in if li == 0 else p["raw"]
+            d = SeqDxDesc(rows, m_pad, k_pad, half.nets, s)
+            _call("vunet_seq_dx", ctypes.byref(d), _p(half.w[li][0]), _p(half.w[li][1] if half.nets > 1 else None), _p(dzs[li]), _p(raw),
+                  _stream())
+            if li > 0:
+                _call("vunet_seq_dz_finish", _p(raw), _p(ys[li - 1]), _p(dzs[li - 1]), half.nets, s, b_pad, k_pad, LRELU_SLOPE, _stream())
+
+    def _dw_table(self, p: dict, grads: Optional[dict]) -> dict:
+        """The update sweep's descriptor table: per block (last first) and half (1, then 0) the eight layers of its two nets.
+        ``grads`` (write mode): name -> (g, bg) buffers."""
+        b_pad = p["b_pad"]
+        entries, ranges, tile = [], [], 0
+        for bi in reversed(range(len(self.blocks))):
+            for hi in (1, 0):
+                half = self.blocks[bi]["halves"][hi]
+                first = tile
+                for ni in range(half.nets):
+                    for li, (m_pad, k_pad) in enumerate(half.dims):
+                        lay = self.layers[bi][hi][ni][li]
+                        x = (p["s0"][bi] if hi == 0 else p["s1"][bi]) if li == 0 else p["y"][bi][hi][li - 1][ni * b_pad * k_pad:]
+                        dz = p["dz"][bi][hi][li][ni * b_pad * m_pad:]
+                        g, bg = grads[lay.name] if grads is not None else (None, None)
+                        entries.append(SeqDwLayer(_ptr(lay.w), _ptr(lay.m), _ptr(lay.v), _ptr(g), _ptr(lay.b), _ptr(lay.bm), _ptr(lay.bv),
+                                                  _ptr(bg), dz.data_ptr(), x.data_ptr(), m_pad, k_pad, m_pad,
+                                                  self.ld if li == 0 else k_pad, tile, k_pad // 64, lay.lin.weight.shape[1], 0))
+                        tile += (m_pad // 64) * (k_pad // 64)
+                ranges.append((first, tile - first))
+        return dict(table=_table(entries, self.blocks[0]["scale"].device), n=len(entries), ranges=ranges, tiles=tile)
+
+    def _norm_table(self, p: dict, grads: Optional[dict]) -> torch.Tensor:
+        entries = []
+        for bi, (blk, mod) in enumerate(zip(self.blocks, self.flow.sub_layers)):
+            mom = self.norm_moments[0][bi]
+            gs, gl = grads[f"sub_layers.{bi}.norm_layer"] if grads is not None else (None, None)
+            entries.append(SeqActnormLayer(_ptr(blk["scale"]), _ptr(blk["loc"]), _ptr(mom[0]), _ptr(mom[1]), _ptr(mom[2]), _ptr(mom[3]),
+                                           _ptr(gs), _ptr(gl), _ptr(p["gfull"][bi]), _ptr(p["s0"][bi]), self.ld, 0))
+        return _table(entries, self.blocks[0]["scale"].device)
+
+    def _issue_train_backward(self, rows: int, p: dict, gz: torch.Tensor, ld_gz: int, tables: dict, hp: Optional[SeqAdamHp]):
+        """``gz``: d loss / d z [rows.., ld_gz]; ``p['dld']``: d loss / d logdet.  Per block, last first: the step that ends the
+        block (coupling half 1 + shuffle + the next block's ActNorm), its MLP chain, the update of that half's eight layers;
+        the same for half 0; finally block 0's ActNorm and the ActNorm gradients of all blocks."""
+        n = len(self.blocks)
+        hpp = ctypes.byref(hp) if hp is not None else None
+        dw = tables["dw"]
+        gbase, ld_g, gsl = gz, ld_gz, None
+        rng = iter(dw["ranges"])
+        for i in reversed(range(n)):
+            blk = self.blocks[i]
+            h0, h1 = blk["halves"]
+            last = i == n - 1
+            nxt = None if last else self.blocks[i + 1]
+            # half 1: out[c] = A_next(v[fwd[c]]), v = couple_1(S1_i)
+            self._coupling_bwd(rows, p, gbase, ld_g, gsl, blk["bwd"], None if last else nxt["scale"], p["s1"][i], h1, p["y"][i][1][-1],
+                               None if last else p["gfull"][i + 1], p["g1"], self.ld, p["dz"][i][1][-1])
+            self._mlp_bwd(rows, p, h1, p["y"][i][1], p["dz"][i][1], p["raw_in"][1])
+            first, cnt = next(rng)
+            _call("vunet_seq_dw", _p(dw["table"]), dw["n"], first, cnt, rows, hpp, _stream())
+            # half 0: out[c] = v[swap[c]], v = couple_0(S0_i)
+            g0 = p["g0"][i % 2]
+            self._coupling_bwd(rows, p, p["g1"], self.ld, p["raw_in"][1], self.inv_swap, None, p["s0"][i], h0, p["y"][i][0][-1], None, g0,
+                               self.ld, p["dz"][i][0][-1])
+            self._mlp_bwd(rows, p, h0, p["y"][i][0], p["dz"][i][0], p["raw_in"][0])
+            first, cnt = next(rng)
+            _call("vunet_seq_dw", _p(dw["table"]), dw["n"], first, cnt, rows, hpp, _stream())
+            gbase, ld_g, gsl = g0, self.ld, p["raw_in"][0]
+        # the first step of the pass: S0_0 = A_0(x)
+        self._coupling_bwd(rows, p, gbase, ld_g, gsl, None, self.blocks[0]["scale"], None, None, None, p["gfull"][0], p["dx"], self.C, None)
+        _call("vunet_seq_actnorm_bwd", _p(tables["norm"]), n, self.C, rows, _p(p["dld"]), hpp, _stream())
+
+    def _write_back(self):
+        for lay in self._all_layers():
+            lay.write_back()
+
+    # ---- the fused step
+    def _initialise_actnorm(self, x2: torch.Tensor):
+        """ActNorm's data-dependent initialisation happens on the first forward call of a fresh flow (lib/modules.py:303-305)."""
+        if self._initialised():
+            return
+        if not 2 <= x2.shape[0] <= 64:
+            raise ValueError("ActNorm's data-dependent initialisation needs one batch of 2..64 rows")
+        p = FlowEngine._plan(self, x2.shape[0])
+        p["x_in"].copy_(x2)
+        self._issue_forward_init(x2.shape[0], p)
+        self._all_init = True
+
+    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+        _need_device(x)
+        _lib.lib()
+        self._pack()
+        x2 = x.reshape(x.shape[0], -1)
+        if x2.shape[1] != self.C:
+            raise ValueError(f"flow over {self.C} channels got {tuple(x.shape)}")
+        if not 1 <= x2.shape[0] <= 64:
+            raise ValueError(f"the flow's training step takes one batch of 1..64 rows (config/behavior_net.yaml: 64), got {x2.shape[0]}")
+        for t in list(self.flow.parameters()) + list(self.flow.buffers()):
+            if t.device != x.device:
+                raise RuntimeError(f"flow on {t.device}, input on {x.device}")
+        return x2
+
+    def train_step(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One optimisation step on the batch ``x`` [B, C]: -> device tensor [4] = (flow_loss, reference_nll_loss, nlogdet_loss,
+        nll_loss), the entries of ``FlowLoss``'s log (lib/losses.py:310-315).  ``noise``: the draw behind the logged
+        ``reference_nll_loss`` (None: ``torch.randn``, as :309 does)."""
+        x2 = self._check_input(x.detach())
+        rows = x2.shape[0]
+        self._initialise_actnorm(x2)
+        self._ensure_moments()
+        p = self._plan(rows)
+        p["x_in"].copy_(x2)
+        if noise is None:
+            torch.randn(p["noise"].shape, out=p["noise"])
+        else:
+            p["noise"].copy_(noise.reshape(rows, self.C))
+        if "tables" not in p:
+            p["tables"] = dict(dw=self._dw_table(p, None), norm=self._norm_table(p, None))
+
+        def issue():
+            self.adam.tick()
+            self._issue_train_forward(rows, p)
+            _call("vunet_seq_flow_loss", _p(p["x_out"]), self.C, _p(p["logdet"]), _p(p["noise"]), rows, self.C, _p(p["scalars"]),
+                  _p(p["dzl"]), self.ld, _p(p["dld"]), _stream())
+            self._issue_train_backward(rows, p, p["dzl"], self.ld, p["tables"], self.adam.hp)
+            self._write_back()
+        self.graph.run_step(("train", rows), issue)
+        return p["scalars"]
+
+    # ---- autograd's view of the same kernels
+    def train_forward(self, x: torch.Tensor):
+        x2 = self._check_input(x.detach())
+        rows = x2.shape[0]
+        self._initialise_actnorm(x2)
+        p = self._plan(rows)
+        p["x_in"].copy_(x2)
+        self._issue_train_forward(rows, p)
+        self._generation += 1
+        return p["x_out"].clone(), p["logdet"][:rows].clone(), (rows, self._generation)
+
+    def train_backward(self, token, gz: Optional[torch.Tensor], gld: Optional[torch.Tensor]):
+        """-> (dx [B, C], {parameter name: gradient}) for the forward pass ``token`` came from."""
+        rows, gen = token
+        if gen != self._generation:
+            raise RuntimeError("the flow was run again before this pass's backward: its saved activations are gone "
+                               "(one forward / backward pair at a time)")
+        p = self._plan(rows)
+        dev = p["x_in"].device
+        p["dzl"].zero_()
+        if gz is not None:
+            p["dzl"][:rows, :self.C].copy_(gz.reshape(rows, self.C))
+        p["dld"].zero_()
+        if gld is not None:
+            p["dld"][:rows].copy_(gld.reshape(rows))
+        grads = {lay.name: (torch.empty_like(lay.w), torch.empty_like(lay.b)) for lay in self._all_layers()}
+        for bi in range(len(self.blocks)):
+            grads[f"sub_layers.{bi}.norm_layer"] = (torch.empty(self.C, device=dev), torch.empty(self.C, device=dev))
+        tables = dict(dw=self._dw_table(p, grads), norm=self._norm_table(p, grads))
+        self._issue_train_backward(rows, p, p["dzl"], self.ld, tables, None)
+        out = {}
+        for lay in self._all_layers():
+            g, bg = grads[lay.name]
+            m, k = lay.lin.weight.shape
+            out[lay.name + ".weight"] = g if g.shape == (m, k) else g[:m, :k].contiguous()
+            out[lay.name + ".bias"] = bg if bg.numel() == m else bg[:m].contiguous()
+        for bi in range(len(self.blocks)):
+            gs, gl = grads[f"sub_layers.{bi}.norm_layer"]
+            out[f"sub_layers.{bi}.norm_layer.scale"] = gs.reshape(1, self.C, 1, 1)
+            out[f"sub_layers.{bi}.norm_layer.loc"] = gl.reshape(1, self.C, 1, 1)
+        self._generation += 1      # the activations are spent
+        return p["dx"].clone(), out
+
+    # ---- torch.optim.Adam's state layout (checkpoints: experiments/behavior_net.py:392-393, :1003-1011)
+    def optimizer_state_dict(self) -> dict:
+        self._pack()
+        self._ensure_moments()
+        step = torch.tensor(float(self.adam.step))
+        state, names = {}, [n for n, _ in self.flow.named_parameters()]
+        by_name = {}
+        for lay in self._all_layers():
+            m, k = lay.lin.weight.shape
+            by_name[lay.name + ".weight"] = (lay.m[:m, :k], lay.v[:m, :k])
+            by_name[lay.name + ".bias"] = (lay.bm[:m], lay.bv[:m])
+        for bi in range(len(self.blocks)):
+            mom = self.norm_moments[0][bi]
+            by_name[f"sub_layers.{bi}.norm_layer.scale"] = (mom[0].reshape(1, -1, 1, 1), mom[1].reshape(1, -1, 1, 1))
+            by_name[f"sub_layers.{bi}.norm_layer.loc"] = (mom[2].reshape(1, -1, 1, 1), mom[3].reshape(1, -1, 1, 1))
+        for idx, n in enumerate(names):
+            m, v = by_name[n]
+            state[idx] = {"step": step.clone(), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        a = self.adam
+        group = {"lr": a.lr, "betas": a.betas, "eps": a.eps, "weight_decay": a.weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "name": "latent_flow",
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict):
+        self._pack()
+        self._ensure_moments()
+        names = [n for n, _ in self.flow.named_parameters()]
+        group = sd["param_groups"][0]
+        a = self.adam
+        a.set_lr(group["lr"])
+        a.betas, a.eps, a.weight_decay = tuple(float(b) for b in group["betas"]), float(group["eps"]), float(group["weight_decay"])
+        a.hp.beta1, a.hp.beta2, a.hp.eps, a.hp.weight_decay = a.betas[0], a.betas[1], a.eps, a.weight_decay
+        lay_by = {lay.name: lay for lay in self._all_layers()}
+        step = 0
+        for idx, n in enumerate(names):
+            st = sd["state"].get(idx)
+            if st is None:
+                continue
+            step = int(st["step"])
+            m, v = st["exp_avg"].to(a.lr_dev.device), st["exp_avg_sq"].to(a.lr_dev.device)
+            base, leaf = n.rsplit(".", 1)
+            if base in lay_by:
+                lay = lay_by[base]
+                if leaf == "weight":
+                    lay.m[:m.shape[0], :m.shape[1]].copy_(m)
+                    lay.v[:v.shape[0], :v.shape[1]].copy_(v)
+                else:
+                    lay.bm[:m.numel()].copy_(m)
+                    lay.bv[:v.numel()].copy_(v)
+            else:
+                bi = int(n.split(".")[1])
+                o = 0 if leaf == "scale" else 2
+                self.norm_moments[0][bi][o].copy_(m.reshape(-1))
+                self.norm_moments[0][bi][o + 1].copy_(v.reshape(-1))
+        a.step_dev.fill_(step)
+        self.graph.graphs.clear()   # the hyper-parameters are launch arguments of the recorded step
+
+
+class _FlowFn(torch.autograd.Function):
+    """``UnconditionalFlow2.forward(x)`` -> (z, logdet) as one autograd node whose backward is ``FlowTrainEngine.train_backward``:
+    what ``f_loss.backward()`` (experiments/behavior_net.py:710) reaches when the reference's own loop drives these modules."""
+
+    @staticmethod
+    def forward(ctx, engine, names, x, *params):
+        z, logdet, token = engine.train_forward(x)
+        ctx.engine, ctx.names, ctx.token, ctx.x_shape = engine, names, token, x.shape
+        return z, logdet
+
+    @staticmethod
+    def backward(ctx, gz, gld):
+        dx, grads = ctx.engine.train_backward(ctx.token, gz, gld)
+        out = [None, None, dx.reshape(ctx.x_shape) if ctx.needs_input_grad[2] else None]
+        for i, n in enumerate(ctx.names):
+            out.append(grads[n] if ctx.needs_input_grad[3 + i] else None)
+        return tuple(out)
+
+
+def flow_autograd(engine: FlowTrainEngine, x: torch.Tensor):
+    """(z [B, C], logdet [B]) with a graph: the forward of the flow for a loop that calls ``backward()`` itself."""
+    named = list(engine.flow.named_parameters())
+    return _FlowFn.apply(engine, [n for n, _ in named], x, *[p for _, p in named])

@@ -1,0 +1,120 @@
+/*
+ * vunet_seq_train.h -- C ABI of the TRAINING half of the behaviour path (BASELINE config 4): the normalizing flow's
+ * maximum-likelihood step and the behaviour cVAE's step, csrc/seq_train.hip.  Part of libvunet_hip.so; same conventions as
+ * vunet_hip.h (plain pointers and sizes, caller-owned fp32 device buffers, `stream` = hipStream_t as void*, 0 or a negative
+ * VUNET_ERR_* code).
+ *
+ * What it replaces in the reference (CompVis/behavior-driven-video-synthesis, paths relative to the upstream root):
+ *   experiments/behavior_net.py:703-714   gauss, logdet = latent_flow(bs.detach()); f_loss = flow_loss(gauss, logdet);
+ *                                         flow_optimizer.zero_grad(); f_loss.backward(); flow_optimizer.step()
+ *   experiments/behavior_net.py:384-395   Adam(latent_flow.parameters(), lr = flow_lr * batch_size, betas = (0.5, 0.9), weight_decay)
+ *   lib/losses.py:294-331                 FlowLoss / nll
+ *   experiments/behavior_net.py:591-660   the cVAE step: net(seq, seq, len) -> recon (MSE) + gamma * kl_loss -> backward -> Adam
+ *   lib/losses.py:283-291                 kl_loss
+ * i.e. what autograd derives for models/flow/blocks.py:95-128, :276-319, :531-559, :692-704, lib/modules.py:236-331 and
+ * models/pose_behavior_rnn.py:125-209, :463-534, :574-626, plus torch.optim.Adam's update.
+ *
+ * Layout of a flow training step (B <= 64 rows, Bp = B rounded up to 16; all matrices row-major fp32):
+ *   forward     vunet_seq_linear / vunet_seq_coupling (vunet_hip.h) into per-layer buffers that stay alive (the saved activations)
+ *   loss        vunet_seq_flow_loss          nll + (-logdet) means, d loss / d z, d loss / d logdet
+ *   backward    vunet_seq_coupling_bwd       everything between two MLP evaluations, backwards: the incoming gradient (+ the raw
+ *                                            input-gradient slabs of the MLP evaluated after it), un-shuffle, ActNorm, affine
+ *                                            coupling -> gradient wrt the step's input rows and the head layers' dZ
+ *               vunet_seq_dx                 dX = dZ . W of one MLP layer (both nets of a coupling in one launch) as RAW partial
+ *                                            slabs over S row ranges of W -- a workgroup owns a 64-column stripe of W over M / S rows
+ *               vunet_seq_dz_finish          dZ_prev = (sum of the slabs) * LeakyReLU'(Y_prev)
+ *   update      vunet_seq_dw                 dW = dZ^T . X per 64 x 64 tile of W on the fp32 matrix cores, and -- in the same
+ *                                            tile, while it is in registers -- torch.optim.Adam's update of W, exp_avg,
+ *                                            exp_avg_sq (or, hp == NULL, the gradient written out for autograd); bias likewise
+ *               vunet_seq_actnorm_bwd        ActNorm's loc / scale gradients (a column reduction over the batch) + Adam
+ *               vunet_seq_adam_tick          ++step (device-resident, so a captured hipGraph replays the step unchanged)
+ */
+#ifndef VUNET_SEQ_TRAIN_H
+#define VUNET_SEQ_TRAIN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* torch.optim.Adam's hyper-parameters; the learning rate and the step count live in DEVICE memory (nothing that changes
+ * between steps is a launch argument).  The update follows torch/optim/adam.py (_single_tensor_adam, amsgrad False,
+ * maximize False): g += weight_decay * p; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g g;
+ * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps). */
+typedef struct vunet_seq_adam_hp {
+  const double* lr_dev;
+  const int64_t* step_dev;   /* t of the update being applied (>= 1) */
+  float beta1, beta2, eps, weight_decay;
+} vunet_seq_adam_hp;
+
+/* dX = dZ . W: w_n [M][K] (nets <= 2), dz [nets][Bp][M], raw [nets][S][Bp][K].  K % 64 == 0, M % (16 S) == 0, B <= 64. */
+typedef struct vunet_seq_dx_desc {
+  int32_t B, M, K, nets, S;
+} vunet_seq_dx_desc;
+int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw, void* stream);
+
+/* dz[n][b][k] = (sum_s raw[n][s][b][k]) * (y[n][b][k] > 0 ? 1 : slope): the derivative of nn.LeakyReLU (lib/modules.py:244)
+ * read off the saved OUTPUT (slope > 0 keeps the sign).  All Bp rows. */
+int vunet_seq_dz_finish(const float* raw, const float* y, float* dz, int32_t nets, int32_t S, int32_t Bp, int32_t K, float slope,
+                        void* stream);
+
+/* One step of the flow backwards (the mirror of vunet_seq_coupling, forward direction).  The forward step was
+ *   v = couple(in);  out[c] = A(v[map[c]])   with couple = x_k exp(s) + t on columns >= c1, A = ActNorm of the NEXT block.
+ * g[c]      = gbase[b][c] + (c < c1s ? sum over n_sl slabs gslabs[n][b][c] : 0)      the gradient wrt out (complete)
+ * gfull     (optional) receives g: the ActNorm gradient kernel's input
+ * dv[j]     = g[inv_map[j]] * scale[inv_map[j]]
+ * gout[b][j] = dv[j] (j < c1)  |  dv[j] exp(s)  (j >= c1)
+ * dzh       [2][Bp][Mp]: the head layers' dZ -- scale net: (dv x_k exp(s) + dld[b]) (1 - s^2), translation net: dv
+ * st / bias_s / bias_t / S / Mp as vunet_seq_coupling took them in the forward pass (st == NULL: no coupling in this step). */
+typedef struct vunet_seq_coupling_bwd_desc {
+  int32_t B, C, c1, ld_g, ld_in, ld_out, ld_full, Mp, S, n_sl, ld_sl, c1s;
+} vunet_seq_coupling_bwd_desc;
+int vunet_seq_coupling_bwd(const vunet_seq_coupling_bwd_desc* d, const float* gbase, const float* gslabs, const int32_t* inv_map,
+                           const float* scale, const float* in, const float* st, const float* bias_s, const float* bias_t,
+                           const float* dld, float* gfull, float* gout, float* dzh, void* stream);
+
+/* One Linear layer of the update sweep.  A launch covers a list of layers: `tile0` is the layer's first 64 x 64 tile in the
+ * launch's flat tile list, `tiles_k` = K / 64.  M % 64 == 0, K % 64 == 0 (zero-padded images; a parameter whose shape fits is
+ * used in place).  g / bg: gradient outputs of the write mode (hp == NULL); m, v / bm, bv: Adam's moments. */
+typedef struct vunet_seq_dw_layer {
+  float* w; float* m; float* v; float* g;
+  float* bias; float* bm; float* bv; float* bg;
+  const float* dz;   /* [Bp][ldz]: gradient wrt the layer's pre-activation output; rows >= B are zero */
+  const float* x;    /* [Bp][ldx]: the layer's input rows */
+  int32_t M, K, ldz, ldx, tile0, tiles_k;
+  int32_t kv;        /* valid columns: the gradient of columns >= kv is forced to zero (an MLP's first layer reads its input from
+                        rows that continue with other data beyond its c1 columns; its padding columns must stay zero) */
+  int32_t pad;
+} vunet_seq_dw_layer;
+int vunet_seq_dw(const vunet_seq_dw_layer* table_dev, int32_t n_layers, int32_t first_tile, int32_t n_tiles, int32_t B,
+                 const vunet_seq_adam_hp* hp, void* stream);
+
+/* ActNorm (lib/modules.py:260-331) of every block in one launch: out = scale (u + loc), logdet += sum log|scale|.
+ * d scale[c] = (sum_b gfull[b][c] out[b][c] + sum_b dld[b]) / scale[c];  d loc[c] = scale[c] sum_b gfull[b][c]. */
+typedef struct vunet_seq_actnorm_layer {
+  float* scale; float* loc;
+  float* sm; float* sv; float* lm; float* lv;   /* Adam moments of scale / loc */
+  float* gs; float* gl;                         /* write mode: gradients */
+  const float* gfull; const float* out;         /* [B][ld] */
+  int32_t ld, pad;
+} vunet_seq_actnorm_layer;
+int vunet_seq_actnorm_bwd(const vunet_seq_actnorm_layer* table_dev, int32_t n_layers, int32_t C, int32_t B, const float* dld,
+                          const vunet_seq_adam_hp* hp, void* stream);
+
+/* FlowLoss (lib/losses.py:294-317): nll = mean_b 0.5 sum_c z^2, nlogdet = -mean_b logdet, loss = nll + nlogdet,
+ * reference_nll = mean_b 0.5 sum_c noise^2 (noise NULL: 0).  scalars[4] = loss, reference_nll, nlogdet, nll.
+ * dz[b][c] = z[b][c] / B (rows B..Bp zeroed), dld[b] = -1 / B. */
+int vunet_seq_flow_loss(const float* z, int32_t ldz, const float* logdet, const float* noise, int32_t B, int32_t C, float* scalars,
+                        float* dz, int32_t ld_dz, float* dld, void* stream);
+
+int vunet_seq_adam_tick(int64_t* step_dev, void* stream);
+
+/* dst[m][k] = src[(row_off + row_mul m) ld_src + col_off + k] (the inverse of vunet_seq_pack_rows; `accumulate`: +=) */
+int vunet_seq_unpack_rows(const float* src, int32_t ld_src, int32_t col_off, int32_t row_off, int32_t row_mul, float* dst, int32_t M,
+                          int32_t K, int32_t accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

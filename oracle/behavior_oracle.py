@@ -12,7 +12,12 @@ A functional (state-dict driven) restatement in plain PyTorch-CPU fp32 of
 * ``ResidualBehaviorNet``: ``BEncoder`` (one-layer LSTM over the sequence + the two 1x1 ``NormConv2d`` heads),
   ``ResidualRNNDecoder`` (LSTM cell + ``n_out`` + residual) and ``generate_seq``
   (models/pose_behavior_rnn.py:125-209, :463-534, :538-626).  The decoder's ``rnn_type="gru"`` branch is not
-  restated: the reference defines ``n_out`` only inside the LSTM branch (:473-478), so its GRU decoder cannot run.
+  restated: the reference defines ``n_out`` only inside the LSTM branch (:473-478), so its GRU decoder cannot run;
+* the flow stage of BASELINE config 4's training loop: ``FlowLoss`` (lib/losses.py:294-331), ActNorm's data-dependent
+  initialisation (lib/modules.py:270-290, :303-305) and the step ``latent_flow(bs.detach())`` -> ``flow_loss`` ->
+  ``zero_grad`` / ``backward`` / ``step`` (experiments/behavior_net.py:703-714) with the optimiser of :384-395.  Gradients
+  come from torch.autograd over the functions of this file and the update from ``torch.optim.Adam`` -- the third-party
+  pieces the reference itself uses for them.  Pinned by ``tests/golden/g10_flow_training.npz``.
 
 Every function cites the reference lines it follows (paths relative to the upstream repository root) and takes a
 flat ``sd`` mapping with the reference's state-dict key names, so the product modules' ``state_dict()`` can be fed
@@ -68,6 +73,16 @@ def actnorm_reverse(sd: SD, p: str, y: Tensor) -> Tensor:
     return y / sd[f"{p}.scale"].reshape(1, -1) - sd[f"{p}.loc"].reshape(1, -1)
 
 
+def actnorm_initialize(sd: SD, p: str, x: Tensor) -> None:
+    """loc = -mean, scale = 1 / (std + 1e-6) per channel over the batch (unbiased std); marks the layer initialised
+    (lib/modules.py:270-290, :303-305).  In place on ``sd`` (the values, not the autograd graph)."""
+    with torch.no_grad():
+        mean, std = x.mean(dim=0), x.std(dim=0)
+        sd[f"{p}.loc"].copy_((-mean).reshape(sd[f"{p}.loc"].shape))
+        sd[f"{p}.scale"].copy_((1.0 / (std + 1e-6)).reshape(sd[f"{p}.scale"].shape))
+        sd[f"{p}.initialized"] = torch.tensor(1, dtype=torch.uint8)
+
+
 # --------------------------------------------------------------------------
 # DoubleVectorCouplingBlock2 -- models/flow/blocks.py:276-319
 # --------------------------------------------------------------------------
@@ -111,10 +126,14 @@ def flow_n_blocks(sd: SD, p: str = "flow") -> int:
 
 
 def flow_forward(sd: SD, x: Tensor, p: str = "flow") -> Tuple[Tensor, Tensor]:
-    """x [B, C] -> (z [B, C], logdet [B]); ActNorm, coupling, shuffle per block   (models/flow/blocks.py:111-121, :540-551)."""
+    """x [B, C] -> (z [B, C], logdet [B]); ActNorm, coupling, shuffle per block   (models/flow/blocks.py:111-121, :540-551).
+    An ActNorm whose ``initialized`` flag is 0 takes its statistics from the batch as it reaches the layer (lib/modules.py:303-305)."""
     logdet = torch.zeros(x.shape[0])
     for i in range(flow_n_blocks(sd, p)):
         q = f"{p}.sub_layers.{i}"
+        flag = sd.get(f"{q}.norm_layer.initialized")
+        if flag is not None and int(flag) == 0:
+            actnorm_initialize(sd, f"{q}.norm_layer", x.detach())
         x, ld = actnorm_forward(sd, f"{q}.norm_layer", x)
         logdet = logdet + ld
         x, ld = coupling_forward(sd, f"{q}.coupling", x)
@@ -132,6 +151,55 @@ def flow_reverse(sd: SD, z: Tensor, p: str = "flow") -> Tensor:
         x = coupling_reverse(sd, f"{q}.coupling", x)
         x = actnorm_reverse(sd, f"{q}.norm_layer", x)
     return x
+
+
+# --------------------------------------------------------------------------
+# FlowLoss + the flow stage's optimisation step -- lib/losses.py:294-331, experiments/behavior_net.py:384-395, :703-714
+# --------------------------------------------------------------------------
+def flow_loss(z: Tensor, logdet: Tensor, noise: Optional[Tensor] = None):
+    """``FlowLoss.forward`` on flat z [B, C]: nll = 0.5 sum z^2 per row (lib/losses.py:330-331; the reference sums over
+    [1, 2, 3] of [B, C, 1, 1]), loss = mean(nll) - mean(logdet); ``reference_nll_loss`` is the same nll of a standard-normal
+    draw (``noise``; logged only).  -> (loss, log)."""
+    nll_loss = torch.mean(0.5 * torch.sum(torch.pow(z, 2), dim=1))
+    assert logdet.dim() == 1
+    nlogdet_loss = -torch.mean(logdet)
+    loss = nll_loss + nlogdet_loss
+    log = {"flow_loss": float(loss.detach()), "nlogdet_loss": float(nlogdet_loss.detach()), "nll_loss": float(nll_loss.detach())}
+    if noise is not None:
+        log["reference_nll_loss"] = float(torch.mean(0.5 * torch.sum(torch.pow(noise, 2), dim=1)))
+    return loss, log
+
+
+def flow_parameters(sd: SD, p: str = "flow") -> List[str]:
+    """The flow's trainable tensors in ``nn.Module.named_parameters()`` order (per block: ActNorm loc, scale; the s nets'
+    then the t nets' Linear weight / bias) -- the order ``torch.optim.Adam``'s state dict indexes them by."""
+    names = []
+    for i in range(flow_n_blocks(sd, p)):
+        q = f"{p}.sub_layers.{i}"
+        names += [f"{q}.norm_layer.loc", f"{q}.norm_layer.scale"]
+        for kind in ("s", "t"):
+            for j in range(2):
+                for li in range(fully_connected_depth(sd, f"{q}.coupling.{kind}.{j}") + 2):
+                    names += [f"{q}.coupling.{kind}.{j}.main.{2 * li}.weight", f"{q}.coupling.{kind}.{j}.main.{2 * li}.bias"]
+    return names
+
+
+def flow_optimizer(sd: SD, lr: float, weight_decay: float = 0.0, betas=(0.5, 0.9), p: str = "flow"):
+    """``Adam(params=[{"params": latent_flow.parameters(), "name": "latent_flow"}], lr=flow_lr * batch_size, betas=(0.5, 0.9),
+    weight_decay=...)`` (experiments/behavior_net.py:384-392) over the leaves of ``sd`` (made to require grad)."""
+    params = [sd[n].requires_grad_(True) for n in flow_parameters(sd, p)]
+    return torch.optim.Adam(params=[{"params": params, "name": "latent_flow"}], lr=lr, betas=betas, weight_decay=weight_decay)
+
+
+def flow_train_step(sd: SD, opt, bs: Tensor, noise: Optional[Tensor] = None, p: str = "flow") -> Dict[str, float]:
+    """experiments/behavior_net.py:703-714: ``gauss, logdet = latent_flow(bs.detach())``; ``flow_loss``; ``zero_grad``;
+    ``backward``; ``step``.  -> the step's log."""
+    z, logdet = flow_forward(sd, bs.detach(), p)
+    loss, log = flow_loss(z, logdet, noise)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return log
 
 
 # --------------------------------------------------------------------------

@@ -779,6 +779,72 @@ def g9_behavior():
     save("g9_behavior", meta, arrays)
 
 
+def g10_flow_training():
+    """BASELINE config 4, flow stage (experiments/behavior_net.py:384-395, :703-714): the reference's own
+    ``UnsupervisedTransformer2`` + ``FlowLoss`` (lib/losses.py:294-317) + ``torch.optim.Adam(betas=(0.5, 0.9), weight_decay)``
+    driven for K = 3 steps exactly as ``train_fn`` drives them -- ``gauss, logdet = latent_flow(bs)``; ``flow_loss``;
+    ``zero_grad``; ``backward``; ``step`` -- at small sizes: an even channel count with ActNorm's data-dependent
+    initialisation happening inside step 1 (a fresh flow, as the reference trains it), and an odd one, pre-initialised, with
+    weight decay.  Stored: the permutations, every step's log, the parameters and two moments after the last step."""
+    from models.flow import simple_flow as rf
+    seed = 101
+    arrays, meta = {}, {"seed": seed, "steps": 3, "cases": {}}
+    cases = {"even": dict(chan=32, mid=64, depth=2, n_flows=3, bsz=16, lr=3e-4, wd=0.0, fresh=True),
+             "odd": dict(chan=33, mid=48, depth=1, n_flows=2, bsz=4, lr=3e-4, wd=1e-2, fresh=False)}
+    for tag, c in cases.items():
+        torch.manual_seed(seed)
+        flow = rf.UnsupervisedTransformer2(flow_in_channels=c["chan"], flow_mid_channels=c["mid"], flow_hidden_depth=c["depth"],
+                                           n_flows=c["n_flows"])
+        sd = behavior_state(flow, seed)
+        if c["fresh"]:    # ActNorm as a fresh flow has it: loc 0, scale 1, not initialised (lib/modules.py:264-268)
+            for k in list(sd):
+                leaf = k.rsplit(".", 1)[-1]
+                if leaf == "initialized":
+                    sd[k] = torch.tensor(0, dtype=torch.uint8)
+                elif leaf == "loc":
+                    sd[k] = torch.zeros_like(sd[k])
+                elif leaf == "scale" and ".norm_layer." in k:
+                    sd[k] = torch.ones_like(sd[k])
+            flow.load_state_dict(sd)
+        flow.train()
+        opt = torch.optim.Adam(params=[{"params": flow.parameters(), "name": "latent_flow"}], lr=c["lr"], betas=(0.5, 0.9),
+                               weight_decay=c["wd"])
+        loss_fn = rl.FlowLoss()
+        logs = []
+        for it in range(meta["steps"]):
+            bs = 0.8 * seeded_randn(f"flowtrain.{tag}.b{it}", (c["bsz"], c["chan"]), seed) + 0.3
+            with FixedNoise(f"flowtrain.{tag}.s{it}", seed):
+                gauss, logdet = flow(bs.detach())
+                f_loss, log = loss_fn(gauss, logdet)
+            opt.zero_grad()
+            f_loss.backward()
+            opt.step()
+            logs.append({k: float(v) for k, v in log.items()})
+        names = [n for n, _ in flow.named_parameters()]
+        fin = flow.state_dict()
+        meta["cases"][tag] = {"kw": dict(flow_in_channels=c["chan"], flow_mid_channels=c["mid"], flow_hidden_depth=c["depth"],
+                                         n_flows=c["n_flows"]), "batch": c["bsz"], "lr": c["lr"], "weight_decay": c["wd"],
+                              "fresh": c["fresh"], "logs": logs, "shapes": {k: list(v.shape) for k, v in sd.items()},
+                              "checksums": {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in fin.items()
+                                            if v.dtype.is_floating_point}}
+        for k, v in sd.items():
+            if k.endswith("_shuffle_idx"):
+                arrays[f"{tag}.sd.{k}"] = v.numpy()
+        keep = [n for n in names if ".norm_layer." in n or n.endswith(".bias")
+                or n.startswith("flow.sub_layers.0.coupling.s.0.") or n.startswith(f"flow.sub_layers.{c['n_flows'] - 1}.coupling.t.1.")]
+        if tag == "odd":
+            keep = names
+        for n in keep:
+            arrays[f"{tag}.final.{n}"] = fin[n].numpy()
+        st = opt.state_dict()["state"]
+        for n in (f"flow.sub_layers.0.coupling.s.0.main.0.weight", f"flow.sub_layers.{c['n_flows'] - 1}.norm_layer.scale"):
+            idx = names.index(n)
+            arrays[f"{tag}.exp_avg.{n}"] = st[idx]["exp_avg"].numpy()
+            arrays[f"{tag}.exp_avg_sq.{n}"] = st[idx]["exp_avg_sq"].numpy()
+        meta["cases"][tag]["adam_step"] = int(st[0]["step"])
+    save("g10_flow_training", meta, arrays)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -800,3 +866,4 @@ if __name__ == "__main__":
     g1c_l2norm_init()
     g8_pretrained_dir()
     g9_behavior()
+    g10_flow_training()

@@ -436,3 +436,49 @@ def test_g9_behavior_net(tag):
     xs, _, b, *_ = B.behavior_net_forward(sd, x1, x2, length, start_frame=0, sample_noise=noise)
     close(b, arr[f"net_{tag}.b_prior"])
     close(xs, arr[f"net_{tag}.xs_prior"])
+
+
+# ---------------------------------------------------------------- G10 flow stage of config 4 (training)
+def _g10_state(info, arr, tag, seed):
+    sd = _behavior_sd(info, arr, tag, seed)
+    if info["fresh"]:   # a fresh flow: ActNorm not yet initialised (loc 0, scale 1)
+        for k in list(sd):
+            leaf = k.rsplit(".", 1)[-1]
+            if leaf == "initialized":
+                sd[k] = torch.tensor(0, dtype=torch.uint8)
+            elif leaf == "loc":
+                sd[k] = torch.zeros_like(sd[k])
+            elif leaf == "scale" and ".norm_layer." in k:
+                sd[k] = torch.ones_like(sd[k])
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["even", "odd"])
+def test_g10_flow_training_trajectory(tag):
+    """Three optimisation steps of the flow stage (experiments/behavior_net.py:703-714) vs the reference's own modules +
+    FlowLoss + torch.optim.Adam: every step's log, the parameters and Adam moments afterwards."""
+    from oracle import behavior_oracle as B
+    meta, arr = load_golden("g10_flow_training")
+    seed, info = meta["seed"], meta["cases"][tag]
+    sd = _g10_state(info, arr, tag, seed)
+    chan, bsz = info["kw"]["flow_in_channels"], info["batch"]
+    opt = B.flow_optimizer(sd, info["lr"], info["weight_decay"])
+    for it in range(meta["steps"]):
+        bs = 0.8 * seeded_randn(f"flowtrain.{tag}.b{it}", (bsz, chan), seed) + 0.3
+        noise = seeded_randn(f"flowtrain.{tag}.s{it}.eps0", (bsz, chan, 1, 1), seed).reshape(bsz, chan)
+        log = B.flow_train_step(sd, opt, bs, noise)
+        for k, v in info["logs"][it].items():
+            assert abs(log[k] - v) <= 1e-4 * abs(v) + 1e-4, (it, k, log[k], v)
+    for k, v in arr.items():
+        if k.startswith(f"{tag}.final."):
+            close(sd[k[len(tag) + 7:]].detach(), v, rtol=1e-4, atol=1e-6)
+    for k, (s, a) in info["checksums"].items():
+        assert abs(float(sd[k].detach().double().abs().sum()) - a) <= 1e-5 * a + 1e-6, k
+    names = B.flow_parameters(sd)
+    st = opt.state_dict()["state"]
+    assert int(st[0]["step"]) == info["adam_step"]
+    for k, v in arr.items():
+        for kind in ("exp_avg", "exp_avg_sq"):
+            if k.startswith(f"{tag}.{kind}."):
+                # (gradient-sized entries; small ones carry the fp32 summation-order noise of the large ones)
+                close(st[names.index(k[len(tag) + len(kind) + 2:])][kind], v, rtol=1e-4, atol=1e-5 * float(np.abs(v).max()))
