@@ -127,8 +127,19 @@ __global__ __launch_bounds__(256) void seq_coupling_bwd_kernel(SeqCouplingBwdArg
   if (j >= a.C) return;
   const int c = a.inv_map ? a.inv_map[j] : j;
   float g = a.gbase[(size_t)b * a.ld_g + c];
-  if (a.gslabs && c < a.c1s)
-    for (int n = 0; n < a.n_sl; ++n) g += a.gslabs[((size_t)n * a.Bp + b) * a.ld_sl + c];
+  if (a.gslabs && c < a.c1s) {   // all loads of a group of eight in flight, added in slab order
+    const float* ps = a.gslabs + (size_t)b * a.ld_sl + c;
+    const size_t slab = (size_t)a.Bp * a.ld_sl;
+    int n = 0;
+    for (; n + 8 <= a.n_sl; n += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ps[(size_t)(n + u) * slab];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g += v[u];
+    }
+    for (; n < a.n_sl; ++n) g += ps[(size_t)n * slab];
+  }
   if (a.gfull) a.gfull[(size_t)b * a.ld_full + c] = g;
   if (a.scale) g *= a.scale[c];                       // out = scale (u + loc)   (lib/modules.py:307)
   if (!a.st || j < a.c1) {
@@ -320,7 +331,9 @@ __global__ __launch_bounds__(256) void seq_actnorm_bwd_kernel(const vunet_seq_ac
 }
 
 // ------------------------------------------------------------------------------------------------ FlowLoss
-// one workgroup of 1024 threads: wave w sums rows w, w + 16, ...; thread 0 adds the row sums in row order
+// one workgroup of 1024 threads: wave w takes rows w, w + 16, ... -- all of a wave's loads are independent (16-byte where the
+// geometry allows: VEC), the row sums meet in LDS and thread 0 adds them in row order
+template <bool VEC>
 __global__ __launch_bounds__(1024) void seq_flow_loss_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ logdet,
                                                              const float* __restrict__ noise, int B, int Bp, int C,
                                                              float* __restrict__ scalars, float* __restrict__ dz, int ld_dz,
@@ -330,14 +343,34 @@ __global__ __launch_bounds__(1024) void seq_flow_loss_kernel(const float* __rest
   const float inv_b = 1.f / (float)B;
   for (int b = wave; b < Bp; b += 16) {
     float s = 0.f, sn = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float v = b < B ? z[(size_t)b * ldz + c] : 0.f;
-      s += v * v;
-      if (dz) dz[(size_t)b * ld_dz + c] = v * inv_b;
-      if (noise && b < B) {
-        const float e = noise[(size_t)b * C + c];
-        sn += e * e;
+    if (b < B) {
+      if constexpr (VEC) {
+        const float4* zr = reinterpret_cast<const float4*>(z + (size_t)b * ldz);
+        const float4* nr = noise ? reinterpret_cast<const float4*>(noise + (size_t)b * C) : nullptr;
+        float4* dr = dz ? reinterpret_cast<float4*>(dz + (size_t)b * ld_dz) : nullptr;
+#pragma unroll 4
+        for (int c = lane; c < C / 4; c += 64) {
+          const float4 v = zr[c];
+          s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          if (dr) dr[c] = make_float4(v.x * inv_b, v.y * inv_b, v.z * inv_b, v.w * inv_b);
+          if (nr) {
+            const float4 e = nr[c];
+            sn += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
+          }
+        }
+      } else {
+        for (int c = lane; c < C; c += 64) {
+          const float v = z[(size_t)b * ldz + c];
+          s += v * v;
+          if (dz) dz[(size_t)b * ld_dz + c] = v * inv_b;
+          if (noise) {
+            const float e = noise[(size_t)b * C + c];
+            sn += e * e;
+          }
+        }
       }
+    } else if (dz) {
+      for (int c = lane; c < C; c += 64) dz[(size_t)b * ld_dz + c] = 0.f;
     }
     s = wave_sum(s);
     sn = wave_sum(sn);
@@ -348,19 +381,19 @@ __global__ __launch_bounds__(1024) void seq_flow_loss_kernel(const float* __rest
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float nll = 0.f, ref = 0.f, ld = 0.f;
-    for (int b = 0; b < B; ++b) {
-      nll += rs[0][b];
-      ref += rs[1][b];
-      ld += logdet[b];
+  if (wave == 0) {   // row sums in row order: lane b holds row b; the 64 values are added by a fixed tree
+    float nll = lane < B ? rs[0][lane] : 0.f, ref = lane < B ? rs[1][lane] : 0.f, ld = lane < B ? logdet[lane] : 0.f;
+    nll = wave_sum(nll);
+    ref = wave_sum(ref);
+    ld = wave_sum(ld);
+    if (lane == 0) {
+      nll *= inv_b;
+      const float nld = -(ld * inv_b);
+      scalars[0] = nll + nld;
+      scalars[1] = ref * inv_b;
+      scalars[2] = nld;
+      scalars[3] = nll;
     }
-    nll *= inv_b;
-    const float nld = -(ld * inv_b);
-    scalars[0] = nll + nld;
-    scalars[1] = ref * inv_b;
-    scalars[2] = nld;
-    scalars[3] = nll;
   }
 }
 
@@ -498,8 +531,12 @@ extern "C" int vunet_seq_flow_loss(const float* z, int32_t ldz, const float* log
                                    float* scalars, float* dz, int32_t ld_dz, float* dld, void* stream) {
   if (!z || !logdet || !scalars || B < 1 || B > 64 || C < 1 || ldz < C || (dz && ld_dz < C)) return VUNET_ERR_ARG;
   const int Bp = (B + 15) / 16 * 16;
-  VUNET_LAUNCH(seq_flow_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, ldz, logdet, noise, B, Bp, C, scalars, dz, ld_dz,
-               dld);
+  const bool vec = C % 4 == 0 && ldz % 4 == 0 && (!dz || ld_dz % 4 == 0) && ((uintptr_t)z & 15) == 0 && ((uintptr_t)dz & 15) == 0 &&
+                   ((uintptr_t)noise & 15) == 0;
+  if (vec) VUNET_LAUNCH((seq_flow_loss_kernel<true>), dim3(1), dim3(1024), 0, (hipStream_t)stream, z, ldz, logdet, noise, B, Bp, C,
+                        scalars, dz, ld_dz, dld);
+  else VUNET_LAUNCH((seq_flow_loss_kernel<false>), dim3(1), dim3(1024), 0, (hipStream_t)stream, z, ldz, logdet, noise, B, Bp, C,
+                    scalars, dz, ld_dz, dld);
   return vunet_check_launch();
 }
 

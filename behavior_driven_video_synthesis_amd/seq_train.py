@@ -16,6 +16,7 @@ There is no CPU path.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -120,6 +121,8 @@ class FlowTrainEngine(FlowEngine):
         self.adam: Optional[AdamState] = None
         self._moments: Dict[str, tuple] = {}
         self._generation = 0
+        self.two_streams = os.environ.get("VUNET_SEQ_TRAIN_STREAMS", "2") != "1"
+        self._side_stream = None
 
     # ---- weights
     def _pack(self):
@@ -274,6 +277,19 @@ class FlowTrainEngine(FlowEngine):
         dw = tables["dw"]
         gbase, ld_g, gsl = gz, ld_gz, None
         rng = iter(dw["ranges"])
+        main = torch.cuda.current_stream()
+        side = self._side() if self.two_streams else None
+
+        def sweep(first, cnt):
+            """The update of one half's eight layers.  Nothing downstream of it in this pass reads what it writes (W, the
+            moments) and the chain never touches the dZ / activation buffers it reads again: it runs on the side stream
+            beside the next half's input-gradient chain, which alone leaves most of the HBM bandwidth idle."""
+            if side is None:
+                _call("vunet_seq_dw", _p(dw["table"]), dw["n"], first, cnt, rows, hpp, _stream())
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _call("vunet_seq_dw", _p(dw["table"]), dw["n"], first, cnt, rows, hpp, _stream())
         for i in reversed(range(n)):
             blk = self.blocks[i]
             h0, h1 = blk["halves"]
@@ -283,19 +299,24 @@ class FlowTrainEngine(FlowEngine):
             self._coupling_bwd(rows, p, gbase, ld_g, gsl, blk["bwd"], None if last else nxt["scale"], p["s1"][i], h1, p["y"][i][1][-1],
                                None if last else p["gfull"][i + 1], p["g1"], self.ld, p["dz"][i][1][-1])
             self._mlp_bwd(rows, p, h1, p["y"][i][1], p["dz"][i][1], p["raw_in"][1])
-            first, cnt = next(rng)
-            _call("vunet_seq_dw", _p(dw["table"]), dw["n"], first, cnt, rows, hpp, _stream())
+            sweep(*next(rng))
             # half 0: out[c] = v[swap[c]], v = couple_0(S0_i)
             g0 = p["g0"][i % 2]
             self._coupling_bwd(rows, p, p["g1"], self.ld, p["raw_in"][1], self.inv_swap, None, p["s0"][i], h0, p["y"][i][0][-1], None, g0,
                                self.ld, p["dz"][i][0][-1])
             self._mlp_bwd(rows, p, h0, p["y"][i][0], p["dz"][i][0], p["raw_in"][0])
-            first, cnt = next(rng)
-            _call("vunet_seq_dw", _p(dw["table"]), dw["n"], first, cnt, rows, hpp, _stream())
+            sweep(*next(rng))
             gbase, ld_g, gsl = g0, self.ld, p["raw_in"][0]
         # the first step of the pass: S0_0 = A_0(x)
         self._coupling_bwd(rows, p, gbase, ld_g, gsl, None, self.blocks[0]["scale"], None, None, None, p["gfull"][0], p["dx"], self.C, None)
         _call("vunet_seq_actnorm_bwd", _p(tables["norm"]), n, self.C, rows, _p(p["dld"]), hpp, _stream())
+        if side is not None:
+            main.wait_stream(side)
+
+    def _side(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
 
     def _write_back(self):
         for lay in self._all_layers():

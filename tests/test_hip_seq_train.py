@@ -20,6 +20,15 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def _rel_q(a, b, q=0.99):
+    """(the q-quantile, the maximum) of |a - b| relative to max |b|."""
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    d = (a - b).abs() / b.abs().max().clamp_min(1e-30)
+    if d.numel() < 2:
+        return float(d.max()), float(d.max())
+    return float(torch.kthvalue(d, max(1, int(q * d.numel()))).values), float(d.max())
+
+
 def _g10_state(info, arr, tag, seed):
     stored = {k[len(tag) + 4:]: torch.from_numpy(v) for k, v in arr.items() if k.startswith(tag + ".sd.")}
     sd = synth_behavior_state(info["shapes"], seed, stored)
@@ -149,9 +158,14 @@ def test_flow_gradients_vs_oracle_over_batch_sizes(bsz):
 
 
 def test_flow_step_at_the_reference_width_vs_oracle():
-    """config/behavior_net.yaml's sizes (1024 channels, 2048 hidden, depth 2, batch 64), 3 of the 15 blocks: two fused steps vs
-    the oracle's (torch.autograd + torch.optim.Adam on the CPU), every weight compared; graph replay equals eager issue bit for
-    bit; the parameters are updated in place (no padded copies at these sizes)."""
+    """config/behavior_net.yaml's sizes (1024 channels, 2048 hidden, depth 2, batch 64), 3 of the 15 blocks, three fused steps.
+    Graph replay equals eager issue bit for bit; the parameters are updated in place (no padded copies at these sizes).  Every
+    step is held to the oracle's step FROM THE SAME STATE (weights, moments and step count copied out of the engine through
+    ``optimizer_state_dict`` into ``torch.optim.Adam``): two fp32 trajectories through 36 LeakyReLU layers do not stay together
+    (measured 4e-2 of max|exp_avg| after three free-running steps).  Even within one step the two sides differ in a handful of
+    places by construction: of the step's 4.7 M hidden pre-activations a few lie within summation rounding (3e-6) of zero, and
+    there the unit's derivative is 1 on one side and 0.01 on the other -- one sample's share of one row of dW.  So the moments
+    are held to a tight bar at the 99th percentile of every tensor's elements and to a loose one at the maximum."""
     from oracle import behavior_oracle as B
     lr = 4.5e-7 * 64            # flow_lr * batch_size (experiments/behavior_net.py:382)
     runs = {}
@@ -159,30 +173,47 @@ def test_flow_step_at_the_reference_width_vs_oracle():
         flow, sd = _random_flow(1024, 2048, 2, 3, 7)
         eng = flow.flow.train_engine(lr=lr, betas=(0.5, 0.9), weight_decay=0.0)
         eng.graph.enabled = graph
-        logs = []
+        logs, worst = [], dict(loss=0.0, exp_avg=0.0, exp_avg_sq=0.0, exp_avg_max=0.0, w_far=0.0, w_max=0.0)
         for it in range(3):
-            bs = seeded_randn(f"w.b{it}", (64, 1024), 7).cuda()
-            logs.append(eng.train_step(bs, torch.zeros(64, 1024, device="cuda")).tolist())
+            batch = seeded_randn(f"w.b{it}", (64, 1024), 7)
+            if graph:   # the oracle takes this step from the engine's state
+                ref = {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()}
+                opt = B.flow_optimizer(ref, lr, 0.0)
+                if it:
+                    opt.load_state_dict(eng.optimizer_state_dict())
+                log = B.flow_train_step(ref, opt, batch)
+            logs.append(eng.train_step(batch.cuda(), torch.zeros(64, 1024, device="cuda")).tolist())
+            if not graph:
+                continue
+            for gi, name in ((0, "flow_loss"), (3, "nll_loss"), (2, "nlogdet_loss")):
+                worst["loss"] = max(worst["loss"], abs(logs[-1][gi] - log[name]) / abs(log[name]))
+            mine, theirs = eng.optimizer_state_dict()["state"], opt.state_dict()["state"]
+            assert int(mine[0]["step"]) == int(theirs[0]["step"]) == it + 1
+            for i in range(len(theirs)):
+                q, mx = _rel_q(mine[i]["exp_avg"], theirs[i]["exp_avg"])
+                worst["exp_avg"], worst["exp_avg_max"] = max(worst["exp_avg"], q), max(worst["exp_avg_max"], mx)
+                worst["exp_avg_sq"] = max(worst["exp_avg_sq"], _rel_q(mine[i]["exp_avg_sq"], theirs[i]["exp_avg_sq"])[0])
+            # weights move by lr m / (sqrt(v) + eps) ~ +-lr whatever the gradient's size: an element whose gradient is
+            # summation noise may go the other way (at most 2 lr apart) -- bounded, and counted
+            far = total = 0
+            for k, v in flow.state_dict().items():
+                if v.dtype.is_floating_point and v.dim() > 0:
+                    d = (v.detach().cpu() - ref[k].detach()).abs()
+                    worst["w_max"] = max(worst["w_max"], float(d.max()) / lr)
+                    far += int((d > 0.02 * lr).sum())
+                    total += d.numel()
+            worst["w_far"] = max(worst["w_far"], far / total)
         assert all(lay.w_inplace and lay.b_inplace for lay in eng._all_layers())
         runs[graph] = (logs, {k: v.detach().clone() for k, v in flow.state_dict().items()})
     for k, v in runs[False][1].items():
         assert torch.equal(v, runs[True][1][k]), k
     assert runs[False][0] == runs[True][0]
-    ref = {k: v.clone() for k, v in sd.items()}
-    opt = B.flow_optimizer(ref, lr, 0.0)
-    for it in range(3):
-        log = B.flow_train_step(ref, opt, seeded_randn(f"w.b{it}", (64, 1024), 7))
-        got = runs[True][0][it]
-        for gi, name in ((0, "flow_loss"), (3, "nll_loss"), (2, "nlogdet_loss")):
-            assert abs(got[gi] - log[name]) <= 1e-5 * abs(log[name]), (it, name, got, log)
-    worst_w = worst_d = 0.0
-    for k, v in runs[True][1].items():
-        if v.dtype.is_floating_point and v.dim() > 0:
-            worst_w = max(worst_w, _rel(v, ref[k]))
-            # the UPDATE is what the step computes: compare it too (3 Adam steps of lr 2.9e-5 against weights of O(0.03))
-            worst_d = max(worst_d, _rel(v.cpu() - sd[k], ref[k].detach() - sd[k]))
-    print(f"\n[1024/2048 x 3 blocks, 3 steps] weights {worst_w:.2e}, updates {worst_d:.2e} of max|.|")
-    assert worst_w <= 1e-6 and worst_d <= 2e-3
+    print(f"\n[1024/2048 x 3 blocks, 3 steps, each vs the oracle's step from the same state] losses {worst['loss']:.1e}; exp_avg "
+          f"{worst['exp_avg']:.1e} at the 99th percentile, {worst['exp_avg_max']:.1e} at the maximum, exp_avg_sq "
+          f"{worst['exp_avg_sq']:.1e} (of max|.|); weights: max |diff| {worst['w_max']:.2f} lr, share more than 0.02 lr apart "
+          f"{worst['w_far']:.1e}")
+    assert worst["loss"] <= 2e-6 and worst["exp_avg"] <= 2e-5 and worst["exp_avg_sq"] <= 2e-5 and worst["exp_avg_max"] <= 1e-2
+    assert worst["w_max"] <= 2.002 and worst["w_far"] <= 1e-4
 
 
 def test_flow_training_refuses_what_it_cannot_do():
@@ -198,3 +229,60 @@ def test_flow_training_refuses_what_it_cannot_do():
         z.sum().backward()
     with pytest.raises(RuntimeError):
         flow.reverse(torch.randn(4, 64, device="cuda"))          # the reverse direction stays inference only
+
+
+# ---------------------------------------------------------------- the two matrix kernels on their own, through the C ABI
+@pytest.mark.parametrize("B,M,K,nets,S", [(64, 2048, 2048, 2, 4), (64, 2048, 512, 2, 16), (64, 512, 2048, 2, 4), (16, 2048, 2048, 2, 4),
+                                          (33, 1024, 1088, 1, 2), (48, 256, 64, 1, 1), (5, 4096, 1088, 1, 1), (64, 4096, 1024, 1, 8)])
+def test_dx_kernel_vs_float64(B, M, K, nets, S):
+    """vunet_seq_dx: dX = dZ . W as S raw slabs (both wave counts of the kernel, every batch-tile count) vs a float64 product."""
+    import ctypes
+    from behavior_driven_video_synthesis_amd import seq_train as T
+    from behavior_driven_video_synthesis_amd.ops import _call, _p, _stream
+    g = torch.Generator().manual_seed(B * 7 + M + K)
+    bp = (B + 15) // 16 * 16
+    w = [torch.randn(M, K, generator=g).cuda() for _ in range(nets)]
+    dz = torch.zeros(nets, bp, M)
+    dz[:, :B] = torch.randn(nets, B, M, generator=g)
+    dz = dz.cuda()
+    raw = torch.full((nets, S, bp, K), float("nan"), device="cuda")
+    d = T.SeqDxDesc(B, M, K, nets, S)
+    _call("vunet_seq_dx", ctypes.byref(d), _p(w[0]), _p(w[1] if nets > 1 else None), _p(dz), _p(raw), _stream())
+    got = raw.double().sum(dim=1)
+    for n in range(nets):
+        want = dz[n].double() @ w[n].double()
+        assert _rel(got[n], want) <= 2e-6, (n, _rel(got[n], want))
+        # each slab is the product over its own row range
+        rows = M // S
+        for s in (0, S - 1):
+            part = dz[n][:, s * rows:(s + 1) * rows].double() @ w[n][s * rows:(s + 1) * rows].double()
+            assert _rel(raw[n, s], part) <= 2e-6
+
+
+@pytest.mark.parametrize("B", [7, 16, 40, 64])
+def test_dw_kernel_write_mode_vs_float64(B):
+    """vunet_seq_dw without Adam: the tiles of dW = dZ^T . X and the bias gradient of a two-layer table (different shapes, a
+    first layer that reads its input from longer rows and masks its padding columns)."""
+    from behavior_driven_video_synthesis_amd import seq_train as T
+    from behavior_driven_video_synthesis_amd.ops import _call, _p, _stream
+    g = torch.Generator().manual_seed(B)
+    bp = (B + 15) // 16 * 16
+    shapes = [(128, 192, 256, 150), (2048, 512, 512, 512)]    # M, K, ldx, valid columns
+    entries, keep, tile = [], [], 0
+    for (m, k, ldx, kv) in shapes:
+        dz, x = torch.zeros(bp, m), torch.zeros(bp, ldx)
+        dz[:B], x[:B] = torch.randn(B, m, generator=g), torch.randn(B, ldx, generator=g)
+        dz, x = dz.cuda(), x.cuda()
+        gw, gb = torch.full((m, k), float("nan"), device="cuda"), torch.full((m,), float("nan"), device="cuda")
+        bias = torch.zeros(m, device="cuda")
+        entries.append(T.SeqDwLayer(None, None, None, gw.data_ptr(), bias.data_ptr(), None, None, gb.data_ptr(), dz.data_ptr(),
+                                    x.data_ptr(), m, k, m, ldx, tile, k // 64, kv, 0))
+        tile += (m // 64) * (k // 64)
+        keep.append((dz, x, gw, gb, bias, kv, k))
+    tab = T._table(entries, "cuda")
+    _call("vunet_seq_dw", _p(tab), len(entries), 0, tile, B, None, _stream())
+    for dz, x, gw, gb, _, kv, k in keep:
+        want = dz.double().t() @ x[:, :k].double()
+        want[:, kv:] = 0
+        assert _rel(gw, want) <= 2e-6
+        assert _rel(gb, dz.double().sum(0)) <= 2e-6
