@@ -28,6 +28,7 @@
 //     decoder adds seq_dec_out_kernel: the output layer + residual (``ResidualRNNDecoder.forward``), which writes the step's pose
 //     and the next operand's x.  The decoder's optional input layer is folded into the gate matrix when the weights are packed.
 #include "common.h"
+#include "../../include/vunet_seq_train.h"
 
 namespace {
 
@@ -47,6 +48,7 @@ struct SeqLinearArgs {
   float* xh_next;         // [Bp][ldx] the NEXT step's operand rows (another buffer than x): h at hoff
   float* h_out;           // [Bp][H] or NULL
   const float* x_next;    // encoder: the next input pose, row b at + b * seq_stride (NULL: the decoder's second launch writes x)
+  float* gates_out;       // training: [Bp][H][4] = sigmoid(i), sigmoid(f), tanh(g), sigmoid(o) of every unit (NULL: not kept)
   long long seq_stride;
   int H, hoff, n, B;
 };
@@ -161,8 +163,10 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
     {
       const int nrow = nb * 16 + i;
       const float4 g = add4(v[0], bv);
-      const float c2 = sigmoid_f(g.y) * a.c_in[(size_t)nrow * a.H + j] + sigmoid_f(g.x) * tanhf(g.z);
-      const float h = sigmoid_f(g.w) * tanhf(c2);
+      const float si = sigmoid_f(g.x), sf = sigmoid_f(g.y), tg = tanhf(g.z), so = sigmoid_f(g.w);
+      const float c2 = sf * a.c_in[(size_t)nrow * a.H + j] + si * tg;
+      const float h = so * tanhf(c2);
+      if (a.gates_out) *reinterpret_cast<float4*>(a.gates_out + ((size_t)nrow * a.H + j) * 4) = make_float4(si, sf, tg, so);
       a.c_out[(size_t)nrow * a.H + j] = c2;
       a.xh_next[(size_t)nrow * a.ldx + a.hoff + j] = h;
       if (a.h_out) a.h_out[(size_t)nrow * a.H + j] = h;
@@ -484,7 +488,7 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   a.act[1] = d->act1;
   a.shared_in = d->shared_in;
   a.S = d->S;
-  a.c_in = nullptr; a.c_out = nullptr; a.xh_next = nullptr; a.h_out = nullptr; a.x_next = nullptr;
+  a.c_in = nullptr; a.c_out = nullptr; a.xh_next = nullptr; a.h_out = nullptr; a.x_next = nullptr; a.gates_out = nullptr;
   a.seq_stride = 0; a.H = a.hoff = a.n = a.B = 0;
   // (RT = 2, a 32-row tile per workgroup, halves the operand traffic per weight byte but leaves half the CUs without a workgroup
   // at every layer size of the reference configuration: not instantiated)
@@ -548,8 +552,9 @@ extern "C" int vunet_seq_start(const float* x0, int64_t x0_stride, const float* 
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
-                                    const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, void* stream) {
+static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
+                           const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, float* gates_out,
+                           void* stream) {
   if (!d || !w_perm || !xh || !bias_perm || !c_in || !c_out || c_in == c_out || !xh_next || xh_next == xh) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->H < 4 || d->H % 4 || d->n < 1 || d->hoff < d->n || d->ldx < d->hoff + d->H) return VUNET_ERR_ARG;
   if (d->ldx % 32) return VUNET_ERR_ARG;
@@ -572,6 +577,7 @@ extern "C" int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w
   a.xh_next = xh_next;
   a.h_out = h_out;
   a.x_next = x_next;
+  a.gates_out = gates_out;
   a.seq_stride = d->seq_stride;
   a.H = d->H;
   a.hoff = d->hoff;
@@ -594,6 +600,19 @@ extern "C" int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w
   }
 #undef SEQ_LSTM_CASE
   return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
+                                    const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, void* stream) {
+  return seq_lstm_launch(d, w_perm, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, nullptr, stream);
+}
+
+// the same step with the gate activations kept for the backward pass (include/vunet_seq_train.h)
+extern "C" int vunet_seq_lstm_gates_train(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
+                                          const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next,
+                                          float* gates_out, void* stream) {
+  if (!gates_out) return VUNET_ERR_ARG;
+  return seq_lstm_launch(d, w_perm, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, gates_out, stream);
 }
 
 extern "C" int vunet_seq_decoder_out(const vunet_seq_lstm_desc* d, float* xh, const float* w_out, const float* b_out, float* xraw, float* xs,

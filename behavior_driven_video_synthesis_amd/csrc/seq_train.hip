@@ -32,7 +32,7 @@ struct SeqDxArgs {
   const float* w[2];   // [M][K]
   const float* dz;     // [nets][Bp][M]
   float* raw;          // [nets][S][Bp][K]
-  int M, K, Bp, S;
+  int M, K, Bp, S, ldw;
 };
 
 // grid (K / 64, S, nets), 64 WAVES threads.  Lane l: i = l & 15, q = l >> 4.  In a 16-row group starting at row mb the lane loads
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   const int i = lane & 15, q = lane >> 4;
   const int k0 = blockIdx.x * 64, s = blockIdx.y, net = blockIdx.z;
   const int rows = a.M / a.S, ngrp = rows >> 4;
-  const float* __restrict__ w = a.w[net] + (size_t)(s * rows + 4 * q) * a.K + k0 + 4 * i;
+  const float* __restrict__ w = a.w[net] + (size_t)(s * rows + 4 * q) * a.ldw + k0 + 4 * i;
   const float* __restrict__ dz = a.dz + ((size_t)net * a.Bp + i) * a.M + s * rows + 4 * q;
   f32x4 acc[4][NB];
 #pragma unroll
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   for (int g = wave; g < ngrp; g += WAVES) {
     float4 wv[4], dv[NB];
 #pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) wv[e2] = *reinterpret_cast<const float4*>(w + (size_t)(16 * g + e2) * a.K);
+    for (int e2 = 0; e2 < 4; ++e2) wv[e2] = *reinterpret_cast<const float4*>(w + (size_t)(16 * g + e2) * a.ldw);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) dv[nb] = *reinterpret_cast<const float4*>(dz + (size_t)16 * nb * a.M + 16 * g);
     __builtin_amdgcn_sched_barrier(0);
@@ -214,28 +214,40 @@ __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* _
   const int t = tile - L.tile0, tm = t / L.tiles_k, tk = t - tm * L.tiles_k;
   const int m0 = 64 * tm, k0 = 64 * tk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  if (ADAM && tid == 0) hsh = adam_resolve(hp);
-  for (int idx = tid; idx < 16 * NB * 16; idx += 256) {
-    const int b = idx >> 4, c4 = idx & 15;
-    *reinterpret_cast<float4*>(&dzs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(L.dz + (size_t)b * L.ldz + m0 + 4 * c4);
-    *reinterpret_cast<float4*>(&xs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(L.x + (size_t)b * L.ldx + k0 + 4 * c4);
+  AdamResolved h = AdamResolved{};
+  if constexpr (ADAM) {
+    if (tid == 0) hsh = adam_resolve(hp);
   }
-  __syncthreads();
-  float av[4 * NB];
-#pragma unroll
-  for (int c = 0; c < 4 * NB; ++c) av[c] = dzs[(4 * c + q) * DW_LD + 16 * wave + i];
   f32x4 acc[4];
 #pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
-    acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4 * NB; ++c)
-      acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], xs[(4 * c + q) * DW_LD + 16 * blk + i], acc[blk], 0, 0, 0);
-  }
-  // bias: d b[m] = sum_b dZ[b][m], rows in order (the k = 0 tiles)
+  for (int blk = 0; blk < 4; ++blk) acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  if (tk == 0 && tid < 64 && L.bias)
-    for (int b = 0; b < 16 * NB; ++b) bsum += dzs[b * DW_LD + tid];
+  const int nchunk = L.nchunk > 1 ? L.nchunk : 1;
+  for (int ch = 0; ch < nchunk; ++ch) {   // (one block of Bp rows for a flow layer; one per time step for a recurrent layer)
+    const float* dzp = L.dz + (size_t)ch * L.chunk_z;
+    const float* xp = L.x + (size_t)ch * L.chunk_x;
+    if (ch) __syncthreads();   // the previous block's operands have been read
+    for (int idx = tid; idx < 16 * NB * 16; idx += 256) {
+      const int b = idx >> 4, c4 = idx & 15;
+      *reinterpret_cast<float4*>(&dzs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(dzp + (size_t)b * L.ldz + m0 + 4 * c4);
+      *reinterpret_cast<float4*>(&xs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(xp + (size_t)b * L.ldx + k0 + 4 * c4);
+    }
+    __syncthreads();
+    if constexpr (ADAM) {
+      if (ch == 0) h = hsh;   // (before the padding columns of row 0 are staged over again)
+    }
+    float av[4 * NB];
+#pragma unroll
+    for (int c = 0; c < 4 * NB; ++c) av[c] = dzs[(4 * c + q) * DW_LD + 16 * wave + i];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int c = 0; c < 4 * NB; ++c)
+        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], xs[(4 * c + q) * DW_LD + 16 * blk + i], acc[blk], 0, 0, 0);
+    // bias: d b[m] = sum_b dZ[b][m], rows in order (the k = 0 tiles)
+    if (tk == 0 && tid < 64 && L.bias)
+      for (int b = 0; b < 16 * NB; ++b) bsum += dzs[b * DW_LD + tid];
+  }
   __syncthreads();   // every wave has read its operands: the space of xs becomes the tile of dW, by rows
   float* dws = xs;
 #pragma unroll
@@ -243,7 +255,6 @@ __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) dws[(16 * wave + 4 * q + r) * DW_LDO + 16 * blk + i] = acc[blk][r];
   __syncthreads();
-  const AdamResolved h = ADAM ? hsh : AdamResolved{};
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
@@ -414,7 +425,9 @@ extern "C" int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const f
   if (!d || !w0 || !dz || !raw) return VUNET_ERR_ARG;
   if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 64 || d->K < 64 || d->K % 64 || d->S < 1 || d->M < 16 * d->S || d->M % (16 * d->S)) return VUNET_ERR_ARG;
+  if (d->ldw && (d->ldw < d->K || d->ldw % 4)) return VUNET_ERR_ARG;
   SeqDxArgs a;
+  a.ldw = d->ldw ? d->ldw : d->K;
   a.w[0] = w0;
   a.w[1] = w1;
   a.dz = dz;

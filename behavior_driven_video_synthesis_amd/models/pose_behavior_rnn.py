@@ -70,6 +70,7 @@ class ResidualBehaviorNet(nn.Module):
         self.decoder = ResidualRNNDecoder(n_in_out=n_kps, n_hidden=self.dim_hidden_b, rnn_type=self.dec_type,
                                           use_nin=self.use_nin_dec)
         self._engine = None
+        self._train_engine = None
 
     def engine(self):
         if self._engine is None:
@@ -77,7 +78,23 @@ class ResidualBehaviorNet(nn.Module):
             object.__setattr__(self, "_engine", seq.BehaviorEngine(self))
         return self._engine
 
+    def train_engine(self):
+        """The training plans of this net (``seq_train.BehaviorTrainEngine``: the forward pass with everything kept and
+        back-propagation through time, csrc/seq_bptt.hip)."""
+        if self._train_engine is None:
+            from .. import seq_train
+            object.__setattr__(self, "_train_engine", seq_train.BehaviorTrainEngine(self))
+        return self._train_engine
+
     def forward(self, x1, x2, len, start_frame=0, sample=False, eps=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # autograd is recording (the cVAE stage of experiments/behavior_net.py:591-660): the same forward pass with every
+            # step kept, as one node whose backward is the HIP back-propagation through time
+            from .. import seq_train
+            if eps is None:
+                eps = torch.randn(x1.shape[0], self.dim_hidden_b, device=x1.device, dtype=x1.dtype)
+            xs, cs, b, mu, logstd, pre = seq_train.behavior_autograd(self.train_engine(), x1, x2, len, start_frame, eps, sample)
+            return xs, cs, [], b, mu, logstd, pre
         b = self.infer_b(x1, sample, eps=eps)
         xs, cs, zs_gen, _ = self.generate_seq(b[0] if self.ib else b, x2, len, start_frame=start_frame)
         if self.ib:

@@ -238,13 +238,14 @@ class _GraphCache:
         """``run`` for a launch sequence with side effects (an optimisation step): every call executes it exactly once -- the
         first call with a key eagerly (first-launch work stays outside a recording), the second records it and replays the
         recording, later ones replay."""
-        if not self.enabled or torch.cuda.is_current_stream_capturing() or key in self.graphs:
-            return self.run(key, issue)
+        if key in self.graphs and self.enabled and not torch.cuda.is_current_stream_capturing():
+            self.graphs[key].replay()
+            return "replayed"
         warmed = self.__dict__.setdefault("_warmed", set())
-        if key not in warmed:
+        if not self.enabled or torch.cuda.is_current_stream_capturing() or key not in warmed:
             warmed.add(key)
             issue()
-            return
+            return "eager"
         torch.cuda.synchronize()
         if self._stream is None:
             self._stream = torch.cuda.Stream()
@@ -261,6 +262,7 @@ class _GraphCache:
             self.drop(next(iter(self.graphs)))
         self.graphs[key] = g
         g.replay()
+        return "captured"
 
     def drop(self, key):
         if self.graphs.pop(key, None) is not None and self.on_evict is not None:
@@ -493,6 +495,8 @@ class BehaviorEngine:
     def net(self):
         return self._net()
 
+    HOFF_PAD = 32     # the hidden part of an operand row [x | 0 | h] starts at this multiple (training: 64, the backward tiles)
+
     def _pack(self):
         net = self.net
         key = _versions(list(net.parameters()))
@@ -502,50 +506,59 @@ class BehaviorEngine:
         self.n, self.H = dec.n_in_out, dec.n_hidden
         if self.H % 32:
             raise ValueError("dim_hidden_b must be a multiple of 32 on the HIP path")
-        self.hoff = _up(self.n, 32)
+        self.hoff = _up(self.n, self.HOFF_PAD)
         self.ldx = self.hoff + self.H
         self.ldraw = _up(self.n, 64)
         dev = dec.rnn.weight_ih.device
+        z = lambda *shape: torch.zeros(*shape, device=dev)   # noqa: E731
+        # the images: allocated once per geometry, refilled when the parameters change (zero padding is written once)
+        geo = (self.n, self.H, self.hoff, dec.use_nin, bool(enc.ib), str(dev))
+        if getattr(self, "_geo", None) != geo:
+            self._geo = geo
+            self.dec_w, self.enc_w = z(4 * self.H, self.ldx), z(4 * self.H, self.ldx)
+            self.dec_b, self.enc_b = z(4 * self.H), z(4 * self.H)
+            self.dec_fold = (z(4 * self.H, self.n), z(4 * self.H)) if dec.use_nin else None
+            self.heads = ([z(self.H, self.H) for _ in range(2)], [z(self.H) for _ in range(2)]) if enc.ib else None
+            self.head_rs = [z(self.H) for _ in range(2)] if enc.ib else None
+            self._plans.clear()
+            self.graph.graphs.clear()
+            self.graph.__dict__.pop("_warmed", None)
+        self._fill_images()
+        self._packed_for = key
 
-        def gate_image(w_ih, w_hh):
+    def _fill_images(self):
+        """(Re)write the kernels' weight images from the module's parameters, in place."""
+        net = self.net
+        dec, enc = net.decoder, net.b_enc
+
+        def gate_image(w_ih, w_hh, img):
             """[W_ih | 0 | W_hh] with gate-interleaved rows: row 4 j + q = gate q (i, f, g, o) of hidden unit j."""
-            img = torch.zeros(4 * self.H, self.ldx, device=dev)
             for src, off in ((w_ih.detach().contiguous(), 0), (w_hh.detach().contiguous(), self.hoff)):
                 for q in range(4):
                     part = src[q * self.H:(q + 1) * self.H]
                     _call("vunet_seq_pack_rows", _p(part), self.H, part.shape[1], None, _p(img), self.ldx, off, q, 4, _stream())
-            return img
 
-        def gate_bias(b_ih, b_hh, fold):
-            out = torch.empty(4 * self.H, device=dev)
+        def gate_bias(b_ih, b_hh, fold, out):
             _call("vunet_seq_lstm_bias", _p(b_ih.detach().contiguous()), _p(b_hh.detach().contiguous()), _p(fold), self.H, _p(out),
                   _stream())
-            return out
         self.dec_fold_bias = None
         w_ih = dec.rnn.weight_ih
         if dec.use_nin:   # x = n_in(x) in front of the cell (:494-495): W_ih (W_in x + b_in) = (W_ih W_in) x + W_ih b_in
-            w_fold, self.dec_fold_bias = torch.empty(4 * self.H, self.n, device=dev), torch.empty(4 * self.H, device=dev)
+            w_fold, self.dec_fold_bias = self.dec_fold
             _call("vunet_seq_fold_input", _p(w_ih.detach().contiguous()), _p(dec.n_in.weight.detach().contiguous()),
                   _p(dec.n_in.bias.detach().contiguous()), 4 * self.H, self.n, _p(w_fold), _p(self.dec_fold_bias), _stream())
             w_ih = w_fold
-        self.dec_w = gate_image(w_ih, dec.rnn.weight_hh)
-        self.dec_b = gate_bias(dec.rnn.bias_ih, dec.rnn.bias_hh, self.dec_fold_bias)
-        self.enc_w = gate_image(enc.rnn.weight_ih_l0, enc.rnn.weight_hh_l0)
-        self.enc_b = gate_bias(enc.rnn.bias_ih_l0, enc.rnn.bias_hh_l0, None)
-        self.heads = None
+        gate_image(w_ih, dec.rnn.weight_hh, self.dec_w)
+        gate_bias(dec.rnn.bias_ih, dec.rnn.bias_hh, self.dec_fold_bias, self.dec_b)
+        gate_image(enc.rnn.weight_ih_l0, enc.rnn.weight_hh_l0, self.enc_w)
+        gate_bias(enc.rnn.bias_ih_l0, enc.rnn.bias_hh_l0, None, self.enc_b)
         if enc.ib:
-            scales, biases = [], []
-            for head in (enc.mu_fn, enc.std_fn):
+            for i, head in enumerate((enc.mu_fn, enc.std_fn)):
                 v, g, b, gamma, beta = head._params()
-                rs, be = torch.empty(self.H, device=dev), torch.empty(self.H, device=dev)
                 _call("vunet_seq_normlinear_rows", _p(v.detach().contiguous()), _p(g.detach().contiguous()), _p(b.detach().contiguous()),
-                      _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), self.H, self.H, _p(rs), _p(be), _stream())
-                scales.append(weight_image(v, self.H, self.H, 0, row_scale=rs))
-                biases.append(be)
-            self.heads = (scales, biases)
-        self._packed_for = key
-        self._plans.clear()
-        self.graph.graphs.clear()
+                      _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), self.H, self.H, _p(self.head_rs[i]),
+                      _p(self.heads[1][i]), _stream())
+                weight_image(v, self.H, self.H, 0, row_scale=self.head_rs[i], out=self.heads[0][i])
 
     def _plan(self, rows: int) -> dict:
         p = self._plans.get(rows)

@@ -34,7 +34,7 @@ class SeqAdamHp(ctypes.Structure):
 
 
 class SeqDxDesc(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "nets", "S")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "M", "K", "nets", "S", "ldw")]
 
 
 class SeqCouplingBwdDesc(ctypes.Structure):
@@ -43,7 +43,7 @@ class SeqCouplingBwdDesc(ctypes.Structure):
 
 class SeqDwLayer(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_void_p) for n in ("w", "m", "v", "g", "bias", "bm", "bv", "bg", "dz", "x")]
-                + [(n, ctypes.c_int32) for n in ("M", "K", "ldz", "ldx", "tile0", "tiles_k", "kv", "pad")])
+                + [(n, ctypes.c_int32) for n in ("M", "K", "ldz", "ldx", "tile0", "tiles_k", "kv", "nchunk", "chunk_z", "chunk_x")])
 
 
 class SeqActnormLayer(ctypes.Structure):
@@ -231,7 +231,7 @@ class FlowTrainEngine(FlowEngine):
             m_pad, k_pad = half.dims[li]
             s = p["S"][li]
             raw = raw_in if li == 0 else p["raw"]
-            d = SeqDxDesc(rows, m_pad, k_pad, half.nets, s)
+            d = SeqDxDesc(rows, m_pad, k_pad, half.nets, s, 0)
             _call("vunet_seq_dx", ctypes.byref(d), _p(half.w[li][0]), _p(half.w[li][1] if half.nets > 1 else None), _p(dzs[li]), _p(raw),
                   _stream())
             if li > 0:
@@ -254,7 +254,7 @@ class FlowTrainEngine(FlowEngine):
                         g, bg = grads[lay.name] if grads is not None else (None, None)
                         entries.append(SeqDwLayer(_ptr(lay.w), _ptr(lay.m), _ptr(lay.v), _ptr(g), _ptr(lay.b), _ptr(lay.bm), _ptr(lay.bv),
                                                   _ptr(bg), dz.data_ptr(), x.data_ptr(), m_pad, k_pad, m_pad,
-                                                  self.ld if li == 0 else k_pad, tile, k_pad // 64, lay.lin.weight.shape[1], 0))
+                                                  self.ld if li == 0 else k_pad, tile, k_pad // 64, lay.lin.weight.shape[1], 1, 0, 0))
                         tile += (m_pad // 64) * (k_pad // 64)
                 ranges.append((first, tile - first))
         return dict(table=_table(entries, self.blocks[0]["scale"].device), n=len(entries), ranges=ranges, tiles=tile)
@@ -500,3 +500,233 @@ def flow_autograd(engine: FlowTrainEngine, x: torch.Tensor):
     """(z [B, C], logdet [B]) with a graph: the forward of the flow for a loop that calls ``backward()`` itself."""
     named = list(engine.flow.named_parameters())
     return _FlowFn.apply(engine, [n for n, _ in named], x, *[p for _, p in named])
+
+
+# ================================================================================================
+# the behaviour cVAE (first stage of experiments/behavior_net.py: :591-660)
+# ================================================================================================
+class SeqCellBwdDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "H", "n", "n_sl", "ld_sl", "hoff_sl", "first", "pad")] + [("gl_stride", ctypes.c_int64)]
+
+
+from .seq import BehaviorEngine, SeqLinearDesc, SeqLstmDesc, ACT_NONE, linear   # noqa: E402
+
+
+class BehaviorTrainEngine(BehaviorEngine):
+    """``ResidualBehaviorNet.forward(x1, x2, len)`` (models/pose_behavior_rnn.py:574-586) with every step's operand row, cell
+    state and gate activations kept, and its backward pass: back-propagation through time over the decoder's roll-out and the
+    encoder's LSTM (csrc/seq_bptt.hip + the matrix kernels of csrc/seq_train.hip).  One batch of <= 64 rows
+    (config/behavior_net.yaml: 64).  Gradients are written in torch's parameter layout -- into the ``.grad`` views of the fused
+    optimiser (``experiments.behavior_net``) or into fresh tensors for autograd (``behavior_autograd``)."""
+
+    HOFF_PAD = 64
+
+    def __init__(self, net):
+        super().__init__(net)
+        self._generation = 0
+
+    def _check(self):
+        net = self.net
+        if net.decoder.use_nin:
+            raise NotImplementedError("training with linear_in_decoder=True is not built (config/behavior_net.yaml trains with False): "
+                                      "the input layer is folded into the gate matrix on this path")
+        if not net.ib:
+            raise NotImplementedError("training without the information bottleneck is not built (experiments/behavior_net.py:310 "
+                                      "always constructs the net with information_bottleneck=True)")
+        self._pack()
+        if self.H % 64:
+            raise ValueError("dim_hidden_b must be a multiple of 64 for training on the HIP path")
+
+    def _tplan(self, rows: int, t_in: int, t2: int, length: int) -> dict:
+        key = ("train", rows, t_in, t2, length)
+        p = self._plans.get(key)
+        if p is not None:
+            return p
+        dev = self.dec_w.device
+        bp, H, n, ldx = _up(rows, 16), self.H, self.n, self.ldx
+        z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
+        s_d = FlowTrainEngine._dx_split(4 * H, ldx, 1)
+        s_e = FlowTrainEngine._dx_split(4 * H, H, 1)
+        s_h = FlowTrainEngine._dx_split(H, H, 2)
+        p = dict(b_pad=bp, x1=z(rows, t_in, n), x2=z(rows, t2, n), eps=z(rows, H), target=z(rows, length, n),
+                 xh_e=z(t_in + 1, bp, ldx), c_e=z(t_in + 1, bp, H), gates_e=z(t_in, bp, 4 * H),
+                 xh_d=z(length + 1, bp, ldx), c_d=z(length + 1, bp, H), gates_d=z(length, bp, 4 * H),
+                 xraw=z(bp, self.ldraw), pre=z(bp, H), heads=z(2 * bp * H), mu=z(rows, H), logstd=z(rows, H), b=z(rows, H),
+                 xs=z(rows, length, n), cs=z(rows, length, n),
+                 dgates_d=z(length, bp, 4 * H), dgates_e=z(t_in, bp, 4 * H), gx=z(length + 1, bp, 64), gc=z(bp, H), dy=z(2, bp, H),
+                 S=(s_d, s_e, s_h), raw_d=z(s_d * bp * ldx), raw_e=z(s_e * bp * H), raw_h=z(2 * s_h * bp * H),
+                 gxs=z(rows, length, n), gmu=z(rows, H), glogstd=z(rows, H),
+                 g_dec=z(4 * H, ldx), gb_dec=z(4 * H), g_enc=z(4 * H, ldx), gb_enc=z(4 * H), g_out=z(64, H), gb_out=z(64),
+                 g_mu=z(H, H), gb_mu=z(H), g_std=z(H, H), gb_std=z(H), zero_bias=z(4 * H),
+                 part=z(length + rows), scalars=z(4), per_seq=z(length))
+        # the weight-gradient sweep (write mode): every layer of the net in one launch
+        entries, tile = [], 0
+
+        def layer(g, gb, dz, x, m, k, ldz, ldx_, nchunk, cz, cx):
+            nonlocal tile
+            entries.append(SeqDwLayer(None, None, None, g.data_ptr(), p["zero_bias"].data_ptr(), None, None, gb.data_ptr(), dz.data_ptr(),
+                                      x.data_ptr(), m, k, ldz, ldx_, tile, k // 64, k, nchunk, cz, cx))
+            tile += (m // 64) * (k // 64)
+        layer(p["g_dec"], p["gb_dec"], p["dgates_d"], p["xh_d"], 4 * H, ldx, 4 * H, ldx, length, bp * 4 * H, bp * ldx)
+        layer(p["g_enc"], p["gb_enc"], p["dgates_e"], p["xh_e"], 4 * H, ldx, 4 * H, ldx, t_in, bp * 4 * H, bp * ldx)
+        layer(p["g_out"], p["gb_out"], p["gx"], p["xh_d"][1:, :, self.hoff:], 64, H, 64, ldx, length, bp * 64, bp * ldx)
+        layer(p["g_mu"], p["gb_mu"], p["dy"][0], p["pre"], H, H, H, H, 1, 0, 0)
+        layer(p["g_std"], p["gb_std"], p["dy"][1], p["pre"], H, H, H, H, 1, 0, 0)
+        p["dw"] = dict(table=_table(entries, dev), n=len(entries), tiles=tile)
+        self._plans[key] = p
+        return p
+
+    # ---- forward, everything kept
+    def _issue_train_forward(self, rows, p, t_in, t2, length, start_frame, sample_prior: bool):
+        dec = self.net.decoder
+        n, H, esz = self.n, self.H, 4
+        x1, x2 = p["x1"], p["x2"]
+        _call("vunet_seq_start", _p(x1), t_in * n, None, None, None, 0, _p(p["xh_e"][0]), self.ldx, self.hoff, _p(p["c_e"][0]), rows, n, H,
+              _stream())
+        d = SeqLstmDesc(rows, H, self.ldx, self.hoff, n, self.ldraw, t_in * n)
+        for t in range(t_in):
+            x_next = ctypes.c_void_p(x1.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
+            _call("vunet_seq_lstm_gates_train", ctypes.byref(d), _p(self.enc_w), _p(p["xh_e"][t]), _p(self.enc_b), _p(p["c_e"][t]),
+                  _p(p["c_e"][t + 1]), _p(p["xh_e"][t + 1]), _p(p["pre"]) if t == t_in - 1 else None, x_next, _p(p["gates_e"][t]), _stream())
+        w, bias = self.heads
+        dl = SeqLinearDesc(rows, H, H, H, ACT_NONE, ACT_NONE, 2, 1, 1)
+        linear(dl, w, p["pre"], bias, p["heads"])
+        _call("vunet_seq_bottleneck", _p(p["heads"]), H, _p(p["eps"]), _p(p["mu"]), _p(p["logstd"]), _p(p["b"]), rows, H, _stream())
+        b_used = p["eps"] if sample_prior else p["b"]      # ``sample=True``: b is the noise itself (:198-199, :208-209)
+        x0 = ctypes.c_void_p(x2.data_ptr() + start_frame * n * esz)
+        _call("vunet_seq_start", x0, t2 * n, _p(b_used), _p(b_used), _p(p["xraw"]), self.ldraw, _p(p["xh_d"][0]), self.ldx, self.hoff,
+              _p(p["c_d"][0]), rows, n, H, _stream())
+        d = SeqLstmDesc(rows, H, self.ldx, self.hoff, n, self.ldraw, length * n)
+        xs, cs = p["xs"], p["cs"]
+        for t in range(length):
+            _call("vunet_seq_lstm_gates_train", ctypes.byref(d), _p(self.dec_w), _p(p["xh_d"][t]), _p(self.dec_b), _p(p["c_d"][t]),
+                  _p(p["c_d"][t + 1]), _p(p["xh_d"][t + 1]), None, None, _p(p["gates_d"][t]), _stream())
+            _call("vunet_seq_decoder_out", ctypes.byref(d), _p(p["xh_d"][t + 1]), _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()),
+                  _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), _stream())
+
+    # ---- backward
+    def _issue_train_backward(self, rows, p, t_in, length, sample_prior: bool, gpre: Optional[torch.Tensor] = None):
+        """``p['gxs']`` = d loss / d xs, ``p['gmu']`` / ``p['glogstd']`` = the loss's direct gradients wrt the heads.  Leaves the
+        weight gradients as images in ``p`` (``_unpack_grads`` turns them into torch's layout)."""
+        dec = self.net.decoder
+        n, H, esz = self.n, self.H, 4
+        s_d, s_e, s_h = p["S"]
+        w_out = dec.n_out.weight.detach()
+        for t in reversed(range(length)):
+            first = t == length - 1
+            d = SeqCellBwdDesc(rows, H, n, s_d, self.ldx, self.hoff, 3 if first else 0, 0, length * n)
+            _call("vunet_seq_cell_bwd", ctypes.byref(d), None if first else _p(p["raw_d"]), _p(w_out),
+                  ctypes.c_void_p(p["gxs"].data_ptr() + t * n * esz), None if first else _p(p["gx"][t + 1]), _p(p["gx"][t]),
+                  _p(p["gates_d"][t]), _p(p["c_d"][t]), _p(p["c_d"][t + 1]), _p(p["gc"]), _p(p["dgates_d"][t]), _stream())
+            dd = SeqDxDesc(rows, 4 * H, self.ldx, 1, s_d, 0)
+            _call("vunet_seq_dx", ctypes.byref(dd), _p(self.dec_w), None, _p(p["dgates_d"][t]), _p(p["raw_d"]), _stream())
+        # h0 = c0 = b (models/pose_behavior_rnn.py:612-614); b = eps exp(logstd) + mu, or the noise itself
+        _call("vunet_seq_bottleneck_bwd", _p(p["raw_d"]), s_d, self.ldx, self.hoff, _p(p["gc"]), None if sample_prior else _p(p["eps"]),
+              _p(p["logstd"]), _p(p["gmu"]), _p(p["glogstd"]), _p(p["dy"]), rows, H, _stream())
+        if sample_prior:   # b does not depend on the encoder: only the loss's direct terms reach the heads
+            p["dy"][0, :rows].copy_(p["gmu"])
+            p["dy"][1, :rows].copy_(p["glogstd"])
+        dh = SeqDxDesc(rows, H, H, 2, s_h, 0)
+        _call("vunet_seq_dx", ctypes.byref(dh), _p(self.heads[0][0]), _p(self.heads[0][1]), _p(p["dy"]), _p(p["raw_h"]), _stream())
+        if gpre is not None:
+            p["raw_h"][:p["b_pad"] * H].view(p["b_pad"], H)[:rows].add_(gpre)
+        enc_w_h = ctypes.c_void_p(self.enc_w.data_ptr() + self.hoff * esz)
+        for t in reversed(range(t_in)):
+            last = t == t_in - 1
+            d = SeqCellBwdDesc(rows, H, n, 2 * s_h if last else s_e, H, 0, 2 if last else 0, 0, 0)
+            _call("vunet_seq_cell_bwd", ctypes.byref(d), _p(p["raw_h"] if last else p["raw_e"]), None, None, None, None,
+                  _p(p["gates_e"][t]), _p(p["c_e"][t]), _p(p["c_e"][t + 1]), _p(p["gc"]), _p(p["dgates_e"][t]), _stream())
+            if t > 0:   # (h0 of the encoder is a constant)
+                de = SeqDxDesc(rows, 4 * H, H, 1, s_e, self.ldx)
+                _call("vunet_seq_dx", ctypes.byref(de), enc_w_h, None, _p(p["dgates_e"][t]), _p(p["raw_e"]), _stream())
+        _call("vunet_seq_dw", _p(p["dw"]["table"]), p["dw"]["n"], 0, p["dw"]["tiles"], rows, None, _stream())
+
+    def _unpack_grads(self, p, out: Dict[str, torch.Tensor]):
+        """The images of the sweep -> ``out[name]`` (tensors in the parameters' shapes, written in place)."""
+        net = self.net
+        n, H = self.n, self.H
+        _call("vunet_seq_lstm_grads_unpack", _p(p["g_dec"]), _p(p["gb_dec"]), self.ldx, self.hoff, n, H, _p(out["decoder.rnn.weight_ih"]),
+              _p(out["decoder.rnn.weight_hh"]), _p(out["decoder.rnn.bias_ih"]), _p(out["decoder.rnn.bias_hh"]), _stream())
+        _call("vunet_seq_lstm_grads_unpack", _p(p["g_enc"]), _p(p["gb_enc"]), self.ldx, self.hoff, n, H, _p(out["b_enc.rnn.weight_ih_l0"]),
+              _p(out["b_enc.rnn.weight_hh_l0"]), _p(out["b_enc.rnn.bias_ih_l0"]), _p(out["b_enc.rnn.bias_hh_l0"]), _stream())
+        _call("vunet_seq_unpack_rows", _p(p["g_out"]), H, 0, 0, 1, _p(out["decoder.n_out.weight"]), n, H, 0, _stream())
+        _call("vunet_seq_unpack_rows", _p(p["gb_out"]), 64, 0, 0, 1, _p(out["decoder.n_out.bias"]), 1, n, 0, _stream())
+        for tag, head, g, gb in (("mu_fn", net.b_enc.mu_fn, p["g_mu"], p["gb_mu"]), ("std_fn", net.b_enc.std_fn, p["g_std"], p["gb_std"])):
+            v, gg, bias, gamma, beta = head._params()
+            q = f"b_enc.{tag}."
+            _call("vunet_seq_normlinear_bwd", _p(g), _p(gb), _p(v.detach()), _p(gg.detach()), _p(bias.detach()), _p(gamma.detach()), H, H,
+                  _p(out[q + "conv.weight_v"]), _p(out[q + "conv.weight_g"]), _p(out[q + "conv.bias"]), _p(out[q + "gamma"]),
+                  _p(out[q + "beta"]), _stream())
+
+    def grad_names(self):
+        return [n for n, _ in self.net.named_parameters()]
+
+    # ---- autograd's view
+    def train_forward(self, x1, x2, length, start_frame, eps, sample_prior):
+        _need_device(x1, x2, eps)
+        _lib.lib()
+        self._check()
+        rows, t_in, t2 = x1.shape[0], x1.shape[1], x2.shape[1]
+        if not 1 <= rows <= 64:
+            raise ValueError(f"the behaviour net's training step takes one batch of 1..64 rows, got {rows}")
+        if x1.shape[2] != self.n or x2.shape[2] != self.n or x2.shape[0] != rows:
+            raise ValueError(f"forward: sequences {tuple(x1.shape)}, {tuple(x2.shape)} for {self.n} pose dimensions")
+        start_frame = start_frame % t2
+        p = self._tplan(rows, t_in, t2, length)
+        p["x1"].copy_(x1)
+        p["x2"].copy_(x2)
+        p["eps"].copy_(eps)
+        self._fill_images()
+        self._issue_train_forward(rows, p, t_in, t2, length, start_frame, sample_prior)
+        self._generation += 1
+        return p, (rows, t_in, t2, length, sample_prior, self._generation)
+
+    def train_backward(self, token, gxs, gcs, gb, gmu, glogstd, gpre):
+        rows, t_in, t2, length, sample_prior, gen = token
+        if gen != self._generation:
+            raise RuntimeError("the net was run again before this pass's backward: its saved activations are gone "
+                               "(one forward / backward pair at a time)")
+        p = self._tplan(rows, t_in, t2, length)
+        p["gxs"].zero_()
+        if gxs is not None:
+            p["gxs"].copy_(gxs)
+        if gcs is not None:      # cs[t] is the input of step t: x_start for t = 0, xs[t - 1] after (:618-620)
+            p["gxs"][:, :-1].add_(gcs[:, 1:])
+        p["gmu"].zero_()
+        p["glogstd"].zero_()
+        if gmu is not None:
+            p["gmu"].copy_(gmu)
+        if glogstd is not None:
+            p["glogstd"].copy_(glogstd)
+        if gb is not None and not sample_prior:   # b = eps exp(logstd) + mu
+            p["gmu"].add_(gb)
+            p["glogstd"].add_(gb * p["eps"] * torch.exp(p["logstd"]))
+        self._issue_train_backward(rows, p, t_in, length, sample_prior, gpre)
+        out = {n: torch.empty_like(q) for n, q in self.net.named_parameters()}
+        self._unpack_grads(p, out)
+        self._generation += 1
+        return out
+
+
+class _BehaviorFn(torch.autograd.Function):
+    """``ResidualBehaviorNet.forward`` as one autograd node (inputs are data: no gradient wrt the sequences)."""
+
+    @staticmethod
+    def forward(ctx, engine, names, x1, x2, length, start_frame, eps, sample_prior, *params):
+        p, token = engine.train_forward(x1, x2, length, start_frame, eps, sample_prior)
+        ctx.engine, ctx.names, ctx.token = engine, names, token
+        ctx.set_materialize_grads(False)
+        b = p["eps"] if sample_prior else p["b"]
+        return p["xs"].clone(), p["cs"].clone(), b.clone(), p["mu"].clone(), p["logstd"].clone(), p["pre"][:x1.shape[0]].clone()
+
+    @staticmethod
+    def backward(ctx, gxs, gcs, gb, gmu, glogstd, gpre):
+        grads = ctx.engine.train_backward(ctx.token, gxs, gcs, gb, gmu, glogstd, gpre)
+        return (None,) * 8 + tuple(grads[n] if ctx.needs_input_grad[8 + i] else None for i, n in enumerate(ctx.names))
+
+
+def behavior_autograd(engine: BehaviorTrainEngine, x1, x2, length, start_frame, eps, sample_prior):
+    """(xs, cs, b, mu, logstd, pre) with a graph whose backward is the HIP back-propagation through time."""
+    named = list(engine.net.named_parameters())
+    return _BehaviorFn.apply(engine, [n for n, _ in named], x1.contiguous(), x2.contiguous(), int(length), int(start_frame), eps,
+                             bool(sample_prior), *[q for _, q in named])

@@ -48,9 +48,10 @@ typedef struct vunet_seq_adam_hp {
   float beta1, beta2, eps, weight_decay;
 } vunet_seq_adam_hp;
 
-/* dX = dZ . W: w_n [M][K] (nets <= 2), dz [nets][Bp][M], raw [nets][S][Bp][K].  K % 64 == 0, M % (16 S) == 0, B <= 64. */
+/* dX = dZ . W: w_n [M][ldw] (nets <= 2; columns 0 .. K of each row are used: ldw = 0 means K), dz [nets][Bp][M],
+ * raw [nets][S][Bp][K].  K % 64 == 0, M % (16 S) == 0, ldw % 4 == 0, B <= 64. */
 typedef struct vunet_seq_dx_desc {
-  int32_t B, M, K, nets, S;
+  int32_t B, M, K, nets, S, ldw;
 } vunet_seq_dx_desc;
 int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw, void* stream);
 
@@ -85,7 +86,9 @@ typedef struct vunet_seq_dw_layer {
   int32_t M, K, ldz, ldx, tile0, tiles_k;
   int32_t kv;        /* valid columns: the gradient of columns >= kv is forced to zero (an MLP's first layer reads its input from
                         rows that continue with other data beyond its c1 columns; its padding columns must stay zero) */
-  int32_t pad;
+  int32_t nchunk;    /* the reduction runs over nchunk blocks of Bp rows (a recurrent layer: one block per time step):
+                        block i at dz + i chunk_z, x + i chunk_x (floats); 0 or 1: a single block */
+  int32_t chunk_z, chunk_x;
 } vunet_seq_dw_layer;
 int vunet_seq_dw(const vunet_seq_dw_layer* table_dev, int32_t n_layers, int32_t first_tile, int32_t n_tiles, int32_t B,
                  const vunet_seq_adam_hp* hp, void* stream);
@@ -113,6 +116,52 @@ int vunet_seq_adam_tick(int64_t* step_dev, void* stream);
 /* dst[m][k] = src[(row_off + row_mul m) ld_src + col_off + k] (the inverse of vunet_seq_pack_rows; `accumulate`: +=) */
 int vunet_seq_unpack_rows(const float* src, int32_t ld_src, int32_t col_off, int32_t row_off, int32_t row_mul, float* dst, int32_t M,
                           int32_t K, int32_t accumulate, void* stream);
+
+/* ---- the behaviour cVAE's step (experiments/behavior_net.py:591-660; models/pose_behavior_rnn.py:125-209, :463-534, :574-626):
+ * back-propagation through time over the decoder's roll-out and the encoder's LSTM.
+ *
+ *   vunet_seq_lstm_gates_train   vunet_seq_lstm_gates (vunet_hip.h) that also keeps the step's gate activations:
+ *                                gates_out [Bp][H][4] = sigmoid(i), sigmoid(f), tanh(g), sigmoid(o)
+ *   vunet_seq_cell_bwd           one LSTM step backwards, pointwise part.  For batch row b, unit j:
+ *                                  dh = sum_s hsl[s][b][hoff_sl + j]                        (the later step's W_hh^T dgates, raw slabs of vunet_seq_dx)
+ *                                     + sum_r w_out[r][j] gx[b][r]                          (decoder: x' = W_out h + b_out + x)
+ *                                  dc = gc[b][j] + dh o (1 - tanh(c')^2);  gc[b][j] <- dc f  (in place)
+ *                                  `first`: bit 0 -- no later step: hsl / gx_next are not read; bit 1 -- gc is taken as 0
+ *                                  dgates[b][j][0..4) = dc g i(1-i), dc c f(1-f), dc i (1-g^2), dh tanh(c') o(1-o)
+ *                                  (c = c_prev: the state the step started from, c' = c_new; gates = the kept activations)
+ *                                decoder (w_out != NULL): gx[b][r] = gl[b][r] (d loss / d x' of this step, row at + b gl_stride)
+ *                                  + gx_next[b][r] + sum_s hsl[s][b][r] (the later step's residual and W_ih^T dgates; absent with bit 0 of `first`),
+ *                                  also written to gx_out [Bp][64] (the output layer's dZ).
+ *   vunet_seq_bottleneck_bwd     b = eps exp(logstd) + mu (models/pose_behavior_rnn.py:203-206) with h0 = c0 = b (:612-614):
+ *                                  G = sum_s hsl[s][b][hoff_sl + j] + gc[b][j];  dy[0] = dmu + G;  dy[1] = dlogstd + G eps exp(logstd)
+ *   vunet_seq_vae_loss           recon = mean (xs - target)^2 (nn.MSELoss(reduction none) + mean, :358, :134-149), kl = kl_loss(mu, logstd)
+ *                                (lib/losses.py:283-291), loss = w recon + gamma kl (:606-611); gamma read from the device and -- `gamma_step`
+ *                                > 0 -- advanced for the NEXT step as __update_gamma does after the optimiser step (:111-116, :655):
+ *                                gamma <- max(gamma - gamma_step (imax - kl), 0).  scalars = loss, recon, kl, gamma used; per_seq[t] =
+ *                                mean over batch and dims of step t's squared error.  dxs = w 2 (xs - target) / (B T n);
+ *                                dmu = gamma mu / B; dlogstd = gamma (exp(2 logstd) - 1) / B.   `part`: scratch of T + B floats.
+ *   vunet_seq_normlinear_bwd     NormConv2d 1x1 as a linear layer, W_eff = gamma g v / ||v||, b_eff = gamma bias + beta: from dW_eff [M][K]
+ *                                and db_eff [M] the gradients of v [M][K], g, bias, gamma, beta [M]
+ *   vunet_seq_lstm_grads_unpack  the gate-interleaved image gradient [4H][ldx] = [dW_ih | . | dW_hh] and bias gradient [4H] -> torch's
+ *                                layout: dW_ih [4H][n], dW_hh [4H][H], db_ih = db_hh [4H] (row q H + j <- image row 4 j + q) */
+typedef struct vunet_seq_cell_bwd_desc {
+  int32_t B, H, n, n_sl, ld_sl, hoff_sl, first, pad;
+  int64_t gl_stride;
+} vunet_seq_cell_bwd_desc;
+int vunet_seq_lstm_gates_train(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm, const float* c_in,
+                               float* c_out, float* xh_next, float* h_out, const float* x_next, float* gates_out, void* stream);
+int vunet_seq_cell_bwd(const vunet_seq_cell_bwd_desc* d, const float* hsl, const float* w_out, const float* gl, const float* gx_next,
+                       float* gx_out, const float* gates, const float* c_prev, const float* c_new, float* gc, float* dgates,
+                       void* stream);
+int vunet_seq_bottleneck_bwd(const float* hsl, int32_t n_sl, int32_t ld_sl, int32_t hoff_sl, const float* gc, const float* eps,
+                             const float* logstd, const float* dmu, const float* dlogstd, float* dy, int32_t B, int32_t H, void* stream);
+int vunet_seq_vae_loss(const float* xs, const float* target, const float* mu, const float* logstd, int32_t B, int32_t T, int32_t n,
+                       int32_t H, float recon_weight, float* gamma_dev, const float* imax_dev, float gamma_step, float* part,
+                       float* scalars, float* per_seq, float* dxs, float* dmu, float* dlogstd, void* stream);
+int vunet_seq_normlinear_bwd(const float* dweff, const float* dbeff, const float* v, const float* g, const float* bias, const float* gamma,
+                             int32_t M, int32_t K, float* dv, float* dg, float* dbias, float* dgamma, float* dbeta, void* stream);
+int vunet_seq_lstm_grads_unpack(const float* gimg, const float* gbias, int32_t ldx, int32_t hoff, int32_t n, int32_t H, float* dwih,
+                                float* dwhh, float* dbih, float* dbhh, void* stream);
 
 #ifdef __cplusplus
 }

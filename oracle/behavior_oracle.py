@@ -17,7 +17,10 @@ A functional (state-dict driven) restatement in plain PyTorch-CPU fp32 of
   initialisation (lib/modules.py:270-290, :303-305) and the step ``latent_flow(bs.detach())`` -> ``flow_loss`` ->
   ``zero_grad`` / ``backward`` / ``step`` (experiments/behavior_net.py:703-714) with the optimiser of :384-395.  Gradients
   come from torch.autograd over the functions of this file and the update from ``torch.optim.Adam`` -- the third-party
-  pieces the reference itself uses for them.  Pinned by ``tests/golden/g10_flow_training.npz``.
+  pieces the reference itself uses for them.  Pinned by ``tests/golden/g10_flow_training.npz``;
+* the cVAE stage of the same loop (experiments/behavior_net.py:591-660 with ``get_loss`` :134-149, ``kl_loss``
+  lib/losses.py:283-291, the gamma controller :111-116, ``Adam(to_optim, lr_init)`` :324-336), ``use_regressor`` off -- with it
+  on the reference's own step raises on torch >= 1.5 (recorded in the fixture).  Pinned by ``tests/golden/g11_cvae_training.npz``.
 
 Every function cites the reference lines it follows (paths relative to the upstream repository root) and takes a
 flat ``sd`` mapping with the reference's state-dict key names, so the product modules' ``state_dict()`` can be fed
@@ -276,6 +279,65 @@ def behavior_net_forward(sd: SD, x1: Tensor, x2: Tensor, length: int, start_fram
     b, mu, logstd, pre = infer_b(sd, x1, eps, sample_noise)
     xs, cs = generate_seq(sd, b, x2, length, start_frame)
     return xs, cs, b, mu, logstd, pre
+
+
+# --------------------------------------------------------------------------
+# the cVAE stage's optimisation step -- experiments/behavior_net.py:591-660, :111-116, :134-149, :329-336; lib/losses.py:283-291
+# --------------------------------------------------------------------------
+def kl_loss(mu: Tensor, logstd: Tensor) -> Tensor:
+    """lib/losses.py:283-291: mean over the batch of sum(-logstd + 0.5 (std^2 + mu^2)) - 0.5 dim."""
+    dim = mu.shape[1]
+    std = torch.exp(logstd)
+    return (torch.sum(-logstd + 0.5 * (std ** 2 + mu ** 2), dim=-1) - 0.5 * dim).mean()
+
+
+def behavior_parameters(sd: SD) -> Tuple[List[str], List[str]]:
+    """(encoder names, decoder names) in ``named_parameters()`` order: the two Adam param groups "z_enc" and "dec"
+    (experiments/behavior_net.py:324-327)."""
+    enc = [f"b_enc.rnn.{n}_l0" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    for h in ("mu_fn", "std_fn"):
+        if f"b_enc.{h}.gamma" in sd:
+            enc += [f"b_enc.{h}.{n}" for n in ("beta", "gamma", "conv.bias", "conv.weight_g", "conv.weight_v")]
+    dec = [f"decoder.rnn.{n}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] + ["decoder.n_out.weight", "decoder.n_out.bias"]
+    if "decoder.n_in.weight" in sd:
+        dec += ["decoder.n_in.weight", "decoder.n_in.bias"]
+    return enc, dec
+
+
+def behavior_optimizer(sd: SD, lr: float):
+    """``Adam([{"params": net.b_enc.parameters(), "name": "z_enc"}, {"params": net.decoder.parameters(), "name": "dec"}],
+    lr=lr_init)`` (experiments/behavior_net.py:324-336) over the leaves of ``sd``."""
+    enc, dec = behavior_parameters(sd)
+    return torch.optim.Adam([{"params": [sd[n].requires_grad_(True) for n in enc], "name": "z_enc"},
+                             {"params": [sd[n].requires_grad_(True) for n in dec], "name": "dec"}], lr=lr)
+
+
+def update_gamma(gamma: float, avg_kl: float, gamma_step: float, imax: float) -> float:
+    """``__update_gamma`` (experiments/behavior_net.py:111-116)."""
+    return max(gamma - gamma_step * (imax - avg_kl), 0)
+
+
+def cvae_train_step(sd: SD, opt, kps: Tensor, eps: Tensor, gamma: float, recon_loss_weight: float, gamma_step: float, imax: float):
+    """One step of ``train_fn`` with ``only_flow`` and ``use_regressor`` off (experiments/behavior_net.py:591-660):
+    ``prepare_input`` (lib/utils.py:914-917), ``net(seq_b, seq_b, seq_len)``, ``get_loss`` (:134-149), ``kl_loss``,
+    ``loss = recon_loss_weight * recon + gamma * kl`` (:606-611; ``cvae: False``), ``zero_grad`` / ``backward`` / ``step``, then the
+    gamma update.  The second ``net(seq_2, ...)`` pass of the reference (:600-603) feeds nothing and is not restated.
+    -> (log, new gamma, (xs, b))."""
+    seq_b, target = kps[:, :-1], kps[:, 1:]
+    seq_len = seq_b.shape[1]
+    xs, cs, b, mu, logstd, pre = behavior_net_forward(sd, seq_b, seq_b, seq_len, 0, eps=eps)
+    r = F.mse_loss(xs, target, reduction="none")
+    recon, per_seq = torch.mean(r), torch.mean(r, dim=[0, 2])
+    kl = kl_loss(mu, logstd)
+    loss = recon_loss_weight * recon + gamma * kl
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    new_gamma = update_gamma(gamma, float(kl.detach()), gamma_step, imax)
+    log = {"loss": float(loss.detach()), "loss_recon": float(recon.detach()), "kl_loss": float(kl.detach()), "gamma_used": gamma,
+           "gamma": new_gamma, "mu_s": float(mu.detach().mean()), "logstd_s": float(logstd.detach().mean()),
+           "loss_per_seq_recon": per_seq.detach()}
+    return log, new_gamma, (xs.detach(), b.detach())
 
 
 # --------------------------------------------------------------------------

@@ -845,6 +845,87 @@ def g10_flow_training():
     save("g10_flow_training", meta, arrays)
 
 
+def g11_cvae_training():
+    """BASELINE config 4, first stage (experiments/behavior_net.py:591-660 with ``get_loss`` :134-149, ``kl_loss``
+    lib/losses.py:283-291, the gamma controller :111-116 and ``Adam(to_optim, lr=lr_init)`` :329-336): the reference's own
+    ``ResidualBehaviorNet`` driven for K = 3 steps as ``train_fn`` drives it -- ``net(seq_b, seq_b, seq_len)``, recon =
+    mean(MSELoss(reduction none)), ``loss = recon_loss_weight * recon + gamma * kl``, ``zero_grad`` / ``backward`` / ``step``,
+    then the gamma update -- with recorded reparametrisation noise.  ``use_regressor`` is off: with it on the reference's
+    step cannot run on torch >= 1.5 (the regressor's weights are stepped in place between the loss's forward and its
+    backward, :636-653); the fixture records the error the reference raises here."""
+    from models import pose_behavior_rnn as rb
+    seed = 111
+    n_kps, hid, bsz, t_len = 51, 64, 5, 6
+    w_recon, gamma, gamma_step, imax, lr = 2.5, 0.05, 1e-3, 5.0, 1e-3
+    torch.manual_seed(seed)
+    net = rb.ResidualBehaviorNet(n_kps=n_kps, information_bottleneck=True, decoder_arch="lstm", linear_in_decoder=False,
+                                 dim_hidden_b=hid)
+    sd = behavior_state(net, seed)
+    net.train()
+    net.b_enc.init_hidden = lambda bs, device: rb.BEncoder.init_hidden(net.b_enc, bs, "cpu")   # get_device() is -1 on CPU
+    opt = torch.optim.Adam([{"params": net.b_enc.parameters(), "name": "z_enc"}, {"params": net.decoder.parameters(), "name": "dec"}],
+                           lr=lr)
+    rec_loss = torch.nn.MSELoss(reduction="none")
+    meta = {"seed": seed, "steps": 3, "kw": dict(n_kps=n_kps, information_bottleneck=True, decoder_arch="lstm", linear_in_decoder=False,
+                                                 dim_hidden_b=hid),
+            "batch": bsz, "seq_len": t_len, "recon_loss_weight": w_recon, "gamma_init": gamma, "gamma_step": gamma_step, "imax": imax,
+            "lr": lr, "shapes": {k: list(v.shape) for k, v in sd.items()}, "logs": []}
+    arrays = {}
+    for it in range(meta["steps"]):
+        kps = 0.5 * seeded_randn(f"cvae.kps{it}", (bsz, t_len + 1, n_kps), seed)
+        seq_b, target = kps[:, :-1], kps[:, 1:]                      # prepare_input (lib/utils.py:914-917)
+        with FixedNoise(f"cvae.s{it}", seed) as fn:
+            xs, cs, _, bs, mu, logstd, pre = net(seq_b, seq_b, t_len)
+        r = rec_loss(xs, target)
+        recon, per_seq = torch.mean(r), torch.mean(r, dim=[0, 2])
+        kl = rl.kl_loss(mu, logstd)
+        loss = w_recon * recon + gamma * kl
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        used = gamma
+        gamma = max(gamma - gamma_step * (imax - float(kl)), 0)
+        meta["logs"].append({"loss": float(loss), "loss_recon": float(recon), "kl_loss": float(kl), "gamma_used": used, "gamma": gamma,
+                             "mu_s": float(torch.mean(mu)), "logstd_s": float(torch.mean(logstd))})
+        arrays[f"per_seq{it}"] = per_seq.detach().numpy()
+        if it == 0:
+            arrays["xs0"], arrays["bs0"] = xs.detach().numpy(), bs.detach().numpy()
+            # the gradients of the first step, before the update (zero_grad ran before backward)
+    meta["noise_shapes"] = fn.shapes
+    fin = net.state_dict()
+    meta["checksums"] = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in fin.items()}
+    for k, v in fin.items():
+        arrays[f"final.{k}"] = (v[:24] if v.dim() == 2 and v.shape[0] > 64 else v).numpy()
+    names = [n for n, _ in net.named_parameters()]
+    st = opt.state_dict()["state"]
+    for n in ("decoder.rnn.weight_hh", "b_enc.mu_fn.conv.weight_v", "decoder.n_out.bias"):
+        e = st[names.index(n)]
+        arrays[f"exp_avg.{n}"] = (e["exp_avg"][:24] if e["exp_avg"].dim() == 2 and e["exp_avg"].shape[0] > 64 else e["exp_avg"]).numpy()
+    meta["adam_step"] = int(st[0]["step"])
+    # the regressor path of the reference's step, as it stands, on this torch
+    try:
+        reg = rb.Regressor_fly(hid, n_kps)
+        ropt = torch.optim.Adam(reg.parameters(), lr=1e-4)
+        kps = 0.5 * seeded_randn("cvae.kpsr", (bsz, 51, n_kps), seed)
+        seq_b = kps[:, :-1]
+        with FixedNoise("cvae.sr", seed):
+            xs, cs, _, bs, mu, logstd, pre = net(seq_b, seq_b, 50)
+        loss = torch.mean(rec_loss(xs, kps[:, 1:]))
+        for _ in range(5):
+            idx = torch.randint(0, 50, (1,))
+            oh = torch.nn.functional.one_hot(idx.repeat(mu.size(0)), num_classes=50)
+            lreg = torch.mean((reg(mu, oh.float()) - seq_b[:, idx].squeeze()) ** 2)
+            ropt.zero_grad()
+            lreg.backward(retain_graph=True)
+            ropt.step()
+        loss -= torch.clamp(lreg, max=0.45) * 0.01
+        loss.backward()
+        meta["regressor_path"] = "ran"
+    except RuntimeError as e:
+        meta["regressor_path"] = "RuntimeError: " + str(e).split("\n")[0][:160]
+    save("g11_cvae_training", meta, arrays)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -867,3 +948,4 @@ if __name__ == "__main__":
     g8_pretrained_dir()
     g9_behavior()
     g10_flow_training()
+    g11_cvae_training()

@@ -482,3 +482,40 @@ def test_g10_flow_training_trajectory(tag):
             if k.startswith(f"{tag}.{kind}."):
                 # (gradient-sized entries; small ones carry the fp32 summation-order noise of the large ones)
                 close(st[names.index(k[len(tag) + len(kind) + 2:])][kind], v, rtol=1e-4, atol=1e-5 * float(np.abs(v).max()))
+
+
+def test_g11_cvae_training_trajectory():
+    """Three steps of the cVAE stage (experiments/behavior_net.py:591-660) vs the reference's own ResidualBehaviorNet + losses +
+    torch.optim.Adam + gamma controller."""
+    from oracle import behavior_oracle as B
+    from synth import synth_behavior_state
+    meta, arr = load_golden("g11_cvae_training")
+    seed = meta["seed"]
+    sd = synth_behavior_state(meta["shapes"], seed, {})
+    opt = B.behavior_optimizer(sd, meta["lr"])
+    bsz, t_len, n_kps, hid = meta["batch"], meta["seq_len"], meta["kw"]["n_kps"], meta["kw"]["dim_hidden_b"]
+    gamma = meta["gamma_init"]
+    assert meta["noise_shapes"] == [[bsz, hid]] and meta["regressor_path"].startswith("RuntimeError")
+    for it in range(meta["steps"]):
+        kps = 0.5 * seeded_randn(f"cvae.kps{it}", (bsz, t_len + 1, n_kps), seed)
+        eps = seeded_randn(f"cvae.s{it}.eps0", (bsz, hid), seed)
+        log, gamma, (xs, b) = B.cvae_train_step(sd, opt, kps, eps, gamma, meta["recon_loss_weight"], meta["gamma_step"], meta["imax"])
+        for k, v in meta["logs"][it].items():
+            assert abs(log[k] - v) <= 1e-5 * abs(v) + 1e-6, (it, k, log[k], v)
+        close(log["loss_per_seq_recon"], arr[f"per_seq{it}"], rtol=1e-5, atol=1e-6)
+        if it == 0:
+            close(xs, arr["xs0"], rtol=1e-5, atol=1e-6)
+            close(b, arr["bs0"], rtol=1e-5, atol=1e-6)
+    for k, v in arr.items():
+        if k.startswith("final."):
+            t = sd[k[6:]].detach()
+            close(t[:24] if t.dim() == 2 and t.shape[0] > 64 else t, v, rtol=1e-4, atol=1e-6)
+    for k, (s, a) in meta["checksums"].items():
+        assert abs(float(sd[k].detach().double().abs().sum()) - a) <= 1e-5 * a + 1e-6, k
+    enc, dec = B.behavior_parameters(sd)
+    names, st = enc + dec, opt.state_dict()["state"]
+    assert int(st[0]["step"]) == meta["adam_step"]
+    for k, v in arr.items():
+        if k.startswith("exp_avg."):
+            e = st[names.index(k[8:])]["exp_avg"]
+            close(e[:24] if e.dim() == 2 and e.shape[0] > 64 else e, v, rtol=1e-4, atol=1e-5 * float(np.abs(v).max()))
