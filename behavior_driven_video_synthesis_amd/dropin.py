@@ -7,8 +7,13 @@
 ``lib.modules``, ``lib.losses``, ``models.vunets``, ``models.imagenet_pretrained``, ``models.synth_discriminator``,
 ``models.pose_behavior_rnn``, ``models.flow.blocks``, ``models.flow.simple_flow`` -- so
 ``experiments/shape_and_pose_net.py``'s ``from models.vunets import VunetAlter`` (:10), ``from lib.losses import vgg_loss``
-and friends resolve to the HIP-backed classes without a single edited line.  Each alias is a HYBRID module: names this
-package defines come from here; every other name (the flow / behaviour-net building blocks of ``lib/modules.py:236-707``,
+and friends resolve to the HIP-backed classes without a single edited line.  ``UnsupervisedTransformer2`` and
+``ResidualBehaviorNet`` train under autograd on this path (``experiments/behavior_net.py:591-714``: csrc/seq_train.hip,
+csrc/seq_bptt.hip), so an unchanged ``main.py --config config/behavior_net.yaml`` runs both of its stages.  Each alias is a
+HYBRID module: names this package defines come from here -- except ``HIDDEN`` ones, the flat-input building blocks of
+``lib/modules.py`` (``ActNorm``, ``BasicFullyConnectedNet``) that the reference's OTHER flows (``ConditionalFlow``,
+``SupervisedTransformer``, ... in its own ``models/flow/blocks.py``) import by name and use on 4-d inputs and under autograd:
+those keep getting the reference's own classes; every other name (the flow / behaviour-net building blocks of ``lib/modules.py:236-707``,
 the sequence losses of ``lib/losses.py``, ...) falls through to the reference's own file, loaded from the checkout under a
 private name, so the experiments outside the hot path keep working.  ``lib`` / ``models`` stay the checkout's namespace
 packages; only these sub-modules are replaced.
@@ -40,10 +45,15 @@ ALIASES = {
 }
 
 
+# names this package defines for its own modules' use but does NOT export under the reference's module name
+HIDDEN = {"lib.modules": ("ActNorm", "BasicFullyConnectedNet", "Linear", "_Marker")}
+
+
 def _hybrid(alias: str, ours, ref_root: str):
     """Module ``alias`` whose attributes come from ``ours`` first, then from the reference's own file (loaded lazily)."""
     mod = types.ModuleType(alias, doc=f"{ours.__name__} (MI355X path) over the reference's {alias}")
-    mod.__dict__.update({k: v for k, v in vars(ours).items() if not k.startswith("__")})
+    hidden = HIDDEN.get(alias, ())
+    mod.__dict__.update({k: v for k, v in vars(ours).items() if not k.startswith("__") and k not in hidden})
     mod.__vunet_hip_alias__ = ours.__name__
     ref_file = os.path.join(ref_root, *alias.split(".")) + ".py"
     state = {"ref": None, "tried": False}

@@ -102,6 +102,7 @@ class ShapePoseNet:
             self._gan_rng = torch.Generator().manual_seed(config["general"].get("seed", 42) + 7919)
             self._gan_off = torch.zeros(2, dtype=torch.int32, device=self.device)   # this step's window corner (oy, ox)
         # ---- data parallel (replaces nn.DataParallel, :213-214)
+        self._pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if self.world > 1:
             # every rank seeds torch alike (same initial weights), but the ranks are different SAMPLES of the global batch:
@@ -224,11 +225,14 @@ class ShapePoseNet:
         return (self.vunet, self.gan.disc) if self.gan is not None else (self.vunet,)
 
     def _capture_agreed(self, ok_here: bool) -> bool:
-        """True iff EVERY rank recorded the step (single process: this one did)."""
+        """True iff EVERY rank of the trainer's process group recorded the step (single process: this one did).  Reached when a
+        rank meets a new graph key: batch shapes -- hence keys -- must be the same on every rank at every step (the
+        data-parallel contract: equal per-rank batches), or the ranks would not enter this reduction together."""
         if not (self.averager.active and dist.is_initialized() and self.world > 1):
             return ok_here
-        flag = torch.tensor([1 if ok_here else 0], device=self.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        pg = getattr(self, "_pg", None)
+        flag = torch.tensor([1 if ok_here else 0], device=self.device if dist.get_backend(pg) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
         return int(flag.item()) == 1
 
     def _train_fn_graph_on_stream(self, batch, it, eps, reg_eps):

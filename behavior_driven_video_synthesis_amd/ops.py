@@ -850,12 +850,18 @@ class prepacked:
         if prepacked._depth == 0:
             _reset_amax_arena()
         prepacked._depth += 1
-        for model in self.models:
-            cur = _build_prepack_set(model)
-            if cur is not None:
-                _call("vunet_weightnorm_fwd_multi", _p(cur["table"]), cur["n"], cur["max_cout"], _stream())
-                _active_prepack.update(cur["entries"])
-                self._keys.extend(cur["entries"].keys())
+        try:
+            for model in self.models:
+                cur = _build_prepack_set(model)
+                if cur is not None:
+                    _call("vunet_weightnorm_fwd_multi", _p(cur["table"]), cur["n"], cur["max_cout"], _stream())
+                    _active_prepack.update(cur["entries"])
+                    self._keys.extend(cur["entries"].keys())
+        except BaseException:
+            # __exit__ is not called when __enter__ raises: undo what this block added, or stale folded weights would stay
+            # active across optimiser steps and every later outermost block would skip its reset
+            self.__exit__(None, None, None)
+            raise
         return self
 
     def __exit__(self, *a):

@@ -48,6 +48,21 @@ def _need_device(*ts):
             raise RuntimeError("the behaviour path runs on hand-written gfx950 kernels: fp32 device tensors only (no CPU fallback)")
 
 
+def _need_module_on(dev, named):
+    """The kernels take the modules' parameters and buffers as raw pointers: each must be an fp32 (index buffers: integer)
+    tensor on the input's device -- a flow left on the CPU, or cast with .double() / .half(), would otherwise be read as
+    garbage or fault instead of raising the mismatch torch raises."""
+    for name, t in named:
+        if t is None:
+            continue
+        if t.device != dev:
+            raise RuntimeError(f"{name} is on {t.device} but the input is on {dev}: move the module with .to(device) first")
+        if t.dtype.is_floating_point and t.dtype != torch.float32:
+            raise RuntimeError(f"{name} is {t.dtype}: the behaviour path's kernels read fp32 parameters")
+        if not t.dtype.is_floating_point and t.dtype not in (torch.int64, torch.int32, torch.uint8):
+            raise RuntimeError(f"{name} is {t.dtype}: expected an integer index buffer")
+
+
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 
 
@@ -147,6 +162,7 @@ class MlpEngine:
         _need_device(x)
         _lib.lib()
         lin = self.net.linears()
+        _need_module_on(x.device, self.net.named_parameters())
         _inference_only([p for l in lin for p in (l.weight, l.bias)])
         key = _versions([p for l in lin for p in (l.weight, l.bias)])
         if key != self._packed_for:
@@ -177,6 +193,7 @@ def _flat2(x: torch.Tensor) -> torch.Tensor:
 def actnorm_initialize(mod, x: torch.Tensor):
     """lib/modules.py:270-290 on the rows of ``x`` [B, C]; writes ``mod.loc`` / ``mod.scale`` in place."""
     _need_device(x)
+    _need_module_on(x.device, (("ActNorm.loc", mod.loc), ("ActNorm.scale", mod.scale)))
     x2 = _flat2(x).contiguous()
     b, c = x2.shape
     _call("vunet_seq_actnorm_init", _p(x2), c, b, c, _p(mod.loc.data), _p(mod.scale.data), _stream())
@@ -185,6 +202,7 @@ def actnorm_initialize(mod, x: torch.Tensor):
 def actnorm_apply(mod, x: torch.Tensor, reverse: bool):
     """-> (h shaped like x, logdet [B] or None): lib/modules.py:307-316 / :320-331."""
     _need_device(x)
+    _need_module_on(x.device, (("ActNorm.loc", mod.loc), ("ActNorm.scale", mod.scale)))
     _inference_only([mod.loc, mod.scale])
     x2 = _flat2(x).contiguous()
     b, c = x2.shape
@@ -301,11 +319,13 @@ class FlowEngine:
         return self._flow()
 
     # ---- weights
-    def _pack(self):
+    def _pack(self, dev=None):
         params = list(self.flow.parameters()) + list(self.flow.buffers())
         key = _versions(params)
         if key == self._packed_for:
             return
+        if dev is not None:
+            _need_module_on(dev, list(self.flow.named_parameters()) + list(self.flow.named_buffers()))
         blocks = list(self.flow.sub_layers)
         c = self.flow.in_channels
         dev = blocks[0].norm_layer.loc.device
@@ -424,7 +444,7 @@ class FlowEngine:
         _need_device(x)
         _inference_only(self.flow.parameters())
         _lib.lib()
-        self._pack()
+        self._pack(x.device)
         if not reverse and not self._initialised():
             x2 = x.reshape(x.shape[0], -1)
             if x2.shape[0] > MAX_ROWS or x2.shape[0] < 2:
@@ -497,11 +517,13 @@ class BehaviorEngine:
 
     HOFF_PAD = 32     # the hidden part of an operand row [x | 0 | h] starts at this multiple (training: 64, the backward tiles)
 
-    def _pack(self):
+    def _pack(self, dev=None):
         net = self.net
         key = _versions(list(net.parameters()))
         if key == self._packed_for:
             return
+        if dev is not None:
+            _need_module_on(dev, net.named_parameters())
         dec, enc = net.decoder, net.b_enc
         self.n, self.H = dec.n_in_out, dec.n_hidden
         if self.H % 32:
@@ -592,7 +614,7 @@ class BehaviorEngine:
         _need_device(b, x_pose)
         _inference_only(self.net.parameters())
         _lib.lib()
-        self._pack()
+        self._pack(b.device)
         if x_pose.dim() != 3 or x_pose.shape[2] != self.n or b.shape[1] != self.H:
             raise ValueError(f"generate_seq: poses {tuple(x_pose.shape)}, behaviour {tuple(b.shape)}")
         start_frame = start_frame % x_pose.shape[1]
@@ -637,7 +659,7 @@ class BehaviorEngine:
         _need_device(seq, eps)
         _inference_only(self.net.parameters())
         _lib.lib()
-        self._pack()
+        self._pack(seq.device)
         if seq.dim() != 3 or seq.shape[2] != self.n:
             raise ValueError(f"infer_b: sequence {tuple(seq.shape)}")
         res = []

@@ -125,9 +125,9 @@ class FlowTrainEngine(FlowEngine):
         self._side_stream = None
 
     # ---- weights
-    def _pack(self):
+    def _pack(self, dev=None):
         before = self._packed_for
-        super()._pack()
+        super()._pack(dev)
         if self._packed_for == before and getattr(self, "layers", None) is not None:
             return
         dev = self.blocks[0]["scale"].device
@@ -337,15 +337,12 @@ class FlowTrainEngine(FlowEngine):
     def _check_input(self, x: torch.Tensor) -> torch.Tensor:
         _need_device(x)
         _lib.lib()
-        self._pack()
+        self._pack(x.device)
         x2 = x.reshape(x.shape[0], -1)
         if x2.shape[1] != self.C:
             raise ValueError(f"flow over {self.C} channels got {tuple(x.shape)}")
         if not 1 <= x2.shape[0] <= 64:
             raise ValueError(f"the flow's training step takes one batch of 1..64 rows (config/behavior_net.yaml: 64), got {x2.shape[0]}")
-        for t in list(self.flow.parameters()) + list(self.flow.buffers()):
-            if t.device != x.device:
-                raise RuntimeError(f"flow on {t.device}, input on {x.device}")
         return x2
 
     def train_step(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -525,7 +522,7 @@ class BehaviorTrainEngine(BehaviorEngine):
         super().__init__(net)
         self._generation = 0
 
-    def _check(self):
+    def _check(self, dev=None):
         net = self.net
         if net.decoder.use_nin:
             raise NotImplementedError("training with linear_in_decoder=True is not built (config/behavior_net.yaml trains with False): "
@@ -533,7 +530,7 @@ class BehaviorTrainEngine(BehaviorEngine):
         if not net.ib:
             raise NotImplementedError("training without the information bottleneck is not built (experiments/behavior_net.py:310 "
                                       "always constructs the net with information_bottleneck=True)")
-        self._pack()
+        self._pack(dev)
         if self.H % 64:
             raise ValueError("dim_hidden_b must be a multiple of 64 for training on the HIP path")
 
@@ -665,7 +662,7 @@ class BehaviorTrainEngine(BehaviorEngine):
     def train_forward(self, x1, x2, length, start_frame, eps, sample_prior):
         _need_device(x1, x2, eps)
         _lib.lib()
-        self._check()
+        self._check(x1.device)
         rows, t_in, t2 = x1.shape[0], x1.shape[1], x2.shape[1]
         if not 1 <= rows <= 64:
             raise ValueError(f"the behaviour net's training step takes one batch of 1..64 rows, got {rows}")

@@ -272,7 +272,8 @@ def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
     co = tmp_path / "checkout"
     (co / "lib").mkdir(parents=True)
     (co / "models").mkdir()
-    (co / "lib" / "modules.py").write_text("class NormConv2d:\n    ORIGIN = 'checkout'\nclass GINActNorm:\n    ORIGIN = 'checkout'\n")
+    (co / "lib" / "modules.py").write_text("class NormConv2d:\n    ORIGIN = 'checkout'\nclass GINActNorm:\n    ORIGIN = 'checkout'\n"
+                                            "class ActNorm:\n    ORIGIN = 'checkout'\nclass BasicFullyConnectedNet:\n    ORIGIN = 'checkout'\n")
     (co / "lib" / "utils.py").write_text("def helper():\n    return 'checkout utils'\n")
     (co / "lib" / "losses.py").write_text("from lib.utils import helper\nclass FlowLoss:\n    ORIGIN = helper()\n")
     (co / "models" / "vunets.py").write_text("class VunetAlter:\n    ORIGIN = 'checkout'\n")
@@ -282,7 +283,7 @@ def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
     (co / "models" / "pose_behavior_rnn.py").write_text("class ResidualBehaviorNet:\n    ORIGIN = 'checkout'\nclass MTVAE:\n    ORIGIN = 'checkout'\n")
     (co / "main.py").write_text(
         "from models.vunets import VunetAlter, Regressor\n"
-        "from lib.modules import NormConv2d, GINActNorm\n"
+        "from lib.modules import NormConv2d, GINActNorm, ActNorm, BasicFullyConnectedNet\n"
         "from lib.losses import vgg_loss, compute_kl_with_prior, FlowLoss\n"
         "from lib.utils import helper\n"
         "from models.imagenet_pretrained import PerceptualVGG\n"
@@ -295,6 +296,7 @@ def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
         "print('VUNET', VunetAlter.__module__)\n"
         "print('NORMCONV', NormConv2d.__module__)\n"
         "print('ACTNORM', GINActNorm.ORIGIN)\n"
+        "print('FLOWBLOCKS', ActNorm.ORIGIN, BasicFullyConnectedNet.ORIGIN)\n"
         "print('FLOWLOSS', FlowLoss.ORIGIN)\n"
         "print('UTILS', helper())\n"
         "print('VGGLOSS', vgg_loss.__module__, PerceptualVGG.__module__, DiscTrainer.__module__)\n")
@@ -307,6 +309,8 @@ def test_dropin_runs_an_unchanged_main_against_a_checkout(tmp_path):
     assert out["ARGS"] == "['--config', 'x.yaml']"
     assert out["VUNET"] == pkg + ".models.vunets" and out["NORMCONV"] == pkg + ".lib.modules"
     assert out["ACTNORM"] == "checkout" and out["FLOWLOSS"] == "checkout utils" and out["UTILS"] == "checkout utils"
+    # the reference's other flows import these two by name and use them on 4-d inputs under autograd: they stay the checkout's
+    assert out["FLOWBLOCKS"] == "checkout checkout"
     assert out["BEHAVIOR"] == f"{pkg}.models.flow.simple_flow {pkg}.models.pose_behavior_rnn checkout checkout"
     assert out["VGGLOSS"] == f"{pkg}.lib.losses {pkg}.models.imagenet_pretrained {pkg}.models.synth_discriminator"
 

@@ -232,6 +232,38 @@ def test_stand_alone_mlp_and_the_cpu_refusal():
         net(x)
 
 
+def test_a_module_left_on_the_cpu_or_cast_is_refused():
+    """The kernels take parameters as raw pointers: a module on another device than its input, or cast away from fp32, raises
+    before any launch (a CUDA input with host pointers would otherwise fault the GPU)."""
+    from behavior_driven_video_synthesis_amd.lib.modules import ActNorm, BasicFullyConnectedNet
+    from behavior_driven_video_synthesis_amd.models.flow.simple_flow import UnsupervisedTransformer2
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    z = torch.randn(4, 32, device="cuda")
+    flow = UnsupervisedTransformer2(flow_in_channels=32, flow_mid_channels=48, flow_hidden_depth=1, n_flows=1)
+    for blk in flow.flow.sub_layers:
+        blk.norm_layer.initialized.fill_(1)
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        flow.reverse(z)
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        flow(z)
+    with pytest.raises(RuntimeError, match="float64"):
+        flow.cuda().double().reverse(z)
+    assert flow.float().reverse(z).shape == (4, 32, 1, 1)
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        BasicFullyConnectedNet(dim=32, depth=1, hidden_dim=32)(z)
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        ActNorm(32)(z)
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        ActNorm(32).reverse(z)
+    net = ResidualBehaviorNet(51, information_bottleneck=True, decoder_arch="lstm", dim_hidden_b=64)
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        net.generate_seq(torch.randn(2, 64, device="cuda"), torch.randn(2, 3, 51, device="cuda"), len=2, start_frame=0)
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        net.infer_b(torch.randn(2, 3, 51, device="cuda"), False)
+    with pytest.raises(RuntimeError, match="float16"):
+        net.cuda().half().infer_b(torch.randn(2, 3, 51, device="cuda"), False)
+
+
 @pytest.mark.parametrize("stats_dtype", ["float32", "float64"])
 @pytest.mark.parametrize("dims", [51, 96])
 def test_pose_projection_vs_the_reference_numpy_chain(dims, stats_dtype):
@@ -324,17 +356,18 @@ def test_recordings_and_their_buffers_are_capped_together():
     assert torch.equal(first, again)
 
 
-def test_a_recorded_call_is_refused():
-    """No backward is built for the behaviour path: with autograd recording and trainable parameters the modules raise instead
-    of handing back tensors without a graph (a reference training loop driven through the drop-in must not train on nothing)."""
+def test_a_recorded_call_trains_or_is_refused():
+    """With autograd recording and trainable parameters, the flow's forward direction and the behaviour net's forward come back
+    WITH a graph (csrc/seq_train.hip, csrc/seq_bptt.hip: tests/test_hip_seq_train.py); the pieces that have no backward -- the
+    flow's reverse direction, the stand-alone building blocks -- raise instead of handing back tensors without one."""
     from behavior_driven_video_synthesis_amd.lib.modules import ActNorm, BasicFullyConnectedNet
     flow, _ = _random_flow(32, 48, 1, 1, 3)
     z = torch.randn(2, 32, device="cuda")
     with torch.enable_grad():
         with pytest.raises(RuntimeError, match="inference only"):
             flow.reverse(z)
-        with pytest.raises(RuntimeError, match="inference only"):
-            flow(z)
+        out, logdet = flow(z)
+        assert out.requires_grad and logdet.requires_grad
         with pytest.raises(RuntimeError, match="inference only"):
             BasicFullyConnectedNet(dim=16, depth=1, hidden_dim=32).cuda()(z[:, :16])
         with pytest.raises(RuntimeError, match="inference only"):
