@@ -121,7 +121,9 @@ class FlowTrainEngine(FlowEngine):
         self.adam: Optional[AdamState] = None
         self._moments: Dict[str, tuple] = {}
         self._generation = 0
-        self.two_streams = os.environ.get("VUNET_SEQ_TRAIN_STREAMS", "2") != "1"
+        # the update sweep beside the next half's chain on a second stream: measured slower (8.1 vs 7.75 ms per step: the sweep's
+        # 5120 workgroups hold every CU, the chain's 1024-thread workgroups wait for room) -- off unless asked for
+        self.two_streams = os.environ.get("VUNET_SEQ_TRAIN_STREAMS", "1") == "2"
         self._side_stream = None
 
     # ---- weights

@@ -51,7 +51,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
 X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
 FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
 PMC_TRAFFIC_RENDER = ["profiles/r05_pmc_traffic_render.json", "profiles/r04_pmc_traffic_render.json", "profiles/r03_pmc_traffic_render.json"]
-PMC_TRAFFIC_SEQ = ["profiles/r05_pmc_traffic_seq.json"]
+PMC_TRAFFIC_SEQ = ["profiles/r06_pmc_traffic_seq.json", "profiles/r05_pmc_traffic_seq.json"]
+PMC_TRAFFIC_SEQ_TRAIN = ["profiles/r06_pmc_traffic_seq_train.json"]
 PMC_TRAFFIC = ["profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json",
                "profiles/r01_pmc_traffic.json"]
 
@@ -182,6 +183,10 @@ def cpu_baseline_child(path):
         out["behavior"] = _cpu_behavior(cores)
     except Exception as e:   # noqa: BLE001 -- the headline baseline must not depend on this extra row
         out["behavior"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        out["behavior_train"] = _cpu_behavior_train(cores)
+    except Exception as e:   # noqa: BLE001
+        out["behavior_train"] = {"error": f"{type(e).__name__}: {e}"}
     print("CPU_BASELINE " + json.dumps(out))
 
 
@@ -227,6 +232,64 @@ def _cpu_behavior(cores, rows=16, blocks=3, frames=50):
     return {"flow_reverse_ms": 1e3 * t_flow, "decode_ms": 1e3 * t_dec, "rows": rows, "cores": cores, "kind": "port",
             "sample": f"oracle/behavior_oracle.py: flow reverse of {blocks} of the 15 blocks at 1024 / 2048 (x {15 // blocks}: the pass is "
                       f"15 such blocks in sequence) and the full {frames}-step decoder roll-out at 1024 hidden, {rows} rows, median of 5"}
+
+
+def _cpu_behavior_train(cores, rows=64, blocks=2, frames=50):
+    """BASELINE configs[3] on the oracle (PyTorch-CPU fp32: torch.autograd + torch.optim.Adam), bounded: the flow stage's step on
+    ``blocks`` of the 15 blocks at the reference width (x 15 / blocks: the blocks are identical and sequential), and one full
+    cVAE step (1024 hidden, 51 dims, 50 frames), batch 64."""
+    from oracle import behavior_oracle as B
+    g = torch.Generator().manual_seed(4)
+    c, mid, c1 = 1024, 2048, 512
+    sd = {}
+    for i in range(blocks):
+        q = f"flow.sub_layers.{i}"
+        sd[f"{q}.norm_layer.loc"] = 0.1 * torch.randn(1, c, 1, 1, generator=g)
+        sd[f"{q}.norm_layer.scale"] = 0.7 + 0.3 * torch.rand(1, c, 1, 1, generator=g)
+        perm = torch.randperm(c, generator=g)
+        sd[f"{q}.shuffle.forward_shuffle_idx"], sd[f"{q}.shuffle.backward_shuffle_idx"] = perm, torch.argsort(perm)
+        for kind in ("s", "t"):
+            for j in range(2):
+                for li, (o, k) in enumerate([(mid, c1), (mid, mid), (mid, mid), (c1, mid)]):
+                    gain = 0.1 if (kind == "s" and li == 3) else 1.0
+                    sd[f"{q}.coupling.{kind}.{j}.main.{2 * li}.weight"] = gain * torch.randn(o, k, generator=g) * (1.5 / k) ** 0.5
+                    sd[f"{q}.coupling.{kind}.{j}.main.{2 * li}.bias"] = 0.1 * torch.randn(o, generator=g)
+    opt = B.flow_optimizer(sd, 4.5e-7 * rows, 0.0)
+    bs = torch.randn(rows, c, generator=g)
+    B.flow_train_step(sd, opt, bs)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        B.flow_train_step(sd, opt, bs)
+        ts.append(time.perf_counter() - t0)
+    t_flow = statistics.median(ts) * (15.0 / blocks)
+    del sd, opt
+    hid, n = 1024, 51
+    net = {"decoder.rnn.weight_ih": torch.randn(4 * hid, n, generator=g) / hid ** 0.5,
+           "decoder.rnn.weight_hh": torch.randn(4 * hid, hid, generator=g) / hid ** 0.5,
+           "decoder.rnn.bias_ih": 0.1 * torch.randn(4 * hid, generator=g), "decoder.rnn.bias_hh": 0.1 * torch.randn(4 * hid, generator=g),
+           "decoder.n_out.weight": 0.05 * torch.randn(n, hid, generator=g) / hid ** 0.5, "decoder.n_out.bias": 0.1 * torch.randn(n, generator=g),
+           "b_enc.rnn.weight_ih_l0": torch.randn(4 * hid, n, generator=g) / hid ** 0.5,
+           "b_enc.rnn.weight_hh_l0": torch.randn(4 * hid, hid, generator=g) / hid ** 0.5,
+           "b_enc.rnn.bias_ih_l0": 0.1 * torch.randn(4 * hid, generator=g), "b_enc.rnn.bias_hh_l0": 0.1 * torch.randn(4 * hid, generator=g)}
+    for h in ("mu_fn", "std_fn"):
+        net[f"b_enc.{h}.beta"], net[f"b_enc.{h}.gamma"] = torch.zeros(1, hid, 1, 1), torch.ones(1, hid, 1, 1)
+        net[f"b_enc.{h}.conv.bias"], net[f"b_enc.{h}.conv.weight_g"] = torch.zeros(hid), torch.ones(hid, 1, 1, 1)
+        net[f"b_enc.{h}.conv.weight_v"] = torch.randn(hid, hid, 1, 1, generator=g) / hid ** 0.5
+    vopt = B.behavior_optimizer(net, 1e-4)
+    kps, eps = 0.5 * torch.randn(rows, frames + 1, n, generator=g), torch.randn(rows, hid, generator=g)
+    B.cvae_train_step(net, vopt, kps, eps, 0.0, 2.5, 1e-5, 100.0)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        B.cvae_train_step(net, vopt, kps, eps, 0.0, 2.5, 1e-5, 100.0)
+        ts.append(time.perf_counter() - t0)
+    t_vae = statistics.median(ts)
+    return {"flow_stage": {"value": rows / t_flow, "unit": "samples/s", "step_s": t_flow},
+            "cvae_stage": {"value": rows / t_vae, "unit": "sequences/s", "step_s": t_vae}, "rows": rows, "cores": cores, "kind": "port",
+            "sample": f"oracle/behavior_oracle.py (torch.autograd + torch.optim.Adam): the flow stage's step on {blocks} of the 15 blocks at "
+                      f"1024 / 2048 (x {15.0 / blocks:g}: the pass is 15 such blocks in sequence) and one full cVAE step (1024 hidden, 51 "
+                      f"dims, {frames} frames), batch {rows}, median of 3 after 1 warm-up"}
 
 
 def cpu_baseline(args, cfg, batch, cfg1, batch1):
@@ -383,6 +446,80 @@ def behavior_row(vunet, device, size, frames=50, rows=16, iters=10):
                          "note": "whole reverse pass incl. its 31 coupling launches; per-CU L1 fill bound, see profiles/r05_seq_time.txt"}}
 
 
+def behavior_train_row(device, rows=64, frames=50, iters=10):
+    """BASELINE configs[3]: the two training stages of experiments/behavior_net.py at config/behavior_net.yaml's sizes, random
+    weights, synthetic batches of 64 sequences.
+      flow stage  (:703-714) UnsupervisedTransformer2 1024 / 2048 / depth 2 / 15 blocks = 629 M parameters: forward, FlowLoss,
+                  backward, Adam(betas (0.5, 0.9)) with the weight gradient fused into the update (csrc/seq_train.hip), one
+                  replayed hipGraph per step.  Roofline: HBM.  Algorithmic bytes per step = 28 B per weight (W read by the
+                  forward pass; W, exp_avg, exp_avg_sq read and written once by the update) = 17.6 GB.
+      cVAE stage  (:591-660) ResidualBehaviorNet (1024 hidden, 51 pose dimensions), 50 frames: forward, MSE + gamma KL,
+                  back-propagation through time (100 cell steps), fused Adam, gamma controller (csrc/seq_bptt.hip)."""
+    import copy
+    from behavior_driven_video_synthesis_amd.experiments.behavior_net import BehaviorNet, DEFAULT_CONFIG
+    torch.manual_seed(12)
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    tr = BehaviorNet(cfg, n_kps=51, device=device)
+    for blk in tr.latent_flow.flow.sub_layers:
+        blk.norm_layer.initialized.fill_(1)
+        for mlp in blk.coupling.s:     # an untrained scale net saturates its tanh: keep the pass conditioned like a trained one
+            mlp.linears()[-1].weight.data.mul_(0.1)
+    tr.net.decoder.n_out.weight.data.mul_(0.05)
+    batch = {"keypoints": 0.5 * torch.randn(rows, frames + 1, 51, device=device)}
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return 1e-3 * a.elapsed_time(b) / iters
+    t_vae = timed(lambda: tr.train_fn(batch, sync=False))
+    out_vae = tr.train_fn(batch)
+    bs = torch.randn(rows, 1024, device=device)
+    noise = torch.randn(rows, 1024, device=device)
+    t_flow = timed(lambda: tr.flow_engine.train_step(bs, noise))
+    fl = tr.flow_engine.train_step(bs, noise).tolist()
+    n_w = sum(p.numel() for n, p in tr.latent_flow.named_parameters() if ".main." in n and n.endswith("weight"))
+    alg = 28.0 * n_w
+    traffic = traffic_src = None
+    for rel in PMC_TRAFFIC_SEQ_TRAIN:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        kern = {k: v for k, v in pmc.get("kernels", {}).items() if k.startswith("seq_")}
+        ticks = [v for k, v in kern.items() if k.startswith("seq_flow_loss_kernel")]
+        if ticks:   # one FlowLoss launch per step
+            steps = sum(v["launches_sampled"] for v in ticks)
+            traffic = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in kern.values()) / steps
+            traffic_src = {"file": rel, "collected_at_commit": pmc.get("head", ""), "correction": pmc.get("correction", ""),
+                           "unit": "HBM bytes of all seq_* kernels per training step"}
+            break
+    row = {"workload": f"behavior_net training (BASELINE configs[3]), batch {rows}: flow stage = UnsupervisedTransformer2 1024 / 2048 / "
+                       f"depth 2 / 15 blocks ({n_w / 1e6:.0f} M weights) forward + FlowLoss + backward + Adam; cVAE stage = "
+                       f"ResidualBehaviorNet 1024 hidden / 51 dims over {frames} frames forward + MSE + gamma KL + BPTT + Adam",
+           "data": "synthetic, random weights",
+           "flow_stage": {"value": rows / t_flow, "unit": "samples/s", "ms_per_step": 1e3 * t_flow, "hip_graph": True,
+                          "log": dict(zip(("flow_loss", "reference_nll_loss", "nlogdet_loss", "nll_loss"), fl)),
+                          "roofline": {"bound": "hbm", "kernel": "the step's seq_* kernels (seq_dw_kernel: 15.1 of the 17.6 GB)",
+                                       "achieved": alg / t_flow / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t_flow / 8e12,
+                                       "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_step": alg,
+                                       "note": "28 B per weight: W read by the forward pass; W, exp_avg, exp_avg_sq read and "
+                                               "written once by the fused update.  The input-gradient chain reads W a second time "
+                                               "(+4 B per weight of actual traffic)."}},
+           "cvae_stage": {"value": rows / t_vae, "unit": "sequences/s", "ms_per_step": 1e3 * t_vae, "hip_graph": True,
+                          "frames_per_s": rows * frames / t_vae,
+                          "log": {k: out_vae[k] for k in ("loss", "loss_recon", "kl_loss", "gamma")}}}
+    del tr
+    torch.cuda.empty_cache()
+    return row
+
+
 def render_row(vunet, device, size, frames=50, chunk=50, iters=5):
     """BASELINE config 5 (the render half): a 50-frame pose sequence -> one raster launch -> batched VunetAlter.transfer
     (reference: per-frame cv2 raster + batch-1 transfer, data/data_conversions_3d.py:1130-1185).  Modes: fp32-accurate
@@ -507,6 +644,7 @@ def timed_steps(trainer, batch, warmup, steps, sync_all):
     for _ in range(warmup):
         trainer.train_fn(batch)
     sync_all()
+    heartbeat("warm-up done")
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
@@ -516,45 +654,139 @@ def timed_steps(trainer, batch, warmup, steps, sync_all):
     return time.perf_counter() - t0, out
 
 
+class GraphGuard:
+    """In-process watchdog of the graph-replay phase of a multi-rank run (see main): armed before the first replay of a graph
+    that holds RCCL collectives, cancelled when the timed replays have come back.  On expiry rank 0 writes the eager result it
+    was given -- with the reason -- as THE JSON line, and the process leaves with os._exit (its stream is stuck in a collective:
+    nothing can be torn down in order)."""
+
+    def __init__(self, limit_s, json_fd, eager_result):
+        import threading
+        self._done = threading.Event()
+        self._limit, self._fd, self._res = limit_s, json_fd, eager_result
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def cancel(self):
+        self._done.set()
+
+    def _run(self):
+        if self._done.wait(self._limit):
+            return
+        reason = f"the recorded graph (captured RCCL collectives) did not complete {self._limit:.0f} s after it was armed"
+        print(f"bench.py: {reason}; reporting the eager measurement", file=sys.stderr, flush=True)
+        if self._fd is not None:
+            res = dict(self._res)
+            res["config"] = dict(res["config"], hip_graph=False, fallback_reason=reason)
+            os.write(self._fd, (json.dumps(res) + "\n").encode())
+        os._exit(0)
+
+
+def heartbeat(phase):
+    """Rank 0 tells the launching parent that the run is alive (stderr; the parent's watchdog restarts a silent child tree)."""
+    if os.environ.get("VUNET_BENCH_LAUNCHED") == "1" and int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench heartbeat] {phase}", file=sys.stderr, flush=True)
+
+
+def run_with_watchdog(cmd, env, first_deadline, progress_deadline, echo=sys.stderr):
+    """Run ``cmd`` as a child process TREE of its own (new session) and watch its stderr for ``[bench heartbeat]`` lines: no line
+    within ``first_deadline`` seconds of the start, or within ``progress_deadline`` of the previous one, and the whole tree is
+    killed (SIGKILL to the process group -- this process never touched the GPU, nothing is exec'ed).
+    -> (return code or None if killed, stdout text, the last phase heard, reason or None)."""
+    import signal
+    import subprocess
+    import threading
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    state = {"last": time.monotonic(), "phase": None, "beats": 0}
+    out_chunks = []
+
+    def pump_err():
+        for line in p.stderr:
+            if line.startswith("[bench heartbeat]"):
+                state["last"], state["phase"] = time.monotonic(), line[len("[bench heartbeat]"):].strip()
+                state["beats"] += 1
+            if echo is not None:
+                echo.write(line)
+                echo.flush()
+
+    def pump_out():
+        for line in p.stdout:
+            out_chunks.append(line)
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in threads:
+        t.start()
+    reason = None
+    while p.poll() is None:
+        time.sleep(0.2)
+        limit = first_deadline if state["beats"] == 0 else progress_deadline
+        if time.monotonic() - state["last"] > limit:
+            reason = (f"no heartbeat for {limit:.0f} s after " + (f"phase '{state['phase']}'" if state["beats"] else "the start"))
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            p.wait()
+            break
+    for t in threads:
+        t.join(timeout=5)
+    return (None if reason else p.returncode), "".join(out_chunks), state["phase"], reason
+
+
 def launch_ranks(args):
     """``bench.py --gpus N`` outside a torchrun environment: start the N ranks as a fresh child process tree, relay rank
     0's JSON line.  Nothing in THIS process has touched the GPU (``torch.cuda.device_count()`` does not initialise HIP)
-    and nothing will: the parent only waits.  Returns the exit code."""
+    and nothing will: the parent only waits -- with a watchdog.  Rank 0 prints a heartbeat after start-up, settle, warm-up
+    and the timed steps; a child tree that goes silent (a replayed collective that never completes is the case this is
+    for: with several ranks the step's RCCL all-reduces are captured into the hipGraph) is killed and ONE fresh tree is
+    started with ``--hip-graph off``; the line then says so (``config.fallback_reason``).  A second failure exits
+    non-zero.  Returns the exit code."""
     import socket
-    import subprocess
     n = args.gpus
     have = torch.cuda.device_count()
     if have < n:
         print(f"bench.py --gpus {n}: only {have} GPU(s) visible", file=sys.stderr)
         return 3
-    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
-    env["VUNET_BENCH_LAUNCHED"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    print("bench.py: starting " + " ".join(cmd), file=sys.stderr)
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)   # stderr passes through
-    line = None
-    for ln in p.stdout.splitlines():
-        if ln.startswith('{"metric"'):
-            line = ln
-        elif ln.strip():
-            print(ln, file=sys.stderr)              # anything else the ranks wrote to stdout is not the result
-    if p.returncode != 0:
-        print(f"bench.py --gpus {n}: the rank processes exited with code {p.returncode}", file=sys.stderr)
-        return p.returncode
-    if line is None:
-        print(f"bench.py --gpus {n}: rank 0 printed no JSON line", file=sys.stderr)
-        return 4
+    first = float(os.environ.get("VUNET_BENCH_START_TIMEOUT", "600"))       # imports + RCCL bring-up on a fresh box
+    progress = float(os.environ.get("VUNET_BENCH_PROGRESS_TIMEOUT", "240"))
+    argv = list(sys.argv[1:])
+    fallback_reason = None
+    for attempt in range(2):
+        with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+        env["VUNET_BENCH_LAUNCHED"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+        print("bench.py: starting " + " ".join(cmd), file=sys.stderr)
+        rc, out, phase, reason = run_with_watchdog(cmd, env, first, progress)
+        line = None
+        for ln in out.splitlines():
+            if ln.startswith('{"metric"'):
+                line = ln
+            elif ln.strip():
+                print(ln, file=sys.stderr)              # anything else the ranks wrote to stdout is not the result
+        if reason is None and rc == 0 and line is not None:
+            break
+        why = reason or (f"the rank processes exited with code {rc}" if rc else "rank 0 printed no JSON line")
+        print(f"bench.py --gpus {n}: attempt {attempt + 1} failed: {why}", file=sys.stderr)
+        graph_off = "--hip-graph" in argv and argv[argv.index("--hip-graph") + 1] == "off"
+        if attempt == 1 or graph_off:
+            return rc if rc else 6
+        # once more, a FRESH process tree, the step issued eagerly (no captured collectives)
+        if "--hip-graph" in argv:
+            argv[argv.index("--hip-graph") + 1] = "off"
+        else:
+            argv += ["--hip-graph", "off"]
+        fallback_reason = f"first attempt (--hip-graph auto): {why}"
     res = json.loads(line)
     if res.get("n_gpus") != n or res.get("config", {}).get("rccl_world_size") != n:
         print(f"bench.py --gpus {n}: the line reports n_gpus={res.get('n_gpus')}, "
               f"rccl_world_size={res.get('config', {}).get('rccl_world_size')}", file=sys.stderr)
         return 5
-    sys.stdout.write(line + "\n")
+    res.setdefault("config", {})["fallback_reason"] = fallback_reason
+    sys.stdout.write(json.dumps(res) + "\n")
     sys.stdout.flush()
     return 0
 
@@ -581,6 +813,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("VUNET_DP_FORCE") == "1":
         dist.init_process_group("nccl", device_id=device)
+    heartbeat("process group up")
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
     ops.set_conv_precision(args.precision)
@@ -594,7 +827,14 @@ def main():
         # the C-ABI RCCL communicator (ordinary stream operations: capturable); an eagerly issued step is 12-22 ms of
         # Python on a slow-host box, exactly what a scaling figure is sensitive to.  A capture that fails on ANY rank sends
         # every rank back to eager issue together (ShapePoseNet._capture_agreed; said on stderr, `config.hip_graph` false).
-        if args.hip_graph == "on" or (args.hip_graph == "auto" and (not trainer.averager.active or trainer.averager.native)):
+        want_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and (not trainer.averager.active or trainer.averager.native))
+        # Several ranks, `auto`: the K timed steps are measured EAGERLY first (a complete, valid result), then again from the
+        # recorded graph under a watchdog.  Replaying captured RCCL collectives on N ranks has never run on hardware: if the
+        # replay does not come back, rank 0 prints the eager line (config.fallback_reason says why) and every rank leaves
+        # with os._exit -- the run cannot end without a number, whoever launched the ranks (bench.py's own launcher adds a
+        # second net: launch_ranks' heartbeat watchdog and one restart with --hip-graph off).
+        two_phase = want_graph and args.hip_graph == "auto" and trainer.averager.active
+        if want_graph and not two_phase:
             try:
                 trainer.enable_hip_graph()
             except RuntimeError as e:      # a configuration the capture does not cover (stated by the trainer)
@@ -602,11 +842,68 @@ def main():
                     raise
                 print(f"bench.py: hipGraph mode not available here ({e}); issuing eagerly", file=sys.stderr)
     batch = synthetic_batch(args.batch, args.size, device, seed=42, with_regressor=args.regressor, rank=rank)
+    heartbeat("trainer built")
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def build_result(elapsed, out, settle, host_issue_ms, fallback_reason=None):
+        loss_val = float(out["loss"])
+        assert loss_val == loss_val, "loss is NaN"
+        res = {
+            "metric": "frames/sec VUnet 256x256 bs=16 fwd+bwd", "value": world * args.batch * args.steps / elapsed,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"h2": "f32 (operands scaled by a power of two and split into 2 fp16 terms, 3 partial products on fp16 MFMA, "
+                            "fp32 accumulate; weight gradients and uncovered layers: 3 bf16 terms / 6 products, fp32-input "
+                            "MFMA, fp32 VALU)",
+                      "x6": "f32 (operands split exactly into 3 bf16 terms, 6 partial products on bf16 MFMA, fp32 accumulate; "
+                            "fp32-input MFMA / fp32 VALU for the layers the split kernels do not cover)",
+                      "f32": "f32"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": f"Human3.6m shape_and_pose_net VunetAlter {args.size}x{args.size} per-GPU bs={args.batch} "
+                                   "fwd+bwd, VGG19 perceptual + KL loss, fused Adam, dropout 0.05"
+                                   + (", regressor side loop on" if args.regressor else ", regressor side loop off")
+                                   + (", adversarial term on" if args.gan else "")
+                                   + ", seeded-synthetic VGG19 weights, rasterised synthetic stickmen",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_precision": args.precision,
+                       "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val,
+                       "hip_streams": 1 if trainer.vunet._side_stream is None else 4,
+                       "hip_graph": bool(trainer._graphs), "graph_settle_steps": settle,
+                       "host_issue_ms_per_step": host_issue_ms,
+                       "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "dp_backend": trainer.averager.backend,
+                       "allreduce_ms_per_step": trainer.averager.mean_allreduce_ms(),
+                       # share of the all-reduce time that ran while backward was still computing (HIP events)
+                       "allreduce_overlap_frac": trainer.averager.overlap_fraction(),
+                       # (HIP events cannot be read back from a captured graph: under replay the two figures above are those of the
+                       #  eagerly issued steps before the capture -- same kernels, same streams)
+                       "allreduce_timed_on": ("eager steps before the capture" if trainer._graphs else "timed steps")
+                                             if trainer.averager.active else None},
+        }
+        res["config"]["fallback_reason"] = fallback_reason
+        return res
+
+    eager_first, guard = None, None
+    if two_phase:
+        for _ in range(6):                 # past the initialisation batches: the step has its final form
+            trainer.train_fn(batch)
+        el, out_e = timed_steps(trainer, batch, args.warmup, args.steps, sync_all)
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        eager_first = build_result(float(t.item()), out_e, 0, None)
+        heartbeat("eager timed steps done")
+        limit = float(os.environ.get("VUNET_BENCH_GRAPH_TIMEOUT", "180"))
+        guard = GraphGuard(limit, json_fd if rank == 0 else None, eager_first)
+        try:
+            trainer.enable_hip_graph()
+        except RuntimeError as e:
+            print(f"bench.py: hipGraph mode not available here ({e}); the eager measurement stands", file=sys.stderr)
+            guard.cancel()
+            guard = None
 
     # graph mode: the step is recorded after the initialisation batches (the KL term joins the loss then) and two eager
     # steps of the final form -- all of that happens HERE, before the W warm-up steps, so that the timed region holds
@@ -615,7 +912,12 @@ def main():
     while trainer._dev_sched and trainer._capture and not trainer._graphs and settle < 12:
         trainer.train_fn(batch)
         settle += 1
+    sync_all()
+    heartbeat(f"settled ({settle} steps, graph {'recorded' if trainer._graphs else 'not in use'})")
     elapsed, out = timed_steps(trainer, batch, args.warmup, args.steps, sync_all)
+    if guard is not None:
+        guard.cancel()                     # the replayed steps came back: the graph measurement is the result
+    heartbeat("timed steps done")
     # host time to ISSUE one step: measured on steps that start with an empty device queue (inside the timed loop the host
     # runs ahead until the launch queue is full and is then throttled to the GPU's pace, which says nothing about the host)
     issue = []
@@ -630,41 +932,11 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(out["loss"])
-    assert loss_val == loss_val, "loss is NaN"
+    result = build_result(elapsed, out, settle, host_issue_ms)
+    if eager_first is not None:
+        result["config"]["eager_issue"] = {"value": eager_first["value"], "ms_per_step": eager_first["ms_per_step"],
+                                           "note": "the same K timed steps issued eagerly, measured first (see --hip-graph)"}
 
-    result = {
-        "metric": "frames/sec VUnet 256x256 bs=16 fwd+bwd", "value": world * args.batch * args.steps / elapsed,
-        "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": {"h2": "f32 (operands scaled by a power of two and split into 2 fp16 terms, 3 partial products on fp16 MFMA, "
-                        "fp32 accumulate; weight gradients and uncovered layers: 3 bf16 terms / 6 products, fp32-input "
-                        "MFMA, fp32 VALU)",
-                  "x6": "f32 (operands split exactly into 3 bf16 terms, 6 partial products on bf16 MFMA, fp32 accumulate; "
-                        "fp32-input MFMA / fp32 VALU for the layers the split kernels do not cover)",
-                  "f32": "f32"}[args.precision],
-        "data": "synthetic",
-        "config": {"workload": f"Human3.6m shape_and_pose_net VunetAlter {args.size}x{args.size} per-GPU bs={args.batch} "
-                               "fwd+bwd, VGG19 perceptual + KL loss, fused Adam, dropout 0.05"
-                               + (", regressor side loop on" if args.regressor else ", regressor side loop off")
-                               + (", adversarial term on" if args.gan else "")
-                               + ", seeded-synthetic VGG19 weights, rasterised synthetic stickmen",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_precision": args.precision,
-                   "flop_per_frame": FLOP_PER_FRAME, "final_loss": loss_val,
-                   "hip_streams": 1 if trainer.vunet._side_stream is None else 4,
-                   "hip_graph": bool(trainer._graphs), "graph_settle_steps": settle,
-                   "host_issue_ms_per_step": host_issue_ms,
-                   "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
-                   "dp_backend": trainer.averager.backend,
-                   "allreduce_ms_per_step": trainer.averager.mean_allreduce_ms(),
-                   # share of the all-reduce time that ran while backward was still computing (HIP events)
-                   "allreduce_overlap_frac": trainer.averager.overlap_fraction(),
-                   # (HIP events cannot be read back from a captured graph: under replay the two figures above are those of the
-                   #  eagerly issued steps before the capture -- same kernels, same streams)
-                   "allreduce_timed_on": ("eager steps before the capture" if trainer._graphs else "timed steps")
-                                         if trainer.averager.active else None},
-    }
     if result["config"]["rccl_world_size"] != args.gpus:
         raise SystemExit(f"rank {rank}: RCCL communicator spans {result['config']['rccl_world_size']} rank(s), --gpus {args.gpus}")
     if dist.is_initialized():
@@ -694,6 +966,7 @@ def main():
         trainer.vunet._side_stream = side_stream
         trainer._capture = capture
         ops.enable_wgrad_streams(wgrad_streams)
+    heartbeat("instrumented steps done")
     if rank == 0 and not args.no_roofline:
         recs = ops._prof["recs"][:]                       # raw (key, flop, ev0, ev1) records of the instrumented steps
         fam = ops.profile_stop()                           # per family: conv_gather_fwd / conv_gather_dgrad / conv_wgrad
@@ -711,6 +984,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_render and args.size % 32 == 0:
         result["render"] = render_row(trainer.vunet, device, args.size)
         result["behavior"] = behavior_row(trainer.vunet, device, args.size)
+        result["behavior_train"] = behavior_train_row(device)
     # BASELINE config 1 (Market 128^2, bs 2, 30-channel 64x64 appearance input): plumbing rows, GPU and CPU
     cfg1 = batch1 = None
     if rank == 0 and world == 1 and not args.no_config1:

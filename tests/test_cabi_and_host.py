@@ -433,3 +433,68 @@ def test_bench_gpus_n_starts_ranks_or_fails_loudly():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "must agree" in r.stderr
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_watchdog_kills_a_silent_child_tree_and_keeps_a_talking_one(tmp_path):
+    """bench.py --gpus N starts the ranks as a child tree and must not be able to wait forever (a replayed collective that
+    never completes): a child that stops sending heartbeats is killed with everything it started; one that keeps talking and
+    finishes is relayed.  Stub children stand in for the ranks."""
+    import io
+    import sys
+    import time
+    bench = _load_bench()
+    hang = tmp_path / "hang.py"
+    hang.write_text("import subprocess, sys, time\n"
+                    "print('[bench heartbeat] settled', file=sys.stderr, flush=True)\n"
+                    "subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\n"   # a grandchild, as torchrun has
+                    "time.sleep(600)\n")
+    t0 = time.monotonic()
+    rc, out, phase, reason = bench.run_with_watchdog([sys.executable, str(hang)], dict(os.environ), 20.0, 1.5, echo=io.StringIO())
+    assert rc is None and phase == "settled" and "no heartbeat" in reason and "'settled'" in reason
+    assert time.monotonic() - t0 < 15.0
+    mute = tmp_path / "mute.py"
+    mute.write_text("import time\ntime.sleep(600)\n")
+    rc, out, phase, reason = bench.run_with_watchdog([sys.executable, str(mute)], dict(os.environ), 1.0, 30.0, echo=io.StringIO())
+    assert rc is None and phase is None and "after the start" in reason
+    ok = tmp_path / "ok.py"
+    ok.write_text("import sys, time\n"
+                  "for p in ('a', 'b', 'c'):\n"
+                  "    print('[bench heartbeat] ' + p, file=sys.stderr, flush=True)\n"
+                  "    time.sleep(0.6)\n"
+                  "print('{\"metric\": 1}')\n")
+    echo = io.StringIO()
+    rc, out, phase, reason = bench.run_with_watchdog([sys.executable, str(ok)], dict(os.environ), 5.0, 1.0, echo=echo)
+    assert rc == 0 and reason is None and phase == "c" and out.strip() == '{"metric": 1}' and "[bench heartbeat] b" in echo.getvalue()
+
+
+def test_bench_graph_guard_prints_the_eager_line_when_the_replay_never_returns(tmp_path):
+    """The in-process net of a multi-rank run: the eager measurement is taken first; if the graph phase does not come back the
+    guard writes THAT line (with the reason) and leaves -- exit code 0, one JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "stuck.py"
+    script.write_text(
+        "import importlib.util, os, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('b', {os.path.join(root, 'bench.py')!r})\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "g = b.GraphGuard(0.5, 1, {'metric': 'm', 'value': 700.0, 'config': {'hip_graph': True, 'fallback_reason': None}})\n"
+        "time.sleep(600)\n")                          # "the replay": never returns
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    import json
+    line = json.loads(r.stdout.strip())
+    assert line["value"] == 700.0 and line["config"]["hip_graph"] is False and "did not complete" in line["config"]["fallback_reason"]
+    ok = tmp_path / "fine.py"
+    ok.write_text(script.read_text().replace("time.sleep(600)", "g.cancel(); time.sleep(1.0); print('{\"metric\": \"graph\"}')"))
+    r = subprocess.run([sys.executable, str(ok)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == '{"metric": "graph"}'
