@@ -779,6 +779,48 @@ def g9_behavior():
     save("g9_behavior", meta, arrays)
 
 
+def g9b_projection():
+    """The numpy chain between the decoder's pose vectors and the rasteriser's pixel keypoints, from the reference's own
+    functions: ``unNormalizeData`` (data/data_conversions_3d.py:178-211), ``apply_affine_transform`` (:588-605),
+    ``camera_projection`` (:892-912) and the joint rescale of the render loop (:1132-1133, :1149-1150).  Two statistics dtypes
+    (numpy's promotion differs: float32 statistics keep the un-normalisation in float32), ignored dimensions, a rectangular
+    source image.  ``data.data_conversions_3d`` imports the dataset stack at module level: the absent third-party packages
+    behind it are stubbed; the three functions are pure numpy."""
+    for name in ["h5py", "imagesize", "skimage", "skimage.metrics", "natsort", "kornia.geometry", "umap"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+                sys.modules[name].__getattr__ = lambda k: type(k, (), {"__init__": lambda self, *a, **kw: None})
+    from data import data_conversions_3d as dc
+    arrays, meta = {}, {"cases": {}}
+    for tag, (dims, n_ignore, stats_dtype) in {"h36m_f32": (96, 45, "float32"), "h36m_f64": (96, 45, "float64"),
+                                               "plain": (51, 3, "float64")}.items():
+        rng = np.random.RandomState(17 + dims)
+        ignore = sorted(rng.choice(dims, size=n_ignore, replace=False).tolist())
+        mean = (rng.randn(dims) * 300.0).astype(stats_dtype)
+        std = (50.0 + 200.0 * rng.rand(dims)).astype(stats_dtype)
+        ang = 0.4
+        rot = np.array([[np.cos(ang), 0.0, np.sin(ang)], [0.0, 1.0, 0.0], [-np.sin(ang), 0.0, np.cos(ang)]])
+        ext = np.concatenate([rot, np.array([[50.0], [-120.0], [5200.0]])], axis=1)
+        intr = (1145.0, 512.5, 1143.8, 515.4)
+        image_size, spatial = (1000, 1002), 256
+        x = rng.randn(23, dims - n_ignore).astype(np.float32)
+        poses = dc.revert_output_format(x, mean, std, ignore).reshape(23, -1, 3)                 # experiments/behavior_net.py:1181-1183
+        size_arr = np.full((1, 2), spatial, dtype=float)
+        out = []
+        for p_ in poses:
+            pose_c = dc.apply_affine_transform(p_, ext)
+            pose_i = dc.camera_projection(pose_c, intr)
+            out.append(pose_i * (size_arr / np.expand_dims(np.asarray(image_size, dtype=float), axis=0)))
+        meta["cases"][tag] = {"dims": dims, "ignore": ignore, "stats_dtype": stats_dtype, "intrinsics": list(intr),
+                              "image_size": list(image_size), "spatial_size": spatial}
+        arrays[f"{tag}.x"], arrays[f"{tag}.mean"], arrays[f"{tag}.std"], arrays[f"{tag}.ext"] = x, mean, std, ext
+        arrays[f"{tag}.kps"] = np.stack(out)
+    save("g9b_projection", meta, arrays)
+
+
 def g10_flow_training():
     """BASELINE config 4, flow stage (experiments/behavior_net.py:384-395, :703-714): the reference's own
     ``UnsupervisedTransformer2`` + ``FlowLoss`` (lib/losses.py:294-317) + ``torch.optim.Adam(betas=(0.5, 0.9), weight_decay)``
@@ -947,5 +989,6 @@ if __name__ == "__main__":
     g1c_l2norm_init()
     g8_pretrained_dir()
     g9_behavior()
+    g9b_projection()
     g10_flow_training()
     g11_cvae_training()

@@ -18,9 +18,11 @@ def _no_grad():
         yield
 
 TOL = dict(rtol=2e-4, atol=2e-5)   # fp32 chains of 20 - 60 layers / 50 recurrent steps, different summation order
-FLOW_TOL = dict(rtol=1e-3, atol=1e-4)   # a flow pass multiplies by exp(+-s) and 1/scale 2 x n_flows times: rounding differences
-#                                         of the MLP sums (k order: four waves x S slabs here, one dot product on the CPU) grow
-#                                         with the pass's condition number; measured 3.7e-4 on one element of 320, 1e-6 typical
+FLOW_TOL = dict(rtol=1e-3, atol=1e-4)   # the small FIXTURE flows (synthetic O(1) scale nets: every tanh saturated, a pass multiplies
+#                                         by e^(+-1) per half-coupling and by 1/scale per block): rounding differences of the MLP
+#                                         sums grow with that condition number; measured 3.7e-4 on one element of 320, 1e-6
+#                                         typical.  Flows conditioned like a trained one are held to the float64 oracle instead,
+#                                         relative to the CPU float32 oracle's own distance from it (the width tests below)
 
 
 def close(a, b, **kw):
@@ -264,6 +266,41 @@ def test_a_module_left_on_the_cpu_or_cast_is_refused():
         net.cuda().half().infer_b(torch.randn(2, 3, 51, device="cuda"), False)
 
 
+def test_full_flow_of_the_reference_configuration_vs_oracle():
+    """config/behavior_net.yaml's WHOLE flow -- 1024 channels, 2048 hidden, depth 2, all 15 blocks (629 M
+    parameters, 2.5 GB) -- in both directions at 16 rows (experiments/behavior_net.py:1173 samples that many), where the
+    e^(+-s) conditioning compounds over 30 half-couplings: against the float64 oracle, next to the CPU float32 oracle's own
+    distance from it, and the round trip.  Graph replay equals eager issue bit for bit."""
+    from oracle import behavior_oracle as B
+    flow, sd = _random_flow(1024, 2048, 2, 15, 21, s_gain=0.1)
+    z = seeded_randn("full.z", (16, 1024), 21)
+    x = seeded_randn("full.x", (16, 1024), 21)
+    eng = flow.flow.engine()
+    eng.graph.enabled = False
+    rev_e = flow.reverse(z.cuda()).reshape(16, 1024)
+    fwd_e, ld_e = flow(x.cuda())
+    eng.graph.enabled = True
+    rev = [flow.reverse(z.cuda()).reshape(16, 1024) for _ in range(2)][-1]
+    fwd, ld = [flow(x.cuda()) for _ in range(2)][-1]
+    assert torch.equal(rev, rev_e) and torch.equal(fwd, fwd_e) and torch.equal(ld, ld_e)
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    r32, r64 = B.flow_reverse(sd, z), B.flow_reverse(sd64, z.double())
+    f32, l32 = B.flow_forward(sd, x)
+    f64, l64 = B.flow_forward(sd64, x.double())
+
+    def dist(a, ref):
+        return float((a.detach().cpu().double() - ref).abs().max() / ref.abs().max())
+    rows = {"reverse": (dist(rev, r64), dist(r32, r64)), "forward": (dist(fwd.reshape(16, 1024), f64), dist(f32, f64)),
+            "logdet": (dist(ld, l64), dist(l32, l64))}
+    for name, (e_hip, e_cpu) in rows.items():
+        print(f"15-block flow, {name}: max err / max|.| vs float64  HIP {e_hip:.2e}  CPU fp32 {e_cpu:.2e}")
+        assert e_hip <= max(3.0 * e_cpu, 2e-6), (name, e_hip, e_cpu)
+    back = flow.reverse(fwd).reshape(16, 1024)
+    rt = dist(back, x.double())
+    print(f"15-block flow, reverse(forward(x)) - x: {rt:.2e} of max|x|")
+    assert rt <= 1e-4
+
+
 @pytest.mark.parametrize("stats_dtype", ["float32", "float64"])
 @pytest.mark.parametrize("dims", [51, 96])
 def test_pose_projection_vs_the_reference_numpy_chain(dims, stats_dtype):
@@ -286,6 +323,22 @@ def test_pose_projection_vs_the_reference_numpy_chain(dims, stats_dtype):
     got = cam.project(torch.from_numpy(x).cuda())
     assert got.shape == (37, dims // 3, 2)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-6, atol=2e-4)   # fp32 storage of pixel coordinates ~ 256
+
+
+@pytest.mark.parametrize("tag", ["h36m_f32", "h36m_f64", "plain"])
+def test_pose_projection_vs_the_reference_fixture(tag):
+    """``seq_pose_project_kernel`` vs what the reference's own numpy functions produced (tests/golden/g9b_projection.npz:
+    unNormalizeData, apply_affine_transform, camera_projection, joint rescale)."""
+    from behavior_driven_video_synthesis_amd.render import PoseCamera
+    meta, arr = load_golden("g9b_projection")
+    c = meta["cases"][tag]
+    use = [i for i in range(c["dims"]) if i not in c["ignore"]]
+    cam = PoseCamera(arr[f"{tag}.mean"], arr[f"{tag}.std"], use, arr[f"{tag}.ext"], tuple(c["intrinsics"]), tuple(c["image_size"]),
+                     c["spatial_size"])
+    got = cam.project(torch.from_numpy(arr[f"{tag}.x"]).cuda())
+    want = arr[f"{tag}.kps"]
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=2e-4)   # fp32 storage of pixel coordinates ~ 256
 
 
 def test_behavior_video_end_to_end_vs_the_pieces():

@@ -307,8 +307,10 @@ def test_benchmark_size_step_vs_oracle():
     Bars: the six perceptual terms, the KL term and the loss to 1e-4 relative.  The four gradient buckets by relative L2:
     the gradient of an L1 loss on ReLU / max-pool features is discontinuous in the features, so two float32 evaluations of
     d loss / d image can differ by ~3e-3 on adversarial inputs (profiles/r04_vgg_grad_cmp_256.txt: float32 oracle 2.6e-3 and
-    this path 3.3e-3 from the float64 oracle on random images) and every generator gradient inherits that: the bar is 2e-3.
-    Measured on this step (profiles/r05_bench_size_parity.txt): eu 3.9e-7, ed 3.1e-7, du 2.2e-5, dd 2.1e-5."""
+    this path 3.3e-3 from the float64 oracle on random images) and every generator gradient inherits that; on THIS step no
+    feature sits on a kink and the measured distances are eu 3.9e-7, ed 3.1e-7, du 2.2e-5, dd 2.1e-5
+    (profiles/r05_bench_size_parity.txt).  The bar is 2e-4 -- ten times the largest measured value (SURVEY 8c proposes 1e-3 on
+    weight gradients); a step that lands a feature on a kink would have to be looked at, not waved through."""
     import copy
     from behavior_driven_video_synthesis_amd import ops
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
@@ -385,7 +387,51 @@ def test_benchmark_size_step_vs_oracle():
                          .reshape(-1) for k, _ in get_member(tr.vunet, n).named_parameters()])
         rel = float((got[n].double() - ref.double()).norm() / ref.double().norm())
         print(f"bucket {n}: relative L2 distance to the oracle {rel:.2e}")
-        assert rel <= 2e-3, (n, rel)
+        assert rel <= 2e-4, (n, rel)
+
+
+def test_benchmark_size_step_with_the_regressor_side_loop_vs_oracle():
+    """the configuration bench.py times as ``variants.regressor`` -- 256^2, batch 16, ``train_regressor`` --
+    through ``ShapePoseNet.train_fn``: the side loop's five regressor steps (experiments/shape_and_pose_net.py:407-425: frozen
+    ``ed(eu(reg_imgs[:, i]))``, L2-norm loss, the regressor's own Adam) against the oracle's ``regressor_side_loop`` on the same
+    weights, images, targets and posterior noise: every step's loss is not exposed, the LAST one is (the value the step's loss
+    subtracts, clamped and weighted, :424-425), and the regressor's parameters after its five updates.  Dropout is off here:
+    the side loop's encoder passes would need their 5 x 28 keep-masks handed to the oracle; the kernels are the same."""
+    from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import ShapePoseNet, synthetic_batch
+    from oracle import vunet_oracle as O
+    cfg = _benchmark_cfg(n_init_batches=0, train_regressor=True, dropout_prob=0.0)
+    tr = ShapePoseNet(cfg, device="cuda:0", total_steps=1000, vgg_synthetic=True, hip_graph=False)
+    batch = synthetic_batch(16, 256, "cuda:0", seed=11, with_regressor=True)
+    R = batch["reg_imgs"].shape[1]
+    assert R == 5
+    g = torch.Generator().manual_seed(5)
+    lat = [(16, 128, 4, 4), (16, 128, 8, 8)]
+    eps = [torch.randn(*s_, generator=g) for s_ in lat]
+    reg_eps = [[torch.randn(*s_, generator=g) for s_ in lat] for _ in range(R)]
+    sd0 = {k: v.detach().cpu().clone() for k, v in tr.vunet.state_dict().items()}
+    rsd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in tr.regressor.state_dict().items()}
+    out = tr.train_fn(batch, [e.cuda() for e in eps], [[e.cuda() for e in es] for es in reg_eps])
+    torch.cuda.synchronize()
+    mcfg = dict(cfg["architecture"])
+    mcfg.update(cfg["data"])
+    mcfg["dropout_prob"] = 0.0
+    opt_reg = torch.optim.Adam(list(rsd.values()), lr=0.001)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 64))
+    try:
+        last, values = O.regressor_side_loop(sd0, mcfg, rsd, opt_reg, batch["reg_imgs"].cpu(), batch["reg_targets"].cpu(), reg_eps)
+    finally:
+        torch.set_num_threads(threads)
+    got = float(out["loss_reg"])
+    print(f"regressor side loop at 256^2 / batch 16: last loss {got:.6f} vs oracle {values[-1]:.6f} (steps: {values})")
+    assert abs(got - values[-1]) <= 1e-4 * abs(values[-1]), (got, values)
+    worst = 0.0
+    for k, v in tr.regressor.state_dict().items():
+        d = float((v.detach().cpu().double() - rsd[k].detach().double()).abs().max() / rsd[k].detach().double().abs().max().clamp_min(1e-30))
+        worst = max(worst, d)
+    print(f"regressor parameters after 5 Adam steps: {worst:.2e} of max|.|")
+    assert worst <= 1e-4
+    assert float(out["loss"]) == float(out["loss"])      # (the loss's composition is the trajectory tests' subject)
 
 
 def test_shape_pose_net_l2_conv_variant_initialises_and_trains():
@@ -722,22 +768,23 @@ def test_gradient_pass_through_changes_nothing_but_the_launch_count():
     assert adds_off - adds_on >= 4 + 3, (adds_on, adds_off)
 
 
-def test_full_size_step_with_the_adversarial_term_vs_oracle():
-    """BASELINE config 2's "+GAN" at full size -- VunetAlter 256x256 (nf 32 .. 128), full-width VGG19,
-    batch 4, ``training.gan.enabled``: one training step.  Finite, bit-reproducible from the seed (two trainers: identical
+@pytest.mark.parametrize("bsz", [4, 16])
+def test_full_size_step_with_the_adversarial_term_vs_oracle(bsz):
+    """BASELINE config 2's "+GAN" at full size -- VunetAlter 256x256 (nf 32 .. 128), full-width
+    VGG19, batch 4 and batch 16 (the configuration bench.py times as ``variants.gan``), ``training.gan.enabled``: one training step.  Finite, bit-reproducible from the seed (two trainers: identical
     scalars and parameters), and the adversarial scalars against the oracle's restatement of DiscTrainer
     (models/synth_discriminator.py:139-191: BCE-with-logits of the PartDiscriminator on the step's real / generated
     window) evaluated on the CPU with the discriminator's pre-step weights -- 1e-4."""
     from behavior_driven_video_synthesis_amd.experiments.shape_and_pose_net import (DEFAULT_CONFIG, ShapePoseNet,
                                                                                      synthetic_batch)
     from oracle import vunet_oracle as O
-    batch = synthetic_batch(4, 256, "cuda:0", seed=11)
+    batch = synthetic_batch(bsz, 256, "cuda:0", seed=11)
     g = torch.Generator().manual_seed(5)
-    eps = [torch.randn(4, 128, w, w, generator=g).cuda() for w in (4, 8)]
+    eps = [torch.randn(bsz, 128, w, w, generator=g).cuda() for w in (4, 8)]
 
     def run():
         cfg = copy.deepcopy(DEFAULT_CONFIG)
-        cfg["training"].update(train_regressor=False, dropout_prob=0.0,
+        cfg["training"].update(train_regressor=False, dropout_prob=0.0, batch_size=bsz,
                                gan=dict(enabled=True, weight=1.0, pd_scales=3, lr=2e-4))
         tr = ShapePoseNet(cfg, device="cuda:0", total_steps=1000, vgg_synthetic=True)
         dsd = {k: v.detach().clone().cpu() for k, v in tr.gan.disc.state_dict().items()}

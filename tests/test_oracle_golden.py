@@ -519,3 +519,15 @@ def test_g11_cvae_training_trajectory():
         if k.startswith("exp_avg."):
             e = st[names.index(k[8:])]["exp_avg"]
             close(e[:24] if e.dim() == 2 and e.shape[0] > 64 else e, v, rtol=1e-4, atol=1e-5 * float(np.abs(v).max()))
+
+
+@pytest.mark.parametrize("tag", ["h36m_f32", "h36m_f64", "plain"])
+def test_g9b_projection_vs_the_reference_numpy_functions(tag):
+    """``poses_to_keypoints`` vs the reference's own unNormalizeData / apply_affine_transform / camera_projection + joint rescale
+    (data/data_conversions_3d.py:178-211, :588-605, :892-912, :1132-1150): same dtypes, so bit for bit."""
+    from oracle import behavior_oracle as B
+    meta, arr = load_golden("g9b_projection")
+    c = meta["cases"][tag]
+    got = B.poses_to_keypoints(arr[f"{tag}.x"], arr[f"{tag}.mean"], arr[f"{tag}.std"], c["ignore"], arr[f"{tag}.ext"],
+                               tuple(c["intrinsics"]), tuple(c["image_size"]), c["spatial_size"])
+    assert got.dtype == arr[f"{tag}.kps"].dtype and np.array_equal(got, arr[f"{tag}.kps"])
