@@ -272,7 +272,18 @@ def test_full_flow_of_the_reference_configuration_vs_oracle():
     e^(+-s) conditioning compounds over 30 half-couplings: against the float64 oracle, next to the CPU float32 oracle's own
     distance from it, and the round trip.  Graph replay equals eager issue bit for bit."""
     from oracle import behavior_oracle as B
-    flow, sd = _random_flow(1024, 2048, 2, 15, 21, s_gain=0.1)
+    flow, sd = _random_flow(1024, 2048, 2, 15, 21, s_gain=0.02)
+    # conditioned like a trained flow (every block near the identity, activations O(1) through all 15): the recipe's O(1)
+    # translation nets and ActNorm scales of 0.7 - 1 compound to a map that float32 cannot carry on the CPU either (measured
+    # with s_gain 0.1 alone: CPU float32 0.81 of max|x| from float64 on the reverse pass)
+    for k in list(sd):
+        if ".coupling.t." in k and ".main.6." in k:
+            sd[k] = sd[k] * 0.2
+        elif k.endswith("norm_layer.scale"):
+            sd[k] = 1.0 + 0.05 * seeded_randn(k, tuple(sd[k].shape), 21)
+        elif k.endswith("norm_layer.loc"):
+            sd[k] = 0.05 * seeded_randn(k, tuple(sd[k].shape), 21)
+    flow.load_state_dict(sd)
     z = seeded_randn("full.z", (16, 1024), 21)
     x = seeded_randn("full.x", (16, 1024), 21)
     eng = flow.flow.engine()
@@ -298,7 +309,7 @@ def test_full_flow_of_the_reference_configuration_vs_oracle():
     back = flow.reverse(fwd).reshape(16, 1024)
     rt = dist(back, x.double())
     print(f"15-block flow, reverse(forward(x)) - x: {rt:.2e} of max|x|")
-    assert rt <= 1e-4
+    assert rt <= 1e-5      # measured 7.3e-7
 
 
 @pytest.mark.parametrize("stats_dtype", ["float32", "float64"])
