@@ -494,7 +494,10 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   // at every layer size of the reference configuration: not instantiated)
   const dim3 grid(d->M / 16, d->S, d->nets);
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = d->K / d->S >= 16 * 32;   // 16 waves: at least one chunk each
+  // 16 waves where K gives each at least one chunk -- up to 32 batch rows.  With 3 - 4 batch tiles (the training batch of 64) a
+  // wave's operand loads are four times its weight loads and four waves with deeper groups are faster (flow training step at
+  // 64 rows: 7.77 -> 7.41 ms; at 16 rows the two forms measured the same, profiles/r05_seq_time.txt)
+  const bool wide = d->K / d->S >= 16 * 32 && d->B <= 32;
 #define SEQ_LINEAR_CASE(NB)                                                              \
   case NB:                                                                               \
     if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16>), grid, dim3(1024), 0, st, a);  \

@@ -170,6 +170,16 @@ struct AdamResolved {
 };
 
 __device__ __forceinline__ AdamResolved adam_resolve(const vunet_seq_adam_hp& hp) {
+  if (hp.resolved_dev) {   // formed once per step by seq_adam_tick_kernel (the same expressions): two scalar loads
+    AdamResolved r;
+    r.step_size = hp.resolved_dev[0];
+    r.inv_sqrt_bc2 = hp.resolved_dev[1];
+    r.b1 = hp.beta1;
+    r.b2 = hp.beta2;
+    r.eps = hp.eps;
+    r.wd = hp.weight_decay;
+    return r;
+  }
   // bias corrections in double, as torch forms them on the host (torch/optim/adam.py: bias_correction1 / 2, step_size)
   const double t = (double)*hp.step_dev;
   const double bc1 = 1.0 - pow((double)hp.beta1, t), bc2 = 1.0 - pow((double)hp.beta2, t);
@@ -191,8 +201,27 @@ __device__ __forceinline__ void adam_update(const AdamResolved& h, float g, floa
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dZ^T . X (+ Adam)
-constexpr int DW_LD = 80;    // LDS row stride of the staged 64-column tiles: 4 rows q * 80 fall into four disjoint bank groups
-constexpr int DW_LDO = 68;   // ... of the tile of dW on its way from the accumulator layout to rows
+#ifdef VUNET_SEQ_NO_NT   // (timing-ablation build, tools/ab_build.sh)
+#define SEQ_NT_LOAD(ptr) (*reinterpret_cast<const float4*>(ptr))
+#define SEQ_NT_STORE(ptr, val) (*reinterpret_cast<float4*>(ptr) = (val))
+#else
+typedef float seq_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 seq_nt_load(const float* p) {
+  const seq_f4 t = __builtin_nontemporal_load(reinterpret_cast<const seq_f4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void seq_nt_store(float* p, const float4& v) {
+  seq_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<seq_f4*>(p));
+}
+#define SEQ_NT_LOAD(ptr) seq_nt_load(ptr)
+#define SEQ_NT_STORE(ptr, val) seq_nt_store(ptr, val)
+#endif
+// LDS tiles are [rows][64] floats with the column XOR-ed by 16 * (row & 3) (operand tiles: the four rows 4 c + q of a matrix
+// step fall into four disjoint bank groups) resp. 16 * ((row >> 2) & 3) (the tile of dW on its way from the accumulator layout
+// -- rows 4 q + r -- to rows): conflict-free without padding, 32 KB per workgroup at 64 batch rows = five workgroups per CU.
+__device__ __forceinline__ int dw_sw(int row, int col) { return row * 64 + (col ^ ((row & 3) << 4)); }
+__device__ __forceinline__ int dw_swo(int row, int col) { return row * 64 + (col ^ (((row >> 2) & 3) << 4)); }
 
 // grid: one workgroup per 64 x 64 tile of the launch's flat tile list, 256 threads.  Wave w owns rows 16 w .. 16 w + 15 of the
 // tile: A = dZ^T (row i <-> W row m0 + 16 w + i), B = X (column j <-> W column k0 + 16 blk + j), reduction over the batch rows
@@ -200,9 +229,8 @@ constexpr int DW_LDO = 68;   // ... of the tile of dW on its way from the accumu
 template <int NB, bool ADAM>
 __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* __restrict__ tab, int n_layers, int first_tile,
                                                      vunet_seq_adam_hp hp) {
-  __shared__ float dzs[16 * NB * DW_LD];
-  __shared__ float xs[64 * DW_LD];      // (the tile of dW, [64][DW_LDO], reuses this space)
-  AdamResolved& hsh = *reinterpret_cast<AdamResolved*>(&dzs[64]);   // (in the padding columns of row 0)
+  __shared__ float dzs[16 * NB * 64];
+  __shared__ float xs[64 * 64];      // (the tile of dW reuses this space)
   const int tile = first_tile + blockIdx.x;
   int lo = 0, hi = n_layers;
   while (hi - lo > 1) {
@@ -215,9 +243,7 @@ __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* _
   const int m0 = 64 * tm, k0 = 64 * tk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
   AdamResolved h = AdamResolved{};
-  if constexpr (ADAM) {
-    if (tid == 0) hsh = adam_resolve(hp);
-  }
+  if constexpr (ADAM) h = adam_resolve(hp);
   f32x4 acc[4];
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -229,36 +255,33 @@ __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* _
     if (ch) __syncthreads();   // the previous block's operands have been read
     for (int idx = tid; idx < 16 * NB * 16; idx += 256) {
       const int b = idx >> 4, c4 = idx & 15;
-      *reinterpret_cast<float4*>(&dzs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(dzp + (size_t)b * L.ldz + m0 + 4 * c4);
-      *reinterpret_cast<float4*>(&xs[b * DW_LD + 4 * c4]) = *reinterpret_cast<const float4*>(xp + (size_t)b * L.ldx + k0 + 4 * c4);
+      *reinterpret_cast<float4*>(&dzs[dw_sw(b, 4 * c4)]) = *reinterpret_cast<const float4*>(dzp + (size_t)b * L.ldz + m0 + 4 * c4);
+      *reinterpret_cast<float4*>(&xs[dw_sw(b, 4 * c4)]) = *reinterpret_cast<const float4*>(xp + (size_t)b * L.ldx + k0 + 4 * c4);
     }
     __syncthreads();
-    if constexpr (ADAM) {
-      if (ch == 0) h = hsh;   // (before the padding columns of row 0 are staged over again)
-    }
     float av[4 * NB];
 #pragma unroll
-    for (int c = 0; c < 4 * NB; ++c) av[c] = dzs[(4 * c + q) * DW_LD + 16 * wave + i];
+    for (int c = 0; c < 4 * NB; ++c) av[c] = dzs[dw_sw(4 * c + q, 16 * wave + i)];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
       for (int c = 0; c < 4 * NB; ++c)
-        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], xs[(4 * c + q) * DW_LD + 16 * blk + i], acc[blk], 0, 0, 0);
+        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], xs[dw_sw(4 * c + q, 16 * blk + i)], acc[blk], 0, 0, 0);
     // bias: d b[m] = sum_b dZ[b][m], rows in order (the k = 0 tiles)
     if (tk == 0 && tid < 64 && L.bias)
-      for (int b = 0; b < 16 * NB; ++b) bsum += dzs[b * DW_LD + tid];
+      for (int b = 0; b < 16 * NB; ++b) bsum += dzs[dw_sw(b, tid)];
   }
   __syncthreads();   // every wave has read its operands: the space of xs becomes the tile of dW, by rows
   float* dws = xs;
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dws[(16 * wave + 4 * q + r) * DW_LDO + 16 * blk + i] = acc[blk][r];
+    for (int r = 0; r < 4; ++r) dws[dw_swo(16 * wave + 4 * q + r, 16 * blk + i)] = acc[blk][r];
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
-    float4 g = *reinterpret_cast<const float4*>(&dws[row * DW_LDO + 4 * c4]);
+    float4 g = *reinterpret_cast<const float4*>(&dws[dw_swo(row, 4 * c4)]);
     if (k0 + 4 * c4 + 3 >= L.kv) {   // (padding columns of the image: only where K is not the layer's own width)
       const int kc = k0 + 4 * c4;
       if (kc >= L.kv) g.x = 0.f;
@@ -268,15 +291,15 @@ __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* _
     }
     const size_t off = (size_t)(m0 + row) * L.K + k0 + 4 * c4;
     if constexpr (ADAM) {
-      float4 p = *reinterpret_cast<const float4*>(L.w + off), m = *reinterpret_cast<const float4*>(L.m + off),
-             v = *reinterpret_cast<const float4*>(L.v + off);
+      // (each of these bytes is touched once per step: keep them out of the L2 that holds the operand rows)
+      float4 p = SEQ_NT_LOAD(L.w + off), m = SEQ_NT_LOAD(L.m + off), v = SEQ_NT_LOAD(L.v + off);
       adam_update(h, g.x, p.x, m.x, v.x);
       adam_update(h, g.y, p.y, m.y, v.y);
       adam_update(h, g.z, p.z, m.z, v.z);
       adam_update(h, g.w, p.w, m.w, v.w);
-      *reinterpret_cast<float4*>(L.w + off) = p;
-      *reinterpret_cast<float4*>(L.m + off) = m;
-      *reinterpret_cast<float4*>(L.v + off) = v;
+      SEQ_NT_STORE(L.w + off, p);
+      SEQ_NT_STORE(L.m + off, m);
+      SEQ_NT_STORE(L.v + off, v);
     } else {
       *reinterpret_cast<float4*>(L.g + off) = g;
     }
@@ -408,7 +431,16 @@ __global__ __launch_bounds__(1024) void seq_flow_loss_kernel(const float* __rest
   }
 }
 
-__global__ void seq_adam_tick_kernel(int64_t* step) { *step += 1; }
+// ++step, and the step's bias-corrected constants for every kernel of the step to read (formed as adam_resolve forms them)
+__global__ void seq_adam_tick_kernel(int64_t* step, const double* lr, float b1, float b2, float* resolved) {
+  const int64_t t = *step + 1;
+  *step = t;
+  if (resolved) {
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    resolved[0] = (float)(*lr / bc1);
+    resolved[1] = (float)(1.0 / sqrt(bc2));
+  }
+}
 
 __global__ __launch_bounds__(256) void seq_unpack_rows_kernel(const float* __restrict__ src, int ld_src, int col_off, int row_off,
                                                               int row_mul, float* __restrict__ dst, int M, int K, int accumulate) {
@@ -438,7 +470,7 @@ extern "C" int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const f
   a.S = d->S;
   const dim3 grid(d->K / 64, d->S, d->nets);
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = d->M / d->S >= 16 * 16;   // 16 waves: at least one 16-row group each
+  const bool wide = d->M / d->S >= 16 * 16 && d->B <= 32;   // 16 waves: at least one 16-row group each (64 rows: see vunet_seq_linear)
 #define SEQ_DX_CASE(NB)                                                          \
   case NB:                                                                       \
     if (wide) VUNET_LAUNCH((seq_dx_kernel<NB, 16>), grid, dim3(1024), 0, st, a); \
@@ -553,9 +585,9 @@ extern "C" int vunet_seq_flow_loss(const float* z, int32_t ldz, const float* log
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_adam_tick(int64_t* step_dev, void* stream) {
-  if (!step_dev) return VUNET_ERR_ARG;
-  VUNET_LAUNCH(seq_adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+extern "C" int vunet_seq_adam_tick(int64_t* step_dev, const double* lr_dev, float beta1, float beta2, float* resolved_dev, void* stream) {
+  if (!step_dev || (resolved_dev && !lr_dev)) return VUNET_ERR_ARG;
+  VUNET_LAUNCH(seq_adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr_dev, beta1, beta2, resolved_dev);
   return vunet_check_launch();
 }
 

@@ -30,7 +30,7 @@ LRELU_SLOPE = 0.01   # nn.LeakyReLU() default (lib/modules.py:244)
 
 class SeqAdamHp(ctypes.Structure):
     _fields_ = [("lr_dev", ctypes.c_void_p), ("step_dev", ctypes.c_void_p), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
-                ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float)]
+                ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float), ("resolved_dev", ctypes.c_void_p)]
 
 
 class SeqDxDesc(ctypes.Structure):
@@ -68,7 +68,9 @@ class AdamState:
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.lr_dev = torch.full((1,), self.lr, dtype=torch.float64, device=device)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=device)
-        self.hp = SeqAdamHp(self.lr_dev.data_ptr(), self.step_dev.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay)
+        self.resolved_dev = torch.zeros(2, dtype=torch.float32, device=device)    # written by tick(), read by the step's kernels
+        self.hp = SeqAdamHp(self.lr_dev.data_ptr(), self.step_dev.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                            self.resolved_dev.data_ptr())
 
     def set_lr(self, lr: float):
         if float(lr) != self.lr:
@@ -76,7 +78,7 @@ class AdamState:
             self.lr_dev.fill_(self.lr)
 
     def tick(self):
-        _call("vunet_seq_adam_tick", _p(self.step_dev), _stream())
+        _call("vunet_seq_adam_tick", _p(self.step_dev), _p(self.lr_dev), self.hp.beta1, self.hp.beta2, _p(self.resolved_dev), _stream())
 
     @property
     def step(self) -> int:

@@ -46,6 +46,8 @@ typedef struct vunet_seq_adam_hp {
   const double* lr_dev;
   const int64_t* step_dev;   /* t of the update being applied (>= 1) */
   float beta1, beta2, eps, weight_decay;
+  const float* resolved_dev; /* NULL, or {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)} as vunet_seq_adam_tick left them for THIS t:
+                                the kernels then read two floats instead of forming the powers themselves */
 } vunet_seq_adam_hp;
 
 /* dX = dZ . W: w_n [M][ldw] (nets <= 2; columns 0 .. K of each row are used: ldw = 0 means K), dz [nets][Bp][M],
@@ -111,7 +113,8 @@ int vunet_seq_actnorm_bwd(const vunet_seq_actnorm_layer* table_dev, int32_t n_la
 int vunet_seq_flow_loss(const float* z, int32_t ldz, const float* logdet, const float* noise, int32_t B, int32_t C, float* scalars,
                         float* dz, int32_t ld_dz, float* dld, void* stream);
 
-int vunet_seq_adam_tick(int64_t* step_dev, void* stream);
+/* ++*step_dev; resolved_dev != NULL: also the step's constants {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)} (double arithmetic) */
+int vunet_seq_adam_tick(int64_t* step_dev, const double* lr_dev, float beta1, float beta2, float* resolved_dev, void* stream);
 
 /* dst[m][k] = src[(row_off + row_mul m) ld_src + col_off + k] (the inverse of vunet_seq_pack_rows; `accumulate`: +=) */
 int vunet_seq_unpack_rows(const float* src, int32_t ld_src, int32_t col_off, int32_t row_off, int32_t row_mul, float* dst, int32_t M,

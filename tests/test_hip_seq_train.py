@@ -158,25 +158,38 @@ def test_flow_gradients_vs_oracle_over_batch_sizes(bsz):
     assert worst <= 1e-4, f"{worst:.2e}"
 
 
+def _away_from_the_kink(sd, depth):
+    """Hidden biases of +-6 (alternating units): every LeakyReLU pre-activation of the synthetic flow (standard deviation about
+    1.2) then sits at least 3 away from zero, half of the units on each slope.  Without this, of a step's 4.7 M hidden
+    pre-activations a few lie within summation rounding of zero, and there the derivative is 1 on one side of a comparison and
+    0.01 on the other: one sample's share of one row of dW, and a small change of that sample's signal in everything upstream
+    (measured: 6e-2 of max on one row of 2048, 1e-4 on the ActNorm gradients, tools/dbg_flow_train.py) -- which says nothing
+    about either implementation.  The generic case is the small-size gradient tests' subject."""
+    for k in list(sd):
+        if k.endswith(".bias") and ".coupling." in k and f".main.{2 * (depth + 1)}." not in k:
+            n = sd[k].numel()
+            sd[k] = 6.0 * (1.0 - 2.0 * (torch.arange(n) % 2).float()) + 0.1 * sd[k]
+        elif k.endswith(".weight") and ".coupling." in k and f".main.{2 * (depth + 1)}." in k:
+            sd[k] = 0.02 * sd[k]          # (hidden activations of size 6 instead of 1: keep the heads' outputs O(1))
+    return sd
+
+
 def test_flow_step_at_the_reference_width_vs_oracle():
     """config/behavior_net.yaml's sizes (1024 channels, 2048 hidden, depth 2, batch 64), 3 of the 15 blocks, three fused steps.
     Graph replay equals eager issue bit for bit; the parameters are updated in place (no padded copies at these sizes).  Every
     step is held to the oracle's step FROM THE SAME STATE (weights, moments and step count copied out of the engine through
-    ``optimizer_state_dict`` into ``torch.optim.Adam``): two fp32 trajectories through 36 LeakyReLU layers do not stay together
-    (measured 4e-2 of max|exp_avg| after three free-running steps).  Even within one step the two sides differ in a handful of
-    places by construction: of the step's 4.7 M hidden pre-activations a few lie within summation rounding (3e-6) of zero, and
-    there the unit's derivative is 1 on one side and 0.01 on the other -- one sample's share of that row of dW, and a small
-    change of that sample's signal in everything upstream.  So the moments are held to a tight bar at the median of every
-    tensor's elements, a looser one at the 99th percentile and a loose one at the maximum (the first step alone, where no flip
-    happened to occur, agrees to 1e-5 at the maximum: tools/dbg_flow_train.py)."""
+    ``optimizer_state_dict`` into ``torch.optim.Adam``): the step's losses, Adam's moments (linear / quadratic in the gradients)
+    at the maximum over every tensor's elements, and the weights."""
     from oracle import behavior_oracle as B
     lr = 4.5e-7 * 64            # flow_lr * batch_size (experiments/behavior_net.py:382)
     runs = {}
     for graph in (False, True):
         flow, sd = _random_flow(1024, 2048, 2, 3, 7)
+        sd = _away_from_the_kink(sd, 2)
+        flow.load_state_dict(sd)
         eng = flow.flow.train_engine(lr=lr, betas=(0.5, 0.9), weight_decay=0.0)
         eng.graph.enabled = graph
-        logs, worst = [], dict(loss=0.0, exp_avg=0.0, exp_avg_med=0.0, exp_avg_sq=0.0, exp_avg_max=0.0, w_far=0.0, w_max=0.0)
+        logs, worst = [], dict(loss=0.0, exp_avg=0.0, exp_avg_sq=0.0, w_far=0.0, w_max=0.0)
         for it in range(3):
             batch = seeded_randn(f"w.b{it}", (64, 1024), 7)
             if graph:   # the oracle takes this step from the engine's state
@@ -193,10 +206,8 @@ def test_flow_step_at_the_reference_width_vs_oracle():
             mine, theirs = eng.optimizer_state_dict()["state"], opt.state_dict()["state"]
             assert int(mine[0]["step"]) == int(theirs[0]["step"]) == it + 1
             for i in range(len(theirs)):
-                md, q, mx = _rel_q(mine[i]["exp_avg"], theirs[i]["exp_avg"])
-                worst["exp_avg_med"] = max(worst["exp_avg_med"], md)
-                worst["exp_avg"], worst["exp_avg_max"] = max(worst["exp_avg"], q), max(worst["exp_avg_max"], mx)
-                worst["exp_avg_sq"] = max(worst["exp_avg_sq"], _rel_q(mine[i]["exp_avg_sq"], theirs[i]["exp_avg_sq"])[1])
+                worst["exp_avg"] = max(worst["exp_avg"], _rel(mine[i]["exp_avg"], theirs[i]["exp_avg"]))
+                worst["exp_avg_sq"] = max(worst["exp_avg_sq"], _rel(mine[i]["exp_avg_sq"], theirs[i]["exp_avg_sq"]))
             # weights move by lr m / (sqrt(v) + eps) ~ +-lr whatever the gradient's size: an element whose gradient is
             # summation noise may go the other way (at most 2 lr apart) -- bounded, and counted
             far = total = 0
@@ -213,13 +224,11 @@ def test_flow_step_at_the_reference_width_vs_oracle():
         assert torch.equal(v, runs[True][1][k]), k
     assert runs[False][0] == runs[True][0]
     print(f"\n[1024/2048 x 3 blocks, 3 steps, each vs the oracle's step from the same state] losses {worst['loss']:.1e}; exp_avg "
-          f"{worst['exp_avg_med']:.1e} at the median, {worst['exp_avg']:.1e} at the 99th percentile, {worst['exp_avg_max']:.1e} at the "
-          f"maximum, exp_avg_sq {worst['exp_avg_sq']:.1e} at the 99th percentile (of max|.|); weights: max |diff| {worst['w_max']:.2f} "
-          f"lr, share more than 0.02 lr apart {worst['w_far']:.1e}")
-    # measured: 1.0e-7, 2.1e-6, 9.7e-5, 2.1e-5, 9.9e-4
-    assert worst["loss"] <= 1e-6 and worst["exp_avg_med"] <= 2e-5 and worst["exp_avg"] <= 5e-4 and worst["exp_avg_sq"] <= 2e-4
-    assert worst["exp_avg_max"] <= 1e-2
-    assert worst["w_max"] <= 2.002 and worst["w_far"] <= 1e-4
+          f"{worst['exp_avg']:.1e}, exp_avg_sq {worst['exp_avg_sq']:.1e} of max|.| (maximum over all elements); weights: max |diff| "
+          f"{worst['w_max']:.2f} lr, share more than 0.02 lr apart {worst['w_far']:.1e}")
+    # measured: 2.3e-7, 6.2e-7, 1.0e-6; 1.94 lr, 9.1e-7
+    assert worst["loss"] <= 2e-6 and worst["exp_avg"] <= 1e-5 and worst["exp_avg_sq"] <= 1e-5
+    assert worst["w_max"] <= 2.002 and worst["w_far"] <= 1e-5
 
 
 def test_flow_training_refuses_what_it_cannot_do():
