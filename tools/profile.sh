@@ -18,6 +18,20 @@ mkdir -p $OUT
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 # (PMC passes and the one-stream trace issue the step eagerly: the same kernels, one dispatch per launch for the counters)
+seqtrain() {
+# 6. the flow stage's training step (BASELINE config 4): per-kernel times of tools/time_seq_train.py (replayed graph) and the HBM
+#    bytes of the step (eager issue, one stream: 3 warm-up + 2 timed steps)
+rm -rf $OUT/${TAG}_st $OUT/${TAG}_stfetch $OUT/${TAG}_stwrite
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_st -- python3 tools/time_seq_train.py --reps 10 > $OUT/${TAG}_seq_train_time.json 2> $OUT/${TAG}_st.err
+cp $(ls $OUT/${TAG}_st/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_seq_train_kernel_stats.csv 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_stfetch -- python3 tools/time_seq_train.py --reps 2 --eager > /dev/null 2> $OUT/${TAG}_stfetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_stwrite -- python3 tools/time_seq_train.py --reps 2 --eager > /dev/null 2> $OUT/${TAG}_stwrite.err
+python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_stfetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_stwrite/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic_seq_train.json
+rm -rf $OUT/${TAG}_st $OUT/${TAG}_stfetch $OUT/${TAG}_stwrite
+# the cVAE stage's step at the same configuration's sizes
+python3 tools/time_seq_train.py --stage cvae --reps 10 > $OUT/${TAG}_seq_train_cvae_time.json 2>> $OUT/${TAG}_st.err
+}
+if [ "${2:-}" = "seqtrain" ]; then seqtrain; ls -la $OUT/${TAG}_*; exit 0; fi
 BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-config1 --no-render --no-variants --hip-graph off"
 
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
@@ -55,15 +69,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_sfe
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_swrite -- python3 tools/time_seq.py --rows 16 --reps 4 --eager --only reverse > /dev/null 2> $OUT/${TAG}_swrite.err
 python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_sfetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_swrite/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic_seq.json
 rm -rf $OUT/${TAG}_seq $OUT/${TAG}_sfetch $OUT/${TAG}_swrite
-# 6. the flow stage's training step (BASELINE config 4): per-kernel times of tools/time_seq_train.py (replayed graph) and the HBM
-#    bytes of the step (eager issue, one stream: 3 warm-up + 2 timed steps)
-rm -rf $OUT/${TAG}_st $OUT/${TAG}_stfetch $OUT/${TAG}_stwrite
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_st -- python3 tools/time_seq_train.py --reps 10 > $OUT/${TAG}_seq_train_time.json 2> $OUT/${TAG}_st.err
-cp $(ls $OUT/${TAG}_st/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_seq_train_kernel_stats.csv 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_stfetch -- python3 tools/time_seq_train.py --reps 2 --eager > /dev/null 2> $OUT/${TAG}_stfetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_stwrite -- python3 tools/time_seq_train.py --reps 2 --eager > /dev/null 2> $OUT/${TAG}_stwrite.err
-python3 tools/pmc_summary.py traffic $(ls $OUT/${TAG}_stfetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${TAG}_stwrite/*/*_counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic_seq_train.json
-rm -rf $OUT/${TAG}_st $OUT/${TAG}_stfetch $OUT/${TAG}_stwrite
+seqtrain
 # the raw per-dispatch tables are large: keep the summaries only
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq
 ls -la $OUT/${TAG}_*
