@@ -29,6 +29,7 @@
 //     and the next operand's x.  The decoder's optional input layer is folded into the gate matrix when the weights are packed.
 #include "common.h"
 #include "../../include/vunet_seq_train.h"
+#include "../../include/vunet_seq_tiled.h"
 
 namespace {
 
@@ -64,7 +65,19 @@ __device__ __forceinline__ float seq_act(float v, int act) {
 // The weight stream is the cost and a wave has few chunks (2 - 8), so what matters is bytes in flight: a group of U chunks
 // issues all of its loads (weights of RT tiles, the operand of NB batch tiles) before the first MFMA.  The scheduling barrier
 // keeps it that way: without it the scheduler interleaves loads and uses to save registers and keeps ~7 loads in flight.
-template <int NB, int RT, int U, int WAVES>
+#ifdef SEQ_W_NO_NT   // (timing-ablation build, tools/ab_build.sh)
+__device__ __forceinline__ float4 seq_w_load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#else
+typedef float seq_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 seq_w_load(const float* p) {
+  const seq_f4v t = __builtin_nontemporal_load(reinterpret_cast<const seq_f4v*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+#endif
+
+// LAY (include/vunet_seq_tiled.h): bit 0 -- the weights are tile-major images, bit 1 -- the operand is: a chunk is then 2 KB
+// contiguous, [half][lane] float4, and each of a wave's loads covers 1 KB contiguous.
+template <int NB, int RT, int U, int WAVES, int LAY>
 __device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const float* __restrict__ w, const float* __restrict__ x, int c0,
                                                  f32x4 (&acc)[RT][NB]) {
   float4 wv[RT][U][2], xv[NB][U][2];
@@ -72,17 +85,32 @@ __device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const f
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* wp = w + (size_t)rt * 16 * a.K + 32 * (c0 + WAVES * u);
-      wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
-      wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 4);
+      if constexpr (LAY & 1) {   // (read once per pass by this one workgroup: streamed past the caches' retention, SEQ_W_NT)
+        const float* wp = w + (size_t)rt * 16 * a.K + 512 * (c0 + WAVES * u);
+        wv[rt][u][0] = seq_w_load(wp);
+        wv[rt][u][1] = seq_w_load(wp + 256);
+      } else {
+        // (row-major weights: the parameters themselves when a flow trains -- the input-gradient chain and the update sweep read
+        //  them again within the same block's 168 MB, from the Infinity Cache: default policy.  Non-temporal here: 7.21 -> 7.40 ms
+        //  per training step.)
+        const float* wp = w + (size_t)rt * 16 * a.K + 32 * (c0 + WAVES * u);
+        wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
+        wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 4);
+      }
     }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* xp = x + (size_t)nb * 16 * a.ldx + 32 * (c0 + WAVES * u);
-      xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
-      xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 4);
+      if constexpr (LAY & 2) {
+        const float* xp = x + (size_t)nb * 16 * a.K + 512 * (c0 + WAVES * u);
+        xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
+        xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 256);
+      } else {
+        const float* xp = x + (size_t)nb * 16 * a.ldx + 32 * (c0 + WAVES * u);
+        xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
+        xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 4);
+      }
     }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -111,15 +139,18 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 // WAVES = 16 where K has >= 16 chunks, else 4.  Four waves with 16 chunks each and sixteen with 4 measured the same on the
 // 2048 x 2048 layers (12 us: the bound is what a CU pulls through its L1, not the number of round trips); sixteen are kept
 // because the batch tiles' epilogues then run on separate waves and the short layers request all their weights at once.
-template <int NB, int RT, int WAVES, bool LSTM = false>
+template <int NB, int RT, int WAVES, bool LSTM = false, int LAY = 0>
 __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a) {
   __shared__ float4 red[WAVES][RT][NB][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16 * RT, net = blockIdx.z;
   const int kb = a.K / a.S, nchunk = kb >> 5;   // (S = 1 everywhere but the flow's 512-row head layers)
-  const float* __restrict__ w = a.w[net] + (size_t)(m0 + i) * a.K + (size_t)blockIdx.y * kb + 8 * kq;
-  const float* __restrict__ x = a.x + (a.shared_in ? 0 : (size_t)net * a.Bp * a.ldx) + (size_t)i * a.ldx + (size_t)blockIdx.y * kb + 8 * kq;
+  const float* __restrict__ w = (LAY & 1) ? a.w[net] + (size_t)m0 * a.K + (size_t)blockIdx.y * kb * 16 + 4 * lane
+                                          : a.w[net] + (size_t)(m0 + i) * a.K + (size_t)blockIdx.y * kb + 8 * kq;
+  const float* __restrict__ x = (LAY & 2) ? a.x + (a.shared_in ? 0 : (size_t)net * a.Bp * a.K) + (size_t)blockIdx.y * kb * 16 + 4 * lane
+                                          : a.x + (a.shared_in ? 0 : (size_t)net * a.Bp * a.ldx) + (size_t)i * a.ldx +
+                                                (size_t)blockIdx.y * kb + 8 * kq;
   f32x4 acc[RT][NB];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -129,14 +160,14 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
   int c = wave;
   // (16 waves share the CU's registers: 128 each)
   constexpr int UMAX = WAVES == 16 ? (NB == 1 ? 4 : 2) : ((NB + RT <= 3) ? 4 : 2);
-  for (; c + WAVES * (UMAX - 1) < nchunk; c += WAVES * UMAX) seq_linear_group<NB, RT, UMAX, WAVES>(a, w, x, c, acc);
+  for (; c + WAVES * (UMAX - 1) < nchunk; c += WAVES * UMAX) seq_linear_group<NB, RT, UMAX, WAVES, LAY>(a, w, x, c, acc);
   if constexpr (UMAX == 4)
     if (c + WAVES < nchunk) {
-      seq_linear_group<NB, RT, 2, WAVES>(a, w, x, c, acc);
+      seq_linear_group<NB, RT, 2, WAVES, LAY>(a, w, x, c, acc);
       c += 2 * WAVES;
     }
   if constexpr (UMAX > 1)
-    for (; c < nchunk; c += WAVES) seq_linear_group<NB, RT, 1, WAVES>(a, w, x, c, acc);
+    for (; c < nchunk; c += WAVES) seq_linear_group<NB, RT, 1, WAVES, LAY>(a, w, x, c, acc);
   // every wave's partial -> LDS; wave w < NB adds them in wave order for batch tile w and finishes that tile (the epilogues run
   // side by side: with tanh / the LSTM cell in them, one wave finishing four tiles was a 4 us tail)
 #pragma unroll
@@ -192,7 +223,16 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
     if (bias) bv = *reinterpret_cast<const float4*>(bias + col + 16 * rt);
     float4 t = add4(v[rt], bv);
     t = make_float4(seq_act(t.x, act), seq_act(t.y, act), seq_act(t.z, act), seq_act(t.w, act));
-    *reinterpret_cast<float4*>(y + (size_t)(nb * 16 + i) * a.M + 16 * rt) = t;
+    if constexpr (LAY & 4) {
+      // the next layer's operand tile: this lane's four columns m0 + 4 kq .. + 3 of batch row i are chunk m0 / 32, slot
+      // 2 (m0 / 16 & 1) + kq / 2, half kq & 1 there -- one of its lane slots' float4
+      const int mm = m0 + 16 * rt;
+      float* yt = a.y + (size_t)net * a.Bp * a.M + ((size_t)(nb * (a.M >> 5) + (mm >> 5)) * 2 + (kq & 1)) * 256 +
+                  (i + 16 * (2 * ((mm >> 4) & 1) + (kq >> 1))) * 4;
+      *reinterpret_cast<float4*>(yt) = t;
+    } else {
+      *reinterpret_cast<float4*>(y + (size_t)(nb * 16 + i) * a.M + 16 * rt) = t;
+    }
   }
 }
 
@@ -450,7 +490,25 @@ __global__ __launch_bounds__(256) void seq_pose_project_kernel(const float* x, i
   kps[2 * (size_t)idx + 1] = (float)(w * cam[17]);
 }
 
+// wt[mt][c][h][l][e] = w[16 mt + (l & 15)][32 c + 8 (l >> 4) + 4 h + e]: one thread per float4 of the image
+__global__ __launch_bounds__(256) void seq_pack_tiles_kernel(const float* __restrict__ w, int ld, int M, int K, float* __restrict__ wt) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
+  if (idx >= (size_t)M * K / 4) return;
+  const int l = (int)(idx & 63), h = (int)((idx >> 6) & 1);
+  const size_t tc = idx >> 7;                                   // mt * (K / 32) + c
+  const int nck = K >> 5, mt = (int)(tc / nck), c = (int)(tc - (size_t)mt * nck);
+  reinterpret_cast<float4*>(wt)[idx] =
+      *reinterpret_cast<const float4*>(w + (size_t)(16 * mt + (l & 15)) * ld + 32 * c + 8 * (l >> 4) + 4 * h);
+}
+
 }  // namespace
+
+extern "C" int vunet_seq_pack_tiles(const float* w, int32_t ld, int32_t M, int32_t K, float* wt, void* stream) {
+  if (!w || !wt || M < 16 || M % 16 || K < 32 || K % 32 || ld < K || ld % 4) return VUNET_ERR_ARG;
+  const size_t n4 = (size_t)M * K / 4;
+  VUNET_LAUNCH(seq_pack_tiles_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ld, M, K, wt);
+  return vunet_check_launch();
+}
 
 extern "C" int vunet_seq_pose_project(const float* x, int32_t n_use, const int32_t* dims_to_use, const double* mean, const double* stdv,
                                       int32_t D, int32_t f32_math, const double* cam, float* kps, int32_t T, int32_t J, void* stream) {
@@ -466,9 +524,11 @@ extern "C" int vunet_seq_actnorm_init(const float* x, int32_t ld, int32_t B, int
   return vunet_check_launch();
 }
 
-extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* x, const float* bias0,
-                                const float* bias1, float* y, void* stream) {
+static int seq_linear_launch(const vunet_seq_linear_desc* d, int layout, const float* w0, const float* w1, const float* x,
+                             const float* bias0, const float* bias1, float* y, void* stream) {
   if (!d || !w0 || !x || !y) return VUNET_ERR_ARG;
+  if (layout != 0 && layout != 3 && layout != 5 && layout != 7) return VUNET_ERR_UNSUPPORTED;   // (the forms the flow uses)
+  if ((layout & 4) && (d->S != 1 || d->M % 32)) return VUNET_ERR_ARG;
   if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->M < 16 || d->M % 16) return VUNET_ERR_ARG;
   if (d->S < 1 || d->S > 8 || d->K < 32 || d->K % (32 * d->S) || d->ldx < d->K || d->ldx % 4) return VUNET_ERR_ARG;
@@ -498,10 +558,15 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
   // wave's operand loads are four times its weight loads and four waves with deeper groups are faster (flow training step at
   // 64 rows: 7.77 -> 7.41 ms; at 16 rows the two forms measured the same, profiles/r05_seq_time.txt)
   const bool wide = d->K / d->S >= 16 * 32 && d->B <= 32;
-#define SEQ_LINEAR_CASE(NB)                                                              \
-  case NB:                                                                               \
-    if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16>), grid, dim3(1024), 0, st, a);  \
-    else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4>), grid, dim3(256), 0, st, a);         \
+#define SEQ_LINEAR_LAY(NB, LAY)                                                                     \
+  if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16, false, LAY>), grid, dim3(1024), 0, st, a);   \
+  else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4, false, LAY>), grid, dim3(256), 0, st, a);
+#define SEQ_LINEAR_CASE(NB)                        \
+  case NB:                                         \
+    if (layout == 0) { SEQ_LINEAR_LAY(NB, 0) }     \
+    else if (layout == 3) { SEQ_LINEAR_LAY(NB, 3) } \
+    else if (layout == 5) { SEQ_LINEAR_LAY(NB, 5) } \
+    else { SEQ_LINEAR_LAY(NB, 7) }                 \
     break;
   switch (a.Bp / 16) {
     SEQ_LINEAR_CASE(1)
@@ -511,7 +576,18 @@ extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0,
     default: return VUNET_ERR_ARG;
   }
 #undef SEQ_LINEAR_CASE
+#undef SEQ_LINEAR_LAY
   return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* x, const float* bias0,
+                                const float* bias1, float* y, void* stream) {
+  return seq_linear_launch(d, 0, w0, w1, x, bias0, bias1, y, stream);
+}
+
+extern "C" int vunet_seq_linear_tiled(const vunet_seq_linear_desc* d, int32_t layout, const float* w0, const float* w1, const float* x,
+                                      const float* bias0, const float* bias1, float* y, void* stream) {
+  return seq_linear_launch(d, layout, w0, w1, x, bias0, bias1, y, stream);
 }
 
 extern "C" int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const float* bias_s,

@@ -27,6 +27,24 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 
 __device__ __forceinline__ float comp4(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
+// weights and moments are streamed: each byte is touched once per kernel by one workgroup
+#ifdef VUNET_SEQ_NO_NT   // (timing-ablation build, tools/ab_build.sh)
+#define SEQ_NT_LOAD(ptr) (*reinterpret_cast<const float4*>(ptr))
+#define SEQ_NT_STORE(ptr, val) (*reinterpret_cast<float4*>(ptr) = (val))
+#else
+typedef float seq_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 seq_nt_load(const float* p) {
+  const seq_f4 t = __builtin_nontemporal_load(reinterpret_cast<const seq_f4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void seq_nt_store(float* p, const float4& v) {
+  seq_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<seq_f4*>(p));
+}
+#define SEQ_NT_LOAD(ptr) seq_nt_load(ptr)
+#define SEQ_NT_STORE(ptr, val) seq_nt_store(ptr, val)
+#endif
+
 // ------------------------------------------------------------------------------------------------ dX = dZ . W
 struct SeqDxArgs {
   const float* w[2];   // [M][K]
@@ -57,7 +75,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   for (int g = wave; g < ngrp; g += WAVES) {
     float4 wv[4], dv[NB];
 #pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) wv[e2] = *reinterpret_cast<const float4*>(w + (size_t)(16 * g + e2) * a.ldw);
+    for (int e2 = 0; e2 < 4; ++e2) wv[e2] = *reinterpret_cast<const float4*>(w + (size_t)(16 * g + e2) * a.ldw);   // (default policy: the sweep re-reads W)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) dv[nb] = *reinterpret_cast<const float4*>(dz + (size_t)16 * nb * a.M + 16 * g);
     __builtin_amdgcn_sched_barrier(0);
@@ -201,22 +219,7 @@ __device__ __forceinline__ void adam_update(const AdamResolved& h, float g, floa
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dZ^T . X (+ Adam)
-#ifdef VUNET_SEQ_NO_NT   // (timing-ablation build, tools/ab_build.sh)
-#define SEQ_NT_LOAD(ptr) (*reinterpret_cast<const float4*>(ptr))
-#define SEQ_NT_STORE(ptr, val) (*reinterpret_cast<float4*>(ptr) = (val))
-#else
-typedef float seq_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 seq_nt_load(const float* p) {
-  const seq_f4 t = __builtin_nontemporal_load(reinterpret_cast<const seq_f4*>(p));
-  return make_float4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ void seq_nt_store(float* p, const float4& v) {
-  seq_f4 t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<seq_f4*>(p));
-}
-#define SEQ_NT_LOAD(ptr) seq_nt_load(ptr)
-#define SEQ_NT_STORE(ptr, val) seq_nt_store(ptr, val)
-#endif
+
 // LDS tiles are [rows][64] floats with the column XOR-ed by 16 * (row & 3) (operand tiles: the four rows 4 c + q of a matrix
 // step fall into four disjoint bank groups) resp. 16 * ((row >> 2) & 3) (the tile of dW on its way from the accumulator layout
 // -- rows 4 q + r -- to rows): conflict-free without padding, 32 KB per workgroup at 64 batch rows = five workgroups per CU.

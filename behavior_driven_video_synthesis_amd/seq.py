@@ -89,9 +89,25 @@ def padded_vector(b: torch.Tensor, n_pad: int) -> torch.Tensor:
     return out
 
 
-def linear(desc: SeqLinearDesc, w: Sequence[torch.Tensor], x: torch.Tensor, bias: Sequence[Optional[torch.Tensor]], y: torch.Tensor):
+def linear(desc: SeqLinearDesc, w: Sequence[torch.Tensor], x: torch.Tensor, bias: Sequence[Optional[torch.Tensor]], y: torch.Tensor,
+           layout: int = 0):
+    """``layout`` (include/vunet_seq_tiled.h): 1 = tile-major weight images, 2 = tile-major operand, 4 = tile-major output."""
+    if layout:
+        _call("vunet_seq_linear_tiled", ctypes.byref(desc), layout, _p(w[0]), _p(w[1] if len(w) > 1 else None), _p(x), _p(bias[0]),
+              _p(bias[1] if len(bias) > 1 else None), _p(y), _stream())
+        return
     _call("vunet_seq_linear", ctypes.byref(desc), _p(w[0]), _p(w[1] if len(w) > 1 else None), _p(x), _p(bias[0]),
           _p(bias[1] if len(bias) > 1 else None), _p(y), _stream())
+
+
+def tile_image(w_img: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A row-major [M, K] weight image -> its tile-major copy (``vunet_seq_pack_tiles``): every wave load of the layer's kernel
+    then covers 1 KB contiguous."""
+    m, k = w_img.shape
+    if out is None:
+        out = torch.empty(m * k, device=w_img.device, dtype=torch.float32)
+    _call("vunet_seq_pack_tiles", _p(w_img), k, m, k, _p(out), _stream())
+    return out
 
 
 class MlpGroup:
@@ -102,9 +118,11 @@ class MlpGroup:
     are single."""
 
     def __init__(self, layers: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], k_in_pad: int, tanh_head: Sequence[bool],
-                 split_head: bool = False, pad_hidden: int = 32, pad_out: int = 16):
+                 split_head: bool = False, pad_hidden: int = 32, pad_out: int = 16, tiled: bool = False):
         """``pad_hidden`` / ``pad_out``: the multiples the hidden / head widths are padded to (training pads both to 64: the
-        tiles of ``vunet_seq_dx`` / ``vunet_seq_dw``)."""
+        tiles of ``vunet_seq_dx`` / ``vunet_seq_dw``).  ``tiled``: the kernels read TILE-MAJOR copies of the weight images and
+        hand the hidden activations to each other tile-major (include/vunet_seq_tiled.h) -- a second copy of the weights (the
+        row-major parameters stay what ``state_dict`` / an optimiser see), bit-identical results."""
         self.nets = len(layers)
         n_layers = len(layers[0])
         self.dims = []     # per layer: (m_pad, k_pad)
@@ -120,6 +138,8 @@ class MlpGroup:
             self.dims.append((m_pad, k_pad))
             k_pad = m_pad
         self.out_pad = self.dims[-1][0]
+        self.tiled = tiled and n_layers >= 2
+        self.wt = [[tile_image(weight_image(net[li][0], m, k)) for net in layers] for li, (m, k) in enumerate(self.dims)] if self.tiled else None
         # the head layer as raw partial slabs for seq_coupling_kernel to add (``split_head``: the consumer is that kernel): a
         # 512-row head would otherwise run on 32 workgroups per net; K is split until the launch has 256
         self.head_split = 1
@@ -142,7 +162,10 @@ class MlpGroup:
             act = self.head_act if li == last else [ACT_LRELU, ACT_LRELU]
             d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, act[0], act[1], self.nets, shared,
                               self.head_split if li == last else 1)
-            linear(d, self.w[li], src, self.b[li], dst)
+            if self.tiled:   # layer 0 reads the row-major state rows; the heads' output is the coupling kernel's, row-major
+                linear(d, self.wt[li], src, self.b[li], dst, layout=1 | (2 if li > 0 else 0) | (4 if li < last else 0))
+            else:
+                linear(d, self.w[li], src, self.b[li], dst)
             src, shared = dst, 0
         return src
 
@@ -307,6 +330,7 @@ class FlowEngine:
 
     PAD = 32          # operand row length / MLP input and hidden widths are padded to this multiple
     PAD_OUT = 16      # ... and the head widths to this one
+    TILED = os.environ.get("VUNET_SEQ_TILED", "1") != "0"   # tile-major weight copies + activations (inference plans)
 
     def __init__(self, flow):
         self._flow = weakref.ref(flow)     # the module owns the engine; no cycle for the collector to find
@@ -338,7 +362,8 @@ class FlowEngine:
         for blk in blocks:
             cp = blk.coupling
             halves = [MlpGroup([[(l.weight, l.bias) for l in cp.s[i].linears()], [(l.weight, l.bias) for l in cp.t[i].linears()]],
-                               _up(c1, self.PAD), [True, False], split_head=True, pad_hidden=self.PAD, pad_out=self.PAD_OUT)
+                               _up(c1, self.PAD), [True, False], split_head=True, pad_hidden=self.PAD, pad_out=self.PAD_OUT,
+                               tiled=self.TILED)
                       for i in range(2)]
             self.blocks.append(dict(
                 halves=halves, scale=blk.norm_layer.scale.detach().reshape(-1), loc=blk.norm_layer.loc.detach().reshape(-1),
@@ -347,7 +372,7 @@ class FlowEngine:
         self._all_init = False
         # a re-pack that finds every image where it was (parameters used in place, updated by an optimiser: their version
         # counters moved, their storage did not) keeps the buffers and the recordings, which hold nothing but pointers
-        sig = tuple(t.data_ptr() for blk in self.blocks for h in blk["halves"] for lay in (h.w + h.b) for t in lay) + tuple(
+        sig = tuple(t.data_ptr() for blk in self.blocks for h in blk["halves"] for lay in (h.w + h.b + (h.wt or [])) for t in lay) + tuple(
             blk[k].data_ptr() for blk in self.blocks for k in ("scale", "loc", "fwd", "bwd"))
         if sig != getattr(self, "_image_sig", None):
             self._image_sig = sig

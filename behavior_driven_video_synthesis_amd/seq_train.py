@@ -116,6 +116,7 @@ class FlowTrainEngine(FlowEngine):
 
     PAD = 64
     PAD_OUT = 64
+    TILED = False     # the parameters are the kernels' images here and change every step: no second copy to keep in step
 
     def __init__(self, flow, lr: float = 1e-3, betas=(0.5, 0.9), eps: float = 1e-8, weight_decay: float = 0.0):
         super().__init__(flow)
@@ -374,6 +375,9 @@ class FlowTrainEngine(FlowEngine):
             self._issue_train_backward(rows, p, p["dzl"], self.ld, p["tables"], self.adam.hp)
             self._write_back()
         self.graph.run_step(("train", rows), issue)
+        inf = getattr(self.flow, "_engine", None)
+        if inf is not None:
+            inf._packed_for = None       # its tile-major weight copies are a step behind: re-packed at its next call
         return p["scalars"]
 
     # ---- autograd's view of the same kernels

@@ -1,0 +1,42 @@
+/*
+ * vunet_seq_tiled.h -- C ABI of the tile-major form of the behaviour path's MLP layers (csrc/seq.hip; part of libvunet_hip.so,
+ * conventions of vunet_hip.h).  It replaces the same reference operations as vunet_seq_linear: the Linear + LeakyReLU / Tanh
+ * stacks of lib/modules.py:236-257 inside models/flow/blocks.py:276-319.
+ *
+ * vunet_seq_linear reads a [16 rows][32 k] chunk of W as sixteen 128-byte row pieces, 2048 floats apart, and a lane's two 16-byte
+ * loads of a chunk sit 16 bytes apart with 16-byte gaps between lanes.  In TILE-MAJOR order a chunk is 2 KB contiguous and every
+ * wave instruction loads 1 KB contiguous:
+ *
+ *   weights   wt[M / 16][K / 32][2][64][4]   wt[mt][c][h][l][e] = w[16 mt + (l & 15)][32 c + 8 (l >> 4) + 4 h + e]
+ *   operand   xt[Bp / 16][K / 32][2][64][4]  xt[nb][c][h][l][e] = x[16 nb + (l & 15)][32 c + 8 (l >> 4) + 4 h + e]
+ *
+ * (lane l of a wave holds row l & 15 and the eight k of slot l >> 4 of a chunk: the operand registers of the kernel's eight
+ * v_mfma_f32_16x16x4_f32 per chunk, loaded as they are used).  The arithmetic and its order are those of vunet_seq_linear: results
+ * are bit-identical.
+ *
+ *   vunet_seq_pack_tiles     w [M][ld] row-major (M % 16 == 0, K % 32 == 0, ld % 4 == 0) -> wt
+ *   vunet_seq_linear_tiled   vunet_seq_linear with `layout` bits: 1 = the weights are wt images, 2 = the operand is xt (one per
+ *                            net or shared, as x; ldx is ignored), 4 = the output is written as the NEXT layer's xt
+ *                            ([nets][Bp / 16][M / 32][2][64][4]; M % 32 == 0, S == 1).  Layer 0 of an MLP of the flow reads the
+ *                            row-major state rows and writes tiles (1 | 4), hidden layers 1 | 2 | 4, the head layer 1 | 2.
+ */
+#ifndef VUNET_SEQ_TILED_H
+#define VUNET_SEQ_TILED_H
+#include "vunet_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VUNET_SEQ_TILED_W 1
+#define VUNET_SEQ_TILED_X 2
+#define VUNET_SEQ_TILED_Y 4
+
+int vunet_seq_pack_tiles(const float* w, int32_t ld, int32_t M, int32_t K, float* wt, void* stream);
+int vunet_seq_linear_tiled(const vunet_seq_linear_desc* d, int32_t layout, const float* w0, const float* w1, const float* x,
+                           const float* bias0, const float* bias1, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

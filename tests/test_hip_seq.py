@@ -266,6 +266,35 @@ def test_a_module_left_on_the_cpu_or_cast_is_refused():
         net.cuda().half().infer_b(torch.randn(2, 3, 51, device="cuda"), False)
 
 
+@pytest.mark.parametrize("shape", [(96, 160, 2, 2, 5), (33, 48, 1, 2, 4), (1024, 2048, 2, 2, 16)])
+def test_tile_major_weights_and_activations_change_nothing(shape):
+    """include/vunet_seq_tiled.h: the flow's inference plans read tile-major COPIES of the weight images and hand the hidden
+    activations to each other tile-major (every wave load 1 KB contiguous); the arithmetic and its order are unchanged, so both
+    directions, logdet included, are bit-identical to the row-major path -- padded widths, an odd channel count, the reference
+    width; eager and replayed."""
+    chan, mid, depth, n_flows, bsz = shape
+    flow, _ = _random_flow(chan, mid, depth, n_flows, 31, s_gain=0.1)
+    z = seeded_randn("tm.z", (bsz, chan), 31).cuda()
+    x = seeded_randn("tm.x", (bsz, chan), 31).cuda()
+    eng = flow.flow.engine()
+    assert eng.TILED
+    outs = {}
+    for tiled in (True, False):
+        eng.TILED = tiled
+        eng._packed_for = None
+        eng._image_sig = None
+        for graph in (False, True):
+            eng.graph.enabled = graph
+            rev = [flow.reverse(z) for _ in range(2)][-1]
+            fwd, ld = [flow(x) for _ in range(2)][-1]
+            outs[(tiled, graph)] = (rev.clone(), fwd.clone(), ld.clone())
+        assert all((h.wt is not None) == tiled for blk in eng.blocks for h in blk["halves"])
+    ref = outs[(False, False)]
+    for key, got in outs.items():
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), key
+
+
 def test_full_flow_of_the_reference_configuration_vs_oracle():
     """config/behavior_net.yaml's WHOLE flow -- 1024 channels, 2048 hidden, depth 2, all 15 blocks (629 M
     parameters, 2.5 GB) -- in both directions at 16 rows (experiments/behavior_net.py:1173 samples that many), where the
