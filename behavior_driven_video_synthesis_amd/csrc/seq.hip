@@ -664,7 +664,7 @@ static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, co
   a.B = d->B;
   const dim3 grid(a.M / 16, 1, 1);
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = a.K >= 16 * 32;
+  const bool wide = a.K >= 16 * 32 && d->B <= 32;   // (3 - 4 batch tiles: four waves, as vunet_seq_linear; 50-step roll-out at 64 rows 1.03 -> 0.93 ms)
 #define SEQ_LSTM_CASE(NB)                                                                      \
   case NB:                                                                                     \
     if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16, true>), grid, dim3(1024), 0, st, a);  \
