@@ -49,6 +49,7 @@ struct SeqLinearArgs {
   float* xh_next;         // [Bp][ldx] the NEXT step's operand rows (another buffer than x): h at hoff
   float* h_out;           // [Bp][H] or NULL
   const float* x_next;    // encoder: the next input pose, row b at + b * seq_stride (NULL: the decoder's second launch writes x)
+  float* y2;              // tile-major output (LAY & 4) AND this row-major copy [nets][Bp][M] (training keeps both; NULL: none)
   float* gates_out;       // training: [Bp][H][4] = sigmoid(i), sigmoid(f), tanh(g), sigmoid(o) of every unit (NULL: not kept)
   long long seq_stride;
   int H, hoff, n, B;
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
       float* yt = a.y + (size_t)net * a.Bp * a.M + ((size_t)(nb * (a.M >> 5) + (mm >> 5)) * 2 + (kq & 1)) * 256 +
                   (i + 16 * (2 * ((mm >> 4) & 1) + (kq >> 1))) * 4;
       *reinterpret_cast<float4*>(yt) = t;
+      if (a.y2) *reinterpret_cast<float4*>(a.y2 + (size_t)net * a.Bp * a.M + col + (size_t)(nb * 16 + i) * a.M + 16 * rt) = t;
     } else {
       *reinterpret_cast<float4*>(y + (size_t)(nb * 16 + i) * a.M + 16 * rt) = t;
     }
@@ -525,9 +527,10 @@ extern "C" int vunet_seq_actnorm_init(const float* x, int32_t ld, int32_t B, int
 }
 
 static int seq_linear_launch(const vunet_seq_linear_desc* d, int layout, const float* w0, const float* w1, const float* x,
-                             const float* bias0, const float* bias1, float* y, void* stream) {
+                             const float* bias0, const float* bias1, float* y, float* y2, void* stream) {
   if (!d || !w0 || !x || !y) return VUNET_ERR_ARG;
-  if (layout != 0 && layout != 3 && layout != 5 && layout != 7) return VUNET_ERR_UNSUPPORTED;   // (the forms the flow uses)
+  if (layout < 0 || layout > 7 || layout == 1) return VUNET_ERR_UNSUPPORTED;   // (inference: 3 / 5 / 7; training: 2 / 4 / 6)
+  if (y2 && !(layout & 4)) return VUNET_ERR_ARG;
   if ((layout & 4) && (d->S != 1 || d->M % 32)) return VUNET_ERR_ARG;
   if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->M < 16 || d->M % 16) return VUNET_ERR_ARG;
@@ -549,6 +552,7 @@ static int seq_linear_launch(const vunet_seq_linear_desc* d, int layout, const f
   a.shared_in = d->shared_in;
   a.S = d->S;
   a.c_in = nullptr; a.c_out = nullptr; a.xh_next = nullptr; a.h_out = nullptr; a.x_next = nullptr; a.gates_out = nullptr;
+  a.y2 = y2;
   a.seq_stride = 0; a.H = a.hoff = a.n = a.B = 0;
   // (RT = 2, a 32-row tile per workgroup, halves the operand traffic per weight byte but leaves half the CUs without a workgroup
   // at every layer size of the reference configuration: not instantiated)
@@ -564,8 +568,11 @@ static int seq_linear_launch(const vunet_seq_linear_desc* d, int layout, const f
 #define SEQ_LINEAR_CASE(NB)                        \
   case NB:                                         \
     if (layout == 0) { SEQ_LINEAR_LAY(NB, 0) }     \
+    else if (layout == 2) { SEQ_LINEAR_LAY(NB, 2) } \
     else if (layout == 3) { SEQ_LINEAR_LAY(NB, 3) } \
+    else if (layout == 4) { SEQ_LINEAR_LAY(NB, 4) } \
     else if (layout == 5) { SEQ_LINEAR_LAY(NB, 5) } \
+    else if (layout == 6) { SEQ_LINEAR_LAY(NB, 6) } \
     else { SEQ_LINEAR_LAY(NB, 7) }                 \
     break;
   switch (a.Bp / 16) {
@@ -582,12 +589,12 @@ static int seq_linear_launch(const vunet_seq_linear_desc* d, int layout, const f
 
 extern "C" int vunet_seq_linear(const vunet_seq_linear_desc* d, const float* w0, const float* w1, const float* x, const float* bias0,
                                 const float* bias1, float* y, void* stream) {
-  return seq_linear_launch(d, 0, w0, w1, x, bias0, bias1, y, stream);
+  return seq_linear_launch(d, 0, w0, w1, x, bias0, bias1, y, nullptr, stream);
 }
 
 extern "C" int vunet_seq_linear_tiled(const vunet_seq_linear_desc* d, int32_t layout, const float* w0, const float* w1, const float* x,
-                                      const float* bias0, const float* bias1, float* y, void* stream) {
-  return seq_linear_launch(d, layout, w0, w1, x, bias0, bias1, y, stream);
+                                      const float* bias0, const float* bias1, float* y, float* y_rowmajor, void* stream) {
+  return seq_linear_launch(d, layout, w0, w1, x, bias0, bias1, y, y_rowmajor, stream);
 }
 
 extern "C" int vunet_seq_coupling(const vunet_seq_coupling_desc* d, const float* in, const float* st, const float* bias_s,
@@ -656,6 +663,7 @@ static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, co
   a.xh_next = xh_next;
   a.h_out = h_out;
   a.x_next = x_next;
+  a.y2 = nullptr;
   a.gates_out = gates_out;
   a.seq_stride = d->seq_stride;
   a.H = d->H;

@@ -90,11 +90,12 @@ def padded_vector(b: torch.Tensor, n_pad: int) -> torch.Tensor:
 
 
 def linear(desc: SeqLinearDesc, w: Sequence[torch.Tensor], x: torch.Tensor, bias: Sequence[Optional[torch.Tensor]], y: torch.Tensor,
-           layout: int = 0):
-    """``layout`` (include/vunet_seq_tiled.h): 1 = tile-major weight images, 2 = tile-major operand, 4 = tile-major output."""
+           layout: int = 0, y_rowmajor: Optional[torch.Tensor] = None):
+    """``layout`` (include/vunet_seq_tiled.h): 1 = tile-major weight images, 2 = tile-major operand, 4 = tile-major output
+    (``y_rowmajor``: and a row-major copy)."""
     if layout:
         _call("vunet_seq_linear_tiled", ctypes.byref(desc), layout, _p(w[0]), _p(w[1] if len(w) > 1 else None), _p(x), _p(bias[0]),
-              _p(bias[1] if len(bias) > 1 else None), _p(y), _stream())
+              _p(bias[1] if len(bias) > 1 else None), _p(y), _p(y_rowmajor), _stream())
         return
     _call("vunet_seq_linear", ctypes.byref(desc), _p(w[0]), _p(w[1] if len(w) > 1 else None), _p(x), _p(bias[0]),
           _p(bias[1] if len(bias) > 1 else None), _p(y), _stream())
@@ -152,11 +153,26 @@ class MlpGroup:
     def act_floats(self, b_pad: int) -> int:
         return max(self.nets * b_pad * m * (self.head_split if li == len(self.dims) - 1 else 1) for li, (m, _) in enumerate(self.dims))
 
-    def run(self, rows: int, xin: torch.Tensor, ldx: int, bufs: Sequence[torch.Tensor]) -> torch.Tensor:
+    def run(self, rows: int, xin: torch.Tensor, ldx: int, bufs: Sequence[torch.Tensor],
+            tile_bufs: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
         """``xin``: [b_pad, ldx] operand (read from column 0).  Returns the buffer holding the heads' [nets][b_pad][out_pad].
-        ``bufs``: two buffers used alternately, or one per layer (training keeps every layer's output)."""
+        ``bufs``: two buffers used alternately, or one per layer (training keeps every layer's output).  ``tile_bufs`` (training,
+        row-major weights): two more buffers through which the hidden activations ALSO go tile-major from layer to layer."""
         src, shared = xin, 1
         last = len(self.dims) - 1
+        if tile_bufs is not None and last >= 1:
+            for li, (m_pad, k_pad) in enumerate(self.dims):
+                dst = bufs[li % len(bufs)]
+                act = self.head_act if li == last else [ACT_LRELU, ACT_LRELU]
+                d = SeqLinearDesc(rows, m_pad, k_pad, ldx if li == 0 else k_pad, act[0], act[1], self.nets, shared,
+                                  self.head_split if li == last else 1)
+                if li == last:
+                    linear(d, self.w[li], tile_bufs[(li - 1) % 2], self.b[li], dst, layout=2)
+                else:
+                    linear(d, self.w[li], src if li == 0 else tile_bufs[(li - 1) % 2], self.b[li], tile_bufs[li % 2],
+                           layout=4 | (2 if li > 0 else 0), y_rowmajor=dst)
+                src, shared = dst, 0
+            return src
         for li, (m_pad, k_pad) in enumerate(self.dims):
             dst = bufs[li % len(bufs)]
             act = self.head_act if li == last else [ACT_LRELU, ACT_LRELU]

@@ -128,6 +128,9 @@ class FlowTrainEngine(FlowEngine):
         # 5120 workgroups hold every CU, the chain's 1024-thread workgroups wait for room) -- off unless asked for
         self.two_streams = os.environ.get("VUNET_SEQ_TRAIN_STREAMS", "1") == "2"
         self._side_stream = None
+        # hidden activations also handed from layer to layer tile-major (include/vunet_seq_tiled.h; the row-major copies are the
+        # backward pass's): bit-identical values
+        self.tile_activations = os.environ.get("VUNET_SEQ_TRAIN_TILED_X", "1") != "0"
 
     # ---- weights
     def _pack(self, dev=None):
@@ -186,6 +189,7 @@ class FlowTrainEngine(FlowEngine):
                  y=[[[z(h.nets * b_pad * m * (h.head_split if li == n_lay - 1 else 1)) for li, (m, _) in enumerate(h.dims)]
                      for h in blk["halves"]] for blk in self.blocks],
                  dz=[[[z(h.nets * b_pad * m) for (m, _) in h.dims] for h in blk["halves"]] for blk in self.blocks],
+                 yt=[z(max(h0.nets * b_pad * m for (m, _) in h0.dims[:-1])) for _ in range(2)] if n_lay > 1 else None,
                  dzl=z(b_pad, self.ld), dld=z(b_pad), g0=[z(b_pad, self.ld) for _ in range(2)], g1=z(b_pad, self.ld),
                  gfull=[z(b_pad, self.ld) for _ in range(n)], dx=z(rows, self.C))
         # raw input-gradient slabs: S row ranges of W per launch, chosen so that a launch has >= 256 workgroups
@@ -211,9 +215,10 @@ class FlowTrainEngine(FlowEngine):
         self._step(rows, p["x_in"], self.C, p["s0"][0], self.ld, 0, scale=self.blocks[0]["scale"], loc=self.blocks[0]["loc"], logdet=ld_acc)
         for i, blk in enumerate(self.blocks):
             h0, h1 = blk["halves"]
-            part = h0.run(rows, p["s0"][i], self.ld, p["y"][i][0])
+            tb = p["yt"] if self.tile_activations else None
+            part = h0.run(rows, p["s0"][i], self.ld, p["y"][i][0], tile_bufs=tb)
             self._step(rows, p["s0"][i], self.ld, p["s1"][i], self.ld, 0, half=h0, st=part, map_=self.swap, logdet=ld_acc)
-            part = h1.run(rows, p["s1"][i], self.ld, p["y"][i][1])
+            part = h1.run(rows, p["s1"][i], self.ld, p["y"][i][1], tile_bufs=tb)
             last = i == n - 1
             nxt = None if last else self.blocks[i + 1]
             self._step(rows, p["s1"][i], self.ld, p["x_out"] if last else p["s0"][i + 1], self.C if last else self.ld, 0, half=h1, st=part,

@@ -19,6 +19,10 @@
  *                            net or shared, as x; ldx is ignored), 4 = the output is written as the NEXT layer's xt
  *                            ([nets][Bp / 16][M / 32][2][64][4]; M % 32 == 0, S == 1).  Layer 0 of an MLP of the flow reads the
  *                            row-major state rows and writes tiles (1 | 4), hidden layers 1 | 2 | 4, the head layer 1 | 2.
+ *                            Training reads the parameters themselves (row-major, updated every step: no bit 1) and still hands the
+ *                            activations on tile-major (4, 2 | 4, 2) -- at 64 batch rows the operand is four times the weight
+ *                            bytes of a workgroup; y_rowmajor != NULL (with bit 4): the output is ALSO written row-major
+ *                            [nets][Bp][M], what the backward kernels of vunet_seq_train.h read.
  */
 #ifndef VUNET_SEQ_TILED_H
 #define VUNET_SEQ_TILED_H
@@ -34,7 +38,7 @@ extern "C" {
 
 int vunet_seq_pack_tiles(const float* w, int32_t ld, int32_t M, int32_t K, float* wt, void* stream);
 int vunet_seq_linear_tiled(const vunet_seq_linear_desc* d, int32_t layout, const float* w0, const float* w1, const float* x,
-                           const float* bias0, const float* bias1, float* y, void* stream);
+                           const float* bias0, const float* bias1, float* y, float* y_rowmajor, void* stream);
 
 #ifdef __cplusplus
 }

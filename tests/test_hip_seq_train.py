@@ -231,6 +231,25 @@ def test_flow_step_at_the_reference_width_vs_oracle():
     assert worst["w_max"] <= 2.002 and worst["w_far"] <= 1e-5
 
 
+@pytest.mark.parametrize("shape", [(96, 160, 2, 2, 17), (1024, 2048, 2, 2, 64)])
+def test_tile_major_activations_in_the_training_forward_change_nothing(shape):
+    """The training forward hands the hidden activations on tile-major as well (include/vunet_seq_tiled.h, layouts 4 / 6 / 2 with a
+    row-major copy for the backward pass): two fused steps are bit-identical with and without."""
+    chan, mid, depth, n_flows, bsz = shape
+    res = {}
+    for tiled in (True, False):
+        flow, _ = _random_flow(chan, mid, depth, n_flows, 41)
+        eng = flow.flow.train_engine(lr=1e-4, betas=(0.5, 0.9))
+        eng.tile_activations = tiled
+        eng.graph.enabled = False
+        logs = [eng.train_step(seeded_randn(f"ta.b{it}", (bsz, chan), 41).cuda(), torch.zeros(bsz, chan, device="cuda")).tolist()
+                for it in range(2)]
+        res[tiled] = (logs, {k: v.detach().clone() for k, v in flow.state_dict().items()})
+    assert res[True][0] == res[False][0]
+    for k, v in res[True][1].items():
+        assert torch.equal(v, res[False][1][k]), k
+
+
 def test_flow_training_refuses_what_it_cannot_do():
     flow, _ = _random_flow(64, 96, 1, 2, 3)
     eng = flow.flow.train_engine(lr=1e-3)
