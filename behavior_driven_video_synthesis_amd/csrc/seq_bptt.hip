@@ -120,12 +120,28 @@ __global__ __launch_bounds__(256) void seq_vae_loss_parts_kernel(const float* __
   } else {
     const int b = blockIdx.x - T;
     const float gm = *gamma / (float)B;
+    float sm = 0.f, sl = 0.f;
     for (int j = threadIdx.x; j < H; j += 256) {
       const size_t o = (size_t)b * H + j;
       const float l = logstd[o], m = mu[o], sd = expf(l);
       s += -l + 0.5f * (sd * sd + m * m);          // lib/losses.py:288-289
+      sm += m;
+      sl += l;
       if (dmu) dmu[o] = gm * m;
       if (dlogstd) dlogstd[o] = gm * (sd * sd - 1.f);
+    }
+    // the row's share of the logged means of mu and logstd (experiments/behavior_net.py:717-718)
+    __shared__ float red2[2][4];
+    sm = wave_sum(sm);
+    sl = wave_sum(sl);
+    if ((threadIdx.x & 63) == 0) {
+      red2[0][threadIdx.x >> 6] = sm;
+      red2[1][threadIdx.x >> 6] = sl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part[T + B + b] = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
+      part[T + 2 * B + b] = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
     }
   }
   s = wave_sum(s);
@@ -144,10 +160,19 @@ __global__ __launch_bounds__(64) void seq_vae_loss_final_kernel(const float* __r
     r += part[t];
     if (per_seq) per_seq[t] = part[t] / ((float)B * (float)n);
   }
-  for (int b = lane; b < B; b += 64) k += part[T + b] - 0.5f * (float)H;   // ... - 0.5 dim   (lib/losses.py:289)
+  float sm = 0.f, sl = 0.f;
+  for (int b = lane; b < B; b += 64) {
+    k += part[T + b] - 0.5f * (float)H;   // ... - 0.5 dim   (lib/losses.py:289)
+    sm += part[T + B + b];
+    sl += part[T + 2 * B + b];
+  }
   r = wave_sum(r);
   k = wave_sum(k);
+  sm = wave_sum(sm);
+  sl = wave_sum(sl);
   if (lane == 0) {
+    scalars[4] = sm / ((float)B * (float)H);
+    scalars[5] = sl / ((float)B * (float)H);
     const float recon = r / ((float)B * (float)T * (float)n), kl = k / (float)B, g = *gamma;
     scalars[0] = recon_weight * recon + g * kl;
     scalars[1] = recon;

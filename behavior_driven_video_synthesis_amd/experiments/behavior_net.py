@@ -124,7 +124,7 @@ class BehaviorNet:
         if not self.only_flow:
             p = self._cvae_step(seq_b, target, eps)
             sc = p["scalars"]
-            out.update(loss=sc[0], loss_recon=sc[1], kl_loss=sc[2], gamma=self.gamma_dev[0], mu_s=p["mu"].mean(), logstd_s=p["logstd"].mean(),
+            out.update(loss=sc[0], loss_recon=sc[1], kl_loss=sc[2], gamma=self.gamma_dev[0], mu_s=sc[4], logstd_s=sc[5],
                        loss_per_seq_recon=p["per_seq"])
         else:
             with torch.no_grad():
@@ -139,7 +139,7 @@ class BehaviorNet:
             self.flow_engine.graph.enabled = self.hip_graph
             fl = self.flow_engine.train_step(bs.detach(), noise)
             out.update(flow_loss=fl[0], reference_nll_loss=fl[1], nlogdet_loss=fl[2], nll_loss=fl[3], loss_recon=sc[1], kl_loss=sc[2],
-                       gamma=self.gamma_dev[0], mu_s=mu_s.mean(), logstd_s=logstd_s.mean(), loss_per_seq_recon=p["per_seq"])
+                       gamma=self.gamma_dev[0], mu_s=sc[4], logstd_s=sc[5], loss_per_seq_recon=p["per_seq"])
         out["imax"], out["seq_len"] = self.imax, seq_len
         if sync:
             out = {k: (v.detach().cpu().numpy() if k == "loss_per_seq_recon" else float(v)) if isinstance(v, torch.Tensor) else v

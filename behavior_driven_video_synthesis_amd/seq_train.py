@@ -568,7 +568,7 @@ class BehaviorTrainEngine(BehaviorEngine):
                  gxs=z(rows, length, n), gmu=z(rows, H), glogstd=z(rows, H),
                  g_dec=z(4 * H, ldx), gb_dec=z(4 * H), g_enc=z(4 * H, ldx), gb_enc=z(4 * H), g_out=z(64, H), gb_out=z(64),
                  g_mu=z(H, H), gb_mu=z(H), g_std=z(H, H), gb_std=z(H), zero_bias=z(4 * H),
-                 part=z(length + rows), scalars=z(4), per_seq=z(length))
+                 part=z(length + 3 * rows), scalars=z(6), per_seq=z(length))
         # the weight-gradient sweep (write mode): every layer of the net in one launch
         entries, tile = [], 0
 

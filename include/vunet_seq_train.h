@@ -140,9 +140,10 @@ int vunet_seq_unpack_rows(const float* src, int32_t ld_src, int32_t col_off, int
  *   vunet_seq_vae_loss           recon = mean (xs - target)^2 (nn.MSELoss(reduction none) + mean, :358, :134-149), kl = kl_loss(mu, logstd)
  *                                (lib/losses.py:283-291), loss = w recon + gamma kl (:606-611); gamma read from the device and -- `gamma_step`
  *                                > 0 -- advanced for the NEXT step as __update_gamma does after the optimiser step (:111-116, :655):
- *                                gamma <- max(gamma - gamma_step (imax - kl), 0).  scalars = loss, recon, kl, gamma used; per_seq[t] =
+ *                                gamma <- max(gamma - gamma_step (imax - kl), 0).  scalars[6] = loss, recon, kl, gamma used, mean(mu),
+ *                                mean(logstd) (the logged mu_s / logstd_s, :717-718); per_seq[t] =
  *                                mean over batch and dims of step t's squared error.  dxs = w 2 (xs - target) / (B T n);
- *                                dmu = gamma mu / B; dlogstd = gamma (exp(2 logstd) - 1) / B.   `part`: scratch of T + B floats.
+ *                                dmu = gamma mu / B; dlogstd = gamma (exp(2 logstd) - 1) / B.   `part`: scratch of T + 3 B floats.
  *   vunet_seq_normlinear_bwd     NormConv2d 1x1 as a linear layer, W_eff = gamma g v / ||v||, b_eff = gamma bias + beta: from dW_eff [M][K]
  *                                and db_eff [M] the gradients of v [M][K], g, bias, gamma, beta [M]
  *   vunet_seq_lstm_grads_unpack  the gate-interleaved image gradient [4H][ldx] = [dW_ih | . | dW_hh] and bias gradient [4H] -> torch's
