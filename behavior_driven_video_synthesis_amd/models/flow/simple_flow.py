@@ -25,8 +25,9 @@ class UnsupervisedTransformer2(nn.Module):
         if reverse:
             return self.reverse(input)
         if train:
-            raise NotImplementedError("train=True returns per-block outputs for the flow's training loss; the training of the "
-                                      "flow (BASELINE config 4) is not part of this build")
+            raise NotImplementedError("train=True returns every block's output and running logdet (models/flow/blocks.py:116-119); "
+                                      "no call site of the reference passes it (experiments/behavior_net.py:705 trains the flow "
+                                      "through forward(input)): the fused blocks here do not keep the per-block values")
         return self.flow(input)
 
     def reverse(self, out):
