@@ -480,3 +480,96 @@ def test_cvae_step_at_the_reference_size_vs_oracle():
         worst = max(worst, _rel(mine[order.index(n)]["exp_avg"], theirs[i]["exp_avg"]))
     print(f"\n[cVAE 1024 / 51 / 64 x 50] first moments after one step: {worst:.2e} of max|.|")
     assert worst <= 3e-5      # measured 2.4e-6
+
+
+# ================================================================ the trainer's surface (experiments/behavior_net.py)
+def _small_trainer(only_flow, graph=True, seed=23):
+    from behavior_driven_video_synthesis_amd.experiments.behavior_net import BehaviorNet, DEFAULT_CONFIG
+    import copy
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["architecture"].update(dim_hidden_b=64, n_flows=2, flow_mid_channels_factor=2, flow_hidden_depth=1)
+    cfg["training"].update(batch_size=6, lr_init=1e-3, gamma_init=0.05, gamma_step=1e-3, information_max=5, flow_lr=5e-5, weight_decay=1e-3,
+                           only_flow=only_flow)
+    tr = BehaviorNet(cfg, n_kps=51, hip_graph=graph)
+    fsd = synth_behavior_state({k: list(v.shape) for k, v in tr.latent_flow.state_dict().items()}, seed,
+                               {k: v.cpu() for k, v in tr.latent_flow.state_dict().items() if k.endswith("_shuffle_idx")})
+    nsd = synth_behavior_state({k: list(v.shape) for k, v in tr.net.state_dict().items()}, seed, {})
+    tr.latent_flow.load_state_dict(fsd)
+    tr.net.load_state_dict(nsd)
+    return tr, fsd, nsd
+
+
+def test_flow_stage_through_train_fn_vs_oracle():
+    """``only_flow`` (experiments/behavior_net.py:591-604, :703-714): the net encodes under no_grad -- its parameters do not move --,
+    the flow takes one optimisation step on ``bs.detach()``; the log carries the flow's four scalars and the net's recon / KL.
+    Three steps (eager, recorded, replayed) against the oracle driven the same way."""
+    from oracle import behavior_oracle as B
+    tr, fsd, nsd = _small_trainer(True)
+    fref = {k: v.clone() for k, v in fsd.items()}
+    opt = B.flow_optimizer(fref, 5e-5 * 6, 1e-3)
+    for it in range(3):
+        kps = 0.5 * seeded_randn(f"fs.kps{it}", (6, 8, 51), 23)
+        eps = seeded_randn(f"fs.eps{it}", (6, 64), 23)
+        out = tr.train_fn({"keypoints": kps.cuda()}, eps=eps.cuda(), noise=torch.zeros(6, 64, device="cuda"))
+        with torch.no_grad():
+            xs, cs, b, mu, logstd, pre = B.behavior_net_forward(nsd, kps[:, :-1], kps[:, :-1], 7, 0, eps=eps)
+            recon = torch.nn.functional.mse_loss(xs, kps[:, 1:])
+            kl = B.kl_loss(mu, logstd)
+        log = B.flow_train_step(fref, opt, b)
+        for k, want in (("flow_loss", log["flow_loss"]), ("nll_loss", log["nll_loss"]), ("nlogdet_loss", log["nlogdet_loss"]),
+                        ("loss_recon", float(recon)), ("kl_loss", float(kl)), ("mu_s", float(mu.mean())), ("logstd_s", float(logstd.mean()))):
+            assert abs(out[k] - want) <= 5e-5 * abs(want) + 2e-6, (it, k, out[k], want)
+        assert out["seq_len"] == 7 and out["gamma"] == pytest.approx(0.05)      # the controller does not run in this stage
+    for k, v in tr.net.state_dict().items():
+        assert torch.equal(v.cpu(), nsd[k]), k
+    # (Adam moves an element by about lr whatever its gradient's size: one whose gradient is summation noise may go the other way)
+    lr, far, total, worst = 5e-5 * 6, 0, 0, 0.0
+    for k, v in tr.latent_flow.state_dict().items():
+        if v.dtype.is_floating_point and v.dim() > 0:
+            d = (v.detach().cpu().double() - fref[k].detach().double()).abs()
+            worst, far, total = max(worst, float(d.max())), far + int((d > 0.02 * lr).sum()), total + d.numel()
+    assert worst <= 2.001 * 3 * lr and far <= max(3, 1e-4 * total), (worst / lr, far, total)
+
+
+@pytest.mark.parametrize("only_flow", [False, True])
+def test_trainer_checkpoint_round_trip(only_flow):
+    """``state_dict`` / ``load_state_dict`` (model, optimizer, flow, flow optimizer in torch.optim.Adam's layout, gamma): a trainer
+    restored from a checkpoint takes the next step bit for bit like the one that wrote it."""
+    tr, _, _ = _small_trainer(only_flow, graph=False)
+    batches = [({"keypoints": (0.5 * seeded_randn(f"ck.kps{it}", (6, 8, 51), 29)).cuda()}, seeded_randn(f"ck.eps{it}", (6, 64), 29).cuda())
+               for it in range(3)]
+    noise = torch.zeros(6, 64, device="cuda")
+    for b_, e_ in batches[:2]:
+        tr.train_fn(b_, eps=e_, noise=noise)
+    import copy
+    ck = copy.deepcopy(tr.state_dict())     # (what torch.save would freeze: state_dict() hands out the live tensors, as nn.Module's does)
+    assert set(ck) == {"model", "optimizer", "flow", "flow_optimizer", "gamma"}
+    torch.optim.Adam(tr.latent_flow.parameters()).load_state_dict(ck["flow_optimizer"])      # (it is torch's layout)
+    out_a = tr.train_fn(batches[2][0], eps=batches[2][1], noise=noise)
+    tr2, _, _ = _small_trainer(only_flow, graph=False, seed=77)        # different weights: everything must come from the checkpoint
+    tr2.load_state_dict(ck)
+    out_b = tr2.train_fn(batches[2][0], eps=batches[2][1], noise=noise)
+    for k, v in out_a.items():
+        assert np.array_equal(np.asarray(v), np.asarray(out_b[k])), k
+    for k, v in tr.net.state_dict().items():
+        assert torch.equal(v, tr2.net.state_dict()[k]), k
+    for k, v in tr.latent_flow.state_dict().items():
+        assert torch.equal(v, tr2.latent_flow.state_dict()[k]), k
+
+
+def test_learning_rate_schedule_reaches_the_recorded_step():
+    """``MultiStepLR`` steps the net's learning rate between epochs (experiments/behavior_net.py:337-339): ``set_lr`` must take
+    effect on the RECORDED step (the rate lives in device memory, nothing is re-recorded)."""
+    tr, _, nsd = _small_trainer(False, graph=True)
+    batch = {"keypoints": (0.5 * seeded_randn("lr.kps", (6, 8, 51), 31)).cuda()}
+    eps = seeded_randn("lr.eps", (6, 64), 31).cuda()
+    for _ in range(3):
+        tr.train_fn(batch, eps=eps)          # eager, recorded, replayed
+    before = {k: v.detach().clone() for k, v in tr.net.state_dict().items()}
+    tr.set_lr(0.0)
+    tr.train_fn(batch, eps=eps)
+    assert all(torch.equal(v, before[k]) for k, v in tr.net.state_dict().items())       # a step of rate 0 moves nothing
+    tr.set_lr(1e-3)
+    tr.train_fn(batch, eps=eps)
+    assert any(not torch.equal(v, before[k]) for k, v in tr.net.state_dict().items())
+    assert tr.optimizer.state_dict()["state"][0]["step"] == 5
