@@ -50,10 +50,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA
 X6_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate MAC block in the split kernels (csrc/conv_x6_kernel.h)
 FLOP_PER_FRAME = 275.6e9        # VUnet f+b 130.0 GF + perceptual (target fwd, pred fwd+dgrad) 145.6 GF
-PMC_TRAFFIC_RENDER = ["profiles/r05_pmc_traffic_render.json", "profiles/r04_pmc_traffic_render.json", "profiles/r03_pmc_traffic_render.json"]
+PMC_TRAFFIC_RENDER = ["profiles/r06_pmc_traffic_render.json", "profiles/r05_pmc_traffic_render.json", "profiles/r04_pmc_traffic_render.json", "profiles/r03_pmc_traffic_render.json"]
 PMC_TRAFFIC_SEQ = ["profiles/r06_pmc_traffic_seq.json", "profiles/r05_pmc_traffic_seq.json"]
 PMC_TRAFFIC_SEQ_TRAIN = ["profiles/r06_pmc_traffic_seq_train.json"]
-PMC_TRAFFIC = ["profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json",
+PMC_TRAFFIC = ["profiles/r06_pmc_traffic.json", "profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json",
                "profiles/r01_pmc_traffic.json"]
 
 
@@ -427,7 +427,8 @@ def behavior_row(vunet, device, size, frames=50, rows=16, iters=10):
             pmc = json.load(open(os.path.join(ROOT, rel)))
         except (OSError, ValueError):
             continue
-        kern = {k: v for k, v in pmc.get("kernels", {}).items() if k.startswith("seq_")}
+        # (the pass's kernels: not the one-time packing of the tile-major weight copies)
+        kern = {k: v for k, v in pmc.get("kernels", {}).items() if k.startswith("seq_") and not k.startswith("seq_pack")}
         coup = [v for k, v in kern.items() if k.startswith("seq_coupling_kernel")]
         if coup:
             passes = sum(v["launches_sampled"] for v in coup) / 31.0      # 31 coupling launches per 15-block reverse pass
