@@ -321,6 +321,138 @@ __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* _
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ dW (+ Adam) AND dX in one pass over W
+// The layer's weights are read ONCE in the backward pass: the workgroup that updates a tile of W also forms that tile's share of
+// dX = dZ . W -- from the values it loaded, before the update -- so the input-gradient chain needs no pass of its own over W
+// (seq_dx_kernel: +2.5 GB per step for the flow).  A workgroup owns a (up to) 256-row x 64-column tile as four 64 x 64 sub-tiles:
+// per sub-tile dW and the update exactly as seq_dw_kernel does them, then the OLD 64 x 64 block of W goes to LDS (where the tile of
+// dW just was) and the four waves add dX^T[k][b] += sum_m W[m][k] dZ[b][m] for their 16 columns each (A = W^T: row i <-> column
+// k0 + 16 w + i; B = dZ^T: column j <-> batch row 16 bt + j; reduction slot q <-> row 4 c + q of the sub-tile).  The partial sums
+// of the M / 256 tiles of a column stripe leave as RAW slabs [M / 256][Bp][K]; whoever reads them adds them in slab order
+// (seq_dz_finish_kernel, seq_coupling_bwd_kernel), as with seq_dx_kernel's.
+// D2: lane holds dX[16 bt + (l & 15)][k0 + 16 w + 4 q + r] in acc2[bt][r]: a float4 along k.
+template <int NB, bool ADAM>
+__global__ __launch_bounds__(256) void seq_dwx_kernel(const vunet_seq_dw_layer* __restrict__ tab, int n_layers, int first_tile,
+                                                      vunet_seq_adam_hp hp) {
+  __shared__ float dzs[16 * NB * 64];
+  __shared__ float xs[16 * NB * 64];
+  __shared__ float ws[64 * 64];       // the sub-tile of dW on its way to rows, then the old sub-tile of W
+  const int tile = first_tile + blockIdx.x;
+  int lo = 0, hi = n_layers;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid].tile0 <= tile) lo = mid;
+    else hi = mid;
+  }
+  const vunet_seq_dw_layer L = tab[lo];
+  const int t = tile - L.tile0, tm = t / L.tiles_k, tk = t - tm * L.tiles_k;
+  const int tsub = L.nchunk > 0 ? L.nchunk : 4;                  // 64-row sub-tiles per tile (vunet_seq_dwx: nchunk = tile rows / 64)
+  const int row0 = 64 * tsub * tm, nsub = min(tsub, (L.M - row0) >> 6);   // (the last row tile of a layer may be short)
+  const int k0 = 64 * tk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  AdamResolved h = AdamResolved{};
+  if constexpr (ADAM) h = adam_resolve(hp);
+  for (int idx = tid; idx < 16 * NB * 16; idx += 256) {
+    const int b = idx >> 4, c4 = idx & 15;
+    *reinterpret_cast<float4*>(&xs[dw_sw(b, 4 * c4)]) = *reinterpret_cast<const float4*>(L.x + (size_t)b * L.ldx + k0 + 4 * c4);
+  }
+  f32x4 acc2[NB];
+#pragma unroll
+  for (int bt = 0; bt < NB; ++bt) acc2[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sub = 0; sub < nsub; ++sub) {
+    const int m0 = row0 + 64 * sub;
+    if (sub) __syncthreads();   // the previous sub-tile's dZ / W blocks have been read
+    for (int idx = tid; idx < 16 * NB * 16; idx += 256) {
+      const int b = idx >> 4, c4 = idx & 15;
+      *reinterpret_cast<float4*>(&dzs[dw_sw(b, 4 * c4)]) = *reinterpret_cast<const float4*>(L.dz + (size_t)b * L.ldz + m0 + 4 * c4);
+    }
+    __syncthreads();
+    f32x4 acc[4];
+    {
+      float av[4 * NB];
+#pragma unroll
+      for (int c = 0; c < 4 * NB; ++c) av[c] = dzs[dw_sw(4 * c + q, 16 * wave + i)];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4 * NB; ++c)
+          acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], xs[dw_sw(4 * c + q, 16 * blk + i)], acc[blk], 0, 0, 0);
+      }
+    }
+    float bsum = 0.f;
+    if (tk == 0 && tid < 64 && L.bias)
+      for (int b = 0; b < 16 * NB; ++b) bsum += dzs[dw_sw(b, tid)];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ws[dw_swo(16 * wave + 4 * q + r, 16 * blk + i)] = acc[blk][r];
+    __syncthreads();
+    float4 pold[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
+      float4 g = *reinterpret_cast<const float4*>(&ws[dw_swo(row, 4 * c4)]);
+      if (k0 + 4 * c4 + 3 >= L.kv) {   // (padding columns of the image: only where K is not the layer's own width)
+        const int kc = k0 + 4 * c4;
+        if (kc >= L.kv) g.x = 0.f;
+        if (kc + 1 >= L.kv) g.y = 0.f;
+        if (kc + 2 >= L.kv) g.z = 0.f;
+        g.w = 0.f;
+      }
+      const size_t off = (size_t)(m0 + row) * L.K + k0 + 4 * c4;
+      if constexpr (ADAM) {
+        float4 p = SEQ_NT_LOAD(L.w + off), m = SEQ_NT_LOAD(L.m + off), v = SEQ_NT_LOAD(L.v + off);
+        pold[it] = p;
+        adam_update(h, g.x, p.x, m.x, v.x);
+        adam_update(h, g.y, p.y, m.y, v.y);
+        adam_update(h, g.z, p.z, m.z, v.z);
+        adam_update(h, g.w, p.w, m.w, v.w);
+        SEQ_NT_STORE(L.w + off, p);
+        SEQ_NT_STORE(L.m + off, m);
+        SEQ_NT_STORE(L.v + off, v);
+      } else {
+        pold[it] = L.dx_raw ? *reinterpret_cast<const float4*>(L.w + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(L.g + off) = g;
+      }
+    }
+    if (tk == 0 && tid < 64 && L.bias) {
+      const int m = m0 + tid;
+      if constexpr (ADAM) {
+        float p = L.bias[m], mm = L.bm[m], vv = L.bv[m];
+        adam_update(h, bsum, p, mm, vv);
+        L.bias[m] = p;
+        L.bm[m] = mm;
+        L.bv[m] = vv;
+      } else {
+        L.bg[m] = bsum;
+      }
+    }
+    if (!L.dx_raw) continue;   // (uniform per launch entry)
+    __syncthreads();           // every thread has taken its float4 of dW out of ws
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
+      *reinterpret_cast<float4*>(&ws[dw_sw(row, 4 * c4)]) = pold[it];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+      const float wa = ws[dw_sw(4 * c + q, 16 * wave + i)];
+#pragma unroll
+      for (int bt = 0; bt < NB; ++bt)
+        acc2[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, dzs[dw_sw(16 * bt + i, 4 * c + q)], acc2[bt], 0, 0, 0);
+    }
+  }
+  if (L.dx_raw) {
+    float* out = L.dx_raw + (size_t)tm * (16 * NB) * L.K + k0 + 16 * wave + 4 * q;
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt)
+      *reinterpret_cast<float4*>(out + (size_t)(16 * bt + i) * L.K) = make_float4(acc2[bt][0], acc2[bt][1], acc2[bt][2], acc2[bt][3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ ActNorm loc / scale
 // grid (ceil(C / 64), n_layers), 256 threads: channel bx 64 + (t & 63), row group t >> 6 takes rows rg, rg + 4, ...
 template <bool ADAM>
@@ -562,6 +694,28 @@ extern "C" int vunet_seq_dw(const vunet_seq_dw_layer* table_dev, int32_t n_layer
     default: return VUNET_ERR_ARG;
   }
 #undef SEQ_DW_CASE
+  return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_dwx(const vunet_seq_dw_layer* table_dev, int32_t n_layers, int32_t first_tile, int32_t n_tiles, int32_t B,
+                             const vunet_seq_adam_hp* hp, void* stream) {
+  if (!table_dev || n_layers < 1 || first_tile < 0 || n_tiles < 1 || B < 1 || B > 64) return VUNET_ERR_ARG;
+  if (hp && !adam_hp_ok(hp)) return VUNET_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const vunet_seq_adam_hp h = hp ? *hp : vunet_seq_adam_hp{};
+#define SEQ_DWX_CASE(NB)                                                                                                  \
+  case NB:                                                                                                                \
+    if (hp) VUNET_LAUNCH((seq_dwx_kernel<NB, true>), dim3(n_tiles), dim3(256), 0, st, table_dev, n_layers, first_tile, h); \
+    else VUNET_LAUNCH((seq_dwx_kernel<NB, false>), dim3(n_tiles), dim3(256), 0, st, table_dev, n_layers, first_tile, h);   \
+    break;
+  switch ((B + 15) / 16) {
+    SEQ_DWX_CASE(1)
+    SEQ_DWX_CASE(2)
+    SEQ_DWX_CASE(3)
+    SEQ_DWX_CASE(4)
+    default: return VUNET_ERR_ARG;
+  }
+#undef SEQ_DWX_CASE
   return vunet_check_launch();
 }
 

@@ -43,7 +43,8 @@ class SeqCouplingBwdDesc(ctypes.Structure):
 
 class SeqDwLayer(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_void_p) for n in ("w", "m", "v", "g", "bias", "bm", "bv", "bg", "dz", "x")]
-                + [(n, ctypes.c_int32) for n in ("M", "K", "ldz", "ldx", "tile0", "tiles_k", "kv", "nchunk", "chunk_z", "chunk_x")])
+                + [(n, ctypes.c_int32) for n in ("M", "K", "ldz", "ldx", "tile0", "tiles_k", "kv", "nchunk", "chunk_z", "chunk_x")]
+                + [("dx_raw", ctypes.c_void_p)])
 
 
 class SeqActnormLayer(ctypes.Structure):
@@ -131,6 +132,12 @@ class FlowTrainEngine(FlowEngine):
         # hidden activations also handed from layer to layer tile-major (include/vunet_seq_tiled.h; the row-major copies are the
         # backward pass's): bit-identical values
         self.tile_activations = os.environ.get("VUNET_SEQ_TRAIN_TILED_X", "1") != "0"
+        # "1": ONE pass over W per layer in the backward pass -- the update sweep also forms the layer's input gradient
+        # (vunet_seq_dwx: no second read of W, 2.5 GB less traffic per step).  Built, bit-for-bit tested, and SLOWER: 7.59 ms per
+        # step against 7.09 for the separate vunet_seq_dx chain + one vunet_seq_dw launch per coupling half -- the update then runs
+        # as 120 dependent per-layer launches of 512 - 1024 workgroups (each ~15 us per 64 x 64 sub-tile, whatever its size) instead
+        # of 30 launches of 5120 independent tiles.  Off by default.
+        self.fused_dx = os.environ.get("VUNET_SEQ_TRAIN_FUSED_DX", "0") == "1"
 
     # ---- weights
     def _pack(self, dev=None):
@@ -193,11 +200,24 @@ class FlowTrainEngine(FlowEngine):
                  dzl=z(b_pad, self.ld), dld=z(b_pad), g0=[z(b_pad, self.ld) for _ in range(2)], g1=z(b_pad, self.ld),
                  gfull=[z(b_pad, self.ld) for _ in range(n)], dx=z(rows, self.C))
         # raw input-gradient slabs: S row ranges of W per launch, chosen so that a launch has >= 256 workgroups
-        p["S"] = [self._dx_split(m, k, h0.nets) for (m, k) in h0.dims]
+        # fused form (vunet_seq_dwx): one slab per 256-row tile of W; separate form: S row ranges chosen for >= 256 workgroups
+        p["tsub"] = [self._dwx_rows(m, k, h0.nets) for (m, k) in h0.dims]      # 64-row sub-tiles per tile of the fused form
+        p["S"] = ([(m + 64 * t - 1) // (64 * t) for (m, _), t in zip(h0.dims, p["tsub"])] if self.fused_dx
+                  else [self._dx_split(m, k, h0.nets) for (m, k) in h0.dims])
         p["raw"] = z(max(h0.nets * s * b_pad * k for s, (_, k) in zip(p["S"], h0.dims)))
         p["raw_in"] = [z(h0.nets * p["S"][0] * b_pad * h0.dims[0][1]) for _ in range(2)]
         self._plans[("train", rows)] = p
         return p
+
+    @staticmethod
+    def _dwx_rows(m: int, k: int, nets: int) -> int:
+        """Rows per tile of ``vunet_seq_dwx`` in units of 64: as tall as leaves the launch >= ``VUNET_SEQ_DWX_WGS`` workgroups
+        (taller tiles: fewer slabs of dX to write and add; shorter: more workgroups in flight)."""
+        want = int(os.environ.get("VUNET_SEQ_DWX_WGS", "512"))     # (measured: 512 -> 7.59 ms per step, 1024 -> 8.16, 2048 -> 8.37)
+        t = 4
+        while t > 1 and ((m + 64 * t - 1) // (64 * t)) * (k // 64) * nets < want:
+            t //= 2
+        return t
 
     @staticmethod
     def _dx_split(m: int, k: int, nets: int) -> int:
@@ -264,9 +284,36 @@ class FlowTrainEngine(FlowEngine):
                         g, bg = grads[lay.name] if grads is not None else (None, None)
                         entries.append(SeqDwLayer(_ptr(lay.w), _ptr(lay.m), _ptr(lay.v), _ptr(g), _ptr(lay.b), _ptr(lay.bm), _ptr(lay.bv),
                                                   _ptr(bg), dz.data_ptr(), x.data_ptr(), m_pad, k_pad, m_pad,
-                                                  self.ld if li == 0 else k_pad, tile, k_pad // 64, lay.lin.weight.shape[1], 1, 0, 0))
+                                                  self.ld if li == 0 else k_pad, tile, k_pad // 64, lay.lin.weight.shape[1], 1, 0, 0, None))
                         tile += (m_pad // 64) * (k_pad // 64)
                 ranges.append((first, tile - first))
+        return dict(table=_table(entries, self.blocks[0]["scale"].device), n=len(entries), ranges=ranges, tiles=tile)
+
+    def _dwx_table(self, p: dict, grads: Optional[dict]) -> dict:
+        """The fused form's table: per block (last first), half (1, then 0) and LAYER (head first) the two nets' entries -- one
+        ``vunet_seq_dwx`` launch each: the update of the layer AND its input gradient (raw slabs over the 256-row tiles of W)."""
+        b_pad = p["b_pad"]
+        entries, ranges, tile = [], {}, 0
+        for bi in reversed(range(len(self.blocks))):
+            for hi in (1, 0):
+                half = self.blocks[bi]["halves"][hi]
+                for li in reversed(range(len(half.dims))):
+                    m_pad, k_pad = half.dims[li]
+                    first = tile
+                    s_li = p["S"][li]
+                    raw = p["raw_in"][hi] if li == 0 else p["raw"]
+                    for ni in range(half.nets):
+                        lay = self.layers[bi][hi][ni][li]
+                        x = (p["s0"][bi] if hi == 0 else p["s1"][bi]) if li == 0 else p["y"][bi][hi][li - 1][ni * b_pad * k_pad:]
+                        dz = p["dz"][bi][hi][li][ni * b_pad * m_pad:]
+                        g, bg = grads[lay.name] if grads is not None else (None, None)
+                        dx = raw[ni * s_li * b_pad * k_pad:]
+                        entries.append(SeqDwLayer(_ptr(lay.w), _ptr(lay.m), _ptr(lay.v), _ptr(g), _ptr(lay.b), _ptr(lay.bm), _ptr(lay.bv),
+                                                  _ptr(bg), dz.data_ptr(), x.data_ptr(), m_pad, k_pad, m_pad,
+                                                  self.ld if li == 0 else k_pad, tile, k_pad // 64, lay.lin.weight.shape[1], p["tsub"][li], 0, 0,
+                                                  dx.data_ptr()))
+                        tile += s_li * (k_pad // 64)
+                    ranges[(bi, hi, li)] = (first, tile - first)
         return dict(table=_table(entries, self.blocks[0]["scale"].device), n=len(entries), ranges=ranges, tiles=tile)
 
     def _norm_table(self, p: dict, grads: Optional[dict]) -> torch.Tensor:
@@ -284,6 +331,8 @@ class FlowTrainEngine(FlowEngine):
         the same for half 0; finally block 0's ActNorm and the ActNorm gradients of all blocks."""
         n = len(self.blocks)
         hpp = ctypes.byref(hp) if hp is not None else None
+        if self.fused_dx:
+            return self._issue_train_backward_fused(rows, p, gz, ld_gz, tables, hpp)
         dw = tables["dw"]
         gbase, ld_g, gsl = gz, ld_gz, None
         rng = iter(dw["ranges"])
@@ -322,6 +371,36 @@ class FlowTrainEngine(FlowEngine):
         _call("vunet_seq_actnorm_bwd", _p(tables["norm"]), n, self.C, rows, _p(p["dld"]), hpp, _stream())
         if side is not None:
             main.wait_stream(side)
+
+    def _issue_train_backward_fused(self, rows, p, gz, ld_gz, tables, hpp):
+        """The same pass with ONE pass over W per layer: ``vunet_seq_dwx`` updates the layer and leaves its input gradient as raw
+        slabs (no ``vunet_seq_dx``: the chain does not read W a second time)."""
+        n, b_pad = len(self.blocks), p["b_pad"]
+        dwx = tables["dwx"]
+
+        def mlp(bi, hi, half):
+            for li in reversed(range(len(half.dims))):
+                first, cnt = dwx["ranges"][(bi, hi, li)]
+                _call("vunet_seq_dwx", _p(dwx["table"]), dwx["n"], first, cnt, rows, hpp, _stream())
+                if li > 0:
+                    _call("vunet_seq_dz_finish", _p(p["raw"]), _p(p["y"][bi][hi][li - 1]), _p(p["dz"][bi][hi][li - 1]), half.nets,
+                          p["S"][li], b_pad, half.dims[li][1], LRELU_SLOPE, _stream())
+        gbase, ld_g, gsl = gz, ld_gz, None
+        for i in reversed(range(n)):
+            blk = self.blocks[i]
+            h0, h1 = blk["halves"]
+            last = i == n - 1
+            nxt = None if last else self.blocks[i + 1]
+            self._coupling_bwd(rows, p, gbase, ld_g, gsl, blk["bwd"], None if last else nxt["scale"], p["s1"][i], h1, p["y"][i][1][-1],
+                               None if last else p["gfull"][i + 1], p["g1"], self.ld, p["dz"][i][1][-1])
+            mlp(i, 1, h1)
+            g0 = p["g0"][i % 2]
+            self._coupling_bwd(rows, p, p["g1"], self.ld, p["raw_in"][1], self.inv_swap, None, p["s0"][i], h0, p["y"][i][0][-1], None, g0,
+                               self.ld, p["dz"][i][0][-1])
+            mlp(i, 0, h0)
+            gbase, ld_g, gsl = g0, self.ld, p["raw_in"][0]
+        self._coupling_bwd(rows, p, gbase, ld_g, gsl, None, self.blocks[0]["scale"], None, None, None, p["gfull"][0], p["dx"], self.C, None)
+        _call("vunet_seq_actnorm_bwd", _p(tables["norm"]), n, self.C, rows, _p(p["dld"]), hpp, _stream())
 
     def _side(self):
         if self._side_stream is None:
@@ -370,7 +449,8 @@ class FlowTrainEngine(FlowEngine):
         else:
             p["noise"].copy_(noise.reshape(rows, self.C))
         if "tables" not in p:
-            p["tables"] = dict(dw=self._dw_table(p, None), norm=self._norm_table(p, None))
+            p["tables"] = dict(norm=self._norm_table(p, None), **({"dwx": self._dwx_table(p, None)} if self.fused_dx
+                                                                 else {"dw": self._dw_table(p, None)}))
 
         def issue():
             self.adam.tick()
@@ -413,7 +493,8 @@ class FlowTrainEngine(FlowEngine):
         grads = {lay.name: (torch.empty_like(lay.w), torch.empty_like(lay.b)) for lay in self._all_layers()}
         for bi in range(len(self.blocks)):
             grads[f"sub_layers.{bi}.norm_layer"] = (torch.empty(self.C, device=dev), torch.empty(self.C, device=dev))
-        tables = dict(dw=self._dw_table(p, grads), norm=self._norm_table(p, grads))
+        tables = dict(norm=self._norm_table(p, grads), **({"dwx": self._dwx_table(p, grads)} if self.fused_dx
+                                                          else {"dw": self._dw_table(p, grads)}))
         self._issue_train_backward(rows, p, p["dzl"], self.ld, tables, None)
         out = {}
         for lay in self._all_layers():
@@ -575,7 +656,7 @@ class BehaviorTrainEngine(BehaviorEngine):
         def layer(g, gb, dz, x, m, k, ldz, ldx_, nchunk, cz, cx):
             nonlocal tile
             entries.append(SeqDwLayer(None, None, None, g.data_ptr(), p["zero_bias"].data_ptr(), None, None, gb.data_ptr(), dz.data_ptr(),
-                                      x.data_ptr(), m, k, ldz, ldx_, tile, k // 64, k, nchunk, cz, cx))
+                                      x.data_ptr(), m, k, ldz, ldx_, tile, k // 64, k, nchunk, cz, cx, None))
             tile += (m // 64) * (k // 64)
         layer(p["g_dec"], p["gb_dec"], p["dgates_d"], p["xh_d"], 4 * H, ldx, 4 * H, ldx, length, bp * 4 * H, bp * ldx)
         layer(p["g_enc"], p["gb_enc"], p["dgates_e"], p["xh_e"], 4 * H, ldx, 4 * H, ldx, t_in, bp * 4 * H, bp * ldx)

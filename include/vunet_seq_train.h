@@ -91,9 +91,18 @@ typedef struct vunet_seq_dw_layer {
   int32_t nchunk;    /* the reduction runs over nchunk blocks of Bp rows (a recurrent layer: one block per time step):
                         block i at dz + i chunk_z, x + i chunk_x (floats); 0 or 1: a single block */
   int32_t chunk_z, chunk_x;
+  float* dx_raw;     /* vunet_seq_dwx only: [ceil(M / (64 nchunk))][Bp][K] raw slabs of dX = dZ . W (NULL: not wanted) */
 } vunet_seq_dw_layer;
 int vunet_seq_dw(const vunet_seq_dw_layer* table_dev, int32_t n_layers, int32_t first_tile, int32_t n_tiles, int32_t B,
                  const vunet_seq_adam_hp* hp, void* stream);
+/* The same update AND the layer's input gradient in ONE pass over W: a workgroup owns a (64 nchunk)-row x 64-column tile (nchunk
+ * = 1, 2 or 4 here: the tile's rows / 64, not a row-block count; tile0 / tiles_k count THOSE tiles: ceil(M / (64 nchunk)) x K / 64
+ * per layer; the last row tile may be short), takes it through its 64 x 64 sub-tiles as vunet_seq_dw does, and adds each sub-tile's share of dX = dZ . W_old (the values it loaded, before the update) for
+ * its 64 columns: dx_raw[tm][b][k], raw slabs over the row tiles, added in slab order by whoever reads them (vunet_seq_dz_finish,
+ * vunet_seq_coupling_bwd).
+ * No separate vunet_seq_dx pass over W.  A single block of Bp rows (no reduction over time steps here). */
+int vunet_seq_dwx(const vunet_seq_dw_layer* table_dev, int32_t n_layers, int32_t first_tile, int32_t n_tiles, int32_t B,
+                  const vunet_seq_adam_hp* hp, void* stream);
 
 /* ActNorm (lib/modules.py:260-331) of every block in one launch: out = scale (u + loc), logdet += sum log|scale|.
  * d scale[c] = (sum_b gfull[b][c] out[b][c] + sum_b dld[b]) / scale[c];  d loc[c] = scale[c] sum_b gfull[b][c]. */

@@ -250,6 +250,32 @@ def test_tile_major_activations_in_the_training_forward_change_nothing(shape):
         assert torch.equal(v, res[False][1][k]), k
 
 
+@pytest.mark.parametrize("shape", [(96, 160, 2, 2, 17), (33, 48, 1, 2, 4), (1024, 2048, 2, 2, 64)])
+def test_one_pass_backward_matches_the_two_pass_one(shape):
+    """``vunet_seq_dwx`` (the update sweep also forms the layer's input gradient: one pass over W; off by default, it is slower)
+    against the default backward pass: the same products in another summation order -- two fused steps agree to rounding, and the
+    autograd form hands out the same gradients."""
+    chan, mid, depth, n_flows, bsz = shape
+    res = {}
+    for fused in (True, False):
+        flow, _ = _random_flow(chan, mid, depth, n_flows, 43)
+        eng = flow.flow.train_engine(lr=1e-4, betas=(0.5, 0.9))
+        eng.fused_dx = fused
+        eng.graph.enabled = False
+        x = seeded_randn("op.x", (bsz, chan), 43).cuda().requires_grad_(True)
+        z, logdet = flow(x)
+        (z.square().sum() * 0.5 - logdet.sum()).backward()
+        grads = {n: p.grad.detach().clone() for n, p in flow.named_parameters()}
+        gx = x.grad.detach().clone()
+        logs = [eng.train_step(seeded_randn(f"op.b{it}", (bsz, chan), 43).cuda(), torch.zeros(bsz, chan, device="cuda")).tolist()
+                for it in range(2)]
+        res[fused] = (logs, grads, gx)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert all(abs(u - v) <= 1e-5 * abs(v) + 1e-6 for u, v in zip(a, b)), (a, b)
+    assert _rel(res[True][2], res[False][2]) <= 2e-5
+    assert max(_rel(g, res[False][1][n]) for n, g in res[True][1].items()) <= 5e-5
+
+
 def test_flow_training_refuses_what_it_cannot_do():
     flow, _ = _random_flow(64, 96, 1, 2, 3)
     eng = flow.flow.train_engine(lr=1e-3)
@@ -310,7 +336,7 @@ def test_dw_kernel_write_mode_vs_float64(B):
         gw, gb = torch.full((m, k), float("nan"), device="cuda"), torch.full((m,), float("nan"), device="cuda")
         bias = torch.zeros(m, device="cuda")
         entries.append(T.SeqDwLayer(None, None, None, gw.data_ptr(), bias.data_ptr(), None, None, gb.data_ptr(), dz.data_ptr(),
-                                    x.data_ptr(), m, k, m, ldx, tile, k // 64, kv, 1, 0, 0))
+                                    x.data_ptr(), m, k, m, ldx, tile, k // 64, kv, 1, 0, 0, None))
         tile += (m // 64) * (k // 64)
         keep.append((dz, x, gw, gb, bias, kv, k))
     tab = T._table(entries, "cuda")
