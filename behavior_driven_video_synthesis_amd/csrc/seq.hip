@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
   // this wave's chunks: wave, wave + WAVES, ... (ascending k; the order of the sums is fixed by the geometry alone)
   int c = wave;
   // (16 waves share the CU's registers: 128 each)
+  // (four-wave form at 3 - 4 batch tiles with groups of 4 instead of 2: 6.96 -> 7.10 ms per flow training step)
   constexpr int UMAX = WAVES == 16 ? (NB == 1 ? 4 : 2) : ((NB + RT <= 3) ? 4 : 2);
   for (; c + WAVES * (UMAX - 1) < nchunk; c += WAVES * UMAX) seq_linear_group<NB, RT, UMAX, WAVES, LAY>(a, w, x, c, acc);
   if constexpr (UMAX == 4)
