@@ -511,6 +511,18 @@ __global__ __launch_bounds__(64 * NWAVE) void conv_wgrad_s2_kernel(const WgradDi
     else if (D > 2 && newer == 2) s2_wait<(D > 2 ? 2 : 0) * LPS>();
     else if (D > 1 && newer == 1) s2_wait<(D > 1 ? 1 : 0) * LPS>();
     else s2_wait<0>();
+    // The loads were inline assembly with "=v" outputs: to the compiler this slot's registers were valid from the load statement
+    // on, so nothing in the source kept it from copying or spilling them BEFORE the wait above.  Re-defining them here ("+v": read
+    // and written by an empty statement that sits after the wait and cannot be moved across it) makes the order explicit: every
+    // use below depends on THIS statement, which depends on the wait.  No instruction is emitted.
+    {
+      constexpr int K_ = decltype(slot_c)::value;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(xv[K_][i]) : : "memory");
+#pragma unroll
+      for (int i = 0; i < NDY; ++i) asm volatile("" : "+v"(dv[K_][i]) : : "memory");
+      asm volatile("" : "+v"(xhalo[K_]) : : "memory");
+    }
     lds_barrier();                                        // the previous step's fragment reads are done
     if (pro_form == 2) convert(p, std::integral_constant<int, 2>{}, slot_c);
     else if (pro_form == 1) convert(p, std::integral_constant<int, 1>{}, slot_c);
@@ -573,6 +585,8 @@ static bool s2_staged_ok(const vunet_wgrad_desc* d) {
   if (d->C1 % 32 || d->C2 % 32 || d->Cout % 32) return false;
   const int ncot = d->Cout / 32;
   if (ncot != 1 && ncot != 2 && ncot != 4) return false;
+  // (the batching bound of vunet_conv2d_wgrad_batchable, conv_wgrad.hip: layers at or below it share a launch on the direct kernel.
+  //  Both kernels accept any split count, so a bound moved by VUNET_WGRAD_BATCH_PIX only shifts which of the two runs a layer.)
   return (int64_t)d->N * d->Ho * d->Wo > 16384;
 }
 
