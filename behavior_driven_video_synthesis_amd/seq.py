@@ -540,7 +540,8 @@ class BehaviorEngine:
     def _drop_io(self, key):
         """A recording and the input / output buffers its launches point at live and die together."""
         for p in self._plans.values():
-            p["io"].pop(key, None)
+            if "io" in p:          # (the training plans of seq_train.BehaviorTrainEngine keep their buffers for good)
+                p["io"].pop(key, None)
 
     def _io(self, p: dict, key, make):
         io = p["io"].get(key)
