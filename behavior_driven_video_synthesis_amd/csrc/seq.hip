@@ -86,7 +86,11 @@ __device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const f
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if constexpr (LAY & 1) {   // (read once per pass by this one workgroup: streamed past the caches' retention, SEQ_W_NT)
+      if constexpr ((LAY & 9) == 9) {   // (tile-major, re-read every time step from L2 / the Infinity Cache: default policy)
+        const float* wp = w + (size_t)rt * 16 * a.K + 512 * (c0 + WAVES * u);
+        wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
+        wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 256);
+      } else if constexpr (LAY & 1) {   // (read once per pass by this one workgroup: streamed past the caches' retention, SEQ_W_NT)
         const float* wp = w + (size_t)rt * 16 * a.K + 512 * (c0 + WAVES * u);
         wv[rt][u][0] = seq_w_load(wp);
         wv[rt][u][1] = seq_w_load(wp + 256);
@@ -641,7 +645,7 @@ extern "C" int vunet_seq_start(const float* x0, int64_t x0_stride, const float* 
 
 static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
                            const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, float* gates_out,
-                           void* stream) {
+                           bool w_tiled, void* stream) {
   if (!d || !w_perm || !xh || !bias_perm || !c_in || !c_out || c_in == c_out || !xh_next || xh_next == xh) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->H < 4 || d->H % 4 || d->n < 1 || d->hoff < d->n || d->ldx < d->hoff + d->H) return VUNET_ERR_ARG;
   if (d->ldx % 32) return VUNET_ERR_ARG;
@@ -674,10 +678,13 @@ static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, co
   const dim3 grid(a.M / 16, 1, 1);
   hipStream_t st = (hipStream_t)stream;
   const bool wide = a.K >= 16 * 32 && d->B <= 32;   // (3 - 4 batch tiles: four waves, as vunet_seq_linear; 50-step roll-out at 64 rows 1.03 -> 0.93 ms)
-#define SEQ_LSTM_CASE(NB)                                                                      \
-  case NB:                                                                                     \
-    if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16, true>), grid, dim3(1024), 0, st, a);  \
-    else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4, true>), grid, dim3(256), 0, st, a);         \
+#define SEQ_LSTM_CASE(NB)                                                                                   \
+  case NB:                                                                                                  \
+    if (w_tiled) {                                                                                          \
+      if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16, true, 9>), grid, dim3(1024), 0, st, a);          \
+      else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4, true, 9>), grid, dim3(256), 0, st, a);                 \
+    } else if (wide) VUNET_LAUNCH((seq_linear_kernel<NB, 1, 16, true>), grid, dim3(1024), 0, st, a);        \
+    else VUNET_LAUNCH((seq_linear_kernel<NB, 1, 4, true>), grid, dim3(256), 0, st, a);                      \
     break;
   switch (a.Bp / 16) {
     SEQ_LSTM_CASE(1)
@@ -692,7 +699,15 @@ static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, co
 
 extern "C" int vunet_seq_lstm_gates(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
                                     const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, void* stream) {
-  return seq_lstm_launch(d, w_perm, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, nullptr, stream);
+  return seq_lstm_launch(d, w_perm, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, nullptr, false, stream);
+}
+
+// the same step on a TILE-MAJOR gate image (vunet_seq_pack_tiles of w_perm; include/vunet_seq_tiled.h): gates_out as
+// vunet_seq_lstm_gates_train (NULL: not kept)
+extern "C" int vunet_seq_lstm_gates_tiled(const vunet_seq_lstm_desc* d, const float* w_tiles, const float* xh, const float* bias_perm,
+                                          const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next,
+                                          float* gates_out, void* stream) {
+  return seq_lstm_launch(d, w_tiles, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, gates_out, true, stream);
 }
 
 // the same step with the gate activations kept for the backward pass (include/vunet_seq_train.h)
@@ -700,7 +715,7 @@ extern "C" int vunet_seq_lstm_gates_train(const vunet_seq_lstm_desc* d, const fl
                                           const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next,
                                           float* gates_out, void* stream) {
   if (!gates_out) return VUNET_ERR_ARG;
-  return seq_lstm_launch(d, w_perm, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, gates_out, stream);
+  return seq_lstm_launch(d, w_perm, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, gates_out, false, stream);
 }
 
 extern "C" int vunet_seq_decoder_out(const vunet_seq_lstm_desc* d, float* xh, const float* w_out, const float* b_out, float* xraw, float* xs,

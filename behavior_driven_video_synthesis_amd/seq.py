@@ -580,6 +580,8 @@ class BehaviorEngine:
         if getattr(self, "_geo", None) != geo:
             self._geo = geo
             self.dec_w, self.enc_w = z(4 * self.H, self.ldx), z(4 * self.H, self.ldx)
+            # tile-major copies of the two gate images (include/vunet_seq_tiled.h): what the step kernel reads
+            self.dec_wt, self.enc_wt = z(4 * self.H * self.ldx), z(4 * self.H * self.ldx)
             self.dec_b, self.enc_b = z(4 * self.H), z(4 * self.H)
             self.dec_fold = (z(4 * self.H, self.n), z(4 * self.H)) if dec.use_nin else None
             self.heads = ([z(self.H, self.H) for _ in range(2)], [z(self.H) for _ in range(2)]) if enc.ib else None
@@ -616,6 +618,8 @@ class BehaviorEngine:
         gate_bias(dec.rnn.bias_ih, dec.rnn.bias_hh, self.dec_fold_bias, self.dec_b)
         gate_image(enc.rnn.weight_ih_l0, enc.rnn.weight_hh_l0, self.enc_w)
         gate_bias(enc.rnn.bias_ih_l0, enc.rnn.bias_hh_l0, None, self.enc_b)
+        tile_image(self.dec_w, out=self.dec_wt)
+        tile_image(self.enc_w, out=self.enc_wt)
         if enc.ib:
             for i, head in enumerate((enc.mu_fn, enc.std_fn)):
                 v, g, b, gamma, beta = head._params()
@@ -646,8 +650,8 @@ class BehaviorEngine:
         d = SeqLstmDesc(rows, self.H, self.ldx, self.hoff, n, self.ldraw, length * n)
         for t in range(length):
             cur, nxt = t % 2, 1 - t % 2
-            _call("vunet_seq_lstm_gates", ctypes.byref(d), _p(self.dec_w), _p(p["xh"][cur]), _p(self.dec_b), _p(p["c"][cur]),
-                  _p(p["c"][nxt]), _p(p["xh"][nxt]), None, None, _stream())
+            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.dec_wt), _p(p["xh"][cur]), _p(self.dec_b), _p(p["c"][cur]),
+                  _p(p["c"][nxt]), _p(p["xh"][nxt]), None, None, None, _stream())
             _call("vunet_seq_decoder_out", ctypes.byref(d), _p(p["xh"][nxt]), _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()),
                   _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), _stream())
 
@@ -687,8 +691,8 @@ class BehaviorEngine:
         for t in range(t_in):   # one launch per time step: gate product, cell update and the next input row
             cur, nxt = t % 2, 1 - t % 2
             x_next = ctypes.c_void_p(seq.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
-            _call("vunet_seq_lstm_gates", ctypes.byref(d), _p(self.enc_w), _p(p["xh"][cur]), _p(self.enc_b), _p(p["c"][cur]),
-                  _p(p["c"][nxt]), _p(p["xh"][nxt]), _p(p["pre"]) if t == t_in - 1 else None, x_next, _stream())
+            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.enc_wt), _p(p["xh"][cur]), _p(self.enc_b), _p(p["c"][cur]),
+                  _p(p["c"][nxt]), _p(p["xh"][nxt]), _p(p["pre"]) if t == t_in - 1 else None, x_next, None, _stream())
         if self.heads is not None:
             w, bias = self.heads
             dl = SeqLinearDesc(rows, self.H, self.H, self.H, ACT_NONE, ACT_NONE, 2, 1, 1)

@@ -677,7 +677,7 @@ class BehaviorTrainEngine(BehaviorEngine):
         d = SeqLstmDesc(rows, H, self.ldx, self.hoff, n, self.ldraw, t_in * n)
         for t in range(t_in):
             x_next = ctypes.c_void_p(x1.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
-            _call("vunet_seq_lstm_gates_train", ctypes.byref(d), _p(self.enc_w), _p(p["xh_e"][t]), _p(self.enc_b), _p(p["c_e"][t]),
+            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.enc_wt), _p(p["xh_e"][t]), _p(self.enc_b), _p(p["c_e"][t]),
                   _p(p["c_e"][t + 1]), _p(p["xh_e"][t + 1]), _p(p["pre"]) if t == t_in - 1 else None, x_next, _p(p["gates_e"][t]), _stream())
         w, bias = self.heads
         dl = SeqLinearDesc(rows, H, H, H, ACT_NONE, ACT_NONE, 2, 1, 1)
@@ -690,7 +690,7 @@ class BehaviorTrainEngine(BehaviorEngine):
         d = SeqLstmDesc(rows, H, self.ldx, self.hoff, n, self.ldraw, length * n)
         xs, cs = p["xs"], p["cs"]
         for t in range(length):
-            _call("vunet_seq_lstm_gates_train", ctypes.byref(d), _p(self.dec_w), _p(p["xh_d"][t]), _p(self.dec_b), _p(p["c_d"][t]),
+            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.dec_wt), _p(p["xh_d"][t]), _p(self.dec_b), _p(p["c_d"][t]),
                   _p(p["c_d"][t + 1]), _p(p["xh_d"][t + 1]), None, None, _p(p["gates_d"][t]), _stream())
             _call("vunet_seq_decoder_out", ctypes.byref(d), _p(p["xh_d"][t + 1]), _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()),
                   _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), _stream())

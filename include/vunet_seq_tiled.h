@@ -37,6 +37,11 @@ extern "C" {
 #define VUNET_SEQ_TILED_Y 4
 
 int vunet_seq_pack_tiles(const float* w, int32_t ld, int32_t M, int32_t K, float* wt, void* stream);
+/* vunet_seq_lstm_gates / _train (vunet_hip.h, vunet_seq_train.h) on a tile-major copy of the gate image [W_ih | 0 | W_hh]
+ * (vunet_seq_pack_tiles of the gate-interleaved image; ldx % 32 == 0).  gates_out may be NULL. */
+int vunet_seq_lstm_gates_tiled(const vunet_seq_lstm_desc* d, const float* w_tiles, const float* xh, const float* bias_perm,
+                               const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, float* gates_out,
+                               void* stream);
 int vunet_seq_linear_tiled(const vunet_seq_linear_desc* d, int32_t layout, const float* w0, const float* w1, const float* x,
                            const float* bias0, const float* bias1, float* y, float* y_rowmajor, void* stream);
 
