@@ -498,3 +498,35 @@ def test_bench_graph_guard_prints_the_eager_line_when_the_replay_never_returns(t
     ok.write_text(script.read_text().replace("time.sleep(600)", "g.cancel(); time.sleep(1.0); print('{\"metric\": \"graph\"}')"))
     r = subprocess.run([sys.executable, str(ok)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == '{"metric": "graph"}'
+
+
+def test_ctypes_descriptors_match_the_c_structs(tmp_path):
+    """The host builds the kernels' descriptors with ctypes and uploads tables of them byte for byte: every mirrored struct of
+    include/*.h must have the C compiler's size and field offsets (gcc here; the same LP64 layout hipcc uses)."""
+    import ctypes
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from behavior_driven_video_synthesis_amd import seq, seq_train
+    pairs = {"vunet_seq_linear_desc": seq.SeqLinearDesc, "vunet_seq_coupling_desc": seq.SeqCouplingDesc, "vunet_seq_lstm_desc": seq.SeqLstmDesc,
+             "vunet_seq_adam_hp": seq_train.SeqAdamHp, "vunet_seq_dx_desc": seq_train.SeqDxDesc,
+             "vunet_seq_coupling_bwd_desc": seq_train.SeqCouplingBwdDesc, "vunet_seq_dw_layer": seq_train.SeqDwLayer,
+             "vunet_seq_actnorm_layer": seq_train.SeqActnormLayer, "vunet_seq_cell_bwd_desc": seq_train.SeqCellBwdDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vunet_hip.h"', '#include "vunet_seq_train.h"', '#include "vunet_seq_tiled.h"',
+             "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    for line in out.strip().splitlines():
+        cname, size, *offs = line.split()
+        cls = pairs[cname]
+        assert ctypes.sizeof(cls) == int(size), (cname, ctypes.sizeof(cls), size)
+        assert [getattr(cls, f).offset for f, _ in cls._fields_] == [int(o) for o in offs], cname
