@@ -78,29 +78,34 @@ __device__ __forceinline__ float4 seq_w_load(const float* p) {
 
 // LAY (include/vunet_seq_tiled.h): bit 0 -- the weights are tile-major images, bit 1 -- the operand is: a chunk is then 2 KB
 // contiguous, [half][lane] float4, and each of a wave's loads covers 1 KB contiguous.
-template <int NB, int RT, int U, int WAVES, int LAY>
-__device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const float* __restrict__ w, const float* __restrict__ x, int c0,
-                                                 f32x4 (&acc)[RT][NB]) {
+template <int NB, int RT, int U>
+struct SeqGroupRegs {
   float4 wv[RT][U][2], xv[NB][U][2];
+};
+
+// the loads of a group of U chunks (c0, c0 + WAVES, ...): weights of RT tiles, the operand of NB batch tiles
+template <int NB, int RT, int U, int WAVES, int LAY>
+__device__ __forceinline__ void seq_group_load(const SeqLinearArgs& a, const float* __restrict__ w, const float* __restrict__ x, int c0,
+                                               SeqGroupRegs<NB, RT, U>& r) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr ((LAY & 9) == 9) {   // (tile-major, re-read every time step from L2 / the Infinity Cache: default policy)
         const float* wp = w + (size_t)rt * 16 * a.K + 512 * (c0 + WAVES * u);
-        wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
-        wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 256);
+        r.wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
+        r.wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 256);
       } else if constexpr (LAY & 1) {   // (read once per pass by this one workgroup: streamed past the caches' retention, SEQ_W_NT)
         const float* wp = w + (size_t)rt * 16 * a.K + 512 * (c0 + WAVES * u);
-        wv[rt][u][0] = seq_w_load(wp);
-        wv[rt][u][1] = seq_w_load(wp + 256);
+        r.wv[rt][u][0] = seq_w_load(wp);
+        r.wv[rt][u][1] = seq_w_load(wp + 256);
       } else {
         // (row-major weights: the parameters themselves when a flow trains -- the input-gradient chain and the update sweep read
         //  them again within the same block's 168 MB, from the Infinity Cache: default policy.  Non-temporal here: 7.21 -> 7.40 ms
         //  per training step.)
         const float* wp = w + (size_t)rt * 16 * a.K + 32 * (c0 + WAVES * u);
-        wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
-        wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 4);
+        r.wv[rt][u][0] = *reinterpret_cast<const float4*>(wp);
+        r.wv[rt][u][1] = *reinterpret_cast<const float4*>(wp + 4);
       }
     }
 #pragma unroll
@@ -109,29 +114,42 @@ __device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const f
     for (int u = 0; u < U; ++u) {
       if constexpr (LAY & 2) {
         const float* xp = x + (size_t)nb * 16 * a.K + 512 * (c0 + WAVES * u);
-        xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
-        xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 256);
+        r.xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
+        r.xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 256);
       } else {
         const float* xp = x + (size_t)nb * 16 * a.ldx + 32 * (c0 + WAVES * u);
-        xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
-        xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 4);
+        r.xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
+        r.xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 4);
       }
     }
-  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ... and its matrix steps: chunk by chunk, weight tile by weight tile, batch tile by batch tile, k ascending
+template <int NB, int RT, int U>
+__device__ __forceinline__ void seq_group_mfma(const SeqGroupRegs<NB, RT, U>& r, f32x4 (&acc)[RT][NB]) {
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const float wa[8] = {wv[rt][u][0].x, wv[rt][u][0].y, wv[rt][u][0].z, wv[rt][u][0].w,
-                           wv[rt][u][1].x, wv[rt][u][1].y, wv[rt][u][1].z, wv[rt][u][1].w};
+      const float wa[8] = {r.wv[rt][u][0].x, r.wv[rt][u][0].y, r.wv[rt][u][0].z, r.wv[rt][u][0].w,
+                           r.wv[rt][u][1].x, r.wv[rt][u][1].y, r.wv[rt][u][1].z, r.wv[rt][u][1].w};
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const float xb[8] = {xv[nb][u][0].x, xv[nb][u][0].y, xv[nb][u][0].z, xv[nb][u][0].w,
-                             xv[nb][u][1].x, xv[nb][u][1].y, xv[nb][u][1].z, xv[nb][u][1].w};
+        const float xb[8] = {r.xv[nb][u][0].x, r.xv[nb][u][0].y, r.xv[nb][u][0].z, r.xv[nb][u][0].w,
+                             r.xv[nb][u][1].x, r.xv[nb][u][1].y, r.xv[nb][u][1].z, r.xv[nb][u][1].w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[rt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[j], acc[rt][nb], 0, 0, 0);
       }
     }
+}
+
+template <int NB, int RT, int U, int WAVES, int LAY>
+__device__ __forceinline__ void seq_linear_group(const SeqLinearArgs& a, const float* __restrict__ w, const float* __restrict__ x, int c0,
+                                                 f32x4 (&acc)[RT][NB]) {
+  SeqGroupRegs<NB, RT, U> r;
+  seq_group_load<NB, RT, U, WAVES, LAY>(a, w, x, c0, r);
+  __builtin_amdgcn_sched_barrier(0);
+  seq_group_mfma<NB, RT, U>(r, acc);
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
@@ -166,6 +184,44 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
   // (16 waves share the CU's registers: 128 each)
   // (four-wave form at 3 - 4 batch tiles with groups of 4 instead of 2: 6.96 -> 7.10 ms per flow training step)
   constexpr int UMAX = WAVES == 16 ? (NB == 1 ? 4 : 2) : ((NB + RT <= 3) ? 4 : 2);
+  // Four-wave workgroups at 3 - 4 batch tiles are one wave per SIMD (256 workgroups on 256 CUs): nothing else runs while a wave
+  // waits for its loads, so the wave itself keeps a RING of SEQ_RING stages (of SEQ_RING_U chunks) in flight -- the loads of stage
+  // i + SEQ_RING - 1 are issued before the matrix steps of stage i (the compiler's counted vmcnt waits retire them in order).
+  // Same chunks, same order, same sums as the plain loop.  (flow training step at 64 rows: see DESIGN.md section 5.R6.)
+#ifndef SEQ_RING
+#define SEQ_RING 2
+#endif
+#ifndef SEQ_RING_U
+#define SEQ_RING_U 1
+#endif
+  if constexpr (WAVES == 4 && NB >= 3 && SEQ_RING > 1) {
+    constexpr int D = SEQ_RING, SU = SEQ_RING_U;   // D stages of SU chunks each
+    const int nw = c < nchunk ? (nchunk - c + WAVES - 1) / WAVES : 0;   // this wave's chunks
+    const int ns = nw / SU, n_main = ns - ns % D;                        // ... stages, and those the ring takes
+    if (n_main > 0) {
+      SeqGroupRegs<NB, RT, SU> ring[D];
+#pragma unroll
+      for (int dd = 0; dd < D - 1; ++dd) seq_group_load<NB, RT, SU, WAVES, LAY>(a, w, x, c + WAVES * SU * dd, ring[dd]);
+      int base = 0;
+      for (; base + D < n_main; base += D) {   // steady state: every stage requests the one D - 1 ahead of the one it multiplies
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          seq_group_load<NB, RT, SU, WAVES, LAY>(a, w, x, c + WAVES * SU * (base + dd + D - 1), ring[(dd + D - 1) % D]);
+          __builtin_amdgcn_sched_barrier(0);
+          seq_group_mfma<NB, RT, SU>(ring[dd], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // the last D stages: only the very last one is still to be requested
+      seq_group_load<NB, RT, SU, WAVES, LAY>(a, w, x, c + WAVES * SU * (n_main - 1), ring[D - 1]);
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) {
+        __builtin_amdgcn_sched_barrier(0);
+        seq_group_mfma<NB, RT, SU>(ring[dd], acc);
+      }
+      c += WAVES * SU * n_main;
+    }
+  }
   for (; c + WAVES * (UMAX - 1) < nchunk; c += WAVES * UMAX) seq_linear_group<NB, RT, UMAX, WAVES, LAY>(a, w, x, c, acc);
   if constexpr (UMAX == 4)
     if (c + WAVES < nchunk) {

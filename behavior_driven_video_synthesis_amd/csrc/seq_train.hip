@@ -18,6 +18,8 @@
 //     thousand independent tiles.  hp == NULL: the tile of dW is stored instead (autograd's view of the same kernels).
 //   * seq_coupling_bwd_kernel, seq_actnorm_bwd_kernel, seq_flow_loss_kernel: the pointwise / reduction remainder.
 // Nothing uses float atomics; every sum has a fixed order: a step is bit-reproducible.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/vunet_seq_train.h"
 
@@ -72,20 +74,77 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[e][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int g = wave; g < ngrp; g += WAVES) {
-    float4 wv[4], dv[NB];
+#ifndef SEQ_DX_RING
+#define SEQ_DX_RING 2
+#endif
+#ifndef SEQ_DX_RING_U
+#define SEQ_DX_RING_U 1
+#endif
+  constexpr int SU = (WAVES == 4 && SEQ_DX_RING > 1) ? SEQ_DX_RING_U : 1;   // row groups per stage of the ring below
+  struct Stage {
+    float4 wv[SU][4], dv[SU][NB];
+  };
+  auto load = [&](int g, auto nu_c, Stage& r) {
+    constexpr int NU = decltype(nu_c)::value;
 #pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) wv[e2] = *reinterpret_cast<const float4*>(w + (size_t)(16 * g + e2) * a.ldw);   // (default policy: the sweep re-reads W)
+    for (int u = 0; u < NU; ++u) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) dv[nb] = *reinterpret_cast<const float4*>(dz + (size_t)16 * nb * a.M + 16 * g);
+      for (int e2 = 0; e2 < 4; ++e2)
+        r.wv[u][e2] = *reinterpret_cast<const float4*>(w + (size_t)(16 * (g + WAVES * u) + e2) * a.ldw);   // (default policy: the sweep re-reads W)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) r.dv[u][nb] = *reinterpret_cast<const float4*>(dz + (size_t)16 * nb * a.M + 16 * (g + WAVES * u));
+    }
+  };
+  auto mfma = [&](auto nu_c, const Stage& r) {
+    constexpr int NU = decltype(nu_c)::value;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[e][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(r.wv[u][e2], e), comp4(r.dv[u][nb], e2), acc[e][nb], 0, 0, 0);
+  };
+  constexpr std::integral_constant<int, SU> su_c{};
+  constexpr std::integral_constant<int, 1> one_c{};
+  int g = wave;
+  // Four-wave workgroups (48 - 64 batch rows) are one wave per SIMD: the wave keeps a ring of SEQ_DX_RING stages (of SEQ_DX_RING_U
+  // row groups) in flight, the loads of stage i + SEQ_DX_RING - 1 issued before the matrix steps of stage i (csrc/seq.hip:
+  // seq_linear_kernel's ring).  Same groups, same order, same sums as the plain loop below.
+  if constexpr (WAVES == 4 && SEQ_DX_RING > 1) {
+    constexpr int D = SEQ_DX_RING;
+    const int nw = g < ngrp ? (ngrp - g + WAVES - 1) / WAVES : 0;
+    const int ns = nw / SU, n_main = ns - ns % D;
+    if (n_main > 0) {
+      Stage ring[D];
+#pragma unroll
+      for (int dd = 0; dd < D - 1; ++dd) load(g + WAVES * SU * dd, su_c, ring[dd]);
+      int base = 0;
+      for (; base + D < n_main; base += D) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          load(g + WAVES * SU * (base + dd + D - 1), su_c, ring[(dd + D - 1) % D]);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma(su_c, ring[dd]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      load(g + WAVES * SU * (n_main - 1), su_c, ring[D - 1]);
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) {
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(su_c, ring[dd]);
+      }
+      g += WAVES * SU * n_main;
+    }
+  }
+  for (; g < ngrp; g += WAVES) {
+    Stage r;
+    load(g, one_c, r);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[e][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(wv[e2], e), comp4(dv[nb], e2), acc[e][nb], 0, 0, 0);
+    mfma(one_c, r);
   }
   // the waves' partial sums meet in LDS, one batch tile per round; waves 0..3 (thread t: r = t >> 6) add them in wave order
   float* out = a.raw + ((size_t)net * a.S + s) * a.Bp * a.K;
