@@ -716,7 +716,7 @@ extern "C" int vunet_upsample_bilinear2x_bwd(const float* dy, float* dx, int64_t
   return vunet_check_launch();
 }
 
-extern "C" int vunet_abi_version(void) { return 11; }   // 11: include/vunet_seq_train.h (config 4 training)
+extern "C" int vunet_abi_version(void) { return 12; }   // 11: include/vunet_seq_train.h (config 4 training); 12: vunet_seq_dx_finish
 
 // ------------------------------------------------------------------ window crop with a device-resident corner
 __global__ void crop_window_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int H, int W, int P,

@@ -53,6 +53,11 @@ struct SeqDxArgs {
   const float* dz;     // [nets][Bp][M]
   float* raw;          // [nets][S][Bp][K]
   int M, K, Bp, S, ldw;
+  // FIN (vunet_seq_dx_finish): the workgroup that completes a column stripe's S slabs finishes the stripe
+  const float* y;      // [nets][Bp][K] the previous layer's saved output
+  float* dzp;          // [nets][Bp][K] its dZ
+  int* cnt;            // [nets][K / 64] arrival counters (zero between launches)
+  float slope;
 };
 
 // grid (K / 64, S, nets), 64 WAVES threads.  Lane l: i = l & 15, q = l >> 4.  In a 16-row group starting at row mb the lane loads
@@ -60,7 +65,7 @@ struct SeqDxArgs {
 // dZ[16 nb + i][mb + 4 q .. + 3].  MFMA (e', e, nb): A = component e of load e' (row i of A <-> column k0 + 4 i + e), B = component
 // e' of the dZ load (column j of B <-> batch row 16 nb + j), both at reduction slot q <-> W row mb + 4 q + e'.
 // D: lane holds dX[16 nb + (l & 15)][k0 + 4 (4 q + r) + e] in acc[e][nb][r].
-template <int NB, int WAVES>
+template <int NB, int WAVES, bool FIN = false>
 __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   __shared__ float4 red[WAVES][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
 #ifndef SEQ_DX_RING_U
 #define SEQ_DX_RING_U 1
 #endif
-  constexpr int SU = (WAVES == 4 && SEQ_DX_RING > 1) ? SEQ_DX_RING_U : 1;   // row groups per stage of the ring below
+  constexpr int SU = (WAVES <= 8 && SEQ_DX_RING > 1) ? SEQ_DX_RING_U : 1;   // row groups per stage of the ring below
   struct Stage {
     float4 wv[SU][4], dv[SU][NB];
   };
@@ -110,10 +115,10 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   constexpr std::integral_constant<int, SU> su_c{};
   constexpr std::integral_constant<int, 1> one_c{};
   int g = wave;
-  // Four-wave workgroups (48 - 64 batch rows) are one wave per SIMD: the wave keeps a ring of SEQ_DX_RING stages (of SEQ_DX_RING_U
+  // Four- / eight-wave workgroups (48 - 64 batch rows) are one or two waves per SIMD: the wave keeps a ring of SEQ_DX_RING stages (of SEQ_DX_RING_U
   // row groups) in flight, the loads of stage i + SEQ_DX_RING - 1 issued before the matrix steps of stage i (csrc/seq.hip:
   // seq_linear_kernel's ring).  Same groups, same order, same sums as the plain loop below.
-  if constexpr (WAVES == 4 && SEQ_DX_RING > 1) {
+  if constexpr (WAVES <= 8 && SEQ_DX_RING > 1) {
     constexpr int D = SEQ_DX_RING;
     const int nw = g < ngrp ? (ngrp - g + WAVES - 1) / WAVES : 0;
     const int ns = nw / SU, n_main = ns - ns % D;
@@ -161,6 +166,33 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
       *reinterpret_cast<float4*>(out + (size_t)(16 * nb + i) * a.K + k0 + 16 * q + 4 * r) = v;
     }
     __syncthreads();
+  }
+  if constexpr (FIN) {
+    // The stripe's S workgroups (one per row range of W) count their arrivals; the last one adds the S slabs IN SLAB ORDER --
+    // whoever it is, the sum is the one seq_dz_finish_kernel forms -- applies LeakyReLU' and writes the previous layer's dZ.
+    // Release / acquire at device scope around the counter: the slabs were written by workgroups on other XCDs (other L2s).
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    int* const cnt = a.cnt + net * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) last = atomicAdd(cnt, 1) == a.S - 1;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) *cnt = 0;   // (the next launch that uses the counters starts after this kernel has ended)
+    __threadfence();
+    const size_t slab = (size_t)a.Bp * a.K;
+    const float* r0 = a.raw + (size_t)net * a.S * slab + k0;
+    for (int idx = threadIdx.x; idx < a.Bp * 16; idx += 64 * WAVES) {
+      const size_t off = (size_t)(idx >> 4) * a.K + 4 * (idx & 15);
+      float4 v = *reinterpret_cast<const float4*>(r0 + off);
+      for (int p = 1; p < a.S; ++p) v = add4(v, *reinterpret_cast<const float4*>(r0 + (size_t)p * slab + off));
+      const float4 yv = *reinterpret_cast<const float4*>(a.y + (size_t)net * slab + k0 + off);
+      v.x *= yv.x > 0.f ? 1.f : a.slope;
+      v.y *= yv.y > 0.f ? 1.f : a.slope;
+      v.z *= yv.z > 0.f ? 1.f : a.slope;
+      v.w *= yv.w > 0.f ? 1.f : a.slope;
+      *reinterpret_cast<float4*>(a.dzp + (size_t)net * slab + k0 + off) = v;
+    }
   }
 }
 
@@ -340,30 +372,48 @@ __global__ __launch_bounds__(256) void seq_dw_kernel(const vunet_seq_dw_layer* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) dws[dw_swo(16 * wave + 4 * q + r, 16 * blk + i)] = acc[blk][r];
   __syncthreads();
+  // the tile leaves in rounds of GRP float4 per thread: the round's W / exp_avg / exp_avg_sq requested together, then updated and
+  // stored (-DSEQ_DW_GRP=1: one float4 at a time, =4: the whole tile at once -- 140 registers, three workgroups per CU)
+#ifndef SEQ_DW_GRP
+#define SEQ_DW_GRP 2
+#endif
+  constexpr int GRP = ADAM ? SEQ_DW_GRP : 1;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
-    float4 g = *reinterpret_cast<const float4*>(&dws[dw_swo(row, 4 * c4)]);
-    if (k0 + 4 * c4 + 3 >= L.kv) {   // (padding columns of the image: only where K is not the layer's own width)
-      const int kc = k0 + 4 * c4;
-      if (kc >= L.kv) g.x = 0.f;
-      if (kc + 1 >= L.kv) g.y = 0.f;
-      if (kc + 2 >= L.kv) g.z = 0.f;
-      g.w = 0.f;
+  for (int it0 = 0; it0 < 4; it0 += GRP) {
+    float4 g[GRP], p[GRP], m[GRP], v[GRP];
+    size_t off[GRP];
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int idx = tid + 256 * (it0 + u), row = idx >> 4, c4 = idx & 15;
+      off[u] = (size_t)(m0 + row) * L.K + k0 + 4 * c4;
+      if constexpr (ADAM) {
+        // (each of these bytes is touched once per step: keep them out of the L2 that holds the operand rows)
+        p[u] = SEQ_NT_LOAD(L.w + off[u]);
+        m[u] = SEQ_NT_LOAD(L.m + off[u]);
+        v[u] = SEQ_NT_LOAD(L.v + off[u]);
+      }
+      g[u] = *reinterpret_cast<const float4*>(&dws[dw_swo(row, 4 * c4)]);
+      if (k0 + 4 * c4 + 3 >= L.kv) {   // (padding columns of the image: only where K is not the layer's own width)
+        const int kc = k0 + 4 * c4;
+        if (kc >= L.kv) g[u].x = 0.f;
+        if (kc + 1 >= L.kv) g[u].y = 0.f;
+        if (kc + 2 >= L.kv) g[u].z = 0.f;
+        g[u].w = 0.f;
+      }
     }
-    const size_t off = (size_t)(m0 + row) * L.K + k0 + 4 * c4;
-    if constexpr (ADAM) {
-      // (each of these bytes is touched once per step: keep them out of the L2 that holds the operand rows)
-      float4 p = SEQ_NT_LOAD(L.w + off), m = SEQ_NT_LOAD(L.m + off), v = SEQ_NT_LOAD(L.v + off);
-      adam_update(h, g.x, p.x, m.x, v.x);
-      adam_update(h, g.y, p.y, m.y, v.y);
-      adam_update(h, g.z, p.z, m.z, v.z);
-      adam_update(h, g.w, p.w, m.w, v.w);
-      SEQ_NT_STORE(L.w + off, p);
-      SEQ_NT_STORE(L.m + off, m);
-      SEQ_NT_STORE(L.v + off, v);
-    } else {
-      *reinterpret_cast<float4*>(L.g + off) = g;
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      if constexpr (ADAM) {
+        adam_update(h, g[u].x, p[u].x, m[u].x, v[u].x);
+        adam_update(h, g[u].y, p[u].y, m[u].y, v[u].y);
+        adam_update(h, g[u].z, p[u].z, m[u].z, v[u].z);
+        adam_update(h, g[u].w, p[u].w, m[u].w, v[u].w);
+        SEQ_NT_STORE(L.w + off[u], p[u]);
+        SEQ_NT_STORE(L.m + off[u], m[u]);
+        SEQ_NT_STORE(L.v + off[u], v[u]);
+      } else {
+        *reinterpret_cast<float4*>(L.g + off[u]) = g[u];
+      }
     }
   }
   if (tk == 0 && tid < 64 && L.bias) {
@@ -647,11 +697,13 @@ __global__ __launch_bounds__(256) void seq_unpack_rows_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw, void* stream) {
+static int seq_dx_launch(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw, const float* y,
+                         float* dz_prev, int32_t* counters, float slope, bool fin, void* stream) {
   if (!d || !w0 || !dz || !raw) return VUNET_ERR_ARG;
   if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 64 || d->K < 64 || d->K % 64 || d->S < 1 || d->M < 16 * d->S || d->M % (16 * d->S)) return VUNET_ERR_ARG;
   if (d->ldw && (d->ldw < d->K || d->ldw % 4)) return VUNET_ERR_ARG;
+  if (fin && (!y || !dz_prev || !counters)) return VUNET_ERR_ARG;
   SeqDxArgs a;
   a.ldw = d->ldw ? d->ldw : d->K;
   a.w[0] = w0;
@@ -662,13 +714,24 @@ extern "C" int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const f
   a.K = d->K;
   a.Bp = (d->B + 15) / 16 * 16;
   a.S = d->S;
+  a.y = y;
+  a.dzp = dz_prev;
+  a.cnt = counters;
+  a.slope = slope;
   const dim3 grid(d->K / 64, d->S, d->nets);
   hipStream_t st = (hipStream_t)stream;
   const bool wide = d->M / d->S >= 16 * 16 && d->B <= 32;   // 16 waves: at least one 16-row group each (64 rows: see vunet_seq_linear)
-#define SEQ_DX_CASE(NB)                                                          \
-  case NB:                                                                       \
-    if (wide) VUNET_LAUNCH((seq_dx_kernel<NB, 16>), grid, dim3(1024), 0, st, a); \
-    else VUNET_LAUNCH((seq_dx_kernel<NB, 4>), grid, dim3(256), 0, st, a);        \
+  // a launch that cannot give every CU a workgroup (17 column stripes: the LSTM's gate matrix over [x | h]) runs eight waves per
+  // workgroup on its S / 2 slabs instead of four on S with a second, nearly empty round of workgroups
+  const bool eight = !wide && (long)grid.x * grid.y * grid.z <= 160 && d->M / d->S >= 16 * 16;
+#define SEQ_DX_LAUNCH(NB, FIN)                                                            \
+  if (wide) VUNET_LAUNCH((seq_dx_kernel<NB, 16, FIN>), grid, dim3(1024), 0, st, a);       \
+  else if (eight) VUNET_LAUNCH((seq_dx_kernel<NB, 8, FIN>), grid, dim3(512), 0, st, a);   \
+  else VUNET_LAUNCH((seq_dx_kernel<NB, 4, FIN>), grid, dim3(256), 0, st, a);
+#define SEQ_DX_CASE(NB)                  \
+  case NB:                               \
+    if (fin) { SEQ_DX_LAUNCH(NB, true) } \
+    else { SEQ_DX_LAUNCH(NB, false) }    \
     break;
   switch (a.Bp / 16) {
     SEQ_DX_CASE(1)
@@ -678,7 +741,17 @@ extern "C" int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const f
     default: return VUNET_ERR_ARG;
   }
 #undef SEQ_DX_CASE
+#undef SEQ_DX_LAUNCH
   return vunet_check_launch();
+}
+
+extern "C" int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw, void* stream) {
+  return seq_dx_launch(d, w0, w1, dz, raw, nullptr, nullptr, nullptr, 0.f, false, stream);
+}
+
+extern "C" int vunet_seq_dx_finish(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw,
+                                   const float* y, float* dz_prev, int32_t* counters, float slope, void* stream) {
+  return seq_dx_launch(d, w0, w1, dz, raw, y, dz_prev, counters, slope, true, stream);
 }
 
 extern "C" int vunet_seq_dz_finish(const float* raw, const float* y, float* dz, int32_t nets, int32_t S, int32_t Bp, int32_t K,

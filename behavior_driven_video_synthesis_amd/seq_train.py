@@ -138,6 +138,12 @@ class FlowTrainEngine(FlowEngine):
         # as 120 dependent per-layer launches of 512 - 1024 workgroups (each ~15 us per 64 x 64 sub-tile, whatever its size) instead
         # of 30 launches of 5120 independent tiles.  Off by default.
         self.fused_dx = os.environ.get("VUNET_SEQ_TRAIN_FUSED_DX", "0") == "1"
+        # "1": the slab sum + LeakyReLU' of a hidden layer's input gradient inside the launch that writes the slabs
+        # (vunet_seq_dx_finish: the last workgroup of a column stripe to arrive does it; 90 dependent launches fewer per step).
+        # Built, bit-for-bit tested, and SLOWER: 9.6 ms per step against 6.5 -- the device-scope release / acquire around the
+        # arrival counter (the slabs come from workgroups on other XCDs, i.e. other L2s) writes back and invalidates each L2
+        # once per workgroup, in a step whose update sweep keeps every L2 full of dirty lines.  Off by default.
+        self.fused_finish = os.environ.get("VUNET_SEQ_TRAIN_FUSED_FINISH", "0") == "1"
 
     # ---- weights
     def _pack(self, dev=None):
@@ -205,6 +211,7 @@ class FlowTrainEngine(FlowEngine):
         p["S"] = ([(m + 64 * t - 1) // (64 * t) for (m, _), t in zip(h0.dims, p["tsub"])] if self.fused_dx
                   else [self._dx_split(m, k, h0.nets) for (m, k) in h0.dims])
         p["raw"] = z(max(h0.nets * s * b_pad * k for s, (_, k) in zip(p["S"], h0.dims)))
+        p["dx_cnt"] = torch.zeros(h0.nets * max(k for (_, k) in h0.dims) // 64, dtype=torch.int32, device=dev)   # vunet_seq_dx_finish
         p["raw_in"] = [z(h0.nets * p["S"][0] * b_pad * h0.dims[0][1]) for _ in range(2)]
         self._plans[("train", rows)] = p
         return p
@@ -221,8 +228,11 @@ class FlowTrainEngine(FlowEngine):
 
     @staticmethod
     def _dx_split(m: int, k: int, nets: int) -> int:
-        s = 1
-        while (k // 64) * nets * s < 256 and m % (32 * s) == 0 and m // (2 * s) >= 64 and s < 16:
+        """Row ranges of W per input-gradient launch: doubled while the launch still fits one round of workgroups on the
+        chip's 256 CUs (17 column stripes: 8 slabs = 136 eight-wave workgroups, not 16 = 272 with a nearly empty second round)."""
+        s, wgs = 1, (k // 64) * nets
+        legacy = os.environ.get("VUNET_SEQ_DX_TAIL", "0") == "1"    # ("1": the rule before -- doubled until >= 256 workgroups)
+        while (wgs * s < 256 if legacy else wgs * s * 2 <= 256) and m % (32 * s) == 0 and m // (2 * s) >= 64 and s < 16:
             s *= 2
         return s
 
@@ -262,8 +272,12 @@ class FlowTrainEngine(FlowEngine):
             s = p["S"][li]
             raw = raw_in if li == 0 else p["raw"]
             d = SeqDxDesc(rows, m_pad, k_pad, half.nets, s, 0)
-            _call("vunet_seq_dx", ctypes.byref(d), _p(half.w[li][0]), _p(half.w[li][1] if half.nets > 1 else None), _p(dzs[li]), _p(raw),
-                  _stream())
+            w1 = _p(half.w[li][1] if half.nets > 1 else None)
+            if li > 0 and self.fused_finish:   # the stripe's last workgroup finishes dZ of the layer below: one launch, not two
+                _call("vunet_seq_dx_finish", ctypes.byref(d), _p(half.w[li][0]), w1, _p(dzs[li]), _p(raw), _p(ys[li - 1]),
+                      _p(dzs[li - 1]), _p(p["dx_cnt"]), LRELU_SLOPE, _stream())
+                continue
+            _call("vunet_seq_dx", ctypes.byref(d), _p(half.w[li][0]), w1, _p(dzs[li]), _p(raw), _stream())
             if li > 0:
                 _call("vunet_seq_dz_finish", _p(raw), _p(ys[li - 1]), _p(dzs[li - 1]), half.nets, s, b_pad, k_pad, LRELU_SLOPE, _stream())
 

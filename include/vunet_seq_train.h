@@ -62,6 +62,15 @@ int vunet_seq_dx(const vunet_seq_dx_desc* d, const float* w0, const float* w1, c
 int vunet_seq_dz_finish(const float* raw, const float* y, float* dz, int32_t nets, int32_t S, int32_t Bp, int32_t K, float slope,
                         void* stream);
 
+/* vunet_seq_dx and vunet_seq_dz_finish of its slabs in ONE launch (the hidden layers of an MLP: a dependent launch less per layer).
+ * The S workgroups of a 64-column stripe count their arrivals in counters[n][K / 64] (int32, zero before the first use and left
+ * zero); the one that arrives last adds the stripe's S slabs in slab order -- the sum does not depend on which one it is -- and
+ * writes dz_prev[n][b][k] for the stripe.  y, dz_prev: [nets][Bp][K].  Same values as the two launches.  (Measured slower than
+ * the two launches inside a training step -- the device-scope fences around the counter flush every L2: DESIGN.md 5.R6 -- and not
+ * used by default.) */
+int vunet_seq_dx_finish(const vunet_seq_dx_desc* d, const float* w0, const float* w1, const float* dz, float* raw, const float* y,
+                        float* dz_prev, int32_t* counters, float slope, void* stream);
+
 /* One step of the flow backwards (the mirror of vunet_seq_coupling, forward direction).  The forward step was
  *   v = couple(in);  out[c] = A(v[map[c]])   with couple = x_k exp(s) + t on columns >= c1, A = ActNorm of the NEXT block.
  * g[c]      = gbase[b][c] + (c < c1s ? sum over n_sl slabs gslabs[n][b][c] : 0)      the gradient wrt out (complete)

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.vunet_abi_version() == 11
+    assert lib.vunet_abi_version() == 12
 
 
 def test_header_is_plain_c_abi():

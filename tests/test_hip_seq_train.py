@@ -250,6 +250,29 @@ def test_tile_major_activations_in_the_training_forward_change_nothing(shape):
         assert torch.equal(v, res[False][1][k]), k
 
 
+@pytest.mark.parametrize("shape", [(96, 160, 2, 2, 17), (96, 160, 3, 2, 48), (1024, 2048, 2, 2, 64), (1024, 2048, 2, 2, 16)])
+def test_slab_sum_inside_the_input_gradient_launch_changes_nothing(shape):
+    """``vunet_seq_dx_finish``: the last workgroup of a column stripe to arrive adds the stripe's slabs (in slab order) and applies
+    LeakyReLU' -- one launch instead of ``vunet_seq_dx`` + ``vunet_seq_dz_finish``.  Whichever workgroup that is, the values are
+    those of the two launches: three fused steps are bit-identical, eagerly issued and replayed from the graph (the arrival
+    counters are back at zero after every launch)."""
+    chan, mid, depth, n_flows, bsz = shape
+    res = {}
+    for mode in ("two", "one", "one-graph"):
+        flow, _ = _random_flow(chan, mid, depth, n_flows, 43)
+        eng = flow.flow.train_engine(lr=1e-4, betas=(0.5, 0.9))
+        eng.fused_finish = mode != "two"
+        eng.graph.enabled = mode == "one-graph"
+        logs = [eng.train_step(seeded_randn(f"ff.b{it}", (bsz, chan), 43).cuda(), torch.zeros(bsz, chan, device="cuda")).tolist()
+                for it in range(3)]
+        res[mode] = (logs, {k: v.detach().clone() for k, v in flow.state_dict().items()})
+        assert int(eng._plan(bsz)["dx_cnt"].abs().sum()) == 0
+    for mode in ("one", "one-graph"):
+        assert res[mode][0] == res["two"][0], mode
+        for k, v in res["two"][1].items():
+            assert torch.equal(v, res[mode][1][k]), (mode, k)
+
+
 @pytest.mark.parametrize("shape", [(96, 160, 2, 2, 17), (33, 48, 1, 2, 4), (1024, 2048, 2, 2, 64)])
 def test_one_pass_backward_matches_the_two_pass_one(shape):
     """``vunet_seq_dwx`` (the update sweep also forms the layer's input gradient: one pass over W; off by default, it is slower)
