@@ -26,10 +26,28 @@ struct SeqCellBwdArgs {
 
 // grid (B, ceil(H / 256)), 256 threads: batch row b, hidden unit j.  The decoder's workgroups first assemble the row's gradient
 // wrt x' (n <= 64 values) in LDS -- every workgroup of the row forms the same sums in the same order; the first writes them out.
+// Everything a thread will need is REQUESTED before that: its slabs of W_hh^T dgates, its column of the output layer (n <= 64
+// values), its gates and cell states -- the kernel was three dependent round trips (x' gradient, barrier, slabs, the 51-term
+// product) of 12 us at one launch per time step; the sums keep their order.
 __global__ __launch_bounds__(256) void seq_cell_bwd_kernel(SeqCellBwdArgs a) {
   __shared__ float gx[64];
   const int b = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+  const int jj = j < a.H ? j : a.H - 1;   // (threads past H load a valid neighbour's values and drop them)
   const size_t slab = (size_t)a.Bp * a.ld_sl;
+  const bool later = !(a.first & 1) && a.hsl;
+  constexpr int SMAX = 16;                // slabs held in registers at once (vunet_seq_dx splits W's rows into <= 16 ranges)
+  float hv[SMAX];
+  const float* const hp = later ? a.hsl + (size_t)b * a.ld_sl + a.hoff_sl + jj : nullptr;
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) hv[s] = (later && s < a.n_sl) ? hp[s * slab] : 0.f;
+  float wv[64];
+  if (a.w_out) {
+#pragma unroll
+    for (int r = 0; r < 64; ++r) wv[r] = r < a.n ? a.w_out[(size_t)r * a.H + jj] : 0.f;
+  }
+  const size_t e = (size_t)b * a.H + jj;
+  const float4 g = *reinterpret_cast<const float4*>(a.gates + e * 4);
+  const float cn = a.c_new[e], cp = a.c_prev[e], gc_in = (a.first & 2) ? 0.f : a.gc[e];
   if (a.w_out) {
     if (threadIdx.x < 64) {
       const int r = threadIdx.x;
@@ -38,7 +56,16 @@ __global__ __launch_bounds__(256) void seq_cell_bwd_kernel(SeqCellBwdArgs a) {
         v = a.gl[b * a.gl_stride + r];
         if (!(a.first & 1)) {
           v += a.gx_next[(size_t)b * 64 + r];                                                   // x'' = n_out(h') + x'   (:506)
-          for (int s = 0; s < a.n_sl; ++s) v += a.hsl[s * slab + (size_t)b * a.ld_sl + r];     // W_ih^T dgates of the later step
+          const float* q = a.hsl + (size_t)b * a.ld_sl + r;                                     // W_ih^T dgates of the later step
+          int s = 0;
+          for (; s + 8 <= a.n_sl; s += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = q[(s + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+          }
+          for (; s < a.n_sl; ++s) v += q[s * slab];
         }
       }
       gx[r] = v;
@@ -48,32 +75,26 @@ __global__ __launch_bounds__(256) void seq_cell_bwd_kernel(SeqCellBwdArgs a) {
   }
   if (j >= a.H) return;
   float dh = 0.f;
-  if (!(a.first & 1) && a.hsl) {   // W_hh^T dgates of the later step: slabs in slab order, four loads in flight
-    const float* p = a.hsl + (size_t)b * a.ld_sl + a.hoff_sl + j;
-    int s = 0;
-    for (; s + 4 <= a.n_sl; s += 4) {
-      const float v0 = p[s * slab], v1 = p[(s + 1) * slab], v2 = p[(s + 2) * slab], v3 = p[(s + 3) * slab];
-      dh += v0;
-      dh += v1;
-      dh += v2;
-      dh += v3;
-    }
-    for (; s < a.n_sl; ++s) dh += p[s * slab];
+  if (later) {   // W_hh^T dgates of the later step: slabs in slab order
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s)
+      if (s < a.n_sl) dh += hv[s];
+    for (int s = SMAX; s < a.n_sl; ++s) dh += hp[s * slab];
   }
   if (a.w_out) {
     float acc = 0.f;
-    for (int r = 0; r < a.n; ++r) acc += a.w_out[(size_t)r * a.H + j] * gx[r];   // out = n_out(h)   (:504)
+#pragma unroll
+    for (int r = 0; r < 64; ++r)
+      if (r < a.n) acc += wv[r] * gx[r];   // out = n_out(h)   (:504)
     dh += acc;
   }
-  const size_t e = (size_t)b * a.H + j;
-  const float4 g = *reinterpret_cast<const float4*>(a.gates + e * 4);
   // c' = f c + i g,  h = o tanh(c')   (torch.nn.LSTMCell, models/pose_behavior_rnn.py:476, :498)
-  const float tc = tanhf(a.c_new[e]);
-  const float dc = ((a.first & 2) ? 0.f : a.gc[e]) + dh * g.w * (1.f - tc * tc);
+  const float tc = tanhf(cn);
+  const float dc = gc_in + dh * g.w * (1.f - tc * tc);
   a.gc[e] = dc * g.y;
   float4 d;
   d.x = dc * g.z * g.x * (1.f - g.x);
-  d.y = dc * a.c_prev[e] * g.y * (1.f - g.y);
+  d.y = dc * cp * g.y * (1.f - g.y);
   d.z = dc * g.x * (1.f - g.z * g.z);
   d.w = dh * tc * g.w * (1.f - g.w);
   *reinterpret_cast<float4*>(a.dgates + e * 4) = d;
