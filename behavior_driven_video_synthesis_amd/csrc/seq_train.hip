@@ -203,9 +203,15 @@ __global__ __launch_bounds__(256) void seq_dz_finish_kernel(const float* __restr
   if (idx >= per_net4) return;
   const int net = blockIdx.y;
   const float4* r4 = reinterpret_cast<const float4*>(raw) + (size_t)net * S * per_net4 + idx;
-  float4 v = r4[0];
-  for (int s = 1; s < S; ++s) v = add4(v, r4[(size_t)s * per_net4]);
   const float4 yv = reinterpret_cast<const float4*>(y)[(size_t)net * per_net4 + idx];
+  float4 t[8];   // (up to eight slabs requested together; added in slab order)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) t[s] = s < S ? r4[(size_t)s * per_net4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v = t[0];
+#pragma unroll
+  for (int s = 1; s < 8; ++s)
+    if (s < S) v = add4(v, t[s]);
+  for (int s = 8; s < S; ++s) v = add4(v, r4[(size_t)s * per_net4]);
   v.x *= yv.x > 0.f ? 1.f : slope;
   v.y *= yv.y > 0.f ? 1.f : slope;
   v.z *= yv.z > 0.f ? 1.f : slope;
