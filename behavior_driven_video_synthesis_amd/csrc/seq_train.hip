@@ -236,11 +236,27 @@ struct SeqCouplingBwdArgs {
   int B, Bp, C, c1, ld_g, ld_in, ld_out, ld_full, Mp, S, n_sl, ld_sl, c1s;
 };
 
-// grid (B, ceil(C / 256)), 256 threads: batch row b, coupling index j
+// grid (B, ceil(C / 256)), 256 threads: batch row b, coupling index j.  What depends on j alone (the head's slabs, its bias, the
+// step's input, d loss / d logdet) is requested first, beside the un-shuffle index; the gradient's slabs follow the index.
 __global__ __launch_bounds__(256) void seq_coupling_bwd_kernel(SeqCouplingBwdArgs a) {
   const int b = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
   if (j >= a.C) return;
+  const bool cpl = a.st && j >= a.c1;
+  const int q = cpl ? j - a.c1 : 0;
+  float sv[8], bs = 0.f, xk = 0.f, dld = 0.f;
+  {
+    const size_t slab = (size_t)a.Bp * a.Mp;
+    const float* ps = a.st + (size_t)b * a.Mp + q;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) sv[p] = (cpl && p < a.S) ? ps[p * slab] : 0.f;
+    if (cpl) {
+      if (a.S > 1) bs = a.bias_s[q];
+      xk = a.in[(size_t)b * a.ld_in + j];
+      dld = a.dld[b];
+    }
+  }
   const int c = a.inv_map ? a.inv_map[j] : j;
+  const float sc = a.scale ? a.scale[c] : 1.f;
   float g = a.gbase[(size_t)b * a.ld_g + c];
   if (a.gslabs && c < a.c1s) {   // all loads of a group of eight in flight, added in slab order
     const float* ps = a.gslabs + (size_t)b * a.ld_sl + c;
@@ -256,25 +272,21 @@ __global__ __launch_bounds__(256) void seq_coupling_bwd_kernel(SeqCouplingBwdArg
     for (; n < a.n_sl; ++n) g += ps[(size_t)n * slab];
   }
   if (a.gfull) a.gfull[(size_t)b * a.ld_full + c] = g;
-  if (a.scale) g *= a.scale[c];                       // out = scale (u + loc)   (lib/modules.py:307)
-  if (!a.st || j < a.c1) {
+  if (a.scale) g *= sc;                               // out = scale (u + loc)   (lib/modules.py:307)
+  if (!cpl) {
     a.gout[(size_t)b * a.ld_out + j] = g;
     return;
   }
-  const int q = j - a.c1;
-  float s;
-  if (a.S == 1) s = a.st[(size_t)b * a.Mp + q];
-  else {   // the forward pass left raw slabs: the same sum in the same order (csrc/seq.hip, seq_coupling_kernel)
-    const size_t slab = (size_t)a.Bp * a.Mp;
-    const float* ps = a.st + (size_t)b * a.Mp + q;
-    s = ps[0];
-    for (int p = 1; p < a.S; ++p) s += ps[p * slab];
-    s = tanhf(s + a.bias_s[q]);
+  float s = sv[0];
+  if (a.S > 1) {   // the forward pass left raw slabs: the same sum in the same order (csrc/seq.hip, seq_coupling_kernel)
+#pragma unroll
+    for (int p = 1; p < 8; ++p)
+      if (p < a.S) s += sv[p];
+    s = tanhf(s + bs);
   }
-  const float xk = a.in[(size_t)b * a.ld_in + j];
   const float e = expf(s);
   a.gout[(size_t)b * a.ld_out + j] = g * e;           // x_ = x_k exp(s) + t   (models/flow/blocks.py:304)
-  const float ds = g * xk * e + a.dld[b];             // ... and logdet += sum(s)   (:306)
+  const float ds = g * xk * e + dld;                  // ... and logdet += sum(s)   (:306)
   a.dzh[(size_t)b * a.Mp + q] = ds * (1.f - s * s);   // s = tanh(.)   (lib/modules.py:252-253)
   a.dzh[((size_t)a.Bp + b) * a.Mp + q] = g;
 }
