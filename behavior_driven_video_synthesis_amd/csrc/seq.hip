@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void seq_coupling_kernel(SeqCouplingArgs a) {
       v[u] = in[j[u]];
       const bool cpl = ok[u] && a.st && j[u] >= a.c1;
       const int q = cpl ? j[u] - a.c1 : 0;
-      const float* ps = a.st + (size_t)b * a.Mp + q;
+      const float* ps = cpl ? a.st + (size_t)b * a.Mp + q : in;   // (not read unless cpl)
       const float* pt = ps + (size_t)a.S * slab;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {   // (S <= 8; S = 1: finished values, s already through tanh)

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void seq_coupling_bwd_kernel(SeqCouplingBwdArg
   float sv[8], bs = 0.f, xk = 0.f, dld = 0.f;
   {
     const size_t slab = (size_t)a.Bp * a.Mp;
-    const float* ps = a.st + (size_t)b * a.Mp + q;
+    const float* ps = cpl ? a.st + (size_t)b * a.Mp + q : a.gbase;   // (not read unless cpl)
 #pragma unroll
     for (int p = 0; p < 8; ++p) sv[p] = (cpl && p < a.S) ? ps[p * slab] : 0.f;
     if (cpl) {
