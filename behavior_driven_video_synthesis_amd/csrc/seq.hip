@@ -51,6 +51,8 @@ struct SeqLinearArgs {
   const float* x_next;    // encoder: the next input pose, row b at + b * seq_stride (NULL: the decoder's second launch writes x)
   float* y2;              // tile-major output (LAY & 4) AND this row-major copy [nets][Bp][M] (training keeps both; NULL: none)
   float* gates_out;       // training: [Bp][H][4] = sigmoid(i), sigmoid(f), tanh(g), sigmoid(o) of every unit (NULL: not kept)
+  const float* ht_in;     // LAY & 16: the h part of the operand rows as tiles [Bp / 16][H / 32][2][64][4] (the previous step's ht_out)
+  float* ht_out;          // h ALSO written as the next step's ht_in (NULL: not wanted)
   long long seq_stride;
   int H, hoff, n, B;
 };
@@ -116,6 +118,20 @@ __device__ __forceinline__ void seq_group_load(const SeqLinearArgs& a, const flo
         const float* xp = x + (size_t)nb * 16 * a.K + 512 * (c0 + WAVES * u);
         r.xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
         r.xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 256);
+      } else if constexpr (LAY & 16) {
+        // the LSTM step's operand rows [x | 0 | h]: the chunks of x (and the padding) from the row-major rows, the chunks of h --
+        // 32 of 34 at the reference size -- from the tile-major copy the previous step's epilogue left (1 KB contiguous per wave
+        // load; the row-major form touches two half-used 128-byte lines per row and chunk)
+        const int c = c0 + WAVES * u, ch0 = a.hoff >> 5;
+        if (c >= ch0) {
+          const float* xp = a.ht_in + ((size_t)(nb * (a.H >> 5) + (c - ch0)) * 2) * 256 + 4 * (threadIdx.x & 63);
+          r.xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
+          r.xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 256);
+        } else {
+          const float* xp = x + (size_t)nb * 16 * a.ldx + 32 * c;
+          r.xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
+          r.xv[nb][u][1] = *reinterpret_cast<const float4*>(xp + 4);
+        }
       } else {
         const float* xp = x + (size_t)nb * 16 * a.ldx + 32 * (c0 + WAVES * u);
         r.xv[nb][u][0] = *reinterpret_cast<const float4*>(xp);
@@ -263,6 +279,8 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
       a.c_out[(size_t)nrow * a.H + j] = c2;
       a.xh_next[(size_t)nrow * a.ldx + a.hoff + j] = h;
       if (a.h_out) a.h_out[(size_t)nrow * a.H + j] = h;
+      if (a.ht_out)   // column j of the h part: chunk j / 32, slot (j % 32) / 8, half (j % 8) / 4 (include/vunet_seq_tiled.h)
+        a.ht_out[((size_t)(nb * (a.H >> 5) + (j >> 5)) * 2 + ((j >> 2) & 1)) * 256 + ((((j >> 3) & 3) * 16 + i) * 4) + (j & 3)] = h;
     }
     // the encoder's next input rows: workgroup g copies rows g, g + gridDim.x, ...
     if (a.x_next && wave == 0)
@@ -720,7 +738,7 @@ extern "C" int vunet_seq_start(const float* x0, int64_t x0_stride, const float* 
 
 static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, const float* xh, const float* bias_perm,
                            const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, float* gates_out,
-                           bool w_tiled, void* stream) {
+                           bool w_tiled, void* stream, const float* ht_in = nullptr, float* ht_out = nullptr) {
   if (!d || !w_perm || !xh || !bias_perm || !c_in || !c_out || c_in == c_out || !xh_next || xh_next == xh) return VUNET_ERR_ARG;
   if (d->B < 1 || d->B > 16 * SEQ_MAX_NB || d->H < 4 || d->H % 4 || d->n < 1 || d->hoff < d->n || d->ldx < d->hoff + d->H) return VUNET_ERR_ARG;
   if (d->ldx % 32) return VUNET_ERR_ARG;
@@ -745,14 +763,22 @@ static int seq_lstm_launch(const vunet_seq_lstm_desc* d, const float* w_perm, co
   a.x_next = x_next;
   a.y2 = nullptr;
   a.gates_out = gates_out;
+  a.ht_in = ht_in;
+  a.ht_out = ht_out;
   a.seq_stride = d->seq_stride;
   a.H = d->H;
   a.hoff = d->hoff;
   a.n = d->n;
   a.B = d->B;
+  if ((ht_in || ht_out) && (!w_tiled || d->H % 32 || d->hoff % 32 || d->ldx != d->hoff + d->H || ht_in == ht_out)) return VUNET_ERR_ARG;
   const dim3 grid(a.M / 16, 1, 1);
   hipStream_t st = (hipStream_t)stream;
   const bool wide = a.K >= 16 * 32 && d->B <= 32;   // (3 - 4 batch tiles: four waves, as vunet_seq_linear; 50-step roll-out at 64 rows 1.03 -> 0.93 ms)
+  if (ht_in && !wide && a.Bp >= 48) {   // the h part of the operand from tiles: the four-wave form at 3 - 4 batch tiles
+    if (a.Bp == 48) VUNET_LAUNCH((seq_linear_kernel<3, 1, 4, true, 25>), grid, dim3(256), 0, st, a);
+    else VUNET_LAUNCH((seq_linear_kernel<4, 1, 4, true, 25>), grid, dim3(256), 0, st, a);
+    return vunet_check_launch();
+  }
 #define SEQ_LSTM_CASE(NB)                                                                                   \
   case NB:                                                                                                  \
     if (w_tiled) {                                                                                          \
@@ -783,6 +809,15 @@ extern "C" int vunet_seq_lstm_gates_tiled(const vunet_seq_lstm_desc* d, const fl
                                           const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next,
                                           float* gates_out, void* stream) {
   return seq_lstm_launch(d, w_tiles, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, gates_out, true, stream);
+}
+
+// ... with the h part of the operand rows read from / written as tiles as well (either may be NULL: the first step of a
+// sequence reads the rows vunet_seq_start wrote; batches of <= 32 rows read the rows anyway)
+extern "C" int vunet_seq_lstm_gates_tiled_h(const vunet_seq_lstm_desc* d, const float* w_tiles, const float* xh, const float* h_tiles_in,
+                                            const float* bias_perm, const float* c_in, float* c_out, float* xh_next,
+                                            float* h_tiles_out, float* h_out, const float* x_next, float* gates_out, void* stream) {
+  return seq_lstm_launch(d, w_tiles, xh, bias_perm, c_in, c_out, xh_next, h_out, x_next, gates_out, true, stream, h_tiles_in,
+                         h_tiles_out);
 }
 
 // the same step with the gate activations kept for the backward pass (include/vunet_seq_train.h)

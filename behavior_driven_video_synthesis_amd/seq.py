@@ -638,8 +638,23 @@ class BehaviorEngine:
                      xraw=torch.zeros(b_pad, self.ldraw, device=dev),
                      pre=torch.zeros(b_pad, self.H, device=dev), b_in=torch.zeros(rows, self.H, device=dev),
                      heads=torch.zeros(2 * b_pad * self.H, device=dev), io={})
+            # more than 32 rows: h also goes from step to step as tiles (include/vunet_seq_tiled.h: vunet_seq_lstm_gates_tiled_h)
+            tile_h = (os.environ.get("VUNET_SEQ_LSTM_TILED_H", "1") != "0" and b_pad >= 48 and self.H % 32 == 0
+                      and self.hoff % 32 == 0 and self.ldx == self.hoff + self.H)
+            p["ht"] = [torch.zeros(b_pad * self.H, device=dev) for _ in range(2)] if tile_h else None
             self._plans[rows] = p
         return p
+
+    def _lstm_step(self, d, wt, bias, p, t, h_out, x_next):
+        """Step t of a roll-out on the plan's ping-pong buffers (t even: 0 -> 1)."""
+        cur, nxt = t % 2, 1 - t % 2
+        ht = p["ht"]
+        if ht is not None:
+            _call("vunet_seq_lstm_gates_tiled_h", ctypes.byref(d), _p(wt), _p(p["xh"][cur]), _p(ht[cur]) if t else None, _p(bias),
+                  _p(p["c"][cur]), _p(p["c"][nxt]), _p(p["xh"][nxt]), _p(ht[nxt]), h_out, x_next, None, _stream())
+        else:
+            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(wt), _p(p["xh"][cur]), _p(bias), _p(p["c"][cur]), _p(p["c"][nxt]),
+                  _p(p["xh"][nxt]), h_out, x_next, None, _stream())
 
     def _issue_decode(self, rows, p, x_pose, t_in, start_frame, length, xs, cs):
         dec = self.net.decoder
@@ -649,9 +664,8 @@ class BehaviorEngine:
               self.hoff, _p(p["c"][0]), rows, n, self.H, _stream())
         d = SeqLstmDesc(rows, self.H, self.ldx, self.hoff, n, self.ldraw, length * n)
         for t in range(length):
-            cur, nxt = t % 2, 1 - t % 2
-            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.dec_wt), _p(p["xh"][cur]), _p(self.dec_b), _p(p["c"][cur]),
-                  _p(p["c"][nxt]), _p(p["xh"][nxt]), None, None, None, _stream())
+            nxt = 1 - t % 2
+            self._lstm_step(d, self.dec_wt, self.dec_b, p, t, None, None)
             _call("vunet_seq_decoder_out", ctypes.byref(d), _p(p["xh"][nxt]), _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()),
                   _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), _stream())
 
@@ -689,10 +703,8 @@ class BehaviorEngine:
               self.H, _stream())
         d = SeqLstmDesc(rows, self.H, self.ldx, self.hoff, n, self.ldraw, t_in * n)
         for t in range(t_in):   # one launch per time step: gate product, cell update and the next input row
-            cur, nxt = t % 2, 1 - t % 2
             x_next = ctypes.c_void_p(seq.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
-            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.enc_wt), _p(p["xh"][cur]), _p(self.enc_b), _p(p["c"][cur]),
-                  _p(p["c"][nxt]), _p(p["xh"][nxt]), _p(p["pre"]) if t == t_in - 1 else None, x_next, None, _stream())
+            self._lstm_step(d, self.enc_wt, self.enc_b, p, t, _p(p["pre"]) if t == t_in - 1 else None, x_next)
         if self.heads is not None:
             w, bias = self.heads
             dl = SeqLinearDesc(rows, self.H, self.H, self.H, ACT_NONE, ACT_NONE, 2, 1, 1)

@@ -629,6 +629,9 @@ class BehaviorTrainEngine(BehaviorEngine):
     def __init__(self, net):
         super().__init__(net)
         self._generation = 0
+        # h handed from LSTM step to LSTM step as tiles too (vunet_seq_lstm_gates_tiled_h; batches of more than 32 rows);
+        # "0": the step reads its whole operand from the row-major rows (bit-identical)
+        self.tile_h = os.environ.get("VUNET_SEQ_LSTM_TILED_H", "1") != "0"
 
     def _check(self, dev=None):
         net = self.net
@@ -661,6 +664,8 @@ class BehaviorTrainEngine(BehaviorEngine):
                  dgates_d=z(length, bp, 4 * H), dgates_e=z(t_in, bp, 4 * H), gx=z(length + 1, bp, 64), gc=z(bp, H), dy=z(2, bp, H),
                  S=(s_d, s_e, s_h), raw_d=z(s_d * bp * ldx), raw_e=z(s_e * bp * H), raw_h=z(2 * s_h * bp * H),
                  gxs=z(rows, length, n), gmu=z(rows, H), glogstd=z(rows, H),
+                 # h handed from step to step as tiles as well (include/vunet_seq_tiled.h: vunet_seq_lstm_gates_tiled_h), > 32 rows
+                 ht=[z(bp * H) for _ in range(2)] if (self.tile_h and bp >= 48 and H % 32 == 0 and self.hoff % 32 == 0) else None,
                  g_dec=z(4 * H, ldx), gb_dec=z(4 * H), g_enc=z(4 * H, ldx), gb_enc=z(4 * H), g_out=z(64, H), gb_out=z(64),
                  g_mu=z(H, H), gb_mu=z(H), g_std=z(H, H), gb_std=z(H), zero_bias=z(4 * H),
                  part=z(length + 3 * rows), scalars=z(6), per_seq=z(length))
@@ -689,8 +694,14 @@ class BehaviorTrainEngine(BehaviorEngine):
         _call("vunet_seq_start", _p(x1), t_in * n, None, None, None, 0, _p(p["xh_e"][0]), self.ldx, self.hoff, _p(p["c_e"][0]), rows, n, H,
               _stream())
         d = SeqLstmDesc(rows, H, self.ldx, self.hoff, n, self.ldraw, t_in * n)
+        ht = p["ht"]
         for t in range(t_in):
             x_next = ctypes.c_void_p(x1.data_ptr() + (t + 1) * n * esz) if t + 1 < t_in else None
+            if ht is not None:
+                _call("vunet_seq_lstm_gates_tiled_h", ctypes.byref(d), _p(self.enc_wt), _p(p["xh_e"][t]), _p(ht[t & 1]) if t else None,
+                      _p(self.enc_b), _p(p["c_e"][t]), _p(p["c_e"][t + 1]), _p(p["xh_e"][t + 1]), _p(ht[(t + 1) & 1]),
+                      _p(p["pre"]) if t == t_in - 1 else None, x_next, _p(p["gates_e"][t]), _stream())
+                continue
             _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.enc_wt), _p(p["xh_e"][t]), _p(self.enc_b), _p(p["c_e"][t]),
                   _p(p["c_e"][t + 1]), _p(p["xh_e"][t + 1]), _p(p["pre"]) if t == t_in - 1 else None, x_next, _p(p["gates_e"][t]), _stream())
         w, bias = self.heads
@@ -704,8 +715,13 @@ class BehaviorTrainEngine(BehaviorEngine):
         d = SeqLstmDesc(rows, H, self.ldx, self.hoff, n, self.ldraw, length * n)
         xs, cs = p["xs"], p["cs"]
         for t in range(length):
-            _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.dec_wt), _p(p["xh_d"][t]), _p(self.dec_b), _p(p["c_d"][t]),
-                  _p(p["c_d"][t + 1]), _p(p["xh_d"][t + 1]), None, None, _p(p["gates_d"][t]), _stream())
+            if ht is not None:
+                _call("vunet_seq_lstm_gates_tiled_h", ctypes.byref(d), _p(self.dec_wt), _p(p["xh_d"][t]), _p(ht[t & 1]) if t else None,
+                      _p(self.dec_b), _p(p["c_d"][t]), _p(p["c_d"][t + 1]), _p(p["xh_d"][t + 1]), _p(ht[(t + 1) & 1]), None, None,
+                      _p(p["gates_d"][t]), _stream())
+            else:
+                _call("vunet_seq_lstm_gates_tiled", ctypes.byref(d), _p(self.dec_wt), _p(p["xh_d"][t]), _p(self.dec_b), _p(p["c_d"][t]),
+                      _p(p["c_d"][t + 1]), _p(p["xh_d"][t + 1]), None, None, _p(p["gates_d"][t]), _stream())
             _call("vunet_seq_decoder_out", ctypes.byref(d), _p(p["xh_d"][t + 1]), _p(dec.n_out.weight.detach()), _p(dec.n_out.bias.detach()),
                   _p(p["xraw"]), ctypes.c_void_p(xs.data_ptr() + t * n * esz), ctypes.c_void_p(cs.data_ptr() + t * n * esz), _stream())
 

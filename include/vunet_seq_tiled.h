@@ -42,6 +42,15 @@ int vunet_seq_pack_tiles(const float* w, int32_t ld, int32_t M, int32_t K, float
 int vunet_seq_lstm_gates_tiled(const vunet_seq_lstm_desc* d, const float* w_tiles, const float* xh, const float* bias_perm,
                                const float* c_in, float* c_out, float* xh_next, float* h_out, const float* x_next, float* gates_out,
                                void* stream);
+/* The same step with the h part of the operand rows ALSO handed from step to step as tiles, ht[Bp / 16][H / 32][2][64][4] (the
+ * layout of xt above over the H columns of h; H % 32 == 0, hoff % 32 == 0, ldx == hoff + H): the step reads x (and the padding)
+ * from the rows `xh` and h from `h_tiles_in` (NULL: from the rows as well -- the first step of a sequence, whose rows
+ * vunet_seq_start wrote; batches of <= 32 rows always read the rows), and writes its h to `xh_next` AND to `h_tiles_out` (NULL: not
+ * wanted).  At 64 rows the operand is four times the gate image's bytes per workgroup, and a row-major chunk is two half-used
+ * 128-byte lines per row.  Bit-identical values. */
+int vunet_seq_lstm_gates_tiled_h(const vunet_seq_lstm_desc* d, const float* w_tiles, const float* xh, const float* h_tiles_in,
+                                 const float* bias_perm, const float* c_in, float* c_out, float* xh_next, float* h_tiles_out,
+                                 float* h_out, const float* x_next, float* gates_out, void* stream);
 int vunet_seq_linear_tiled(const vunet_seq_linear_desc* d, int32_t layout, const float* w0, const float* w1, const float* x,
                            const float* bias0, const float* bias1, float* y, float* y_rowmajor, void* stream);
 

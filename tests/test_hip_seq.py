@@ -470,6 +470,37 @@ def test_a_recorded_call_trains_or_is_refused():
         assert flow.reverse(z).shape == (2, 32, 1, 1)     # frozen parameters: nothing to record
 
 
+@pytest.mark.parametrize("bsz,hid,nin", [(64, 128, False), (40, 64, True), (33, 1024, False)])
+def test_roll_outs_with_h_handed_on_as_tiles_vs_the_rows_and_the_oracle(bsz, hid, nin, monkeypatch):
+    """More than 32 rows: the LSTM steps of the decoder roll-out and of the encoder read h from the tile-major copy the step
+    before left (``vunet_seq_lstm_gates_tiled_h``) -- bit-identical with ``VUNET_SEQ_LSTM_TILED_H=0`` (everything from the rows),
+    and both close to the oracle."""
+    from oracle import behavior_oracle as B
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    outs = {}
+    for tiled in ("1", "0"):
+        monkeypatch.setenv("VUNET_SEQ_LSTM_TILED_H", tiled)
+        net = ResidualBehaviorNet(51, information_bottleneck=True, decoder_arch="lstm", linear_in_decoder=nin, dim_hidden_b=hid)
+        sd = synth_behavior_state({k: list(v.shape) for k, v in net.state_dict().items()}, 19, {})
+        net.load_state_dict(sd)
+        net = net.cuda()
+        b = seeded_randn("th.b", (bsz, hid), 19)
+        x = 0.5 * seeded_randn("th.x", (bsz, 6, 51), 19)
+        eps = seeded_randn("th.eps", (bsz, hid), 19)
+        xs, cs, _, _ = net.generate_seq(b.cuda(), x.cuda(), len=7, start_frame=2)
+        enc = net.infer_b(x.cuda(), False, eps=eps.cuda())
+        plan = net.engine()._plans[bsz]
+        assert (plan["ht"] is not None) == (tiled == "1" and hid % 32 == 0 and net.engine().hoff % 32 == 0)
+        outs[tiled] = (xs, cs) + tuple(enc)
+    for a, b_ in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b_)
+    xs_ref, cs_ref = B.generate_seq(sd, b, x, 7, 2)
+    close(outs["1"][0], xs_ref, rtol=1e-3, atol=5e-4)
+    close(outs["1"][1], cs_ref, rtol=1e-3, atol=5e-4)
+    for g, r in zip(outs["1"][2:], B.infer_b(sd, x, eps)):
+        close(g, r, rtol=1e-3, atol=1e-4)
+
+
 @pytest.mark.parametrize("bsz,t_in,length,start", [(1, 1, 1, 0), (65, 3, 4, -1), (16, 2, 9, 1)])
 def test_decoder_and_encoder_edge_shapes_vs_oracle(bsz, t_in, length, start):
     """One row / one frame / one step; more than 64 rows (two chunks); a negative start frame as the reference indexes it."""

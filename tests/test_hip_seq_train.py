@@ -489,6 +489,34 @@ def test_cvae_gradients_vs_oracle(bsz, hid, t_in, length, start):
     assert worst <= 5e-5, f"{worst:.2e}"
 
 
+@pytest.mark.parametrize("bsz,hid,t_in,length", [(48, 64, 5, 7), (64, 128, 6, 6), (33, 128, 4, 5), (16, 64, 4, 4)])
+def test_h_handed_on_as_tiles_changes_nothing(bsz, hid, t_in, length):
+    """``vunet_seq_lstm_gates_tiled_h``: batches of more than 32 rows read the h part of an LSTM step's operand from the tile-major
+    copy the previous step left (the x part and the first step's h from the rows).  Outputs and every parameter's gradient are
+    bit-identical with the path that reads the rows (33 rows -> 48 padded: tiles; 16 rows: the rows either way)."""
+    from behavior_driven_video_synthesis_amd.models.pose_behavior_rnn import ResidualBehaviorNet
+    n_kps = 51
+    res = {}
+    for tiled in (True, False):
+        net = ResidualBehaviorNet(n_kps, information_bottleneck=True, decoder_arch="lstm", dim_hidden_b=hid)
+        net.load_state_dict(synth_behavior_state({k: list(v.shape) for k, v in net.state_dict().items()}, 17, {}))
+        net = net.cuda().train()
+        eng = net.train_engine()
+        eng.tile_h = tiled
+        x1 = (0.5 * seeded_randn("th.x1", (bsz, t_in, n_kps), 17)).cuda()
+        x2 = (0.5 * seeded_randn("th.x2", (bsz, t_in + 1, n_kps), 17)).cuda()
+        eps = seeded_randn("th.eps", (bsz, hid), 17).cuda()
+        xs, cs, _, b, mu, logstd, pre = net(x1, x2, length, start_frame=1, eps=eps)
+        ((xs * xs).sum() + (cs * 0.3).sum() + (mu * logstd).sum() + pre.sum()).backward()
+        plan = next(v for k, v in eng._plans.items() if k and k[0] == "train")
+        assert (plan["ht"] is not None) == (tiled and bsz > 32 and hid % 32 == 0)
+        res[tiled] = ([t.detach().clone() for t in (xs, cs, b, mu, logstd, pre)], {n: q.grad.clone() for n, q in net.named_parameters()})
+    for a, b_ in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b_)
+    for n, g in res[True][1].items():
+        assert torch.equal(g, res[False][1][n]), n
+
+
 def test_cvae_step_at_the_reference_size_vs_oracle():
     """config/behavior_net.yaml: dim_hidden_b 1024, 51 pose dimensions, batch 64, 50 frames: one fused step (graph replay equals
     eager issue bit for bit) vs the oracle's step: the step's log, every parameter's first moment (= 0.1 x its gradient)."""
