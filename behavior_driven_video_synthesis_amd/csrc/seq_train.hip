@@ -71,9 +71,11 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int k0 = blockIdx.x * 64, s = blockIdx.y, net = blockIdx.z;
-  const int rows = a.M / a.S, ngrp = rows >> 4;
-  const float* __restrict__ w = a.w[net] + (size_t)(s * rows + 4 * q) * a.ldw + k0 + 4 * i;
-  const float* __restrict__ dz = a.dz + ((size_t)net * a.Bp + i) * a.M + s * rows + 4 * q;
+  // slab s takes the 16-row groups [s G / S, (s + 1) G / S) of W's G = M / 16: equal ranges where S divides G, else ranges that
+  // differ by one group (17 column stripes x 15 slabs = 255 workgroups for the LSTM's gate matrix: one round on 256 CUs)
+  const int G = a.M >> 4, g_lo = (int)(((long)s * G) / a.S), ngrp = (int)(((long)(s + 1) * G) / a.S) - g_lo, row0 = 16 * g_lo;
+  const float* __restrict__ w = a.w[net] + (size_t)(row0 + 4 * q) * a.ldw + k0 + 4 * i;
+  const float* __restrict__ dz = a.dz + ((size_t)net * a.Bp + i) * a.M + row0 + 4 * q;
   f32x4 acc[4][NB];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -719,7 +721,7 @@ static int seq_dx_launch(const vunet_seq_dx_desc* d, const float* w0, const floa
                          float* dz_prev, int32_t* counters, float slope, bool fin, void* stream) {
   if (!d || !w0 || !dz || !raw) return VUNET_ERR_ARG;
   if (d->nets < 1 || d->nets > 2 || (d->nets == 2 && !w1)) return VUNET_ERR_ARG;
-  if (d->B < 1 || d->B > 64 || d->K < 64 || d->K % 64 || d->S < 1 || d->M < 16 * d->S || d->M % (16 * d->S)) return VUNET_ERR_ARG;
+  if (d->B < 1 || d->B > 64 || d->K < 64 || d->K % 64 || d->S < 1 || d->M < 16 * d->S || d->M % 16) return VUNET_ERR_ARG;
   if (d->ldw && (d->ldw < d->K || d->ldw % 4)) return VUNET_ERR_ARG;
   if (fin && (!y || !dz_prev || !counters)) return VUNET_ERR_ARG;
   SeqDxArgs a;
@@ -739,8 +741,7 @@ static int seq_dx_launch(const vunet_seq_dx_desc* d, const float* w0, const floa
   const dim3 grid(d->K / 64, d->S, d->nets);
   hipStream_t st = (hipStream_t)stream;
   const bool wide = d->M / d->S >= 16 * 16 && d->B <= 32;   // 16 waves: at least one 16-row group each (64 rows: see vunet_seq_linear)
-  // a launch that cannot give every CU a workgroup (17 column stripes: the LSTM's gate matrix over [x | h]) runs eight waves per
-  // workgroup on its S / 2 slabs instead of four on S with a second, nearly empty round of workgroups
+  // a launch that cannot give every CU a workgroup (<= 160 of them, deep slabs) runs eight waves per workgroup
   const bool eight = !wide && (long)grid.x * grid.y * grid.z <= 160 && d->M / d->S >= 16 * 16;
 #define SEQ_DX_LAUNCH(NB, FIN)                                                            \
   if (wide) VUNET_LAUNCH((seq_dx_kernel<NB, 16, FIN>), grid, dim3(1024), 0, st, a);       \

@@ -228,13 +228,16 @@ class FlowTrainEngine(FlowEngine):
 
     @staticmethod
     def _dx_split(m: int, k: int, nets: int) -> int:
-        """Row ranges of W per input-gradient launch: doubled while the launch still fits one round of workgroups on the
-        chip's 256 CUs (17 column stripes: 8 slabs = 136 eight-wave workgroups, not 16 = 272 with a nearly empty second round)."""
-        s, wgs = 1, (k // 64) * nets
-        legacy = os.environ.get("VUNET_SEQ_DX_TAIL", "0") == "1"    # ("1": the rule before -- doubled until >= 256 workgroups)
-        while (wgs * s < 256 if legacy else wgs * s * 2 <= 256) and m % (32 * s) == 0 and m // (2 * s) >= 64 and s < 16:
-            s *= 2
-        return s
+        """Row ranges (slabs) of W per input-gradient launch: as many as keep the launch within ONE round of workgroups on the
+        chip's 256 CUs and a slab at >= 64 rows, at most 16 -- 4 for the flow's 2048 x 2048 layers (64 stripes), 16 for its first
+        layers, 15 for the LSTM's gate matrix over [x | h] (17 stripes: 255 workgroups; slabs of 17 or 18 row groups)."""
+        wgs = (k // 64) * nets
+        if os.environ.get("VUNET_SEQ_DX_TAIL", "0") == "1":    # the rule before: doubled until >= 256 workgroups (17 stripes: 272)
+            s = 1
+            while wgs * s < 256 and m % (32 * s) == 0 and m // (2 * s) >= 64 and s < 16:
+                s *= 2
+            return s
+        return max(1, min(16, 256 // wgs, m // 64))
 
     # ---- forward, everything kept
     def _issue_train_forward(self, rows: int, p: dict):

@@ -51,7 +51,8 @@ typedef struct vunet_seq_adam_hp {
 } vunet_seq_adam_hp;
 
 /* dX = dZ . W: w_n [M][ldw] (nets <= 2; columns 0 .. K of each row are used: ldw = 0 means K), dz [nets][Bp][M],
- * raw [nets][S][Bp][K].  K % 64 == 0, M % (16 S) == 0, ldw % 4 == 0, B <= 64. */
+ * raw [nets][S][Bp][K]: slab s is the share of W's 16-row groups [s G / S, (s + 1) G / S), G = M / 16 (equal ranges where S
+ * divides G).  K % 64 == 0, M % 16 == 0, S <= M / 16, ldw % 4 == 0, B <= 64. */
 typedef struct vunet_seq_dx_desc {
   int32_t B, M, K, nets, S, ldw;
 } vunet_seq_dx_desc;
