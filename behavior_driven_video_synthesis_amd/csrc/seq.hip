@@ -210,7 +210,35 @@ __global__ __launch_bounds__(64 * WAVES) void seq_linear_kernel(SeqLinearArgs a)
 #ifndef SEQ_RING_U
 #define SEQ_RING_U 1
 #endif
-  if constexpr (WAVES == 4 && NB >= 3 && SEQ_RING > 1) {
+  if constexpr (WAVES == 4 && NB >= 3 && SEQ_RING == 2 && SEQ_RING_U == 1) {
+    // depth 2, any number of chunks (an odd count -- 34 chunks over four waves: 9, 9, 8, 8 -- keeps its last chunk in the ring)
+    const int nw = c < nchunk ? (nchunk - c + WAVES - 1) / WAVES : 0;   // this wave's chunks
+    if (nw > 0) {
+      SeqGroupRegs<NB, RT, 1> ra, rb;
+      seq_group_load<NB, RT, 1, WAVES, LAY>(a, w, x, c, ra);
+      int k = 0;
+      for (; k + 2 < nw; k += 2) {   // ra holds chunk k
+        seq_group_load<NB, RT, 1, WAVES, LAY>(a, w, x, c + WAVES * (k + 1), rb);
+        __builtin_amdgcn_sched_barrier(0);
+        seq_group_mfma<NB, RT, 1>(ra, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        seq_group_load<NB, RT, 1, WAVES, LAY>(a, w, x, c + WAVES * (k + 2), ra);
+        __builtin_amdgcn_sched_barrier(0);
+        seq_group_mfma<NB, RT, 1>(rb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nw - k == 2) {
+        seq_group_load<NB, RT, 1, WAVES, LAY>(a, w, x, c + WAVES * (k + 1), rb);
+        __builtin_amdgcn_sched_barrier(0);
+        seq_group_mfma<NB, RT, 1>(ra, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        seq_group_mfma<NB, RT, 1>(rb, acc);
+      } else {
+        seq_group_mfma<NB, RT, 1>(ra, acc);
+      }
+      c += WAVES * nw;
+    }
+  } else if constexpr (WAVES == 4 && NB >= 3 && SEQ_RING > 1) {
     constexpr int D = SEQ_RING, SU = SEQ_RING_U;   // D stages of SU chunks each
     const int nw = c < nchunk ? (nchunk - c + WAVES - 1) / WAVES : 0;   // this wave's chunks
     const int ns = nw / SU, n_main = ns - ns % D;                        // ... stages, and those the ring takes

@@ -120,7 +120,35 @@ __global__ __launch_bounds__(64 * WAVES) void seq_dx_kernel(SeqDxArgs a) {
   // Four- / eight-wave workgroups (48 - 64 batch rows) are one or two waves per SIMD: the wave keeps a ring of SEQ_DX_RING stages (of SEQ_DX_RING_U
   // row groups) in flight, the loads of stage i + SEQ_DX_RING - 1 issued before the matrix steps of stage i (csrc/seq.hip:
   // seq_linear_kernel's ring).  Same groups, same order, same sums as the plain loop below.
-  if constexpr (WAVES <= 8 && SEQ_DX_RING > 1) {
+  if constexpr (WAVES <= 8 && SEQ_DX_RING == 2 && SEQ_DX_RING_U == 1) {
+    // depth 2, any number of row groups (uneven slabs leave a wave 4 or 5 of them: the last one stays in the ring)
+    const int nw = g < ngrp ? (ngrp - g + WAVES - 1) / WAVES : 0;
+    if (nw > 0) {
+      Stage ra, rb;
+      load(g, su_c, ra);
+      int k = 0;
+      for (; k + 2 < nw; k += 2) {   // ra holds group k
+        load(g + WAVES * (k + 1), su_c, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(su_c, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        load(g + WAVES * (k + 2), su_c, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(su_c, rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nw - k == 2) {
+        load(g + WAVES * (k + 1), su_c, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(su_c, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(su_c, rb);
+      } else {
+        mfma(su_c, ra);
+      }
+      g += WAVES * nw;
+    }
+  } else if constexpr (WAVES <= 8 && SEQ_DX_RING > 1) {
     constexpr int D = SEQ_DX_RING;
     const int nw = g < ngrp ? (ngrp - g + WAVES - 1) / WAVES : 0;
     const int ns = nw / SU, n_main = ns - ns % D;
