@@ -530,3 +530,22 @@ def test_ctypes_descriptors_match_the_c_structs(tmp_path):
         cls = pairs[cname]
         assert ctypes.sizeof(cls) == int(size), (cname, ctypes.sizeof(cls), size)
         assert [getattr(cls, f).offset for f, _ in cls._fields_] == [int(o) for o in offs], cname
+
+
+def test_input_gradient_slab_rule(monkeypatch):
+    """``FlowTrainEngine._dx_split``: as many row ranges of W as keep a ``vunet_seq_dx`` launch within ONE round of workgroups on
+    256 CUs, a slab at >= 64 rows, at most 16 -- and the LSTM's 17 column stripes on 15 slabs (255 workgroups), not 16 (272)."""
+    from behavior_driven_video_synthesis_amd.seq_train import FlowTrainEngine as F
+    monkeypatch.delenv("VUNET_SEQ_DX_TAIL", raising=False)
+    want = {(2048, 2048, 2): 4, (2048, 512, 2): 16, (512, 2048, 2): 4, (4096, 1088, 1): 15, (4096, 1024, 1): 16, (1024, 1024, 2): 8,
+            (64, 64, 2): 1, (192, 128, 2): 3}
+    for (m, k, nets), s in want.items():
+        assert F._dx_split(m, k, nets) == s, (m, k, nets)
+    for m in (64, 128, 192, 512, 1024, 2048, 4096):
+        for k in (64, 128, 512, 1088, 2048, 4096):
+            for nets in (1, 2):
+                s = F._dx_split(m, k, nets)
+                wgs = (k // 64) * nets
+                assert 1 <= s <= 16 and s <= m // 16 and (s == 1 or (wgs * s <= 256 and m // s >= 64)), (m, k, nets, s)
+    monkeypatch.setenv("VUNET_SEQ_DX_TAIL", "1")
+    assert F._dx_split(4096, 1088, 1) == 16 and F._dx_split(2048, 2048, 2) == 4
