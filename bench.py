@@ -395,15 +395,19 @@ def behavior_row(vunet, device, size, frames=50, rows=16, iters=10):
     z = torch.randn(rows, 1024, device=device)
     seq = 0.5 * torch.randn(rows, frames, 51, device=device)
 
-    def timed(fn):
+    def timed(fn, batches=5):
+        """Median over ``batches`` batches of ``iters`` calls (one host hiccup inside a 10 ms window otherwise triples a figure)."""
         for _ in range(3):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters
+        means = []
+        for _ in range(batches):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            means.append((time.perf_counter() - t0) / iters)
+        return sorted(means)[len(means) // 2]
     with torch.no_grad():
         t_flow = timed(lambda: flow.reverse(z))
         b = flow.reverse(z).reshape(rows, 1024)
@@ -468,17 +472,21 @@ def behavior_train_row(device, rows=64, frames=50, iters=10):
     tr.net.decoder.n_out.weight.data.mul_(0.05)
     batch = {"keypoints": 0.5 * torch.randn(rows, frames + 1, 51, device=device)}
 
-    def timed(fn):
+    def timed(fn, batches=5):
+        """Median over ``batches`` batches of ``iters`` steps, HIP events around each batch."""
         for _ in range(3):
             fn()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
-        return 1e-3 * a.elapsed_time(b) / iters
+        means = []
+        for _ in range(batches):
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            means.append(1e-3 * a.elapsed_time(b) / iters)
+        return sorted(means)[len(means) // 2]
     t_vae = timed(lambda: tr.train_fn(batch, sync=False))
     out_vae = tr.train_fn(batch)
     bs = torch.randn(rows, 1024, device=device)
